@@ -1,0 +1,128 @@
+/*
+ * lshrs_hip.h — C ABI of liblshrs_hip.so, the MI355X (gfx950) implementation of the
+ * lshrs compute hot path: the LSHHasher signature pass and the top_k_cosine rerank.
+ *
+ * The reference (mxngjxa/lshrs) is pure Python and has no FFI; the seam this library
+ * sits behind is the pair of Python names `LSHRS._hasher` (lshrs/core/main.py:224) and
+ * `top_k_cosine` (lshrs/core/main.py:43, used at :646).  Each entry point below cites the
+ * reference code whose arithmetic it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr());
+ *     the library allocates nothing and frees nothing, and keeps no global mutable state;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and returns immediately: 0 = OK, <0 = -(hipError_t), or one of the
+ *     LSHRS_E_* argument errors.  Nothing is thrown across the ABI;
+ *   - matrices are row-major, float32, inner dimension contiguous.
+ */
+#ifndef LSHRS_HIP_H
+#define LSHRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSHRS_ABI_VERSION 1
+
+#define LSHRS_E_BADARG   (-10001) /* NULL pointer / non-positive size / misaligned workspace */
+#define LSHRS_E_TOOLARGE (-10002) /* shape outside what the kernels support (see each call)  */
+
+/* ABI version of the loaded library (== LSHRS_ABI_VERSION of the header it was built from). */
+int lshrs_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Signature pass — replaces LSHHasher.hash_vector / hash_batch / _project_and_pack
+ * (lshrs/hash/lsh.py:96-211): y = P_band @ v  (:200),  bit = y > 0  (:204),
+ * np.packbits(bitorder="little")  (:208).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Bytes of device workspace that lshrs_sig_pack_projections() fills for a hasher of this
+ * shape (the hyperplanes re-laid-out in MFMA-fragment order + their row norms).
+ * Returns <0 on bad arguments.  Needs 16-byte alignment. */
+int64_t lshrs_sig_workspace_bytes(int32_t num_bands, int32_t rows_per_band, int32_t dim);
+
+/* Build the workspace from the hyperplanes.  P is (num_bands*rows_per_band, dim) f32 row-major:
+ * the reference's `projections` list (lshrs/hash/lsh.py:94) stacked in band order.  Call again
+ * whenever the hyperplanes change (LSHRS.load_from_disk / __setstate__ re-assign them,
+ * lshrs/core/main.py:981,1044). */
+int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                               void* workspace, void* stream);
+
+/* Hash n vectors.
+ *   X          (n, dim) f32, row stride ldx elements (ldx >= dim)
+ *   keys       (n, num_bands, ceil(rows_per_band/8)) u8 — bit i of band b is
+ *              (dot(P[b*rows+i], X[row]) > 0), LSB-first, tail bits 0: byte-for-byte the
+ *              reference's `bytes` keys laid side by side.
+ *   The dot product is evaluated on v_mfma_f32_32x32x2_f32 as a single-rounded fmaf chain
+ *   in the k-order documented in DESIGN.md; it can differ from the host BLAS's sgemv only
+ *   where |y| is within rounding noise of 0.  Those places are reported, not hidden:
+ *   tie_list   optional (may be NULL): int64[tie_cap]; entry = row*65536 + w means that some
+ *              projection of `row` among padded columns [32w, 32w+32) has
+ *              |y| <= tau * ||x_row|| * ||p_j||.   Order of entries is unspecified.
+ *   tie_count  int32[1] (required iff tie_list != NULL); must be zeroed by the caller before
+ *              the call; receives the number of entries the kernel WANTED to write — if it
+ *              exceeds tie_cap the list is truncated and the caller must retry with room.
+ *   row_flags  optional (may be NULL): u8[n]; bit0 = every |x| <= 1e-8f — the "zero vector"
+ *              test of LSHRS._prepare_vector (lshrs/core/main.py:1083);
+ *              bit1 = row contains a NaN.
+ *   tau        relative tie threshold (e.g. 32 * 2^-24); ignored when tie_list == NULL.
+ * Padded columns: band b occupies columns [b*8*B, b*8*B + rows_per_band), B = ceil(rows/8).
+ * Limits: num_bands*B*8 <= 2^21 padded columns; n < 2^47. */
+int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
+                             const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                             uint8_t* keys,
+                             int64_t* tie_list, int32_t tie_cap, int32_t* tie_count, float tau,
+                             uint8_t* row_flags, void* stream);
+
+/* Diagnostic twin of the above: writes the raw projections instead of their sign bits.
+ *   Y (n, ldy) f32 with ldy >= padded columns rounded up to the kernel's column tile
+ *   (lshrs_sig_padded_columns()); column b*8*B + i holds dot(P[b*rows+i], X[row]).
+ * Used by the parity tests to compare the MFMA chain with the CPU chain model bit for bit. */
+int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx,
+                          const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                          float* Y, int64_t ldy, void* stream);
+
+/* Column count (multiple of 32) of the Y matrix lshrs_sig_project_f32 writes. */
+int32_t lshrs_sig_padded_columns(int32_t num_bands, int32_t rows_per_band);
+
+/* Tie-break plumbing: copy m rows X[rows[t]] into dst (m, dim) contiguous. */
+int lshrs_gather_rows_f32(const float* X, int64_t ldx, int32_t dim, const int64_t* rows, int64_t m,
+                          float* dst, void* stream);
+
+/* Tie-break plumbing: keys[rows[t]][bands[t]][:] = patch[t][:]  (patch is (m, B) u8). */
+int lshrs_scatter_band_keys_u8(uint8_t* keys, int32_t num_bands, int32_t band_bytes,
+                               const int64_t* rows, const int32_t* bands, const uint8_t* patch, int64_t m,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cosine rerank — replaces cosine_similarity / top_k_cosine (lshrs/utils/similarity.py:80-90,
+ * 157-183) and the per-candidate l2_norm (lshrs/utils/norm.py:48-61).
+ * ------------------------------------------------------------------------------------------ */
+
+/* scores[qi][ci] = dot(c, q) / (||c|| * ||q||) in f32, c = corpus[cand_idx[qi][ci]]
+ * (or corpus[qi*c + ci] when cand_idx == NULL: candidates given densely, per query).
+ *   corpus   (m, dim) f32, row stride ldc;  queries (q, dim) f32 contiguous
+ *   cand_idx (q, c) int64 or NULL
+ *   scores   (q, c) f32
+ *   status   (q, c) u8: 0 ok, 1 = candidate has zero norm (reference raises "Cannot normalize
+ *            zero vector", norm.py:56-57), 2 = index out of [0, m); score is NaN for both
+ *   qstatus  (q,) u8: 1 = query has zero norm.
+ * Limit: dim <= 16384. */
+int lshrs_cosine_batch_f32(const float* corpus, int64_t m, int64_t ldc, int32_t dim,
+                           const float* queries, int32_t q,
+                           const int64_t* cand_idx, int32_t c,
+                           float* scores, uint8_t* status, uint8_t* qstatus, void* stream);
+
+/* Per-query descending order — replaces argpartition + argsort (similarity.py:174-179).
+ *   scores (q, c) f32 -> order (q, k) int32 positions, sorted (q, k) f32, k <= c.
+ * Ties are broken by ascending position (the reference's order on ties is unspecified);
+ * NaN scores sort last.  Limit: c <= 16384 (one LDS-resident bitonic network per query). */
+int lshrs_topk_desc_f32(const float* scores, int32_t q, int32_t c, int32_t k,
+                        int32_t* order, float* sorted, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSHRS_HIP_H */

@@ -1,0 +1,17 @@
+"""lshrs_amd — MI355X-native implementation of the lshrs compute hot path.
+
+Drop-in names (same surface as the reference package ``lshrs``):
+
+    LSHRS / lshrs, LSHHasher, HashSignatures, top_k_cosine, cosine_similarity, l2_norm
+
+The arithmetic lives in ``csrc/lshrs_hip.hip`` (gfx950 only) behind the C ABI of
+``include/lshrs_hip.h``; this package is the Python boundary around it.  There is
+no CPU compute path: without the built extension and a visible MI355X every
+compute call raises ``lshrs_amd._native.NativeLibraryError``.
+"""
+
+from ._config import HashSignatures
+from .hasher import LSHHasher
+
+__all__ = ["HashSignatures", "LSHHasher"]
+__version__ = "0.1.0"

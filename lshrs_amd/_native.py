@@ -1,0 +1,143 @@
+"""ctypes binding of ``csrc/liblshrs_hip.so`` (the C ABI declared in ``include/lshrs_hip.h``).
+
+There is no CPU implementation behind this module: if the shared library has not
+been built, or the ABI version does not match, loading raises — loudly — and so
+does every compute entry point of the package.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+SOURCE = os.path.join(CSRC, "lshrs_hip.hip")
+LIBRARY = os.path.join(CSRC, "liblshrs_hip.so")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+ABI_VERSION = 1
+
+E_BADARG = -10001
+E_TOOLARGE = -10002
+
+_lock = threading.Lock()
+_lib: Optional[ctypes.CDLL] = None
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP extension is missing, stale or reported an error."""
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP source for gfx950 into the in-tree shared library."""
+    with _lock:
+        newest_src = max(os.path.getmtime(SOURCE), os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h")))
+        if not force and os.path.exists(LIBRARY) and os.path.getmtime(LIBRARY) >= newest_src:
+            return LIBRARY
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, SOURCE,
+               "-o", LIBRARY + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        os.replace(LIBRARY + ".tmp", LIBRARY)
+        return LIBRARY
+
+
+def _declare(lib: ctypes.CDLL) -> None:
+    c = ctypes
+    vp, i32, i64, f32 = c.c_void_p, c.c_int32, c.c_int64, c.c_float
+    lib.lshrs_abi_version.argtypes = []
+    lib.lshrs_abi_version.restype = c.c_int
+    lib.lshrs_sig_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.lshrs_sig_workspace_bytes.restype = i64
+    lib.lshrs_sig_padded_columns.argtypes = [i32, i32]
+    lib.lshrs_sig_padded_columns.restype = i32
+    lib.lshrs_sig_pack_projections.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.lshrs_sig_pack_projections.restype = c.c_int
+    lib.lshrs_sig_hash_batch_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp]
+    lib.lshrs_sig_hash_batch_f32.restype = c.c_int
+    lib.lshrs_sig_project_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, i64, vp]
+    lib.lshrs_sig_project_f32.restype = c.c_int
+    lib.lshrs_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, vp, vp]
+    lib.lshrs_gather_rows_f32.restype = c.c_int
+    lib.lshrs_scatter_band_keys_u8.argtypes = [vp, i32, i32, vp, vp, vp, i64, vp]
+    lib.lshrs_scatter_band_keys_u8.restype = c.c_int
+    lib.lshrs_cosine_batch_f32.argtypes = [vp, i64, i64, i32, vp, i32, vp, i32, vp, vp, vp, vp]
+    lib.lshrs_cosine_batch_f32.restype = c.c_int
+    lib.lshrs_topk_desc_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.lshrs_topk_desc_f32.restype = c.c_int
+
+
+EXPORTS = (
+    "lshrs_abi_version",
+    "lshrs_sig_workspace_bytes",
+    "lshrs_sig_padded_columns",
+    "lshrs_sig_pack_projections",
+    "lshrs_sig_hash_batch_f32",
+    "lshrs_sig_project_f32",
+    "lshrs_gather_rows_f32",
+    "lshrs_scatter_band_keys_u8",
+    "lshrs_cosine_batch_f32",
+    "lshrs_topk_desc_f32",
+)
+
+
+def load() -> ctypes.CDLL:
+    """Load the library (once).  Raises NativeLibraryError when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIBRARY):
+            raise NativeLibraryError(
+                f"{LIBRARY} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "lshrs_amd has no CPU fallback."
+            )
+        # torch ships its own libamdhip64 (same SONAME); importing it first makes our
+        # NEEDED entry resolve to the runtime torch allocates with.
+        import torch  # noqa: F401
+
+        try:
+            lib = ctypes.CDLL(LIBRARY)
+        except OSError as exc:  # pragma: no cover - environment specific
+            raise NativeLibraryError(f"cannot load {LIBRARY}: {exc}") from exc
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise NativeLibraryError(f"{LIBRARY} does not export {name}; rebuild it")
+        _declare(lib)
+        got = lib.lshrs_abi_version()
+        if got != ABI_VERSION:
+            raise NativeLibraryError(f"{LIBRARY} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+        _lib = lib
+        return lib
+
+
+def check(code: int, what: str) -> None:
+    """Turn a C-ABI status into an exception."""
+    if code == 0:
+        return
+    if code == E_BADARG:
+        raise NativeLibraryError(f"{what}: bad argument (LSHRS_E_BADARG)")
+    if code == E_TOOLARGE:
+        raise NativeLibraryError(f"{what}: shape outside kernel limits (LSHRS_E_TOOLARGE)")
+    raise NativeLibraryError(f"{what}: HIP error {-code}")
+
+
+def require_gpu():
+    """Return the torch module after checking a GPU is usable; raise loudly otherwise."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise NativeLibraryError(
+            "no MI355X/ROCm device is visible to PyTorch; lshrs_amd computes only on the GPU "
+            "(there is no CPU fallback)."
+        )
+    return torch

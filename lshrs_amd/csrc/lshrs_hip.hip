@@ -1,0 +1,696 @@
+// lshrs_hip.hip — gfx950 (MI355X / CDNA4) kernels + C ABI for the lshrs hot path.
+//
+//   K1  sig_kernel        random-projection signature pass (exact-f32 MFMA, ballot bit-pack)
+//   K2  cosine_kernel     gather + dot + norm cosine of candidates against a query
+//   K3  topk_kernel       per-query descending order (LDS bitonic network)
+//   + small helpers (hyperplane re-layout, row gather, key patch scatter)
+//
+// Written for wave64 / v_mfma_f32_32x32x2_f32 / 160 KiB LDS; there is no other target.
+// ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "lshrs_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K1 geometry
+// ------------------------------------------------------------------------------------------
+constexpr int kKTile = 32;        // k per LDS tile; MFMA step s uses k = s (lanes 0-31) and 16+s (lanes 32-63)
+constexpr int kWaves = 8;         // waves per workgroup (two per SIMD)
+constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
+constexpr int kBlockRows = kWaves * kRowsPerWave;
+constexpr int kThreads = kWaves * 64;
+constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
+
+struct SigGeom {
+  int nt;        // 32-column tiles per workgroup (1, 2, 4 or 8)
+  int cb;        // column blocks (grid.y)
+  int ktiles;    // ceil(dim / 32)
+  int bb;        // bytes per band
+  int padcols;   // num_bands * bb * 8
+  int tiles32;   // ceil(padcols / 32)
+};
+
+inline SigGeom sig_geom(int num_bands, int rows, int dim) {
+  SigGeom g;
+  g.bb = (rows + 7) / 8;
+  g.padcols = num_bands * g.bb * 8;
+  g.tiles32 = (g.padcols + 31) / 32;
+  g.nt = g.tiles32 >= 8 ? 8 : (g.tiles32 > 2 ? 4 : (g.tiles32 > 1 ? 2 : 1));
+  g.cb = (g.tiles32 + g.nt - 1) / g.nt;
+  g.ktiles = (dim + kKTile - 1) / kKTile;
+  return g;
+}
+
+inline int64_t sig_image_floats(const SigGeom& g) { return (int64_t)g.cb * g.ktiles * g.nt * 4 * kFragFloats; }
+inline int64_t sig_norm_floats(const SigGeom& g) { return (int64_t)g.cb * g.nt * 32; }
+
+// ------------------------------------------------------------------------------------------
+// Hyperplane re-layout.  image[cb][kt][jt][q][lane][r] = P'[col = (cb*NT + jt)*32 + (lane&31)]
+//                                                          [k   = kt*32 + 16*(lane>>5) + 4*q + r]
+// where P' is P with every band padded to 8*B columns (zero rows) and k padded to 32 (zeros).
+// One (jt, q) block is exactly what one ds_read_b128 per lane hands to four MFMA steps.
+// ------------------------------------------------------------------------------------------
+__global__ void pack_image_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb, int nt,
+                                  int ktiles, int64_t chunks, f32x4* __restrict__ image) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= chunks) return;
+  const int lane = (int)(c & 63);
+  const int q = (int)((c >> 6) & 3);
+  int64_t t = c >> 8;
+  const int jt = (int)(t % nt);
+  t /= nt;
+  const int kt = (int)(t % ktiles);
+  const int cb = (int)(t / ktiles);
+  const int col = (cb * nt + jt) * 32 + (lane & 31);
+  const int band = col / (bb * 8);
+  const int bit = col % (bb * 8);
+  const int k0 = kt * kKTile + 16 * (lane >> 5) + 4 * q;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (band < num_bands && bit < rows) {
+    const float* src = P + ((int64_t)band * rows + bit) * dim;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (k0 + r < dim) v[r] = src[k0 + r];
+  }
+  image[c] = v;
+}
+
+__global__ void pack_norm_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb, int cols,
+                                 float* __restrict__ norms) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  const int band = col / (bb * 8);
+  const int bit = col % (bb * 8);
+  double s = 0.0;
+  if (band < num_bands && bit < rows) {
+    const float* src = P + ((int64_t)band * rows + bit) * dim;
+    for (int k = 0; k < dim; ++k) s += (double)src[k] * (double)src[k];
+  }
+  norms[col] = (float)sqrt(s);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------
+struct SigArgs {
+  const float* X;
+  int64_t n;
+  int64_t ldx;
+  int dim;
+  int ktiles;
+  const float* image;
+  const float* norms;
+  // keys mode
+  uint8_t* keys;
+  int row_bytes;       // num_bands * bb
+  int vec_store;       // 1: rows of keys may be written with aligned vector stores
+  int64_t* tie_list;
+  int tie_cap;
+  int* tie_count;
+  float tau;
+  uint8_t* row_flags;
+  // project mode
+  float* Y;
+  int64_t ldy;
+};
+
+template <bool ALIGNED>
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ xrow, int kbase, int dim, f32x4 (&a)[4]) {
+  // lane (i, h) owns k = kbase + 4q + r, q,r in 0..3 (kbase already includes 16*h): 64 contiguous bytes
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = kbase + 4 * q;
+    if (ALIGNED) {
+      if (k < dim)
+        a[q] = *reinterpret_cast<const f32x4*>(xrow + k);
+      else
+        a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (k + r < dim) ? xrow[k + r] : 0.f;
+      a[q] = v;
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void stage_p_tile(const float* __restrict__ tile, float* lds_buf, int tid) {
+  // NT*4 KiB, linear copy, 16 B per lane per instruction, straight into LDS (no VGPR round trip)
+  constexpr int kChunks = NT * 4 * 64;  // 16-byte chunks
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int base = 0; base < kChunks; base += kThreads) {
+    if (base + wave * 64 < kChunks) {  // wave-uniform
+      const float* g = tile + (size_t)(base + tid) * 4;
+      float* l = lds_buf + (size_t)(base + wave * 64) * 4;  // wave-uniform base; hardware adds lane*16
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 16, 0, 0);
+    }
+  }
+}
+
+// Deposit a wave-uniform word into one lane's register (lane index is a compile-time constant:
+// a v_cndmask under a constant 64-bit lane mask).
+__device__ __forceinline__ uint32_t put_lane(uint32_t old, uint32_t uniform_word, int lane, int target) {
+  return lane == target ? uniform_word : old;
+}
+
+template <int NT, bool ALIGNED, bool PROJECT>
+__global__ __launch_bounds__(kThreads, 2) void sig_kernel(const SigArgs args) {
+  constexpr int kTileFloats = NT * 4 * kFragFloats;
+  __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + kWaves * 32];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int h = lane >> 5;
+  const int i = lane & 31;
+  const int cb = blockIdx.y;
+  const int64_t row0 = (int64_t)blockIdx.x * kBlockRows + wave * kRowsPerWave;
+  const int64_t myrow = row0 + i;
+  const int64_t ldrow = myrow < args.n ? myrow : args.n - 1;  // clamp: loads stay in bounds, stores are masked
+  const float* __restrict__ xrow = args.X + ldrow * args.ldx;
+  const int dim = args.dim;
+  const int ktiles = args.ktiles;
+  const float* __restrict__ img = args.image + (size_t)cb * ktiles * kTileFloats;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+
+  f32x4 a_cur[4], a_nxt[4];
+  float ss = 0.f;    // sum of squares of this lane's share of the row
+  float amax = 0.f;  // max |x| of this lane's share (NaN-ignoring; NaN shows up in ss)
+
+  stage_p_tile<NT>(img, lds, tid);
+  load_x_tile<ALIGNED>(xrow, 16 * h, dim, a_cur);
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const float* lb = lds + (kt & 1) * kTileFloats;
+    if (kt + 1 < ktiles) {
+      stage_p_tile<NT>(img + (size_t)(kt + 1) * kTileFloats, lds + ((kt + 1) & 1) * kTileFloats, tid);
+      load_x_tile<ALIGNED>(xrow, (kt + 1) * kKTile + 16 * h, dim, a_nxt);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 b[NT];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+        b[jt] = *reinterpret_cast<const f32x4*>(lb + ((jt * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float av = a_cur[q][r];
+        ss = __builtin_fmaf(av, av, ss);
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(av));
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+          acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[jt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+  }
+
+  // accumulator map (32x32 tile): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if (PROJECT) {
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < args.n) args.Y[row * args.ldy + (cb * NT + jt) * 32 + i] = acc[jt][r];
+      }
+    return;
+  }
+
+  // ---- row statistics: ||x||, zero-vector flag ------------------------------------------
+  ss += __shfl_xor(ss, 32);
+  amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32));
+  float* norm_lds = lds + 2 * kTileFloats + wave * 32;
+  if (h == 0) {
+    norm_lds[i] = sqrtf(ss) * args.tau;
+    if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
+      const bool has_nan = ss != ss;
+      const bool zero = (amax <= 1e-8f) && !has_nan;
+      args.row_flags[myrow] = (uint8_t)((zero ? 1 : 0) | (has_nan ? 2 : 0));
+    }
+  }
+  __syncthreads();
+
+  // ---- sign bits + tie bits, one ballot per accumulator register -------------------------
+  constexpr int LPR = NT >= 2 ? 2 : 1;   // lanes that hold one output row
+  constexpr int WPL = NT >= 2 ? NT / 2 : 1;  // 32-bit words per lane
+  uint32_t kw[WPL], tw[WPL];
+#pragma unroll
+  for (int w = 0; w < WPL; ++w) { kw[w] = 0u; tw[w] = 0u; }
+
+  const bool want_ties = args.tie_list != nullptr;
+  f32x4 rn[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(norm_lds + 8 * g + 4 * h);
+
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const float pn = args.norms[(cb * NT + jt) * 32 + i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float y = acc[jt][r];
+      const uint64_t pos = __builtin_amdgcn_ballot_w64(y > 0.f);
+      const int rho = (r & 3) + 8 * (r >> 2);
+      const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
+      const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
+      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)pos, lane, l0);
+      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)(pos >> 32), lane, l1);
+      if (want_ties) {
+        const float thr = rn[r >> 2][r & 3] * pn;
+        const uint64_t tie = __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) <= thr);
+        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)tie, lane, l0);
+        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)(tie >> 32), lane, l1);
+      }
+    }
+  }
+
+  // ---- stores: lane L holds words [ (L % LPR) * WPL, +WPL ) of row L / LPR -----------------
+  const int orow = lane / LPR;
+  const int64_t grow = row0 + orow;
+  const bool lane_on = (NT >= 2 || lane < 32) && grow < args.n;
+  const int word0 = cb * NT + (lane % LPR) * WPL;  // first 32-column word this lane holds
+  const int byte0 = word0 * 4;
+  if (lane_on) {
+    uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
+    if (args.vec_store && byte0 + 4 * WPL <= args.row_bytes) {
+      if (WPL == 4) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{kw[0], kw[1 % WPL], kw[2 % WPL], kw[3 % WPL]};
+      } else if (WPL == 2) {
+        *reinterpret_cast<u32x2*>(dst) = u32x2{kw[0], kw[1 % WPL]};
+      } else {
+        *reinterpret_cast<uint32_t*>(dst) = kw[0];
+      }
+    } else {
+#pragma unroll
+      for (int w = 0; w < WPL; ++w)
+#pragma unroll
+        for (int bsel = 0; bsel < 4; ++bsel)
+          if (byte0 + 4 * w + bsel < args.row_bytes) dst[4 * w + bsel] = (uint8_t)(kw[w] >> (8 * bsel));
+    }
+    if (want_ties) {
+#pragma unroll
+      for (int w = 0; w < WPL; ++w) {
+        if (tw[w] != 0u) {
+          const int slot = atomicAdd(args.tie_count, 1);
+          if (slot < args.tie_cap) args.tie_list[slot] = grow * 65536 + (word0 + w);
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+int launch_sig(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
+  const dim3 grid((unsigned)((a.n + kBlockRows - 1) / kBlockRows), (unsigned)g.cb, 1);
+  const dim3 block(kThreads, 1, 1);
+  if (project) {
+    if (aligned)
+      hipLaunchKernelGGL((sig_kernel<NT, true, true>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((sig_kernel<NT, false, true>), grid, block, 0, s, a);
+  } else {
+    if (aligned)
+      hipLaunchKernelGGL((sig_kernel<NT, true, false>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((sig_kernel<NT, false, false>), grid, block, 0, s, a);
+  }
+  return -(int)hipGetLastError();
+}
+
+int dispatch_sig(const SigArgs& a, const SigGeom& g, bool project, hipStream_t s) {
+  const bool aligned = (a.dim % 4 == 0) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+  switch (g.nt) {
+    case 8: return launch_sig<8>(a, g, aligned, project, s);
+    case 4: return launch_sig<4>(a, g, aligned, project, s);
+    case 2: return launch_sig<2>(a, g, aligned, project, s);
+    default: return launch_sig<1>(a, g, aligned, project, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// tie-break plumbing
+// ------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ X, int64_t ldx, int dim, const int64_t* __restrict__ rows,
+                                   int64_t m, float* __restrict__ dst) {
+  const int64_t t = blockIdx.x;
+  if (t >= m) return;
+  const float* src = X + rows[t] * ldx;
+  float* out = dst + t * (int64_t)dim;
+  for (int k = threadIdx.x; k < dim; k += blockDim.x) out[k] = src[k];
+}
+
+__global__ void scatter_keys_kernel(uint8_t* __restrict__ keys, int num_bands, int bb, const int64_t* __restrict__ rows,
+                                    const int32_t* __restrict__ bands, const uint8_t* __restrict__ patch, int64_t m) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * bb) return;
+  const int64_t e = t / bb;
+  const int byte = (int)(t % bb);
+  keys[(rows[e] * num_bands + bands[e]) * (int64_t)bb + byte] = patch[e * bb + byte];
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: cosine of gathered candidates against a query.  One workgroup = one (query, slice of
+// its candidates); the query sits in LDS, each wave streams whole candidate rows (16 B per
+// lane per load, four rows in flight), reduces dot and ||c||^2 across the wave, and lane 0
+// writes dot / (||c|| * ||q||).
+// ------------------------------------------------------------------------------------------
+constexpr int kCosThreads = 256;
+constexpr int kCosWaves = kCosThreads / 64;
+constexpr int kCosInflight = 4;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kCosThreads) void cosine_kernel(const float* __restrict__ corpus, int64_t m, int64_t ldc,
+                                                             int dim, const float* __restrict__ queries,
+                                                             const int64_t* __restrict__ cand_idx, int c, int slices,
+                                                             float* __restrict__ scores, uint8_t* __restrict__ status,
+                                                             uint8_t* __restrict__ qstatus) {
+  extern __shared__ __attribute__((aligned(16))) float qlds[];  // dim floats (+ pad to 4) + kCosWaves partials
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int qi = blockIdx.x / slices;
+  const int slice = blockIdx.x % slices;
+  const int dim4 = (dim + 3) & ~3;
+  const float* __restrict__ qv = queries + (int64_t)qi * dim;
+
+  float qq = 0.f;
+  for (int k = tid; k < dim4; k += kCosThreads) {
+    const float v = k < dim ? qv[k] : 0.f;
+    qlds[k] = v;
+    qq = __builtin_fmaf(v, v, qq);
+  }
+  qq = wave_sum(qq);
+  float* part = qlds + dim4;
+  if (lane == 0) part[wave] = qq;
+  __syncthreads();
+  float qnorm2 = 0.f;
+#pragma unroll
+  for (int w = 0; w < kCosWaves; ++w) qnorm2 += part[w];
+  const float qnorm = sqrtf(qnorm2);
+  if (slice == 0 && tid == 0 && qstatus != nullptr) qstatus[qi] = (qnorm == 0.f) ? 1 : 0;
+
+  // candidates of this slice, dealt to waves in groups of kCosInflight
+  const int per_slice = (c + slices - 1) / slices;
+  const int c_begin = slice * per_slice;
+  const int c_end = min(c, c_begin + per_slice);
+
+  for (int base = c_begin + wave * kCosInflight; base < c_end; base += kCosWaves * kCosInflight) {
+    const float* rowp[kCosInflight];
+    int st[kCosInflight];
+#pragma unroll
+    for (int u = 0; u < kCosInflight; ++u) {
+      const int ci = base + u;
+      int64_t idx = 0;
+      st[u] = 3;  // 3 = not a candidate (past the end)
+      if (ci < c_end) {
+        idx = cand_idx != nullptr ? cand_idx[(int64_t)qi * c + ci] : (int64_t)qi * c + ci;
+        st[u] = (idx < 0 || idx >= m) ? 2 : 0;
+      }
+      rowp[u] = corpus + (st[u] == 0 ? idx : 0) * ldc;
+    }
+    float dot[kCosInflight], nn[kCosInflight];
+#pragma unroll
+    for (int u = 0; u < kCosInflight; ++u) { dot[u] = 0.f; nn[u] = 0.f; }
+
+    if (ALIGNED) {
+      for (int k = lane * 4; k < dim; k += 256) {
+        const f32x4 qx = *reinterpret_cast<const f32x4*>(qlds + k);
+        f32x4 cx[kCosInflight];
+#pragma unroll
+        for (int u = 0; u < kCosInflight; ++u) cx[u] = *reinterpret_cast<const f32x4*>(rowp[u] + k);
+#pragma unroll
+        for (int u = 0; u < kCosInflight; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dot[u] = __builtin_fmaf(cx[u][e], qx[e], dot[u]);
+            nn[u] = __builtin_fmaf(cx[u][e], cx[u][e], nn[u]);
+          }
+      }
+    } else {
+      for (int k = lane; k < dim; k += 64) {
+        const float qx = qlds[k];
+#pragma unroll
+        for (int u = 0; u < kCosInflight; ++u) {
+          const float cx = rowp[u][k];
+          dot[u] = __builtin_fmaf(cx, qx, dot[u]);
+          nn[u] = __builtin_fmaf(cx, cx, nn[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kCosInflight; ++u) {
+      const float d = wave_sum(dot[u]);
+      const float s2 = wave_sum(nn[u]);
+      if (lane == 0 && st[u] != 3) {
+        const int64_t o = (int64_t)qi * c + base + u;
+        int code = st[u];
+        float sc;
+        if (code == 0) {
+          const float cn = sqrtf(s2);
+          if (cn == 0.f) code = 1;
+          sc = d / (cn * qnorm);
+        }
+        if (code != 0) sc = __builtin_nanf("");
+        scores[o] = sc;
+        if (status != nullptr) status[o] = (uint8_t)code;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: descending order of each query's scores: bitonic network over 64-bit (key, position)
+// pairs in LDS.  key ascending == score descending; NaN last; ties by ascending position.
+// ------------------------------------------------------------------------------------------
+constexpr int kTopkThreads = 256;
+
+__device__ __forceinline__ uint32_t desc_key(float f) {
+  if (f != f) return 0xFFFFFFFFu;  // NaN: after everything
+  uint32_t u = __float_as_uint(f);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-orderable
+  return ~u;                                       // descending, and never 0xFFFFFFFF for non-NaN? (-inf -> 0xFF800000 -> fine)
+}
+
+__global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restrict__ scores, int c, int cpad, int k,
+                                                            int32_t* __restrict__ order, float* __restrict__ sorted) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t items[];
+  const int qi = blockIdx.x;
+  const float* s = scores + (int64_t)qi * c;
+  for (int t = threadIdx.x; t < cpad; t += kTopkThreads) {
+    uint64_t v = ~0ull;  // padding sorts after every real item (position field > any real position)
+    if (t < c) v = ((uint64_t)desc_key(s[t]) << 32) | (uint32_t)t;
+    items[t] = v;
+  }
+  __syncthreads();
+  for (int size = 2; size <= cpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (cpad >> 1); t += kTopkThreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const uint64_t a = items[lo], b = items[hi];
+        if ((a > b) == up) {
+          items[lo] = b;
+          items[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < k; t += kTopkThreads) {
+    const uint32_t pos = (uint32_t)items[t];
+    order[(int64_t)qi * k + t] = (int32_t)pos;
+    sorted[(int64_t)qi * k + t] = s[pos];
+  }
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
+
+static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
+  if (num_bands <= 0 || rows <= 0 || dim <= 0) return false;
+  const int64_t padcols = (int64_t)num_bands * ((rows + 7) / 8) * 8;
+  return padcols <= (1 << 21);
+}
+
+int64_t lshrs_sig_workspace_bytes(int32_t num_bands, int32_t rows_per_band, int32_t dim) {
+  if (!sig_shape_ok(num_bands, rows_per_band, dim)) return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  return (sig_image_floats(g) + sig_norm_floats(g)) * (int64_t)sizeof(float);
+}
+
+int32_t lshrs_sig_padded_columns(int32_t num_bands, int32_t rows_per_band) {
+  if (num_bands <= 0 || rows_per_band <= 0) return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, 1);
+  return g.cb * g.nt * 32;
+}
+
+int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_per_band, int32_t dim, void* workspace,
+                               void* stream) {
+  if (P == nullptr || workspace == nullptr || !sig_shape_ok(num_bands, rows_per_band, dim)) return LSHRS_E_BADARG;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* image = static_cast<float*>(workspace);
+  float* norms = image + sig_image_floats(g);
+  const int64_t chunks = sig_image_floats(g) / 4;
+  hipLaunchKernelGGL(pack_image_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                     rows_per_band, dim, g.bb, g.nt, g.ktiles, chunks, reinterpret_cast<f32x4*>(image));
+  const int cols = g.cb * g.nt * 32;
+  hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64), 0, s, P, num_bands, rows_per_band,
+                     dim, g.bb, cols, norms);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                             int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
+                             int32_t* tie_count, float tau, uint8_t* row_flags, void* stream) {
+  if (n == 0) return 0;
+  if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim ||
+      !sig_shape_ok(num_bands, rows_per_band, dim))
+    return LSHRS_E_BADARG;
+  if (tie_list != nullptr && (tie_count == nullptr || tie_cap < 0)) return LSHRS_E_BADARG;
+  if (n >= ((int64_t)1 << 47)) return LSHRS_E_TOOLARGE;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  if ((n + kBlockRows - 1) / kBlockRows > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
+  SigArgs a{};
+  a.X = X;
+  a.n = n;
+  a.ldx = ldx;
+  a.dim = dim;
+  a.ktiles = g.ktiles;
+  a.image = static_cast<const float*>(workspace);
+  a.norms = a.image + sig_image_floats(g);
+  a.keys = keys;
+  a.row_bytes = num_bands * g.bb;
+  const int wpl_bytes = g.nt >= 2 ? 2 * g.nt : 4;  // bytes one lane stores
+  a.vec_store = (a.row_bytes % wpl_bytes == 0) && ((reinterpret_cast<uintptr_t>(keys) % wpl_bytes) == 0);
+  a.tie_list = tie_list;
+  a.tie_cap = tie_cap;
+  a.tie_count = tie_count;
+  a.tau = tau;
+  a.row_flags = row_flags;
+  return dispatch_sig(a, g, false, static_cast<hipStream_t>(stream));
+}
+
+int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                          int32_t rows_per_band, int32_t dim, float* Y, int64_t ldy, void* stream) {
+  if (n == 0) return 0;
+  if (X == nullptr || workspace == nullptr || Y == nullptr || n < 0 || ldx < dim ||
+      !sig_shape_ok(num_bands, rows_per_band, dim))
+    return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  if (ldy < (int64_t)g.cb * g.nt * 32) return LSHRS_E_BADARG;
+  if ((n + kBlockRows - 1) / kBlockRows > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
+  SigArgs a{};
+  a.X = X;
+  a.n = n;
+  a.ldx = ldx;
+  a.dim = dim;
+  a.ktiles = g.ktiles;
+  a.image = static_cast<const float*>(workspace);
+  a.norms = a.image + sig_image_floats(g);
+  a.Y = Y;
+  a.ldy = ldy;
+  return dispatch_sig(a, g, true, static_cast<hipStream_t>(stream));
+}
+
+int lshrs_gather_rows_f32(const float* X, int64_t ldx, int32_t dim, const int64_t* rows, int64_t m, float* dst,
+                          void* stream) {
+  if (m == 0) return 0;
+  if (X == nullptr || rows == nullptr || dst == nullptr || dim <= 0 || m < 0 || ldx < dim) return LSHRS_E_BADARG;
+  if (m > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)m), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, dim,
+                     rows, m, dst);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_scatter_band_keys_u8(uint8_t* keys, int32_t num_bands, int32_t band_bytes, const int64_t* rows,
+                               const int32_t* bands, const uint8_t* patch, int64_t m, void* stream) {
+  if (m == 0) return 0;
+  if (keys == nullptr || rows == nullptr || bands == nullptr || patch == nullptr || num_bands <= 0 || band_bytes <= 0 ||
+      m < 0)
+    return LSHRS_E_BADARG;
+  const int64_t total = m * band_bytes;
+  if ((total + 255) / 256 > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  hipLaunchKernelGGL(scatter_keys_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), keys, num_bands, band_bytes, rows, bands, patch, m);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_cosine_batch_f32(const float* corpus, int64_t m, int64_t ldc, int32_t dim, const float* queries, int32_t q,
+                           const int64_t* cand_idx, int32_t c, float* scores, uint8_t* status, uint8_t* qstatus,
+                           void* stream) {
+  if (q == 0 || c == 0) return 0;
+  if (corpus == nullptr || queries == nullptr || scores == nullptr || m <= 0 || dim <= 0 || q < 0 || c < 0 || ldc < dim)
+    return LSHRS_E_BADARG;
+  if (dim > 16384) return LSHRS_E_TOOLARGE;
+  if (cand_idx == nullptr && (int64_t)q * c > m) return LSHRS_E_BADARG;
+  // enough workgroups to fill 256 CUs several times over even for a single query
+  int slices = 1;
+  const int per_block = kCosWaves * kCosInflight;
+  while ((int64_t)q * slices < 4096 && (c + slices - 1) / slices > 2 * per_block) slices *= 2;
+  if ((int64_t)q * slices > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  const bool aligned = (dim % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0);
+  const size_t shmem = (size_t)(((dim + 3) & ~3) + kCosWaves) * sizeof(float);
+  const dim3 grid((unsigned)((int64_t)q * slices)), block(kCosThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (aligned)
+    hipLaunchKernelGGL(cosine_kernel<true>, grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_idx, c, slices,
+                       scores, status, qstatus);
+  else
+    hipLaunchKernelGGL(cosine_kernel<false>, grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_idx, c, slices,
+                       scores, status, qstatus);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_topk_desc_f32(const float* scores, int32_t q, int32_t c, int32_t k, int32_t* order, float* sorted,
+                        void* stream) {
+  if (q == 0 || k == 0) return 0;
+  if (scores == nullptr || order == nullptr || sorted == nullptr || q < 0 || c <= 0 || k < 0 || k > c)
+    return LSHRS_E_BADARG;
+  if (c > 16384) return LSHRS_E_TOOLARGE;
+  int cpad = 2;
+  while (cpad < c) cpad <<= 1;
+  const size_t shmem = (size_t)cpad * sizeof(uint64_t);
+  hipLaunchKernelGGL(topk_kernel, dim3((unsigned)q), dim3(kTopkThreads), shmem, static_cast<hipStream_t>(stream),
+                     scores, c, cpad, k, order, sorted);
+  return -(int)hipGetLastError();
+}
+
+}  // extern "C"

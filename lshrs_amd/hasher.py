@@ -1,0 +1,375 @@
+"""``LSHHasher`` — the signature pass of lshrs on MI355X.
+
+Same constructor, attributes, methods and error messages as the reference class
+(lshrs/hash/lsh.py:51-247); the arithmetic runs in ``csrc/lshrs_hip.hip`` through
+the C ABI of ``include/lshrs_hip.h``.  There is no CPU hashing path in here.
+
+Bit-exactness.  The reference's bits are ``sign(sgemv_f32(P_band, x))`` as rounded
+by the *host's* BLAS; the kernel evaluates the same dot products as a single-rounded
+fmaf chain on the f32 matrix cores.  Two correctly-rounded f32 evaluations of one dot
+product can only disagree in sign when |y| is inside their rounding noise, so the
+kernel reports every projection with ``|y| <= tau * ||x|| * ||p||`` (a few per 100k
+vectors) and this class re-evaluates exactly those (row, band) pairs with the
+reference's own expression, ``projection @ vector`` — the same NumPy call on the same
+host-resident hyperplanes — and patches the bytes.  ``tie_break="none"`` returns the
+raw kernel bits; ``last_stats`` records how many pairs were touched.
+"""
+
+from __future__ import annotations
+
+import threading
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from ._config import HashSignatures
+
+__all__ = ["LSHHasher"]
+
+_U = 2.0 ** -24  # unit roundoff of float32
+
+
+class _ProjectionList(list):
+    """``list`` of per-band hyperplane matrices that notices item re-assignment."""
+
+    def __init__(self, items, owner: "LSHHasher") -> None:
+        super().__init__(items)
+        self._owner = owner
+
+    def _touch(self) -> None:
+        self._owner._projection_version += 1
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        self._touch()
+
+    def __delitem__(self, key):
+        super().__delitem__(key)
+        self._touch()
+
+    def append(self, value):
+        super().append(value)
+        self._touch()
+
+    def extend(self, values):
+        super().extend(values)
+        self._touch()
+
+    def insert(self, index, value):
+        super().insert(index, value)
+        self._touch()
+
+    def pop(self, *a):
+        out = super().pop(*a)
+        self._touch()
+        return out
+
+    def clear(self):
+        super().clear()
+        self._touch()
+
+    def __reduce__(self):  # pickle as a plain list (LSHRS.__getstate__ reads this attribute)
+        return (list, (list(self),))
+
+
+class LSHHasher:
+    """Sign-random-projection hasher; drop-in for ``lshrs.hash.lsh.LSHHasher``.
+
+    Extra keyword arguments (not in the reference):
+      device      torch device index / ``torch.device`` (default: current device at call time)
+      tie_break   "host" (default: bytes equal the reference on this host), or "none" (raw kernel bits)
+      tau_ulps    tie threshold in units of float32 roundoff: |y| <= tau_ulps * 2^-24 * ||x|| * ||p||
+    """
+
+    def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
+                 tie_break: str = "host", tau_ulps: float = 32.0) -> None:
+        # messages: lshrs/hash/lsh.py:78-83
+        if num_bands <= 0:
+            raise ValueError("num_bands must be > 0")
+        if rows_per_band <= 0:
+            raise ValueError("rows_per_band must be > 0")
+        if dim <= 0:
+            raise ValueError("dim must be > 0")
+        if tie_break not in ("host", "none"):
+            raise ValueError("tie_break must be 'host' or 'none'")
+        self.num_bands = int(num_bands)
+        self.rows_per_band = int(rows_per_band)
+        self.dim = int(dim)
+        self.tie_break = tie_break
+        self.tau_ulps = float(tau_ulps)
+        self._device = device
+        self._lock = threading.Lock()
+        self._projection_version = 0
+        self._workspaces: Dict[int, Tuple[int, object]] = {}
+        self.last_stats: Dict[str, int] = {}
+        # hyperplanes: one generator, num_bands float64 draws cast to float32 (lsh.py:93-94)
+        gen = np.random.default_rng(seed)
+        planes = [gen.standard_normal((self.rows_per_band, self.dim)).astype(np.float32)
+                  for _ in range(self.num_bands)]
+        self._projections = _ProjectionList(planes, self)
+
+    # ------------------------------------------------------------------ hyperplanes
+    @property
+    def projections(self) -> List[np.ndarray]:
+        """Host-owned hyperplanes, one (rows_per_band, dim) float32 matrix per band.
+
+        Source of truth: re-assigning the attribute (``load_from_disk`` and ``__setstate__`` of the
+        orchestrator do, lshrs/core/main.py:981,1044) or an item of the list re-uploads the device copy on
+        the next call.  After editing a matrix *in place* call :meth:`refresh_device`.
+        """
+        return self._projections
+
+    @projections.setter
+    def projections(self, value) -> None:
+        self._projections = _ProjectionList(list(value), self)
+        self._projection_version += 1
+
+    def refresh_device(self) -> None:
+        self._projection_version += 1
+
+    @property
+    def band_bytes(self) -> int:
+        return (self.rows_per_band + 7) // 8
+
+    def _stacked(self) -> np.ndarray:
+        planes = [np.ascontiguousarray(p, dtype=np.float32) for p in self._projections]
+        if len(planes) != self.num_bands or any(p.shape != (self.rows_per_band, self.dim) for p in planes):
+            raise ValueError(
+                f"projections must be {self.num_bands} arrays of shape ({self.rows_per_band}, {self.dim})")
+        return np.concatenate(planes, axis=0)
+
+    # ------------------------------------------------------------------ device plumbing
+    def _torch_device(self, like=None):
+        torch = _native.require_gpu()
+        if like is not None:
+            return like.device
+        if self._device is None:
+            return torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(self._device) if not isinstance(self._device, int) else torch.device("cuda", self._device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return dev
+
+    def _workspace(self, dev):
+        """Device image of the hyperplanes in MFMA-fragment order (rebuilt when they change)."""
+        torch = _native.require_gpu()
+        lib = _native.load()
+        cached = self._workspaces.get(dev.index)
+        if cached is not None and cached[0] == self._projection_version:
+            return cached[1]
+        nbytes = lib.lshrs_sig_workspace_bytes(self.num_bands, self.rows_per_band, self.dim)
+        if nbytes < 0:
+            _native.check(int(nbytes), "lshrs_sig_workspace_bytes")
+        with torch.cuda.device(dev):
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            p_dev = torch.from_numpy(self._stacked()).to(dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _native.check(
+                lib.lshrs_sig_pack_projections(p_dev.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
+                                               ws.data_ptr(), stream),
+                "lshrs_sig_pack_projections")
+            torch.cuda.current_stream(dev).synchronize()  # p_dev may be freed after this
+        self._workspaces[dev.index] = (self._projection_version, ws)
+        return ws
+
+    # ------------------------------------------------------------------ core: device -> device
+    def hash_device(self, x, *, out=None, row_flags=None, tie_break: Optional[str] = None):
+        """Hash a device-resident ``(n, dim)`` float32 ``torch.Tensor``.
+
+        Returns a ``(n, num_bands, band_bytes)`` uint8 tensor on the same device.  ``row_flags``
+        (optional uint8 tensor of n) receives bit0 = zero vector, bit1 = NaN present.
+        """
+        torch = _native.require_gpu()
+        if x.dim() != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"Expected vectors of dimension {self.dim}, received {tuple(x.shape)}")
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise TypeError("hash_device expects a float32 CUDA/ROCm tensor")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        mode = self.tie_break if tie_break is None else tie_break
+        with self._lock:
+            return self._hash_device_locked(x, out, row_flags, mode, host_rows=None)
+
+    def _hash_device_locked(self, x, out, row_flags, mode, host_rows):
+        torch = _native.require_gpu()
+        lib = _native.load()
+        dev = x.device
+        n = int(x.shape[0])
+        bb = self.band_bytes
+        if out is None:
+            out = torch.empty((n, self.num_bands, bb), dtype=torch.uint8, device=dev)
+        elif out.shape != (n, self.num_bands, bb) or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous uint8 tensor of shape (n, num_bands, band_bytes)")
+        stats = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+        self.last_stats = stats
+        if n == 0:
+            return out
+        ws = self._workspace(dev)
+        tau = float(self.tau_ulps * _U)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            flags_ptr = row_flags.data_ptr() if row_flags is not None else None
+            if mode == "none":
+                _native.check(
+                    lib.lshrs_sig_hash_batch_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                                 self.rows_per_band, self.dim, out.data_ptr(), None, 0, None, 0.0,
+                                                 flags_ptr, stream),
+                    "lshrs_sig_hash_batch_f32")
+                return out
+            cap = min(max(4096, n // 16 + 4096), 2 ** 31 - 1)
+            while True:
+                tie_list = torch.empty(cap, dtype=torch.int64, device=dev)
+                tie_count = torch.zeros(1, dtype=torch.int32, device=dev)
+                _native.check(
+                    lib.lshrs_sig_hash_batch_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                                 self.rows_per_band, self.dim, out.data_ptr(), tie_list.data_ptr(),
+                                                 cap, tie_count.data_ptr(), tau, flags_ptr, stream),
+                    "lshrs_sig_hash_batch_f32")
+                cnt = int(tie_count.item())  # synchronises the stream
+                if cnt <= cap:
+                    break
+                cap = cnt  # the kernel counted every entry it wanted to write: relaunch with room
+                stats["relaunches"] += 1
+            stats["tie_entries"] = cnt
+            if cnt:
+                entries = tie_list[:cnt].cpu().numpy()
+                rows, bands = self._tie_pairs(entries)
+                stats["tie_pairs"] = int(rows.shape[0])
+                urows, inverse = np.unique(rows, return_inverse=True)
+                if host_rows is not None:
+                    xh = host_rows(urows)
+                else:
+                    idx_dev = torch.from_numpy(urows).to(dev)
+                    xg = torch.empty((urows.shape[0], self.dim), dtype=torch.float32, device=dev)
+                    _native.check(
+                        lib.lshrs_gather_rows_f32(x.data_ptr(), x.stride(0), self.dim, idx_dev.data_ptr(),
+                                                  urows.shape[0], xg.data_ptr(), stream),
+                        "lshrs_gather_rows_f32")
+                    xh = xg.cpu().numpy()
+                patch = self._tie_patches(xh, inverse, bands)
+                rows_dev = torch.from_numpy(rows).to(dev)
+                bands_dev = torch.from_numpy(bands).to(dev)
+                patch_dev = torch.from_numpy(patch).to(dev)
+                _native.check(
+                    lib.lshrs_scatter_band_keys_u8(out.data_ptr(), self.num_bands, bb, rows_dev.data_ptr(),
+                                                   bands_dev.data_ptr(), patch_dev.data_ptr(), rows.shape[0], stream),
+                    "lshrs_scatter_band_keys_u8")
+                torch.cuda.current_stream(dev).synchronize()  # the small staging tensors die with this frame
+        return out
+
+    def _tie_pairs(self, entries: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Kernel tie entries (row*65536 + 32-column word) -> unique (row, band) pairs."""
+        rows = entries >> 16
+        words = entries & 0xFFFF
+        band_cols = 8 * self.band_bytes
+        first = (32 * words) // band_cols
+        last = np.minimum((32 * words + 31) // band_cols, self.num_bands - 1)
+        keep = first < self.num_bands
+        rows, first, last = rows[keep], first[keep], last[keep]
+        span = int((last - first).max()) + 1 if rows.size else 0
+        codes = []
+        for d in range(span):
+            sel = first + d <= last
+            codes.append(rows[sel] * self.num_bands + first[sel] + d)
+        code = np.unique(np.concatenate(codes)) if codes else np.empty(0, dtype=np.int64)
+        return (code // self.num_bands).astype(np.int64), (code % self.num_bands).astype(np.int32)
+
+    def _tie_patches(self, xrows: np.ndarray, inverse: np.ndarray, bands: np.ndarray) -> np.ndarray:
+        """Band keys of the flagged pairs, by the reference's own expression
+        (``projection @ vector``, ``> 0``, ``np.packbits(..., bitorder='little')``: lsh.py:200-208)."""
+        planes = self._projections
+        patch = np.empty((bands.shape[0], self.band_bytes), dtype=np.uint8)
+        for t in range(bands.shape[0]):
+            y = planes[int(bands[t])] @ xrows[inverse[t]]
+            patch[t] = np.packbits((y > 0).astype(np.uint8), bitorder="little")
+        return patch
+
+    # ------------------------------------------------------------------ host-facing API
+    def hash_batch_packed(self, vectors, *, return_row_flags: bool = False, chunk_rows: int = 262_144,
+                          tie_break: Optional[str] = None):
+        """Hash host vectors; returns a NumPy ``(n, num_bands, band_bytes)`` uint8 array
+        (the reference's ``bytes`` keys side by side) and, on request, the per-row flag byte."""
+        torch = _native.require_gpu()
+        arr = np.asarray(vectors, dtype=np.float32)
+        if arr.ndim != 2:
+            raise ValueError("Batch input must be a 2D array")
+        if arr.shape[1] != self.dim:
+            raise ValueError(f"Expected vectors of dimension {self.dim}, received {arr.shape[1]}")
+        arr = np.ascontiguousarray(arr)
+        n = arr.shape[0]
+        mode = self.tie_break if tie_break is None else tie_break
+        keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
+        flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
+        dev = self._torch_device()
+        total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+        with self._lock:
+            for lo in range(0, n, chunk_rows):
+                hi = min(n, lo + chunk_rows)
+                chunk = arr[lo:hi]
+                x = torch.from_numpy(chunk).to(dev)
+                fl = torch.empty(hi - lo, dtype=torch.uint8, device=dev) if return_row_flags else None
+                out = self._hash_device_locked(x, None, fl, mode, host_rows=lambda r, c=chunk: c[r])
+                keys[lo:hi] = out.cpu().numpy()
+                if fl is not None:
+                    flags[lo:hi] = fl.cpu().numpy()
+                for k in ("tie_entries", "tie_pairs", "relaunches"):
+                    total[k] += self.last_stats.get(k, 0)
+        self.last_stats = total
+        return (keys, flags) if return_row_flags else keys
+
+    def hash_vector(self, vector) -> HashSignatures:
+        """One vector -> ``HashSignatures`` (reference: lsh.py:96-134)."""
+        vec = self._validate_vector(vector)
+        packed = self.hash_batch_packed(vec.reshape(1, -1))
+        return HashSignatures(tuple(packed[0, b].tobytes() for b in range(self.num_bands)))
+
+    def hash_batch(self, vectors) -> List[HashSignatures]:
+        """``(n, dim)`` -> list of ``HashSignatures`` (reference: lsh.py:136-169)."""
+        packed = self.hash_batch_packed(vectors)
+        nb = self.num_bands
+        return [HashSignatures(tuple(row[b].tobytes() for b in range(nb))) for row in packed]
+
+    def project_device(self, x):
+        """Diagnostic: raw f32 projections ``(n, num_perm)`` as the kernel accumulates them."""
+        torch = _native.require_gpu()
+        lib = _native.load()
+        if x.dim() != 2 or x.shape[1] != self.dim or x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError("project_device expects a float32 device tensor of shape (n, dim)")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        dev = x.device
+        n = int(x.shape[0])
+        ldy = int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band))
+        y = torch.empty((n, ldy), dtype=torch.float32, device=dev)
+        with self._lock, torch.cuda.device(dev):
+            ws = self._workspace(dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _native.check(
+                lib.lshrs_sig_project_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                          self.rows_per_band, self.dim, y.data_ptr(), ldy, stream),
+                "lshrs_sig_project_f32")
+        band_cols = 8 * self.band_bytes
+        cols = (torch.arange(self.num_bands, device=dev).repeat_interleave(self.rows_per_band) * band_cols
+                + torch.arange(self.rows_per_band, device=dev).repeat(self.num_bands))
+        return y[:, cols]
+
+    # ------------------------------------------------------------------ validation (lsh.py:213-247)
+    def _validate_vector(self, vector) -> np.ndarray:
+        vec = np.asarray(vector, dtype=np.float32).reshape(-1)
+        if vec.ndim != 1 or vec.shape[0] != self.dim:
+            raise ValueError(f"Expected vector of dimension {self.dim}, received {vec.shape}")
+        return vec
+
+    # ------------------------------------------------------------------ pickling: host state only
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_lock"] = None
+        state["_workspaces"] = {}
+        state["_projections"] = list(self._projections)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._lock = threading.Lock()
+        self._projections = _ProjectionList(state["_projections"], self)

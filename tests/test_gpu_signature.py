@@ -1,0 +1,218 @@
+"""GPU parity of the signature pass (K1) — every call goes through the C ABI.
+
+Three anchors:
+  (1) the MFMA accumulation is bit-for-bit the fmaf chain of oracle/chain_model.c
+      (projections AND raw keys) — proves the kernel computes what DESIGN.md says;
+  (2) with the host tie-break, keys are byte-identical to the NumPy literal restatement
+      of the reference (oracle/lshrs_oracle.py) on this machine;
+  (3) the committed reference-generated goldens (tests/golden) on rows whose sign
+      margin is far above f32 rounding noise (BLAS summation order differs between CPUs).
+"""
+
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (seed, bands, rows, dim, data_seed) — same list as tests/golden/make_golden.py
+    (42, 16, 4, 128, 101),
+    (42, 16, 16, 768, 102),
+    (7, 16, 32, 1536, 103),
+    (123, 3, 5, 4, 104),
+    (42, 4, 12, 32, 105),
+    (5, 2, 24, 100, 106),
+    (9, 5, 8, 30, 107),
+]
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _hasher(seed, nb, r, dim, **kw):
+    from lshrs_amd import LSHHasher
+
+    return LSHHasher(num_bands=nb, rows_per_band=r, dim=dim, seed=seed, **kw)
+
+
+@pytest.mark.parametrize("seed,nb,r,dim,dseed", SHAPES)
+def test_mfma_projection_is_the_fmaf_chain(torch_mod, seed, nb, r, dim, dseed):
+    from oracle.build import chain_project
+
+    torch = torch_mod
+    h = _hasher(seed, nb, r, dim)
+    x = np.random.default_rng(dseed).standard_normal((300, dim)).astype(np.float32)
+    y_gpu = h.project_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    y_cpu = chain_project(h.projections, x)
+    assert y_gpu.shape == y_cpu.shape
+    assert np.array_equal(y_gpu, y_cpu), f"max |diff| = {np.abs(y_gpu - y_cpu).max()}"
+
+
+@pytest.mark.parametrize("seed,nb,r,dim,dseed", SHAPES)
+def test_raw_keys_equal_chain_model(torch_mod, seed, nb, r, dim, dseed):
+    from oracle.build import chain_hash_packed
+
+    h = _hasher(seed, nb, r, dim, tie_break="none")
+    x = np.random.default_rng(dseed + 1000).standard_normal((777, dim)).astype(np.float32)
+    keys = h.hash_batch_packed(x)
+    assert keys.shape == (777, nb, (r + 7) // 8)
+    assert np.array_equal(keys, chain_hash_packed(h.projections, x))
+
+
+@pytest.mark.parametrize("seed,nb,r,dim,dseed", SHAPES)
+def test_keys_equal_reference_restatement(torch_mod, seed, nb, r, dim, dseed):
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(seed, nb, r, dim)
+    x = np.random.default_rng(dseed + 2000).standard_normal((2048, dim)).astype(np.float32)
+    keys = h.hash_batch_packed(x)
+    assert np.array_equal(keys, hash_batch_literal_packed(h.projections, x))
+
+
+def test_c2_shape_64k_rows_bit_exact_with_ties_exercised(torch_mod):
+    """65 536 x 768, 16x16: ~1.7e7 projections, so tens of them sit inside the tie window."""
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(42, 16, 16, 768)
+    x = np.random.default_rng(20240101).standard_normal((65536, 768)).astype(np.float32)
+    keys = h.hash_batch_packed(x)
+    stats = dict(h.last_stats)
+    ref = hash_batch_literal_packed(h.projections, x)
+    assert np.array_equal(keys, ref)
+    assert stats["tie_pairs"] > 0, "tie window never hit: threshold or flagging broken"
+    assert stats["tie_pairs"] < 65536 * 16 * 1e-3
+    # and the raw kernel differs from the host BLAS in at most a handful of those places
+    raw = h.hash_batch_packed(x, tie_break="none")
+    differing = int((raw != ref).any(axis=2).sum())
+    assert differing <= stats["tie_pairs"]
+
+
+@pytest.mark.parametrize("seed,nb,r,dim,dseed", SHAPES)
+def test_reference_goldens(torch_mod, golden_dir, seed, nb, r, dim, dseed):
+    g = np.load(os.path.join(golden_dir, "g2_signatures.npz"))
+    tag = f"s{seed}_b{nb}_r{r}_d{dim}_x{dseed}"
+    want, margin = g[tag + "_keys"], g[tag + "_minabs"]
+    h = _hasher(seed, nb, r, dim)
+    x = np.random.default_rng(dseed).standard_normal((256, dim)).astype(np.float32)
+    got = h.hash_batch_packed(x)
+    safe = margin >= 1e-3  # rows whose every projection is far from 0: identical on any CPU/GPU
+    assert safe.sum() > 0.5 * len(safe) or dim <= 32
+    assert np.array_equal(got[safe], want[safe])
+    # the remaining rows may only differ inside bands holding a near-zero projection
+    assert (got != want).any(axis=(1, 2)).sum() <= (~safe).sum()
+
+
+def test_special_values_match_reference(torch_mod, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g3_specials.json")))
+    h = _hasher(1, 2, 4, 4)
+    h.projections = [np.array(p, dtype=np.float32) for p in g["projections"]]
+    for case in g["cases"]:
+        x = np.frombuffer(bytes.fromhex(case["x_hex"]), dtype=np.float32)
+        got = [k.hex() for k in h.hash_vector(x)]
+        assert got == case["keys_hex"], case["name"]
+
+
+def test_row_flags_zero_and_nan(torch_mod):
+    from oracle.lshrs_oracle import is_zero_vector_rows
+
+    h = _hasher(3, 4, 8, 64)
+    x = np.random.default_rng(5).standard_normal((600, 64)).astype(np.float32)
+    x[3] = 0.0
+    x[17] = 1e-9
+    x[18] = -1e-8
+    x[19, 5] = 2e-8
+    x[255] = 0.0
+    x[256] = 0.0
+    x[400] = 0.0
+    x[400, 63] = np.nan
+    x[599] = 0.0
+    _, flags = h.hash_batch_packed(x, return_row_flags=True)
+    assert np.array_equal((flags & 1).astype(bool), is_zero_vector_rows(x))
+    assert np.array_equal(np.nonzero(flags & 2)[0], [400])
+
+
+def test_hash_vector_and_batch_api(torch_mod):
+    from lshrs_amd import HashSignatures
+
+    h1, h2 = _hasher(123, 3, 5, 4), _hasher(123, 3, 5, 4)
+    v = np.arange(4, dtype=np.float32)
+    a, b = h1.hash_vector(v), h2.hash_vector(v)
+    assert isinstance(a, HashSignatures) and a.as_tuple() == b.as_tuple() and len(a) == 3
+    assert all(isinstance(k, bytes) and len(k) == 1 for k in a)
+    with pytest.raises(ValueError):
+        h1.hash_vector(np.arange(5, dtype=np.float32))
+    with pytest.raises(ValueError):
+        h1.hash_batch(np.ones((2, 3, 4), dtype=np.float32))
+    with pytest.raises(ValueError):
+        h1.hash_batch(np.ones((2, 5), dtype=np.float32))
+    batch = np.array([[1, 0, -1, 2], [-1, 1, 0, 0.5], [0.5, 0.5, 0.5, 0.5]], dtype=np.float32)
+    sigs = h1.hash_batch(batch)
+    assert len(sigs) == 3 and all(isinstance(s, HashSignatures) for s in sigs)
+    assert [s.as_tuple() for s in sigs] == [h1.hash_vector(r).as_tuple() for r in batch]
+    assert h1.hash_batch(np.empty((0, 4), dtype=np.float32)) == []
+
+
+def test_projection_reassignment_reuploads(torch_mod):
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(42, 4, 4, 32)
+    other = _hasher(7, 4, 4, 32)
+    x = np.random.default_rng(1).standard_normal((100, 32)).astype(np.float32)
+    before = h.hash_batch_packed(x)
+    h.projections = [p.copy() for p in other.projections]
+    after = h.hash_batch_packed(x)
+    assert np.array_equal(after, hash_batch_literal_packed(other.projections, x))
+    assert not np.array_equal(before, after)
+    h.projections[0] = -h.projections[0]
+    assert np.array_equal(h.hash_batch_packed(x), hash_batch_literal_packed(h.projections, x))
+
+
+def test_strided_and_unaligned_inputs(torch_mod):
+    torch = torch_mod
+    from oracle.build import chain_hash_packed
+
+    h = _hasher(11, 8, 16, 96, tie_break="none")
+    base = torch.randn(500, 200, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    view = base[:, 4:100]          # row stride 200, 16-byte aligned start
+    view_odd = base[:, 3:99]       # not 16-byte aligned -> scalar-load kernel variant
+    for v in (view, view_odd):
+        got = h.hash_device(v).cpu().numpy()
+        assert np.array_equal(got, chain_hash_packed(h.projections, v.cpu().numpy()))
+
+
+def test_full_size_properties_1m_rows(torch_mod):
+    """BASELINE config 2 size (1M x 768, 256 bits): size-independent properties."""
+    torch = torch_mod
+    h = _hasher(42, 16, 16, 768, tie_break="none")
+    gen = torch.Generator("cuda").manual_seed(2024)
+    x = torch.randn(1_000_000, 768, device="cuda", generator=gen)
+    k1 = h.hash_device(x)
+    assert torch.equal(k1, h.hash_device(x)), "not deterministic"
+    # scaling by a power of two is exact in binary floating point: every sign is unchanged
+    assert torch.equal(k1, h.hash_device(x * 4.0))
+    # rows are independent: hashing a permutation == permuting the hashes; chunking changes nothing
+    perm = torch.randperm(1_000_000, device="cuda", generator=gen)
+    assert torch.equal(h.hash_device(x[perm]), k1[perm])
+    assert torch.equal(h.hash_device(x[123_457:654_321]), k1[123_457:654_321])
+    # negation flips every bit whose projection is non-zero
+    kneg = h.hash_device(-x)
+    assert (kneg ^ k1).eq(0xFF).float().mean().item() > 0.999999
+    # balanced hyperplanes: about half the bits are set
+    ones = torch.tensor([bin(i).count("1") for i in range(256)], device="cuda")[k1.long()].sum().item()
+    assert abs(ones / (1_000_000 * 256) - 0.5) < 1e-3
+    # bit-exact against the CPU on a slice, through the tie-break path
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    hb = _hasher(42, 16, 16, 768)
+    sl = x[500_000:504_096]
+    assert np.array_equal(hb.hash_device(sl).cpu().numpy(),
+                          hash_batch_literal_packed(hb.projections, sl.cpu().numpy()))
