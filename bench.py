@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the lshrs hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): vectors/sec hashed at dim=768, num_perm=256.  One *step* = one pass of
+the signature path over one resident batch: every rank hashes ROWS_PER_GPU (default 1 000 000,
+BASELINE config 2) synthetic N(0,1) float32 vectors already in its HBM into (rows, 16, 2) uint8
+band keys in HBM, **including the tie-break that makes the keys byte-identical to the reference**
+(the raw-kernel rate is reported next to it).  Ranks share nothing (replicated hyperplanes, no
+collective in the data path): weak scaling.  Rank 0 prints ONE JSON line.
+
+Also in the line:
+  roofline      the signature kernel alone: algorithmic FLOPs per launch / mean launch duration,
+                measured with HIP events on the launch stream inside the timed region, against
+                the dense f32 MFMA peak (the op is a dense contraction in exact f32);
+  cpu_baseline  the oracle's literal restatement of the reference (per vector, per band NumPy
+                calls, one thread) timed on this host on a bounded prefix of the same workload;
+  rerank        BASELINE's second metric (cosine-rerank candidates/s: 1M x 768 corpus,
+                10k queries x 1k candidates, config 3), N=1 only, with its HBM roofline.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DIM, NUM_PERM, BANDS, ROWS = 768, 256, 16, 16
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (spec); 155 measured
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=150_000, help="rows of the workload the CPU baseline hashes")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rerank", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the (untimed) parity check against the oracle")
+    return ap.parse_args()
+
+
+def main() -> None:
+    args = parse()
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from lshrs_amd import LSHHasher
+
+    n = args.rows_per_gpu
+    hasher = LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_rank)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    x = torch.randn(n, DIM, device=dev, generator=gen)           # resident in HBM before timing starts
+    keys = torch.empty((n, BANDS, hasher.band_bytes), dtype=torch.uint8, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        hasher.hash_device(x, out=keys)
+
+    for _ in range(args.warmup):
+        step()
+    hasher.kernel_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events, hasher.kernel_events = hasher.kernel_events, None
+    stats = dict(hasher.last_stats)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    kernel_ms_mean = sum(kernel_ms) / max(1, len(kernel_ms))
+
+    # raw-kernel-only pass of the same workload (not the headline value; reported beside it)
+    raw_ms = None
+    if rank == 0:
+        ev = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            hasher.hash_device(x, out=keys, tie_break="none")
+            b.record()
+            ev.append((a, b))
+        torch.cuda.synchronize(dev)
+        raw_ms = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+
+    result = None
+    if rank == 0:
+        total_rows = n * world
+        flops_per_launch = 2.0 * DIM * NUM_PERM * n
+        bytes_per_launch = (4.0 * DIM + NUM_PERM / 8) * n
+        achieved_tflops = flops_per_launch / (kernel_ms_mean * 1e-3) / 1e12
+        result = {
+            "metric": "vectors/sec hashed (768-d, num_perm=256)",
+            "value": total_rows * args.steps / elapsed,
+            "unit": "vectors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config 2 per GPU: 1M x 768-d f32 N(0,1) vectors, num_perm=256 (16 bands x 16 rows), "
+                            "HBM-resident in and out, keys byte-identical to the reference (tie-break included)",
+                "rows_per_gpu": n, "dim": DIM, "num_perm": NUM_PERM, "num_bands": BANDS, "rows_per_band": ROWS,
+                "total_rows": total_rows, "sharding": f"row-sharded x{world}, replicated hyperplanes, no collective",
+                "tie_break": hasher.tie_break, "tau_ulps": hasher.tau_ulps,
+            },
+            "roofline": {
+                "kernel": "sig_kernel<8,true,false>",
+                "bound": "mfma",
+                "achieved": achieved_tflops,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None,
+                "kernel_ms_mean": kernel_ms_mean,
+                "launches_timed": len(kernel_ms),
+                "flops_per_launch": flops_per_launch,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "hbm_GBps_algorithmic": bytes_per_launch / (kernel_ms_mean * 1e-3) / 1e9,
+                "hbm_frac_of_8TBps": bytes_per_launch / (kernel_ms_mean * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            },
+            "kernel_only": {"ms_per_launch_median": raw_ms, "vectors_per_s": n / (raw_ms * 1e-3) if raw_ms else None},
+            "tie_break_stats_last_step": stats,
+        }
+
+    # ---------------- untimed parity check of what was just measured ----------------
+    if rank == 0 and not args.no_check:
+        from oracle.lshrs_oracle import hash_batch_literal_packed
+
+        hasher.hash_device(x, out=keys)
+        sl = slice(0, 4096)
+        want = hash_batch_literal_packed(hasher.projections, x[sl].cpu().numpy())
+        ok = bool(np.array_equal(keys[sl].cpu().numpy(), want))
+        result["parity_check"] = {"rows": 4096, "bit_exact_vs_oracle": ok}
+        if not ok:
+            raise SystemExit("bench: keys differ from the oracle — result invalid")
+
+    # ---------------- CPU baseline (rank 0, N=1 only) ----------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.lshrs_oracle import hash_batch_literal_packed
+
+        m = min(n, args.cpu_sample_rows)
+        xs = x[:m].cpu().numpy()
+        hash_batch_literal_packed(hasher.projections, xs[:2000])  # warm BLAS
+        t0 = time.perf_counter()
+        hash_batch_literal_packed(hasher.projections, xs)
+        dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": m / dt, "unit": "vectors/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} rows of the same 1M x 768 workload, reference-literal per-vector/per-band NumPy "
+                      f"calls ({dt:.1f} s), host cpu_count={os.cpu_count()}",
+        }
+        result["speedup_vs_cpu_baseline"] = result["value"] / (m / dt)
+
+    # ---------------- second metric: cosine rerank (config 3), N=1 only ----------------
+    if rank == 0 and world == 1 and not args.no_rerank:
+        result["rerank"] = bench_rerank(torch, dev, x, np, not args.no_cpu_baseline)
+
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def bench_rerank(torch, dev, corpus, np, with_cpu: bool):
+    """BASELINE config 3: corpus = the 1M x 768 vectors resident on the device, 10k queries x 1k candidates."""
+    from lshrs_amd.similarity import cosine_scores_device, topk_desc_device
+
+    gen = torch.Generator(device=dev).manual_seed(7)
+    m = corpus.shape[0]
+    q, c = 10_000, 1_000
+    qrows = torch.randperm(m, device=dev, generator=gen)[:q]
+    queries = corpus[qrows] + 0.1 * torch.randn(q, DIM, device=dev, generator=gen)
+    cidx = torch.randint(0, m, (q, c), device=dev, generator=gen)
+
+    def one():
+        scores, status, qstatus = cosine_scores_device(corpus, queries, cidx)
+        return topk_desc_device(scores, c)
+
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize(dev)
+    reps = 5
+    ev_total, ev_cos = [], []
+    for _ in range(reps):
+        a, b, e = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        a.record()
+        scores, status, qstatus = cosine_scores_device(corpus, queries, cidx)
+        b.record()
+        topk_desc_device(scores, c)
+        e.record()
+        ev_total.append((a, e))
+        ev_cos.append((a, b))
+    torch.cuda.synchronize(dev)
+    total_ms = sorted(a.elapsed_time(b) for a, b in ev_total)[reps // 2]
+    cos_ms = sorted(a.elapsed_time(b) for a, b in ev_cos)[reps // 2]
+    bytes_per_launch = (4.0 * DIM + 8 + 4) * q * c
+    out = {
+        "metric": "cosine-rerank candidates/sec (1M x 768 corpus, 10k queries x 1k candidates, k=1000)",
+        "value": q * c / (total_ms * 1e-3), "unit": "candidates/s", "ms_per_pass": total_ms,
+        "roofline": {
+            "kernel": "cosine_kernel<true>", "bound": "hbm", "achieved": bytes_per_launch / (cos_ms * 1e-3) / 1e9,
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / (cos_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "traffic": None, "kernel_ms": cos_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+        },
+        "topk_ms": total_ms - cos_ms,
+    }
+    if with_cpu:
+        from oracle.lshrs_oracle import top_k_cosine
+
+        nq = 100
+        qh = queries[:nq].cpu().numpy()
+        ch = [corpus[cidx[i]].cpu().numpy() for i in range(nq)]
+        t0 = time.perf_counter()
+        for i in range(nq):
+            top_k_cosine(qh[i], ch[i], k=c)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nq * c / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
+                               "sample": f"{nq} of the 10k queries x 1k candidates, reference-literal top_k_cosine ({dt:.1f} s)"}
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -58,9 +58,10 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
  *   The dot product is evaluated on v_mfma_f32_32x32x2_f32 as a single-rounded fmaf chain
  *   in the k-order documented in DESIGN.md; it can differ from the host BLAS's sgemv only
  *   where |y| is within rounding noise of 0.  Those places are reported, not hidden:
- *   tie_list   optional (may be NULL): int64[tie_cap]; entry = row*65536 + w means that some
- *              projection of `row` among padded columns [32w, 32w+32) has
- *              |y| <= tau * ||x_row|| * ||p_j||.   Order of entries is unspecified.
+ *   tie_list   optional (may be NULL): int64[2 * tie_cap]; entry e = (tie_list[2e], tie_list[2e+1]) =
+ *              (row*65536 + w, mask): bit c of the 32-bit mask is set when the projection of `row`
+ *              on padded column 32w + c has |y| < tau * ||x_row|| * ||p_j||.  Entry order is
+ *              unspecified.
  *   tie_count  int32[1] (required iff tie_list != NULL); must be zeroed by the caller before
  *              the call; receives the number of entries the kernel WANTED to write — if it
  *              exceeds tie_cap the list is truncated and the caller must retry with room.
@@ -114,6 +115,12 @@ int lshrs_cosine_batch_f32(const float* corpus, int64_t m, int64_t ldc, int32_t 
                            const float* queries, int32_t q,
                            const int64_t* cand_idx, int32_t c,
                            float* scores, uint8_t* status, uint8_t* qstatus, void* stream);
+
+/* out[i] = X[i] / ||X[i]||_2 (float32) — the reference's l2_norm (lshrs/utils/norm.py:48-61) for n rows
+ * at once.  status (n,) u8, optional: 1 where the norm is 0 (the reference raises "Cannot normalize
+ * zero vector"; the row of `out` is then NaN/Inf and must not be used). */
+int lshrs_l2_normalize_f32(const float* X, int64_t n, int64_t ldx, int32_t dim, float* out, uint8_t* status,
+                           void* stream);
 
 /* Per-query descending order — replaces argpartition + argsort (similarity.py:174-179).
  *   scores (q, c) f32 -> order (q, k) int32 positions, sorted (q, k) f32, k <= c.

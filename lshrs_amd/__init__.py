@@ -11,7 +11,15 @@ compute call raises ``lshrs_amd._native.NativeLibraryError``.
 """
 
 from ._config import HashSignatures
+from ._native import NativeLibraryError
+from .bandrows import get_optimal_config
+from .core import LSHRS, lshrs
 from .hasher import LSHHasher
+from .similarity import cosine_similarity, l2_norm, rerank_batch, top_k_cosine
+from .storage import BucketOperation, InMemoryStorage
 
-__all__ = ["HashSignatures", "LSHHasher"]
+__all__ = [
+    "LSHRS", "lshrs", "LSHHasher", "HashSignatures", "top_k_cosine", "cosine_similarity", "l2_norm",
+    "rerank_batch", "get_optimal_config", "InMemoryStorage", "BucketOperation", "NativeLibraryError",
+]
 __version__ = "0.1.0"

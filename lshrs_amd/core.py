@@ -1,0 +1,327 @@
+"""``LSHRS`` — the caller side of the hot path, batched for the GPU.
+
+Thin counterpart of the reference orchestrator (lshrs/core/main.py) for exactly the
+methods that reach the accelerated path: constructor, ``ingest`` / ``index`` /
+``create_signatures`` / ``flush`` (signature pass) and ``query`` / ``get_top_k`` /
+``get_above_p`` (signature pass + cosine rerank), plus the trivial storage pass-throughs.
+Same keyword arguments, return types, error types and messages; storage (Redis) and the
+loaders (PostgreSQL / Parquet) are the reference's own components and are not re-implemented.
+
+What is different on purpose: ``index()`` hashes a whole loader batch in ONE kernel launch
+instead of looping ``ingest()`` per vector (lshrs/core/main.py:514-515), while reproducing
+what that loop lets a caller observe —
+  * operations are enqueued vector-major, band-minor (main.py:1125-1128);
+  * the buffer is flushed, whole, at the first vector boundary where it holds at least
+    ``buffer_size`` operations (main.py:1131-1143), and once more at the end (main.py:518);
+  * a bad row (negative id, zero vector) raises the same ``ValueError`` after every earlier row
+    was enqueued (and possibly flushed), and the trailing flush is then not reached.
+tests/golden/g5_orchestration.json holds the reference's own batches for these cases.
+"""
+
+from __future__ import annotations
+
+import logging
+import math
+from threading import Lock
+from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from .bandrows import get_optimal_config
+from .hasher import LSHHasher
+from .similarity import top_k_cosine
+from .storage import BucketOperation, default_storage
+
+logger = logging.getLogger(__name__)
+
+VectorFetchFn = Callable[[Sequence[int]], np.ndarray]
+Loader = Callable[..., Iterator[Tuple[Sequence[int], np.ndarray]]]
+
+__all__ = ["LSHRS", "lshrs"]
+
+_ZERO_MSG = "Cannot index zero vector - norm undefined. Check embeddings for corruption."
+
+
+class LSHRS:
+    """Redis-backed LSH index whose hashing and reranking run on MI355X.
+
+    Keyword arguments are those of the reference constructor (lshrs/core/main.py:154-173).
+    Extras: ``hasher`` (inject a ready hasher object; default builds ``LSHHasher``) and
+    ``device`` (GPU index for the default hasher).
+    """
+
+    def __init__(
+        self,
+        *,
+        dim: int,
+        num_perm: int = 128,
+        num_bands: Optional[int] = None,
+        rows_per_band: Optional[int] = None,
+        similarity_threshold: float = 0.5,
+        buffer_size: int = 10_000,
+        vector_fetch_fn: Optional[VectorFetchFn] = None,
+        storage: Any = None,
+        redis_host: str = "localhost",
+        redis_port: int = 6379,
+        redis_db: int = 0,
+        redis_password: Optional[str] = None,
+        redis_prefix: str = "lsh",
+        redis_max_connections: int = 50,
+        decode_responses: bool = False,
+        seed: int = 42,
+        hasher: Any = None,
+        device: Any = None,
+    ) -> None:
+        if dim <= 0:
+            raise ValueError("Vector dimensionality must be greater than zero")
+        if num_perm <= 0:
+            raise ValueError("num_perm must be greater than zero")
+        if buffer_size <= 0:
+            raise ValueError("buffer_size must be greater than zero")
+
+        if num_bands is None or rows_per_band is None:
+            num_bands, rows_per_band = get_optimal_config(num_perm, similarity_threshold)
+        if num_bands is None or rows_per_band is None:  # pragma: no cover - defensive, as the reference
+            raise RuntimeError(
+                f"Auto-config failed: get_optimal_config({num_perm}, {similarity_threshold}) "
+                f"-> ({num_bands}, {rows_per_band})")
+        if num_bands * rows_per_band != num_perm:
+            raise ValueError(
+                f"num_bands * rows_per_band must equal num_perm (received {num_bands} * {rows_per_band} != {num_perm})")
+
+        self._dim = dim
+        self._buffer_size = buffer_size
+        self._vector_fetch_fn = vector_fetch_fn
+        self._hasher = hasher if hasher is not None else LSHHasher(
+            num_bands=num_bands, rows_per_band=rows_per_band, dim=dim, seed=seed, device=device)
+        self._storage = storage if storage is not None else default_storage(
+            host=redis_host, port=redis_port, db=redis_db, password=redis_password,
+            decode_responses=decode_responses, prefix=redis_prefix, max_connections=redis_max_connections)
+        self._buffer: List[BucketOperation] = []
+        self._buffer_lock = Lock()
+        self._config: Dict[str, Any] = {
+            "dim": dim, "num_perm": num_perm, "num_bands": num_bands, "rows_per_band": rows_per_band,
+            "similarity_threshold": similarity_threshold, "buffer_size": buffer_size, "seed": seed,
+        }
+        self._redis_config: Dict[str, Any] = {
+            "host": redis_host, "port": redis_port, "db": redis_db, "password": redis_password,
+            "prefix": redis_prefix, "decode_responses": decode_responses, "max_connections": redis_max_connections,
+        }
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self) -> None:
+        self.flush()
+        self._storage.close()
+
+    def __enter__(self) -> "LSHRS":
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback) -> None:
+        self.close()
+
+    # ------------------------------------------------------------------ ingestion
+    def create_signatures(self, format: str = "postgres", **loader_kwargs: Any) -> None:
+        """Stream ``(indices, vectors)`` batches from a loader and index each with one launch
+        (reference: main.py:315-384).  ``format`` is "postgres"/"pg", "parquet"/"pq" (the reference's
+        loaders, when that package is importable) or "batches" with ``batches=<iterable>``."""
+        loader = self._resolve_loader(format)
+        for indices, vectors in loader(**loader_kwargs):
+            self.index(indices, vectors)
+
+    def ingest(self, index: int, vector) -> None:
+        """Hash one vector and buffer its bucket operations (reference: main.py:386-411)."""
+        if index < 0:
+            raise ValueError("index must be non-negative")
+        arr = self._check_dim(vector)
+        keys, flags = self._hasher.hash_batch_packed(arr.reshape(1, -1), return_row_flags=True)
+        if flags[0] & 1:
+            raise ValueError(_ZERO_MSG)
+        self._enqueue_packed(int(index), keys[0])
+        self._flush_buffer_if_needed()
+
+    def index(self, indices: Sequence[int], vectors: Optional[np.ndarray] = None) -> None:
+        """Index a batch: one signature-pass launch, then the reference's enqueue/flush sequence
+        (reference: main.py:442-518)."""
+        if len(indices) == 0:
+            return
+        if vectors is None:
+            vectors = self._require_vector_fetch_fn()(indices)
+        arr = np.asarray(vectors, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[1] != self._dim:
+            raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")
+        if arr.shape[0] != len(indices):
+            raise ValueError(
+                "Number of vectors does not match number of indices "
+                f"(received {arr.shape[0]} vectors for {len(indices)} indices)")
+
+        ids = [int(i) for i in indices]
+        keys, flags = self._hasher.hash_batch_packed(arr, return_row_flags=True)
+
+        # first row the per-vector loop of the reference would have choked on, and why
+        stop, error = len(ids), None
+        neg = next((j for j, i in enumerate(ids) if i < 0), None)
+        zero_rows = np.flatnonzero(flags & 1)
+        zero = int(zero_rows[0]) if zero_rows.size else None
+        if neg is not None and (zero is None or neg <= zero):
+            stop, error = neg, ValueError("index must be non-negative")
+        elif zero is not None:
+            stop, error = zero, ValueError(_ZERO_MSG)
+
+        nb = keys.shape[1]
+        bb = keys.shape[2]
+        blob = keys[:stop].tobytes()
+        stride = nb * bb
+        for j in range(stop):
+            base = j * stride
+            idx = ids[j]
+            ops = [(b, blob[base + b * bb: base + (b + 1) * bb], idx) for b in range(nb)]
+            with self._buffer_lock:
+                self._buffer.extend(ops)
+                full = len(self._buffer) >= self._buffer_size
+            if full:
+                self.flush()
+        if error is not None:
+            raise error
+        self.flush()
+
+    def flush(self) -> None:
+        """Send every buffered operation in one ``batch_add``; on failure put them back in front
+        and re-raise (reference: main.py:413-440)."""
+        with self._buffer_lock:
+            if not self._buffer:
+                return
+            pending = self._buffer
+            self._buffer = []
+        try:
+            self._storage.batch_add(pending)
+        except Exception as exc:
+            logger.error(f"Failed to flush buffer to Redis: {exc}")
+            with self._buffer_lock:
+                self._buffer[0:0] = pending
+            raise
+
+    # ------------------------------------------------------------------ queries
+    def query(self, vector, *, top_k: Optional[int] = 10, top_p: Optional[float] = None
+              ) -> Union[List[int], List[Tuple[int, float]]]:
+        """Band-collision candidates, optionally reranked by cosine (reference: main.py:524-658)."""
+        query_vector = self._check_dim(vector)
+        keys, flags = self._hasher.hash_batch_packed(query_vector.reshape(1, -1), return_row_flags=True)
+        if flags[0] & 1:
+            raise ValueError(_ZERO_MSG)
+        counts = self._candidate_counts_from_keys(keys[0])
+        if not counts:
+            return []
+        ordered = sorted(counts.items(), key=lambda item: (-item[1], item[0]))
+
+        if top_p is None:
+            if top_k is None:
+                top_k = len(ordered)
+            if top_k <= 0:
+                raise ValueError("top_k must be greater than zero when provided")
+            return [idx for idx, _ in ordered[:top_k]]
+
+        if not 0 < top_p <= 1:
+            raise ValueError("top_p must be within the range (0, 1]")
+        candidate_indices = [idx for idx, _ in ordered]
+        fetched = self._require_vector_fetch_fn()(candidate_indices)
+        arr = np.asarray(fetched, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[1] != self._dim:
+            raise ValueError(f"Fetched vectors must have shape (n, {self._dim}); received {arr.shape}")
+        if arr.shape[0] != len(candidate_indices):
+            raise ValueError(
+                "vector_fetch_fn returned mismatched batch size "
+                f"(expected {len(candidate_indices)}, received {arr.shape[0]})")
+
+        ranked = top_k_cosine(query_vector, arr, k=len(candidate_indices))
+        scored = [(candidate_indices[pos], score) for pos, score in ranked]
+        limit = max(1, math.ceil(len(scored) * top_p))
+        if top_k is not None:
+            if top_k <= 0:
+                raise ValueError("top_k must be greater than zero when provided")
+            limit = min(limit, top_k)
+        return scored[:limit]
+
+    def get_top_k(self, vector, topk: int = 10) -> List[int]:
+        return list(self.query(vector, top_k=topk, top_p=None))  # type: ignore[arg-type]
+
+    def get_above_p(self, vector, p: float = 0.95) -> List[Tuple[int, float]]:
+        return list(self.query(vector, top_k=None, top_p=p))  # type: ignore[arg-type]
+
+    # ------------------------------------------------------------------ storage pass-throughs
+    def delete(self, indices: Union[int, Sequence[int]]) -> None:
+        """Remove ids from every bucket (reference: main.py:744-784)."""
+        if isinstance(indices, (int, np.integer)):
+            ids = [int(indices)]
+        else:
+            ids = [int(i) for i in indices]
+        if not ids:
+            return
+        self.flush()
+        self._storage.remove_indices(ids)
+
+    def clear(self) -> None:
+        """Drop buffered operations and every bucket (reference: main.py:786-796)."""
+        with self._buffer_lock:
+            self._buffer = []
+        self._storage.clear()
+
+    def stats(self) -> Dict[str, Any]:
+        """Static configuration summary (reference: main.py:798-840)."""
+        cfg = self._config
+        return {
+            "dimension": cfg["dim"], "num_perm": cfg["num_perm"], "num_bands": cfg["num_bands"],
+            "rows_per_band": cfg["rows_per_band"], "buffer_size": cfg["buffer_size"],
+            "similarity_threshold": cfg["similarity_threshold"], "redis_prefix": self._redis_config["prefix"],
+        }
+
+    # ------------------------------------------------------------------ helpers
+    def _check_dim(self, vector) -> np.ndarray:
+        """float32, flattened, right length (reference: main.py:1075-1080; the near-zero test of
+        :1083 is evaluated by the kernel's row flag, see ``_ZERO_MSG`` call sites)."""
+        arr = np.asarray(vector, dtype=np.float32).reshape(-1)
+        if arr.shape[0] != self._dim:
+            raise ValueError(f"Vector must have dimension {self._dim}; received {arr.shape[0]}")
+        return arr
+
+    def _candidate_counts_from_keys(self, band_keys: np.ndarray) -> Dict[int, int]:
+        """Collision count per stored id over the query's band buckets (reference: main.py:1088-1111)."""
+        counts: Dict[int, int] = {}
+        for band_id in range(band_keys.shape[0]):
+            for candidate in self._storage.get_bucket(band_id, band_keys[band_id].tobytes()):
+                counts[candidate] = counts.get(candidate, 0) + 1
+        return counts
+
+    def _enqueue_packed(self, index: int, band_keys: np.ndarray) -> None:
+        ops = [(b, band_keys[b].tobytes(), index) for b in range(band_keys.shape[0])]
+        with self._buffer_lock:
+            self._buffer.extend(ops)
+
+    def _flush_buffer_if_needed(self) -> None:
+        with self._buffer_lock:
+            full = len(self._buffer) >= self._buffer_size
+        if full:
+            self.flush()
+
+    def _require_vector_fetch_fn(self) -> VectorFetchFn:
+        if self._vector_fetch_fn is None:
+            raise RuntimeError("vector_fetch_fn must be supplied for operations requiring reranking")
+        return self._vector_fetch_fn
+
+    def _resolve_loader(self, format: str) -> Loader:
+        """Loader lookup (reference: main.py:1159-1196).  The PostgreSQL / Parquet readers are the
+        reference's own modules (I/O is out of scope here) and are imported from that package."""
+        normalized = format.lower()
+        if normalized in {"batches", "iter", "iterable"}:
+            def _from_iterable(batches: Iterable[Tuple[Sequence[int], np.ndarray]]):
+                yield from batches
+            return _from_iterable
+        if normalized in {"postgres", "pg"}:
+            from lshrs.io.postgres import iter_postgres_vectors  # reference component
+            return iter_postgres_vectors
+        if normalized in {"parquet", "pq"}:
+            from lshrs.io.parquet import iter_parquet_vectors  # reference component
+            return iter_parquet_vectors
+        raise ValueError(f"Unsupported signature creation format '{format}'")
+
+
+lshrs = LSHRS  # lower-case alias kept by the reference (lshrs/core/main.py, last line)

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kThreads, 2) void sig_kernel(const SigArgs args) {
       kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)(pos >> 32), lane, l1);
       if (want_ties) {
         const float thr = rn[r >> 2][r & 3] * pn;
-        const uint64_t tie = __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) <= thr);
+        const uint64_t tie = __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < thr);  // strict: thr == 0 (zero x, padded column) never ties
         tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)tie, lane, l0);
         tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)(tie >> 32), lane, l1);
       }
@@ -315,7 +315,10 @@ __global__ __launch_bounds__(kThreads, 2) void sig_kernel(const SigArgs args) {
       for (int w = 0; w < WPL; ++w) {
         if (tw[w] != 0u) {
           const int slot = atomicAdd(args.tie_count, 1);
-          if (slot < args.tie_cap) args.tie_list[slot] = grow * 65536 + (word0 + w);
+          if (slot < args.tie_cap) {
+            args.tie_list[2 * (int64_t)slot] = grow * 65536 + (word0 + w);
+            args.tie_list[2 * (int64_t)slot + 1] = (int64_t)tw[w];
+          }
         }
       }
     }
@@ -485,6 +488,25 @@ __global__ __launch_bounds__(kCosThreads) void cosine_kernel(const float* __rest
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// l2_norm: out = x / ||x||, one workgroup per row (reference helper lshrs/utils/norm.py:48-61)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ X, int64_t ldx, int dim,
+                                                           float* __restrict__ out, uint8_t* __restrict__ status) {
+  __shared__ float part[4];
+  const int64_t row = blockIdx.x;
+  const float* x = X + row * ldx;
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < dim; k += 256) ss = __builtin_fmaf(x[k], x[k], ss);
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float norm = sqrtf(part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0 && status != nullptr) status[row] = (norm == 0.f) ? 1 : 0;
+  float* o = out + row * (int64_t)dim;
+  for (int k = threadIdx.x; k < dim; k += 256) o[k] = x[k] / norm;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -679,6 +701,16 @@ int lshrs_cosine_batch_f32(const float* corpus, int64_t m, int64_t ldc, int32_t 
   return -(int)hipGetLastError();
 }
 
+int lshrs_l2_normalize_f32(const float* X, int64_t n, int64_t ldx, int32_t dim, float* out, uint8_t* status,
+                           void* stream) {
+  if (n == 0) return 0;
+  if (X == nullptr || out == nullptr || n < 0 || dim <= 0 || ldx < dim) return LSHRS_E_BADARG;
+  if (n > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx,
+                     dim, out, status);
+  return -(int)hipGetLastError();
+}
+
 int lshrs_topk_desc_f32(const float* scores, int32_t q, int32_t c, int32_t k, int32_t* order, float* sorted,
                         void* stream) {
   if (q == 0 || k == 0) return 0;
@@ -688,6 +720,11 @@ int lshrs_topk_desc_f32(const float* scores, int32_t q, int32_t c, int32_t k, in
   int cpad = 2;
   while (cpad < c) cpad <<= 1;
   const size_t shmem = (size_t)cpad * sizeof(uint64_t);
+  if (shmem > 48 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return -(int)e;
+  }
   hipLaunchKernelGGL(topk_kernel, dim3((unsigned)q), dim3(kTopkThreads), shmem, static_cast<hipStream_t>(stream),
                      scores, c, cpad, k, order, sorted);
   return -(int)hipGetLastError();

@@ -103,6 +103,9 @@ class LSHHasher:
         self._projection_version = 0
         self._workspaces: Dict[int, Tuple[int, object]] = {}
         self.last_stats: Dict[str, int] = {}
+        # set to a list to collect (start, end) torch.cuda.Event pairs around every signature-kernel
+        # launch (bench.py uses it to time the kernel on the stream it runs on)
+        self.kernel_events: Optional[list] = None
         # hyperplanes: one generator, num_bands float64 draws cast to float32 (lsh.py:93-94)
         gen = np.random.default_rng(seed)
         planes = [gen.standard_normal((self.rows_per_band, self.dim)).astype(np.float32)
@@ -211,21 +214,16 @@ class LSHHasher:
             stream = torch.cuda.current_stream(dev).cuda_stream
             flags_ptr = row_flags.data_ptr() if row_flags is not None else None
             if mode == "none":
-                _native.check(
-                    lib.lshrs_sig_hash_batch_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
-                                                 self.rows_per_band, self.dim, out.data_ptr(), None, 0, None, 0.0,
-                                                 flags_ptr, stream),
-                    "lshrs_sig_hash_batch_f32")
+                self._launch_sig(torch, lib, dev, x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                 self.rows_per_band, self.dim, out.data_ptr(), None, 0, None, 0.0, flags_ptr, stream)
                 return out
-            cap = min(max(4096, n // 16 + 4096), 2 ** 31 - 1)
+            cap = min(max(4096, n // 16 + 4096), 2 ** 30)
             while True:
-                tie_list = torch.empty(cap, dtype=torch.int64, device=dev)
+                tie_list = torch.empty((cap, 2), dtype=torch.int64, device=dev)
                 tie_count = torch.zeros(1, dtype=torch.int32, device=dev)
-                _native.check(
-                    lib.lshrs_sig_hash_batch_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
-                                                 self.rows_per_band, self.dim, out.data_ptr(), tie_list.data_ptr(),
-                                                 cap, tie_count.data_ptr(), tau, flags_ptr, stream),
-                    "lshrs_sig_hash_batch_f32")
+                self._launch_sig(torch, lib, dev, x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                 self.rows_per_band, self.dim, out.data_ptr(), tie_list.data_ptr(), cap,
+                                 tie_count.data_ptr(), tau, flags_ptr, stream)
                 cnt = int(tie_count.item())  # synchronises the stream
                 if cnt <= cap:
                     break
@@ -258,31 +256,63 @@ class LSHHasher:
                 torch.cuda.current_stream(dev).synchronize()  # the small staging tensors die with this frame
         return out
 
+    def _launch_sig(self, torch, lib, dev, *args) -> None:
+        events = self.kernel_events
+        if events is None:
+            _native.check(lib.lshrs_sig_hash_batch_f32(*args), "lshrs_sig_hash_batch_f32")
+            return
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cur = torch.cuda.current_stream(dev)
+        start.record(cur)
+        _native.check(lib.lshrs_sig_hash_batch_f32(*args), "lshrs_sig_hash_batch_f32")
+        end.record(cur)
+        events.append((start, end))
+
     def _tie_pairs(self, entries: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-        """Kernel tie entries (row*65536 + 32-column word) -> unique (row, band) pairs."""
-        rows = entries >> 16
-        words = entries & 0xFFFF
+        """Kernel tie entries ``(row*65536 + word, 32-bit column mask)`` -> unique (row, band) pairs,
+        sorted by (band, row)."""
+        rows = entries[:, 0] >> 16
+        words = entries[:, 0] & 0xFFFF
+        masks = entries[:, 1].astype(np.uint64)
         band_cols = 8 * self.band_bytes
-        first = (32 * words) // band_cols
-        last = np.minimum((32 * words + 31) // band_cols, self.num_bands - 1)
-        keep = first < self.num_bands
-        rows, first, last = rows[keep], first[keep], last[keep]
-        span = int((last - first).max()) + 1 if rows.size else 0
         codes = []
-        for d in range(span):
-            sel = first + d <= last
-            codes.append(rows[sel] * self.num_bands + first[sel] + d)
+        if band_cols % 32 == 0:
+            # a 32-column word lies inside one band; otherwise (8, 16, 24, 40 ... columns per band)
+            # look at the mask bit by bit
+            band = (32 * words) // band_cols
+            keep = band < self.num_bands
+            codes.append(band[keep] * (1 << 48) + rows[keep])
+        else:
+            for c in range(32):
+                hit = ((masks >> np.uint64(c)) & np.uint64(1)).astype(bool)
+                if not hit.any():
+                    continue
+                band = (32 * words[hit] + c) // band_cols
+                keep = band < self.num_bands
+                codes.append(band[keep] * (1 << 48) + rows[hit][keep])
         code = np.unique(np.concatenate(codes)) if codes else np.empty(0, dtype=np.int64)
-        return (code // self.num_bands).astype(np.int64), (code % self.num_bands).astype(np.int32)
+        return (code & ((1 << 48) - 1)).astype(np.int64), (code >> 48).astype(np.int32)
 
     def _tie_patches(self, xrows: np.ndarray, inverse: np.ndarray, bands: np.ndarray) -> np.ndarray:
-        """Band keys of the flagged pairs, by the reference's own expression
-        (``projection @ vector``, ``> 0``, ``np.packbits(..., bitorder='little')``: lsh.py:200-208)."""
+        """Band keys of the flagged (row, band) pairs by the reference's own expression
+        (``projection @ vector``, ``> 0``, ``np.packbits(..., bitorder='little')``: lsh.py:200-208).
+
+        ``np.matmul(P_band, X[:, :, None])`` runs NumPy's matrix @ vector inner loop once per row, i.e.
+        it issues the very ``cblas_sgemv`` call ``P_band @ x`` issues (same operands, same shapes, same
+        library) without a Python-level loop; tests/test_tiebreak_host.py checks the two bit for bit.
+        ``bands`` arrives sorted, so each band is one contiguous slice.
+        """
         planes = self._projections
         patch = np.empty((bands.shape[0], self.band_bytes), dtype=np.uint8)
-        for t in range(bands.shape[0]):
-            y = planes[int(bands[t])] @ xrows[inverse[t]]
-            patch[t] = np.packbits((y > 0).astype(np.uint8), bitorder="little")
+        if bands.shape[0] == 0:
+            return patch
+        starts = np.flatnonzero(np.r_[True, bands[1:] != bands[:-1]])
+        stops = np.r_[starts[1:], bands.shape[0]]
+        for lo, hi in zip(starts, stops):
+            plane = np.ascontiguousarray(planes[int(bands[lo])], dtype=np.float32)
+            xs = np.ascontiguousarray(xrows[inverse[lo:hi]])
+            y = np.matmul(plane, xs[:, :, None])[:, :, 0]
+            patch[lo:hi] = np.packbits(y > 0, axis=1, bitorder="little")
         return patch
 
     # ------------------------------------------------------------------ host-facing API

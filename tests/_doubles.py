@@ -1,0 +1,40 @@
+"""Test doubles: an oracle-backed hasher with the interface ``LSHRS`` consumes.
+
+Lives under tests/ on purpose — the product package never imports the oracle.  CPU-only tests use
+it to exercise the orchestrator's host logic (buffering, flush boundaries, error timing, query
+ordering) where no GPU exists; the GPU tests run the same assertions through the HIP hasher.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import lshrs_oracle as O
+
+
+class OracleBackedHasher(O.OracleHasher):
+    def hash_batch_packed(self, vectors, *, return_row_flags: bool = False, **_):
+        arr = np.asarray(vectors, dtype=np.float32)
+        keys = super().hash_batch_packed(arr)
+        if not return_row_flags:
+            return keys
+        flags = O.is_zero_vector_rows(arr).astype(np.uint8)
+        flags |= (np.isnan(arr).any(axis=1).astype(np.uint8) << 1)
+        return keys, flags
+
+
+def make_cpu_lshrs(monkeypatch, **kw):
+    """LSHRS whose hasher and reranker are the oracle (CPU): host logic only."""
+    import lshrs_amd.core as core
+    from lshrs_amd import LSHRS, InMemoryStorage
+    from lshrs_amd.bandrows import get_optimal_config
+
+    dim = kw["dim"]
+    num_perm = kw.get("num_perm", 128)
+    nb, r = kw.get("num_bands"), kw.get("rows_per_band")
+    if nb is None or r is None:
+        nb, r = get_optimal_config(num_perm, kw.get("similarity_threshold", 0.5))
+    kw.setdefault("storage", InMemoryStorage())
+    kw["hasher"] = OracleBackedHasher(nb, r, dim, kw.get("seed", 42))
+    monkeypatch.setattr(core, "top_k_cosine", O.top_k_cosine)
+    return LSHRS(**kw)

@@ -1,0 +1,132 @@
+"""The C-ABI library loads, exports every symbol include/lshrs_hip.h declares, and the product
+package has no CPU compute path behind it.  CPU only — no kernel is launched here."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lshrs_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lshrs_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from lshrs_amd import _native
+
+    _native.build()
+    return _native.load()
+
+
+def test_header_and_library_agree(lib):
+    from lshrs_amd import _native
+
+    names = declared_functions()
+    assert len(names) >= 10
+    assert sorted(_native.EXPORTS) == names, "python binding list and header drifted apart"
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 1
+    m = re.search(r"#define\s+LSHRS_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert int(m.group(1)) == lib.lshrs_abi_version()
+
+
+def test_exported_symbols_are_plain_c(lib):
+    from lshrs_amd import _native
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIBRARY], capture_output=True, text=True, check=True)
+    exported = {line.split()[-1] for line in out.stdout.splitlines() if " T " in line}
+    assert set(declared_functions()) <= exported
+    # the code object for gfx950 is embedded
+    blob = open(_native.LIBRARY, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_pure_host_entry_points(lib):
+    """Size queries need no GPU: check the geometry they report."""
+    assert lib.lshrs_sig_padded_columns(16, 16) == 256
+    assert lib.lshrs_sig_padded_columns(16, 4) == 128      # bands padded to 8 columns each
+    assert lib.lshrs_sig_padded_columns(16, 32) == 512
+    assert lib.lshrs_sig_padded_columns(3, 5) == 32
+    assert lib.lshrs_sig_padded_columns(0, 5) < 0
+    # image: padded columns x dim rounded up to 32, plus one norm per padded column
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (256 * 768 + 256) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (512 * 1536 + 512) * 4
+    assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
+    # argument validation happens before anything touches a device
+    assert lib.lshrs_sig_hash_batch_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None) == -10001
+    assert lib.lshrs_topk_desc_f32(None, 1, 5, 3, None, None, None) == -10001
+    assert lib.lshrs_cosine_batch_f32(None, 1, 4, 4, None, 1, None, 1, None, None, None, None) == -10001
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lshrs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle." not in text.replace("oracle/", ""), f
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful where no GPU is visible")
+def test_compute_fails_loudly_without_gpu():
+    from lshrs_amd import LSHHasher, NativeLibraryError, cosine_similarity, top_k_cosine
+
+    h = LSHHasher(4, 4, 8)
+    with pytest.raises(NativeLibraryError, match="no CPU fallback"):
+        h.hash_vector(np.ones(8, dtype=np.float32))
+    with pytest.raises(NativeLibraryError):
+        h.hash_batch(np.ones((3, 8), dtype=np.float32))
+    with pytest.raises(NativeLibraryError):
+        cosine_similarity(np.ones(8), np.ones((2, 8)))
+    with pytest.raises(NativeLibraryError):
+        top_k_cosine(np.ones(8), np.ones((2, 8)), k=1)
+
+
+def test_missing_library_is_an_error(tmp_path, monkeypatch):
+    from lshrs_amd import _native
+
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIBRARY", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeLibraryError, match="has not been built"):
+        _native.load()
+
+
+def test_hasher_constructor_and_projection_seam():
+    """Host-side contract of the `_hasher` seam (reference: lshrs/hash/lsh.py:51-94; tests/test_lshrs.py:18-28)."""
+    from lshrs_amd import LSHHasher
+    from oracle.lshrs_oracle import make_projections
+
+    for bad in [(0, 1, 1), (1, 0, 1), (1, 1, 0)]:
+        with pytest.raises(ValueError):
+            LSHHasher(*bad)
+    h = LSHHasher(16, 16, 768, seed=42)
+    ref = make_projections(16, 16, 768, 42)
+    assert len(h.projections) == 16 and all(np.array_equal(a, b) for a, b in zip(h.projections, ref))
+    assert all(p.dtype == np.float32 and p.shape == (16, 768) for p in h.projections)
+    v0 = h._projection_version
+    h.projections = [p.copy() for p in ref]          # load_from_disk / __setstate__ do this
+    assert h._projection_version > v0
+    v1 = h._projection_version
+    h.projections[3] = ref[3] * 2
+    assert h._projection_version > v1
+    import pickle
+
+    h2 = pickle.loads(pickle.dumps(h))
+    assert all(np.array_equal(a, b) for a, b in zip(h2.projections, h.projections))
+    with pytest.raises(ValueError, match="dimension"):
+        h._validate_vector(np.ones(5))

@@ -1,0 +1,272 @@
+"""Host logic of ``LSHRS`` (buffering, flush boundaries, error timing, query ordering, validation)
+against the reference's own recorded behaviour (tests/golden/g5_orchestration.json) and the
+behavioural assertions of the reference suite (tests/test_core.py, test_buffer_semantics.py,
+test_concurrency.py upstream).  CPU only: hashing/reranking are supplied by the oracle double
+(tests/_doubles.py); tests/test_gpu_orchestrator.py repeats the golden checks through the HIP path.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from lshrs_amd import LSHRS, InMemoryStorage
+from tests._doubles import make_cpu_lshrs
+
+
+@pytest.fixture(scope="module")
+def g5(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "g5_orchestration.json")))
+
+
+def ops_json(batch):
+    return [[int(b), k.hex(), int(i)] for b, k, i in batch]
+
+
+def small(monkeypatch, **kw):
+    kw.setdefault("dim", 32)
+    kw.setdefault("num_bands", 4)
+    kw.setdefault("rows_per_band", 4)
+    kw.setdefault("num_perm", 16)
+    return make_cpu_lshrs(monkeypatch, **kw)
+
+
+# ----------------------------------------------------------------------------- goldens
+def test_index_batches_equal_reference(monkeypatch, g5):
+    data = np.random.default_rng(301).standard_normal((50, 32)).astype(np.float32)
+    store = InMemoryStorage()
+    idx = small(monkeypatch, buffer_size=10, storage=store, vector_fetch_fn=lambda ids: data[np.asarray(ids)])
+    idx.index(list(range(50)), data)
+    assert [ops_json(b) for b in store.batches] == g5["index50"]["batches"]
+    queries = np.frombuffer(bytes.fromhex(g5["queries_hex"]), dtype=np.float32).reshape(5, 32)
+    assert [idx.get_top_k(q, topk=5) for q in queries] == g5["top_k_5"]
+    for q, want in zip(queries, g5["above_p_half"]):
+        got = idx.get_above_p(q, p=0.5)
+        assert [i for i, _ in got] == [i for i, _ in want]
+        assert np.allclose([s for _, s in got], [s for _, s in want], atol=1e-6)
+        assert all(isinstance(i, int) and isinstance(s, float) for i, s in got)
+    for q, want in zip(queries, g5["query_topk3_topp1"]):
+        got = idx.query(q, top_k=3, top_p=1.0)
+        assert [i for i, _ in got] == [i for i, _ in want]
+
+
+def test_zero_vector_mid_batch_error_timing(monkeypatch, g5):
+    bad = np.frombuffer(bytes.fromhex(g5["bad_hex"]), dtype=np.float32).reshape(12, 32)
+    store = InMemoryStorage()
+    idx = small(monkeypatch, buffer_size=10, storage=store)
+    with pytest.raises(ValueError) as exc:
+        idx.index(list(range(12)), bad)
+    want = g5["zero_row7"]
+    assert str(exc.value) == want["message"]
+    assert [ops_json(b) for b in store.batches] == want["batches"]
+    assert ops_json(idx._buffer) == want["left_in_buffer"]
+
+
+def test_negative_id_mid_batch_error_timing(monkeypatch, g5):
+    bad = np.frombuffer(bytes.fromhex(g5["bad_hex"]), dtype=np.float32).reshape(12, 32)
+    store = InMemoryStorage()
+    idx = small(monkeypatch, buffer_size=1000, storage=store)
+    with pytest.raises(ValueError) as exc:
+        idx.index([0, 1, 2, -4, 5], bad[:5])
+    want = g5["negative_row3"]
+    assert str(exc.value) == want["message"]
+    assert [ops_json(b) for b in store.batches] == want["batches"] == []
+    assert ops_json(idx._buffer) == want["left_in_buffer"]
+
+
+def test_config1_plumbing_10k_x_128(monkeypatch, g5):
+    """BASELINE config 1: 10k x 128-d, num_perm=64 -> (16, 4), in-memory storage, CPU plumbing."""
+    store = InMemoryStorage()
+    idx = make_cpu_lshrs(monkeypatch, dim=128, num_perm=64, storage=store, buffer_size=10_000)
+    x = np.random.default_rng(1).standard_normal((10_000, 128)).astype(np.float32)
+    idx.index(list(range(10_000)), x)
+    want = g5["c1"]
+    assert (idx._hasher.num_bands, idx._hasher.rows_per_band) == (want["num_bands"], want["rows_per_band"])
+    assert [len(b) for b in store.batches] == want["batches"]
+    h = hashlib.sha256()
+    for batch in store.batches:
+        for b, k, i in batch:
+            h.update(bytes([b]) + k + int(i).to_bytes(4, "little"))
+    assert h.hexdigest() == want["ops_sha256"]
+    assert idx.get_top_k(x[0], topk=5) == want["top_k_row0"]
+
+
+# ----------------------------------------------------------------------------- constructor / validation
+def test_constructor_validation():
+    s = InMemoryStorage()
+    with pytest.raises(ValueError, match="dimensionality"):
+        LSHRS(dim=0, storage=s, hasher=object())
+    with pytest.raises(ValueError, match="num_perm"):
+        LSHRS(dim=4, num_perm=0, storage=s, hasher=object())
+    with pytest.raises(ValueError, match="buffer_size"):
+        LSHRS(dim=4, buffer_size=0, storage=s, hasher=object())
+    with pytest.raises(ValueError, match="must equal num_perm"):
+        LSHRS(dim=4, num_perm=16, num_bands=3, rows_per_band=4, storage=s, hasher=object())
+    idx = LSHRS(dim=8, num_perm=256, storage=s, hasher=object())
+    assert (idx._config["num_bands"], idx._config["rows_per_band"]) == (16, 16)
+    assert idx.stats()["num_perm"] == 256
+
+
+def test_ingest_and_index_validation(monkeypatch):
+    idx = small(monkeypatch)
+    v = np.ones(32, dtype=np.float32)
+    with pytest.raises(ValueError, match="non-negative"):
+        idx.ingest(-1, v)
+    with pytest.raises(ValueError, match="dimension"):
+        idx.ingest(0, np.ones(31, dtype=np.float32))
+    with pytest.raises(ValueError, match="zero vector"):
+        idx.ingest(0, np.zeros(32, dtype=np.float32))
+    idx.index([], None)  # no-op
+    with pytest.raises(ValueError, match="shape"):
+        idx.index([0, 1], np.ones((2, 31), dtype=np.float32))
+    with pytest.raises(ValueError, match="does not match"):
+        idx.index([0, 1, 2], np.ones((2, 32), dtype=np.float32))
+    with pytest.raises(RuntimeError, match="vector_fetch_fn"):
+        idx.index([0, 1], None)
+
+
+def test_index_with_fetch_fn_and_self_match(monkeypatch):
+    data = np.random.default_rng(3).standard_normal((40, 32)).astype(np.float32)
+    idx = small(monkeypatch, vector_fetch_fn=lambda ids: data[np.asarray(ids)])
+    idx.index(list(range(40)))
+    assert idx._storage.total_operations == 40 * 4
+    for i in (0, 17, 39):
+        assert idx.get_top_k(data[i], topk=1) == [i]
+        near = data[i] + 1e-4 * np.random.default_rng(i).standard_normal(32).astype(np.float32)
+        assert i in idx.get_top_k(near, topk=3)
+    res = idx.get_above_p(data[5], p=1.0)
+    assert res[0][0] == 5 and res[0][1] == pytest.approx(1.0, abs=1e-5)
+    assert [s for _, s in res] == sorted((s for _, s in res), reverse=True)
+
+
+def test_query_validation(monkeypatch):
+    data = np.random.default_rng(4).standard_normal((10, 32)).astype(np.float32)
+    idx = small(monkeypatch)
+    idx.index(list(range(10)), data)
+    with pytest.raises(ValueError, match="top_k"):
+        idx.query(data[0], top_k=0)
+    with pytest.raises(ValueError, match="top_p"):
+        idx.query(data[0], top_k=None, top_p=1.5)
+    with pytest.raises(ValueError, match="top_p"):
+        idx.query(data[0], top_k=None, top_p=0.0)
+    with pytest.raises(RuntimeError, match="vector_fetch_fn"):
+        idx.get_above_p(data[0], p=0.5)
+    with pytest.raises(ValueError, match="zero vector"):
+        idx.get_top_k(np.zeros(32, dtype=np.float32))
+    with pytest.raises(ValueError, match="dimension"):
+        idx.get_top_k(np.ones(3, dtype=np.float32))
+    empty = small(monkeypatch, storage=InMemoryStorage())
+    assert empty.get_top_k(data[0]) == []
+    bad_fetch = small(monkeypatch, storage=idx._storage, vector_fetch_fn=lambda ids: np.ones((1, 32), np.float32))
+    with pytest.raises(ValueError, match="mismatched batch size"):
+        bad_fetch.get_above_p(data[0], p=1.0)
+    bad_shape = small(monkeypatch, storage=idx._storage, vector_fetch_fn=lambda ids: np.ones((len(ids), 3), np.float32))
+    with pytest.raises(ValueError, match="Fetched vectors must have shape"):
+        bad_shape.get_above_p(data[0], p=1.0)
+
+
+# ----------------------------------------------------------------------------- buffer semantics
+def test_buffered_until_flush_and_close(monkeypatch):
+    store = InMemoryStorage()
+    idx = small(monkeypatch, storage=store, buffer_size=1000)
+    v = np.random.default_rng(0).standard_normal(32).astype(np.float32)
+    idx.ingest(1, v)
+    assert store.batches == [] and len(idx._buffer) == 4
+    assert idx.get_top_k(v) == []          # not visible before the flush
+    idx.flush()
+    assert len(store.batches) == 1 and idx._buffer == []
+    assert idx.get_top_k(v) == [1]
+    idx.flush()                            # empty flush is a no-op
+    assert len(store.batches) == 1
+    idx.ingest(2, v)
+    idx.close()
+    assert store.closed and len(store.batches) == 2
+
+
+def test_auto_flush_boundary(monkeypatch):
+    store = InMemoryStorage()
+    idx = make_cpu_lshrs(monkeypatch, dim=32, num_bands=2, rows_per_band=4, num_perm=8, buffer_size=4, storage=store)
+    rng = np.random.default_rng(1)
+    idx.ingest(0, rng.standard_normal(32).astype(np.float32))
+    assert store.batches == []
+    idx.ingest(1, rng.standard_normal(32).astype(np.float32))
+    assert [len(b) for b in store.batches] == [4]
+
+
+def test_flush_failure_restores_buffer(monkeypatch):
+    store = InMemoryStorage(fail_on_flush=True)
+    idx = small(monkeypatch, storage=store, buffer_size=1000)
+    v = np.random.default_rng(2).standard_normal(32).astype(np.float32)
+    idx.ingest(7, v)
+    before = list(idx._buffer)
+    with pytest.raises(ConnectionError):
+        idx.flush()
+    assert idx._buffer == before
+    store._fail_on_flush = False
+    idx.ingest(8, v)
+    idx.flush()
+    assert [i for _, _, i in store.batches[0]] == [7] * 4 + [8] * 4   # restored ops stay in front
+
+
+def test_context_manager_delete_clear(monkeypatch):
+    store = InMemoryStorage()
+    data = np.random.default_rng(5).standard_normal((6, 32)).astype(np.float32)
+    with small(monkeypatch, storage=store) as idx:
+        idx.index(list(range(6)), data)
+        idx.delete(3)
+        assert 3 not in idx.get_top_k(data[3], topk=6)
+        idx.delete([0, 1])
+        assert idx.get_top_k(data[0], topk=6) == [] or 0 not in idx.get_top_k(data[0], topk=6)
+        idx.clear()
+        assert idx.get_top_k(data[4]) == []
+    assert store.closed
+
+
+# ----------------------------------------------------------------------------- concurrency
+def test_concurrent_ingest_and_flush(monkeypatch):
+    store = InMemoryStorage()
+    idx = small(monkeypatch, storage=store, buffer_size=37)
+    data = np.random.default_rng(6).standard_normal((100, 32)).astype(np.float32)
+    errors = []
+
+    def worker(t):
+        try:
+            for j in range(10):
+                idx.ingest(t * 10 + j, data[t * 10 + j])
+        except Exception as exc:  # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(10)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    flushers = [threading.Thread(target=idx.flush) for _ in range(5)]
+    [t.start() for t in flushers]
+    [t.join() for t in flushers]
+    assert not errors
+    assert store.total_operations == 100 * 4
+    assert store.unique_indices == set(range(100))
+
+
+def test_same_seed_same_keys_different_seed_differs(monkeypatch):
+    data = np.random.default_rng(8).standard_normal((20, 32)).astype(np.float32)
+    a, b, c = InMemoryStorage(), InMemoryStorage(), InMemoryStorage()
+    small(monkeypatch, storage=a, seed=1).index(list(range(20)), data)
+    small(monkeypatch, storage=b, seed=1).index(list(range(20)), data)
+    small(monkeypatch, storage=c, seed=2).index(list(range(20)), data)
+    assert a.batches == b.batches
+    assert a.batches != c.batches
+
+
+def test_create_signatures_from_batches(monkeypatch):
+    data = np.random.default_rng(9).standard_normal((30, 32)).astype(np.float32)
+    store = InMemoryStorage()
+    idx = small(monkeypatch, storage=store)
+    idx.create_signatures("batches", batches=[(list(range(0, 10)), data[:10]), (list(range(10, 30)), data[10:])])
+    assert store.total_operations == 30 * 4 and len(store.batches) == 2
+    with pytest.raises(ValueError, match="Unsupported"):
+        idx.create_signatures("csv")
