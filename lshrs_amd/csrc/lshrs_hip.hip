@@ -56,6 +56,7 @@ inline SigGeom sig_geom(int num_bands, int rows, int dim) {
 
 inline int64_t sig_image_floats(const SigGeom& g) { return (int64_t)g.cb * g.ktiles * g.nt * 4 * kFragFloats; }
 inline int64_t sig_norm_floats(const SigGeom& g) { return (int64_t)g.cb * g.nt * 32; }
+inline int64_t sig_normmax_floats(const SigGeom& g) { return ((int64_t)g.cb + 3) & ~(int64_t)3; }
 
 // ------------------------------------------------------------------------------------------
 // Hyperplane re-layout.  image[cb][kt][jt][q][lane][r] = P'[col = (cb*NT + jt)*32 + (lane&31)]
@@ -102,6 +103,14 @@ __global__ void pack_norm_kernel(const float* __restrict__ P, int num_bands, int
   norms[col] = (float)sqrt(s);
 }
 
+__global__ void pack_normmax_kernel(const float* __restrict__ norms, int cols_per_block, int cb, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= cb) return;
+  float m = 0.f;
+  for (int c = 0; c < cols_per_block; ++c) m = fmaxf(m, norms[b * cols_per_block + c]);
+  out[b] = m;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------
@@ -113,6 +122,7 @@ struct SigArgs {
   int ktiles;
   const float* image;
   const float* norms;
+  const float* norm_max;  // per column block: max of norms
   // keys mode
   uint8_t* keys;
   int row_bytes;       // num_bands * bb
@@ -163,14 +173,17 @@ __device__ __forceinline__ void stage_p_tile(const float* __restrict__ tile, flo
   }
 }
 
-// Deposit a wave-uniform word into one lane's register (lane index is a compile-time constant:
-// a v_cndmask under a constant 64-bit lane mask).
-__device__ __forceinline__ uint32_t put_lane(uint32_t old, uint32_t uniform_word, int lane, int target) {
-  return lane == target ? uniform_word : old;
+// Deposit a wave-uniform word (SGPR) into ONE lane of a VGPR: a single v_writelane_b32 with an
+// immediate lane select (this clang exposes no builtin for it).
+__device__ __forceinline__ uint32_t put_lane(uint32_t old, uint32_t uniform_word, int target) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uniform_word), "n"(target));
+  return old;
 }
 
-template <int NT, bool ALIGNED, bool PROJECT, int W>
+// MODE 0: keys only, 1: keys + tie list, 2: raw projections (diagnostic)
+template <int NT, bool ALIGNED, int MODE, int W>
 __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
+  constexpr bool PROJECT = MODE == 2;
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kBlockRows = W * kRowsPerWave;
   __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + W * 32];
@@ -263,14 +276,26 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
 #pragma unroll
   for (int w = 0; w < WPL; ++w) { kw[w] = 0u; tw[w] = 0u; }
 
-  const bool want_ties = args.tie_list != nullptr;
+  constexpr bool want_ties = MODE == 1;
   f32x4 rn[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(norm_lds + 8 * g + 4 * h);
+  // wave-uniform screen for ties: |y| < (largest tau*||x|| of the wave's rows) * (largest ||p|| of the block)
+  float screen = 0.f;
+  if (want_ties) {
+    float m = __builtin_fmaxf(__builtin_fmaxf(rn[0][0], rn[0][1]), __builtin_fmaxf(rn[0][2], rn[0][3]));
+#pragma unroll
+    for (int g = 1; g < 4; ++g)
+      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(rn[g][0], rn[g][1]), __builtin_fmaxf(rn[g][2], rn[g][3])));
+    m = __builtin_fmaxf(m, __shfl_xor(m, 32));  // lanes of one half hold 16 of the 32 rows
+    // NaN norms (a NaN in x) must not hide the finite rows next to them: fmaxf drops NaNs, so m is the
+    // largest finite norm; rows that are NaN produce NaN projections, which never tie.
+    screen = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))) * args.norm_max[cb];
+  }
 
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
-    const float pn = args.norms[(cb * NT + jt) * 32 + i];
+    uint64_t any = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float y = acc[jt][r];
@@ -278,13 +303,20 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
       const int rho = (r & 3) + 8 * (r >> 2);
       const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
       const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
-      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)pos, lane, l0);
-      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)(pos >> 32), lane, l1);
-      if (want_ties) {
+      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)pos, l0);
+      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)(pos >> 32), l1);
+      if (want_ties) any |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
+    }
+    if (any != 0) {  // wave-uniform, rare (a few % of column tiles): the exact per-element test
+      const float pn = args.norms[(cb * NT + jt) * 32 + i];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         const float thr = rn[r >> 2][r & 3] * pn;
-        const uint64_t tie = __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < thr);  // strict: thr == 0 (zero x, padded column) never ties
-        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)tie, lane, l0);
-        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)(tie >> 32), lane, l1);
+        // strict '<': thr == 0 (zero x, zero-padded column) never ties
+        const uint64_t tie = __builtin_amdgcn_ballot_w64(__builtin_fabsf(acc[jt][r]) < thr);
+        const int rho = (r & 3) + 8 * (r >> 2);
+        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)tie, rho * LPR + jt / WPL);
+        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)(tie >> 32), (rho + 4) * LPR + jt / WPL);
       }
     }
   }
@@ -332,17 +364,14 @@ int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project,
   constexpr int kBlockRows = W * kRowsPerWave;
   const dim3 grid((unsigned)((a.n + kBlockRows - 1) / kBlockRows), (unsigned)g.cb, 1);
   const dim3 block(W * 64, 1, 1);
-  if (project) {
-    if (aligned)
-      hipLaunchKernelGGL((sig_kernel<NT, true, true, W>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((sig_kernel<NT, false, true, W>), grid, block, 0, s, a);
+  const int mode = project ? 2 : (a.tie_list != nullptr ? 1 : 0);
+#define LSHRS_LAUNCH(AL, MD) hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W>), grid, block, 0, s, a)
+  if (aligned) {
+    if (mode == 0) LSHRS_LAUNCH(true, 0); else if (mode == 1) LSHRS_LAUNCH(true, 1); else LSHRS_LAUNCH(true, 2);
   } else {
-    if (aligned)
-      hipLaunchKernelGGL((sig_kernel<NT, true, false, W>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((sig_kernel<NT, false, false, W>), grid, block, 0, s, a);
+    if (mode == 0) LSHRS_LAUNCH(false, 0); else if (mode == 1) LSHRS_LAUNCH(false, 1); else LSHRS_LAUNCH(false, 2);
   }
+#undef LSHRS_LAUNCH
   return -(int)hipGetLastError();
 }
 
@@ -372,6 +401,19 @@ __global__ void gather_rows_kernel(const float* __restrict__ X, int64_t ldx, int
   const float* src = X + rows[t] * ldx;
   float* out = dst + t * (int64_t)dim;
   for (int k = threadIdx.x; k < dim; k += blockDim.x) out[k] = src[k];
+}
+
+// Copy the X row of every tie entry (count read on the device) into a staging matrix, so the host can
+// fetch entries and their vectors without a round trip in between.
+__global__ void gather_tied_rows_kernel(const float* __restrict__ X, int64_t ldx, int dim,
+                                        const int64_t* __restrict__ tie_list, const int32_t* __restrict__ tie_count,
+                                        int tie_cap, float* __restrict__ dst) {
+  const int cnt = min(*tie_count, tie_cap);
+  for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+    const float* src = X + (tie_list[2 * (int64_t)e] >> 16) * ldx;
+    float* out = dst + (int64_t)e * dim;
+    for (int k = threadIdx.x; k < dim; k += blockDim.x) out[k] = src[k];
+  }
 }
 
 __global__ void scatter_keys_kernel(uint8_t* __restrict__ keys, int num_bands, int bb, const int64_t* __restrict__ rows,
@@ -589,7 +631,7 @@ static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
 int64_t lshrs_sig_workspace_bytes(int32_t num_bands, int32_t rows_per_band, int32_t dim) {
   if (!sig_shape_ok(num_bands, rows_per_band, dim)) return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
-  return (sig_image_floats(g) + sig_norm_floats(g)) * (int64_t)sizeof(float);
+  return (sig_image_floats(g) + sig_norm_floats(g) + sig_normmax_floats(g)) * (int64_t)sizeof(float);
 }
 
 int32_t lshrs_sig_padded_columns(int32_t num_bands, int32_t rows_per_band) {
@@ -612,6 +654,8 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
   const int cols = g.cb * g.nt * 32;
   hipLaunchKernelGGL(pack_norm_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64), 0, s, P, num_bands, rows_per_band,
                      dim, g.bb, cols, norms);
+  hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((g.cb + 63) / 64)), dim3(64), 0, s, norms, g.nt * 32, g.cb,
+                     norms + sig_norm_floats(g));
   return -(int)hipGetLastError();
 }
 
@@ -634,6 +678,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
   a.ktiles = g.ktiles;
   a.image = static_cast<const float*>(workspace);
   a.norms = a.image + sig_image_floats(g);
+  a.norm_max = a.norms + sig_norm_floats(g);
   a.keys = keys;
   a.row_bytes = num_bands * g.bb;
   const int wpl_bytes = g.nt >= 2 ? 2 * g.nt : 4;  // bytes one lane stores
@@ -663,6 +708,7 @@ int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* wo
   a.ktiles = g.ktiles;
   a.image = static_cast<const float*>(workspace);
   a.norms = a.image + sig_image_floats(g);
+  a.norm_max = a.norms + sig_norm_floats(g);
   a.Y = Y;
   a.ldy = ldy;
   return dispatch_sig(a, g, true, static_cast<hipStream_t>(stream));
@@ -675,6 +721,18 @@ int lshrs_gather_rows_f32(const float* X, int64_t ldx, int32_t dim, const int64_
   if (m > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)m), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, dim,
                      rows, m, dst);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_gather_tied_rows_f32(const float* X, int64_t ldx, int32_t dim, const int64_t* tie_list,
+                               const int32_t* tie_count, int32_t tie_cap, float* dst, void* stream) {
+  if (tie_cap == 0) return 0;
+  if (X == nullptr || tie_list == nullptr || tie_count == nullptr || dst == nullptr || dim <= 0 || tie_cap < 0 ||
+      ldx < dim)
+    return LSHRS_E_BADARG;
+  const int blocks = tie_cap < 2048 ? tie_cap : 2048;
+  hipLaunchKernelGGL(gather_tied_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X,
+                     ldx, dim, tie_list, tie_count, tie_cap, dst);
   return -(int)hipGetLastError();
 }
 

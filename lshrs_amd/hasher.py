@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from . import _native
+from . import _hostblas, _native
 from ._config import HashSignatures
 
 __all__ = ["LSHHasher"]
@@ -106,6 +106,11 @@ class LSHHasher:
         # set to a list to collect (start, end) torch.cuda.Event pairs around every signature-kernel
         # launch (bench.py uses it to time the kernel on the stream it runs on)
         self.kernel_events: Optional[list] = None
+        self.native_tie_break = True  # use csrc/host_tiebreak.cpp when it reproduces NumPy bit for bit
+        # device batches of >= 2 chunks take the pipelined path; 131072 rows = two full-chip rounds of K1
+        self.pipeline_chunk_rows = 131_072
+        self._side_streams: Dict[int, object] = {}
+        self._pinned_cache: Dict[tuple, tuple] = {}
         # hyperplanes: one generator, num_bands float64 draws cast to float32 (lsh.py:93-94)
         gen = np.random.default_rng(seed)
         planes = [gen.standard_normal((self.rows_per_band, self.dim)).astype(np.float32)
@@ -210,6 +215,8 @@ class LSHHasher:
             return out
         ws = self._workspace(dev)
         tau = float(self.tau_ulps * _U)
+        if mode == "host" and host_rows is None and n >= 2 * self.pipeline_chunk_rows:
+            return self._hash_device_pipelined(x, out, row_flags, ws, tau, stats)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             flags_ptr = row_flags.data_ptr() if row_flags is not None else None
@@ -256,6 +263,116 @@ class LSHHasher:
                 torch.cuda.current_stream(dev).synchronize()  # the small staging tensors die with this frame
         return out
 
+    # ------------------------------------------------------------------ large batches: overlap the tie-break
+    def _hash_device_pipelined(self, x, out, row_flags, ws, tau, stats):
+        """Same result as the plain path, for large device-resident batches: the batch is cut into
+        chunks of ``pipeline_chunk_rows`` (a whole number of full-chip rounds of the kernel); every chunk's
+        kernel and its "gather the tied rows" kernel are enqueued back to back on the caller's stream, and
+        while the GPU works through them the host resolves the ties of the chunks already finished
+        (count / entries / vectors come back over a side stream, patches go out over it)."""
+        torch = _native.require_gpu()
+        lib = _native.load()
+        dev = x.device
+        n = int(x.shape[0])
+        bb = self.band_bytes
+        ch = self.pipeline_chunk_rows
+        cap = ch // 16 + 1024
+        window = 16
+        spans = [(lo, min(n, lo + ch)) for lo in range(0, n, ch)]
+        overflow = []
+        keep = []  # device temporaries stay referenced until the streams have been joined
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            pin_cnt, pin_entries, pin_rows = self._pinned(dev, cap, window)
+            for w0 in range(0, len(spans), window):
+                group = spans[w0:w0 + window]
+                lists = torch.empty((len(group), cap, 2), dtype=torch.int64, device=dev)
+                counts = torch.zeros((len(group),), dtype=torch.int32, device=dev)
+                stage = torch.empty((len(group), cap, self.dim), dtype=torch.float32, device=dev)
+                keep += [lists, counts, stage]
+                ready = []
+                for ci, (lo, hi) in enumerate(group):
+                    xs, os_ = x[lo:hi], out[lo:hi]
+                    flags_ptr = row_flags[lo:hi].data_ptr() if row_flags is not None else None
+                    self._launch_sig(torch, lib, dev, xs.data_ptr(), hi - lo, x.stride(0), ws.data_ptr(),
+                                     self.num_bands, self.rows_per_band, self.dim, os_.data_ptr(),
+                                     lists[ci].data_ptr(), cap, counts[ci:ci + 1].data_ptr(), tau, flags_ptr,
+                                     main.cuda_stream)
+                    _native.check(
+                        lib.lshrs_gather_tied_rows_f32(xs.data_ptr(), x.stride(0), self.dim, lists[ci].data_ptr(),
+                                                       counts[ci:ci + 1].data_ptr(), cap, stage[ci].data_ptr(),
+                                                       main.cuda_stream), "lshrs_gather_tied_rows_f32")
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    side.wait_event(done)
+                    with torch.cuda.stream(side):
+                        pin_cnt[ci:ci + 1].copy_(counts[ci:ci + 1], non_blocking=True)
+                        copied = torch.cuda.Event()
+                        copied.record(side)
+                    ready.append(copied)
+                for ci, (lo, hi) in enumerate(group):
+                    ready[ci].synchronize()
+                    cnt = int(pin_cnt[ci])
+                    if cnt > cap:
+                        overflow.append((lo, hi))
+                        continue
+                    stats["tie_entries"] += cnt
+                    if cnt == 0:
+                        continue
+                    with torch.cuda.stream(side):
+                        pin_entries[:cnt].copy_(lists[ci, :cnt], non_blocking=True)
+                        pin_rows[:cnt].copy_(stage[ci, :cnt], non_blocking=True)
+                    side.synchronize()
+                    entries = pin_entries[:cnt].numpy()
+                    rows, bands = self._tie_pairs(entries)
+                    stats["tie_pairs"] += int(rows.shape[0])
+                    erow = entries[:, 0] >> 16
+                    order = np.argsort(erow, kind="stable")
+                    xindex = order[np.searchsorted(erow[order], rows)]  # an entry that carries this row's vector
+                    patch = self._tie_patches(pin_rows[:cnt].numpy(), xindex, bands)
+                    with torch.cuda.stream(side):
+                        rows_dev = torch.from_numpy(rows).to(dev)
+                        bands_dev = torch.from_numpy(bands).to(dev)
+                        patch_dev = torch.from_numpy(patch).to(dev)
+                        keep += [rows_dev, bands_dev, patch_dev]
+                        _native.check(
+                            lib.lshrs_scatter_band_keys_u8(out[lo:hi].data_ptr(), self.num_bands, bb,
+                                                           rows_dev.data_ptr(), bands_dev.data_ptr(),
+                                                           patch_dev.data_ptr(), rows.shape[0], side.cuda_stream),
+                            "lshrs_scatter_band_keys_u8")
+            main.wait_stream(side)
+            side.synchronize()
+        for lo, hi in overflow:  # a chunk with more ties than its list holds: redo it on the plain path
+            sub = {"n": hi - lo, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+            self.last_stats = sub
+            self._hash_device_locked(x[lo:hi], out[lo:hi], row_flags[lo:hi] if row_flags is not None else None,
+                                     "host", None)
+            for k in ("tie_entries", "tie_pairs"):
+                stats[k] += self.last_stats[k]
+            stats["relaunches"] += 1 + self.last_stats["relaunches"]
+        self.last_stats = stats
+        return out
+
+    def _side_stream(self, dev):
+        torch = _native.require_gpu()
+        s = self._side_streams.get(dev.index)
+        if s is None:
+            s = torch.cuda.Stream(device=dev)
+            self._side_streams[dev.index] = s
+        return s
+
+    def _pinned(self, dev, cap: int, window: int):
+        torch = _native.require_gpu()
+        key = (dev.index, cap, window)
+        buf = self._pinned_cache.get(key)
+        if buf is None:
+            buf = (torch.empty((window,), dtype=torch.int32).pin_memory(),
+                   torch.empty((cap, 2), dtype=torch.int64).pin_memory(),
+                   torch.empty((cap, self.dim), dtype=torch.float32).pin_memory())
+            self._pinned_cache = {key: buf}
+        return buf
+
     def _launch_sig(self, torch, lib, dev, *args) -> None:
         events = self.kernel_events
         if events is None:
@@ -297,21 +414,29 @@ class LSHHasher:
         """Band keys of the flagged (row, band) pairs by the reference's own expression
         (``projection @ vector``, ``> 0``, ``np.packbits(..., bitorder='little')``: lsh.py:200-208).
 
-        ``np.matmul(P_band, X[:, :, None])`` runs NumPy's matrix @ vector inner loop once per row, i.e.
-        it issues the very ``cblas_sgemv`` call ``P_band @ x`` issues (same operands, same shapes, same
-        library) without a Python-level loop; tests/test_tiebreak_host.py checks the two bit for bit.
-        ``bands`` arrives sorted, so each band is one contiguous slice.
+        Fast path: ``csrc/host_tiebreak.cpp`` issues, per pair, the ``cblas_sgemv`` call that NumPy makes
+        for ``P_band @ x`` — through NumPy's own BLAS, after ``_hostblas.verified_for`` has matched it
+        against NumPy bit for bit for this (rows, dim).  Otherwise ``np.matmul(P_band, X[:, :, None])``,
+        which runs NumPy's matrix @ vector inner loop once per row (same call, same operands; checked in
+        tests/test_tiebreak_host.py).  ``bands`` arrives sorted, so each band is one contiguous slice.
         """
-        planes = self._projections
-        patch = np.empty((bands.shape[0], self.band_bytes), dtype=np.uint8)
-        if bands.shape[0] == 0:
-            return patch
+        m = int(bands.shape[0])
+        if m == 0:
+            return np.empty((0, self.band_bytes), dtype=np.uint8)
+        planes = [np.ascontiguousarray(p, dtype=np.float32) for p in self._projections]
+        if self.native_tie_break and m >= 64:
+            lib = _native.load()
+            if _hostblas.verified_for(lib, self.rows_per_band, self.dim):
+                patch = _hostblas.band_keys(lib, planes, xrows, inverse, bands, self.rows_per_band, self.dim,
+                                            _hostblas.worker_threads())
+                if patch is not None:
+                    return patch
+        patch = np.empty((m, self.band_bytes), dtype=np.uint8)
         starts = np.flatnonzero(np.r_[True, bands[1:] != bands[:-1]])
-        stops = np.r_[starts[1:], bands.shape[0]]
+        stops = np.r_[starts[1:], m]
         for lo, hi in zip(starts, stops):
-            plane = np.ascontiguousarray(planes[int(bands[lo])], dtype=np.float32)
             xs = np.ascontiguousarray(xrows[inverse[lo:hi]])
-            y = np.matmul(plane, xs[:, :, None])[:, :, 0]
+            y = np.matmul(planes[int(bands[lo])], xs[:, :, None])[:, :, 0]
             patch[lo:hi] = np.packbits(y > 0, axis=1, bitorder="little")
         return patch
 
@@ -398,6 +523,9 @@ class LSHHasher:
         state = self.__dict__.copy()
         state["_lock"] = None
         state["_workspaces"] = {}
+        state["_side_streams"] = {}
+        state["_pinned_cache"] = {}
+        state["kernel_events"] = None
         state["_projections"] = list(self._projections)
         return state
 

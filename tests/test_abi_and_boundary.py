@@ -61,10 +61,10 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_padded_columns(16, 32) == 512
     assert lib.lshrs_sig_padded_columns(3, 5) == 32
     assert lib.lshrs_sig_padded_columns(0, 5) < 0
-    # image: padded columns x dim rounded up to 32, plus one norm per padded column
-    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (256 * 768 + 256) * 4
-    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (512 * 1536 + 512) * 4
-    assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32) * 4
+    # image: padded columns x dim rounded up to 32, one norm per padded column, one max-norm per column block (x4)
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (256 * 768 + 256 + 4) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (512 * 1536 + 512 + 4) * 4
+    assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device
     assert lib.lshrs_sig_hash_batch_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None) == -10001

@@ -216,3 +216,46 @@ def test_full_size_properties_1m_rows(torch_mod):
     sl = x[500_000:504_096]
     assert np.array_equal(hb.hash_device(sl).cpu().numpy(),
                           hash_batch_literal_packed(hb.projections, sl.cpu().numpy()))
+
+
+def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
+    """Large device batches overlap the host tie-break with later chunks' kernels: same bytes."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(42, 16, 16, 768)
+    gen = torch.Generator("cuda").manual_seed(77)
+    x = torch.randn(300_000, 768, device="cuda", generator=gen)
+    flags = torch.zeros(300_000, dtype=torch.uint8, device="cuda")
+    x[123_456] = 0.0
+    piped = h.hash_device(x, row_flags=flags)
+    stats = dict(h.last_stats)
+    assert stats["tie_pairs"] > 100 and stats["relaunches"] == 0
+    assert flags.nonzero().flatten().tolist() == [123_456]
+    h.pipeline_chunk_rows = 10**9                      # force the plain (single launch) path
+    plain = h.hash_device(x)
+    assert torch.equal(piped, plain)
+    assert h.last_stats["tie_pairs"] == stats["tie_pairs"]
+    sl = slice(130_000, 134_096)                       # straddles a chunk boundary (131 072)
+    assert np.array_equal(piped[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
+    # native and NumPy tie-break evaluate the same sgemv: identical bytes
+    h.native_tie_break = False
+    assert torch.equal(h.hash_device(x), plain)
+
+
+def test_tie_list_overflow_is_recovered(torch_mod):
+    """A threshold so wide that every projection 'ties' overflows the per-chunk list: the chunk is redone
+    with room, and since every band is then recomputed on the host the result is still the reference's."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(3, 4, 16, 64, tau_ulps=1e9)
+    h.pipeline_chunk_rows = 1024
+    x = np.random.default_rng(8).standard_normal((5000, 64)).astype(np.float32)
+    got = h.hash_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert h.last_stats["relaunches"] > 0
+    assert np.array_equal(got, hash_batch_literal_packed(h.projections, x))
+    h.pipeline_chunk_rows = 131_072                     # plain path: relaunch with a bigger list
+    got = h.hash_batch_packed(x)
+    assert h.last_stats["relaunches"] > 0
+    assert np.array_equal(got, hash_batch_literal_packed(h.projections, x))
