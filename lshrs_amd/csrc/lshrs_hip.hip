@@ -173,11 +173,29 @@ __device__ __forceinline__ void stage_p_tile(const float* __restrict__ tile, flo
   }
 }
 
-// Deposit a wave-uniform word (SGPR) into ONE lane of a VGPR: a single v_writelane_b32 with an
-// immediate lane select (this clang exposes no builtin for it).
-__device__ __forceinline__ uint32_t put_lane(uint32_t old, uint32_t uniform_word, int target) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(uniform_word), "n"(target));
-  return old;
+// Ballot + deposit in one block.  The 64-lane compare result (VCC: low half = the 32 columns of row rho,
+// high half = the same columns of row rho + 4) is written into the two lanes that own those output
+// words with v_writelane_b32 (immediate lane select; this clang exposes no builtin for it).
+// gfx940-family hazard: a VALU-written SGPR needs 2 wait states before the next VALU reads it, and hipcc
+// pads nothing inside an asm statement — hence the s_nop 1.
+__device__ __forceinline__ void deposit_positive(uint32_t& word, float y, int lane_lo, int lane_hi) {
+  asm("v_cmp_lt_f32 vcc, 0, %1\n\t"
+      "s_nop 1\n\t"
+      "v_writelane_b32 %0, vcc_lo, %2\n\t"
+      "v_writelane_b32 %0, vcc_hi, %3"
+      : "+v"(word)
+      : "v"(y), "n"(lane_lo), "n"(lane_hi)
+      : "vcc");
+}
+
+__device__ __forceinline__ void deposit_abs_below(uint32_t& word, float y, float bound, int lane_lo, int lane_hi) {
+  asm("v_cmp_lt_f32 vcc, |%1|, %2\n\t"
+      "s_nop 1\n\t"
+      "v_writelane_b32 %0, vcc_lo, %3\n\t"
+      "v_writelane_b32 %0, vcc_hi, %4"
+      : "+v"(word)
+      : "v"(y), "v"(bound), "n"(lane_lo), "n"(lane_hi)
+      : "vcc");
 }
 
 // MODE 0: keys only, 1: keys + tie list, 2: raw projections (diagnostic)
@@ -299,12 +317,10 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float y = acc[jt][r];
-      const uint64_t pos = __builtin_amdgcn_ballot_w64(y > 0.f);
       const int rho = (r & 3) + 8 * (r >> 2);
       const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
       const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
-      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)pos, l0);
-      kw[jt % WPL] = put_lane(kw[jt % WPL], (uint32_t)(pos >> 32), l1);
+      deposit_positive(kw[jt % WPL], y, l0, l1);   // bit = (y > 0): 0, -0 and NaN give 0 (lsh.py:204)
       if (want_ties) any |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
     }
     if (any != 0) {  // wave-uniform, rare (a few % of column tiles): the exact per-element test
@@ -313,10 +329,8 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
       for (int r = 0; r < 16; ++r) {
         const float thr = rn[r >> 2][r & 3] * pn;
         // strict '<': thr == 0 (zero x, zero-padded column) never ties
-        const uint64_t tie = __builtin_amdgcn_ballot_w64(__builtin_fabsf(acc[jt][r]) < thr);
         const int rho = (r & 3) + 8 * (r >> 2);
-        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)tie, rho * LPR + jt / WPL);
-        tw[jt % WPL] = put_lane(tw[jt % WPL], (uint32_t)(tie >> 32), (rho + 4) * LPR + jt / WPL);
+        deposit_abs_below(tw[jt % WPL], acc[jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
       }
     }
   }
