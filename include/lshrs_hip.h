@@ -102,22 +102,6 @@ int lshrs_scatter_band_keys_u8(uint8_t* keys, int32_t num_bands, int32_t band_by
                                const int64_t* rows, const int32_t* bands, const uint8_t* patch, int64_t m,
                                void* stream);
 
-/* HOST-side helper of the tie-break (the one entry point whose pointers are HOST pointers; no GPU work).
- * For pair t: y = cblas_sgemv(ColMajor, Trans, dim, rows, 1, planes[bands[t]], dim, xrows[xindex[t]], 1, 0, y, 1)
- * — the BLAS call NumPy makes for the reference's `projection @ vector` (lshrs/hash/lsh.py:200) — then
- * `y > 0` (:204) and LSB-first packing (:208) into patch[t][0..B).
- *   cblas_sgemv  address of the host BLAS's cblas_sgemv (ilp64 != 0: 64-bit integer interface)
- *   set_num_threads_local  optional: address of openblas_set_num_threads_local(int) — worker threads pin their
- *                BLAS calls to themselves (1) so that they do not serialise on the BLAS thread server
- *   planes       num_bands host pointers to (rows_per_band, dim) f32 matrices (the hasher's `projections`)
- *   xrows        (u, dim) f32 host;  xindex (m,) row of xrows per pair;  bands (m,)
- *   y_out        optional (m, rows_per_band) f32: the raw projections (self-check against NumPy)
- *   threads      worker threads to split the pairs over. */
-int lshrs_host_band_keys_f32(void* cblas_sgemv, int32_t ilp64, void* set_num_threads_local,
-                             const float* const* planes, int32_t rows_per_band,
-                             int32_t dim, const float* xrows, const int64_t* xindex, const int32_t* bands,
-                             int64_t m, uint8_t* patch, float* y_out, int32_t threads);
-
 /* ------------------------------------------------------------------------------------------
  * Cosine rerank — replaces cosine_similarity / top_k_cosine (lshrs/utils/similarity.py:80-90,
  * 157-183) and the per-candidate l2_norm (lshrs/utils/norm.py:48-61).

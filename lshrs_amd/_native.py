@@ -17,7 +17,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCE = os.path.join(CSRC, "lshrs_hip.hip")
-HOST_SOURCE = os.path.join(CSRC, "host_tiebreak.cpp")
 LIBRARY = os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 ABI_VERSION = 1
@@ -36,13 +35,12 @@ class NativeLibraryError(RuntimeError):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP source for gfx950 into the in-tree shared library."""
     with _lock:
-        newest_src = max(os.path.getmtime(SOURCE), os.path.getmtime(HOST_SOURCE),
-                         os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h")))
+        newest_src = max(os.path.getmtime(SOURCE), os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h")))
         if not force and os.path.exists(LIBRARY) and os.path.getmtime(LIBRARY) >= newest_src:
             return LIBRARY
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + INCLUDE,
-               SOURCE, HOST_SOURCE, "-o", LIBRARY + ".tmp"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, SOURCE,
+               "-o", LIBRARY + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
@@ -71,8 +69,6 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_gather_tied_rows_f32.restype = c.c_int
     lib.lshrs_scatter_band_keys_u8.argtypes = [vp, i32, i32, vp, vp, vp, i64, vp]
     lib.lshrs_scatter_band_keys_u8.restype = c.c_int
-    lib.lshrs_host_band_keys_f32.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, i32]
-    lib.lshrs_host_band_keys_f32.restype = c.c_int
     lib.lshrs_cosine_batch_f32.argtypes = [vp, i64, i64, i32, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.lshrs_cosine_batch_f32.restype = c.c_int
     lib.lshrs_l2_normalize_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp]
@@ -91,7 +87,6 @@ EXPORTS = (
     "lshrs_gather_rows_f32",
     "lshrs_gather_tied_rows_f32",
     "lshrs_scatter_band_keys_u8",
-    "lshrs_host_band_keys_f32",
     "lshrs_cosine_batch_f32",
     "lshrs_l2_normalize_f32",
     "lshrs_topk_desc_f32",

@@ -18,11 +18,12 @@ raw kernel bits; ``last_stats`` records how many pairs were touched.
 from __future__ import annotations
 
 import threading
+import time
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from . import _hostblas, _native
+from . import _native
 from ._config import HashSignatures
 
 __all__ = ["LSHHasher"]
@@ -103,10 +104,9 @@ class LSHHasher:
         self._projection_version = 0
         self._workspaces: Dict[int, Tuple[int, object]] = {}
         self.last_stats: Dict[str, int] = {}
-        # set to a list to collect (start, end) torch.cuda.Event pairs around every signature-kernel
-        # launch (bench.py uses it to time the kernel on the stream it runs on)
+        # set to a list to collect (start_event, end_event, rows) around every signature-kernel launch
+        # (bench.py uses it to time the kernel on the stream it runs on)
         self.kernel_events: Optional[list] = None
-        self.native_tie_break = True  # use csrc/host_tiebreak.cpp when it reproduces NumPy bit for bit
         # device batches of >= 2 chunks take the pipelined path; 131072 rows = two full-chip rounds of K1
         self.pipeline_chunk_rows = 131_072
         self._side_streams: Dict[int, object] = {}
@@ -269,7 +269,8 @@ class LSHHasher:
         chunks of ``pipeline_chunk_rows`` (a whole number of full-chip rounds of the kernel); every chunk's
         kernel and its "gather the tied rows" kernel are enqueued back to back on the caller's stream, and
         while the GPU works through them the host resolves the ties of the chunks already finished
-        (count / entries / vectors come back over a side stream, patches go out over it)."""
+        (count / entries / vectors come back over a side stream into two alternating pinned buffers,
+        patches go out over it)."""
         torch = _native.require_gpu()
         lib = _native.load()
         dev = x.device
@@ -311,26 +312,40 @@ class LSHHasher:
                         copied = torch.cuda.Event()
                         copied.record(side)
                     ready.append(copied)
-                for ci, (lo, hi) in enumerate(group):
+
+                def fetch(ci):
+                    """Wait for chunk ci's count, start the D2H of its entries + vectors into slot ci & 1."""
                     ready[ci].synchronize()
                     cnt = int(pin_cnt[ci])
+                    landed = None
+                    if 0 < cnt <= cap:
+                        with torch.cuda.stream(side):
+                            pin_entries[ci & 1, :cnt].copy_(lists[ci, :cnt], non_blocking=True)
+                            pin_rows[ci & 1, :cnt].copy_(stage[ci, :cnt], non_blocking=True)
+                            landed = torch.cuda.Event()
+                            landed.record(side)
+                    return cnt, landed
+
+                nxt = fetch(0)
+                for ci, (lo, hi) in enumerate(group):
+                    t0 = time.perf_counter()
+                    cnt, landed = nxt
+                    if ci + 1 < len(group):
+                        nxt = fetch(ci + 1)  # next chunk's copy runs while this chunk's ties are resolved
                     if cnt > cap:
                         overflow.append((lo, hi))
                         continue
                     stats["tie_entries"] += cnt
                     if cnt == 0:
                         continue
-                    with torch.cuda.stream(side):
-                        pin_entries[:cnt].copy_(lists[ci, :cnt], non_blocking=True)
-                        pin_rows[:cnt].copy_(stage[ci, :cnt], non_blocking=True)
-                    side.synchronize()
-                    entries = pin_entries[:cnt].numpy()
-                    rows, bands = self._tie_pairs(entries)
+                    landed.synchronize()
+                    t1 = time.perf_counter()
+                    entries = pin_entries[ci & 1, :cnt].numpy()
+                    rows, bands, xindex = self._tie_pairs_indexed(entries)
                     stats["tie_pairs"] += int(rows.shape[0])
-                    erow = entries[:, 0] >> 16
-                    order = np.argsort(erow, kind="stable")
-                    xindex = order[np.searchsorted(erow[order], rows)]  # an entry that carries this row's vector
-                    patch = self._tie_patches(pin_rows[:cnt].numpy(), xindex, bands)
+                    t2 = time.perf_counter()
+                    patch = self._tie_patches(pin_rows[ci & 1, :cnt].numpy(), xindex, bands)
+                    t3 = time.perf_counter()
                     with torch.cuda.stream(side):
                         rows_dev = torch.from_numpy(rows).to(dev)
                         bands_dev = torch.from_numpy(bands).to(dev)
@@ -341,6 +356,10 @@ class LSHHasher:
                                                            rows_dev.data_ptr(), bands_dev.data_ptr(),
                                                            patch_dev.data_ptr(), rows.shape[0], side.cuda_stream),
                             "lshrs_scatter_band_keys_u8")
+                    t4 = time.perf_counter()
+                    for key, dt in (("t_wait_ms", t1 - t0), ("t_pairs_ms", t2 - t1), ("t_patch_ms", t3 - t2),
+                                    ("t_scatter_ms", t4 - t3)):
+                        stats[key] = stats.get(key, 0.0) + 1e3 * dt
             main.wait_stream(side)
             side.synchronize()
         for lo, hi in overflow:  # a chunk with more ties than its list holds: redo it on the plain path
@@ -353,6 +372,35 @@ class LSHHasher:
             stats["relaunches"] += 1 + self.last_stats["relaunches"]
         self.last_stats = stats
         return out
+
+    def _tie_pairs_indexed(self, entries: np.ndarray):
+        """Like :meth:`_tie_pairs`, plus for every pair the index of an entry that carries the row's vector
+        (the device stages one vector per entry).  Sorted by band.  Band widths of 8, 16 or 32 columns
+        (rows_per_band <= 32) never give duplicate pairs, so no de-duplication pass is needed there."""
+        band_cols = 8 * self.band_bytes
+        if band_cols not in (8, 16, 32):
+            rows, bands = self._tie_pairs(entries)
+            erow = entries[:, 0] >> 16
+            order = np.argsort(erow, kind="stable")
+            return rows, bands, order[np.searchsorted(erow[order], rows)]
+        erow = entries[:, 0] >> 16
+        words = entries[:, 0] & 0xFFFF
+        masks = entries[:, 1]
+        per_word = 32 // band_cols
+        sub_mask = (1 << band_cols) - 1
+        r_parts, b_parts, e_parts = [], [], []
+        idx = np.arange(entries.shape[0], dtype=np.int64)
+        for sub in range(per_word):
+            band = words * per_word + sub
+            hit = (((masks >> (sub * band_cols)) & sub_mask) != 0) & (band < self.num_bands)
+            r_parts.append(erow[hit])
+            b_parts.append(band[hit])
+            e_parts.append(idx[hit])
+        rows = np.concatenate(r_parts)
+        bands = np.concatenate(b_parts).astype(np.int32)
+        eidx = np.concatenate(e_parts)
+        order = np.argsort(bands, kind="stable")
+        return rows[order].astype(np.int64), bands[order], eidx[order]
 
     def _side_stream(self, dev):
         torch = _native.require_gpu()
@@ -368,8 +416,8 @@ class LSHHasher:
         buf = self._pinned_cache.get(key)
         if buf is None:
             buf = (torch.empty((window,), dtype=torch.int32).pin_memory(),
-                   torch.empty((cap, 2), dtype=torch.int64).pin_memory(),
-                   torch.empty((cap, self.dim), dtype=torch.float32).pin_memory())
+                   torch.empty((2, cap, 2), dtype=torch.int64).pin_memory(),
+                   torch.empty((2, cap, self.dim), dtype=torch.float32).pin_memory())
             self._pinned_cache = {key: buf}
         return buf
 
@@ -383,7 +431,7 @@ class LSHHasher:
         start.record(cur)
         _native.check(lib.lshrs_sig_hash_batch_f32(*args), "lshrs_sig_hash_batch_f32")
         end.record(cur)
-        events.append((start, end))
+        events.append((start, end, int(args[1])))  # args[1] = rows in this launch
 
     def _tie_pairs(self, entries: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """Kernel tie entries ``(row*65536 + word, 32-bit column mask)`` -> unique (row, band) pairs,
@@ -414,29 +462,23 @@ class LSHHasher:
         """Band keys of the flagged (row, band) pairs by the reference's own expression
         (``projection @ vector``, ``> 0``, ``np.packbits(..., bitorder='little')``: lsh.py:200-208).
 
-        Fast path: ``csrc/host_tiebreak.cpp`` issues, per pair, the ``cblas_sgemv`` call that NumPy makes
-        for ``P_band @ x`` — through NumPy's own BLAS, after ``_hostblas.verified_for`` has matched it
-        against NumPy bit for bit for this (rows, dim).  Otherwise ``np.matmul(P_band, X[:, :, None])``,
-        which runs NumPy's matrix @ vector inner loop once per row (same call, same operands; checked in
-        tests/test_tiebreak_host.py).  ``bands`` arrives sorted, so each band is one contiguous slice.
+        ``np.matmul(P_band, X[:, :, None])`` runs NumPy's matrix @ vector inner loop once per row, i.e.
+        it issues the very ``cblas_sgemv`` call ``P_band @ x`` issues (same operands, same shapes, same
+        library) without a Python-level loop; tests/test_tiebreak_host.py checks the two bit for bit.
+        One sgemv of this size costs ~0.6 us and OpenBLAS serialises concurrent callers, so this stays
+        single-threaded.  ``bands`` arrives sorted, so each band is one contiguous slice.
         """
         m = int(bands.shape[0])
-        if m == 0:
-            return np.empty((0, self.band_bytes), dtype=np.uint8)
-        planes = [np.ascontiguousarray(p, dtype=np.float32) for p in self._projections]
-        if self.native_tie_break and m >= 64:
-            lib = _native.load()
-            if _hostblas.verified_for(lib, self.rows_per_band, self.dim):
-                patch = _hostblas.band_keys(lib, planes, xrows, inverse, bands, self.rows_per_band, self.dim,
-                                            _hostblas.worker_threads())
-                if patch is not None:
-                    return patch
         patch = np.empty((m, self.band_bytes), dtype=np.uint8)
+        if m == 0:
+            return patch
+        planes = self._projections
         starts = np.flatnonzero(np.r_[True, bands[1:] != bands[:-1]])
         stops = np.r_[starts[1:], m]
         for lo, hi in zip(starts, stops):
+            plane = np.ascontiguousarray(planes[int(bands[lo])], dtype=np.float32)
             xs = np.ascontiguousarray(xrows[inverse[lo:hi]])
-            y = np.matmul(planes[int(bands[lo])], xs[:, :, None])[:, :, 0]
+            y = np.matmul(plane, xs[:, :, None])[:, :, 0]
             patch[lo:hi] = np.packbits(y > 0, axis=1, bitorder="little")
         return patch
 

@@ -48,27 +48,19 @@ def test_batched_patches_equal_the_reference_expression(nb, r, dim):
     assert h._tie_patches(xrows, inverse[:0], bands[:0]).shape == (0, (r + 7) // 8)
 
 
-@pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (16, 4, 128), (16, 32, 1536), (3, 5, 4), (2, 24, 100), (5, 8, 30)])
-def test_native_loop_is_numpys_sgemv_bit_for_bit(nb, r, dim):
-    """csrc/host_tiebreak.cpp must return the very floats `P_band @ x` returns on this host."""
-    from lshrs_amd import _hostblas, _native
 
-    lib = _native.load()
-    if _hostblas.sgemv_pointer() is None:
-        pytest.skip("NumPy's BLAS exposes no cblas_sgemv symbol here; the NumPy path is used instead")
-    assert _hostblas.verified_for(lib, r, dim)
-    h = LSHHasher(nb, r, dim, seed=9)
-    rng = np.random.default_rng(nb + r + dim)
-    xrows = rng.standard_normal((300, dim)).astype(np.float32)
-    m = 4000
-    inverse = rng.integers(0, 300, size=m)
-    bands = np.sort(rng.integers(0, nb, size=m)).astype(np.int32)
-    planes = [np.ascontiguousarray(p) for p in h.projections]
-    patch, y = _hostblas.band_keys(lib, planes, xrows, inverse, bands, r, dim, threads=4, want_y=True)
-    want = np.stack([h.projections[b] @ xrows[i] for b, i in zip(bands, inverse)])
-    assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
-    assert np.array_equal(patch, np.packbits(want > 0, axis=1, bitorder="little"))
-    # and the hasher picks it up / agrees with its NumPy fallback
-    fast = h._tie_patches(xrows, inverse, bands)
-    h.native_tie_break = False
-    assert np.array_equal(fast, h._tie_patches(xrows, inverse, bands))
+@pytest.mark.parametrize("nb,r", [(16, 16), (16, 4), (16, 32), (5, 12), (2, 24), (4, 64)])
+def test_indexed_pairs_agree_with_plain_pairs(nb, r):
+    h = LSHHasher(nb, r, 32, seed=1)
+    rng = np.random.default_rng(nb * 7 + r)
+    words_max = (nb * 8 * h.band_bytes + 31) // 32
+    m = 2000
+    rows = rng.choice(100_000, m, replace=False)
+    words = rng.integers(0, words_max, m)
+    masks = np.where(rng.random(m) < 0.8, 1 << rng.integers(0, 32, m), rng.integers(1, 2**32, m))
+    ent = np.stack([(rows << 16) | words, masks], axis=1).astype(np.int64)
+    r1, b1 = h._tie_pairs(ent)
+    r2, b2, e2 = h._tie_pairs_indexed(ent)
+    assert sorted(zip(b1.tolist(), r1.tolist())) == sorted(zip(b2.tolist(), r2.tolist()))
+    assert (np.diff(b2) >= 0).all()                 # sorted by band: _tie_patches slices per band
+    assert ((ent[e2, 0] >> 16) == r2).all()         # every pair points at an entry holding its row
