@@ -284,7 +284,10 @@ class LSHHasher:
         keep = []  # device temporaries stay referenced until the streams have been joined
         with torch.cuda.device(dev):
             main = torch.cuda.current_stream(dev)
-            side = self._side_stream(dev)
+            # two in-order side streams: the tiny count copies are all enqueued up front (each behind its own
+            # chunk), so the bulk copies / patches must not queue behind them
+            cstream = self._side_stream(dev, 0)
+            side = self._side_stream(dev, 1)
             pin_cnt, pin_entries, pin_rows = self._pinned(dev, cap, window)
             for w0 in range(0, len(spans), window):
                 group = spans[w0:w0 + window]
@@ -306,19 +309,20 @@ class LSHHasher:
                                                        main.cuda_stream), "lshrs_gather_tied_rows_f32")
                     done = torch.cuda.Event()
                     done.record(main)
-                    side.wait_event(done)
-                    with torch.cuda.stream(side):
+                    cstream.wait_event(done)
+                    with torch.cuda.stream(cstream):
                         pin_cnt[ci:ci + 1].copy_(counts[ci:ci + 1], non_blocking=True)
                         copied = torch.cuda.Event()
-                        copied.record(side)
-                    ready.append(copied)
+                        copied.record(cstream)
+                    ready.append((copied, done))
 
                 def fetch(ci):
                     """Wait for chunk ci's count, start the D2H of its entries + vectors into slot ci & 1."""
-                    ready[ci].synchronize()
+                    ready[ci][0].synchronize()
                     cnt = int(pin_cnt[ci])
                     landed = None
                     if 0 < cnt <= cap:
+                        side.wait_event(ready[ci][1])
                         with torch.cuda.stream(side):
                             pin_entries[ci & 1, :cnt].copy_(lists[ci, :cnt], non_blocking=True)
                             pin_rows[ci & 1, :cnt].copy_(stage[ci, :cnt], non_blocking=True)
@@ -361,6 +365,7 @@ class LSHHasher:
                                     ("t_scatter_ms", t4 - t3)):
                         stats[key] = stats.get(key, 0.0) + 1e3 * dt
             main.wait_stream(side)
+            main.wait_stream(cstream)
             side.synchronize()
         for lo, hi in overflow:  # a chunk with more ties than its list holds: redo it on the plain path
             sub = {"n": hi - lo, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
@@ -402,12 +407,12 @@ class LSHHasher:
         order = np.argsort(bands, kind="stable")
         return rows[order].astype(np.int64), bands[order], eidx[order]
 
-    def _side_stream(self, dev):
+    def _side_stream(self, dev, which: int = 0):
         torch = _native.require_gpu()
-        s = self._side_streams.get(dev.index)
+        s = self._side_streams.get((dev.index, which))
         if s is None:
             s = torch.cuda.Stream(device=dev)
-            self._side_streams[dev.index] = s
+            self._side_streams[(dev.index, which)] = s
         return s
 
     def _pinned(self, dev, cap: int, window: int):
