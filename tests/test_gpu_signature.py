@@ -256,3 +256,23 @@ def test_tie_list_overflow_is_recovered(torch_mod):
     got = h.hash_batch_packed(x)
     assert h.last_stats["relaunches"] > 0
     assert np.array_equal(got, hash_batch_literal_packed(h.projections, x))
+
+
+def test_tie_window_margin(torch_mod):
+    """The tie window must be comfortably wider than the real disagreement between the GPU's fmaf chain
+    and this host's BLAS for projections near zero (where a sign can flip): >= 4x here."""
+    torch = torch_mod
+    u = 2.0 ** -24
+    h = _hasher(42, 16, 16, 768)
+    x = np.random.default_rng(2718).standard_normal((120_000, 768)).astype(np.float32)
+    y_gpu = h.project_device(torch.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+    y_cpu = np.concatenate([np.matmul(p, x[:, :, None])[:, :, 0] for p in h.projections], axis=1).astype(np.float64)
+    scale = (np.linalg.norm(x.astype(np.float64), axis=1)[:, None]
+             * np.linalg.norm(np.concatenate(h.projections).astype(np.float64), axis=1)[None, :] * u)
+    near = np.minimum(np.abs(y_gpu), np.abs(y_cpu)) / scale < 4 * h.tau_ulps
+    assert near.sum() > 1000
+    worst = float((np.abs(y_gpu - y_cpu) / scale)[near].max())
+    assert worst * 4 <= h.tau_ulps, f"GPU-vs-BLAS discrepancy near zero is {worst:.2f} units; window {h.tau_ulps}"
+    flips = (y_gpu > 0) != (y_cpu > 0)
+    if flips.any():
+        assert float((np.abs(y_gpu) / scale)[flips].max()) * 4 <= h.tau_ulps
