@@ -31,7 +31,8 @@ constexpr int kKTile = 32;        // k per LDS tile; MFMA step s uses k = s (lan
 constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
 // Waves per workgroup is a template parameter W: 4 (one wave per SIMD, two workgroups per CU, so the two
 // waves sharing a SIMD belong to different workgroups and never wait at the same barrier) or 8.
-int g_sig_waves = 4;              // tuning knob for A/B runs (lshrs_debug_set_sig_waves); not part of the ABI
+int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
+int g_sig_pipe = 1;               // 1: ring-buffered main loop, 0: two whole-tile buffers
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
 struct SigGeom {
@@ -173,6 +174,70 @@ __device__ __forceinline__ void stage_p_tile(const float* __restrict__ tile, flo
   }
 }
 
+// ---- ring-buffered main loop (PIPE = 1) -----------------------------------------------------------
+// Same arithmetic, same summation order as the plain loop; only the staging differs.  A 32-deep k-tile is
+// handled as two HALVES (fragments q = 0,1 then q = 2,3 of every column tile: MFMA steps s = 0..7 and 8..15).
+// Halves go through a ring of three LDS buffers, staged two halves ahead, and the fragments of the next
+// group are read while the current group's MFMAs issue, so no ds_read latency is exposed behind the
+// barrier that ends each half.
+template <int NT, int W>
+__device__ __forceinline__ void stage_p_half(const float* __restrict__ tile, int part, float* lds_buf, int tid) {
+  constexpr int kThreads = W * 64;
+  constexpr int kBlocks = NT * 2;  // (jt, qq) fragment blocks of 1 KiB in one half
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int base = 0; base < kBlocks; base += kThreads / 64) {
+    const int blk = base + wave;  // wave-uniform
+    if (blk < kBlocks) {
+      const int jt = blk >> 1, qq = blk & 1;
+      const float* g = tile + (size_t)(((jt * 4 + 2 * part + qq) * 64) + lane) * 4;
+      float* l = lds_buf + (size_t)blk * kFragFloats;  // wave-uniform base; hardware adds lane*16
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 16, 0, 0);
+    }
+  }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void load_x_half(const float* __restrict__ xrow, int kbase, int dim, f32x4 (&a)[2]) {
+  // lane (i, h) owns k = kbase + 4qq + r (kbase already holds 32*kt + 16*h + 8*part): 32 contiguous bytes
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const int k = kbase + 4 * qq;
+    if (ALIGNED) {
+      if (k < dim)
+        a[qq] = *reinterpret_cast<const f32x4*>(xrow + k);
+      else
+        a[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (k + r < dim) ? xrow[k + r] : 0.f;
+      a[qq] = v;
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void read_frags(const float* lds_buf, int qq, int lane, f32x4 (&b)[NT]) {
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt)
+    b[jt] = *reinterpret_cast<const f32x4*>(lds_buf + ((jt * 2 + qq) * 64 + lane) * 4);
+}
+
+template <int NT>
+__device__ __forceinline__ void mfma_group(const f32x4& a, const f32x4 (&b)[NT], f32x16 (&acc)[NT], float& ss,
+                                           float& amax) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float av = a[r];
+    ss = __builtin_fmaf(av, av, ss);
+    amax = __builtin_fmaxf(amax, __builtin_fabsf(av));
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[jt], 0, 0, 0);
+  }
+}
+
 // Ballot + deposit in one block.  The 64-lane compare result (VCC: low half = the 32 columns of row rho,
 // high half = the same columns of row rho + 4) is written into the two lanes that own those output
 // words with v_writelane_b32 (immediate lane select; this clang exposes no builtin for it).
@@ -199,12 +264,14 @@ __device__ __forceinline__ void deposit_abs_below(uint32_t& word, float y, float
 }
 
 // MODE 0: keys only, 1: keys + tie list, 2: raw projections (diagnostic)
-template <int NT, bool ALIGNED, int MODE, int W>
+template <int NT, bool ALIGNED, int MODE, int W, int PIPE>
 __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
   constexpr bool PROJECT = MODE == 2;
   constexpr int kTileFloats = NT * 4 * kFragFloats;
+  constexpr int kHalfFloats = NT * 2 * kFragFloats;
+  constexpr int kStageFloats = PIPE ? 3 * kHalfFloats : 2 * kTileFloats;  // ring of 3 halves, or 2 whole tiles
   constexpr int kBlockRows = W * kRowsPerWave;
-  __shared__ __attribute__((aligned(16))) float lds[2 * kTileFloats + W * 32];
+  __shared__ __attribute__((aligned(16))) float lds[kStageFloats + W * 32];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -226,39 +293,73 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
 
-  f32x4 a_cur[4], a_nxt[4];
   float ss = 0.f;    // sum of squares of this lane's share of the row
   float amax = 0.f;  // max |x| of this lane's share (NaN-ignoring; NaN shows up in ss)
 
-  stage_p_tile<NT, W>(img, lds, tid);
-  load_x_tile<ALIGNED>(xrow, 16 * h, dim, a_cur);
-  __syncthreads();
-
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const float* lb = lds + (kt & 1) * kTileFloats;
-    if (kt + 1 < ktiles) {
-      stage_p_tile<NT, W>(img + (size_t)(kt + 1) * kTileFloats, lds + ((kt + 1) & 1) * kTileFloats, tid);
-      load_x_tile<ALIGNED>(xrow, (kt + 1) * kKTile + 16 * h, dim, a_nxt);
+  if (PIPE) {
+    const int halves = 2 * ktiles;
+    f32x4 a_cur[2], a_nxt[2];
+    f32x4 b0[NT], b1[NT];
+    stage_p_half<NT, W>(img, 0, lds, tid);
+    stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
+    load_x_half<ALIGNED>(xrow, 16 * h, dim, a_cur);
+    __syncthreads();
+    read_frags<NT>(lds, 0, lane, b0);
+    // land b0 before the loop, so that on every path into the loop header nothing is pending and the
+    // compiler's wait before group 1 can be a counted lgkmcnt (b1 only), not a drain
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int hh = 0; hh < halves; ++hh) {
+      const float* cur = lds + (hh % 3) * kHalfFloats;
+      if (hh + 2 < halves)
+        stage_p_half<NT, W>(img + (size_t)((hh + 2) >> 1) * kTileFloats, (hh + 2) & 1, lds + ((hh + 2) % 3) * kHalfFloats,
+                            tid);
+      if (hh + 1 < halves)
+        load_x_half<ALIGNED>(xrow, ((hh + 1) >> 1) * kKTile + 16 * h + 8 * ((hh + 1) & 1), dim, a_nxt);
+      // Issue order is pinned (sched_barrier): left alone, the scheduler sinks each ds_read group down to its
+      // first use and the wave then sits out the LDS latency with the matrix pipe idle.
+      read_frags<NT>(cur, 1, lane, b1);                       // lands while group 0 issues
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group<NT>(a_cur[0], b0, acc, ss, amax);
+      // b1 was issued a whole group (32 MFMAs) ago: this wait is free, and taking it BEFORE the next reads are
+      // issued keeps it from turning into a drain of those reads (hipcc emits lgkmcnt(0), not a counted wait)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      // next half's first fragments (visible since the last barrier).  Unconditional on purpose: after the last
+      // half this reads a stale ring slot that nobody uses, which keeps the wait counters branch-free.
+      read_frags<NT>(lds + ((hh + 1) % 3) * kHalfFloats, 0, lane, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group<NT>(a_cur[1], b1, acc, ss, amax);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      a_cur[0] = a_nxt[0];
+      a_cur[1] = a_nxt[1];
     }
+  } else {
+    f32x4 a_cur[4], a_nxt[4];
+    stage_p_tile<NT, W>(img, lds, tid);
+    load_x_tile<ALIGNED>(xrow, 16 * h, dim, a_cur);
+    __syncthreads();
+
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const float* lb = lds + (kt & 1) * kTileFloats;
+      if (kt + 1 < ktiles) {
+        stage_p_tile<NT, W>(img + (size_t)(kt + 1) * kTileFloats, lds + ((kt + 1) & 1) * kTileFloats, tid);
+        load_x_tile<ALIGNED>(xrow, (kt + 1) * kKTile + 16 * h, dim, a_nxt);
+      }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 b[NT];
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-        b[jt] = *reinterpret_cast<const f32x4*>(lb + ((jt * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float av = a_cur[q][r];
-        ss = __builtin_fmaf(av, av, ss);
-        amax = __builtin_fmaxf(amax, __builtin_fabsf(av));
+      for (int q = 0; q < 4; ++q) {
+        f32x4 b[NT];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
-          acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[jt], 0, 0, 0);
+          b[jt] = *reinterpret_cast<const f32x4*>(lb + ((jt * 4 + q) * 64 + lane) * 4);
+        mfma_group<NT>(a_cur[q], b, acc, ss, amax);
       }
-    }
-    __syncthreads();
+      __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    }
   }
 
   // accumulator map (32x32 tile): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -276,7 +377,7 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
   // ---- row statistics: ||x||, zero-vector flag ------------------------------------------
   ss += __shfl_xor(ss, 32);
   amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32));
-  float* norm_lds = lds + 2 * kTileFloats + wave * 32;
+  float* norm_lds = lds + kStageFloats + wave * 32;
   if (h == 0) {
     norm_lds[i] = sqrtf(ss) * args.tau;
     if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
@@ -379,11 +480,21 @@ int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project,
   const dim3 grid((unsigned)((a.n + kBlockRows - 1) / kBlockRows), (unsigned)g.cb, 1);
   const dim3 block(W * 64, 1, 1);
   const int mode = project ? 2 : (a.tie_list != nullptr ? 1 : 0);
-#define LSHRS_LAUNCH(AL, MD) hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W>), grid, block, 0, s, a)
+#define LSHRS_LAUNCH(AL, MD)                                                         \
+  do {                                                                               \
+    if (g_sig_pipe)                                                                  \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1>), grid, block, 0, s, a);     \
+    else                                                                             \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 0>), grid, block, 0, s, a);     \
+  } while (0)
   if (aligned) {
-    if (mode == 0) LSHRS_LAUNCH(true, 0); else if (mode == 1) LSHRS_LAUNCH(true, 1); else LSHRS_LAUNCH(true, 2);
+    if (mode == 0) LSHRS_LAUNCH(true, 0);
+    else if (mode == 1) LSHRS_LAUNCH(true, 1);
+    else LSHRS_LAUNCH(true, 2);
   } else {
-    if (mode == 0) LSHRS_LAUNCH(false, 0); else if (mode == 1) LSHRS_LAUNCH(false, 1); else LSHRS_LAUNCH(false, 2);
+    if (mode == 0) LSHRS_LAUNCH(false, 0);
+    else if (mode == 1) LSHRS_LAUNCH(false, 1);
+    else LSHRS_LAUNCH(false, 2);
   }
 #undef LSHRS_LAUNCH
   return -(int)hipGetLastError();
@@ -633,6 +744,10 @@ int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
 int lshrs_debug_set_sig_waves(int w) {
   if (w != 4 && w != 8) return LSHRS_E_BADARG;
   g_sig_waves = w;
+  return 0;
+}
+int lshrs_debug_set_sig_pipe(int p) {
+  g_sig_pipe = p ? 1 : 0;
   return 0;
 }
 

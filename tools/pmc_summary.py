@@ -12,7 +12,7 @@ for d in sys.argv[1:]:
                 name = row.get("Kernel_Name") or row.get("kernel_name") or ""
                 if not any(k in name for k in KEEP):
                     continue
-                short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:70]
+                short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 counters = sorted({c for k in acc.values() for c in k})
 print("| kernel | dispatches | " + " | ".join(counters) + " |")
