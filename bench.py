@@ -39,6 +39,15 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (spe
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 
 
+def pmc_traffic(kernel: str, field: str, units: float):
+    """HBM bytes per launch measured by the PMC passes committed under profiles/ (None if absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            return json.load(fh)[kernel][field] * units
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,7 +166,9 @@ def main() -> None:
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic("sig_kernel", "hbm_bytes_per_row", rows_per_launch_mean),
+                "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_traffic.json: "
+                                "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), scaled to this launch's rows",
                 "kernel_ms_mean": kernel_ms_mean,
                 "launches_timed": len(kernel_ms),
                 "launches_per_step": len(kernel_ms) / max(1, args.steps),
@@ -251,7 +262,8 @@ def bench_rerank(torch, dev, corpus, np, with_cpu: bool):
         "roofline": {
             "kernel": "cosine_kernel<true>", "bound": "hbm", "achieved": bytes_per_launch / (cos_ms * 1e-3) / 1e9,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / (cos_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "traffic": None, "kernel_ms": cos_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "traffic": pmc_traffic("cosine_kernel", "hbm_bytes_per_candidate", q * c), "kernel_ms": cos_ms,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
         },
         "topk_ms": total_ms - cos_ms,
     }
