@@ -33,6 +33,7 @@ constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
 // waves sharing a SIMD belong to different workgroups and never wait at the same barrier) or 8.
 int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
 int g_sig_pipe = 1;               // 1: ring-buffered main loop, 0: two whole-tile buffers
+int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
 struct SigGeom {
@@ -58,6 +59,26 @@ inline SigGeom sig_geom(int num_bands, int rows, int dim) {
 inline int64_t sig_image_floats(const SigGeom& g) { return (int64_t)g.cb * g.ktiles * g.nt * 4 * kFragFloats; }
 inline int64_t sig_norm_floats(const SigGeom& g) { return (int64_t)g.cb * g.nt * 32; }
 inline int64_t sig_normmax_floats(const SigGeom& g) { return ((int64_t)g.cb + 3) & ~(int64_t)3; }
+
+// "Fine" geometry: one 32-column tile per workgroup (NT = 1, one column block per tile).  Same arithmetic per
+// projection; 8x more, 8x shorter workgroups than NT = 8.  Used where a launch cannot fill the chip with
+// NT = 8 workgroups: small batches (a single query vector: 1/8 of the latency) and the partial last round of
+// a large batch.  Its image follows the main one in the workspace; the per-column norms are shared.
+inline SigGeom sig_fine_geom(const SigGeom& g) {
+  SigGeom f = g;
+  f.nt = 1;
+  f.cb = g.tiles32;
+  return f;
+}
+inline bool sig_has_fine(const SigGeom& g) { return g.nt > 1; }
+inline int64_t sig_main_floats(const SigGeom& g) { return sig_image_floats(g) + sig_norm_floats(g) + sig_normmax_floats(g); }
+inline int64_t sig_workspace_floats(const SigGeom& g) {
+  if (!sig_has_fine(g)) return sig_main_floats(g);
+  const SigGeom f = sig_fine_geom(g);
+  return sig_main_floats(g) + sig_image_floats(f) + sig_normmax_floats(f);
+}
+constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
+constexpr int64_t kFineMaxRows = 36864;     // up to ~0.56 of a round the fine geometry finishes sooner (measured)
 
 // ------------------------------------------------------------------------------------------
 // Hyperplane re-layout.  image[cb][kt][jt][q][lane][r] = P'[col = (cb*NT + jt)*32 + (lane&31)]
@@ -128,6 +149,7 @@ struct SigArgs {
   uint8_t* keys;
   int row_bytes;       // num_bands * bb
   int vec_store;       // 1: rows of keys may be written with aligned vector stores
+  int64_t row_base;    // added to the row index reported in tie entries (launches over a row sub-range)
   int64_t* tie_list;
   int tie_cap;
   int* tie_count;
@@ -465,7 +487,7 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
         if (tw[w] != 0u) {
           const int slot = atomicAdd(args.tie_count, 1);
           if (slot < args.tie_cap) {
-            args.tie_list[2 * (int64_t)slot] = grow * 65536 + (word0 + w);
+            args.tie_list[2 * (int64_t)slot] = (grow + args.row_base) * 65536 + (word0 + w);
             args.tie_list[2 * (int64_t)slot + 1] = (int64_t)tw[w];
           }
         }
@@ -750,6 +772,11 @@ int lshrs_debug_set_sig_pipe(int p) {
   g_sig_pipe = p ? 1 : 0;
   return 0;
 }
+int lshrs_debug_set_sig_fine(int f) {
+  if (f < 0 || f > 2) return LSHRS_E_BADARG;
+  g_sig_fine = f;
+  return 0;
+}
 
 static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
   if (num_bands <= 0 || rows <= 0 || dim <= 0) return false;
@@ -760,7 +787,7 @@ static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
 int64_t lshrs_sig_workspace_bytes(int32_t num_bands, int32_t rows_per_band, int32_t dim) {
   if (!sig_shape_ok(num_bands, rows_per_band, dim)) return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
-  return (sig_image_floats(g) + sig_norm_floats(g) + sig_normmax_floats(g)) * (int64_t)sizeof(float);
+  return sig_workspace_floats(g) * (int64_t)sizeof(float);
 }
 
 int32_t lshrs_sig_padded_columns(int32_t num_bands, int32_t rows_per_band) {
@@ -785,6 +812,15 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
                      dim, g.bb, cols, norms);
   hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((g.cb + 63) / 64)), dim3(64), 0, s, norms, g.nt * 32, g.cb,
                      norms + sig_norm_floats(g));
+  if (sig_has_fine(g)) {
+    const SigGeom f = sig_fine_geom(g);
+    float* fimage = image + sig_main_floats(g);
+    const int64_t fchunks = sig_image_floats(f) / 4;
+    hipLaunchKernelGGL(pack_image_kernel, dim3((unsigned)((fchunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                       rows_per_band, dim, f.bb, f.nt, f.ktiles, fchunks, reinterpret_cast<f32x4*>(fimage));
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((f.cb + 63) / 64)), dim3(64), 0, s, norms, 32, f.cb,
+                       fimage + sig_image_floats(f));
+  }
   return -(int)hipGetLastError();
 }
 
@@ -799,25 +835,49 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
   if (n >= ((int64_t)1 << 47)) return LSHRS_E_TOOLARGE;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   if ((n + 127) / 128 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
-  SigArgs a{};
-  a.X = X;
-  a.n = n;
-  a.ldx = ldx;
-  a.dim = dim;
-  a.ktiles = g.ktiles;
-  a.image = static_cast<const float*>(workspace);
-  a.norms = a.image + sig_image_floats(g);
-  a.norm_max = a.norms + sig_norm_floats(g);
-  a.keys = keys;
-  a.row_bytes = num_bands * g.bb;
-  const int wpl_bytes = g.nt >= 2 ? 2 * g.nt : 4;  // bytes one lane stores
-  a.vec_store = (a.row_bytes % wpl_bytes == 0) && ((reinterpret_cast<uintptr_t>(keys) % wpl_bytes) == 0);
-  a.tie_list = tie_list;
-  a.tie_cap = tie_cap;
-  a.tie_count = tie_count;
-  a.tau = tau;
-  a.row_flags = row_flags;
-  return dispatch_sig(a, g, false, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* base = static_cast<const float*>(workspace);
+  const int row_bytes = num_bands * g.bb;
+  // One launch covers rows [lo, hi) with either geometry.
+  auto launch = [&](int64_t lo, int64_t hi, bool fine) -> int {
+    const SigGeom gg = fine ? sig_fine_geom(g) : g;
+    SigArgs a{};
+    a.X = X + lo * ldx;
+    a.n = hi - lo;
+    a.ldx = ldx;
+    a.dim = dim;
+    a.ktiles = gg.ktiles;
+    a.norms = base + sig_image_floats(g);                       // per padded column: shared by both geometries
+    if (fine) {
+      a.image = base + sig_main_floats(g);
+      a.norm_max = a.image + sig_image_floats(gg);
+    } else {
+      a.image = base;
+      a.norm_max = a.norms + sig_norm_floats(g);
+    }
+    a.keys = keys + lo * row_bytes;
+    a.row_bytes = row_bytes;
+    const int wpl_bytes = gg.nt >= 2 ? 2 * gg.nt : 4;  // bytes one lane stores
+    a.vec_store = (row_bytes % wpl_bytes == 0) && ((reinterpret_cast<uintptr_t>(a.keys) % wpl_bytes) == 0);
+    a.row_base = lo;
+    a.tie_list = tie_list;
+    a.tie_cap = tie_cap;
+    a.tie_count = tie_count;
+    a.tau = tau;
+    a.row_flags = row_flags != nullptr ? row_flags + lo : nullptr;
+    return dispatch_sig(a, gg, false, s);
+  };
+  // Whole rounds of NT-wide workgroups first; what is left (less than one round) takes the fine geometry when
+  // that finishes sooner than one more full-length, mostly idle round.
+  const bool fine_ok = sig_has_fine(g) && g_sig_fine != 0 && g.tiles32 <= 65535;
+  const int64_t n_main = (n / kRoundRows) * kRoundRows;
+  const int64_t tail = n - n_main;
+  if (n_main > 0) {
+    const int rc = launch(0, n_main, false);
+    if (rc != 0) return rc;
+  }
+  if (tail > 0) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || tail <= kFineMaxRows));
+  return 0;
 }
 
 int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
@@ -829,18 +889,31 @@ int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* wo
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   if (ldy < (int64_t)g.cb * g.nt * 32) return LSHRS_E_BADARG;
   if ((n + 127) / 128 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
-  SigArgs a{};
-  a.X = X;
-  a.n = n;
-  a.ldx = ldx;
-  a.dim = dim;
-  a.ktiles = g.ktiles;
-  a.image = static_cast<const float*>(workspace);
-  a.norms = a.image + sig_image_floats(g);
-  a.norm_max = a.norms + sig_norm_floats(g);
-  a.Y = Y;
-  a.ldy = ldy;
-  return dispatch_sig(a, g, true, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* base = static_cast<const float*>(workspace);
+  auto launch = [&](int64_t lo, int64_t hi, bool fine) -> int {  // same launch plan as the hashing entry point
+    const SigGeom gg = fine ? sig_fine_geom(g) : g;
+    SigArgs a{};
+    a.X = X + lo * ldx;
+    a.n = hi - lo;
+    a.ldx = ldx;
+    a.dim = dim;
+    a.ktiles = gg.ktiles;
+    a.norms = base + sig_image_floats(g);
+    a.image = fine ? base + sig_main_floats(g) : base;
+    a.norm_max = fine ? a.image + sig_image_floats(gg) : a.norms + sig_norm_floats(g);
+    a.Y = Y + lo * ldy;
+    a.ldy = ldy;
+    return dispatch_sig(a, gg, true, s);
+  };
+  const bool fine_ok = sig_has_fine(g) && g_sig_fine != 0 && g.tiles32 <= 65535;
+  const int64_t n_main = (n / kRoundRows) * kRoundRows;
+  if (n_main > 0) {
+    const int rc = launch(0, n_main, false);
+    if (rc != 0) return rc;
+  }
+  if (n > n_main) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || n - n_main <= kFineMaxRows));
+  return 0;
 }
 
 int lshrs_gather_rows_f32(const float* X, int64_t ldx, int32_t dim, const int64_t* rows, int64_t m, float* dst,

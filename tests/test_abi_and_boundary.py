@@ -61,9 +61,10 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_padded_columns(16, 32) == 512
     assert lib.lshrs_sig_padded_columns(3, 5) == 32
     assert lib.lshrs_sig_padded_columns(0, 5) < 0
-    # image: padded columns x dim rounded up to 32, one norm per padded column, one max-norm per column block (x4)
-    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (256 * 768 + 256 + 4) * 4
-    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (512 * 1536 + 512 + 4) * 4
+    # main image (padded columns x dim rounded up to 32) + one norm per padded column + one max-norm per column
+    # block (x4); shapes wider than one 32-column tile also carry the fine (one tile per workgroup) image
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (2 * 256 * 768 + 256 + 4 + 8) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (2 * 512 * 1536 + 512 + 4 + 16) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device

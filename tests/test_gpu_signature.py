@@ -276,3 +276,34 @@ def test_tie_window_margin(torch_mod):
     flips = (y_gpu > 0) != (y_cpu > 0)
     if flips.any():
         assert float((np.abs(y_gpu) / scale)[flips].max()) * 4 <= h.tau_ulps
+
+
+def test_launch_plan_main_rounds_plus_fine_tail(torch_mod):
+    """70 000 rows = one full round of 8-tile workgroups + a 4 464-row tail on the one-tile ('fine') geometry:
+    both geometries must produce the same fmaf chain, the same keys, and tie entries with global row numbers."""
+    torch = torch_mod
+    from lshrs_amd import _native
+    from oracle.build import chain_hash_packed, chain_project
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    lib = _native.load()
+    h = _hasher(42, 16, 16, 768)
+    x = np.random.default_rng(4242).standard_normal((70_000, 768)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    y = h.project_device(xd).cpu().numpy()
+    for sl in (slice(0, 256), slice(65_400, 65_700), slice(69_700, 70_000)):
+        assert np.array_equal(y[sl], chain_project(h.projections, x[sl]))
+    try:
+        outs = {}
+        for mode in (0, 1, 2):                    # never / automatic / always fine
+            assert lib.lshrs_debug_set_sig_fine(mode) == 0
+            outs[mode] = (h.hash_device(xd, tie_break="none").cpu().numpy(), h.hash_device(xd).cpu().numpy(),
+                          dict(h.last_stats))
+    finally:
+        lib.lshrs_debug_set_sig_fine(1)
+    for mode in (0, 2):
+        assert np.array_equal(outs[mode][0], outs[1][0]) and np.array_equal(outs[mode][1], outs[1][1])
+        assert outs[mode][2]["tie_pairs"] == outs[1][2]["tie_pairs"]
+    sl = slice(64_000, 68_000)
+    assert np.array_equal(outs[1][0][sl], chain_hash_packed(h.projections, x[sl]))
+    assert np.array_equal(outs[1][1][sl], hash_batch_literal_packed(h.projections, x[sl]))
