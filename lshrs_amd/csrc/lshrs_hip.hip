@@ -32,7 +32,7 @@ constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
 // Waves per workgroup is a template parameter W: 4 (one wave per SIMD, two workgroups per CU, so the two
 // waves sharing a SIMD belong to different workgroups and never wait at the same barrier) or 8.
 int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
-int g_sig_pipe = 1;               // 1: ring-buffered main loop, 0: two whole-tile buffers
+int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles, 2: ring + counted vmcnt waits
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
@@ -78,7 +78,16 @@ inline int64_t sig_workspace_floats(const SigGeom& g) {
   return sig_main_floats(g) + sig_image_floats(f) + sig_normmax_floats(f);
 }
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
-constexpr int64_t kFineMaxRows = 36864;     // up to ~0.56 of a round the fine geometry finishes sooner (measured)
+
+// Which geometry finishes a partial round (m < kRoundRows rows) sooner?  Cost model fitted to
+// profiles/r01_fine_sweep.log (MI355X): NT-wide workgroups run in layers of one workgroup per CU, each layer
+// taking about one tile time (~4.4 us per 32-deep k-tile + launch); the fine geometry is close to linear in the work.
+inline bool sig_prefer_fine(const SigGeom& g, int64_t m) {
+  const double layers = (double)(((m + 127) / 128 * g.cb + 255) / 256);
+  const double t_main = layers * (4.4 * g.ktiles + 10.0);
+  const double t_fine = 30.0 + 2.3e-5 * (double)m * g.tiles32 * g.ktiles;
+  return t_fine < t_main;
+}
 
 // ------------------------------------------------------------------------------------------
 // Hyperplane re-layout.  image[cb][kt][jt][q][lane][r] = P'[col = (cb*NT + jt)*32 + (lane&31)]
@@ -260,6 +269,33 @@ __device__ __forceinline__ void mfma_group(const f32x4& a, const f32x4 (&b)[NT],
   }
 }
 
+// ---- counted-wait main loop (PIPE = 2, 16-byte aligned rows only) -----------------------------------
+// Same ring and arithmetic as PIPE = 1, but no vmcnt(0) drain before the barriers: the X loads for k-tile
+// kt+1 are issued (inline asm, so hipcc does not turn their first use into a drain of the LDS-DMA queue)
+// right after the LDS-DMA of half 2kt+2, and the barrier that ends half 2kt waits with vmcnt(4) — the DMA
+// has landed, the four X loads stay in flight for one more half (HBM latency under load is ~2 us, one
+// half is ~1.7 us).  The barrier ending half 2kt+1 waits vmcnt(0).  Every thread issues the same number of
+// loads every k-tile (out-of-range k is clamped to 0 and the value zeroed), so the counts are exact.
+__device__ __forceinline__ f32x4 asm_load_x4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ void load_x_tile_counted(const float* __restrict__ xrow, int kbase, int dim, f32x4 (&a)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = kbase + 4 * q;
+    a[q] = asm_load_x4(xrow + (k < dim ? k : 0));
+  }
+}
+
+__device__ __forceinline__ void mask_x_tile(int kbase, int dim, f32x4 (&a)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (kbase + 4 * q >= dim) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // Ballot + deposit in one block.  The 64-lane compare result (VCC: low half = the 32 columns of row rho,
 // high half = the same columns of row rho + 4) is written into the two lanes that own those output
 // words with v_writelane_b32 (immediate lane select; this clang exposes no builtin for it).
@@ -291,7 +327,7 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
   constexpr bool PROJECT = MODE == 2;
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kHalfFloats = NT * 2 * kFragFloats;
-  constexpr int kStageFloats = PIPE ? 3 * kHalfFloats : 2 * kTileFloats;  // ring of 3 halves, or 2 whole tiles
+  constexpr int kStageFloats = PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats;  // ring of 3 halves, or 2 whole tiles
   constexpr int kBlockRows = W * kRowsPerWave;
   __shared__ __attribute__((aligned(16))) float lds[kStageFloats + W * 32];
 
@@ -318,7 +354,58 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
   float ss = 0.f;    // sum of squares of this lane's share of the row
   float amax = 0.f;  // max |x| of this lane's share (NaN-ignoring; NaN shows up in ss)
 
-  if (PIPE) {
+  if (PIPE == 2) {
+    // one iteration = one 32-deep k-tile = two halves; see the comment at asm_load_x4
+    f32x4 a_cur[4], a_nxt[4];
+    f32x4 b0[NT], b1[NT];
+    const int halves = 2 * ktiles;
+    stage_p_half<NT, W>(img, 0, lds, tid);
+    stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
+    load_x_tile_counted(xrow, 16 * h, dim, a_cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    mask_x_tile(16 * h, dim, a_cur);
+    read_frags<NT>(lds, 0, lane, b0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const int hh = 2 * kt;
+      // ---------------- half 0 of the k-tile ----------------
+      if (hh + 2 < halves) stage_p_half<NT, W>(img + (size_t)(kt + 1) * kTileFloats, 0, lds + ((hh + 2) % 3) * kHalfFloats, tid);
+      load_x_tile_counted(xrow, kt + 1 < ktiles ? (kt + 1) * kKTile + 16 * h : 16 * h, dim, a_nxt);  // always 4 loads
+      read_frags<NT>(lds + (hh % 3) * kHalfFloats, 1, lane, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group<NT>(a_cur[0], b0, acc, ss, amax);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags<NT>(lds + ((hh + 1) % 3) * kHalfFloats, 0, lane, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group<NT>(a_cur[1], b1, acc, ss, amax);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the LDS-DMA of half hh+2 has landed; 4 X loads stay in flight
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- half 1 ----------------
+      if (hh + 3 < halves) stage_p_half<NT, W>(img + (size_t)(kt + 1) * kTileFloats, 1, lds + ((hh + 3) % 3) * kHalfFloats, tid);
+      read_frags<NT>(lds + ((hh + 1) % 3) * kHalfFloats, 1, lane, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group<NT>(a_cur[2], b0, acc, ss, amax);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags<NT>(lds + ((hh + 2) % 3) * kHalfFloats, 0, lane, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group<NT>(a_cur[3], b1, acc, ss, amax);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of half hh+3 and the X loads of k-tile kt+1 (two halves old)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mask_x_tile(kt + 1 < ktiles ? (kt + 1) * kKTile + 16 * h : dim, dim, a_nxt);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    }
+  } else if (PIPE == 1) {
     const int halves = 2 * ktiles;
     f32x4 a_cur[2], a_nxt[2];
     f32x4 b0[NT], b1[NT];
@@ -502,12 +589,14 @@ int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project,
   const dim3 grid((unsigned)((a.n + kBlockRows - 1) / kBlockRows), (unsigned)g.cb, 1);
   const dim3 block(W * 64, 1, 1);
   const int mode = project ? 2 : (a.tie_list != nullptr ? 1 : 0);
-#define LSHRS_LAUNCH(AL, MD)                                                         \
-  do {                                                                               \
-    if (g_sig_pipe)                                                                  \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1>), grid, block, 0, s, a);     \
-    else                                                                             \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 0>), grid, block, 0, s, a);     \
+#define LSHRS_LAUNCH(AL, MD)                                                                   \
+  do {                                                                                         \
+    if (g_sig_pipe == 2 && AL)                                                                 \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, (AL ? 2 : 1)>), grid, block, 0, s, a);    \
+    else if (g_sig_pipe != 0)                                                                  \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1>), grid, block, 0, s, a);               \
+    else                                                                                       \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 0>), grid, block, 0, s, a);               \
   } while (0)
   if (aligned) {
     if (mode == 0) LSHRS_LAUNCH(true, 0);
@@ -769,7 +858,8 @@ int lshrs_debug_set_sig_waves(int w) {
   return 0;
 }
 int lshrs_debug_set_sig_pipe(int p) {
-  g_sig_pipe = p ? 1 : 0;
+  if (p < 0 || p > 2) return LSHRS_E_BADARG;
+  g_sig_pipe = p;
   return 0;
 }
 int lshrs_debug_set_sig_fine(int f) {
@@ -876,7 +966,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
     const int rc = launch(0, n_main, false);
     if (rc != 0) return rc;
   }
-  if (tail > 0) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || tail <= kFineMaxRows));
+  if (tail > 0) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || sig_prefer_fine(g, tail)));
   return 0;
 }
 
@@ -912,7 +1002,7 @@ int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* wo
     const int rc = launch(0, n_main, false);
     if (rc != 0) return rc;
   }
-  if (n > n_main) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || n - n_main <= kFineMaxRows));
+  if (n > n_main) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || sig_prefer_fine(g, n - n_main)));
   return 0;
 }
 
