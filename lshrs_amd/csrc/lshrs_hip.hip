@@ -32,7 +32,8 @@ constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
 // Waves per workgroup is a template parameter W: 4 (one wave per SIMD, two workgroups per CU, so the two
 // waves sharing a SIMD belong to different workgroups and never wait at the same barrier) or 8.
 int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
-int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles, 2: ring + counted vmcnt waits
+int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles with fragment prefetch
+int g_sig_rowtiles = 1;           // 32-row tiles per wave in the wide geometry: 1 or 2
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
@@ -256,44 +257,23 @@ __device__ __forceinline__ void read_frags(const float* lds_buf, int qq, int lan
     b[jt] = *reinterpret_cast<const f32x4*>(lds_buf + ((jt * 2 + qq) * 64 + lane) * 4);
 }
 
-template <int NT>
-__device__ __forceinline__ void mfma_group(const f32x4& a, const f32x4 (&b)[NT], f32x16 (&acc)[NT], float& ss,
-                                           float& amax) {
+// One fragment group: 4 k-steps x M row tiles x NT column tiles of MFMAs.  Every accumulator tile sees its
+// k-steps in the same order whatever M and NT are (the order oracle/chain_model.c restates).
+template <int NT, int M>
+__device__ __forceinline__ void mfma_group(const f32x4 (&a)[M], const f32x4 (&b)[NT], f32x16 (&acc)[M][NT],
+                                           float (&ss)[M], float (&amax)[M]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float av = a[r];
-    ss = __builtin_fmaf(av, av, ss);
-    amax = __builtin_fmaxf(amax, __builtin_fabsf(av));
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[jt], 0, 0, 0);
+    for (int mt = 0; mt < M; ++mt) {
+      const float av = a[mt][r];
+      ss[mt] = __builtin_fmaf(av, av, ss[mt]);
+      amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fabsf(av));
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+        acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[mt][jt], 0, 0, 0);
+    }
   }
-}
-
-// ---- counted-wait main loop (PIPE = 2, 16-byte aligned rows only) -----------------------------------
-// Same ring and arithmetic as PIPE = 1, but no vmcnt(0) drain before the barriers: the X loads for k-tile
-// kt+1 are issued (inline asm, so hipcc does not turn their first use into a drain of the LDS-DMA queue)
-// right after the LDS-DMA of half 2kt+2, and the barrier that ends half 2kt waits with vmcnt(4) — the DMA
-// has landed, the four X loads stay in flight for one more half (HBM latency under load is ~2 us, one
-// half is ~1.7 us).  The barrier ending half 2kt+1 waits vmcnt(0).  Every thread issues the same number of
-// loads every k-tile (out-of-range k is clamped to 0 and the value zeroed), so the counts are exact.
-__device__ __forceinline__ f32x4 asm_load_x4(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-__device__ __forceinline__ void load_x_tile_counted(const float* __restrict__ xrow, int kbase, int dim, f32x4 (&a)[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int k = kbase + 4 * q;
-    a[q] = asm_load_x4(xrow + (k < dim ? k : 0));
-  }
-}
-
-__device__ __forceinline__ void mask_x_tile(int kbase, int dim, f32x4 (&a)[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (kbase + 4 * q >= dim) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // Ballot + deposit in one block.  The 64-lane compare result (VCC: low half = the 32 columns of row rho,
@@ -322,14 +302,21 @@ __device__ __forceinline__ void deposit_abs_below(uint32_t& word, float y, float
 }
 
 // MODE 0: keys only, 1: keys + tie list, 2: raw projections (diagnostic)
-template <int NT, bool ALIGNED, int MODE, int W, int PIPE>
-__global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
+// W    waves per workgroup (4 or 8)
+// PIPE 0: two whole-tile LDS buffers; 1: ring of three half-tiles with fragment prefetch
+// M    32-row tiles per wave.  M = 1: 128 accumulator registers, two waves per SIMD.  M = 2: 256 accumulator
+//      registers, ONE wave per SIMD with the whole 512-entry register file: every staged fragment feeds twice
+//      as many MFMAs, which halves the LDS-DMA / ds_read / barrier issue cost per MFMA (PIPE = 1 only).
+template <int NT, bool ALIGNED, int MODE, int W, int PIPE, int M>
+__global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigArgs args) {
   constexpr bool PROJECT = MODE == 2;
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kHalfFloats = NT * 2 * kFragFloats;
   constexpr int kStageFloats = PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats;  // ring of 3 halves, or 2 whole tiles
-  constexpr int kBlockRows = W * kRowsPerWave;
-  __shared__ __attribute__((aligned(16))) float lds[kStageFloats + W * 32];
+  constexpr int kWaveRows = kRowsPerWave * M;
+  constexpr int kBlockRows = W * kWaveRows;
+  static_assert(M == 1 || PIPE == 1, "two row tiles per wave are only built for the ring loop");
+  __shared__ __attribute__((aligned(16))) float lds[kStageFloats + W * kWaveRows];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -337,81 +324,42 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
   const int h = lane >> 5;
   const int i = lane & 31;
   const int cb = blockIdx.y;
-  const int64_t row0 = (int64_t)blockIdx.x * kBlockRows + wave * kRowsPerWave;
-  const int64_t myrow = row0 + i;
-  const int64_t ldrow = myrow < args.n ? myrow : args.n - 1;  // clamp: loads stay in bounds, stores are masked
-  const float* __restrict__ xrow = args.X + ldrow * args.ldx;
+  const int64_t row0 = (int64_t)blockIdx.x * kBlockRows + wave * kWaveRows;
   const int dim = args.dim;
   const int ktiles = args.ktiles;
   const float* __restrict__ img = args.image + (size_t)cb * ktiles * kTileFloats;
-
-  f32x16 acc[NT];
+  const float* __restrict__ xrow[M];
 #pragma unroll
-  for (int jt = 0; jt < NT; ++jt)
+  for (int mt = 0; mt < M; ++mt) {
+    const int64_t r = row0 + mt * kRowsPerWave + i;
+    xrow[mt] = args.X + (r < args.n ? r : args.n - 1) * args.ldx;  // clamp: loads stay in bounds, stores are masked
+  }
+
+  f32x16 acc[M][NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+  for (int mt = 0; mt < M; ++mt)
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][jt][r] = 0.f;
 
-  float ss = 0.f;    // sum of squares of this lane's share of the row
-  float amax = 0.f;  // max |x| of this lane's share (NaN-ignoring; NaN shows up in ss)
+  float ss[M], amax[M];  // per row tile: sum of squares / max |x| of this lane's share of its row
+#pragma unroll
+  for (int mt = 0; mt < M; ++mt) { ss[mt] = 0.f; amax[mt] = 0.f; }
 
-  if (PIPE == 2) {
-    // one iteration = one 32-deep k-tile = two halves; see the comment at asm_load_x4
-    f32x4 a_cur[4], a_nxt[4];
-    f32x4 b0[NT], b1[NT];
+  if (PIPE == 1) {
     const int halves = 2 * ktiles;
+    f32x4 a_cur[2][M], a_nxt[2][M];  // [qq][row tile]
+    f32x4 b0[NT], b1[NT];
     stage_p_half<NT, W>(img, 0, lds, tid);
     stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
-    load_x_tile_counted(xrow, 16 * h, dim, a_cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    mask_x_tile(16 * h, dim, a_cur);
-    read_frags<NT>(lds, 0, lane, b0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_sched_barrier(0);
-    for (int kt = 0; kt < ktiles; ++kt) {
-      const int hh = 2 * kt;
-      // ---------------- half 0 of the k-tile ----------------
-      if (hh + 2 < halves) stage_p_half<NT, W>(img + (size_t)(kt + 1) * kTileFloats, 0, lds + ((hh + 2) % 3) * kHalfFloats, tid);
-      load_x_tile_counted(xrow, kt + 1 < ktiles ? (kt + 1) * kKTile + 16 * h : 16 * h, dim, a_nxt);  // always 4 loads
-      read_frags<NT>(lds + (hh % 3) * kHalfFloats, 1, lane, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT>(a_cur[0], b0, acc, ss, amax);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags<NT>(lds + ((hh + 1) % 3) * kHalfFloats, 0, lane, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT>(a_cur[1], b1, acc, ss, amax);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the LDS-DMA of half hh+2 has landed; 4 X loads stay in flight
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---------------- half 1 ----------------
-      if (hh + 3 < halves) stage_p_half<NT, W>(img + (size_t)(kt + 1) * kTileFloats, 1, lds + ((hh + 3) % 3) * kHalfFloats, tid);
-      read_frags<NT>(lds + ((hh + 1) % 3) * kHalfFloats, 1, lane, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT>(a_cur[2], b0, acc, ss, amax);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags<NT>(lds + ((hh + 2) % 3) * kHalfFloats, 0, lane, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT>(a_cur[3], b1, acc, ss, amax);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA of half hh+3 and the X loads of k-tile kt+1 (two halves old)
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      mask_x_tile(kt + 1 < ktiles ? (kt + 1) * kKTile + 16 * h : dim, dim, a_nxt);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    for (int mt = 0; mt < M; ++mt) {
+      f32x4 t[2];
+      load_x_half<ALIGNED>(xrow[mt], 16 * h, dim, t);
+      a_cur[0][mt] = t[0];
+      a_cur[1][mt] = t[1];
     }
-  } else if (PIPE == 1) {
-    const int halves = 2 * ktiles;
-    f32x4 a_cur[2], a_nxt[2];
-    f32x4 b0[NT], b1[NT];
-    stage_p_half<NT, W>(img, 0, lds, tid);
-    stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
-    load_x_half<ALIGNED>(xrow, 16 * h, dim, a_cur);
     __syncthreads();
     read_frags<NT>(lds, 0, lane, b0);
     // land b0 before the loop, so that on every path into the loop header nothing is pending and the
@@ -423,14 +371,21 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
       if (hh + 2 < halves)
         stage_p_half<NT, W>(img + (size_t)((hh + 2) >> 1) * kTileFloats, (hh + 2) & 1, lds + ((hh + 2) % 3) * kHalfFloats,
                             tid);
-      if (hh + 1 < halves)
-        load_x_half<ALIGNED>(xrow, ((hh + 1) >> 1) * kKTile + 16 * h + 8 * ((hh + 1) & 1), dim, a_nxt);
+      if (hh + 1 < halves) {
+#pragma unroll
+        for (int mt = 0; mt < M; ++mt) {
+          f32x4 t[2];
+          load_x_half<ALIGNED>(xrow[mt], ((hh + 1) >> 1) * kKTile + 16 * h + 8 * ((hh + 1) & 1), dim, t);
+          a_nxt[0][mt] = t[0];
+          a_nxt[1][mt] = t[1];
+        }
+      }
       // Issue order is pinned (sched_barrier): left alone, the scheduler sinks each ds_read group down to its
       // first use and the wave then sits out the LDS latency with the matrix pipe idle.
       read_frags<NT>(cur, 1, lane, b1);                       // lands while group 0 issues
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT>(a_cur[0], b0, acc, ss, amax);
-      // b1 was issued a whole group (32 MFMAs) ago: this wait is free, and taking it BEFORE the next reads are
+      mfma_group<NT, M>(a_cur[0], b0, acc, ss, amax);
+      // b1 was issued a whole group (32*M MFMAs) ago: this wait is free, and taking it BEFORE the next reads are
       // issued keeps it from turning into a drain of those reads (hipcc emits lgkmcnt(0), not a counted wait)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -439,23 +394,38 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
       // half this reads a stale ring slot that nobody uses, which keeps the wait counters branch-free.
       read_frags<NT>(lds + ((hh + 1) % 3) * kHalfFloats, 0, lane, b0);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT>(a_cur[1], b1, acc, ss, amax);
+      mfma_group<NT, M>(a_cur[1], b1, acc, ss, amax);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
-      a_cur[0] = a_nxt[0];
-      a_cur[1] = a_nxt[1];
+#pragma unroll
+      for (int mt = 0; mt < M; ++mt) {
+        a_cur[0][mt] = a_nxt[0][mt];
+        a_cur[1][mt] = a_nxt[1][mt];
+      }
     }
   } else {
-    f32x4 a_cur[4], a_nxt[4];
+    f32x4 a_cur[4][M], a_nxt[4][M];
     stage_p_tile<NT, W>(img, lds, tid);
-    load_x_tile<ALIGNED>(xrow, 16 * h, dim, a_cur);
+#pragma unroll
+    for (int mt = 0; mt < M; ++mt) {
+      f32x4 t[4];
+      load_x_tile<ALIGNED>(xrow[mt], 16 * h, dim, t);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_cur[q][mt] = t[q];
+    }
     __syncthreads();
 
     for (int kt = 0; kt < ktiles; ++kt) {
       const float* lb = lds + (kt & 1) * kTileFloats;
       if (kt + 1 < ktiles) {
         stage_p_tile<NT, W>(img + (size_t)(kt + 1) * kTileFloats, lds + ((kt + 1) & 1) * kTileFloats, tid);
-        load_x_tile<ALIGNED>(xrow, (kt + 1) * kKTile + 16 * h, dim, a_nxt);
+#pragma unroll
+        for (int mt = 0; mt < M; ++mt) {
+          f32x4 t[4];
+          load_x_tile<ALIGNED>(xrow[mt], (kt + 1) * kKTile + 16 * h, dim, t);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a_nxt[q][mt] = t[q];
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -463,119 +433,131 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
           b[jt] = *reinterpret_cast<const f32x4*>(lb + ((jt * 4 + q) * 64 + lane) * 4);
-        mfma_group<NT>(a_cur[q], b, acc, ss, amax);
+        mfma_group<NT, M>(a_cur[q], b, acc, ss, amax);
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M; ++mt) a_cur[q][mt] = a_nxt[q][mt];
     }
   }
 
   // accumulator map (32x32 tile): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   if (PROJECT) {
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+    for (int mt = 0; mt < M; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < args.n) args.Y[row * args.ldy + (cb * NT + jt) * 32 + i] = acc[jt][r];
-      }
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + mt * kRowsPerWave + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < args.n) args.Y[row * args.ldy + (cb * NT + jt) * 32 + i] = acc[mt][jt][r];
+        }
     return;
   }
 
   // ---- row statistics: ||x||, zero-vector flag ------------------------------------------
-  ss += __shfl_xor(ss, 32);
-  amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32));
-  float* norm_lds = lds + kStageFloats + wave * 32;
-  if (h == 0) {
-    norm_lds[i] = sqrtf(ss) * args.tau;
-    if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
-      const bool has_nan = ss != ss;
-      const bool zero = (amax <= 1e-8f) && !has_nan;
-      args.row_flags[myrow] = (uint8_t)((zero ? 1 : 0) | (has_nan ? 2 : 0));
+  float* norm_lds = lds + kStageFloats + wave * kWaveRows;
+#pragma unroll
+  for (int mt = 0; mt < M; ++mt) {
+    float s2 = ss[mt] + __shfl_xor(ss[mt], 32);
+    const float am = __builtin_fmaxf(amax[mt], __shfl_xor(amax[mt], 32));
+    const int64_t myrow = row0 + mt * kRowsPerWave + i;
+    if (h == 0) {
+      norm_lds[mt * kRowsPerWave + i] = sqrtf(s2) * args.tau;
+      if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
+        const bool has_nan = s2 != s2;
+        const bool zero = (am <= 1e-8f) && !has_nan;
+        args.row_flags[myrow] = (uint8_t)((zero ? 1 : 0) | (has_nan ? 2 : 0));
+      }
     }
   }
   __syncthreads();
 
-  // ---- sign bits + tie bits, one ballot per accumulator register -------------------------
   constexpr int LPR = NT >= 2 ? 2 : 1;   // lanes that hold one output row
   constexpr int WPL = NT >= 2 ? NT / 2 : 1;  // 32-bit words per lane
-  uint32_t kw[WPL], tw[WPL];
-#pragma unroll
-  for (int w = 0; w < WPL; ++w) { kw[w] = 0u; tw[w] = 0u; }
-
   constexpr bool want_ties = MODE == 1;
-  f32x4 rn[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(norm_lds + 8 * g + 4 * h);
-  // wave-uniform screen for ties: |y| < (largest tau*||x|| of the wave's rows) * (largest ||p|| of the block)
-  float screen = 0.f;
-  if (want_ties) {
-    float m = __builtin_fmaxf(__builtin_fmaxf(rn[0][0], rn[0][1]), __builtin_fmaxf(rn[0][2], rn[0][3]));
-#pragma unroll
-    for (int g = 1; g < 4; ++g)
-      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(rn[g][0], rn[g][1]), __builtin_fmaxf(rn[g][2], rn[g][3])));
-    m = __builtin_fmaxf(m, __shfl_xor(m, 32));  // lanes of one half hold 16 of the 32 rows
-    // NaN norms (a NaN in x) must not hide the finite rows next to them: fmaxf drops NaNs, so m is the
-    // largest finite norm; rows that are NaN produce NaN projections, which never tie.
-    screen = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))) * args.norm_max[cb];
-  }
 
 #pragma unroll
-  for (int jt = 0; jt < NT; ++jt) {
-    uint64_t any = 0;
+  for (int mt = 0; mt < M; ++mt) {
+    // ---- sign bits + tie bits of one 32-row tile, one ballot per accumulator register --------------
+    uint32_t kw[WPL], tw[WPL];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float y = acc[jt][r];
-      const int rho = (r & 3) + 8 * (r >> 2);
-      const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
-      const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
-      deposit_positive(kw[jt % WPL], y, l0, l1);   // bit = (y > 0): 0, -0 and NaN give 0 (lsh.py:204)
-      if (want_ties) any |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
+    for (int w = 0; w < WPL; ++w) { kw[w] = 0u; tw[w] = 0u; }
+    const float* nl = norm_lds + mt * kRowsPerWave;
+    f32x4 rn[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(nl + 8 * g + 4 * h);
+    // wave-uniform screen for ties: |y| < (largest tau*||x|| of the tile's rows) * (largest ||p|| of the block)
+    float screen = 0.f;
+    if (want_ties) {
+      float m = __builtin_fmaxf(__builtin_fmaxf(rn[0][0], rn[0][1]), __builtin_fmaxf(rn[0][2], rn[0][3]));
+#pragma unroll
+      for (int g = 1; g < 4; ++g)
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(rn[g][0], rn[g][1]), __builtin_fmaxf(rn[g][2], rn[g][3])));
+      m = __builtin_fmaxf(m, __shfl_xor(m, 32));  // lanes of one half hold 16 of the 32 rows
+      // NaN norms (a NaN in x) must not hide the finite rows next to them: fmaxf drops NaNs, so m is the
+      // largest finite norm; rows that are NaN produce NaN projections, which never tie.
+      screen = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))) * args.norm_max[cb];
     }
-    if (any != 0) {  // wave-uniform, rare (a few % of column tiles): the exact per-element test
-      const float pn = args.norms[(cb * NT + jt) * 32 + i];
+
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      uint64_t any = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float thr = rn[r >> 2][r & 3] * pn;
-        // strict '<': thr == 0 (zero x, zero-padded column) never ties
+        const float y = acc[mt][jt][r];
         const int rho = (r & 3) + 8 * (r >> 2);
-        deposit_abs_below(tw[jt % WPL], acc[jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
+        const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
+        const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
+        deposit_positive(kw[jt % WPL], y, l0, l1);   // bit = (y > 0): 0, -0 and NaN give 0 (lsh.py:204)
+        if (want_ties) any |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
+      }
+      if (any != 0) {  // wave-uniform, rare (a few % of column tiles): the exact per-element test
+        const float pn = args.norms[(cb * NT + jt) * 32 + i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float thr = rn[r >> 2][r & 3] * pn;
+          // strict '<': thr == 0 (zero x, zero-padded column) never ties
+          const int rho = (r & 3) + 8 * (r >> 2);
+          deposit_abs_below(tw[jt % WPL], acc[mt][jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
+        }
       }
     }
-  }
 
-  // ---- stores: lane L holds words [ (L % LPR) * WPL, +WPL ) of row L / LPR -----------------
-  const int orow = lane / LPR;
-  const int64_t grow = row0 + orow;
-  const bool lane_on = (NT >= 2 || lane < 32) && grow < args.n;
-  const int word0 = cb * NT + (lane % LPR) * WPL;  // first 32-column word this lane holds
-  const int byte0 = word0 * 4;
-  if (lane_on) {
-    uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
-    if (args.vec_store && byte0 + 4 * WPL <= args.row_bytes) {
-      if (WPL == 4) {
-        *reinterpret_cast<u32x4*>(dst) = u32x4{kw[0], kw[1 % WPL], kw[2 % WPL], kw[3 % WPL]};
-      } else if (WPL == 2) {
-        *reinterpret_cast<u32x2*>(dst) = u32x2{kw[0], kw[1 % WPL]};
+    // ---- stores: lane L holds words [ (L % LPR) * WPL, +WPL ) of row L / LPR -----------------
+    const int orow = lane / LPR;
+    const int64_t grow = row0 + mt * kRowsPerWave + orow;
+    const bool lane_on = (NT >= 2 || lane < 32) && grow < args.n;
+    const int word0 = cb * NT + (lane % LPR) * WPL;  // first 32-column word this lane holds
+    const int byte0 = word0 * 4;
+    if (lane_on) {
+      uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
+      if (args.vec_store && byte0 + 4 * WPL <= args.row_bytes) {
+        if (WPL == 4) {
+          *reinterpret_cast<u32x4*>(dst) = u32x4{kw[0], kw[1 % WPL], kw[2 % WPL], kw[3 % WPL]};
+        } else if (WPL == 2) {
+          *reinterpret_cast<u32x2*>(dst) = u32x2{kw[0], kw[1 % WPL]};
+        } else {
+          *reinterpret_cast<uint32_t*>(dst) = kw[0];
+        }
       } else {
-        *reinterpret_cast<uint32_t*>(dst) = kw[0];
+#pragma unroll
+        for (int w = 0; w < WPL; ++w)
+#pragma unroll
+          for (int bsel = 0; bsel < 4; ++bsel)
+            if (byte0 + 4 * w + bsel < args.row_bytes) dst[4 * w + bsel] = (uint8_t)(kw[w] >> (8 * bsel));
       }
-    } else {
+      if (want_ties) {
 #pragma unroll
-      for (int w = 0; w < WPL; ++w)
-#pragma unroll
-        for (int bsel = 0; bsel < 4; ++bsel)
-          if (byte0 + 4 * w + bsel < args.row_bytes) dst[4 * w + bsel] = (uint8_t)(kw[w] >> (8 * bsel));
-    }
-    if (want_ties) {
-#pragma unroll
-      for (int w = 0; w < WPL; ++w) {
-        if (tw[w] != 0u) {
-          const int slot = atomicAdd(args.tie_count, 1);
-          if (slot < args.tie_cap) {
-            args.tie_list[2 * (int64_t)slot] = (grow + args.row_base) * 65536 + (word0 + w);
-            args.tie_list[2 * (int64_t)slot + 1] = (int64_t)tw[w];
+        for (int w = 0; w < WPL; ++w) {
+          if (tw[w] != 0u) {
+            const int slot = atomicAdd(args.tie_count, 1);
+            if (slot < args.tie_cap) {
+              args.tie_list[2 * (int64_t)slot] = (grow + args.row_base) * 65536 + (word0 + w);
+              args.tie_list[2 * (int64_t)slot + 1] = (int64_t)tw[w];
+            }
           }
         }
       }
@@ -585,18 +567,20 @@ __global__ __launch_bounds__(W * 64, 2) void sig_kernel(const SigArgs args) {
 
 template <int NT, int W>
 int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
-  constexpr int kBlockRows = W * kRowsPerWave;
-  const dim3 grid((unsigned)((a.n + kBlockRows - 1) / kBlockRows), (unsigned)g.cb, 1);
-  const dim3 block(W * 64, 1, 1);
   const int mode = project ? 2 : (a.tie_list != nullptr ? 1 : 0);
-#define LSHRS_LAUNCH(AL, MD)                                                                   \
-  do {                                                                                         \
-    if (g_sig_pipe == 2 && AL)                                                                 \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, (AL ? 2 : 1)>), grid, block, 0, s, a);    \
-    else if (g_sig_pipe != 0)                                                                  \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1>), grid, block, 0, s, a);               \
-    else                                                                                       \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 0>), grid, block, 0, s, a);               \
+  // two row tiles per wave: only the wide geometry (NT = 8), the ring loop and 4-wave workgroups
+  const bool two = (g_sig_rowtiles == 2) && NT == 8 && W == 4 && g_sig_pipe != 0;
+  const int block_rows = W * kRowsPerWave * (two ? 2 : 1);
+  const dim3 grid((unsigned)((a.n + block_rows - 1) / block_rows), (unsigned)g.cb, 1);
+  const dim3 block(W * 64, 1, 1);
+#define LSHRS_LAUNCH(AL, MD)                                                                    \
+  do {                                                                                          \
+    if (two)                                                                                    \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1, (NT == 8 && W == 4) ? 2 : 1>), grid, block, 0, s, a); \
+    else if (g_sig_pipe != 0)                                                                   \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1, 1>), grid, block, 0, s, a);             \
+    else                                                                                        \
+      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 0, 1>), grid, block, 0, s, a);             \
   } while (0)
   if (aligned) {
     if (mode == 0) LSHRS_LAUNCH(true, 0);
@@ -858,8 +842,13 @@ int lshrs_debug_set_sig_waves(int w) {
   return 0;
 }
 int lshrs_debug_set_sig_pipe(int p) {
-  if (p < 0 || p > 2) return LSHRS_E_BADARG;
+  if (p < 0 || p > 1) return LSHRS_E_BADARG;
   g_sig_pipe = p;
+  return 0;
+}
+int lshrs_debug_set_sig_rowtiles(int m) {
+  if (m != 1 && m != 2) return LSHRS_E_BADARG;
+  g_sig_rowtiles = m;
   return 0;
 }
 int lshrs_debug_set_sig_fine(int f) {
