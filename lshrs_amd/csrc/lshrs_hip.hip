@@ -33,7 +33,7 @@ constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
 // waves sharing a SIMD belong to different workgroups and never wait at the same barrier) or 8.
 int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
 int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles with fragment prefetch
-int g_sig_rowtiles = 1;           // 32-row tiles per wave in the wide geometry: 1 or 2
+unsigned long long* g_clock_probe = nullptr;  // diagnostics only (lshrs_debug_set_clock_probe)
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
@@ -168,6 +168,8 @@ struct SigArgs {
   // project mode
   float* Y;
   int64_t ldy;
+  // diagnostics: when set, wave 0 of every workgroup stores {shader-clock ticks, 100 MHz ticks} of its main loop
+  unsigned long long* clock_probe;
 };
 
 template <bool ALIGNED>
@@ -304,9 +306,9 @@ __device__ __forceinline__ void deposit_abs_below(uint32_t& word, float y, float
 // MODE 0: keys only, 1: keys + tie list, 2: raw projections (diagnostic)
 // W    waves per workgroup (4 or 8)
 // PIPE 0: two whole-tile LDS buffers; 1: ring of three half-tiles with fragment prefetch
-// M    32-row tiles per wave.  M = 1: 128 accumulator registers, two waves per SIMD.  M = 2: 256 accumulator
-//      registers, ONE wave per SIMD with the whole 512-entry register file: every staged fragment feeds twice
-//      as many MFMAs, which halves the LDS-DMA / ds_read / barrier issue cost per MFMA (PIPE = 1 only).
+// M    32-row tiles per wave.  Shipped: M = 1 (128 accumulator registers, two waves per SIMD).  M = 2 (256
+//      accumulator registers, one wave per SIMD) builds and is bit-identical but measured 3 % slower on
+//      MI355X (profiles/r01_kernel_variants_ab.log), so it is not instantiated.
 template <int NT, bool ALIGNED, int MODE, int W, int PIPE, int M>
 __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigArgs args) {
   constexpr bool PROJECT = MODE == 2;
@@ -346,6 +348,12 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   float ss[M], amax[M];  // per row tile: sum of squares / max |x| of this lane's share of its row
 #pragma unroll
   for (int mt = 0; mt < M; ++mt) { ss[mt] = 0.f; amax[mt] = 0.f; }
+
+  unsigned long long t_shader = 0, t_real = 0;
+  if (args.clock_probe != nullptr) {
+    t_shader = __builtin_amdgcn_s_memtime();
+    t_real = __builtin_amdgcn_s_memrealtime();
+  }
 
   if (PIPE == 1) {
     const int halves = 2 * ktiles;
@@ -441,6 +449,12 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
 #pragma unroll
         for (int mt = 0; mt < M; ++mt) a_cur[q][mt] = a_nxt[q][mt];
     }
+  }
+
+  if (args.clock_probe != nullptr && tid == 0) {
+    const unsigned long long slot = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+    args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
+    args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
   }
 
   // accumulator map (32x32 tile): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -568,16 +582,12 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
 template <int NT, int W>
 int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
   const int mode = project ? 2 : (a.tie_list != nullptr ? 1 : 0);
-  // two row tiles per wave: only the wide geometry (NT = 8), the ring loop and 4-wave workgroups
-  const bool two = (g_sig_rowtiles == 2) && NT == 8 && W == 4 && g_sig_pipe != 0;
-  const int block_rows = W * kRowsPerWave * (two ? 2 : 1);
+  const int block_rows = W * kRowsPerWave;
   const dim3 grid((unsigned)((a.n + block_rows - 1) / block_rows), (unsigned)g.cb, 1);
   const dim3 block(W * 64, 1, 1);
 #define LSHRS_LAUNCH(AL, MD)                                                                    \
   do {                                                                                          \
-    if (two)                                                                                    \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1, (NT == 8 && W == 4) ? 2 : 1>), grid, block, 0, s, a); \
-    else if (g_sig_pipe != 0)                                                                   \
+    if (g_sig_pipe != 0)                                                                        \
       hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1, 1>), grid, block, 0, s, a);             \
     else                                                                                        \
       hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 0, 1>), grid, block, 0, s, a);             \
@@ -846,9 +856,10 @@ int lshrs_debug_set_sig_pipe(int p) {
   g_sig_pipe = p;
   return 0;
 }
-int lshrs_debug_set_sig_rowtiles(int m) {
-  if (m != 1 && m != 2) return LSHRS_E_BADARG;
-  g_sig_rowtiles = m;
+// Diagnostics: device buffer of 2 x (number of workgroups) u64 that the next wide-geometry launches fill with
+// the shader-clock and 100 MHz tick counts of each workgroup's main loop (NULL switches it off).
+int lshrs_debug_set_clock_probe(void* device_buffer) {
+  g_clock_probe = static_cast<unsigned long long*>(device_buffer);
   return 0;
 }
 int lshrs_debug_set_sig_fine(int f) {
@@ -944,6 +955,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
     a.tie_count = tie_count;
     a.tau = tau;
     a.row_flags = row_flags != nullptr ? row_flags + lo : nullptr;
+    a.clock_probe = (lo == 0 && !fine) ? g_clock_probe : nullptr;
     return dispatch_sig(a, gg, false, s);
   };
   // Whole rounds of NT-wide workgroups first; what is left (less than one round) takes the fine geometry when
