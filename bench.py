@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rerank", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the (untimed) parity check against the oracle")
+    ap.add_argument("--backend", default=os.environ.get("LSHRS_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals on one GPU)")
     return ap.parse_args()
 
 
@@ -74,17 +76,21 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and not distributed:
         raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    local_dev = local_rank % max(1, torch.cuda.device_count())   # (== local_rank on a real N-GPU node)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from lshrs_amd import LSHHasher
 
     n = args.rows_per_gpu
-    hasher = LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_rank)
+    hasher = LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_dev)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     x = torch.randn(n, DIM, device=dev, generator=gen)           # resident in HBM before timing starts
     keys = torch.empty((n, BANDS, hasher.band_bytes), dtype=torch.uint8, device=dev)
@@ -110,7 +116,7 @@ def main() -> None:
     events, hasher.kernel_events = hasher.kernel_events, None
     stats = dict(hasher.last_stats)
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # the step cuts its batch into chunks (one kernel launch each): time every launch, weight by its rows
