@@ -130,9 +130,12 @@ int lshrs_l2_normalize_f32(const float* X, int64_t n, int64_t ldx, int32_t dim, 
 /* Per-query descending order — replaces argpartition + argsort (similarity.py:174-179).
  *   scores (q, c) f32 -> order (q, k) int32 positions, sorted (q, k) f32, k <= c.
  * Ties are broken by ascending position (the reference's order on ties is unspecified);
- * NaN scores sort last.  Limit: c <= 16384 (one LDS-resident bitonic network per query). */
+ * NaN scores sort last.  c <= 16384: one LDS-resident bitonic network per query, workspace may be NULL.
+ * Longer lists run the same network over `workspace` (lshrs_topk_workspace_bytes(q, c) bytes, 8-byte
+ * aligned) in global memory; q <= 65535 there. */
+int64_t lshrs_topk_workspace_bytes(int32_t q, int32_t c);
 int lshrs_topk_desc_f32(const float* scores, int32_t q, int32_t c, int32_t k,
-                        int32_t* order, float* sorted, void* stream);
+                        int32_t* order, float* sorted, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_cosine_batch_f32.restype = c.c_int
     lib.lshrs_l2_normalize_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp]
     lib.lshrs_l2_normalize_f32.restype = c.c_int
-    lib.lshrs_topk_desc_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.lshrs_topk_workspace_bytes.argtypes = [i32, i32]
+    lib.lshrs_topk_workspace_bytes.restype = i64
+    lib.lshrs_topk_desc_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     lib.lshrs_topk_desc_f32.restype = c.c_int
 
 
@@ -89,6 +91,7 @@ EXPORTS = (
     "lshrs_scatter_band_keys_u8",
     "lshrs_cosine_batch_f32",
     "lshrs_l2_normalize_f32",
+    "lshrs_topk_workspace_bytes",
     "lshrs_topk_desc_f32",
 )
 

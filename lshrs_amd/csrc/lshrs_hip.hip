@@ -836,6 +836,79 @@ __global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restr
   }
 }
 
+// ---- lists longer than one LDS network: the same bitonic network over a global u64 array ------------
+constexpr int kTopkChunk = 4096;  // items per workgroup-local stage (32 KiB of LDS)
+
+__global__ void topk_fill_kernel(const float* __restrict__ scores, int c, int64_t cpad, uint64_t* __restrict__ items) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cpad) return;
+  const int qi = blockIdx.y;
+  uint64_t v = ~0ull;
+  if (t < c) v = ((uint64_t)desc_key(scores[(int64_t)qi * c + t]) << 32) | (uint32_t)t;
+  items[(int64_t)qi * cpad + t] = v;
+}
+
+// All compare-exchange steps with stride < kTopkChunk of one merge size (or, with full = true, the whole
+// network up to size kTopkChunk) on a chunk held in LDS.  Direction follows the GLOBAL index.
+__global__ __launch_bounds__(kTopkThreads) void topk_local_kernel(uint64_t* __restrict__ items, int64_t cpad, int64_t size,
+                                                                  bool full) {
+  __shared__ uint64_t buf[kTopkChunk];
+  const int qi = blockIdx.y;
+  const int64_t base = (int64_t)blockIdx.x * kTopkChunk;
+  uint64_t* g = items + (int64_t)qi * cpad + base;
+  for (int t = threadIdx.x; t < kTopkChunk; t += kTopkThreads) buf[t] = g[t];
+  __syncthreads();
+  const int64_t first = full ? 2 : size;
+  const int64_t last = full ? kTopkChunk : size;
+  for (int64_t sz = first; sz <= last; sz <<= 1) {
+    const int top = (int)((sz < (int64_t)kTopkChunk ? sz : (int64_t)kTopkChunk) >> 1);
+    for (int stride = top; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (kTopkChunk >> 1); t += kTopkThreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (((base + lo) & sz) == 0);
+        const uint64_t a = buf[lo], b = buf[hi];
+        if ((a > b) == up) {
+          buf[lo] = b;
+          buf[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < kTopkChunk; t += kTopkThreads) g[t] = buf[t];
+}
+
+__global__ void topk_global_step_kernel(uint64_t* __restrict__ items, int64_t cpad, int64_t size, int64_t stride) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (cpad >> 1)) return;
+  uint64_t* g = items + (int64_t)blockIdx.y * cpad;
+  const int64_t lo = 2 * t - (t & (stride - 1));
+  const int64_t hi = lo + stride;
+  const bool up = ((lo & size) == 0);
+  const uint64_t a = g[lo], b = g[hi];
+  if ((a > b) == up) {
+    g[lo] = b;
+    g[hi] = a;
+  }
+}
+
+__global__ void topk_emit_kernel(const float* __restrict__ scores, const uint64_t* __restrict__ items, int c, int64_t cpad,
+                                 int k, int32_t* __restrict__ order, float* __restrict__ sorted) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= k) return;
+  const int qi = blockIdx.y;
+  const uint32_t pos = (uint32_t)items[(int64_t)qi * cpad + t];
+  order[(int64_t)qi * k + t] = (int32_t)pos;
+  sorted[(int64_t)qi * k + t] = scores[(int64_t)qi * c + pos];
+}
+
+inline int64_t topk_pad(int64_t c) {
+  int64_t cpad = kTopkChunk;
+  while (cpad < c) cpad <<= 1;
+  return cpad;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1078,22 +1151,45 @@ int lshrs_l2_normalize_f32(const float* X, int64_t n, int64_t ldx, int32_t dim, 
   return -(int)hipGetLastError();
 }
 
+int64_t lshrs_topk_workspace_bytes(int32_t q, int32_t c) {
+  if (q < 0 || c < 0) return LSHRS_E_BADARG;
+  if (c <= 16384) return 0;
+  return (int64_t)q * topk_pad(c) * (int64_t)sizeof(uint64_t);
+}
+
 int lshrs_topk_desc_f32(const float* scores, int32_t q, int32_t c, int32_t k, int32_t* order, float* sorted,
-                        void* stream) {
+                        void* workspace, void* stream) {
   if (q == 0 || k == 0) return 0;
   if (scores == nullptr || order == nullptr || sorted == nullptr || q < 0 || c <= 0 || k < 0 || k > c)
     return LSHRS_E_BADARG;
-  if (c > 16384) return LSHRS_E_TOOLARGE;
-  int cpad = 2;
-  while (cpad < c) cpad <<= 1;
-  const size_t shmem = (size_t)cpad * sizeof(uint64_t);
-  if (shmem > 48 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return -(int)e;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c <= 16384) {  // one LDS-resident network per query
+    int cpad = 2;
+    while (cpad < c) cpad <<= 1;
+    const size_t shmem = (size_t)cpad * sizeof(uint64_t);
+    if (shmem > 48 * 1024) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (e != hipSuccess) return -(int)e;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)q), dim3(kTopkThreads), shmem, s, scores, c, cpad, k, order, sorted);
+    return -(int)hipGetLastError();
   }
-  hipLaunchKernelGGL(topk_kernel, dim3((unsigned)q), dim3(kTopkThreads), shmem, static_cast<hipStream_t>(stream),
-                     scores, c, cpad, k, order, sorted);
+  if (workspace == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 7)) return LSHRS_E_BADARG;
+  if (q > 65535) return LSHRS_E_TOOLARGE;
+  uint64_t* items = static_cast<uint64_t*>(workspace);
+  const int64_t cpad = topk_pad(c);
+  const dim3 qgrid((unsigned)((cpad + 255) / 256), (unsigned)q), half((unsigned)(((cpad >> 1) + 255) / 256), (unsigned)q);
+  const dim3 chunks((unsigned)(cpad / kTopkChunk), (unsigned)q);
+  hipLaunchKernelGGL(topk_fill_kernel, qgrid, dim3(256), 0, s, scores, c, cpad, items);
+  hipLaunchKernelGGL(topk_local_kernel, chunks, dim3(kTopkThreads), 0, s, items, cpad, (int64_t)kTopkChunk, true);
+  for (int64_t size = 2 * (int64_t)kTopkChunk; size <= cpad; size <<= 1) {
+    for (int64_t stride = size >> 1; stride >= kTopkChunk; stride >>= 1)
+      hipLaunchKernelGGL(topk_global_step_kernel, half, dim3(256), 0, s, items, cpad, size, stride);
+    hipLaunchKernelGGL(topk_local_kernel, chunks, dim3(kTopkThreads), 0, s, items, cpad, size, false);
+  }
+  hipLaunchKernelGGL(topk_emit_kernel, dim3((unsigned)((k + 255) / 256), (unsigned)q), dim3(256), 0, s, scores, items, c,
+                     cpad, k, order, sorted);
   return -(int)hipGetLastError();
 }
 

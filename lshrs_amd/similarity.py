@@ -24,7 +24,7 @@ from . import _native
 __all__ = ["l2_norm", "cosine_similarity", "top_k_cosine", "rerank_batch", "cosine_scores_device", "l2_normalize_device",
            "topk_desc_device"]
 
-_TOPK_MAX_C = 16384
+_TOPK_MAX_Q = 65535
 
 
 def _as_matrix(candidates, dim: Optional[int] = None) -> np.ndarray:
@@ -87,18 +87,21 @@ def topk_desc_device(scores, k: int):
     q, c = int(scores.shape[0]), int(scores.shape[1])
     if k > c or k < 0:
         raise ValueError("k must be within [0, c]")
-    if c > _TOPK_MAX_C:
-        raise NotImplementedError(
-            f"top-k over {c} candidates per query exceeds the LDS-resident sort ({_TOPK_MAX_C}); "
-            "split the candidate list")
     order = torch.empty((q, k), dtype=torch.int32, device=scores.device)
     sorted_scores = torch.empty((q, k), dtype=torch.float32, device=scores.device)
     if q == 0 or k == 0:
         return order, sorted_scores
     with torch.cuda.device(scores.device):
         stream = torch.cuda.current_stream(scores.device).cuda_stream
-        _native.check(lib.lshrs_topk_desc_f32(scores.data_ptr(), q, c, k, order.data_ptr(), sorted_scores.data_ptr(),
-                                              stream), "lshrs_topk_desc_f32")
+        for lo in range(0, q, _TOPK_MAX_Q):      # (the global-memory network takes <= 65535 queries per call)
+            hi = min(q, lo + _TOPK_MAX_Q)
+            nbytes = int(lib.lshrs_topk_workspace_bytes(hi - lo, c))
+            if nbytes < 0:
+                _native.check(nbytes, "lshrs_topk_workspace_bytes")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=scores.device) if nbytes else None
+            _native.check(lib.lshrs_topk_desc_f32(scores[lo:hi].data_ptr(), hi - lo, c, k, order[lo:hi].data_ptr(),
+                                                  sorted_scores[lo:hi].data_ptr(), ws.data_ptr() if ws is not None else None,
+                                                  stream), "lshrs_topk_desc_f32")
     return order, sorted_scores
 
 

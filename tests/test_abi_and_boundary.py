@@ -69,7 +69,9 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device
     assert lib.lshrs_sig_hash_batch_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None) == -10001
-    assert lib.lshrs_topk_desc_f32(None, 1, 5, 3, None, None, None) == -10001
+    assert lib.lshrs_topk_desc_f32(None, 1, 5, 3, None, None, None, None) == -10001
+    assert lib.lshrs_topk_workspace_bytes(10, 1000) == 0
+    assert lib.lshrs_topk_workspace_bytes(3, 40_000) == 3 * 65536 * 8
     assert lib.lshrs_cosine_batch_f32(None, 1, 4, 4, None, 1, None, 1, None, None, None, None) == -10001
 
 

@@ -166,8 +166,18 @@ def test_status_codes_and_limits():
     ref = torch.sort(big, dim=1, descending=True, stable=True)
     assert torch.equal(vals, ref.values)
     assert torch.equal(order.long(), ref.indices)
-    with pytest.raises(NotImplementedError):
-        topk_desc_device(torch.randn(1, 16385, device="cuda"), 5)
+    # lists longer than one LDS network go through the global-memory network: same order
+    for cbig, kk in ((16385, 16385), (40_000, 100), (300_001, 300_001)):
+        big = torch.randn(3, cbig, device="cuda")
+        big[1, 7] = float("nan")
+        big[2, :5] = 10.0                                    # ties (and the maximum) -> ascending position
+        order, vals = topk_desc_device(big, kk)
+        ref = torch.sort(torch.nan_to_num(big, nan=float("-inf")), dim=1, descending=True, stable=True)
+        assert torch.equal(order.long()[0], ref.indices[0, :kk]) and torch.equal(vals[0], ref.values[0, :kk])
+        assert order[2, :5].tolist() == [0, 1, 2, 3, 4]
+        if kk == cbig:
+            assert int(order[1, -1]) == 7 and bool(torch.isnan(vals[1, -1]))
+            assert torch.equal(torch.sort(order.long(), dim=1).values, torch.arange(cbig, device="cuda").expand(3, -1))
 
 
 def test_full_size_config3_properties():
