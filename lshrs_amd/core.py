@@ -3,7 +3,8 @@
 Thin counterpart of the reference orchestrator (lshrs/core/main.py) for exactly the
 methods that reach the accelerated path: constructor, ``ingest`` / ``index`` /
 ``create_signatures`` / ``flush`` (signature pass) and ``query`` / ``get_top_k`` /
-``get_above_p`` (signature pass + cosine rerank), plus the trivial storage pass-throughs.
+``get_above_p`` (signature pass + cosine rerank), plus the storage pass-throughs and the on-disk /
+pickle persistence of configuration + hyperplanes (same format as the reference).
 Same keyword arguments, return types, error types and messages; storage (Redis) and the
 loaders (PostgreSQL / Parquet) are the reference's own components and are not re-implemented.
 
@@ -20,8 +21,10 @@ tests/golden/g5_orchestration.json holds the reference's own batches for these c
 
 from __future__ import annotations
 
+import json
 import logging
 import math
+from pathlib import Path
 from threading import Lock
 from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
 
@@ -39,6 +42,7 @@ Loader = Callable[..., Iterator[Tuple[Sequence[int], np.ndarray]]]
 
 __all__ = ["LSHRS", "lshrs"]
 
+_FORMAT_VERSION = "0.1.1a4"  # on-disk format version string the reference writes (main.py:882)
 _ZERO_MSG = "Cannot index zero vector - norm undefined. Check embeddings for corruption."
 
 
@@ -250,29 +254,77 @@ class LSHRS:
     # ------------------------------------------------------------------ storage pass-throughs
     def delete(self, indices: Union[int, Sequence[int]]) -> None:
         """Remove ids from every bucket (reference: main.py:744-784)."""
-        if isinstance(indices, (int, np.integer)):
-            ids = [int(indices)]
-        else:
-            ids = [int(i) for i in indices]
-        if not ids:
-            return
-        self.flush()
-        self._storage.remove_indices(ids)
+        to_remove = [indices] if isinstance(indices, int) else [int(i) for i in indices]
+        self._storage.remove_indices(to_remove)
 
     def clear(self) -> None:
-        """Drop buffered operations and every bucket (reference: main.py:786-796)."""
-        with self._buffer_lock:
-            self._buffer = []
+        """Flush what is buffered, then drop every bucket (reference: main.py:786-796)."""
+        self.flush()
         self._storage.clear()
 
     def stats(self) -> Dict[str, Any]:
         """Static configuration summary (reference: main.py:798-840)."""
-        cfg = self._config
         return {
-            "dimension": cfg["dim"], "num_perm": cfg["num_perm"], "num_bands": cfg["num_bands"],
-            "rows_per_band": cfg["rows_per_band"], "buffer_size": cfg["buffer_size"],
-            "similarity_threshold": cfg["similarity_threshold"], "redis_prefix": self._redis_config["prefix"],
+            "dimension": self._dim, "num_perm": self._config["num_perm"], "num_bands": self._config["num_bands"],
+            "rows_per_band": self._config["rows_per_band"], "buffer_size": self._buffer_size,
+            "similarity_threshold": self._config["similarity_threshold"], "redis_prefix": self._redis_config["prefix"],
         }
+
+    # ------------------------------------------------------------------ persistence (same on-disk format)
+    def save_to_disk(self, path) -> None:
+        """``metadata.json`` (version, config, redis config with the password redacted) + ``projections.npz``
+        (``arr_0 .. arr_{bands-1}``), the reference's format (main.py:846-895): an index saved by either
+        implementation loads in the other.  Bucket contents live in the storage backend, not here."""
+        self.flush()
+        out = Path(path)
+        out.mkdir(parents=True, exist_ok=True)
+        redis_cfg = self._redis_config.copy()
+        if "password" in redis_cfg:
+            redis_cfg["password"] = "<REDACTED>"
+        with open(out / "metadata.json", "w") as fh:
+            json.dump({"version": _FORMAT_VERSION, "config": self._config, "redis_config": redis_cfg}, fh, indent=2)
+        np.savez_compressed(out / "projections.npz", *self._hasher.projections)
+
+    @classmethod
+    def load_from_disk(cls, path, *, redis_config: Optional[Dict[str, Any]] = None,
+                       vector_fetch_fn: Optional[VectorFetchFn] = None, storage: Any = None) -> "LSHRS":
+        """Rebuild from :meth:`save_to_disk` output (reference: main.py:898-983).  The stored hyperplanes
+        replace the freshly drawn ones — assigning ``_hasher.projections`` re-uploads the device image."""
+        src = Path(path)
+        if not src.exists():
+            raise FileNotFoundError(f"Directory not found: {src}")
+        with open(src / "metadata.json") as fh:
+            meta = json.load(fh)
+        cfg = meta["config"]
+        redis_cfg = meta["redis_config"].copy()
+        if redis_config:
+            redis_cfg.update(redis_config)
+        inst = cls(
+            dim=cfg["dim"], num_perm=cfg["num_perm"], num_bands=cfg["num_bands"], rows_per_band=cfg["rows_per_band"],
+            similarity_threshold=cfg["similarity_threshold"], buffer_size=cfg["buffer_size"],
+            vector_fetch_fn=vector_fetch_fn, storage=storage, redis_host=redis_cfg["host"], redis_port=redis_cfg["port"],
+            redis_db=redis_cfg["db"], redis_password=redis_cfg["password"], redis_prefix=redis_cfg["prefix"],
+            decode_responses=redis_cfg["decode_responses"], seed=cfg["seed"])
+        with np.load(src / "projections.npz") as data:
+            inst._hasher.projections = [data[f"arr_{i}"].astype(np.float32) for i in range(len(data.files))]
+        return inst
+
+    def __getstate__(self) -> Dict[str, Any]:
+        """Config + hyperplanes; buffer is flushed, fetch function and storage are not carried
+        (reference: main.py:989-1008)."""
+        self.flush()
+        return {"config": self._config.copy(), "redis_config": self._redis_config.copy(),
+                "projections": [np.asarray(m, dtype=np.float32) for m in self._hasher.projections]}
+
+    def __setstate__(self, state: Dict[str, Any]) -> None:
+        cfg, rc = state["config"], state["redis_config"]
+        restored = self.__class__(
+            dim=cfg["dim"], num_perm=cfg["num_perm"], num_bands=cfg["num_bands"], rows_per_band=cfg["rows_per_band"],
+            similarity_threshold=cfg["similarity_threshold"], buffer_size=cfg["buffer_size"], vector_fetch_fn=None,
+            redis_host=rc["host"], redis_port=rc["port"], redis_db=rc["db"], redis_password=rc["password"],
+            redis_prefix=rc["prefix"], decode_responses=rc["decode_responses"], seed=cfg["seed"])
+        self.__dict__ = restored.__dict__
+        self._hasher.projections = [np.asarray(m, dtype=np.float32) for m in state["projections"]]
 
     # ------------------------------------------------------------------ helpers
     def _check_dim(self, vector) -> np.ndarray:

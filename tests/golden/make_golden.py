@@ -17,6 +17,7 @@ inputs, and stores inputs' seeds + the reference's outputs as data:
   g4_cosine.npz/.json   cosine_similarity / top_k_cosine outputs
   g5_orchestration.json LSHRS.index batches, get_top_k / get_above_p results, error timing
   g6_autoconfig.json    get_optimal_config table
+  g7_saved_index/       an index directory written by the reference's save_to_disk
 
 Fixtures are data only (inputs are regenerated from seeds by the tests).
 """
@@ -262,6 +263,15 @@ def main() -> None:
                     "batches": [len(b) for b in store4.batches], "ops_sha256": h.hexdigest(),
                     "top_k_row0": idx4.get_top_k(x1[0], topk=5)}
         json.dump(g5, open(os.path.join(OUT, "g5_orchestration.json"), "w"), indent=1)
+
+        # ---- G7 persistence: an index directory written by the reference itself ---------------
+        import shutil
+
+        g7 = os.path.join(OUT, "g7_saved_index")
+        shutil.rmtree(g7, ignore_errors=True)
+        idx7 = LSHRS(dim=32, num_bands=4, rows_per_band=4, num_perm=16, buffer_size=77, seed=9, storage=MockStorage(),
+                     redis_password="hunter2", redis_prefix="pfx", similarity_threshold=0.6)
+        idx7.save_to_disk(g7)
 
     print("golden fixtures written to", OUT)
 
