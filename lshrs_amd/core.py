@@ -32,6 +32,7 @@ import numpy as np
 
 from .bandrows import get_optimal_config
 from .hasher import LSHHasher
+from .similarity import rerank_padded as _rerank_padded
 from .similarity import top_k_cosine
 from .storage import BucketOperation, default_storage
 
@@ -250,6 +251,74 @@ class LSHRS:
 
     def get_above_p(self, vector, p: float = 0.95) -> List[Tuple[int, float]]:
         return list(self.query(vector, top_k=None, top_p=p))  # type: ignore[arg-type]
+
+    def query_many(self, vectors, *, top_k: Optional[int] = 10, top_p: Optional[float] = None, corpus=None
+                   ) -> List[Union[List[int], List[Tuple[int, float]]]]:
+        """Batched :meth:`query`: returns ``[query(v, top_k=top_k, top_p=top_p) for v in vectors]`` with ONE
+        signature launch for all queries and ONE rerank launch for all candidate lists (the step between the
+        two hot kernels; reference per query: main.py:524-658).
+
+        ``corpus``: optional device-resident ``(m, dim)`` float32 tensor whose row ``i`` is the vector of id
+        ``i``; with it the candidates are gathered on the device and ``vector_fetch_fn`` is not called.
+        """
+        arr = np.asarray(vectors, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[1] != self._dim:
+            raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")
+        if top_p is None and top_k is not None and top_k <= 0:
+            raise ValueError("top_k must be greater than zero when provided")
+        if top_p is not None and not 0 < top_p <= 1:
+            raise ValueError("top_p must be within the range (0, 1]")
+        if top_p is not None and top_k is not None and top_k <= 0:
+            raise ValueError("top_k must be greater than zero when provided")
+        nq = arr.shape[0]
+        if nq == 0:
+            return []
+        keys, flags = self._hasher.hash_batch_packed(arr, return_row_flags=True)
+        if (flags & 1).any():
+            raise ValueError(_ZERO_MSG)
+        ordered_ids: List[List[int]] = []
+        for qi in range(nq):
+            counts = self._candidate_counts_from_keys(keys[qi])
+            ordered_ids.append([idx for idx, _ in sorted(counts.items(), key=lambda item: (-item[1], item[0]))])
+        if top_p is None:
+            return [ids if top_k is None else ids[:top_k] for ids in ordered_ids]
+
+        # rerank every non-empty candidate list in one launch: a (q, c_max) index matrix padded with -1
+        # (out-of-range entries score NaN, which the device sort places last)
+        if corpus is None:
+            fetch = self._require_vector_fetch_fn()
+            blocks, offsets, total = [], [], 0
+            for ids in ordered_ids:
+                offsets.append(total)
+                if ids:
+                    got = np.asarray(fetch(ids), dtype=np.float32)
+                    if got.ndim != 2 or got.shape[1] != self._dim:
+                        raise ValueError(f"Fetched vectors must have shape (n, {self._dim}); received {got.shape}")
+                    if got.shape[0] != len(ids):
+                        raise ValueError("vector_fetch_fn returned mismatched batch size "
+                                         f"(expected {len(ids)}, received {got.shape[0]})")
+                    blocks.append(got)
+                    total += len(ids)
+            table = np.concatenate(blocks, axis=0) if blocks else np.zeros((1, self._dim), dtype=np.float32)
+        c_max = max((len(ids) for ids in ordered_ids), default=0)
+        if c_max == 0:
+            return [[] for _ in ordered_ids]
+        cand = np.full((nq, c_max), -1, dtype=np.int64)
+        for qi, ids in enumerate(ordered_ids):
+            if ids:
+                cand[qi, :len(ids)] = ids if corpus is not None else np.arange(offsets[qi], offsets[qi] + len(ids))
+        ranked = _rerank_padded(arr, corpus if corpus is not None else table, cand)
+        out: List[List[Tuple[int, float]]] = []
+        for qi, ids in enumerate(ordered_ids):
+            if not ids:
+                out.append([])
+                continue
+            scored = [(ids[pos], score) for pos, score in ranked[qi][:len(ids)]]
+            limit = max(1, math.ceil(len(scored) * top_p))
+            if top_k is not None:
+                limit = min(limit, top_k)
+            out.append(scored[:limit])
+        return out
 
     # ------------------------------------------------------------------ storage pass-throughs
     def delete(self, indices: Union[int, Sequence[int]]) -> None:

@@ -21,7 +21,8 @@ import numpy as np
 
 from . import _native
 
-__all__ = ["l2_norm", "cosine_similarity", "top_k_cosine", "rerank_batch", "cosine_scores_device", "l2_normalize_device",
+__all__ = ["l2_norm", "cosine_similarity", "top_k_cosine", "rerank_batch", "rerank_padded", "cosine_scores_device",
+           "l2_normalize_device",
            "topk_desc_device"]
 
 _TOPK_MAX_Q = 65535
@@ -207,3 +208,28 @@ def rerank_batch(queries, corpus, cand_idx, *, k: int, return_tensors: bool = Fa
     o = order.cpu().numpy()
     s = sorted_scores.cpu().numpy()
     return [[(int(p), float(v)) for p, v in zip(o[i], s[i])] for i in range(o.shape[0])]
+
+
+def rerank_padded(queries, corpus, cand_idx):
+    """Ragged batched rerank: ``cand_idx`` is ``(q, c_max)`` int64 with ``-1`` padding after each query's
+    candidates.  Returns, per query, ``[(position, score), ...]`` over its *valid* candidates in descending
+    score (padding scores NaN on the device and sorts last, so it is simply cut off).  Zero-norm vectors raise
+    like the reference; an index outside the corpus raises ``IndexError``."""
+    torch = _native.require_gpu()
+
+    def dev(a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a if a.is_cuda else a.cuda()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).cuda()
+
+    d_q, d_c, d_i = dev(queries, np.float32), dev(corpus, np.float32), dev(cand_idx, np.int64)
+    scores, status, qstatus = cosine_scores_device(d_c, d_q, d_i)
+    valid = d_i >= 0
+    if bool((qstatus != 0).any()) or bool(((status == 1) & valid).any()):
+        raise ValueError("Cannot normalize zero vector")
+    if bool(((status == 2) & valid).any()):
+        raise IndexError("candidate index out of range of the corpus")
+    order, sorted_scores = topk_desc_device(scores, int(d_i.shape[1]))
+    counts = valid.sum(dim=1).cpu().numpy()
+    o, s = order.cpu().numpy(), sorted_scores.cpu().numpy()
+    return [[(int(p), float(v)) for p, v in zip(o[i, :counts[i]], s[i, :counts[i]])] for i in range(o.shape[0])]

@@ -37,4 +37,16 @@ def make_cpu_lshrs(monkeypatch, **kw):
     kw.setdefault("storage", InMemoryStorage())
     kw["hasher"] = OracleBackedHasher(nb, r, dim, kw.get("seed", 42))
     monkeypatch.setattr(core, "top_k_cosine", O.top_k_cosine)
+    monkeypatch.setattr(core, "_rerank_padded", oracle_rerank_padded)
     return LSHRS(**kw)
+
+
+def oracle_rerank_padded(queries, corpus, cand_idx):
+    """CPU stand-in for lshrs_amd.similarity.rerank_padded: the oracle's top_k_cosine per query."""
+    corpus = np.asarray(corpus, dtype=np.float32)
+    out = []
+    for qi in range(len(queries)):
+        idx = np.asarray(cand_idx[qi])
+        idx = idx[idx >= 0]
+        out.append(O.top_k_cosine(queries[qi], corpus[idx], k=len(idx)) if len(idx) else [])
+    return out

@@ -137,3 +137,32 @@ def test_recall_smoke_768d():
         assert idx.get_top_k(near, topk=1) == [i]
         res = idx.get_above_p(near, p=1.0)
         assert res[0][0] == i and res[0][1] > 0.99
+
+
+def test_query_many_through_hip_equals_query_loop():
+    """One signature launch + one rerank launch for all queries == the per-query path; device-resident corpus too."""
+    import torch
+
+    from lshrs_amd import LSHRS, InMemoryStorage
+
+    rng = np.random.default_rng(21)
+    data = rng.standard_normal((4000, 768)).astype(np.float32)
+    idx = LSHRS(dim=768, num_perm=256, storage=InMemoryStorage(), vector_fetch_fn=lambda ids: data[np.asarray(ids)])
+    idx.index(list(range(4000)), data)
+    # make some buckets crowded so candidate lists are ragged and non-trivial
+    dup = data[:50] + 0.02 * rng.standard_normal((50, 768)).astype(np.float32)
+    idx.index(list(range(4000, 4050)), dup)
+    data = np.concatenate([data, dup])
+    queries = data[rng.choice(4050, 120, replace=False)] + 0.03 * rng.standard_normal((120, 768)).astype(np.float32)
+    for kw in ({"top_k": 5, "top_p": None}, {"top_k": None, "top_p": 1.0}, {"top_k": 2, "top_p": 0.5}):
+        many = idx.query_many(queries, **kw)
+        single = [idx.query(q, **kw) for q in queries]
+        for a, b in zip(many, single):
+            if kw["top_p"] is None:
+                assert a == b
+            else:
+                assert [i for i, _ in a] == [i for i, _ in b]
+                assert np.abs(np.array([s for _, s in a]) - np.array([s for _, s in b])).max() <= 1e-6
+    corpus = torch.from_numpy(data).cuda()
+    on_device = idx.query_many(queries, top_k=None, top_p=1.0, corpus=corpus)
+    assert [[i for i, _ in r] for r in on_device] == [[i for i, _ in r] for r in idx.query_many(queries, top_k=None, top_p=1.0)]

@@ -270,3 +270,35 @@ def test_create_signatures_from_batches(monkeypatch):
     assert store.total_operations == 30 * 4 and len(store.batches) == 2
     with pytest.raises(ValueError, match="Unsupported"):
         idx.create_signatures("csv")
+
+
+def test_query_many_equals_looping_query(monkeypatch):
+    """Batched multi-query == [query(v) for v in vectors], ragged candidate lists included."""
+    rng = np.random.default_rng(77)
+    data = rng.standard_normal((300, 32)).astype(np.float32)
+    idx = small(monkeypatch, vector_fetch_fn=lambda ids: data[np.asarray(ids)], buffer_size=100_000)
+    idx.index(list(range(300)), data)
+    queries = np.concatenate([data[:20] + 0.05 * rng.standard_normal((20, 32)).astype(np.float32),
+                              rng.standard_normal((5, 32)).astype(np.float32) * 50.0])
+    for kw in ({"top_k": 5, "top_p": None}, {"top_k": None, "top_p": None}, {"top_k": None, "top_p": 0.5},
+               {"top_k": 3, "top_p": 1.0}, {"top_k": None, "top_p": 1e-9}):
+        many = idx.query_many(queries, **kw)
+        single = [idx.query(q, **kw) for q in queries]
+        assert len(many) == len(single) == 25
+        for a, b in zip(many, single):
+            if kw["top_p"] is None:
+                assert a == b
+            else:
+                assert [i for i, _ in a] == [i for i, _ in b]
+                assert np.allclose([s for _, s in a], [s for _, s in b], atol=1e-6)
+    assert idx.query_many(np.empty((0, 32), dtype=np.float32)) == []
+    with pytest.raises(ValueError, match="zero vector"):
+        idx.query_many(np.zeros((2, 32), dtype=np.float32))
+    with pytest.raises(ValueError, match="shape"):
+        idx.query_many(np.ones((2, 31), dtype=np.float32))
+    with pytest.raises(ValueError, match="top_k"):
+        idx.query_many(queries, top_k=0)
+    with pytest.raises(ValueError, match="top_p"):
+        idx.query_many(queries, top_k=None, top_p=2.0)
+    empty = small(monkeypatch, storage=InMemoryStorage(), vector_fetch_fn=lambda ids: data[np.asarray(ids)])
+    assert empty.query_many(queries[:3], top_k=None, top_p=0.5) == [[], [], []]
