@@ -102,6 +102,11 @@ int lshrs_scatter_band_keys_u8(uint8_t* keys, int32_t num_bands, int32_t band_by
                                const int64_t* rows, const int32_t* bands, const uint8_t* patch, int64_t m,
                                void* stream);
 
+/* Storage-op path: hex[2i], hex[2i+1] = lower-case hex digits of keys[i] — the text
+ * `hash_val.hex()` puts into the reference's bucket key `{prefix}:{band}:bucket:{hex}`
+ * (lshrs/storage/redis.py:225), for all N x bands keys in one pass. */
+int lshrs_keys_to_hex_u8(const uint8_t* keys, int64_t nbytes, uint8_t* hex, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Cosine rerank — replaces cosine_similarity / top_k_cosine (lshrs/utils/similarity.py:80-90,
  * 157-183) and the per-candidate l2_norm (lshrs/utils/norm.py:48-61).

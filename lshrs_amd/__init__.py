@@ -15,11 +15,13 @@ from ._native import NativeLibraryError
 from .bandrows import get_optimal_config
 from .core import LSHRS, lshrs
 from .hasher import LSHHasher
+from .packed_ops import RedisPackedWriter, group_by_bucket, hex_keys
 from .similarity import cosine_similarity, l2_norm, rerank_batch, top_k_cosine
 from .storage import BucketOperation, InMemoryStorage
 
 __all__ = [
     "LSHRS", "lshrs", "LSHHasher", "HashSignatures", "top_k_cosine", "cosine_similarity", "l2_norm",
     "rerank_batch", "get_optimal_config", "InMemoryStorage", "BucketOperation", "NativeLibraryError",
+    "RedisPackedWriter", "group_by_bucket", "hex_keys",
 ]
 __version__ = "0.1.0"

@@ -69,6 +69,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_gather_tied_rows_f32.restype = c.c_int
     lib.lshrs_scatter_band_keys_u8.argtypes = [vp, i32, i32, vp, vp, vp, i64, vp]
     lib.lshrs_scatter_band_keys_u8.restype = c.c_int
+    lib.lshrs_keys_to_hex_u8.argtypes = [vp, i64, vp, vp]
+    lib.lshrs_keys_to_hex_u8.restype = c.c_int
     lib.lshrs_cosine_batch_f32.argtypes = [vp, i64, i64, i32, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.lshrs_cosine_batch_f32.restype = c.c_int
     lib.lshrs_l2_normalize_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp]
@@ -89,6 +91,7 @@ EXPORTS = (
     "lshrs_gather_rows_f32",
     "lshrs_gather_tied_rows_f32",
     "lshrs_scatter_band_keys_u8",
+    "lshrs_keys_to_hex_u8",
     "lshrs_cosine_batch_f32",
     "lshrs_l2_normalize_f32",
     "lshrs_topk_workspace_bytes",

@@ -51,8 +51,10 @@ class LSHRS:
     """Redis-backed LSH index whose hashing and reranking run on MI355X.
 
     Keyword arguments are those of the reference constructor (lshrs/core/main.py:154-173).
-    Extras: ``hasher`` (inject a ready hasher object; default builds ``LSHHasher``) and
-    ``device`` (GPU index for the default hasher).
+    Extras: ``hasher`` (inject a ready hasher object; default builds ``LSHHasher``), ``device`` (GPU index for
+    the default hasher) and ``packed_ingest`` (hand whole key arrays to ``storage.batch_add_packed`` instead of
+    building one ``(band, key, id)`` tuple per operation; off by default so that ``batch_add`` sees exactly the
+    reference's operation lists).
     """
 
     def __init__(
@@ -76,6 +78,7 @@ class LSHRS:
         seed: int = 42,
         hasher: Any = None,
         device: Any = None,
+        packed_ingest: bool = False,
     ) -> None:
         if dim <= 0:
             raise ValueError("Vector dimensionality must be greater than zero")
@@ -97,6 +100,7 @@ class LSHRS:
         self._dim = dim
         self._buffer_size = buffer_size
         self._vector_fetch_fn = vector_fetch_fn
+        self._packed_ingest = bool(packed_ingest)
         self._hasher = hasher if hasher is not None else LSHHasher(
             num_bands=num_bands, rows_per_band=rows_per_band, dim=dim, seed=seed, device=device)
         self._storage = storage if storage is not None else default_storage(
@@ -171,6 +175,18 @@ class LSHRS:
             stop, error = neg, ValueError("index must be non-negative")
         elif zero is not None:
             stop, error = zero, ValueError(_ZERO_MSG)
+
+        if self._packed_ingest and hasattr(self._storage, "batch_add_packed"):
+            # array path: same buckets, same members, no per-operation Python objects.
+            # Anything already buffered goes first so the storage sees operations in the original order.
+            self.flush()
+            per_call = max(1, -(-self._buffer_size // keys.shape[1]))  # vectors per storage call ~ buffer_size ops
+            for lo in range(0, stop, per_call):
+                hi = min(stop, lo + per_call)
+                self._storage.batch_add_packed(ids[lo:hi], keys[lo:hi])
+            if error is not None:
+                raise error
+            return
 
         nb = keys.shape[1]
         bb = keys.shape[2]

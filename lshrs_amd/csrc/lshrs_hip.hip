@@ -646,6 +646,20 @@ __global__ void gather_tied_rows_kernel(const float* __restrict__ X, int64_t ldx
   }
 }
 
+// Lower-case hex of every key byte (what `bytes.hex()` gives; the text of the reference's bucket keys,
+// lshrs/storage/redis.py:225), 16 input bytes -> 32 output characters per thread.
+__global__ void keys_to_hex_kernel(const uint8_t* __restrict__ keys, int64_t nbytes, uint8_t* __restrict__ hex) {
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (t >= nbytes) return;
+  const int64_t end = t + 16 < nbytes ? t + 16 : nbytes;
+  for (int64_t i = t; i < end; ++i) {
+    const uint8_t b = keys[i];
+    const uint8_t hi = b >> 4, lo = b & 15;
+    hex[2 * i] = (uint8_t)(hi < 10 ? '0' + hi : 'a' + (hi - 10));
+    hex[2 * i + 1] = (uint8_t)(lo < 10 ? '0' + lo : 'a' + (lo - 10));
+  }
+}
+
 __global__ void scatter_keys_kernel(uint8_t* __restrict__ keys, int num_bands, int bb, const int64_t* __restrict__ rows,
                                     const int32_t* __restrict__ bands, const uint8_t* __restrict__ patch, int64_t m) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1099,6 +1113,16 @@ int lshrs_gather_tied_rows_f32(const float* X, int64_t ldx, int32_t dim, const i
   const int blocks = tie_cap < 2048 ? tie_cap : 2048;
   hipLaunchKernelGGL(gather_tied_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X,
                      ldx, dim, tie_list, tie_count, tie_cap, dst);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_keys_to_hex_u8(const uint8_t* keys, int64_t nbytes, uint8_t* hex, void* stream) {
+  if (nbytes == 0) return 0;
+  if (keys == nullptr || hex == nullptr || nbytes < 0) return LSHRS_E_BADARG;
+  const int64_t threads = (nbytes + 15) / 16;
+  if ((threads + 255) / 256 > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  hipLaunchKernelGGL(keys_to_hex_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), keys, nbytes, hex);
   return -(int)hipGetLastError();
 }
 

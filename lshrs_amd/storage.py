@@ -31,6 +31,7 @@ class InMemoryStorage:
         self._lock = threading.Lock()
         self._fail_on_flush = fail_on_flush
         self.batches: List[List[BucketOperation]] = []
+        self.packed_batches: List[Tuple[int, int]] = []   # (vectors, distinct buckets) per batch_add_packed call
         self.closed = False
 
     # key format of the reference (redis.py:187-225)
@@ -53,6 +54,19 @@ class InMemoryStorage:
             self.batches.append(ops)
             for band_id, hash_val, index in ops:
                 self._buckets.setdefault(self.bucket_key(band_id, hash_val), set()).add(int(index))
+
+    def batch_add_packed(self, ids, keys) -> None:
+        """Array form of :meth:`batch_add` (see lshrs_amd/packed_ops.py): ``keys`` is the ``(n, bands, B)``
+        uint8 key array, ``ids`` the n vector ids.  Same bucket contents as the equivalent op list."""
+        from .packed_ops import group_by_bucket
+
+        if self._fail_on_flush:
+            raise ConnectionError("simulated storage failure")
+        groups = list(group_by_bucket(ids, keys))
+        with self._lock:
+            self.packed_batches.append((len(ids), len(groups)))
+            for band, key_bytes, members in groups:
+                self._buckets.setdefault(self.bucket_key(band, key_bytes), set()).update(int(m) for m in members)
 
     def remove_indices(self, indices: Iterable[int]) -> None:
         gone = {int(i) for i in indices}

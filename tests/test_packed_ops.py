@@ -1,0 +1,119 @@
+"""Packed-key -> storage-op path: grouping and writers (CPU), hex kernel (GPU)."""
+
+from __future__ import annotations
+
+import contextlib
+
+import numpy as np
+import pytest
+
+from lshrs_amd import InMemoryStorage, LSHRS, RedisPackedWriter, group_by_bucket
+from tests._doubles import OracleBackedHasher, make_cpu_lshrs
+
+
+def ops_from_keys(ids, keys):
+    return [(b, keys[j, b].tobytes(), int(ids[j])) for j in range(len(ids)) for b in range(keys.shape[1])]
+
+
+def test_groups_cover_exactly_the_reference_operations():
+    rng = np.random.default_rng(0)
+    keys = rng.integers(0, 4, size=(500, 6, 2), dtype=np.uint8)     # few distinct values: crowded buckets
+    ids = rng.permutation(10_000)[:500]
+    got = set()
+    for band, key, members in group_by_bucket(ids, keys):
+        assert len(set(members.tolist())) == len(members)
+        got.update((band, key, int(m)) for m in members)
+    assert got == set(ops_from_keys(ids, keys))
+    with pytest.raises(ValueError):
+        list(group_by_bucket(ids[:10], keys))
+
+
+def test_packed_ingest_builds_the_same_buckets(monkeypatch):
+    rng = np.random.default_rng(1)
+    data = rng.standard_normal((700, 32)).astype(np.float32)
+    data[300:340] = data[:40] + 1e-3 * rng.standard_normal((40, 32)).astype(np.float32)   # shared buckets
+    plain, packed = InMemoryStorage(), InMemoryStorage()
+    make_cpu_lshrs(monkeypatch, dim=32, num_bands=4, rows_per_band=4, num_perm=16, storage=plain).index(list(range(700)), data)
+    idx = make_cpu_lshrs(monkeypatch, dim=32, num_bands=4, rows_per_band=4, num_perm=16, storage=packed,
+                         packed_ingest=True, buffer_size=400)
+    idx.ingest(9999, data[0])                       # something buffered: must be flushed before the packed batch
+    idx.index(list(range(700)), data)
+    assert packed.batches and packed.batches[0][0][2] == 9999
+    assert [n for n, _ in packed.packed_batches] == [100] * 7           # ~buffer_size operations per storage call
+    expect = {k: set(v) for k, v in plain._buckets.items()}
+    for key in packed._buckets:
+        expect.setdefault(key, set())
+    for b, kb, i in packed.batches[0]:
+        expect[packed.bucket_key(b, kb)].add(i)
+    assert packed._buckets == expect
+    assert idx.get_top_k(data[5], topk=1) == [5] or 9999 in idx.get_top_k(data[0], topk=2)
+    # error timing: rows before the bad one are stored, then the same error
+    bad = data[:10].copy()
+    bad[6] = 0
+    store = InMemoryStorage()
+    with pytest.raises(ValueError, match="zero vector"):
+        make_cpu_lshrs(monkeypatch, dim=32, num_bands=4, rows_per_band=4, num_perm=16, storage=store,
+                       packed_ingest=True).index(list(range(10)), bad)
+    assert {i for s in store._buckets.values() for i in s} == set(range(6))
+
+
+class FakePipeline:
+    def __init__(self, log):
+        self.log = log
+
+    def sadd(self, name, *members):
+        self.log.append((name, members))
+
+
+class FakeRedisStorage:
+    """The two members of the reference's RedisStorage the writer uses (redis.py:187, :508)."""
+    prefix = "lsh"
+
+    def __init__(self):
+        self.commands = []
+
+    def bucket_key(self, band_id, hash_val):
+        return f"{self.prefix}:{band_id}:bucket:{hash_val.hex()}"
+
+    @contextlib.contextmanager
+    def pipeline(self):
+        yield FakePipeline(self.commands)
+
+    def get_bucket(self, band_id, hash_val):
+        return {1, 2}
+
+
+def test_redis_writer_sends_the_same_members_in_fewer_commands():
+    rng = np.random.default_rng(2)
+    keys = rng.integers(0, 3, size=(400, 4, 1), dtype=np.uint8)
+    ids = np.arange(400)
+    fake = FakeRedisStorage()
+    writer = RedisPackedWriter(fake, max_members_per_command=50)
+    n = writer.batch_add_packed(ids, keys)
+    assert n == len(fake.commands) < 400 * 4
+    assert all(len(m) <= 50 for _, m in fake.commands)
+    sent = {(name, m) for name, members in fake.commands for m in members}
+    want = {(fake.bucket_key(b, k), i) for b, k, i in ops_from_keys(ids, keys)}   # what one SADD per op would add
+    assert sent == want
+    assert writer.get_bucket(0, b"\x00") == {1, 2}          # everything else is delegated
+
+
+@pytest.mark.gpu
+def test_hex_kernel_equals_bytes_hex():
+    import torch
+
+    from lshrs_amd import hex_keys
+    from lshrs_amd.packed_ops import hex_keys_device
+
+    rng = np.random.default_rng(3)
+    for shape in ((1000, 16, 2), (77, 3, 1), (5, 16, 4), (1, 1, 3), (0, 4, 2)):
+        keys = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        hx = hex_keys(keys)
+        assert hx.shape == shape[:2] and hx.dtype == np.dtype(f"S{2 * shape[2]}")
+        for i in range(0, shape[0], max(1, shape[0] // 7)):
+            for b in range(shape[1]):
+                assert hx[i, b] == keys[i, b].tobytes().hex().encode()
+    every = np.arange(256, dtype=np.uint8).reshape(16, 16, 1)
+    assert [h.decode() for h in hex_keys(every).reshape(-1)] == [f"{v:02x}" for v in range(256)]
+    dev = hex_keys_device(torch.from_numpy(every).cuda())
+    assert dev.shape == (16, 16, 2) and dev.is_cuda
