@@ -456,7 +456,7 @@ class LSHRS:
             from lshrs.io.postgres import iter_postgres_vectors  # reference component
             return iter_postgres_vectors
         if normalized in {"parquet", "pq"}:
-            from lshrs.io.parquet import iter_parquet_vectors  # reference component
+            from .parquet_fast import iter_parquet_vectors  # same contract as the reference's, array-based
             return iter_parquet_vectors
         raise ValueError(f"Unsupported signature creation format '{format}'")
 
