@@ -50,22 +50,39 @@ def hex_keys(keys) -> np.ndarray:
     return np.ascontiguousarray(hx).view(f"S{hx.shape[2]}")[:, :, 0]
 
 
+def _band_codes(col: np.ndarray) -> np.ndarray:
+    """(n, B) key bytes of one band -> one sortable integer per row (B <= 8), else a void view."""
+    n, bb = col.shape
+    if bb <= 8:
+        wide = np.zeros((n, 8), dtype=np.uint8)
+        wide[:, :bb] = col
+        return wide.view(np.uint64)[:, 0]
+    return np.ascontiguousarray(col).view(np.dtype((np.void, bb)))[:, 0]
+
+
 def group_by_bucket(ids: Sequence[int], keys: np.ndarray) -> Iterator[Tuple[int, bytes, np.ndarray]]:
     """Yield ``(band, key_bytes, member_ids)`` for every distinct bucket touched by this batch; members keep
-    their order of appearance.  ``keys`` is the ``(n, bands, B)`` uint8 array; pure data movement."""
+    their order of appearance.  ``keys`` is the ``(n, bands, B)`` uint8 array; pure data movement (one stable
+    integer sort per band, no Python loop over vectors)."""
     keys = np.ascontiguousarray(keys, dtype=np.uint8)
     id_arr = np.asarray(ids, dtype=np.int64)
     n, nb, bb = keys.shape
     if id_arr.shape[0] != n:
         raise ValueError("ids and keys disagree in length")
+    if n == 0:
+        return
     for band in range(nb):
-        col = np.ascontiguousarray(keys[:, band, :]).view(np.dtype((np.void, bb)))[:, 0]
-        uniq, inverse = np.unique(col, return_inverse=True)
-        order = np.argsort(inverse, kind="stable")
-        bounds = np.flatnonzero(np.r_[True, np.diff(inverse[order]) != 0, True])
-        for g in range(len(uniq)):
-            members = id_arr[order[bounds[g]:bounds[g + 1]]]
-            yield band, uniq[g].tobytes(), members
+        col = keys[:, band, :]
+        codes = _band_codes(col)
+        order = np.argsort(codes, kind="stable")
+        sorted_codes = codes[order]
+        starts = np.flatnonzero(np.r_[True, sorted_codes[1:] != sorted_codes[:-1]])
+        stops = np.r_[starts[1:], n]
+        members_sorted = id_arr[order]
+        first_rows = order[starts]
+        key_blob = np.ascontiguousarray(col[first_rows]).tobytes()
+        for g in range(len(starts)):
+            yield band, key_blob[g * bb:(g + 1) * bb], members_sorted[starts[g]:stops[g]]
 
 
 class RedisPackedWriter:

@@ -66,7 +66,7 @@ class InMemoryStorage:
         with self._lock:
             self.packed_batches.append((len(ids), len(groups)))
             for band, key_bytes, members in groups:
-                self._buckets.setdefault(self.bucket_key(band, key_bytes), set()).update(int(m) for m in members)
+                self._buckets.setdefault(self.bucket_key(band, key_bytes), set()).update(members.tolist())
 
     def remove_indices(self, indices: Iterable[int]) -> None:
         gone = {int(i) for i in indices}
