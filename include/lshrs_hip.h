@@ -77,6 +77,24 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
                              int64_t* tie_list, int32_t tie_cap, int32_t* tie_count, float tau,
                              uint8_t* row_flags, void* stream);
 
+/* Split-precision form of lshrs_sig_hash_batch_f32 (same keys, same tie list, ~3x the rate): stage 1 evaluates
+ * every projection as xh*ph + xh*pm + xm*ph on the bf16 matrix cores (x = xh + xm + ..., bf16 pieces) — the terms
+ * it drops are bounded by 192 units of 2^-24 ||x|| ||p|| — and lists every projection with
+ * NOT(|y1| > tau1 * ||x|| * ||p||) in flag_list; stage 2 re-evaluates exactly those as the f32 fmaf chain of the
+ * f32 kernel, corrects their key bits and reports ties (|y| < tau ...) as above.  With tau1 >= 2^-16 (256 units)
+ * the keys are those of lshrs_sig_hash_batch_f32.
+ *   flag_list int64[2*flag_cap], flag_count int32[1] (zeroed by the caller): scratch with the tie-list format;
+ *   if *flag_count > flag_cap afterwards the pass is incomplete and must be repeated with a larger list.
+ * Only for shapes with >= 256 padded columns whose key rows are whole 32-bit words (else LSHRS_E_TOOLARGE:
+ * use lshrs_sig_hash_batch_f32). */
+int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
+                                   const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                                   uint8_t* keys,
+                                   int64_t* tie_list, int32_t tie_cap, int32_t* tie_count, float tau,
+                                   uint8_t* row_flags,
+                                   int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
+                                   void* stream);
+
 /* Diagnostic twin of the above: writes the raw projections instead of their sign bits.
  *   Y (n, ldy) f32 with ldy >= padded columns rounded up to the kernel's column tile
  *   (lshrs_sig_padded_columns()); column b*8*B + i holds dot(P[b*rows+i], X[row]).

@@ -18,6 +18,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -73,10 +75,17 @@ inline SigGeom sig_fine_geom(const SigGeom& g) {
 }
 inline bool sig_has_fine(const SigGeom& g) { return g.nt > 1; }
 inline int64_t sig_main_floats(const SigGeom& g) { return sig_image_floats(g) + sig_norm_floats(g) + sig_normmax_floats(g); }
-inline int64_t sig_workspace_floats(const SigGeom& g) {
-  if (!sig_has_fine(g)) return sig_main_floats(g);
+inline int64_t sig_fine_floats(const SigGeom& g) {
+  if (!sig_has_fine(g)) return 0;
   const SigGeom f = sig_fine_geom(g);
-  return sig_main_floats(g) + sig_image_floats(f) + sig_normmax_floats(f);
+  return sig_image_floats(f) + sig_normmax_floats(f);
+}
+// Split-precision first pass (PIPE = 3): the same fragment image with every hyperplane entry as two bf16 values
+// (hi = bf16(p), mid = bf16(p - hi)) instead of one f32 — same byte size; wide geometry (NT = 8) only.
+inline bool sig_has_split(const SigGeom& g) { return g.nt == 8; }
+inline int64_t sig_split_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
+inline int64_t sig_workspace_floats(const SigGeom& g) {
+  return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? sig_image_floats(g) : 0);
 }
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
 
@@ -117,6 +126,46 @@ __global__ void pack_image_kernel(const float* __restrict__ P, int num_bands, in
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (k0 + r < dim) v[r] = src[k0 + r];
+  }
+  image[c] = v;
+}
+
+__device__ __forceinline__ uint16_t bf16_rne_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+  return (uint16_t)(u >> 16);
+}
+
+// bf16 hi/mid image: block (jt, 2*half + part) of k-tile kt holds, for lane (col c = lane & 31, h = lane >> 5), the 8
+// values part(P'[col][k = 32 kt + 16 half + 8 h + j]), j = 0..7 — one MFMA 32x32x16 B operand per lane.
+__global__ void pack_image_bf16_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb, int nt,
+                                       int ktiles, int64_t chunks, u16x8* __restrict__ image) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= chunks) return;
+  const int lane = (int)(c & 63);
+  const int part = (int)((c >> 6) & 1);
+  const int half = (int)((c >> 7) & 1);
+  int64_t t = c >> 8;
+  const int jt = (int)(t % nt);
+  t /= nt;
+  const int kt = (int)(t % ktiles);
+  const int cb = (int)(t / ktiles);
+  const int col = (cb * nt + jt) * 32 + (lane & 31);
+  const int band = col / (bb * 8);
+  const int bit = col % (bb * 8);
+  const int k0 = kt * kKTile + 16 * half + 8 * (lane >> 5);
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (band < num_bands && bit < rows) {
+    const float* src = P + ((int64_t)band * rows + bit) * dim;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (k0 + j < dim) {
+        const float x = src[k0 + j];
+        const uint16_t hi = bf16_rne_bits(x);
+        const float hif = __uint_as_float((uint32_t)hi << 16);
+        v[j] = part == 0 ? hi : bf16_rne_bits(x - hif);
+      }
+    }
   }
   image[c] = v;
 }
@@ -278,6 +327,32 @@ __device__ __forceinline__ void mfma_group(const f32x4 (&a)[M], const f32x4 (&b)
   }
 }
 
+// ---- split-precision main loop (PIPE = 3) ---------------------------------------------------------------
+// y1 = sum_k (xh*ph + xh*pm + xm*ph) on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate), x = xh + xm + ex split
+// on the fly, p pre-split in the image.  The dropped terms are bounded by 3 * 2^-18 * sum|x_k p_k| <= 192 units
+// of 2^-24 ||x|| ||p||; every projection with |y1| inside the (wider) stage-1 window is re-evaluated by
+// sig_fix_kernel as the exact f32 fmaf chain, so the final bits equal the f32 kernel's.
+__device__ __forceinline__ void split_bf16(const f32x4& lo4, const f32x4& hi4, bf16x8& hi, bf16x8& mid) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = j < 4 ? lo4[j & 3] : hi4[j & 3];
+    const __bf16 h = (__bf16)v;             // v_cvt_pk_bf16_f32: round to nearest even
+    hi[j] = h;
+    mid[j] = (__bf16)(v - (float)h);        // v - h is exact in f32
+  }
+}
+
+// Stage-1 flag: NOT (|y| > bound) — also true for a NaN y, so a projection that overflowed in bf16 is re-evaluated.
+__device__ __forceinline__ void deposit_not_above(uint32_t& word, float y, float bound, int lane_lo, int lane_hi) {
+  asm("v_cmp_ngt_f32 vcc, |%1|, %2\n\t"
+      "s_nop 1\n\t"
+      "v_writelane_b32 %0, vcc_lo, %3\n\t"
+      "v_writelane_b32 %0, vcc_hi, %4"
+      : "+v"(word)
+      : "v"(y), "v"(bound), "n"(lane_lo), "n"(lane_hi)
+      : "vcc");
+}
+
 // Ballot + deposit in one block.  The 64-lane compare result (VCC: low half = the 32 columns of row rho,
 // high half = the same columns of row rho + 4) is written into the two lanes that own those output
 // words with v_writelane_b32 (immediate lane select; this clang exposes no builtin for it).
@@ -317,7 +392,8 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   constexpr int kStageFloats = PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats;  // ring of 3 halves, or 2 whole tiles
   constexpr int kWaveRows = kRowsPerWave * M;
   constexpr int kBlockRows = W * kWaveRows;
-  static_assert(M == 1 || PIPE == 1, "two row tiles per wave are only built for the ring loop");
+  static_assert(M == 1 || PIPE == 1 || PIPE == 3, "two row tiles per wave are only built for the ring loops");
+  constexpr bool SPLIT = PIPE == 3;
   __shared__ __attribute__((aligned(16))) float lds[kStageFloats + W * kWaveRows];
 
   const int tid = threadIdx.x;
@@ -355,7 +431,68 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     t_real = __builtin_amdgcn_s_memrealtime();
   }
 
-  if (PIPE == 1) {
+  if (PIPE == 3) {
+    // halves of 16 k = one bf16 MFMA k-step; ring and staging exactly as PIPE = 1 (block (jt, 2*half + part))
+    const int halves = 2 * ktiles;
+    f32x4 a_cur[2][M], a_nxt[2][M];  // raw f32 x: 8 consecutive k per lane and row tile
+    stage_p_half<NT, W>(img, 0, lds, tid);
+    stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
+#pragma unroll
+    for (int mt = 0; mt < M; ++mt) {
+      f32x4 t[2];
+      load_x_half<ALIGNED>(xrow[mt], 8 * h, dim, t);
+      a_cur[0][mt] = t[0];
+      a_cur[1][mt] = t[1];
+    }
+    __syncthreads();
+    for (int hh = 0; hh < halves; ++hh) {
+      const float* cur = lds + (hh % 3) * kHalfFloats;
+      if (hh + 2 < halves)
+        stage_p_half<NT, W>(img + (size_t)((hh + 2) >> 1) * kTileFloats, (hh + 2) & 1, lds + ((hh + 2) % 3) * kHalfFloats,
+                            tid);
+      if (hh + 1 < halves) {
+#pragma unroll
+        for (int mt = 0; mt < M; ++mt) {
+          f32x4 t[2];
+          load_x_half<ALIGNED>(xrow[mt], ((hh + 1) >> 1) * kKTile + 16 * ((hh + 1) & 1) + 8 * h, dim, t);
+          a_nxt[0][mt] = t[0];
+          a_nxt[1][mt] = t[1];
+        }
+      }
+      f32x4 bh[NT], bm[NT];
+      read_frags<NT>(cur, 0, lane, bh);
+      read_frags<NT>(cur, 1, lane, bm);
+      bf16x8 ah[M], am[M];
+#pragma unroll
+      for (int mt = 0; mt < M; ++mt) {
+        split_bf16(a_cur[0][mt], a_cur[1][mt], ah[mt], am[mt]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v0 = a_cur[0][mt][e], v1 = a_cur[1][mt][e];
+          ss[mt] = __builtin_fmaf(v0, v0, ss[mt]);
+          ss[mt] = __builtin_fmaf(v1, v1, ss[mt]);
+          amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+        }
+      }
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        const bf16x8 bhj = __builtin_bit_cast(bf16x8, bh[jt]);
+        const bf16x8 bmj = __builtin_bit_cast(bf16x8, bm[jt]);
+#pragma unroll
+        for (int mt = 0; mt < M; ++mt) {
+          acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bhj, acc[mt][jt], 0, 0, 0);
+          acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bmj, acc[mt][jt], 0, 0, 0);
+          acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mt], bhj, acc[mt][jt], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < M; ++mt) {
+        a_cur[0][mt] = a_nxt[0][mt];
+        a_cur[1][mt] = a_nxt[1][mt];
+      }
+    }
+  } else if (PIPE == 1) {
     const int halves = 2 * ktiles;
     f32x4 a_cur[2][M], a_nxt[2][M];  // [qq][row tile]
     f32x4 b0[NT], b1[NT];
@@ -514,6 +651,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
       // NaN norms (a NaN in x) must not hide the finite rows next to them: fmaxf drops NaNs, so m is the
       // largest finite norm; rows that are NaN produce NaN projections, which never tie.
       screen = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))) * args.norm_max[cb];
+      if (SPLIT && !(screen > 0.f)) screen = -1.f;  // all-zero tile: nothing to re-evaluate (NOT(|y| > -1) is false)
     }
 
 #pragma unroll
@@ -526,16 +664,23 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
         const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
         const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
         deposit_positive(kw[jt % WPL], y, l0, l1);   // bit = (y > 0): 0, -0 and NaN give 0 (lsh.py:204)
-        if (want_ties) any |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
+        if (want_ties)
+          any |= SPLIT ? __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(y) > screen))
+                       : __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
       }
       if (any != 0) {  // wave-uniform, rare (a few % of column tiles): the exact per-element test
         const float pn = args.norms[(cb * NT + jt) * 32 + i];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float thr = rn[r >> 2][r & 3] * pn;
+          float thr = rn[r >> 2][r & 3] * pn;
           // strict '<': thr == 0 (zero x, zero-padded column) never ties
           const int rho = (r & 3) + 8 * (r >> 2);
-          deposit_abs_below(tw[jt % WPL], acc[mt][jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
+          if (SPLIT) {
+            thr = thr > 0.f ? thr : -1.f;  // zero row / zero-padded column: y is exactly 0 in both passes
+            deposit_not_above(tw[jt % WPL], acc[mt][jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
+          } else {
+            deposit_abs_below(tw[jt % WPL], acc[mt][jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
+          }
         }
       }
     }
@@ -574,6 +719,102 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
             }
           }
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 2 of the split-precision pass: one thread per flagged (row, padded column).  Re-evaluates the
+// projection as the canonical f32 fmaf chain (the order of the f32 MFMA kernel and of oracle/chain_model.c:
+// per 32-deep k-tile, step s multiplies k = 32t+s then k = 32t+16+s), corrects the key bit if stage 1 had it
+// wrong, and reports the projection as a tie when |y| < tau * ||x|| * ||p||.
+// ------------------------------------------------------------------------------------------
+struct FixArgs {
+  const float* X;
+  int64_t ldx;
+  int dim;
+  int ktiles;
+  int nt;                 // column tiles per column block of the f32 image
+  const float* image;     // f32 fragment image (wide geometry)
+  const float* norms;
+  uint8_t* keys;
+  int row_bytes;
+  int padcols;            // valid padded columns = row_bytes * 8
+  const int64_t* flag_list;
+  const int* flag_count;
+  int flag_cap;
+  int64_t row_base;
+  int64_t* tie_list;
+  int tie_cap;
+  int* tie_count;
+  float tau;
+};
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void sig_fix_kernel(const FixArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t e = t >> 5;
+  const int bit = (int)(t & 31);
+  const int cnt = min(*a.flag_count, a.flag_cap);
+  if (e >= cnt) return;
+  const int64_t head = a.flag_list[2 * e];
+  const uint32_t mask = (uint32_t)a.flag_list[2 * e + 1];
+  if (!((mask >> bit) & 1u)) return;
+  const int64_t row = head >> 16;                 // relative to this launch's X / keys
+  const int word = (int)(head & 0xFFFF);
+  const int col = word * 32 + bit;
+  if (col >= a.padcols) return;
+  const float* __restrict__ x = a.X + row * a.ldx;
+  const int cb = word / a.nt, jt = word % a.nt;
+  const float* __restrict__ img = a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats;  // + kt * nt*4*256
+  const size_t kt_stride = (size_t)a.nt * 4 * kFragFloats;
+  float acc = 0.f, ss = 0.f;
+  for (int kt = 0; kt < a.ktiles; ++kt) {
+    const float* tile = img + kt * kt_stride;
+    f32x4 p4[2][4], x4[2][4];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        p4[hh][q] = *reinterpret_cast<const f32x4*>(tile + ((q * 64) + hh * 32 + bit) * 4);
+        const int k = kt * kKTile + 16 * hh + 4 * q;
+        if (ALIGNED) {
+          x4[hh][q] = k < a.dim ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (k + r < a.dim) ? x[k + r] : 0.f;
+          x4[hh][q] = v;
+        }
+      }
+#pragma unroll
+    for (int sstep = 0; sstep < 16; ++sstep) {
+      const int q = sstep >> 2, r = sstep & 3;
+      acc = __builtin_fmaf(x4[0][q][r], p4[0][q][r], acc);
+      acc = __builtin_fmaf(x4[1][q][r], p4[1][q][r], acc);
+      ss = __builtin_fmaf(x4[0][q][r], x4[0][q][r], ss);
+      ss = __builtin_fmaf(x4[1][q][r], x4[1][q][r], ss);
+    }
+  }
+  // key bit
+  uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
+  unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
+  const unsigned int bitmask = 1u << (8 * (unsigned)(addr & 3) + (col & 7));
+  const bool want = acc > 0.f;
+  const bool have = (*kb >> (col & 7)) & 1;
+  if (want != have) {
+    if (want) atomicOr(w32, bitmask);
+    else atomicAnd(w32, ~bitmask);
+  }
+  if (a.tie_list != nullptr) {
+    const float thr = a.tau * sqrtf(ss) * a.norms[col];
+    if (__builtin_fabsf(acc) < thr) {
+      const int slot = atomicAdd(a.tie_count, 1);
+      if (slot < a.tie_cap) {
+        a.tie_list[2 * (int64_t)slot] = (row + a.row_base) * 65536 + word;
+        a.tie_list[2 * (int64_t)slot + 1] = (int64_t)(1u << bit);
       }
     }
   }
@@ -998,6 +1239,12 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((f.cb + 63) / 64)), dim3(64), 0, s, norms, 32, f.cb,
                        fimage + sig_image_floats(f));
   }
+  if (sig_has_split(g)) {
+    float* simage = image + sig_split_offset_floats(g);
+    const int64_t schunks = sig_image_floats(g) / 4;  // 16-byte chunks: same count as the f32 image
+    hipLaunchKernelGGL(pack_image_bf16_kernel, dim3((unsigned)((schunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                       rows_per_band, dim, g.bb, g.nt, g.ktiles, schunks, reinterpret_cast<u16x8*>(simage));
+  }
   return -(int)hipGetLastError();
 }
 
@@ -1056,6 +1303,81 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
   }
   if (tail > 0) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || sig_prefer_fine(g, tail)));
   return 0;
+}
+
+int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                                   int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list,
+                                   int32_t tie_cap, int32_t* tie_count, float tau, uint8_t* row_flags,
+                                   int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1, void* stream) {
+  if (n == 0) return 0;
+  if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
+      flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
+    return LSHRS_E_BADARG;
+  if (tie_list != nullptr && (tie_count == nullptr || tie_cap < 0)) return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  const int row_bytes = num_bands * g.bb;
+  // the second stage patches key bits with 32-bit atomics: rows must be whole words
+  if (!sig_has_split(g) || row_bytes % 4 != 0 || (reinterpret_cast<uintptr_t>(keys) & 3)) return LSHRS_E_TOOLARGE;
+  if (n >= ((int64_t)1 << 47) || (n + 255) / 256 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* base = static_cast<const float*>(workspace);
+  const bool aligned = (dim % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  // stage 1: bf16 x 3 projections -> keys + list of (row, word, mask) inside the stage-1 window
+  SigArgs a{};
+  a.X = X;
+  a.n = n;
+  a.ldx = ldx;
+  a.dim = dim;
+  a.ktiles = g.ktiles;
+  a.image = base + sig_split_offset_floats(g);
+  a.norms = base + sig_image_floats(g);
+  a.norm_max = a.norms + sig_norm_floats(g);
+  a.keys = keys;
+  a.row_bytes = row_bytes;
+  a.vec_store = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(keys) % 16) == 0);
+  a.row_base = 0;
+  a.tie_list = flag_list;
+  a.tie_cap = flag_cap;
+  a.tie_count = flag_count;
+  a.tau = tau1;
+  a.row_flags = row_flags;
+  {
+    constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles
+    const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
+    if (aligned)
+      hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
+    else
+      hipLaunchKernelGGL((sig_kernel<8, false, 1, 4, 3, 2>), grid, block, 0, s, a);
+  }
+  // stage 2: exact f32 chain for the flagged projections
+  FixArgs f{};
+  f.X = X;
+  f.ldx = ldx;
+  f.dim = dim;
+  f.ktiles = g.ktiles;
+  f.nt = g.nt;
+  f.image = base;
+  f.norms = a.norms;
+  f.keys = keys;
+  f.row_bytes = row_bytes;
+  f.padcols = row_bytes * 8;
+  f.flag_list = flag_list;
+  f.flag_count = flag_count;
+  f.flag_cap = flag_cap;
+  f.row_base = 0;
+  f.tie_list = tie_list;
+  f.tie_cap = tie_cap;
+  f.tie_count = tie_count;
+  f.tau = tau;
+  {
+    const int64_t threads = (int64_t)flag_cap * 32;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (aligned)
+      hipLaunchKernelGGL(sig_fix_kernel<true>, grid, block, 0, s, f);
+    else
+      hipLaunchKernelGGL(sig_fix_kernel<false>, grid, block, 0, s, f);
+  }
+  return -(int)hipGetLastError();
 }
 
 int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,

@@ -86,10 +86,13 @@ class LSHHasher:
                   projection differ by at most 1.2 of those units (rms 0.3) and every sign disagreement
                   had |y| <= 0.41; tests/test_gpu_signature.py re-checks the margin on the box it runs on.
                   Raise it (e.g. 2*dim for the deterministic worst-case bound) for adversarial inputs.
+      precision   "f32" (default) or "bf16x3" (split-precision first pass for batches >= 65 536 rows; same keys)
+      tau1_ulps   stage-1 window of the bf16x3 pass, same unit; must stay >= 192 + the f32 rounding allowance
     """
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
-                 tie_break: str = "host", tau_ulps: float = 8.0) -> None:
+                 tie_break: str = "host", tau_ulps: float = 8.0, precision: str = "f32",
+                 tau1_ulps: float = 256.0) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -99,11 +102,18 @@ class LSHHasher:
             raise ValueError("dim must be > 0")
         if tie_break not in ("host", "none"):
             raise ValueError("tie_break must be 'host' or 'none'")
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' or 'bf16x3'")
         self.num_bands = int(num_bands)
         self.rows_per_band = int(rows_per_band)
         self.dim = int(dim)
         self.tie_break = tie_break
         self.tau_ulps = float(tau_ulps)
+        # "bf16x3": large batches take the split-precision first pass (bf16 matrix cores, ~3x the rate) followed by
+        # the exact f32 chain for every projection inside the stage-1 window; same keys as "f32" 
+        self.precision = precision
+        self.tau1_ulps = float(tau1_ulps)
+        self.split_min_rows = 65_536
         self._device = device
         self._lock = threading.Lock()
         self._projection_version = 0
@@ -116,6 +126,7 @@ class LSHHasher:
         self.pipeline_chunk_rows = 131_072
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
+        self._flag_cap_hint = 0
         # hyperplanes: one generator, num_bands float64 draws cast to float32 (lsh.py:93-94)
         gen = np.random.default_rng(seed)
         planes = [gen.standard_normal((self.rows_per_band, self.dim)).astype(np.float32)
@@ -226,20 +237,25 @@ class LSHHasher:
             stream = torch.cuda.current_stream(dev).cuda_stream
             flags_ptr = row_flags.data_ptr() if row_flags is not None else None
             if mode == "none":
-                self._launch_sig(torch, lib, dev, x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
-                                 self.rows_per_band, self.dim, out.data_ptr(), None, 0, None, 0.0, flags_ptr, stream)
-                return out
+                while True:
+                    flag = self._launch_sig(torch, lib, dev, x.data_ptr(), n, x.stride(0), ws.data_ptr(),
+                                            self.num_bands, self.rows_per_band, self.dim, out.data_ptr(), None, 0,
+                                            None, 0.0, flags_ptr, stream)
+                    if not self._flag_overflow(flag):
+                        return out
+                    stats["relaunches"] += 1
             cap = min(max(4096, n // 16 + 4096), 2 ** 30)
             while True:
                 tie_list = torch.empty((cap, 2), dtype=torch.int64, device=dev)
                 tie_count = torch.zeros(1, dtype=torch.int32, device=dev)
-                self._launch_sig(torch, lib, dev, x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
-                                 self.rows_per_band, self.dim, out.data_ptr(), tie_list.data_ptr(), cap,
-                                 tie_count.data_ptr(), tau, flags_ptr, stream)
+                flag = self._launch_sig(torch, lib, dev, x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                        self.rows_per_band, self.dim, out.data_ptr(), tie_list.data_ptr(), cap,
+                                        tie_count.data_ptr(), tau, flags_ptr, stream)
                 cnt = int(tie_count.item())  # synchronises the stream
-                if cnt <= cap:
+                overflow = self._flag_overflow(flag)
+                if cnt <= cap and not overflow:
                     break
-                cap = cnt  # the kernel counted every entry it wanted to write: relaunch with room
+                cap = max(cap, cnt)  # the kernels counted every entry they wanted to write: relaunch with room
                 stats["relaunches"] += 1
             stats["tie_entries"] = cnt
             if cnt:
@@ -293,7 +309,7 @@ class LSHHasher:
             # chunk), so the bulk copies / patches must not queue behind them
             cstream = self._side_stream(dev, 0)
             side = self._side_stream(dev, 1)
-            pin_cnt, pin_entries, pin_rows = self._pinned(dev, cap, window)
+            pin_cnt, pin_entries, pin_rows, pin_fcnt = self._pinned(dev, cap, window)
             for w0 in range(0, len(spans), window):
                 group = spans[w0:w0 + window]
                 lists = torch.empty((len(group), cap, 2), dtype=torch.int64, device=dev)
@@ -301,13 +317,17 @@ class LSHHasher:
                 stage = torch.empty((len(group), cap, self.dim), dtype=torch.float32, device=dev)
                 keep += [lists, counts, stage]
                 ready = []
+                split_flags = []
                 for ci, (lo, hi) in enumerate(group):
                     xs, os_ = x[lo:hi], out[lo:hi]
                     flags_ptr = row_flags[lo:hi].data_ptr() if row_flags is not None else None
-                    self._launch_sig(torch, lib, dev, xs.data_ptr(), hi - lo, x.stride(0), ws.data_ptr(),
-                                     self.num_bands, self.rows_per_band, self.dim, os_.data_ptr(),
-                                     lists[ci].data_ptr(), cap, counts[ci:ci + 1].data_ptr(), tau, flags_ptr,
-                                     main.cuda_stream)
+                    flag = self._launch_sig(torch, lib, dev, xs.data_ptr(), hi - lo, x.stride(0), ws.data_ptr(),
+                                            self.num_bands, self.rows_per_band, self.dim, os_.data_ptr(),
+                                            lists[ci].data_ptr(), cap, counts[ci:ci + 1].data_ptr(), tau, flags_ptr,
+                                            main.cuda_stream)
+                    split_flags.append(flag)
+                    if flag is not None:
+                        keep.append(flag)
                     _native.check(
                         lib.lshrs_gather_tied_rows_f32(xs.data_ptr(), x.stride(0), self.dim, lists[ci].data_ptr(),
                                                        counts[ci:ci + 1].data_ptr(), cap, stage[ci].data_ptr(),
@@ -317,6 +337,8 @@ class LSHHasher:
                     cstream.wait_event(done)
                     with torch.cuda.stream(cstream):
                         pin_cnt[ci:ci + 1].copy_(counts[ci:ci + 1], non_blocking=True)
+                        if flag is not None:
+                            pin_fcnt[ci:ci + 1].copy_(flag[0], non_blocking=True)
                         copied = torch.cuda.Event()
                         copied.record(cstream)
                     ready.append((copied, done))
@@ -325,6 +347,9 @@ class LSHHasher:
                     """Wait for chunk ci's count, start the D2H of its entries + vectors into slot ci & 1."""
                     ready[ci][0].synchronize()
                     cnt = int(pin_cnt[ci])
+                    if split_flags[ci] is not None and int(pin_fcnt[ci]) > split_flags[ci][1]:
+                        self._flag_cap_hint = int(int(pin_fcnt[ci]) * 1.25) + 4096
+                        cnt = cap + 1          # stage-1 list overflowed: the chunk is redone on the plain path
                     landed = None
                     if 0 < cnt <= cap:
                         side.wait_event(ready[ci][1])
@@ -427,21 +452,57 @@ class LSHHasher:
         if buf is None:
             buf = (torch.empty((window,), dtype=torch.int32).pin_memory(),
                    torch.empty((2, cap, 2), dtype=torch.int64).pin_memory(),
-                   torch.empty((2, cap, self.dim), dtype=torch.float32).pin_memory())
+                   torch.empty((2, cap, self.dim), dtype=torch.float32).pin_memory(),
+                   torch.empty((window,), dtype=torch.int32).pin_memory())
             self._pinned_cache = {key: buf}
         return buf
 
-    def _launch_sig(self, torch, lib, dev, *args) -> None:
+    def _split_applies(self, n: int) -> bool:
+        if self.precision != "bf16x3" or n < self.split_min_rows:
+            return False
+        lib = _native.load()
+        return (int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) >= 256
+                and (self.num_bands * self.band_bytes) % 4 == 0)
+
+    def _launch_sig(self, torch, lib, dev, *args):
+        """Enqueue one signature pass (args = the arguments of ``lshrs_sig_hash_batch_f32``).  Returns ``None``, or
+        for the split-precision pass ``(flag_count tensor, flag_cap)`` — the caller must compare them once the
+        stream has been synchronised and repeat the launch with a larger ``flag_cap`` on overflow."""
+        n = int(args[1])
+        split = self._split_applies(n)
+        flag = None
+        if split:
+            cap = max(int(self._flag_cap_hint), n // 4 + 4096)
+            flag_list = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+            flag_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            flag = (flag_count, cap, flag_list)
+            call = lambda: lib.lshrs_sig_hash_batch_split_f32(  # noqa: E731
+                *args[:-1], flag_list.data_ptr(), cap, flag_count.data_ptr(), float(self.tau1_ulps * _U), args[-1])
+            name = "lshrs_sig_hash_batch_split_f32"
+        else:
+            call = lambda: lib.lshrs_sig_hash_batch_f32(*args)  # noqa: E731
+            name = "lshrs_sig_hash_batch_f32"
         events = self.kernel_events
         if events is None:
-            _native.check(lib.lshrs_sig_hash_batch_f32(*args), "lshrs_sig_hash_batch_f32")
-            return
+            _native.check(call(), name)
+            return flag
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cur = torch.cuda.current_stream(dev)
         start.record(cur)
-        _native.check(lib.lshrs_sig_hash_batch_f32(*args), "lshrs_sig_hash_batch_f32")
+        _native.check(call(), name)
         end.record(cur)
-        events.append((start, end, int(args[1])))  # args[1] = rows in this launch
+        events.append((start, end, n))
+        return flag
+
+    def _flag_overflow(self, flag) -> bool:
+        """After a synchronisation: did the split pass need more room than it had?  (Remembers the need.)"""
+        if flag is None:
+            return False
+        wanted = int(flag[0].item())
+        if wanted > flag[1]:
+            self._flag_cap_hint = int(wanted * 1.25) + 4096
+            return True
+        return False
 
     def _tie_pairs(self, entries: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """Kernel tie entries ``(row*65536 + word, 32-bit column mask)`` -> unique (row, band) pairs,

@@ -307,3 +307,38 @@ def test_launch_plan_main_rounds_plus_fine_tail(torch_mod):
     sl = slice(64_000, 68_000)
     assert np.array_equal(outs[1][0][sl], chain_hash_packed(h.projections, x[sl]))
     assert np.array_equal(outs[1][1][sl], hash_batch_literal_packed(h.projections, x[sl]))
+
+
+def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
+    """precision="bf16x3": bf16 matrix-core first pass + exact f32 chain for every projection inside the stage-1
+    window.  Raw keys must equal the f32 kernel's (== the CPU chain model), final keys the reference's."""
+    torch = torch_mod
+    from oracle.build import chain_hash_packed
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 70_000), (3, 32, 8, 100, 70_001)):
+        h32 = _hasher(seed, nb, r, dim)
+        hs = _hasher(seed, nb, r, dim, precision="bf16x3")
+        gen = torch.Generator("cuda").manual_seed(seed + 5)
+        x = torch.randn(n, dim, device="cuda", generator=gen)
+        x[7] = 0.0                                            # zero row: nothing to flag, flag bit set
+        x[9, 3] = float("nan")
+        flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        raw_split = hs.hash_device(x, tie_break="none", row_flags=flags)
+        raw_f32 = h32.hash_device(x, tie_break="none")
+        assert hs._split_applies(n)
+        assert torch.equal(raw_split, raw_f32), f"{int((raw_split != raw_f32).sum())} key bytes differ"
+        assert flags[7].item() == 1 and flags[9].item() == 2 and int(flags.sum()) == 3
+        sl = slice(n - 3000, n)                               # includes a partial 256-row workgroup
+        xs = x[sl].cpu().numpy()
+        assert np.array_equal(raw_split[sl].cpu().numpy(), chain_hash_packed(hs.projections, xs))
+        final = hs.hash_device(x)
+        assert hs.last_stats["tie_pairs"] > 0
+        assert torch.equal(final, h32.hash_device(x))
+        assert np.array_equal(final[sl].cpu().numpy(), hash_batch_literal_packed(hs.projections, xs))
+    # a stage-1 list that is too small is detected and the pass repeated with room
+    hs = _hasher(42, 16, 16, 768, precision="bf16x3", tau1_ulps=1e6)
+    x = torch.randn(70_000, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    got = hs.hash_device(x, tie_break="none")
+    assert hs.last_stats["relaunches"] > 0
+    assert torch.equal(got, _hasher(42, 16, 16, 768).hash_device(x, tie_break="none"))
