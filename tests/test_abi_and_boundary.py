@@ -62,13 +62,17 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_padded_columns(3, 5) == 32
     assert lib.lshrs_sig_padded_columns(0, 5) < 0
     # main image (padded columns x dim rounded up to 32) + one norm per padded column + one max-norm per column
-    # block (x4); shapes wider than one 32-column tile also carry the fine (one tile per workgroup) image
-    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (2 * 256 * 768 + 256 + 4 + 8) * 4
-    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (2 * 512 * 1536 + 512 + 4 + 16) * 4
+    # block (x4); shapes wider than one 32-column tile also carry the fine (one tile per workgroup) image, and
+    # shapes of >= 256 padded columns the bf16 hi/mid image of the split-precision pass (same size again)
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (3 * 256 * 768 + 256 + 4 + 8) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (3 * 512 * 1536 + 512 + 4 + 16) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (2 * 128 * 128 + 128 + 4 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device
     assert lib.lshrs_sig_hash_batch_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None) == -10001
+    assert lib.lshrs_sig_hash_batch_split_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None, 0, None,
+                                              0.0, None) == -10001
     assert lib.lshrs_topk_desc_f32(None, 1, 5, 3, None, None, None, None) == -10001
     assert lib.lshrs_topk_workspace_bytes(10, 1000) == 0
     assert lib.lshrs_topk_workspace_bytes(3, 40_000) == 3 * 65536 * 8
