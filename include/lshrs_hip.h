@@ -83,8 +83,8 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
  * NOT(|y1| > tau1 * ||x|| * ||p||) in flag_list; stage 2 re-evaluates exactly those as the f32 fmaf chain of the
  * f32 kernel, corrects their key bits and reports ties (|y| < tau ...) as above.  With tau1 >= 2^-16 (256 units)
  * the keys are those of lshrs_sig_hash_batch_f32.
- *   flag_list int64[2*flag_cap], flag_count int32[1] (zeroed by the caller): scratch with the tie-list format;
- *   if *flag_count > flag_cap afterwards the pass is incomplete and must be repeated with a larger list.
+ *   flag_list int64[flag_cap], flag_count int32[1] (zeroed by the caller): scratch, one entry per flagged
+ *   projection; if *flag_count > flag_cap afterwards the pass is incomplete and must be repeated with a larger list.
  * Only for shapes with >= 256 padded columns whose key rows are whole 32-bit words (else LSHRS_E_TOOLARGE:
  * use lshrs_sig_hash_batch_f32). */
 int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,

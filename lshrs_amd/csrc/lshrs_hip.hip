@@ -389,7 +389,8 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   constexpr bool PROJECT = MODE == 2;
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kHalfFloats = NT * 2 * kFragFloats;
-  constexpr int kStageFloats = PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats;  // ring of 3 halves, or 2 whole tiles
+  // LDS staging: PIPE 0 two whole tiles, PIPE 1 ring of three halves, PIPE 3 ring of three whole tiles
+  constexpr int kStageFloats = PIPE == 3 ? 3 * kTileFloats : (PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats);
   constexpr int kWaveRows = kRowsPerWave * M;
   constexpr int kBlockRows = W * kWaveRows;
   static_assert(M == 1 || PIPE == 1 || PIPE == 3, "two row tiles per wave are only built for the ring loops");
@@ -432,65 +433,78 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   }
 
   if (PIPE == 3) {
-    // halves of 16 k = one bf16 MFMA k-step; ring and staging exactly as PIPE = 1 (block (jt, 2*half + part))
-    const int halves = 2 * ktiles;
-    f32x4 a_cur[2][M], a_nxt[2][M];  // raw f32 x: 8 consecutive k per lane and row tile
+    // One stage = one 32-deep k-tile = two bf16 MFMA k-steps (halves of 16 k); ring of three 32 KiB LDS slots staged
+    // two tiles ahead, so the LDS-DMA latency hides under a whole tile (96 MFMAs per wave) — with one wave per
+    // SIMD there is no partner wave to hide it.  Slot layout: [half][(jt, part) block], blocks as in the image.
+    f32x4 a_cur[4][M], a_nxt[4][M];  // raw f32 x: [2*half + piece][row tile], 8 consecutive k per half
     stage_p_half<NT, W>(img, 0, lds, tid);
     stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
-#pragma unroll
-    for (int mt = 0; mt < M; ++mt) {
-      f32x4 t[2];
-      load_x_half<ALIGNED>(xrow[mt], 8 * h, dim, t);
-      a_cur[0][mt] = t[0];
-      a_cur[1][mt] = t[1];
+    if (ktiles > 1) {
+      stage_p_half<NT, W>(img + kTileFloats, 0, lds + kTileFloats, tid);
+      stage_p_half<NT, W>(img + kTileFloats, 1, lds + kTileFloats + kHalfFloats, tid);
     }
+#pragma unroll
+    for (int mt = 0; mt < M; ++mt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        f32x4 t[2];
+        load_x_half<ALIGNED>(xrow[mt], 16 * hf + 8 * h, dim, t);
+        a_cur[2 * hf][mt] = t[0];
+        a_cur[2 * hf + 1][mt] = t[1];
+      }
     __syncthreads();
-    for (int hh = 0; hh < halves; ++hh) {
-      const float* cur = lds + (hh % 3) * kHalfFloats;
-      if (hh + 2 < halves)
-        stage_p_half<NT, W>(img + (size_t)((hh + 2) >> 1) * kTileFloats, (hh + 2) & 1, lds + ((hh + 2) % 3) * kHalfFloats,
-                            tid);
-      if (hh + 1 < halves) {
-#pragma unroll
-        for (int mt = 0; mt < M; ++mt) {
-          f32x4 t[2];
-          load_x_half<ALIGNED>(xrow[mt], ((hh + 1) >> 1) * kKTile + 16 * ((hh + 1) & 1) + 8 * h, dim, t);
-          a_nxt[0][mt] = t[0];
-          a_nxt[1][mt] = t[1];
-        }
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const float* cur = lds + (kt % 3) * kTileFloats;
+      if (kt + 2 < ktiles) {
+        float* dst = lds + ((kt + 2) % 3) * kTileFloats;
+        stage_p_half<NT, W>(img + (size_t)(kt + 2) * kTileFloats, 0, dst, tid);
+        stage_p_half<NT, W>(img + (size_t)(kt + 2) * kTileFloats, 1, dst + kHalfFloats, tid);
       }
-      f32x4 bh[NT], bm[NT];
-      read_frags<NT>(cur, 0, lane, bh);
-      read_frags<NT>(cur, 1, lane, bm);
-      bf16x8 ah[M], am[M];
+      if (kt + 1 < ktiles) {
 #pragma unroll
-      for (int mt = 0; mt < M; ++mt) {
-        split_bf16(a_cur[0][mt], a_cur[1][mt], ah[mt], am[mt]);
+        for (int mt = 0; mt < M; ++mt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v0 = a_cur[0][mt][e], v1 = a_cur[1][mt][e];
-          ss[mt] = __builtin_fmaf(v0, v0, ss[mt]);
-          ss[mt] = __builtin_fmaf(v1, v1, ss[mt]);
-          amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
-        }
+          for (int hf = 0; hf < 2; ++hf) {
+            f32x4 t[2];
+            load_x_half<ALIGNED>(xrow[mt], (kt + 1) * kKTile + 16 * hf + 8 * h, dim, t);
+            a_nxt[2 * hf][mt] = t[0];
+            a_nxt[2 * hf + 1][mt] = t[1];
+          }
       }
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        const bf16x8 bhj = __builtin_bit_cast(bf16x8, bh[jt]);
-        const bf16x8 bmj = __builtin_bit_cast(bf16x8, bm[jt]);
+      for (int hf = 0; hf < 2; ++hf) {
+        f32x4 bh[NT], bm[NT];
+        read_frags<NT>(cur + hf * kHalfFloats, 0, lane, bh);
+        read_frags<NT>(cur + hf * kHalfFloats, 1, lane, bm);
+        bf16x8 ah[M], am[M];
 #pragma unroll
         for (int mt = 0; mt < M; ++mt) {
-          acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bhj, acc[mt][jt], 0, 0, 0);
-          acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bmj, acc[mt][jt], 0, 0, 0);
-          acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mt], bhj, acc[mt][jt], 0, 0, 0);
+          split_bf16(a_cur[2 * hf][mt], a_cur[2 * hf + 1][mt], ah[mt], am[mt]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v0 = a_cur[2 * hf][mt][e], v1 = a_cur[2 * hf + 1][mt][e];
+            ss[mt] = __builtin_fmaf(v0, v0, ss[mt]);
+            ss[mt] = __builtin_fmaf(v1, v1, ss[mt]);
+            amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+          }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          const bf16x8 bhj = __builtin_bit_cast(bf16x8, bh[jt]);
+          const bf16x8 bmj = __builtin_bit_cast(bf16x8, bm[jt]);
+#pragma unroll
+          for (int mt = 0; mt < M; ++mt) {
+            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bhj, acc[mt][jt], 0, 0, 0);
+            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bmj, acc[mt][jt], 0, 0, 0);
+            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mt], bhj, acc[mt][jt], 0, 0, 0);
+          }
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int mt = 0; mt < M; ++mt) {
-        a_cur[0][mt] = a_nxt[0][mt];
-        a_cur[1][mt] = a_nxt[1][mt];
-      }
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M; ++mt) a_cur[q][mt] = a_nxt[q][mt];
     }
   } else if (PIPE == 1) {
     const int halves = 2 * ktiles;
@@ -711,7 +725,17 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
       if (want_ties) {
 #pragma unroll
         for (int w = 0; w < WPL; ++w) {
-          if (tw[w] != 0u) {
+          if (SPLIT) {
+            // stage 1: one list entry per flagged projection, (row << 21) | padded column, so that stage 2 can
+            // give every one of them a full thread
+            uint32_t m = tw[w];
+            while (m != 0u) {
+              const int bit = __builtin_ctz(m);
+              m &= m - 1u;
+              const int slot = atomicAdd(args.tie_count, 1);
+              if (slot < args.tie_cap) args.tie_list[slot] = (grow << 21) | (int64_t)((word0 + w) * 32 + bit);
+            }
+          } else if (tw[w] != 0u) {
             const int slot = atomicAdd(args.tie_count, 1);
             if (slot < args.tie_cap) {
               args.tie_list[2 * (int64_t)slot] = (grow + args.row_base) * 65536 + (word0 + w);
@@ -752,50 +776,62 @@ struct FixArgs {
 };
 
 template <bool ALIGNED>
+__device__ __forceinline__ void fix_load_tile(const float* __restrict__ tile, const float* __restrict__ x, int kt, int c,
+                                              int dim, f32x4 (&p4)[2][4], f32x4 (&x4)[2][4]) {
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      p4[hh][q] = *reinterpret_cast<const f32x4*>(tile + ((q * 64) + hh * 32 + c) * 4);
+      const int k = kt * kKTile + 16 * hh + 4 * q;
+      if (ALIGNED) {
+        x4[hh][q] = k < dim ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (k + r < dim) ? x[k + r] : 0.f;
+        x4[hh][q] = v;
+      }
+    }
+}
+
+__device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f32x4 (&x4)[2][4], float& acc, float& ss) {
+#pragma unroll
+  for (int sstep = 0; sstep < 16; ++sstep) {
+    const int q = sstep >> 2, r = sstep & 3;
+    acc = __builtin_fmaf(x4[0][q][r], p4[0][q][r], acc);
+    acc = __builtin_fmaf(x4[1][q][r], p4[1][q][r], acc);
+    ss = __builtin_fmaf(x4[0][q][r], x4[0][q][r], ss);
+    ss = __builtin_fmaf(x4[1][q][r], x4[1][q][r], ss);
+  }
+}
+
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void sig_fix_kernel(const FixArgs a) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t e = t >> 5;
-  const int bit = (int)(t & 31);
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cnt = min(*a.flag_count, a.flag_cap);
   if (e >= cnt) return;
-  const int64_t head = a.flag_list[2 * e];
-  const uint32_t mask = (uint32_t)a.flag_list[2 * e + 1];
-  if (!((mask >> bit) & 1u)) return;
-  const int64_t row = head >> 16;                 // relative to this launch's X / keys
-  const int word = (int)(head & 0xFFFF);
-  const int col = word * 32 + bit;
+  const int64_t item = a.flag_list[e];
+  const int64_t row = item >> 21;                 // relative to this launch's X / keys
+  const int col = (int)(item & ((1 << 21) - 1));
   if (col >= a.padcols) return;
+  const int word = col >> 5, c = col & 31;
   const float* __restrict__ x = a.X + row * a.ldx;
   const int cb = word / a.nt, jt = word % a.nt;
-  const float* __restrict__ img = a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats;  // + kt * nt*4*256
+  const float* __restrict__ img = a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats;
   const size_t kt_stride = (size_t)a.nt * 4 * kFragFloats;
   float acc = 0.f, ss = 0.f;
-  for (int kt = 0; kt < a.ktiles; ++kt) {
-    const float* tile = img + kt * kt_stride;
-    f32x4 p4[2][4], x4[2][4];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        p4[hh][q] = *reinterpret_cast<const f32x4*>(tile + ((q * 64) + hh * 32 + bit) * 4);
-        const int k = kt * kKTile + 16 * hh + 4 * q;
-        if (ALIGNED) {
-          x4[hh][q] = k < a.dim ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-          f32x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (k + r < a.dim) ? x[k + r] : 0.f;
-          x4[hh][q] = v;
-        }
-      }
-#pragma unroll
-    for (int sstep = 0; sstep < 16; ++sstep) {
-      const int q = sstep >> 2, r = sstep & 3;
-      acc = __builtin_fmaf(x4[0][q][r], p4[0][q][r], acc);
-      acc = __builtin_fmaf(x4[1][q][r], p4[1][q][r], acc);
-      ss = __builtin_fmaf(x4[0][q][r], x4[0][q][r], ss);
-      ss = __builtin_fmaf(x4[1][q][r], x4[1][q][r], ss);
-    }
+  f32x4 pa[2][4], xa[2][4], pb[2][4], xb[2][4];
+  int kt = 0;
+  for (; kt + 1 < a.ktiles; kt += 2) {            // two k-tiles of loads in flight per thread
+    fix_load_tile<ALIGNED>(img + kt * kt_stride, x, kt, c, a.dim, pa, xa);
+    fix_load_tile<ALIGNED>(img + (kt + 1) * kt_stride, x, kt + 1, c, a.dim, pb, xb);
+    fix_chain_tile(pa, xa, acc, ss);
+    fix_chain_tile(pb, xb, acc, ss);
+  }
+  if (kt < a.ktiles) {
+    fix_load_tile<ALIGNED>(img + kt * kt_stride, x, kt, c, a.dim, pa, xa);
+    fix_chain_tile(pa, xa, acc, ss);
   }
   // key bit
   uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
@@ -814,7 +850,7 @@ __global__ __launch_bounds__(256) void sig_fix_kernel(const FixArgs a) {
       const int slot = atomicAdd(a.tie_count, 1);
       if (slot < a.tie_cap) {
         a.tie_list[2 * (int64_t)slot] = (row + a.row_base) * 65536 + word;
-        a.tie_list[2 * (int64_t)slot + 1] = (int64_t)(1u << bit);
+        a.tie_list[2 * (int64_t)slot + 1] = (int64_t)(1u << c);
       }
     }
   }
@@ -1370,8 +1406,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   f.tie_count = tie_count;
   f.tau = tau;
   {
-    const int64_t threads = (int64_t)flag_cap * 32;
-    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    const dim3 grid((unsigned)(((int64_t)flag_cap + 255) / 256)), block(256);
     if (aligned)
       hipLaunchKernelGGL(sig_fix_kernel<true>, grid, block, 0, s, f);
     else

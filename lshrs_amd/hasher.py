@@ -473,7 +473,7 @@ class LSHHasher:
         flag = None
         if split:
             cap = max(int(self._flag_cap_hint), n // 4 + 4096)
-            flag_list = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+            flag_list = torch.empty((cap,), dtype=torch.int64, device=dev)
             flag_count = torch.zeros(1, dtype=torch.int32, device=dev)
             flag = (flag_count, cap, flag_list)
             call = lambda: lib.lshrs_sig_hash_batch_split_f32(  # noqa: E731
