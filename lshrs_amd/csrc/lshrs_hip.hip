@@ -327,6 +327,12 @@ __device__ __forceinline__ void mfma_group(const f32x4 (&a)[M], const f32x4 (&b)
   }
 }
 
+__device__ __forceinline__ f32x4 asm_load_x4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 // ---- split-precision main loop (PIPE = 3) ---------------------------------------------------------------
 // y1 = sum_k (xh*ph + xh*pm + xm*ph) on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate), x = xh + xm + ex split
 // on the fly, p pre-split in the image.  The dropped terms are bounded by 3 * 2^-18 * sum|x_k p_k| <= 192 units
@@ -433,44 +439,43 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   }
 
   if (PIPE == 3) {
-    // One stage = one 32-deep k-tile = two bf16 MFMA k-steps (halves of 16 k); ring of three 32 KiB LDS slots staged
-    // two tiles ahead, so the LDS-DMA latency hides under a whole tile (96 MFMAs per wave) — with one wave per
-    // SIMD there is no partner wave to hide it.  Slot layout: [half][(jt, part) block], blocks as in the image.
-    f32x4 a_cur[4][M], a_nxt[4][M];  // raw f32 x: [2*half + piece][row tile], 8 consecutive k per half
-    stage_p_half<NT, W>(img, 0, lds, tid);
-    stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
-    if (ktiles > 1) {
-      stage_p_half<NT, W>(img + kTileFloats, 0, lds + kTileFloats, tid);
-      stage_p_half<NT, W>(img + kTileFloats, 1, lds + kTileFloats + kHalfFloats, tid);
-    }
+    // One stage = one 32-deep k-tile = two bf16 MFMA k-steps (halves of 16 k); ring of three 32 KiB LDS slots.
+    // One wave per SIMD means nobody else hides memory latency, so everything is prefetched TWO tiles ahead and
+    // nothing is ever drained: during tile t every thread issues exactly 16 vector-memory operations (8 LDS-DMA
+    // pieces of hyperplane tile t+2, 8 X loads of tile t+2 — unconditional, indices clamped, so the count is exact),
+    // and the barrier that ends tile t waits with vmcnt(16): tile t+1's data, issued during tile t-1, has landed,
+    // tile t+2's stays in flight.  The X loads are inline asm so that hipcc does not turn their first use into a
+    // vmcnt(0); __syncthreads() would drain too, hence the raw s_barrier.  (ALIGNED rows only.)
+    static_assert(!SPLIT || ALIGNED, "the split pass is built for 16-byte aligned rows");
+    f32x4 xa[4][M], xb[4][M], xc[4][M];  // raw f32 x of tiles t, t+1, t+2: [2*half + piece][row tile]
+    const int last = ktiles - 1;
+    auto issue_tile = [&](int t, f32x4 (&dst)[4][M]) {   // 8 LDS-DMA + 4*M X loads for tile min(t, last)
+      const int tt = t < last ? t : last;
+      float* slot = lds + (t % 3) * kTileFloats;
+      stage_p_half<NT, W>(img + (size_t)tt * kTileFloats, 0, slot, tid);
+      stage_p_half<NT, W>(img + (size_t)tt * kTileFloats, 1, slot + kHalfFloats, tid);
 #pragma unroll
-    for (int mt = 0; mt < M; ++mt)
+      for (int mt = 0; mt < M; ++mt)
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        f32x4 t[2];
-        load_x_half<ALIGNED>(xrow[mt], 16 * hf + 8 * h, dim, t);
-        a_cur[2 * hf][mt] = t[0];
-        a_cur[2 * hf + 1][mt] = t[1];
-      }
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-      const float* cur = lds + (kt % 3) * kTileFloats;
-      if (kt + 2 < ktiles) {
-        float* dst = lds + ((kt + 2) % 3) * kTileFloats;
-        stage_p_half<NT, W>(img + (size_t)(kt + 2) * kTileFloats, 0, dst, tid);
-        stage_p_half<NT, W>(img + (size_t)(kt + 2) * kTileFloats, 1, dst + kHalfFloats, tid);
-      }
-      if (kt + 1 < ktiles) {
+        for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int mt = 0; mt < M; ++mt)
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            f32x4 t[2];
-            load_x_half<ALIGNED>(xrow[mt], (kt + 1) * kKTile + 16 * hf + 8 * h, dim, t);
-            a_nxt[2 * hf][mt] = t[0];
-            a_nxt[2 * hf + 1][mt] = t[1];
+          for (int pc = 0; pc < 2; ++pc) {
+            const int k = tt * kKTile + 16 * hf + 8 * h + 4 * pc;
+            dst[2 * hf + pc][mt] = asm_load_x4(xrow[mt] + (k < dim ? k : 0));
           }
-      }
+    };
+    auto mask_tile = [&](int t, f32x4 (&v)[4][M]) {      // zero what lies beyond dim (loaded from a clamped address)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+          if (t * kKTile + 16 * hf + 8 * h + 4 * pc >= dim)
+#pragma unroll
+            for (int mt = 0; mt < M; ++mt) v[2 * hf + pc][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute_tile = [&](int t, f32x4 (&v)[4][M]) {
+      const float* cur = lds + (t % 3) * kTileFloats;
+      mask_tile(t, v);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         f32x4 bh[NT], bm[NT];
@@ -479,10 +484,10 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
         bf16x8 ah[M], am[M];
 #pragma unroll
         for (int mt = 0; mt < M; ++mt) {
-          split_bf16(a_cur[2 * hf][mt], a_cur[2 * hf + 1][mt], ah[mt], am[mt]);
+          split_bf16(v[2 * hf][mt], v[2 * hf + 1][mt], ah[mt], am[mt]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float v0 = a_cur[2 * hf][mt][e], v1 = a_cur[2 * hf + 1][mt][e];
+            const float v0 = v[2 * hf][mt][e], v1 = v[2 * hf + 1][mt][e];
             ss[mt] = __builtin_fmaf(v0, v0, ss[mt]);
             ss[mt] = __builtin_fmaf(v1, v1, ss[mt]);
             amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
@@ -500,12 +505,37 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
           }
         }
       }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int mt = 0; mt < M; ++mt) a_cur[q][mt] = a_nxt[q][mt];
+    };
+    issue_tile(0, xa);
+    issue_tile(1, xb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the ring of x registers is rotated by unrolling three tiles per iteration (no register copies, and every
+    // array index stays a compile-time constant)
+    int kt = 0;
+    for (; kt + 2 < ktiles; kt += 3) {
+      issue_tile(kt + 2, xc);
+      compute_tile(kt, xa);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_tile(kt + 3, xa);
+      compute_tile(kt + 1, xb);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_tile(kt + 4, xb);
+      compute_tile(kt + 2, xc);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
+    // tail: tiles kt (in xa) and kt+1 (in xb) may remain
+    if (kt < ktiles) {
+      compute_tile(kt, xa);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < ktiles) compute_tile(kt + 1, xb);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped prefetches beyond the last tile must land before exit
+    __builtin_amdgcn_s_barrier();
   } else if (PIPE == 1) {
     const int halves = 2 * ktiles;
     f32x4 a_cur[2][M], a_nxt[2][M];  // [qq][row tile]
@@ -1358,6 +1388,9 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
   const bool aligned = (dim % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (!aligned)  // the split pass is built for 16-byte aligned rows; anything else takes the f32 pass (same keys)
+    return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
+                                    tie_count, tau, row_flags, stream);
   // stage 1: bf16 x 3 projections -> keys + list of (row, word, mask) inside the stage-1 window
   SigArgs a{};
   a.X = X;
@@ -1380,10 +1413,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   {
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
-    if (aligned)
-      hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
-    else
-      hipLaunchKernelGGL((sig_kernel<8, false, 1, 4, 3, 2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
   }
   // stage 2: exact f32 chain for the flagged projections
   FixArgs f{};
