@@ -9,6 +9,9 @@
 // ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md.
 
 #include <hip/hip_runtime.h>
+#ifndef LSHRS_SPLIT_PROBE
+#define LSHRS_SPLIT_PROBE 0
+#endif
 #include <stdint.h>
 #include <math.h>
 
@@ -19,6 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -272,7 +276,7 @@ __device__ __forceinline__ void stage_p_half(const float* __restrict__ tile, int
 #pragma unroll
   for (int base = 0; base < kBlocks; base += kThreads / 64) {
     const int blk = base + wave;  // wave-uniform
-    if (blk < kBlocks) {
+    if (kBlocks % (kThreads / 64) == 0 || blk < kBlocks) {
       const int jt = blk >> 1, qq = blk & 1;
       const float* g = tile + (size_t)(((jt * 4 + 2 * part + qq) * 64) + lane) * 4;
       float* l = lds_buf + (size_t)blk * kFragFloats;  // wave-uniform base; hardware adds lane*16
@@ -325,12 +329,6 @@ __device__ __forceinline__ void mfma_group(const f32x4 (&a)[M], const f32x4 (&b)
         acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[mt][jt], 0, 0, 0);
     }
   }
-}
-
-__device__ __forceinline__ f32x4 asm_load_x4(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
 }
 
 // ---- split-precision main loop (PIPE = 3) ---------------------------------------------------------------
@@ -395,8 +393,9 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   constexpr bool PROJECT = MODE == 2;
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kHalfFloats = NT * 2 * kFragFloats;
-  // LDS staging: PIPE 0 two whole tiles, PIPE 1 ring of three halves, PIPE 3 ring of three whole tiles
-  constexpr int kStageFloats = PIPE == 3 ? 3 * kTileFloats : (PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats);
+  // LDS staging: PIPE 0 two whole tiles, PIPE 1 ring of three halves, PIPE 3 ring of four (fragment half + x half) stages
+  constexpr int kStageFloats = PIPE == 3 ? 4 * (kHalfFloats + W * M * 2 * kFragFloats)
+                                         : (PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats);
   constexpr int kWaveRows = kRowsPerWave * M;
   constexpr int kBlockRows = W * kWaveRows;
   static_assert(M == 1 || PIPE == 1 || PIPE == 3, "two row tiles per wave are only built for the ring loops");
@@ -439,102 +438,172 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   }
 
   if (PIPE == 3) {
-    // One stage = one 32-deep k-tile = two bf16 MFMA k-steps (halves of 16 k); ring of three 32 KiB LDS slots.
-    // One wave per SIMD means nobody else hides memory latency, so everything is prefetched TWO tiles ahead and
-    // nothing is ever drained: during tile t every thread issues exactly 16 vector-memory operations (8 LDS-DMA
-    // pieces of hyperplane tile t+2, 8 X loads of tile t+2 — unconditional, indices clamped, so the count is exact),
-    // and the barrier that ends tile t waits with vmcnt(16): tile t+1's data, issued during tile t-1, has landed,
-    // tile t+2's stays in flight.  The X loads are inline asm so that hipcc does not turn their first use into a
-    // vmcnt(0); __syncthreads() would drain too, hence the raw s_barrier.  (ALIGNED rows only.)
-    static_assert(!SPLIT || ALIGNED, "the split pass is built for 16-byte aligned rows");
-    f32x4 xa[4][M], xb[4][M], xc[4][M];  // raw f32 x of tiles t, t+1, t+2: [2*half + piece][row tile]
-    const int last = ktiles - 1;
-    auto issue_tile = [&](int t, f32x4 (&dst)[4][M]) {   // 8 LDS-DMA + 4*M X loads for tile min(t, last)
-      const int tt = t < last ? t : last;
-      float* slot = lds + (t % 3) * kTileFloats;
-      stage_p_half<NT, W>(img + (size_t)tt * kTileFloats, 0, slot, tid);
-      stage_p_half<NT, W>(img + (size_t)tt * kTileFloats, 1, slot + kHalfFloats, tid);
+    // One ring stage = one 16-deep half k-tile = one bf16 MFMA k-step: 16 KiB of hyperplane fragments (staged
+    // cooperatively) + 16 KiB of raw f32 x (each lane lands its OWN 2*M pieces of 16 bytes, and later reads them
+    // back from lane*16: LDS is only the landing zone).  Both travel by LDS-DMA, so no VGPR is ever the target of
+    // a pending load and the only vector-memory counter traffic is the 8 DMAs per thread and stage issued below:
+    // the waits are plain counted s_waitcnt vmcnt(16) and nothing is ever drained.  (X loads into registers need
+    // either compiler-tracked loads, which hipcc waits for with vmcnt(0), or asm outputs, which the register
+    // allocator is free to copy or reuse while the load is still in flight.)
+    // One wave per SIMD means nobody else hides memory latency: ring of FOUR stages, prefetch three ahead.
+    static_assert(!SPLIT || (ALIGNED && NT == 8 && M == 2 && W == 4), "the split pass is built for this geometry");
+    constexpr int kXHalfFloats = W * M * 2 * kFragFloats;
+    constexpr int kStage = kHalfFloats + kXHalfFloats;
+    const int halves = 2 * ktiles;
+    const int lasth = halves - 1;
+    // X addressing: uniform 64-bit base per workgroup + one 32-bit byte offset per lane and row tile.
+    // The host only takes this pass when dim % 32 == 0, so no piece reaches past its row.
+    const int64_t blk_row0 = (int64_t)blockIdx.x * kBlockRows;
+    const char* xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
+    unsigned xoff[M];
+#pragma unroll
+    for (int mt = 0; mt < M; ++mt) {
+      const int64_t r = row0 + mt * kRowsPerWave + i;
+      const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;   // clamp: loads stay in bounds, stores are masked
+      xoff[mt] = (unsigned)((rl * args.ldx + 8 * h) * 4);
+    }
+    // DMA addressing is loop-invariant per lane (32-bit offsets) on top of uniform bases, and the LDS targets are
+    // computed on the scalar unit: the whole issue block is 8 x (s_mov m0 + global_load_lds) and a few s_adds.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned poff[4], xo[M][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int blk = 4 * q + wave_u;             // this wave stages fragment blocks wave, wave+4, wave+8, wave+12
+      poff[q] = (unsigned)((((blk >> 1) * 4 + (blk & 1)) * 64 + lane) * 16);
+    }
+#pragma unroll
+    for (int mt = 0; mt < M; ++mt) { xo[mt][0] = xoff[mt]; xo[mt][1] = xoff[mt] + 16u; }
+    auto issue_half = [&](int hh) {       // exactly 8 DMAs per thread: 4 fragment blocks + 2*M x pieces of half min(hh, lasth)
+      const int c = hh < lasth ? hh : lasth;
+      float* st = lds + (hh & 3) * kStage;
+      const char* pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + poff[q]),
+                                         (LDS_AS void*)(st + (4 * q + wave_u) * kFragFloats), 16, 0, 0);
+      float* xl = st + kHalfFloats + wave_u * (M * 2 * kFragFloats);
+      const char* xg = xblk + (size_t)c * 64;
 #pragma unroll
       for (int mt = 0; mt < M; ++mt)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-          for (int pc = 0; pc < 2; ++pc) {
-            const int k = tt * kKTile + 16 * hf + 8 * h + 4 * pc;
-            dst[2 * hf + pc][mt] = asm_load_x4(xrow[mt] + (k < dim ? k : 0));
-          }
-    };
-    auto mask_tile = [&](int t, f32x4 (&v)[4][M]) {      // zero what lies beyond dim (loaded from a clamped address)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
         for (int pc = 0; pc < 2; ++pc)
-          if (t * kKTile + 16 * hf + 8 * h + 4 * pc >= dim)
-#pragma unroll
-            for (int mt = 0; mt < M; ++mt) v[2 * hf + pc][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + xo[mt][pc]),
+                                           (LDS_AS void*)(xl + (mt * 2 + pc) * kFragFloats), 16, 0, 0);
     };
-    auto compute_tile = [&](int t, f32x4 (&v)[4][M]) {
-      const float* cur = lds + (t % 3) * kTileFloats;
-      mask_tile(t, v);
+    auto read_x = [&](int hh, f32x4 (&v)[2][M]) {
+      const float* xl = lds + (hh & 3) * kStage + kHalfFloats + wave_u * (M * 2 * kFragFloats) + lane * 4;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        f32x4 bh[NT], bm[NT];
-        read_frags<NT>(cur + hf * kHalfFloats, 0, lane, bh);
-        read_frags<NT>(cur + hf * kHalfFloats, 1, lane, bm);
-        bf16x8 ah[M], am[M];
+      for (int mt = 0; mt < M; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < M; ++mt) {
-          split_bf16(v[2 * hf][mt], v[2 * hf + 1][mt], ah[mt], am[mt]);
+        for (int pc = 0; pc < 2; ++pc) v[pc][mt] = *reinterpret_cast<const f32x4*>(xl + (mt * 2 + pc) * kFragFloats);
+    };
+    // The split of one stage's x (2*M pieces of 4 floats per lane) is cut into 8 pair-slices of three steps each,
+    // so that it can be dealt out one step per MFMA (see stage()).
+    // ss: sum of squares of the bf16 HIGH parts (v_dot2c_f32_bf16, 2 products per instruction): within 0.8 % of
+    // ||x||^2, which only sizes the stage-1 window (the epilogue widens it by 1 %).  amax: exact max |x|.
+    struct Bf16Pairs { bf16x2 p[4]; };
+    float r0 = 0.f, r1 = 0.f;             // residuals of the pair in flight
+    auto split_step = [&](int g, int step, const f32x4 (&v)[2][M], Bf16Pairs (&hi)[M], Bf16Pairs (&mid)[M]) {
+      const int mt = g >> 2, pr = g & 3, pc = pr >> 1, e = 2 * (pr & 1);
+      const float v0 = v[pc][mt][e], v1 = v[pc][mt][e + 1];
+      if (step == 0) {
+        const bf16x2 hp = bf16x2{(__bf16)v0, (__bf16)v1};       // v_cvt_pk_bf16_f32: round to nearest even
+        hi[mt].p[pr] = hp;
+        r0 = v0 - (float)hp[0];                                 // exact in f32
+        r1 = v1 - (float)hp[1];
+      } else if (step == 1) {
+        mid[mt].p[pr] = bf16x2{(__bf16)r0, (__bf16)r1};
+      } else {
+        ss[mt] = __builtin_amdgcn_fdot2_f32_bf16(hi[mt].p[pr], hi[mt].p[pr], ss[mt], false);
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax[mt]) : "v"(v0), "v"(v1));
+      }
+    };
+    // Fragments travel in QUARTERS (4 column tiles x {hi, mid} = 8 ds_read_b128 = 32 VGPRs).
+    auto read_quarter = [&](const float* half_base, int j0, f32x4 (&f)[4][2]) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v0 = v[2 * hf][mt][e], v1 = v[2 * hf + 1][mt][e];
-            ss[mt] = __builtin_fmaf(v0, v0, ss[mt]);
-            ss[mt] = __builtin_fmaf(v1, v1, ss[mt]);
-            amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
-          }
-        }
+      for (int j = 0; j < 4; ++j) {
+        f[j][0] = *reinterpret_cast<const f32x4*>(half_base + (((j0 + j) * 2 + 0) * 64 + lane) * 4);
+        f[j][1] = *reinterpret_cast<const f32x4*>(half_base + (((j0 + j) * 2 + 1) * 64 + lane) * 4);
+      }
+    };
+    // MFMA number k (0..23) of a quarter: column tile j0 + k/6, row tile (k/3)%2, term k%3 of xh*ph + xh*pm + xm*ph
+    auto mfma_one = [&](int j0, int k, const f32x4 (&f)[4][2], const Bf16Pairs (&hi)[M], const Bf16Pairs (&mid)[M]) {
+      const int j = k / 6, mt = (k / 3) % 2, term = k % 3;
+      const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[mt] : hi[mt]);
+      const bf16x8 bb = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
+      acc[mt][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[mt][j0 + j], 0, 0, 0);
+    };
+    // Software pipeline over the stage barrier: every group of 24 MFMAs runs while the LDS reads of the NEXT group
+    // are in flight, and every lgkmcnt(0) is taken a whole group after the reads it covers were issued:
+    //   barrier(hh) | read A(hh) | MFMA B(hh-1) + split x(hh) | wait | read B(hh), x(hh+1) | MFMA A(hh) + DMA(hh+3) | wait
+    // (A/B = column tiles 0-3 / 4-7).  B(hh-1) sits in registers across the barrier, so the slot of stage hh-1 is
+    // free for DMA(hh+3) as soon as the barrier is passed.  x pieces are wave-private: reading x(hh+1) only needs
+    // this wave's own vmcnt, not the barrier.
+    // An MFMA holds the vector issue port for 8 of its 32 cycles, so up to ~24 cycles of other instructions ride in
+    // its shadow - but only if they are dealt out one small slice per MFMA: the order below is pinned slice by
+    // slice with sched_barrier (hipcc otherwise clumps them, and a clump hides only its first 24 cycles).
+    f32x4 xr[2][M];
+    f32x4 fa[4][2], fb[4][2];
+    Bf16Pairs ahx[M], amx[M], ahy[M], amy[M];   // bf16 x of the previous / current stage, ping-pong (no copies)
+    auto stage = [&](int hh, const bool first, const Bf16Pairs (&ahp)[M], const Bf16Pairs (&amp)[M],
+                     Bf16Pairs (&ahc)[M], Bf16Pairs (&amc)[M]) {
+      const float* st = lds + (hh & 3) * kStage;
+      read_quarter(st, 0, fa);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          const bf16x8 bhj = __builtin_bit_cast(bf16x8, bh[jt]);
-          const bf16x8 bmj = __builtin_bit_cast(bf16x8, bm[jt]);
+      for (int k = 0; k < 24; ++k) {
+        if (!first) mfma_one(4, k, fb, ahp, amp);
+        split_step(k / 3, k % 3, xr, ahc, amc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): A(hh), a whole group old
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's DMAs of stage hh+1 have landed (hh+2 pending)
+      read_quarter(st, 4, fb);
+      read_x(hh + 1, xr);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int c = hh + 3 < lasth ? hh + 3 : lasth;
+        float* nst = lds + ((hh + 3) & 3) * kStage;       // the slot of stage hh-1, which every wave has left
+        const char* pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
+        float* xl = nst + kHalfFloats + wave_u * (M * 2 * kFragFloats);
+        const char* xg = xblk + (size_t)c * 64;
 #pragma unroll
-          for (int mt = 0; mt < M; ++mt) {
-            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bhj, acc[mt][jt], 0, 0, 0);
-            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bmj, acc[mt][jt], 0, 0, 0);
-            acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mt], bhj, acc[mt][jt], 0, 0, 0);
+        for (int k = 0; k < 24; ++k) {
+          mfma_one(0, k, fa, ahc, amc);
+          if (k % 3 == 0) {                     // one of the 8 DMAs of stage hh+3 every third MFMA
+            const int d = k / 3;
+            if (d < 4)
+              __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + poff[d]),
+                                               (LDS_AS void*)(nst + (4 * d + wave_u) * kFragFloats), 16, 0, 0);
+            else
+              __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + xo[(d - 4) >> 1][(d - 4) & 1]),
+                                               (LDS_AS void*)(xl + (d - 4) * kFragFloats), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);       // B(hh) and x(hh+1): a whole group old
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();             // everybody's stage hh+1 is in LDS, everybody holds B(hh) in registers
     };
-    issue_tile(0, xa);
-    issue_tile(1, xb);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_half(0);
+    issue_half(1);
+    issue_half(2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 has landed, stages 1 and 2 stay in flight
     __builtin_amdgcn_s_barrier();
-    // the ring of x registers is rotated by unrolling three tiles per iteration (no register copies, and every
-    // array index stays a compile-time constant)
-    int kt = 0;
-    for (; kt + 2 < ktiles; kt += 3) {
-      issue_tile(kt + 2, xc);
-      compute_tile(kt, xa);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      issue_tile(kt + 3, xa);
-      compute_tile(kt + 1, xb);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      issue_tile(kt + 4, xb);
-      compute_tile(kt + 2, xc);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+    read_x(0, xr);
+    stage(0, true, ahx, amx, ahy, amy);
+    int hh = 1;
+    for (; hh + 1 < halves; hh += 2) {          // halves is even: an odd number of stages remains, pairs + one
+      stage(hh, false, ahy, amy, ahx, amx);
+      stage(hh + 1, false, ahx, amx, ahy, amy);
     }
-    // tail: tiles kt (in xa) and kt+1 (in xb) may remain
-    if (kt < ktiles) {
-      compute_tile(kt, xa);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < ktiles) compute_tile(kt + 1, xb);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped prefetches beyond the last tile must land before exit
+    stage(hh, false, ahy, amy, ahx, amx);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) mfma_one(4, k, fb, ahx, amx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the last stage must land before exit
     __builtin_amdgcn_s_barrier();
   } else if (PIPE == 1) {
     const int halves = 2 * ktiles;
@@ -660,7 +729,15 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     const float am = __builtin_fmaxf(amax[mt], __shfl_xor(amax[mt], 32));
     const int64_t myrow = row0 + mt * kRowsPerWave + i;
     if (h == 0) {
-      norm_lds[mt * kRowsPerWave + i] = sqrtf(s2) * args.tau;
+      float window = sqrtf(s2) * args.tau;
+      if (SPLIT) {
+        // s2 came from the bf16 high parts (<= 0.8 % off): widen by 1 %.  A row whose largest |x| is outside
+        // [2^-60, 2^60] leaves the range in which x*x and the bf16 split neither underflow nor overflow: re-evaluate
+        // all of its projections (NOT(|y| > +inf) holds for every y).  A true zero row gives y = 0 in both passes.
+        window *= 1.01f;
+        if (am != 0.f && !(am >= 0x1p-60f && am <= 0x1p60f)) window = __builtin_inff();
+      }
+      norm_lds[mt * kRowsPerWave + i] = window;
       if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
         const bool has_nan = s2 != s2;
         const bool zero = (am <= 1e-8f) && !has_nan;
@@ -775,6 +852,11 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
         }
       }
     }
+  }
+  if (SPLIT && args.clock_probe != nullptr && tid == 0) {   // diagnostics: whole-workgroup cycles incl. the epilogue
+    const unsigned long long slot = (unsigned long long)gridDim.y * gridDim.x + (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+    args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
+    args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
   }
 }
 
@@ -1387,8 +1469,8 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   if (n >= ((int64_t)1 << 47) || (n + 255) / 256 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
-  const bool aligned = (dim % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  if (!aligned)  // the split pass is built for 16-byte aligned rows; anything else takes the f32 pass (same keys)
+  const bool aligned = (dim % 32 == 0) && (ldx % 4 == 0) && ldx < (1 << 20) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (!aligned)  // the split pass is built for whole k-tiles of 16-byte aligned rows; anything else takes the f32 pass (same keys)
     return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
                                     tie_count, tau, row_flags, stream);
   // stage 1: bf16 x 3 projections -> keys + list of (row, word, mask) inside the stage-1 window
@@ -1410,6 +1492,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   a.tie_count = flag_count;
   a.tau = tau1;
   a.row_flags = row_flags;
+  a.clock_probe = g_clock_probe;
   {
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
