@@ -1,0 +1,65 @@
+/* lshrs_host.h - C ABI of the host tie-break engine (liblshrs_host.so, plain C++/pthreads, no HIP).
+ *
+ * The GPU signature pass (lshrs_hip.h) returns, next to the keys, the list of projections whose sign cannot be
+ * trusted against the reference's summation order.  The bit-exact contract is restored by evaluating those
+ * (row, band) pairs with the very expression the reference uses,
+ *
+ *     projections = projection_matrix @ vector          lshrs/hash/lsh.py:200
+ *     bits        = projections > 0                     lshrs/hash/lsh.py:204
+ *     packed      = np.packbits(bits, bitorder="little")  lshrs/hash/lsh.py:208
+ *
+ * i.e. one cblas_sgemv(RowMajor, NoTrans, rows_per_band, dim) of the BLAS NumPy is linked against, per pair.
+ * This engine issues exactly that call, from several threads, each through a private mapping of the same
+ * library file (OpenBLAS serialises callers that share one mapping).  It is a host-side accelerator of the
+ * reference's own arithmetic, not a re-implementation of it: there is no summation code in it.
+ */
+#ifndef LSHRS_HOST_H
+#define LSHRS_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSHRS_HOST_ABI_VERSION 1
+#define LSHRS_HOST_E_BADARG (-1)
+
+int lshrs_host_abi_version(void);
+
+/* Create an engine with up to n_threads workers (1..64), each bound to its own copy of the shared library at
+ * blas_path.  sgemv_symbol names that library's cblas_sgemv ("scipy_cblas_sgemv64_" for NumPy 2's bundled
+ * OpenBLAS, "cblas_sgemv" for a system BLAS); ilp64 says whether its integer arguments are 64-bit;
+ * set_threads_symbol (may be NULL/"") names its openblas_set_num_threads, called with 1 on every copy.
+ * Returns NULL when not even one copy can be mapped; fewer copies than asked for is not an error
+ * (lshrs_tb_threads tells). */
+void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const char* set_threads_symbol, int ilp64,
+                      int n_threads);
+int lshrs_tb_threads(void* engine);
+void lshrs_tb_destroy(void* engine);
+
+/* For pair p in [0, n_pairs): y = planes[band[p]] (rows_per_band x dim, row-major, contiguous) @ xrows[row_index[p]]
+ * (row stride ldx floats); out_keys[p*band_bytes ..] = packbits(y > 0, little), band_bytes = ceil(rows_per_band/8).
+ * out_y (may be NULL) receives the rows_per_band projections of every pair.  Blocks until done; one call at a
+ * time per engine (serialised internally).  Returns 0 or LSHRS_HOST_E_BADARG.
+ * Replaces the per-vector expression of lshrs/hash/lsh.py:200-208 for the pairs the GPU pass flagged. */
+int lshrs_tb_patch(void* engine, const float* planes, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                   const float* xrows, int64_t ldx, const int32_t* row_index, const int32_t* band, int64_t n_pairs,
+                   uint8_t* out_keys, float* out_y);
+
+/* One pipeline chunk in one call: decode the GPU pass's tie list, evaluate the pairs, lay the patches out for
+ * lshrs_scatter_band_keys_u8 (lshrs_hip.h).
+ *   entries  n_entries x 2 int64, as written by lshrs_sig_hash_batch_f32: (row * 65536 + index of a 32-column word
+ *            of the padded key row, bit mask of the flagged columns in that word)
+ *   xstage   one vector per ENTRY (row stride ldx floats), as staged by lshrs_gather_tied_rows_f32
+ * Output: the unique (row, band) pairs sorted by (band, row) in out_rows / out_bands and their band keys in
+ * out_keys (band_bytes each); *n_pairs = their number.  Returns LSHRS_HOST_E_BADARG (with *n_pairs set) when
+ * out_cap pairs are not enough. */
+int lshrs_tb_resolve(void* engine, const float* planes, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                     const int64_t* entries, int64_t n_entries, const float* xstage, int64_t ldx, int64_t* out_rows,
+                     int32_t* out_bands, uint8_t* out_keys, int64_t out_cap, int64_t* n_pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSHRS_HOST_H */

@@ -1,0 +1,217 @@
+"""ctypes binding of ``csrc/liblshrs_host.so`` (C ABI: ``include/lshrs_host.h``): the host tie-break engine.
+
+The engine re-evaluates the (row, band) pairs the GPU pass flagged with the reference's own BLAS call
+(``projection @ vector``, lshrs/hash/lsh.py:200) on several cores at once — every worker thread calls
+``cblas_sgemv`` through a private mapping of the library NumPy itself is linked against, because callers that
+share one OpenBLAS mapping are serialised by its buffer lock.  No arithmetic of its own: if the library NumPy
+uses cannot be located, or a shape fails the self-check against ``P_band @ x``, the caller keeps using NumPy's
+batched ``matmul`` (same call, one core).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+SOURCE = os.path.join(_HERE, "csrc", "host_tiebreak.cpp")
+LIBRARY = os.path.join(_HERE, "csrc", "liblshrs_host.so")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+ABI_VERSION = 1
+EXPORTS = ("lshrs_host_abi_version", "lshrs_tb_create", "lshrs_tb_threads", "lshrs_tb_destroy", "lshrs_tb_patch",
+           "lshrs_tb_resolve")
+
+# (cblas_sgemv symbol, 64-bit integers?, set_num_threads symbol) in order of preference
+_BLAS_FLAVOURS = (
+    ("scipy_cblas_sgemv64_", 1, "scipy_openblas_set_num_threads64_"),   # NumPy >= 2 wheels
+    ("cblas_sgemv64_", 1, "openblas_set_num_threads64_"),               # NumPy 1.2x wheels
+    ("cblas_sgemv", 0, "openblas_set_num_threads"),                     # system OpenBLAS
+)
+
+_lock = threading.Lock()
+_lib: Optional[ctypes.CDLL] = None
+_engine: Optional["TieBreakEngine"] = None
+_engine_failed = False
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the host engine with g++ into the in-tree shared library."""
+    with _lock:
+        newest = max(os.path.getmtime(SOURCE), os.path.getmtime(os.path.join(INCLUDE, "lshrs_host.h")))
+        if not force and os.path.exists(LIBRARY) and os.path.getmtime(LIBRARY) >= newest:
+            return LIBRARY
+        cxx = os.environ.get("CXX", "g++")
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, SOURCE, "-o", LIBRARY + ".tmp",
+               "-ldl", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        os.replace(LIBRARY + ".tmp", LIBRARY)
+        return LIBRARY
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        lib = ctypes.CDLL(LIBRARY)
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise OSError(f"{LIBRARY} does not export {name}; rebuild it")
+        c = ctypes
+        lib.lshrs_host_abi_version.restype = c.c_int
+        lib.lshrs_tb_create.argtypes = [c.c_char_p, c.c_char_p, c.c_char_p, c.c_int, c.c_int]
+        lib.lshrs_tb_create.restype = c.c_void_p
+        lib.lshrs_tb_threads.argtypes = [c.c_void_p]
+        lib.lshrs_tb_threads.restype = c.c_int
+        lib.lshrs_tb_destroy.argtypes = [c.c_void_p]
+        lib.lshrs_tb_destroy.restype = None
+        lib.lshrs_tb_patch.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_int64,
+                                       c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+        lib.lshrs_tb_patch.restype = c.c_int
+        lib.lshrs_tb_resolve.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_int64,
+                                         c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p]
+        lib.lshrs_tb_resolve.restype = c.c_int
+        if lib.lshrs_host_abi_version() != ABI_VERSION:
+            raise OSError(f"{LIBRARY} has a different ABI version; rebuild it")
+        _lib = lib
+        return lib
+
+
+def numpy_blas() -> Optional[Tuple[str, str, int, str]]:
+    """(path, sgemv symbol, ilp64, set_num_threads symbol) of the BLAS this process's NumPy calls, or None."""
+    np.dot(np.ones((2, 2), np.float32), np.ones(2, np.float32))  # make sure it is mapped
+    paths = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                path = line.rsplit(None, 1)[-1]
+                if "openblas" in os.path.basename(path).lower() and path not in paths and os.path.exists(path):
+                    paths.append(path)
+    except OSError:
+        return None
+    # prefer the copy that lives next to numpy
+    paths.sort(key=lambda p: (0 if "numpy" in p else 1, p))
+    for path in paths:
+        try:
+            handle = ctypes.CDLL(path)
+        except OSError:
+            continue
+        for sym, ilp64, setter in _BLAS_FLAVOURS:
+            if hasattr(handle, sym):
+                return path, sym, ilp64, setter if hasattr(handle, setter) else ""
+    return None
+
+
+def default_threads() -> int:
+    """Worker count: this process's share of the cores (ranks of one node divide them), at most 8."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        cores = os.cpu_count() or 1
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    return max(1, min(8, cores // ranks))
+
+
+class TieBreakEngine:
+    """Thread pool over private BLAS copies; ``patch`` is the drop-in for the NumPy tie-break loop."""
+
+    def __init__(self, threads: int) -> None:
+        info = numpy_blas()
+        if info is None:
+            raise OSError("the BLAS library NumPy calls could not be located (not an OpenBLAS build?)")
+        self.blas_path, self.symbol, self.ilp64, setter = info
+        self._lib = load()
+        self._handle = self._lib.lshrs_tb_create(self.blas_path.encode(), self.symbol.encode(), setter.encode(),
+                                                 self.ilp64, int(threads))
+        if not self._handle:
+            raise OSError(f"could not map a private copy of {self.blas_path}")
+        self.threads = int(self._lib.lshrs_tb_threads(self._handle))
+        self._shape_ok: Dict[Tuple[int, int], bool] = {}
+
+    def close(self) -> None:
+        if self._handle:
+            self._lib.lshrs_tb_destroy(self._handle)
+            self._handle = None
+
+    def patch(self, planes: np.ndarray, xrows: np.ndarray, row_index: np.ndarray, bands: np.ndarray,
+              want_y: bool = False):
+        """planes (num_bands, r, dim) f32 C-contiguous; xrows (m, dim) f32 with contiguous rows;
+        row_index/bands int32 (pairs).  Returns the (pairs, band_bytes) uint8 keys [and the projections]."""
+        nb, r, dim = planes.shape
+        m = int(bands.shape[0])
+        keys = np.empty((m, (r + 7) // 8), dtype=np.uint8)
+        y = np.empty((m, r), dtype=np.float32) if want_y else None
+        if m:
+            assert planes.dtype == np.float32 and planes.flags.c_contiguous
+            assert xrows.dtype == np.float32 and xrows.strides[1] == 4 and xrows.shape[1] == dim
+            row_index = np.ascontiguousarray(row_index, dtype=np.int32)
+            bands = np.ascontiguousarray(bands, dtype=np.int32)
+            if row_index.size and int(row_index.max()) >= xrows.shape[0]:
+                raise IndexError("tie-break row index out of range")
+            rc = self._lib.lshrs_tb_patch(self._handle, planes.ctypes.data, nb, r, dim, xrows.ctypes.data,
+                                          xrows.strides[0] // 4, row_index.ctypes.data, bands.ctypes.data, m,
+                                          keys.ctypes.data, y.ctypes.data if want_y else None)
+            if rc != 0:
+                raise ValueError("lshrs_tb_patch: bad argument")
+        return (keys, y) if want_y else keys
+
+    def resolve(self, planes: np.ndarray, entries_ptr: int, n_entries: int, xstage_ptr: int, ldx: int,
+                rows_ptr: int, bands_ptr: int, keys_ptr: int, out_cap: int) -> int:
+        """One pipeline chunk in one native call (raw pointers into pinned staging buffers): tie entries + staged
+        vectors in, unique (row, band) pairs and their patched band keys out.  Returns the number of pairs."""
+        nb, r, dim = planes.shape
+        n_pairs = ctypes.c_int64(0)
+        rc = self._lib.lshrs_tb_resolve(self._handle, planes.ctypes.data, nb, r, dim, entries_ptr, int(n_entries),
+                                        xstage_ptr, int(ldx), rows_ptr, bands_ptr, keys_ptr, int(out_cap),
+                                        ctypes.byref(n_pairs))
+        if rc != 0:
+            raise ValueError(f"lshrs_tb_resolve: bad argument or {n_pairs.value} pairs exceed the room for {out_cap}")
+        return int(n_pairs.value)
+
+    def shape_trusted(self, planes: np.ndarray) -> bool:
+        """Self-check, once per (rows_per_band, dim): the engine's projections must equal ``P_band @ x`` of this
+        process's NumPy bit for bit (guards against a BLAS whose result depends on its thread count)."""
+        nb, r, dim = planes.shape
+        key = (r, dim)
+        if key not in self._shape_ok:
+            rng = np.random.default_rng(20240229)
+            xs = rng.standard_normal((48, dim)).astype(np.float32)
+            bands = (np.arange(48) % nb).astype(np.int32)
+            rows = np.arange(48, dtype=np.int32)
+            _, y = self.patch(planes, xs, rows, bands, want_y=True)
+            ok = all(np.array_equal((planes[b] @ xs[i]).view(np.uint32), y[i].view(np.uint32))
+                     for i, b in enumerate(bands))
+            self._shape_ok[key] = ok
+        return self._shape_ok[key]
+
+
+def engine(threads: Optional[int] = None) -> Optional[TieBreakEngine]:
+    """The process-wide engine, or None when it cannot be built here (the caller then uses NumPy's matmul)."""
+    global _engine, _engine_failed
+    if _engine is not None or _engine_failed:
+        return _engine
+    want = default_threads() if threads is None else int(threads)
+    if want < 2:
+        _engine_failed = True   # one core: NumPy's own call is the same thing
+        return None
+    try:
+        if not os.path.exists(LIBRARY):
+            raise OSError(f"{LIBRARY} has not been built")
+        eng = TieBreakEngine(want)
+    except OSError:
+        _engine_failed = True
+        return None
+    with _lock:
+        if _engine is None:
+            _engine = eng
+    return _engine

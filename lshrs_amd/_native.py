@@ -33,7 +33,10 @@ class NativeLibraryError(RuntimeError):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP source for gfx950 into the in-tree shared library."""
+    """Compile the HIP source for gfx950 into the in-tree shared library (and the host tie-break engine)."""
+    from . import _hostblas
+
+    _hostblas.build(force=force, verbose=verbose)
     with _lock:
         newest_src = max(os.path.getmtime(SOURCE), os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h")))
         if not force and os.path.exists(LIBRARY) and os.path.getmtime(LIBRARY) >= newest_src:

@@ -1,0 +1,336 @@
+// Host tie-break engine: the reference's own BLAS call, on several cores at once.
+//
+// The signature kernel reports every projection whose magnitude is too small for its sign to be trusted
+// against the reference's summation order.  Those (row, band) pairs are re-evaluated with
+// the expression the reference itself uses, `projection @ vector` (lshrs/hash/lsh.py:200), i.e. one
+// cblas_sgemv(RowMajor, NoTrans, rows_per_band, dim) of NumPy's bundled OpenBLAS per pair.  That costs ~0.9 us
+// per pair on one core and is what bounds the bit-exact ingest rate.
+//
+// OpenBLAS serialises concurrent callers on a process-wide buffer lock, so threads calling into ONE copy of the
+// library do not scale.  This engine therefore maps the library file N times (memfd copies: distinct inodes, so
+// the dynamic loader gives each copy its own globals and its own lock) and gives each worker thread a private
+// copy.  Same machine code, same kernel selection, same operands -> the same bits as NumPy's call
+// (tests/test_tiebreak_host.py compares them, and lshrs_amd/hasher.py self-checks each shape before trusting it).
+//
+// Plain C ABI (include/lshrs_host.h); no HIP, no torch.  Built with g++ by lshrs_amd/_native.py.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "lshrs_host.h"
+
+namespace {
+
+// cblas_sgemv of an ILP64 OpenBLAS (NumPy >= 2 bundles libscipy_openblas64_: 64-bit integers)
+using sgemv64_fn = void (*)(int order, int trans, int64_t m, int64_t n, float alpha, const float* a, int64_t lda,
+                            const float* x, int64_t incx, float beta, float* y, int64_t incy);
+// ... and of an LP64 build (32-bit integers)
+using sgemv32_fn = void (*)(int order, int trans, int m, int n, float alpha, const float* a, int lda, const float* x,
+                            int incx, float beta, float* y, int incy);
+using set_threads_fn = void (*)(int);
+
+constexpr int kRowMajor = 101, kNoTrans = 111;
+
+struct Job {
+  const float* planes = nullptr;
+  int r = 0, dim = 0, band_bytes = 0;
+  const float* xrows = nullptr;
+  int64_t ldx = 0;
+  const int32_t* row_index = nullptr;
+  const int32_t* band = nullptr;
+  int64_t n_pairs = 0;
+  uint8_t* out_keys = nullptr;
+  float* out_y = nullptr;  // optional: the projections themselves (tests)
+};
+
+struct PairRec {
+  int64_t row;
+  int32_t band;
+  int32_t entry;
+};
+
+struct Engine {
+  int ilp64 = 1;
+  std::vector<void*> handles;
+  std::vector<void*> sgemv;
+  std::vector<int> fds;
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  uint64_t generation = 0;
+  std::atomic<uint64_t> gen_atomic{0};     // mirror of generation for the lock-free poll
+  std::atomic<bool> stop_atomic{false};
+  int pending = 0;
+  bool stop = false;
+  Job job;
+  std::atomic<int64_t> next{0};
+  std::mutex run_mu;  // one lshrs_tb_patch / lshrs_tb_resolve at a time
+  std::vector<PairRec> scratch_pairs;
+  std::vector<int32_t> scratch_index;
+};
+
+constexpr int64_t kGrain = 16;  // pairs claimed per atomic fetch
+
+void run_pairs(Engine* e, int t) {
+  const Job& j = e->job;
+  float ybuf[64];
+  std::vector<float> ybig;
+  float* y = ybuf;
+  if (j.r > 64) {
+    ybig.resize(j.r);
+    y = ybig.data();
+  }
+  for (;;) {
+    const int64_t lo = e->next.fetch_add(kGrain, std::memory_order_relaxed);
+    if (lo >= j.n_pairs) break;
+    const int64_t hi = lo + kGrain < j.n_pairs ? lo + kGrain : j.n_pairs;
+    for (int64_t p = lo; p < hi; ++p) {
+      const float* plane = j.planes + (size_t)j.band[p] * j.r * j.dim;
+      const float* x = j.xrows + (size_t)j.row_index[p] * j.ldx;
+      if (e->ilp64)
+        reinterpret_cast<sgemv64_fn>(e->sgemv[t])(kRowMajor, kNoTrans, j.r, j.dim, 1.0f, plane, j.dim, x, 1, 0.0f, y, 1);
+      else
+        reinterpret_cast<sgemv32_fn>(e->sgemv[t])(kRowMajor, kNoTrans, j.r, j.dim, 1.0f, plane, j.dim, x, 1, 0.0f, y, 1);
+      uint8_t* out = j.out_keys + (size_t)p * j.band_bytes;
+      for (int b = 0; b < j.band_bytes; ++b) {  // np.packbits(y > 0, bitorder="little"): lsh.py:204-208
+        unsigned v = 0;
+        for (int k = 0; k < 8 && 8 * b + k < j.r; ++k) v |= (y[8 * b + k] > 0.0f ? 1u : 0u) << k;
+        out[b] = (uint8_t)v;
+      }
+      if (j.out_y != nullptr) memcpy(j.out_y + (size_t)p * j.r, y, sizeof(float) * j.r);
+    }
+  }
+}
+
+void worker_main(Engine* e, int t) {
+  uint64_t seen = 0;
+  for (;;) {
+    // Chunks of one batch arrive a few hundred microseconds apart: poll for that long before going to sleep, a
+    // condition-variable wake-up alone costs as much as the work of a small chunk.
+    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+    while (e->gen_atomic.load(std::memory_order_acquire) == seen && !e->stop_atomic.load(std::memory_order_relaxed) &&
+           std::chrono::steady_clock::now() < spin_until)
+      __builtin_ia32_pause();
+    {
+      std::unique_lock<std::mutex> lk(e->mu);
+      e->cv_go.wait(lk, [&] { return e->stop || e->generation != seen; });
+      if (e->stop) return;
+      seen = e->generation;
+    }
+    run_pairs(e, t);
+    {
+      std::lock_guard<std::mutex> lk(e->mu);
+      if (--e->pending == 0) e->cv_done.notify_all();
+    }
+  }
+}
+
+void* map_private_copy(const char* path, int* fd_out) {
+  const int in = open(path, O_RDONLY | O_CLOEXEC);
+  if (in < 0) return nullptr;
+  const int fd = memfd_create("lshrs_blas_copy", MFD_CLOEXEC);
+  if (fd < 0) {
+    close(in);
+    return nullptr;
+  }
+  std::vector<char> buf(1 << 20);
+  for (;;) {
+    const ssize_t got = read(in, buf.data(), buf.size());
+    if (got < 0) {
+      close(in);
+      close(fd);
+      return nullptr;
+    }
+    if (got == 0) break;
+    ssize_t off = 0;
+    while (off < got) {
+      const ssize_t put = write(fd, buf.data() + off, (size_t)(got - off));
+      if (put <= 0) {
+        close(in);
+        close(fd);
+        return nullptr;
+      }
+      off += put;
+    }
+  }
+  close(in);
+  const std::string proc = "/proc/self/fd/" + std::to_string(fd);
+  // RTLD_DEEPBIND: the copy binds its internal references to ITS OWN globals, not to the first copy loaded.
+  // Its dependencies (libgfortran, libquadmath) are found by SONAME among the libraries NumPy already loaded.
+  void* h = dlopen(proc.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+  if (h == nullptr) {
+    close(fd);
+    return nullptr;
+  }
+  *fd_out = fd;
+  return h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lshrs_host_abi_version(void) { return LSHRS_HOST_ABI_VERSION; }
+
+void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const char* set_threads_symbol, int ilp64,
+                      int n_threads) {
+  if (blas_path == nullptr || sgemv_symbol == nullptr || n_threads < 1 || n_threads > 64) return nullptr;
+  Engine* e = new Engine();
+  e->ilp64 = ilp64 ? 1 : 0;
+  for (int t = 0; t < n_threads; ++t) {
+    int fd = -1;
+    void* h = map_private_copy(blas_path, &fd);
+    void* fn = h ? dlsym(h, sgemv_symbol) : nullptr;
+    if (fn == nullptr) {
+      if (h) dlclose(h);
+      if (fd >= 0) close(fd);
+      break;
+    }
+    if (set_threads_symbol != nullptr && set_threads_symbol[0] != '\0') {
+      void* st = dlsym(h, set_threads_symbol);
+      if (st != nullptr) reinterpret_cast<set_threads_fn>(st)(1);  // each copy serves exactly one caller
+    }
+    e->handles.push_back(h);
+    e->sgemv.push_back(fn);
+    e->fds.push_back(fd);
+  }
+  if (e->handles.empty()) {
+    delete e;
+    return nullptr;
+  }
+  const int got = (int)e->handles.size();
+  for (int t = 1; t < got; ++t) e->workers.emplace_back(worker_main, e, t);  // the caller is worker 0
+  return e;
+}
+
+int lshrs_tb_threads(void* engine) { return engine ? (int)static_cast<Engine*>(engine)->handles.size() : 0; }
+
+void lshrs_tb_destroy(void* engine) {
+  if (engine == nullptr) return;
+  Engine* e = static_cast<Engine*>(engine);
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->stop = true;
+    e->stop_atomic.store(true);
+  }
+  e->cv_go.notify_all();
+  for (auto& w : e->workers) w.join();
+  // The private copies stay mapped: OpenBLAS starts helper threads at load time and unloading a library under
+  // them is not safe.  The memfds can go; the mappings keep the pages alive.
+  for (int fd : e->fds) close(fd);
+  delete e;
+}
+
+static int run_job(Engine* e, const float* planes, int32_t rows_per_band, int32_t dim, const float* xrows, int64_t ldx,
+                   const int32_t* row_index, const int32_t* band, int64_t n_pairs, uint8_t* out_keys, float* out_y) {
+  e->job.planes = planes;
+  e->job.r = rows_per_band;
+  e->job.dim = dim;
+  e->job.band_bytes = (rows_per_band + 7) / 8;
+  e->job.xrows = xrows;
+  e->job.ldx = ldx;
+  e->job.row_index = row_index;
+  e->job.band = band;
+  e->job.n_pairs = n_pairs;
+  e->job.out_keys = out_keys;
+  e->job.out_y = out_y;
+  e->next.store(0, std::memory_order_relaxed);
+  const bool fan_out = !e->workers.empty() && n_pairs > 4 * kGrain;  // a handful of pairs is cheaper done here
+  if (fan_out) {
+    {
+      std::lock_guard<std::mutex> lk(e->mu);
+      e->pending = (int)e->workers.size();
+      ++e->generation;
+      e->gen_atomic.store(e->generation, std::memory_order_release);
+    }
+    e->cv_go.notify_all();
+  }
+  run_pairs(e, 0);
+  if (fan_out) {
+    std::unique_lock<std::mutex> lk(e->mu);
+    e->cv_done.wait(lk, [&] { return e->pending == 0; });
+  }
+  return 0;
+}
+
+int lshrs_tb_patch(void* engine, const float* planes, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                   const float* xrows, int64_t ldx, const int32_t* row_index, const int32_t* band, int64_t n_pairs,
+                   uint8_t* out_keys, float* out_y) {
+  if (n_pairs == 0) return 0;
+  if (engine == nullptr || planes == nullptr || xrows == nullptr || row_index == nullptr || band == nullptr ||
+      out_keys == nullptr || n_pairs < 0 || num_bands < 1 || rows_per_band < 1 || dim < 1 || ldx < dim)
+    return LSHRS_HOST_E_BADARG;
+  for (int64_t p = 0; p < n_pairs; ++p)
+    if (band[p] < 0 || band[p] >= num_bands || row_index[p] < 0) return LSHRS_HOST_E_BADARG;
+  Engine* e = static_cast<Engine*>(engine);
+  std::lock_guard<std::mutex> run(e->run_mu);
+  return run_job(e, planes, rows_per_band, dim, xrows, ldx, row_index, band, n_pairs, out_keys, out_y);
+}
+
+int lshrs_tb_resolve(void* engine, const float* planes, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                     const int64_t* entries, int64_t n_entries, const float* xstage, int64_t ldx, int64_t* out_rows,
+                     int32_t* out_bands, uint8_t* out_keys, int64_t out_cap, int64_t* n_pairs) {
+  if (n_pairs == nullptr) return LSHRS_HOST_E_BADARG;
+  *n_pairs = 0;
+  if (n_entries == 0) return 0;
+  if (engine == nullptr || planes == nullptr || entries == nullptr || xstage == nullptr || out_rows == nullptr ||
+      out_bands == nullptr || out_keys == nullptr || n_entries < 0 || num_bands < 1 || rows_per_band < 1 || dim < 1 ||
+      ldx < dim || n_entries > INT32_MAX)
+    return LSHRS_HOST_E_BADARG;
+  Engine* e = static_cast<Engine*>(engine);
+  std::lock_guard<std::mutex> run(e->run_mu);
+  // entry = (row * 65536 + index of a 32-column word of the padded key row, mask of its flagged columns);
+  // bands are padded to whole bytes: column c belongs to band c / (8 * band_bytes)
+  const int band_cols = 8 * ((rows_per_band + 7) / 8);
+  using Pair = PairRec;
+  std::vector<Pair>& pairs = e->scratch_pairs;
+  pairs.clear();
+  for (int64_t i = 0; i < n_entries; ++i) {
+    const int64_t row = entries[2 * i] >> 16;
+    const int64_t word = entries[2 * i] & 0xFFFF;
+    uint32_t mask = (uint32_t)entries[2 * i + 1];
+    int last = -1;
+    while (mask != 0u) {
+      const int c = __builtin_ctz(mask);
+      mask &= mask - 1u;
+      const int b = (int)((32 * word + c) / band_cols);
+      if (b != last && b < num_bands) pairs.push_back(Pair{row, b, (int32_t)i});
+      last = b;
+    }
+  }
+  // unique (band, row), sorted by band then row (a band of more than 32 columns spans several words)
+  std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) {
+    return a.band != b.band ? a.band < b.band : (a.row != b.row ? a.row < b.row : a.entry < b.entry);
+  });
+  pairs.erase(std::unique(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.band == b.band && a.row == b.row; }),
+              pairs.end());
+  const int64_t m = (int64_t)pairs.size();
+  *n_pairs = m;
+  if (m > out_cap) return LSHRS_HOST_E_BADARG;
+  std::vector<int32_t>& idx = e->scratch_index;
+  idx.resize((size_t)m);
+  for (int64_t p = 0; p < m; ++p) {
+    out_rows[p] = pairs[p].row;
+    out_bands[p] = pairs[p].band;
+    idx[p] = pairs[p].entry;   // the device staged one vector per entry: any entry of the row carries it
+  }
+  return run_job(e, planes, rows_per_band, dim, xstage, ldx, idx.data(), out_bands, m, out_keys, nullptr);
+}
+
+}  // extern "C"

@@ -896,12 +896,18 @@ __device__ __forceinline__ void fix_load_tile(const float* __restrict__ tile, co
     for (int q = 0; q < 4; ++q) {
       p4[hh][q] = *reinterpret_cast<const f32x4*>(tile + ((q * 64) + hh * 32 + c) * 4);
       const int k = kt * kKTile + 16 * hh + 4 * q;
+      // loads are unconditional (clamped address) and masked afterwards: a load under a branch is followed by a
+      // vmcnt(0), which turned the 16 loads of a tile into 16 serial round trips
       if (ALIGNED) {
-        x4[hh][q] = k < dim ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (k < dim ? k : 0));
+        x4[hh][q] = k < dim ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
         f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (k + r < dim) ? x[k + r] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+          const float t = x[k + r < dim ? k + r : 0];
+          v[r] = (k + r < dim) ? t : 0.f;
+        }
         x4[hh][q] = v;
       }
     }
@@ -918,9 +924,14 @@ __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f3
   }
 }
 
+// Every thread walks its own (row, column) pair, so a wave's loads are fully divergent and the chain is pure
+// latency: kFixItemsPerWave lanes per wave keep each load instruction to a handful of cache lines and spread the
+// few thousand flagged projections of a launch over every CU (one full wave per 64 of them used 9 CUs).
+constexpr int kFixItemsPerWave = 8;
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void sig_fix_kernel(const FixArgs a) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void sig_fix_kernel(const FixArgs a) {
+  if ((int)threadIdx.x >= kFixItemsPerWave) return;
+  const int64_t e = (int64_t)blockIdx.x * kFixItemsPerWave + threadIdx.x;
   const int cnt = min(*a.flag_count, a.flag_cap);
   if (e >= cnt) return;
   const int64_t item = a.flag_list[e];
@@ -1519,7 +1530,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   f.tie_count = tie_count;
   f.tau = tau;
   {
-    const dim3 grid((unsigned)(((int64_t)flag_cap + 255) / 256)), block(256);
+    const dim3 grid((unsigned)(((int64_t)flag_cap + kFixItemsPerWave - 1) / kFixItemsPerWave)), block(64);
     if (aligned)
       hipLaunchKernelGGL(sig_fix_kernel<true>, grid, block, 0, s, f);
     else

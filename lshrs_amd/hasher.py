@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from . import _native
+from . import _hostblas, _native
 from ._config import HashSignatures
 
 __all__ = ["LSHHasher"]
@@ -80,6 +80,7 @@ class LSHHasher:
     Extra keyword arguments (not in the reference):
       device      torch device index / ``torch.device`` (default: current device at call time)
       tie_break   "host" (default: bytes equal the reference on this host), or "none" (raw kernel bits)
+      tie_threads host tie-break workers: None = auto (this process's share of the cores, at most 8), 1 = NumPy only
       tau_ulps    tie threshold in units of float32 roundoff: |y| < tau_ulps * 2^-24 * ||x|| * ||p||.
                   Default 8: measured on MI355X + host OpenBLAS (1.2M x 256 projections, Gaussian /
                   all-positive / 5 %-sparse data, dim 128-1536) the two evaluations of a near-zero
@@ -92,7 +93,7 @@ class LSHHasher:
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps: float = 8.0, precision: str = "f32",
-                 tau1_ulps: float = 256.0) -> None:
+                 tau1_ulps: float = 256.0, tie_threads: Optional[int] = None) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -114,6 +115,12 @@ class LSHHasher:
         self.precision = precision
         self.tau1_ulps = float(tau1_ulps)
         self.split_min_rows = 65_536
+        # host tie-break workers (lshrs_amd/_hostblas.py): None = this process's share of the cores (at most 8),
+        # 1 = NumPy's batched matmul on the calling thread.  Same BLAS call either way.
+        if tie_threads is not None and int(tie_threads) < 1:
+            raise ValueError("tie_threads must be >= 1")
+        self.tie_threads = None if tie_threads is None else int(tie_threads)
+        self._host_planes_cache: Optional[Tuple[int, np.ndarray]] = None
         self._device = device
         self._lock = threading.Lock()
         self._projection_version = 0
@@ -122,8 +129,10 @@ class LSHHasher:
         # set to a list to collect (start_event, end_event, rows) around every signature-kernel launch
         # (bench.py uses it to time the kernel on the stream it runs on)
         self.kernel_events: Optional[list] = None
-        # device batches of >= 2 chunks take the pipelined path; 131072 rows = two full-chip rounds of K1
-        self.pipeline_chunk_rows = 131_072
+        # device batches of >= 2 chunks take the pipelined path; 262144 rows = four full-chip rounds of the f32
+        # kernel (128-row workgroups, two per CU) and of the split pass (256-row workgroups, one per CU): each
+        # chunk boundary costs a kernel ramp-down/ramp-up, each chunk a fixed ~60 us of host work
+        self.pipeline_chunk_rows = 262_144
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
@@ -298,7 +307,7 @@ class LSHHasher:
         n = int(x.shape[0])
         bb = self.band_bytes
         ch = self.pipeline_chunk_rows
-        cap = ch // 16 + 1024
+        cap = ch // 32 + 1024    # tie entries per chunk (measured: ~0.25 % of the rows at tau_ulps = 8); more -> plain path
         window = 16
         spans = [(lo, min(n, lo + ch)) for lo in range(0, n, ch)]
         overflow = []
@@ -309,11 +318,14 @@ class LSHHasher:
             # chunk), so the bulk copies / patches must not queue behind them
             cstream = self._side_stream(dev, 0)
             side = self._side_stream(dev, 1)
-            pin_cnt, pin_entries, pin_rows, pin_fcnt = self._pinned(dev, cap, window)
+            pin_cnt, pin_entries, pin_rows, pin_fcnt, pin_patch, dev_patch, pairs_cap = self._pinned(dev, cap, window)
+            native = self._tie_engine()
+            slot_free = [None, None]   # event after which a patch staging slot may be overwritten
             for w0 in range(0, len(spans), window):
                 group = spans[w0:w0 + window]
                 lists = torch.empty((len(group), cap, 2), dtype=torch.int64, device=dev)
-                counts = torch.zeros((len(group),), dtype=torch.int32, device=dev)
+                counts = torch.zeros((2 * len(group),), dtype=torch.int32, device=dev)   # tie counts | stage-1 counts
+                fcounts = counts[len(group):]
                 stage = torch.empty((len(group), cap, self.dim), dtype=torch.float32, device=dev)
                 keep += [lists, counts, stage]
                 ready = []
@@ -324,7 +336,7 @@ class LSHHasher:
                     flag = self._launch_sig(torch, lib, dev, xs.data_ptr(), hi - lo, x.stride(0), ws.data_ptr(),
                                             self.num_bands, self.rows_per_band, self.dim, os_.data_ptr(),
                                             lists[ci].data_ptr(), cap, counts[ci:ci + 1].data_ptr(), tau, flags_ptr,
-                                            main.cuda_stream)
+                                            main.cuda_stream, flag_count=fcounts[ci:ci + 1])
                     split_flags.append(flag)
                     if flag is not None:
                         keep.append(flag)
@@ -374,6 +386,30 @@ class LSHHasher:
                         continue
                     landed.synchronize()
                     t1 = time.perf_counter()
+                    if native is not None:
+                        # decode + sgemv + layout in one native call, straight from / into pinned memory
+                        slot = ci & 1
+                        if slot_free[slot] is not None:
+                            slot_free[slot].synchronize()
+                        base = pin_patch[slot].data_ptr()
+                        m = native[0].resolve(native[1], pin_entries[slot].data_ptr(), cnt, pin_rows[slot].data_ptr(),
+                                              self.dim, base, base + 8 * pairs_cap, base + 12 * pairs_cap, pairs_cap)
+                        stats["tie_pairs"] += m
+                        t3 = time.perf_counter()
+                        used = 12 * pairs_cap + m * bb
+                        with torch.cuda.stream(side):
+                            dev_patch[slot, :used].copy_(pin_patch[slot, :used], non_blocking=True)
+                            dbase = dev_patch[slot].data_ptr()
+                            _native.check(
+                                lib.lshrs_scatter_band_keys_u8(out[lo:hi].data_ptr(), self.num_bands, bb, dbase,
+                                                               dbase + 8 * pairs_cap, dbase + 12 * pairs_cap, m,
+                                                               side.cuda_stream), "lshrs_scatter_band_keys_u8")
+                            slot_free[slot] = torch.cuda.Event()
+                            slot_free[slot].record(side)
+                        t4 = time.perf_counter()
+                        for key, dt in (("t_wait_ms", t1 - t0), ("t_patch_ms", t3 - t1), ("t_scatter_ms", t4 - t3)):
+                            stats[key] = stats.get(key, 0.0) + 1e3 * dt
+                        continue
                     entries = pin_entries[ci & 1, :cnt].numpy()
                     rows, bands, xindex = self._tie_pairs_indexed(entries)
                     stats["tie_pairs"] += int(rows.shape[0])
@@ -450,10 +486,17 @@ class LSHHasher:
         key = (dev.index, cap, window)
         buf = self._pinned_cache.get(key)
         if buf is None:
+            # patch staging (native resolve): per slot rows int64[pairs] | bands int32[pairs] | keys u8[pairs * bb];
+            # a 32-column word of the tie list touches up to 32 / (columns per band) bands
+            pairs_cap = (cap * max(1, 32 // (8 * self.band_bytes)) + 7) // 8 * 8
+            slot_bytes = (12 + self.band_bytes) * pairs_cap
             buf = (torch.empty((window,), dtype=torch.int32).pin_memory(),
                    torch.empty((2, cap, 2), dtype=torch.int64).pin_memory(),
                    torch.empty((2, cap, self.dim), dtype=torch.float32).pin_memory(),
-                   torch.empty((window,), dtype=torch.int32).pin_memory())
+                   torch.empty((window,), dtype=torch.int32).pin_memory(),
+                   torch.empty((2, slot_bytes), dtype=torch.uint8).pin_memory(),
+                   torch.empty((2, slot_bytes), dtype=torch.uint8, device=dev),
+                   pairs_cap)
             self._pinned_cache = {key: buf}
         return buf
 
@@ -464,7 +507,7 @@ class LSHHasher:
         return (int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) >= 256
                 and (self.num_bands * self.band_bytes) % 4 == 0)
 
-    def _launch_sig(self, torch, lib, dev, *args):
+    def _launch_sig(self, torch, lib, dev, *args, flag_count=None):
         """Enqueue one signature pass (args = the arguments of ``lshrs_sig_hash_batch_f32``).  Returns ``None``, or
         for the split-precision pass ``(flag_count tensor, flag_cap)`` — the caller must compare them once the
         stream has been synchronised and repeat the launch with a larger ``flag_cap`` on overflow."""
@@ -474,7 +517,8 @@ class LSHHasher:
         if split:
             cap = max(int(self._flag_cap_hint), n // 4 + 4096)
             flag_list = torch.empty((cap,), dtype=torch.int64, device=dev)
-            flag_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            if flag_count is None:   # (the pipelined path zeroes one counter per chunk in a single fill)
+                flag_count = torch.zeros(1, dtype=torch.int32, device=dev)
             flag = (flag_count, cap, flag_list)
             call = lambda: lib.lshrs_sig_hash_batch_split_f32(  # noqa: E731
                 *args[:-1], flag_list.data_ptr(), cap, flag_count.data_ptr(), float(self.tau1_ulps * _U), args[-1])
@@ -529,6 +573,18 @@ class LSHHasher:
         code = np.unique(np.concatenate(codes)) if codes else np.empty(0, dtype=np.int64)
         return (code & ((1 << 48) - 1)).astype(np.int64), (code >> 48).astype(np.int32)
 
+    def _tie_engine(self):
+        """(engine, planes) when the native host engine is usable for this hasher's shape, else None."""
+        eng = None if self.tie_threads == 1 else _hostblas.engine(self.tie_threads)
+        if eng is None:
+            return None
+        cached = self._host_planes_cache
+        if cached is None or cached[0] != self._projection_version:
+            cached = (self._projection_version,
+                      self._stacked().reshape(self.num_bands, self.rows_per_band, self.dim))
+            self._host_planes_cache = cached
+        return (eng, cached[1]) if eng.shape_trusted(cached[1]) else None
+
     def _tie_patches(self, xrows: np.ndarray, inverse: np.ndarray, bands: np.ndarray) -> np.ndarray:
         """Band keys of the flagged (row, band) pairs by the reference's own expression
         (``projection @ vector``, ``> 0``, ``np.packbits(..., bitorder='little')``: lsh.py:200-208).
@@ -536,13 +592,21 @@ class LSHHasher:
         ``np.matmul(P_band, X[:, :, None])`` runs NumPy's matrix @ vector inner loop once per row, i.e.
         it issues the very ``cblas_sgemv`` call ``P_band @ x`` issues (same operands, same shapes, same
         library) without a Python-level loop; tests/test_tiebreak_host.py checks the two bit for bit.
-        One sgemv of this size costs ~0.6 us and OpenBLAS serialises concurrent callers, so this stays
-        single-threaded.  ``bands`` arrives sorted, so each band is one contiguous slice.
+        One sgemv of this size costs ~0.9 us on one core; with ``tie_threads`` != 1 the pairs go to the
+        host engine instead (lshrs_amd/_hostblas.py: the same call from several threads, each through a private
+        mapping of NumPy's BLAS, self-checked bit for bit against ``P_band @ x`` per shape).
+        ``bands`` arrives sorted, so each band is one contiguous slice.
         """
         m = int(bands.shape[0])
         patch = np.empty((m, self.band_bytes), dtype=np.uint8)
         if m == 0:
             return patch
+        native = self._tie_engine()
+        if native is not None:
+            # the same cblas_sgemv, several cores at once (each worker owns a private mapping of NumPy's BLAS)
+            xr = xrows if (xrows.dtype == np.float32 and xrows.ndim == 2 and xrows.strides[1] == 4) \
+                else np.ascontiguousarray(xrows, dtype=np.float32)
+            return native[0].patch(native[1], xr, inverse, bands)
         planes = self._projections
         starts = np.flatnonzero(np.r_[True, bands[1:] != bands[:-1]])
         stops = np.r_[starts[1:], m]
@@ -638,11 +702,14 @@ class LSHHasher:
         state["_workspaces"] = {}
         state["_side_streams"] = {}
         state["_pinned_cache"] = {}
+        state["_host_planes_cache"] = None
         state["kernel_events"] = None
         state["_projections"] = list(self._projections)
         return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.setdefault("tie_threads", None)
+        self.__dict__.setdefault("_host_planes_cache", None)
         self._lock = threading.Lock()
         self._projections = _ProjectionList(state["_projections"], self)

@@ -43,6 +43,26 @@ def test_header_and_library_agree(lib):
     assert int(m.group(1)) == lib.lshrs_abi_version()
 
 
+def test_host_engine_header_and_library_agree():
+    """include/lshrs_host.h <-> lshrs_amd/_hostblas.py <-> liblshrs_host.so (plain C++, no HIP in it)."""
+    from lshrs_amd import _hostblas
+
+    _hostblas.build()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lshrs_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(lshrs_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(_hostblas.EXPORTS)
+    host = _hostblas.load()
+    assert host.lshrs_host_abi_version() == _hostblas.ABI_VERSION == int(
+        re.search(r"#define\s+LSHRS_HOST_ABI_VERSION\s+(\d+)", text).group(1))
+    out = subprocess.run(["nm", "-D", "--defined-only", _hostblas.LIBRARY], capture_output=True, text=True, check=True)
+    exported = {line.split()[-1] for line in out.stdout.splitlines() if " T " in line}
+    assert set(names) <= exported
+    needed = subprocess.run(["readelf", "-d", _hostblas.LIBRARY], capture_output=True, text=True, check=True).stdout
+    assert "amdhip" not in needed and "openblas" not in needed     # the BLAS is mapped at run time, from NumPy's own file
+    assert host.lshrs_tb_create(b"/nonexistent.so", b"cblas_sgemv", b"", 0, 2) is None
+    assert host.lshrs_tb_threads(None) == 0
+
+
 def test_exported_symbols_are_plain_c(lib):
     from lshrs_amd import _native
 

@@ -228,6 +228,7 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     x = torch.randn(300_000, 768, device="cuda", generator=gen)
     flags = torch.zeros(300_000, dtype=torch.uint8, device="cuda")
     x[123_456] = 0.0
+    h.pipeline_chunk_rows = 131_072                    # three chunks (the default, 262 144, would take the plain path)
     piped = h.hash_device(x, row_flags=flags)
     stats = dict(h.last_stats)
     assert stats["tie_pairs"] > 100 and stats["relaunches"] == 0
@@ -238,6 +239,15 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     assert h.last_stats["tie_pairs"] == stats["tie_pairs"]
     sl = slice(130_000, 134_096)                       # straddles a chunk boundary (131 072)
     assert np.array_equal(piped[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
+    # the same batch through the split-precision pass, pipelined (native host resolve) and NumPy-only tie-break
+    hs = _hasher(42, 16, 16, 768, precision="bf16x3")
+    hs.pipeline_chunk_rows = 131_072
+    assert torch.equal(hs.hash_device(x), piped)
+    assert hs.last_stats["tie_pairs"] == stats["tie_pairs"]
+    h1 = _hasher(42, 16, 16, 768, tie_threads=1)
+    h1.pipeline_chunk_rows = 131_072
+    assert torch.equal(h1.hash_device(x), piped)
+    assert h1.last_stats["tie_pairs"] == stats["tie_pairs"]
 
 
 def test_tie_list_overflow_is_recovered(torch_mod):

@@ -49,6 +49,60 @@ def test_batched_patches_equal_the_reference_expression(nb, r, dim):
 
 
 
+@pytest.mark.parametrize("threads", [1, 2, 5])
+def test_host_engine_and_numpy_path_give_the_same_bytes(threads):
+    """tie_threads=1 is NumPy's batched matmul; anything else is the native engine (private BLAS mappings, one per
+    worker).  Both must equal `P_band @ x` bit for bit — keys AND projections."""
+    from lshrs_amd import _hostblas
+
+    nb, r, dim = 16, 16, 768
+    rng = np.random.default_rng(threads)
+    xrows = rng.standard_normal((300, dim)).astype(np.float32)
+    m = 3000                                          # enough pairs for the engine to fan out
+    inverse = rng.integers(0, 300, size=m).astype(np.int32)
+    bands = np.sort(rng.integers(0, nb, size=m)).astype(np.int32)
+    ref = LSHHasher(nb, r, dim, seed=3, tie_threads=1)._tie_patches(xrows, inverse, bands)
+    if threads == 1:
+        got = ref
+    else:
+        eng = _hostblas.TieBreakEngine(threads)
+        try:
+            assert eng.threads == threads
+            planes = np.stack(LSHHasher(nb, r, dim, seed=3).projections)
+            assert eng.shape_trusted(planes)
+            got, y = eng.patch(planes, xrows, inverse, bands, want_y=True)
+            for t in range(0, m, 97):
+                want = planes[bands[t]] @ xrows[inverse[t]]
+                assert np.array_equal(want.view(np.uint32), y[t].view(np.uint32))
+        finally:
+            eng.close()
+    assert np.array_equal(got, ref)
+    for t in range(0, m, 41):
+        assert got[t].tobytes() == project_and_pack(np.stack(LSHHasher(nb, r, dim, seed=3).projections)[bands[t]],
+                                                    xrows[inverse[t]])
+
+
+def test_host_engine_rejects_bad_pairs_and_handles_strided_rows():
+    from lshrs_amd import _hostblas
+
+    eng = _hostblas.engine()
+    if eng is None:
+        pytest.skip("single-core host: the engine is not used")
+    planes = np.random.default_rng(0).standard_normal((3, 9, 40)).astype(np.float32)
+    wide = np.random.default_rng(1).standard_normal((10, 64)).astype(np.float32)
+    xs = wide[:, :40]                                  # row stride 64 floats
+    rows = np.array([0, 9, 4], dtype=np.int32)
+    bands = np.array([0, 1, 2], dtype=np.int32)
+    keys = eng.patch(planes, xs, rows, bands)
+    for t in range(3):
+        assert keys[t].tobytes() == project_and_pack(planes[bands[t]], np.ascontiguousarray(xs[rows[t]]))
+    with pytest.raises(IndexError):
+        eng.patch(planes, xs, np.array([10], dtype=np.int32), np.array([0], dtype=np.int32))
+    with pytest.raises(ValueError):
+        eng.patch(planes, xs, np.array([1], dtype=np.int32), np.array([3], dtype=np.int32))
+    assert eng.patch(planes, xs, rows[:0], bands[:0]).shape == (0, 2)
+
+
 @pytest.mark.parametrize("nb,r", [(16, 16), (16, 4), (16, 32), (5, 12), (2, 24), (4, 64)])
 def test_indexed_pairs_agree_with_plain_pairs(nb, r):
     h = LSHHasher(nb, r, 32, seed=1)

@@ -17,7 +17,7 @@ for (nb, r, dim, n, seed) in [(16, 16, 768, 1_000_000, 42), (16, 32, 1536, 1_000
             a.record(); h.hash_device(x, out=out, tie_break="none"); b.record(); torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         raw = sorted(ts)[5]
-        h.pipeline_chunk_rows = 131072
+        h.pipeline_chunk_rows = 262144
         for _ in range(2): h.hash_device(x, out=out)
         t = time.perf_counter()
         for _ in range(5): h.hash_device(x, out=out)
