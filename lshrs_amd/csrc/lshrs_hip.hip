@@ -40,6 +40,7 @@ constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
 int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
 int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles with fragment prefetch
 unsigned long long* g_clock_probe = nullptr;  // diagnostics only (lshrs_debug_set_clock_probe)
+hipEvent_t g_split_mid_event = nullptr;       // diagnostics only: recorded once between stage 1 and stage 2
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
@@ -1349,6 +1350,11 @@ int lshrs_debug_set_clock_probe(void* device_buffer) {
   g_clock_probe = static_cast<unsigned long long*>(device_buffer);
   return 0;
 }
+int lshrs_debug_set_split_mid_event(void* event) {
+  g_split_mid_event = static_cast<hipEvent_t>(event);
+  return 0;
+}
+
 int lshrs_debug_set_sig_fine(int f) {
   if (f < 0 || f > 2) return LSHRS_E_BADARG;
   g_sig_fine = f;
@@ -1508,6 +1514,10 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
     hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
+  }
+  if (g_split_mid_event != nullptr) {   // bench.py times stage 1 alone with it
+    (void)hipEventRecord(g_split_mid_event, s);
+    g_split_mid_event = nullptr;
   }
   // stage 2: exact f32 chain for the flagged projections
   FixArgs f{};

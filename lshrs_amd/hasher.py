@@ -17,6 +17,7 @@ raw kernel bits; ``last_stats`` records how many pairs were touched.
 
 from __future__ import annotations
 
+import ctypes
 import threading
 import time
 from typing import Dict, List, Optional, Tuple
@@ -87,12 +88,18 @@ class LSHHasher:
                   projection differ by at most 1.2 of those units (rms 0.3) and every sign disagreement
                   had |y| <= 0.41; tests/test_gpu_signature.py re-checks the margin on the box it runs on.
                   Raise it (e.g. 2*dim for the deterministic worst-case bound) for adversarial inputs.
-      precision   "f32" (default) or "bf16x3" (split-precision first pass for batches >= 65 536 rows; same keys)
+      precision   "bf16x3" (default): batches >= 65 536 rows whose shape allows it (dim % 32 == 0, >= 256 key
+                  columns, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass — bf16 matrix
+                  cores, then the exact f32 chain for every projection inside the stage-1 window — everything
+                  else the f32 kernel; the keys are the same either way.  "f32": always the f32 kernel.
+      tau1_ulps   stage-1 window of the split pass, in the units of tau_ulps.  Default 256; the largest deviation
+                  observed over 2.7e9 projections of six data distributions stayed below 16
+                  (profiles/r01_split_window_margin.log).
       tau1_ulps   stage-1 window of the bf16x3 pass, same unit; must stay >= 192 + the f32 rounding allowance
     """
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
-                 tie_break: str = "host", tau_ulps: float = 8.0, precision: str = "f32",
+                 tie_break: str = "host", tau_ulps: float = 8.0, precision: str = "bf16x3",
                  tau1_ulps: float = 256.0, tie_threads: Optional[int] = None) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
@@ -110,7 +117,7 @@ class LSHHasher:
         self.dim = int(dim)
         self.tie_break = tie_break
         self.tau_ulps = float(tau_ulps)
-        # "bf16x3": large batches take the split-precision first pass (bf16 matrix cores, ~3x the rate) followed by
+        # "bf16x3": large batches take the split-precision first pass (bf16 matrix cores, >2x the rate) followed by
         # the exact f32 chain for every projection inside the stage-1 window; same keys as "f32" 
         self.precision = precision
         self.tau1_ulps = float(tau1_ulps)
@@ -121,6 +128,7 @@ class LSHHasher:
             raise ValueError("tie_threads must be >= 1")
         self.tie_threads = None if tie_threads is None else int(tie_threads)
         self._host_planes_cache: Optional[Tuple[int, np.ndarray]] = None
+        self._split_range_ok: Optional[Tuple[int, bool]] = None
         self._device = device
         self._lock = threading.Lock()
         self._projection_version = 0
@@ -501,11 +509,22 @@ class LSHHasher:
         return buf
 
     def _split_applies(self, n: int) -> bool:
-        if self.precision != "bf16x3" or n < self.split_min_rows:
+        if self.precision != "bf16x3" or n < self.split_min_rows or self.dim % 32 != 0:
             return False
         lib = _native.load()
-        return (int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) >= 256
-                and (self.num_bands * self.band_bytes) % 4 == 0)
+        if (int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) < 256
+                or (self.num_bands * self.band_bytes) % 4 != 0):
+            return False
+        # hyperplanes far outside the unit scale (user-assigned matrices) leave the range in which the bf16 split
+        # and the window arithmetic are safe from under/overflow: those hashers keep the f32 kernel
+        cached = self._split_range_ok
+        if cached is None or cached[0] != self._projection_version:
+            norms = np.sqrt((self._stacked().astype(np.float64) ** 2).sum(axis=1))
+            live = norms[norms > 0]
+            ok = bool(np.isfinite(norms).all() and (live.size == 0 or (live.min() >= 2.0 ** -40 and live.max() <= 2.0 ** 40)))
+            cached = (self._projection_version, ok)
+            self._split_range_ok = cached
+        return cached[1]
 
     def _launch_sig(self, torch, lib, dev, *args, flag_count=None):
         """Enqueue one signature pass (args = the arguments of ``lshrs_sig_hash_batch_f32``).  Returns ``None``, or
@@ -532,10 +551,15 @@ class LSHHasher:
             return flag
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cur = torch.cuda.current_stream(dev)
+        mid = None
+        if split and hasattr(lib, "lshrs_debug_set_split_mid_event"):
+            mid = torch.cuda.Event(enable_timing=True)
+            mid.record(cur)                      # creates the handle; the library re-records it after stage 1
+            lib.lshrs_debug_set_split_mid_event(ctypes.c_void_p(mid.cuda_event))
         start.record(cur)
         _native.check(call(), name)
         end.record(cur)
-        events.append((start, end, n))
+        events.append((start, end, n, mid))      # split pass: start..mid = stage 1, mid..end = exact fix-up
         return flag
 
     def _flag_overflow(self, flag) -> bool:
@@ -711,5 +735,6 @@ class LSHHasher:
         self.__dict__.update(state)
         self.__dict__.setdefault("tie_threads", None)
         self.__dict__.setdefault("_host_planes_cache", None)
+        self.__dict__.setdefault("_split_range_ok", None)
         self._lock = threading.Lock()
         self._projections = _ProjectionList(state["_projections"], self)

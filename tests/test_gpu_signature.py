@@ -239,8 +239,9 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     assert h.last_stats["tie_pairs"] == stats["tie_pairs"]
     sl = slice(130_000, 134_096)                       # straddles a chunk boundary (131 072)
     assert np.array_equal(piped[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
-    # the same batch through the split-precision pass, pipelined (native host resolve) and NumPy-only tie-break
-    hs = _hasher(42, 16, 16, 768, precision="bf16x3")
+    # the same batch through the f32 kernel (the default took the split-precision pass), and with the NumPy-only tie-break
+    assert h._split_applies(131_072)
+    hs = _hasher(42, 16, 16, 768, precision="f32")
     hs.pipeline_chunk_rows = 131_072
     assert torch.equal(hs.hash_device(x), piped)
     assert hs.last_stats["tie_pairs"] == stats["tie_pairs"]
@@ -326,8 +327,9 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
     from oracle.build import chain_hash_packed
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
-    for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 70_000), (3, 32, 8, 100, 70_001)):
-        h32 = _hasher(seed, nb, r, dim)
+    for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 70_000), (3, 32, 8, 96, 70_001),
+                                 (3, 32, 8, 100, 70_001)):     # dim % 32 != 0: the f32 kernel takes over
+        h32 = _hasher(seed, nb, r, dim, precision="f32")
         hs = _hasher(seed, nb, r, dim, precision="bf16x3")
         gen = torch.Generator("cuda").manual_seed(seed + 5)
         x = torch.randn(n, dim, device="cuda", generator=gen)
@@ -336,7 +338,7 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
         flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
         raw_split = hs.hash_device(x, tie_break="none", row_flags=flags)
         raw_f32 = h32.hash_device(x, tie_break="none")
-        assert hs._split_applies(n)
+        assert hs._split_applies(n) == (dim % 32 == 0)
         assert torch.equal(raw_split, raw_f32), f"{int((raw_split != raw_f32).sum())} key bytes differ"
         assert flags[7].item() == 1 and flags[9].item() == 2 and int(flags.sum()) == 3
         sl = slice(n - 3000, n)                               # includes a partial 256-row workgroup
@@ -351,4 +353,4 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
     x = torch.randn(70_000, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
     got = hs.hash_device(x, tie_break="none")
     assert hs.last_stats["relaunches"] > 0
-    assert torch.equal(got, _hasher(42, 16, 16, 768).hash_device(x, tie_break="none"))
+    assert torch.equal(got, _hasher(42, 16, 16, 768, precision="f32").hash_device(x, tie_break="none"))

@@ -8,7 +8,7 @@ from lshrs_amd import LSHHasher, _native
 lib = _native.load()
 lib.lshrs_debug_set_clock_probe.argtypes = [ctypes.c_void_p]
 n = 983040  # 15 full rounds of the 128-row workgroups
-h = LSHHasher(16, 16, 768); h.pipeline_chunk_rows = 10**9
+h = LSHHasher(16, 16, 768, precision="f32"); h.pipeline_chunk_rows = 10**9
 x = torch.randn(n, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
 out = torch.empty((n, 16, 2), dtype=torch.uint8, device="cuda")
 mfma_cycles = 24 * 128 * 64               # per wave-tile, NT=8, dim 768

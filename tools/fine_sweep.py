@@ -6,7 +6,7 @@ import torch
 from lshrs_amd import LSHHasher, _native
 lib = _native.load()
 for (nb, r, dim) in [(16, 16, 768), (16, 32, 1536)]:
-    h = LSHHasher(nb, r, dim); h.pipeline_chunk_rows = 10**9
+    h = LSHHasher(nb, r, dim, precision="f32"); h.pipeline_chunk_rows = 10**9
     xall = torch.randn(1_000_000 if dim == 768 else 400_000, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
     for n in (1, 32, 128, 1024, 4096, 8192, 16384, 24576, 32768, 36864, 40960, 49152, 57344, 65536, 16960 + 983040 if dim == 768 else 131072 + 20000):
         x = xall[:n]; out = torch.empty((n, nb, h.band_bytes), dtype=torch.uint8, device="cuda")

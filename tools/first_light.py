@@ -26,7 +26,7 @@ def time_variants(h, x, out, variants, rounds=6):
     return {v: (sorted(t)[len(t)//2], min(t)) for v, t in res.items()}
 
 for (nb, r, dim, n, seed) in [(16,16,768,1_000_000,42), (16,32,1536,1_000_000,7), (16,4,128,1_000_000,42)]:
-    h = LSHHasher(nb, r, dim, seed=seed)
+    h = LSHHasher(nb, r, dim, seed=seed, precision="f32")
     h.pipeline_chunk_rows = 10**9   # single launch: this tool times the kernel itself
     x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
     out = torch.empty((n, nb, h.band_bytes), dtype=torch.uint8, device="cuda")

@@ -8,15 +8,16 @@ from lshrs_amd import LSHHasher
 from lshrs_amd.similarity import cosine_scores_device, topk_desc_device
 
 n, dim = 1_000_000, 768
-h = LSHHasher(16, 16, dim, seed=42)
 g = torch.Generator("cuda").manual_seed(1000)
 x = torch.randn(n, dim, device="cuda", generator=g)
 keys = torch.empty((n, 16, 2), dtype=torch.uint8, device="cuda")
-h.pipeline_chunk_rows = 10**9           # one launch per pass: per-dispatch counters cover the whole 1M rows
-for _ in range(3):
-    h.hash_device(x, out=keys, tie_break="none")     # sig_kernel MODE 0
-for _ in range(3):
-    h.hash_device(x, out=keys)                       # sig_kernel MODE 1 (+ tie-break)
+for prec in ("f32", "bf16x3"):          # the f32 kernel, and the split-precision pass (stage 1 + sig_fix_kernel)
+    h = LSHHasher(16, 16, dim, seed=42, precision=prec)
+    h.pipeline_chunk_rows = 10**9       # one launch per pass: per-dispatch counters cover the whole 1M rows
+    for _ in range(3):
+        h.hash_device(x, out=keys, tie_break="none")     # MODE 0 (f32) / MODE 1 with the stage-1 list (split)
+    for _ in range(3):
+        h.hash_device(x, out=keys)                       # MODE 1 (+ tie-break)
 y = torch.empty_like(x)
 for _ in range(3):
     y.copy_(x)                                       # calibration: reads 3.072e9 B, writes 3.072e9 B

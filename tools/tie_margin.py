@@ -8,7 +8,7 @@ from lshrs_amd import LSHHasher
 
 U = 2.0 ** -24
 for (nb, r, dim, seed, n) in [(16, 16, 768, 42, 400_000), (16, 32, 1536, 7, 100_000), (16, 4, 128, 42, 400_000)]:
-    h = LSHHasher(nb, r, dim, seed=seed)
+    h = LSHHasher(nb, r, dim, seed=seed, precision="f32")
     rng = np.random.default_rng(5)
     for kind in ("gauss", "positive", "sparse"):
         x = rng.standard_normal((n, dim)).astype(np.float32)
