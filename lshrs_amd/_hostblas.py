@@ -112,14 +112,35 @@ def numpy_blas() -> Optional[Tuple[str, str, int, str]]:
     return None
 
 
-def default_threads() -> int:
-    """Worker count: this process's share of the cores (ranks of one node divide them), at most 8."""
+def _core_budget() -> int:
+    """Cores this process may actually burn: the affinity mask, capped by the cgroup CPU quota (a container on a
+    256-core host often sees all 256 in its mask but is throttled beyond 16)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:  # pragma: no cover
         cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            fields = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    cores = min(cores, max(1, int(fields[0]) // int(fields[1])))
+            else:
+                quota = int(fields[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    cores = min(cores, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return cores
+
+
+def default_threads() -> int:
+    """Worker count: half of this process's share of the core budget (the ranks of one node divide it; the workers
+    poll between chunks, and the Python thread, the HIP runtime and NumPy need cores too), at most 8."""
     ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    return max(1, min(8, cores // ranks))
+    return max(1, min(8, _core_budget() // ranks // 2))
 
 
 class TieBreakEngine:

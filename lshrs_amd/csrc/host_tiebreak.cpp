@@ -27,6 +27,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -123,7 +124,7 @@ void worker_main(Engine* e, int t) {
   for (;;) {
     // Chunks of one batch arrive a few hundred microseconds apart: poll for that long before going to sleep, a
     // condition-variable wake-up alone costs as much as the work of a small chunk.
-    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(250);
     while (e->gen_atomic.load(std::memory_order_acquire) == seen && !e->stop_atomic.load(std::memory_order_relaxed) &&
            std::chrono::steady_clock::now() < spin_until)
       __builtin_ia32_pause();
@@ -193,6 +194,19 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
   if (blas_path == nullptr || sgemv_symbol == nullptr || n_threads < 1 || n_threads > 64) return nullptr;
   Engine* e = new Engine();
   e->ilp64 = ilp64 ? 1 : 0;
+  // OpenBLAS starts a pool of (cores - 1) busy-waiting threads when it is LOADED.  Eight copies on a 256-core
+  // host are ~500 spinning threads for the first tenth of a second - enough to exhaust a container's CPU quota
+  // and get the whole process throttled (measured: 300-480 ms stalls in the first hashing steps).  The copies are
+  // only ever called from one thread each, so they are loaded with the thread count pinned to 1: no pools at all.
+  static const char* const kThreadVars[] = {"OPENBLAS_NUM_THREADS", "GOTO_NUM_THREADS", "OMP_NUM_THREADS"};
+  std::string saved[3];
+  bool had[3];
+  for (int v = 0; v < 3; ++v) {
+    const char* cur = getenv(kThreadVars[v]);
+    had[v] = cur != nullptr;
+    if (had[v]) saved[v] = cur;
+    setenv(kThreadVars[v], "1", 1);
+  }
   for (int t = 0; t < n_threads; ++t) {
     int fd = -1;
     void* h = map_private_copy(blas_path, &fd);
@@ -209,6 +223,10 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
     e->handles.push_back(h);
     e->sgemv.push_back(fn);
     e->fds.push_back(fd);
+  }
+  for (int v = 0; v < 3; ++v) {
+    if (had[v]) setenv(kThreadVars[v], saved[v].c_str(), 1);
+    else unsetenv(kThreadVars[v]);
   }
   if (e->handles.empty()) {
     delete e;

@@ -40,6 +40,7 @@ constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
 int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
 int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles with fragment prefetch
 unsigned long long* g_clock_probe = nullptr;  // diagnostics only (lshrs_debug_set_clock_probe)
+int g_split_m = 2;                // row tiles per wave of the split pass (lshrs_debug_set_split_m)
 hipEvent_t g_split_mid_event = nullptr;       // diagnostics only: recorded once between stage 1 and stage 2
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
@@ -347,6 +348,11 @@ __device__ __forceinline__ void split_bf16(const f32x4& lo4, const f32x4& hi4, b
   }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // Stage-1 flag: NOT (|y| > bound) — also true for a NaN y, so a projection that overflowed in bf16 is re-evaluated.
 __device__ __forceinline__ void deposit_not_above(uint32_t& word, float y, float bound, int lane_lo, int lane_hi) {
   asm("v_cmp_ngt_f32 vcc, |%1|, %2\n\t"
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kHalfFloats = NT * 2 * kFragFloats;
   // LDS staging: PIPE 0 two whole tiles, PIPE 1 ring of three halves, PIPE 3 ring of four (fragment half + x half) stages
-  constexpr int kStageFloats = PIPE == 3 ? 4 * (kHalfFloats + W * M * 2 * kFragFloats)
+  constexpr int kStageFloats = PIPE == 3 ? (M == 2 ? 4 : 3) * (kHalfFloats + W * M * 2 * kFragFloats)
                                          : (PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats);
   constexpr int kWaveRows = kRowsPerWave * M;
   constexpr int kBlockRows = W * kWaveRows;
@@ -447,7 +453,13 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     // either compiler-tracked loads, which hipcc waits for with vmcnt(0), or asm outputs, which the register
     // allocator is free to copy or reuse while the load is still in flight.)
     // One wave per SIMD means nobody else hides memory latency: ring of FOUR stages, prefetch three ahead.
-    static_assert(!SPLIT || (ALIGNED && NT == 8 && M == 2 && W == 4), "the split pass is built for this geometry");
+    static_assert(!SPLIT || (ALIGNED && NT == 8 && W == 4), "the split pass is built for this geometry");
+    // M = 2: 256-row workgroups, one per CU (512 registers per lane), ring of four 32 KiB stages.
+    // M = 1: 128-row workgroups, two per CU (256 registers), ring of three 24 KiB stages: a second, independent
+    //        workgroup on every SIMD fills the other's barrier waits, VALU slices and epilogue with MFMAs.
+    constexpr int kRing = M == 2 ? 4 : 3;          // stages in LDS; prefetch distance kRing - 1
+    constexpr int kDma = 4 + 2 * M;                // DMAs per thread and stage: 4 fragment blocks + 2*M x pieces
+    constexpr int kQuarter = 12 * M;               // MFMAs per quarter (4 column tiles x M row tiles x 3 terms)
     constexpr int kXHalfFloats = W * M * 2 * kFragFloats;
     constexpr int kStage = kHalfFloats + kXHalfFloats;
     const int halves = 2 * ktiles;
@@ -474,9 +486,13 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     }
 #pragma unroll
     for (int mt = 0; mt < M; ++mt) { xo[mt][0] = xoff[mt]; xo[mt][1] = xoff[mt] + 16u; }
+    if (LSHRS_SPLIT_PROBE & 32) {   // timing probe: fully coalesced x DMAs (wrong data)
+#pragma unroll
+      for (int mt = 0; mt < M; ++mt) { xo[mt][0] = lane * 16u + mt * 2048u; xo[mt][1] = lane * 16u + mt * 2048u + 1024u; }
+    }
     auto issue_half = [&](int hh) {       // exactly 8 DMAs per thread: 4 fragment blocks + 2*M x pieces of half min(hh, lasth)
       const int c = hh < lasth ? hh : lasth;
-      float* st = lds + (hh & 3) * kStage;
+      float* st = lds + (hh % kRing) * kStage;
       const char* pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
                                            (LDS_AS void*)(xl + (mt * 2 + pc) * kFragFloats), 16, 0, 0);
     };
     auto read_x = [&](int hh, f32x4 (&v)[2][M]) {
-      const float* xl = lds + (hh & 3) * kStage + kHalfFloats + wave_u * (M * 2 * kFragFloats) + lane * 4;
+      const float* xl = lds + (hh % kRing) * kStage + kHalfFloats + wave_u * (M * 2 * kFragFloats) + lane * 4;
 #pragma unroll
       for (int mt = 0; mt < M; ++mt)
 #pragma unroll
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     };
     // MFMA number k (0..23) of a quarter: column tile j0 + k/6, row tile (k/3)%2, term k%3 of xh*ph + xh*pm + xm*ph
     auto mfma_one = [&](int j0, int k, const f32x4 (&f)[4][2], const Bf16Pairs (&hi)[M], const Bf16Pairs (&mid)[M]) {
-      const int j = k / 6, mt = (k / 3) % 2, term = k % 3;
+      const int j = k / (3 * M), mt = (k / 3) % M, term = k % 3;
       const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[mt] : hi[mt]);
       const bf16x8 bb = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
       acc[mt][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[mt][j0 + j], 0, 0, 0);
@@ -548,32 +564,33 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     Bf16Pairs ahx[M], amx[M], ahy[M], amy[M];   // bf16 x of the previous / current stage, ping-pong (no copies)
     auto stage = [&](int hh, const bool first, const Bf16Pairs (&ahp)[M], const Bf16Pairs (&amp)[M],
                      Bf16Pairs (&ahc)[M], Bf16Pairs (&amc)[M]) {
-      const float* st = lds + (hh & 3) * kStage;
-      read_quarter(st, 0, fa);
+      const float* st = lds + (hh % kRing) * kStage;
+      if (!(LSHRS_SPLIT_PROBE & 1)) read_quarter(st, 0, fa);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 0; k < 24; ++k) {
+      for (int k = 0; k < kQuarter; ++k) {
         if (!first) mfma_one(4, k, fb, ahp, amp);
-        split_step(k / 3, k % 3, xr, ahc, amc);
+        if (!(LSHRS_SPLIT_PROBE & 2)) split_step(k / 3, k % 3, xr, ahc, amc);
         __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): A(hh), a whole group old
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's DMAs of stage hh+1 have landed (hh+2 pending)
-      read_quarter(st, 4, fb);
-      read_x(hh + 1, xr);
+      wait_vmcnt<(kRing - 3) * kDma>();          // this wave's DMAs of stage hh+1 have landed (later stages pending)
+      if (!(LSHRS_SPLIT_PROBE & 1)) read_quarter(st, 4, fb);
+      if (!(LSHRS_SPLIT_PROBE & 16)) read_x(hh + 1, xr);
       __builtin_amdgcn_sched_barrier(0);
       {
-        const int c = hh + 3 < lasth ? hh + 3 : lasth;
-        float* nst = lds + ((hh + 3) & 3) * kStage;       // the slot of stage hh-1, which every wave has left
+        const int nh = hh + kRing - 1;
+        const int c = nh < lasth ? nh : lasth;
+        float* nst = lds + (nh % kRing) * kStage;         // the slot of stage hh-1, which every wave has left
         const char* pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
         float* xl = nst + kHalfFloats + wave_u * (M * 2 * kFragFloats);
         const char* xg = xblk + (size_t)c * 64;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) {
+        for (int k = 0; k < kQuarter; ++k) {
           mfma_one(0, k, fa, ahc, amc);
-          if (k % 3 == 0) {                     // one of the 8 DMAs of stage hh+3 every third MFMA
-            const int d = k / 3;
+          if (!(LSHRS_SPLIT_PROBE & 4) && k % (kQuarter / kDma) == 0) {     // the kDma DMAs of stage hh+kRing-1, spread over the quarter
+            const int d = k / (kQuarter / kDma);
             if (d < 4)
               __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + poff[d]),
                                                (LDS_AS void*)(nst + (4 * d + wave_u) * kFragFloats), 16, 0, 0);
@@ -587,12 +604,11 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);       // B(hh) and x(hh+1): a whole group old
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();             // everybody's stage hh+1 is in LDS, everybody holds B(hh) in registers
+      if (!(LSHRS_SPLIT_PROBE & 8)) __builtin_amdgcn_s_barrier();             // everybody's stage hh+1 is in LDS, everybody holds B(hh) in registers
     };
-    issue_half(0);
-    issue_half(1);
-    issue_half(2);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // stage 0 has landed, stages 1 and 2 stay in flight
+#pragma unroll
+    for (int pre = 0; pre < kRing - 1; ++pre) issue_half(pre);
+    wait_vmcnt<(kRing - 2) * kDma>();            // stage 0 has landed, the later ones stay in flight
     __builtin_amdgcn_s_barrier();
     read_x(0, xr);
     stage(0, true, ahx, amx, ahy, amy);
@@ -603,7 +619,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     }
     stage(hh, false, ahy, amy, ahx, amx);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) mfma_one(4, k, fb, ahx, amx);
+    for (int k = 0; k < kQuarter; ++k) mfma_one(4, k, fb, ahx, amx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the last stage must land before exit
     __builtin_amdgcn_s_barrier();
   } else if (PIPE == 1) {
@@ -1350,6 +1366,12 @@ int lshrs_debug_set_clock_probe(void* device_buffer) {
   g_clock_probe = static_cast<unsigned long long*>(device_buffer);
   return 0;
 }
+int lshrs_debug_set_split_m(int m) {
+  if (m != 1 && m != 2) return LSHRS_E_BADARG;
+  g_split_m = m;
+  return 0;
+}
+
 int lshrs_debug_set_split_mid_event(void* event) {
   g_split_mid_event = static_cast<hipEvent_t>(event);
   return 0;
@@ -1510,10 +1532,14 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   a.tau = tau1;
   a.row_flags = row_flags;
   a.clock_probe = g_clock_probe;
-  {
-    constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles
+  if (g_split_m == 2) {
+    constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles, one workgroup per CU
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
     hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
+  } else {
+    constexpr int kRows = 4 * kRowsPerWave;      // W = 4 waves x one 32-row tile, two workgroups per CU
+    const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
+    hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 1>), grid, block, 0, s, a);
   }
   if (g_split_mid_event != nullptr) {   // bench.py times stage 1 alone with it
     (void)hipEventRecord(g_split_mid_event, s);

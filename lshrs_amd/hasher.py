@@ -318,6 +318,11 @@ class LSHHasher:
         cap = ch // 32 + 1024    # tie entries per chunk (measured: ~0.25 % of the rows at tau_ulps = 8); more -> plain path
         window = 16
         spans = [(lo, min(n, lo + ch)) for lo in range(0, n, ch)]
+        # nothing overlaps the host work of the LAST chunk: keep it small (one full-chip round of the kernel)
+        tail = 65_536
+        if spans[-1][1] - spans[-1][0] >= 2 * tail:
+            lo, hi = spans.pop()
+            spans += [(lo, hi - tail), (hi - tail, hi)]
         overflow = []
         keep = []  # device temporaries stay referenced until the streams have been joined
         with torch.cuda.device(dev):
