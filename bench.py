@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rerank", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the (untimed) parity check against the oracle")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed single-launch extras (kernel_only, roofline_f32_kernel): under rocprofv3 every "
+                         "signature-kernel launch of the process is then a pipeline chunk, like the timed ones")
     ap.add_argument("--backend", default=os.environ.get("LSHRS_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals on one GPU)")
     return ap.parse_args()
@@ -136,7 +139,7 @@ def main() -> None:
     # raw-kernel-only pass of the same workload (not the headline value; reported beside it), and the exact-f32
     # kernel of precision="f32" on the same batch (one launch) for its own roofline
     raw_ms = f32_ms = None
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         def median_ms(h, reps=5):
             h.pipeline_chunk_rows = 10**9
             ev = []
@@ -235,7 +238,7 @@ def main() -> None:
                 "precision": hasher.precision, "tau1_ulps": hasher.tau1_ulps, "pipeline_chunk_rows": hasher.pipeline_chunk_rows,
             },
             "roofline": roofline,
-            "roofline_f32_kernel": {
+            "roofline_f32_kernel": None if f32_ms is None else {
                 "kernel": "sig_kernel<NT=8, ALIGNED, MODE=0, W=4> (precision='f32', one launch of the whole batch)",
                 "bound": "mfma", "achieved": 2.0 * DIM * NUM_PERM * n / (f32_ms * 1e-3) / 1e12,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

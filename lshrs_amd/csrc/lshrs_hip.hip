@@ -904,32 +904,6 @@ struct FixArgs {
   float tau;
 };
 
-template <bool ALIGNED>
-__device__ __forceinline__ void fix_load_tile(const float* __restrict__ tile, const float* __restrict__ x, int kt, int c,
-                                              int dim, f32x4 (&p4)[2][4], f32x4 (&x4)[2][4]) {
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      p4[hh][q] = *reinterpret_cast<const f32x4*>(tile + ((q * 64) + hh * 32 + c) * 4);
-      const int k = kt * kKTile + 16 * hh + 4 * q;
-      // loads are unconditional (clamped address) and masked afterwards: a load under a branch is followed by a
-      // vmcnt(0), which turned the 16 loads of a tile into 16 serial round trips
-      if (ALIGNED) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (k < dim ? k : 0));
-        x4[hh][q] = k < dim ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      } else {
-        f32x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = x[k + r < dim ? k + r : 0];
-          v[r] = (k + r < dim) ? t : 0.f;
-        }
-        x4[hh][q] = v;
-      }
-    }
-}
-
 __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f32x4 (&x4)[2][4], float& acc, float& ss) {
 #pragma unroll
   for (int sstep = 0; sstep < 16; ++sstep) {
@@ -941,38 +915,74 @@ __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f3
   }
 }
 
-// Every thread walks its own (row, column) pair, so a wave's loads are fully divergent and the chain is pure
-// latency: kFixItemsPerWave lanes per wave keep each load instruction to a handful of cache lines and spread the
-// few thousand flagged projections of a launch over every CU (one full wave per 64 of them used 9 CUs).
-constexpr int kFixItemsPerWave = 8;
-template <bool ALIGNED>
+// Stage 2 of the split-precision pass: the exact f32 chain for every flagged projection.  One WAVE per projection:
+// the 64 lanes fetch the row of x (coalesced) and the column of the f32 hyperplane image (one 16-byte fragment
+// chunk per lane and load) into LDS together, then every lane runs the same serial chain from broadcast LDS reads
+// (the chain cannot be split across lanes: its rounding is the canonical k order).  A thread per projection
+// instead walks 12 latency-bound batches of fully divergent loads (53 us per 260k-row chunk; this: ~10 us).
+// The grid is a fixed number of workgroups that stride over the list (its length is only known on the device).
+constexpr int kFixSlabTiles = 32;   // k-tiles staged per pass: 1024 k = 8 KiB of LDS per wave
+constexpr int kFixGrid = 5120;      // 256 CUs x 20 resident single-wave workgroups (8 KiB of LDS each)
 __global__ __launch_bounds__(64) void sig_fix_kernel(const FixArgs a) {
-  if ((int)threadIdx.x >= kFixItemsPerWave) return;
-  const int64_t e = (int64_t)blockIdx.x * kFixItemsPerWave + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float xs[kFixSlabTiles * kKTile];
+  __shared__ __attribute__((aligned(16))) float ps[kFixSlabTiles * kKTile];
+  const int lane = threadIdx.x;
   const int cnt = min(*a.flag_count, a.flag_cap);
-  if (e >= cnt) return;
-  const int64_t item = a.flag_list[e];
-  const int64_t row = item >> 21;                 // relative to this launch's X / keys
-  const int col = (int)(item & ((1 << 21) - 1));
-  if (col >= a.padcols) return;
-  const int word = col >> 5, c = col & 31;
-  const float* __restrict__ x = a.X + row * a.ldx;
-  const int cb = word / a.nt, jt = word % a.nt;
-  const float* __restrict__ img = a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats;
   const size_t kt_stride = (size_t)a.nt * 4 * kFragFloats;
-  float acc = 0.f, ss = 0.f;
-  f32x4 pa[2][4], xa[2][4], pb[2][4], xb[2][4];
-  int kt = 0;
-  for (; kt + 1 < a.ktiles; kt += 2) {            // two k-tiles of loads in flight per thread
-    fix_load_tile<ALIGNED>(img + kt * kt_stride, x, kt, c, a.dim, pa, xa);
-    fix_load_tile<ALIGNED>(img + (kt + 1) * kt_stride, x, kt + 1, c, a.dim, pb, xb);
-    fix_chain_tile(pa, xa, acc, ss);
-    fix_chain_tile(pb, xb, acc, ss);
-  }
-  if (kt < a.ktiles) {
-    fix_load_tile<ALIGNED>(img + kt * kt_stride, x, kt, c, a.dim, pa, xa);
-    fix_chain_tile(pa, xa, acc, ss);
-  }
+  for (int64_t e = blockIdx.x; e < cnt; e += gridDim.x) {   // uniform per wave: every wave reaches the end
+    const int64_t item = a.flag_list[e];
+    const int64_t row = item >> 21;                 // relative to this launch's X / keys
+    const int col = (int)(item & ((1 << 21) - 1));
+    if (col >= a.padcols) continue;
+    const int word = col >> 5, c = col & 31;
+    const float* __restrict__ x = a.X + row * a.ldx;
+    const int cb = word / a.nt, jt = word % a.nt;
+    const float* __restrict__ img = a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats;
+    float acc = 0.f, ss = 0.f;
+    for (int t0 = 0; t0 < a.ktiles; t0 += kFixSlabTiles) {
+      const int tiles = a.ktiles - t0 < kFixSlabTiles ? a.ktiles - t0 : kFixSlabTiles;
+      // Fixed trip counts, unconditional loads from clamped addresses: all of a slab's loads are in flight together
+      // (a loop of unknown length waits for every load before issuing the next one).
+      const int live = tiles * kKTile;
+      float xv[kFixSlabTiles * kKTile / 64];
+      f32x4 pv[kFixSlabTiles * 8 / 64];
+#pragma unroll
+      for (int m = 0; m < kFixSlabTiles * kKTile / 64; ++m) {     // x: 256 contiguous bytes per instruction
+        const int kk = lane + 64 * m, k = t0 * kKTile + kk;
+        xv[m] = x[(kk < live && k < a.dim) ? k : 0];
+      }
+#pragma unroll
+      for (int m = 0; m < kFixSlabTiles * 8 / 64; ++m) {          // p: fragment chunk j = (tile, half, quad)
+        const int j = lane + 64 * m;
+        const int t = j < tiles * 8 ? (j >> 3) : 0, hh = (j >> 2) & 1, q = j & 3;
+        pv[m] = *reinterpret_cast<const f32x4*>(img + (size_t)(t0 + t) * kt_stride + ((q * 64) + hh * 32 + c) * 4);
+      }
+#pragma unroll
+      for (int m = 0; m < kFixSlabTiles * kKTile / 64; ++m) {
+        const int kk = lane + 64 * m, k = t0 * kKTile + kk;
+        if (kk < live) xs[kk] = k < a.dim ? xv[m] : 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < kFixSlabTiles * 8 / 64; ++m) {
+        const int j = lane + 64 * m;
+        if (j < tiles * 8) *reinterpret_cast<f32x4*>(&ps[(j >> 3) * kKTile + 16 * ((j >> 2) & 1) + 4 * (j & 3)]) = pv[m];
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int t = 0; t < tiles; ++t) {
+        f32x4 p4[2][4], x4[2][4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            x4[hh][q] = *reinterpret_cast<const f32x4*>(&xs[t * kKTile + 16 * hh + 4 * q]);
+            p4[hh][q] = *reinterpret_cast<const f32x4*>(&ps[t * kKTile + 16 * hh + 4 * q]);
+          }
+        fix_chain_tile(p4, x4, acc, ss);
+      }
+      __syncthreads();
+    }
+    if (lane != 0) continue;
   // key bit
   uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
   const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
@@ -993,6 +1003,7 @@ __global__ __launch_bounds__(64) void sig_fix_kernel(const FixArgs a) {
         a.tie_list[2 * (int64_t)slot + 1] = (int64_t)(1u << c);
       }
     }
+  }
   }
 }
 
@@ -1566,11 +1577,9 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   f.tie_count = tie_count;
   f.tau = tau;
   {
-    const dim3 grid((unsigned)(((int64_t)flag_cap + kFixItemsPerWave - 1) / kFixItemsPerWave)), block(64);
-    if (aligned)
-      hipLaunchKernelGGL(sig_fix_kernel<true>, grid, block, 0, s, f);
-    else
-      hipLaunchKernelGGL(sig_fix_kernel<false>, grid, block, 0, s, f);
+    const int64_t want = (int64_t)flag_cap < kFixGrid ? (int64_t)flag_cap : kFixGrid;
+    const dim3 grid((unsigned)(want < 1 ? 1 : want)), block(64);
+    hipLaunchKernelGGL(sig_fix_kernel, grid, block, 0, s, f);
   }
   return -(int)hipGetLastError();
 }

@@ -92,15 +92,17 @@ class LSHHasher:
                   columns, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass — bf16 matrix
                   cores, then the exact f32 chain for every projection inside the stage-1 window — everything
                   else the f32 kernel; the keys are the same either way.  "f32": always the f32 kernel.
-      tau1_ulps   stage-1 window of the split pass, in the units of tau_ulps.  Default 256; the largest deviation
-                  observed over 2.7e9 projections of six data distributions stayed below 16
-                  (profiles/r01_split_window_margin.log).
+      tau1_ulps   stage-1 window of the split pass, in the units of tau_ulps.  Default 64: over 2.7e9 projections
+                  of six data distributions (one built from bf16 rounding boundaries) no deviation reached 16,
+                  and their spread is ~3 units (profiles/r01_split_window_margin.log).  The analytic worst case
+                  (every rounding error aligned against a cancelling sum) is 768 units; a hasher that must be
+                  safe against inputs crafted for its own hyperplanes should use precision="f32".
       tau1_ulps   stage-1 window of the bf16x3 pass, same unit; must stay >= 192 + the f32 rounding allowance
     """
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps: float = 8.0, precision: str = "bf16x3",
-                 tau1_ulps: float = 256.0, tie_threads: Optional[int] = None) -> None:
+                 tau1_ulps: float = 64.0, tie_threads: Optional[int] = None) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
