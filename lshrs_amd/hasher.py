@@ -345,7 +345,11 @@ class LSHHasher:
                 keep += [lists, counts, stage]
                 ready = []
                 split_flags = []
-                for ci, (lo, hi) in enumerate(group):
+
+                def enqueue(ci):
+                    """Chunk ci's signature pass + "gather the tied rows" on the caller's stream, its counters' copy on
+                    the count stream."""
+                    lo, hi = group[ci]
                     xs, os_ = x[lo:hi], out[lo:hi]
                     flags_ptr = row_flags[lo:hi].data_ptr() if row_flags is not None else None
                     flag = self._launch_sig(torch, lib, dev, xs.data_ptr(), hi - lo, x.stride(0), ws.data_ptr(),
@@ -370,6 +374,12 @@ class LSHHasher:
                         copied.record(cstream)
                     ready.append((copied, done))
 
+                # the GPU is kept two chunks ahead of the host: enqueueing everything first would let the host start on
+                # chunk 0 only after ~70 us of launch work per chunk, and finish that much after the GPU
+                ahead = 2
+                for ci in range(min(ahead, len(group))):
+                    enqueue(ci)
+
                 def fetch(ci):
                     """Wait for chunk ci's count, start the D2H of its entries + vectors into slot ci & 1."""
                     ready[ci][0].synchronize()
@@ -389,6 +399,8 @@ class LSHHasher:
 
                 nxt = fetch(0)
                 for ci, (lo, hi) in enumerate(group):
+                    if ci + ahead < len(group):
+                        enqueue(ci + ahead)
                     t0 = time.perf_counter()
                     cnt, landed = nxt
                     if ci + 1 < len(group):
