@@ -8,8 +8,8 @@ import numpy as np, torch
 from lshrs_amd import LSHHasher
 from oracle.lshrs_oracle import hash_batch_literal_packed
 
-def run(name, n, nb, r, dim, seed, data_seed):
-    h = LSHHasher(nb, r, dim, seed=seed)
+def run(name, n, nb, r, dim, seed, data_seed, precision):
+    h = LSHHasher(nb, r, dim, seed=seed, precision=precision)
     x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(data_seed))
     keys = torch.empty((n, nb, h.band_bytes), dtype=torch.uint8, device="cuda")
     for _ in range(2):
@@ -33,14 +33,16 @@ def run(name, n, nb, r, dim, seed, data_seed):
     ok = bool(np.array_equal(keys[:m].cpu().numpy(), hash_batch_literal_packed(h.projections, x[:m].cpu().numpy())))
     flops = 2.0 * dim * nb * r * n
     bytes_ = (4.0 * dim + nb * h.band_bytes) * n
-    print(json.dumps({"config": name, "rows": n, "dim": dim, "num_perm": nb * r, "bands_rows": [nb, r],
+    print(json.dumps({"config": name, "precision": precision, "rows": n, "dim": dim, "num_perm": nb * r, "bands_rows": [nb, r],
                       "bit_exact_vectors_per_s": n / e2e, "ms_bit_exact": 1e3 * e2e,
                       "kernel_only_vectors_per_s": n / raw, "ms_kernel_only": 1e3 * raw,
                       "kernel_tflops": flops / raw / 1e12, "frac_of_f32_mfma_peak_157.3": flops / raw / 1e12 / 157.3,
                       "hbm_GBps_algorithmic": bytes_ / raw / 1e9, "frac_of_hbm_8TBps": bytes_ / raw / 1e9 / 8000,
-                      "binding_roof": "f32 MFMA (arithmetic intensity %.0f FLOP/B)" % (flops / bytes_),
+                      "binding_roof": ("f32 MFMA (arithmetic intensity %.0f FLOP/B)" % (flops / bytes_)) if precision == "f32" else
+                                      "split-precision pass: bf16 MFMA x3 / HBM (the f32 matrix roof no longer applies)",
                       "tie_stats": stats, "cpu_bit_check_first_50k_rows": ok}), flush=True)
     assert ok
 
-run("C4 per-GPU shard (10M x 768 over 8 GPUs)", 1_250_000, 16, 16, 768, 42, 1000)
-run("C5 (5M x 1536, num_perm 512)", 5_000_000, 16, 32, 1536, 7, 5)
+for prec in ("bf16x3", "f32"):
+    run("C4 per-GPU shard (10M x 768 over 8 GPUs)", 1_250_000, 16, 16, 768, 42, 1000, prec)
+    run("C5 (5M x 1536, num_perm 512)", 5_000_000, 16, 32, 1536, 7, 5, prec)
