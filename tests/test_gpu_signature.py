@@ -354,3 +354,53 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
     got = hs.hash_device(x, tie_break="none")
     assert hs.last_stats["relaunches"] > 0
     assert torch.equal(got, _hasher(42, 16, 16, 768, precision="f32").hash_device(x, tie_break="none"))
+
+
+def test_split_pass_edge_rows_and_layouts(torch_mod):
+    """Rows the split-precision pass must not get wrong: zero / NaN / +-Inf rows, magnitudes far outside the unit
+    scale (the range guard flags them wholesale), subnormal-sized rows, rows mixing scales, rows proportional to a
+    hyperplane and to its negation; a strided view (row stride > dim) and an unaligned one (the f32 kernel takes
+    over); row flags.  Raw keys must equal the f32 kernel's and the C chain model's, final keys the reference's."""
+    torch = torch_mod
+    from oracle.build import chain_hash_packed
+    from oracle.lshrs_oracle import hash_batch_literal_packed, is_zero_vector_rows
+
+    nb, r, dim, n = 16, 16, 768, 70_000
+    hs = _hasher(42, nb, r, dim)                       # default precision: the split pass at this size
+    h32 = _hasher(42, nb, r, dim, precision="f32")
+    gen = torch.Generator("cuda").manual_seed(99)
+    base = torch.randn(n, dim + 32, device="cuda", generator=gen)
+    x = base[:, 16:16 + dim]                           # row stride dim + 32, 16-byte aligned: stays on the split pass
+    p0 = torch.from_numpy(np.asarray(hs.projections[0][3])).cuda()
+    special = {
+        0: torch.zeros(dim), 1: torch.full((dim,), float("nan")), 2: torch.full((dim,), float("inf")),
+        4: p0.cpu(), 5: -p0.cpu(), 6: p0.cpu() * 1e30, 7: p0.cpu() * 1e-30,
+        8: torch.randn(dim, generator=torch.Generator().manual_seed(1)) * 1e25,
+        9: torch.randn(dim, generator=torch.Generator().manual_seed(2)) * 1e-25,
+        10: torch.randn(dim, generator=torch.Generator().manual_seed(3)) * 1e-42,       # subnormals
+        11: torch.randn(dim, generator=torch.Generator().manual_seed(4)) * torch.logspace(-20, 20, dim),
+        12: torch.full((dim,), 1e-9), 13: torch.full((dim,), 1.0),
+    }
+    for i, v in special.items():
+        x[i] = v.to(torch.float32).cuda()
+    x[3, 5] = float("-inf")
+    x[n - 1] = 0.0
+    x[n - 2, 767] = float("nan")
+    rows = sorted(list(special) + [3, n - 1, n - 2]) + list(range(20_000, 20_400))
+    xs = x[rows].cpu().numpy()
+    flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert hs._split_applies(n)
+    raw = hs.hash_device(x, tie_break="none", row_flags=flags)
+    assert torch.equal(raw, h32.hash_device(x, tie_break="none"))
+    assert np.array_equal(raw[rows].cpu().numpy(), chain_hash_packed(hs.projections, xs))
+    fl = flags.cpu().numpy()
+    assert np.array_equal((fl[rows] & 1).astype(bool), is_zero_vector_rows(xs))
+    assert set(np.nonzero(fl & 2)[0].tolist()) == {1, n - 2}          # NaN present (Inf alone is not NaN)
+    final = hs.hash_device(x)
+    assert torch.equal(final, h32.hash_device(x))
+    assert np.array_equal(final[rows].cpu().numpy(), hash_batch_literal_packed(hs.projections, xs))
+    # unaligned start: the library hands the batch to the f32 kernel, same keys
+    odd = base[:, 3:3 + dim]
+    got = hs.hash_device(odd, tie_break="none")
+    sl = slice(0, 300)
+    assert np.array_equal(got[sl].cpu().numpy(), chain_hash_packed(hs.projections, odd[sl].cpu().numpy()))
