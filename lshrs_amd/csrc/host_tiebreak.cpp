@@ -122,9 +122,9 @@ void run_pairs(Engine* e, int t) {
 void worker_main(Engine* e, int t) {
   uint64_t seen = 0;
   for (;;) {
-    // Chunks of one batch arrive a few hundred microseconds apart: poll for that long before going to sleep, a
+    // Chunks of one batch arrive 100-400 microseconds apart: poll for a millisecond before going to sleep, a
     // condition-variable wake-up alone costs as much as the work of a small chunk.
-    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(250);
+    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(1000);
     while (e->gen_atomic.load(std::memory_order_acquire) == seen && !e->stop_atomic.load(std::memory_order_relaxed) &&
            std::chrono::steady_clock::now() < spin_until)
       __builtin_ia32_pause();

@@ -311,6 +311,7 @@ class LSHHasher:
         while the GPU works through them the host resolves the ties of the chunks already finished
         (count / entries / vectors come back over a side stream into two alternating pinned buffers,
         patches go out over it)."""
+        t_entry = time.perf_counter()
         torch = _native.require_gpu()
         lib = _native.load()
         dev = x.device
@@ -379,6 +380,8 @@ class LSHHasher:
                 ahead = 2
                 for ci in range(min(ahead, len(group))):
                     enqueue(ci)
+                    if ci == 0 and w0 == 0:
+                        stats["t_head_ms"] = 1e3 * (time.perf_counter() - t_entry)
 
                 def fetch(ci):
                     """Wait for chunk ci's count, start the D2H of its entries + vectors into slot ci & 1."""
@@ -399,12 +402,18 @@ class LSHHasher:
 
                 nxt = fetch(0)
                 for ci, (lo, hi) in enumerate(group):
+                    te = time.perf_counter()
+                    if nxt is None:
+                        nxt = fetch(ci)      # (blocking) the previous iteration could not start this copy early
                     if ci + ahead < len(group):
                         enqueue(ci + ahead)
                     t0 = time.perf_counter()
+                    stats["t_enqueue_ms"] = stats.get("t_enqueue_ms", 0.0) + 1e3 * (t0 - te)
                     cnt, landed = nxt
-                    if ci + 1 < len(group):
-                        nxt = fetch(ci + 1)  # next chunk's copy runs while this chunk's ties are resolved
+                    # start the next chunk's copy now if its count is already here (it then runs while this chunk's
+                    # ties are resolved) - but never WAIT for the next chunk before resolving this one
+                    nxt = fetch(ci + 1) if ci + 1 < len(group) and ready[ci + 1][0].query() else None
+                    stats["t_fetch_ms"] = stats.get("t_fetch_ms", 0.0) + 1e3 * (time.perf_counter() - t0)
                     if cnt > cap:
                         overflow.append((lo, hi))
                         continue
@@ -457,9 +466,12 @@ class LSHHasher:
                     for key, dt in (("t_wait_ms", t1 - t0), ("t_pairs_ms", t2 - t1), ("t_patch_ms", t3 - t2),
                                     ("t_scatter_ms", t4 - t3)):
                         stats[key] = stats.get(key, 0.0) + 1e3 * dt
+            t_loop = time.perf_counter()
             main.wait_stream(side)
             main.wait_stream(cstream)
             side.synchronize()
+            stats["t_drain_ms"] = 1e3 * (time.perf_counter() - t_loop)
+            stats["t_total_ms"] = 1e3 * (time.perf_counter() - t_entry)
         for lo, hi in overflow:  # a chunk with more ties than its list holds: redo it on the plain path
             sub = {"n": hi - lo, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
             self.last_stats = sub
