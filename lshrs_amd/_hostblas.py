@@ -38,6 +38,7 @@ _lock = threading.Lock()
 _lib: Optional[ctypes.CDLL] = None
 _engine: Optional["TieBreakEngine"] = None
 _engine_failed = False
+_engine_pid = -1
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -218,7 +219,11 @@ class TieBreakEngine:
 
 def engine(threads: Optional[int] = None) -> Optional[TieBreakEngine]:
     """The process-wide engine, or None when it cannot be built here (the caller then uses NumPy's matmul)."""
-    global _engine, _engine_failed
+    global _engine, _engine_failed, _engine_pid
+    if _engine is not None and _engine_pid != os.getpid():
+        # forked child: the worker threads did not come along (the handle of the parent's engine is abandoned)
+        _engine = None
+        _engine_failed = False
     if _engine is not None or _engine_failed:
         return _engine
     want = default_threads() if threads is None else int(threads)
@@ -235,4 +240,5 @@ def engine(threads: Optional[int] = None) -> Optional[TieBreakEngine]:
     with _lock:
         if _engine is None:
             _engine = eng
+            _engine_pid = os.getpid()
     return _engine

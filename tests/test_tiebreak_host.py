@@ -103,6 +103,39 @@ def test_host_engine_rejects_bad_pairs_and_handles_strided_rows():
     assert eng.patch(planes, xs, rows[:0], bands[:0]).shape == (0, 2)
 
 
+def test_host_engine_survives_a_fork():
+    """Worker threads do not cross fork(): a child that inherits a used engine must build its own, not wait on
+    the parent's workers forever."""
+    import os
+
+    h = LSHHasher(4, 16, 64, seed=1, tie_threads=3)
+    x = np.random.default_rng(0).standard_normal((300, 64)).astype(np.float32)
+    inv = np.arange(300, dtype=np.int32)
+    bands = np.sort(np.arange(300) % 4).astype(np.int32)
+    want = h._tie_patches(x, inv, bands)
+    pid = os.fork()
+    if pid == 0:
+        try:
+            code = 0 if np.array_equal(h._tie_patches(x, inv, bands), want) else 3
+        except BaseException:
+            code = 4
+        os._exit(code)
+    import signal
+    import time
+
+    deadline = time.time() + 60
+    while True:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done:
+            break
+        if time.time() > deadline:
+            os.kill(pid, signal.SIGKILL)
+            os.waitpid(pid, 0)
+            pytest.fail("forked child hung in the host engine")
+        time.sleep(0.05)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
 @pytest.mark.parametrize("nb,r", [(16, 16), (16, 4), (16, 32), (5, 12), (2, 24), (4, 64)])
 def test_indexed_pairs_agree_with_plain_pairs(nb, r):
     h = LSHHasher(nb, r, 32, seed=1)
