@@ -41,6 +41,7 @@ int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_
 int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles with fragment prefetch
 unsigned long long* g_clock_probe = nullptr;  // diagnostics only (lshrs_debug_set_clock_probe)
 int g_split_m = 2;                // row tiles per wave of the split pass (lshrs_debug_set_split_m)
+int g_split_pipe = 4;             // 3: x in fragment-shaped pieces, 4: x in full 128-byte lines (lshrs_debug_set_split_pipe)
 hipEvent_t g_split_mid_event = nullptr;       // diagnostics only: recorded once between stage 1 and stage 2
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
@@ -401,12 +402,13 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kHalfFloats = NT * 2 * kFragFloats;
   // LDS staging: PIPE 0 two whole tiles, PIPE 1 ring of three halves, PIPE 3 ring of four (fragment half + x half) stages
-  constexpr int kStageFloats = PIPE == 3 ? (M == 2 ? 4 : 3) * (kHalfFloats + W * M * 2 * kFragFloats)
+  constexpr int kStageFloats = PIPE == 4 ? 3 * kHalfFloats + 3 * (W * M * kRowsPerWave * kKTile)
+                               : PIPE == 3 ? (M == 2 ? 4 : 3) * (kHalfFloats + W * M * 2 * kFragFloats)
                                          : (PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats);
   constexpr int kWaveRows = kRowsPerWave * M;
   constexpr int kBlockRows = W * kWaveRows;
-  static_assert(M == 1 || PIPE == 1 || PIPE == 3, "two row tiles per wave are only built for the ring loops");
-  constexpr bool SPLIT = PIPE == 3;
+  static_assert(M == 1 || PIPE == 1 || PIPE == 3 || PIPE == 4, "two row tiles per wave are only built for the ring loops");
+  constexpr bool SPLIT = PIPE == 3 || PIPE == 4;
   __shared__ __attribute__((aligned(16))) float lds[kStageFloats + W * kWaveRows];
 
   const int tid = threadIdx.x;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     t_real = __builtin_amdgcn_s_memrealtime();
   }
 
-  if (PIPE == 3) {
+  if (PIPE == 3 || PIPE == 4) {
     // One ring stage = one 16-deep half k-tile = one bf16 MFMA k-step: 16 KiB of hyperplane fragments (staged
     // cooperatively) + 16 KiB of raw f32 x (each lane lands its OWN 2*M pieces of 16 bytes, and later reads them
     // back from lane*16: LDS is only the landing zone).  Both travel by LDS-DMA, so no VGPR is ever the target of
@@ -457,7 +459,17 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     // M = 2: 256-row workgroups, one per CU (512 registers per lane), ring of four 32 KiB stages.
     // M = 1: 128-row workgroups, two per CU (256 registers), ring of three 24 KiB stages: a second, independent
     //        workgroup on every SIMD fills the other's barrier waits, VALU slices and epilogue with MFMAs.
-    constexpr int kRing = M == 2 ? 4 : 3;          // stages in LDS; prefetch distance kRing - 1
+    // PIPE = 4 (FULL): x is staged in FULL 128-byte lines - one DMA piece = 8 rows x 128 B (one 32-deep k-tile of 8
+    // rows) instead of 32 rows x 2 half-line chunks; the texture path then touches 8 whole lines per piece, not 64
+    // sixteen-byte fragments of 32 lines (measured: 9 % of the main loop).  x tiles (32 deep) and fragment halves
+    // (16 deep) then live in separate rings of three: 3 x 32 KiB + 3 x 16 KiB = 144 KiB.  The landing image is
+    // XOR-swizzled per 8-lane row group so that the read-back (each lane: its row's two 16-byte chunks of the
+    // current half) is conflict-free for ds_read_b128's 16-lane groups.
+    constexpr bool FULL = PIPE == 4;
+    static_assert(!FULL || M == 2, "full-line x staging is built for two row tiles per wave");
+    constexpr int kXTile = W * M * kRowsPerWave * kKTile;      // floats of one x tile of the workgroup (FULL)
+    constexpr int kXWave = M * kRowsPerWave * kKTile;          // ... of one wave: 8 pieces of 1 KiB
+    constexpr int kRing = FULL ? 3 : (M == 2 ? 4 : 3);  // fragment stages in LDS; prefetch distance kRing - 1
     constexpr int kDma = 4 + 2 * M;                // DMAs per thread and stage: 4 fragment blocks + 2*M x pieces
     constexpr int kQuarter = 12 * M;               // MFMAs per quarter (4 column tiles x M row tiles x 3 terms)
     constexpr int kXHalfFloats = W * M * 2 * kFragFloats;
@@ -490,6 +502,56 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
 #pragma unroll
       for (int mt = 0; mt < M; ++mt) { xo[mt][0] = lane * 16u + mt * 2048u; xo[mt][1] = lane * 16u + mt * 2048u + 1024u; }
     }
+    // FULL: piece j (0..7) of a wave = rows 8j..8j+7 of its 64; lane l = (r = l>>3, q = l&7) fetches 16-byte chunk
+    // g = q ^ r ^ (j&1) of row 8j + r: an 8-lane group covers one whole 128-byte line (in permuted order).
+    unsigned xfo[8];                       // byte offset of this lane's chunk of piece j, relative to xblk + 128 * tile
+    unsigned xrd[M][2][2];                 // read-back byte offsets inside the wave's tile: [row tile][half][chunk]
+    if (FULL) {
+      const int r8 = lane >> 3, q8 = lane & 7;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t r = row0 + 8 * j + r8;
+        const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;
+        xfo[j] = (unsigned)((rl * args.ldx + 4 * (q8 ^ r8 ^ (j & 1))) * 4);
+      }
+#pragma unroll
+      for (int mt = 0; mt < M; ++mt) {
+        const int R = kRowsPerWave * mt + i, j = R >> 3, r = R & 7;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            xrd[mt][hf][c] = (unsigned)(j * 1024 + (r * 8 + ((4 * hf + 2 * h + c) ^ r ^ (j & 1))) * 16);
+      }
+    }
+    // FULL: the d-th (0..7) DMA a thread issues in stage hh: fragment blocks of half hh+2, then x pieces
+    // 4*(hh&1) .. +3 of tile (hh>>1)+2 (indices clamped at the end: loaded, never read)
+    struct FullDma {                       // everything uniform about one stage's 8 DMAs, computed once per stage
+      const char* pg;
+      const char* xg;
+      float* pdst;
+      float* xdst;
+      int j0;
+    };
+    auto full_plan = [&](int hh) {
+      FullDma f;
+      const int nh = hh + 2, c = nh < lasth ? nh : lasth;
+      const int nt = (hh >> 1) + 2, t = nt < ktiles ? nt : ktiles - 1;
+      f.pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
+      f.xg = xblk + (size_t)t * (kKTile * 4);
+      f.pdst = lds + (nh % 3) * kHalfFloats + wave_u * kFragFloats;
+      f.j0 = 4 * (hh & 1);
+      f.xdst = lds + 3 * kHalfFloats + (nt % 3) * kXTile + wave_u * kXWave + f.j0 * kFragFloats;
+      return f;
+    };
+    auto issue_full = [&](const FullDma& f, int d) {
+      if (d < 4)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + 4 * d * kFragFloats),
+                                         16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[4 + d - 4] : xfo[d - 4])),
+                                         (LDS_AS void*)(f.xdst + (d - 4) * kFragFloats), 16, 0, 0);
+    };
     auto issue_half = [&](int hh) {       // exactly 8 DMAs per thread: 4 fragment blocks + 2*M x pieces of half min(hh, lasth)
       const int c = hh < lasth ? hh : lasth;
       float* st = lds + (hh % kRing) * kStage;
@@ -508,6 +570,14 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
                                            (LDS_AS void*)(xl + (mt * 2 + pc) * kFragFloats), 16, 0, 0);
     };
     auto read_x = [&](int hh, f32x4 (&v)[2][M]) {
+      if (FULL) {
+        const char* xt = reinterpret_cast<const char*>(lds + 3 * kHalfFloats + ((hh >> 1) % 3) * kXTile + wave_u * kXWave);
+#pragma unroll
+        for (int mt = 0; mt < M; ++mt)
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) v[pc][mt] = *reinterpret_cast<const f32x4*>(xt + xrd[mt][hh & 1][pc]);
+        return;
+      }
       const float* xl = lds + (hh % kRing) * kStage + kHalfFloats + wave_u * (M * 2 * kFragFloats) + lane * 4;
 #pragma unroll
       for (int mt = 0; mt < M; ++mt)
@@ -564,7 +634,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     Bf16Pairs ahx[M], amx[M], ahy[M], amy[M];   // bf16 x of the previous / current stage, ping-pong (no copies)
     auto stage = [&](int hh, const bool first, const Bf16Pairs (&ahp)[M], const Bf16Pairs (&amp)[M],
                      Bf16Pairs (&ahc)[M], Bf16Pairs (&amc)[M]) {
-      const float* st = lds + (hh % kRing) * kStage;
+      const float* st = FULL ? lds + (hh % 3) * kHalfFloats : lds + (hh % kRing) * kStage;
       if (!(LSHRS_SPLIT_PROBE & 1)) read_quarter(st, 0, fa);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -575,11 +645,15 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): A(hh), a whole group old
       __builtin_amdgcn_sched_barrier(0);
-      wait_vmcnt<(kRing - 3) * kDma>();          // this wave's DMAs of stage hh+1 have landed (later stages pending)
+      // this wave's DMAs for stage hh+1 have landed.  Ring of four: the 8 of stage hh+2 may be pending.  FULL: the
+      // fragment blocks of half hh+1 were issued (first) in stage hh-1, the x pieces issued after them may be pending;
+      // every x piece is thereby forced to land two stages after its issue, a tile before it is read.
+      wait_vmcnt<FULL ? 4 : (kRing - 3) * kDma>();
       if (!(LSHRS_SPLIT_PROBE & 1)) read_quarter(st, 4, fb);
       if (!(LSHRS_SPLIT_PROBE & 16)) read_x(hh + 1, xr);
       __builtin_amdgcn_sched_barrier(0);
       {
+        const FullDma plan = full_plan(hh);
         const int nh = hh + kRing - 1;
         const int c = nh < lasth ? nh : lasth;
         float* nst = lds + (nh % kRing) * kStage;         // the slot of stage hh-1, which every wave has left
@@ -591,10 +665,12 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
           mfma_one(0, k, fa, ahc, amc);
           if (!(LSHRS_SPLIT_PROBE & 4) && k % (kQuarter / kDma) == 0) {     // the kDma DMAs of stage hh+kRing-1, spread over the quarter
             const int d = k / (kQuarter / kDma);
-            if (d < 4)
+            if (FULL)
+              issue_full(plan, d);
+            else if (d < 4)
               __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + poff[d]),
                                                (LDS_AS void*)(nst + (4 * d + wave_u) * kFragFloats), 16, 0, 0);
-            else
+            else if (!(LSHRS_SPLIT_PROBE & 64))
               __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + xo[(d - 4) >> 1][(d - 4) & 1]),
                                                (LDS_AS void*)(xl + (d - 4) * kFragFloats), 16, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -606,9 +682,26 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
       __builtin_amdgcn_sched_barrier(0);
       if (!(LSHRS_SPLIT_PROBE & 8)) __builtin_amdgcn_s_barrier();             // everybody's stage hh+1 is in LDS, everybody holds B(hh) in registers
     };
+    if (FULL) {
+      // fragments of halves 0 and 1, x tiles 0 and 1, in the order the steady state would have issued them:
+      // [P(0), X tile 0 (8 pieces)], [P(1), X tile 1 (8 pieces)]  (issue_full(hh, d) issues for hh+2 / tile (hh>>1)+2)
+      {
+        const FullDma a0 = full_plan(-4), a1 = full_plan(-3), b0 = full_plan(-2), b1 = full_plan(-1);
 #pragma unroll
-    for (int pre = 0; pre < kRing - 1; ++pre) issue_half(pre);
-    wait_vmcnt<(kRing - 2) * kDma>();            // stage 0 has landed, the later ones stay in flight
+        for (int d = 0; d < 4; ++d) issue_full(b0, d);                               // P(0)
+#pragma unroll
+        for (int d = 4; d < 8; ++d) { issue_full(a0, d); issue_full(a1, d); }        // x tile 0: pieces 0-3 and 4-7
+#pragma unroll
+        for (int d = 0; d < 4; ++d) issue_full(b1, d);                               // P(1)
+#pragma unroll
+        for (int d = 4; d < 8; ++d) { issue_full(b0, d); issue_full(b1, d); }        // x tile 1
+      }
+      wait_vmcnt<12>();                          // P(0) and x tile 0 have landed; P(1) and x tile 1 stay in flight
+    } else {
+#pragma unroll
+      for (int pre = 0; pre < kRing - 1; ++pre) issue_half(pre);
+      wait_vmcnt<(kRing - 2) * kDma>();          // stage 0 has landed, the later ones stay in flight
+    }
     __builtin_amdgcn_s_barrier();
     read_x(0, xr);
     stage(0, true, ahx, amx, ahy, amy);
@@ -1383,6 +1476,12 @@ int lshrs_debug_set_split_m(int m) {
   return 0;
 }
 
+int lshrs_debug_set_split_pipe(int p) {
+  if (p != 3 && p != 4) return LSHRS_E_BADARG;
+  g_split_pipe = p;
+  return 0;
+}
+
 int lshrs_debug_set_split_mid_event(void* event) {
   g_split_mid_event = static_cast<hipEvent_t>(event);
   return 0;
@@ -1546,7 +1645,10 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   if (g_split_m == 2) {
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles, one workgroup per CU
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
-    hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
+    if (g_split_pipe == 4)
+      hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 4, 2>), grid, block, 0, s, a);   // x staged in full 128-byte lines
+    else
+      hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
   } else {
     constexpr int kRows = 4 * kRowsPerWave;      // W = 4 waves x one 32-row tile, two workgroups per CU
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
