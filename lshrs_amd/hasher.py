@@ -88,7 +88,7 @@ class LSHHasher:
                   projection differ by at most 1.2 of those units (rms 0.3) and every sign disagreement
                   had |y| <= 0.41; tests/test_gpu_signature.py re-checks the margin on the box it runs on.
                   Raise it (e.g. 2*dim for the deterministic worst-case bound) for adversarial inputs.
-      precision   "bf16x3" (default): batches >= 65 536 rows whose shape allows it (dim % 32 == 0, >= 256 key
+      precision   "bf16x3" (default): batches of >= 16 M elements (21 846 rows at 768-d) whose shape allows it (dim % 32 == 0, >= 256 key
                   columns, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass — bf16 matrix
                   cores, then the exact f32 chain for every projection inside the stage-1 window — everything
                   else the f32 kernel; the keys are the same either way.  "f32": always the f32 kernel.
@@ -123,7 +123,10 @@ class LSHHasher:
         # the exact f32 chain for every projection inside the stage-1 window; same keys as "f32" 
         self.precision = precision
         self.tau1_ulps = float(tau1_ulps)
-        self.split_min_rows = 65_536
+        # the split pass (two launches, 256-row workgroups) overtakes the f32 kernel at about 16 M input elements:
+        # 20 k rows at 768-d, 8 k at 1536-d, 120 k at 128-d (tools/split_crossover.py)
+        self.split_min_rows = 4_096
+        self.split_min_elems = 16 << 20
         # host tie-break workers (lshrs_amd/_hostblas.py): None = this process's share of the cores (at most 8),
         # 1 = NumPy's batched matmul on the calling thread.  Same BLAS call either way.
         if tie_threads is not None and int(tie_threads) < 1:
@@ -540,7 +543,8 @@ class LSHHasher:
         return buf
 
     def _split_applies(self, n: int) -> bool:
-        if self.precision != "bf16x3" or n < self.split_min_rows or self.dim % 32 != 0:
+        if (self.precision != "bf16x3" or n < self.split_min_rows or n * self.dim < self.split_min_elems
+                or self.dim % 32 != 0):
             return False
         lib = _native.load()
         if (int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) < 256
@@ -767,5 +771,6 @@ class LSHHasher:
         self.__dict__.setdefault("tie_threads", None)
         self.__dict__.setdefault("_host_planes_cache", None)
         self.__dict__.setdefault("_split_range_ok", None)
+        self.__dict__.setdefault("split_min_elems", 16 << 20)
         self._lock = threading.Lock()
         self._projections = _ProjectionList(state["_projections"], self)

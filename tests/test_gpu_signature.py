@@ -331,6 +331,7 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
                                  (3, 32, 8, 100, 70_001)):     # dim % 32 != 0: the f32 kernel takes over
         h32 = _hasher(seed, nb, r, dim, precision="f32")
         hs = _hasher(seed, nb, r, dim, precision="bf16x3")
+        hs.split_min_elems = 0                                # (the size threshold would keep the 96-d case on the f32 kernel)
         gen = torch.Generator("cuda").manual_seed(seed + 5)
         x = torch.randn(n, dim, device="cuda", generator=gen)
         x[7] = 0.0                                            # zero row: nothing to flag, flag bit set
