@@ -253,7 +253,7 @@ class LSHHasher:
             return out
         ws = self._workspace(dev)
         tau = float(self.tau_ulps * _U)
-        if mode == "host" and host_rows is None and n >= 2 * self.pipeline_chunk_rows:
+        if mode == "host" and host_rows is None and n >= max(131_072, self.pipeline_chunk_rows // 2):
             return self._hash_device_pipelined(x, out, row_flags, ws, tau, stats)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -321,6 +321,8 @@ class LSHHasher:
         n = int(x.shape[0])
         bb = self.band_bytes
         ch = self.pipeline_chunk_rows
+        while n < 2 * ch and ch > 65_536:   # mid-size batch: two or three smaller chunks still overlap most of the tie-break
+            ch = max(65_536, ch // 2)
         cap = ch // 32 + 1024    # tie entries per chunk (measured: ~0.25 % of the rows at tau_ulps = 8); more -> plain path
         window = 16
         spans = [(lo, min(n, lo + ch)) for lo in range(0, n, ch)]
@@ -539,7 +541,7 @@ class LSHHasher:
                    torch.empty((2, slot_bytes), dtype=torch.uint8).pin_memory(),
                    torch.empty((2, slot_bytes), dtype=torch.uint8, device=dev),
                    pairs_cap)
-            self._pinned_cache = {key: buf}
+            self._pinned_cache[key] = buf      # at most three chunk sizes exist (pipeline_chunk_rows, /2, /4)
         return buf
 
     def _split_applies(self, n: int) -> bool:
