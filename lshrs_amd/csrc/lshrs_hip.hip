@@ -9,12 +9,13 @@
 // ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md.
 
 #include <hip/hip_runtime.h>
+// Attribution probes of the split-precision main loop (tools/split_probes.py builds one library per value and reads
+// the in-kernel cycle stamps; results are WRONG keys by design): 1 no fragment reads, 2 no bf16 split, 4 no DMA in the
+// loop, 8 no barrier, 16 no x read-back, 32 contiguous x addresses (PIPE 3), 64 no x pieces (PIPE 3).
 #ifndef LSHRS_SPLIT_PROBE
 #define LSHRS_SPLIT_PROBE 0
 #endif
-#ifndef LSHRS_X_AUX
-#define LSHRS_X_AUX 0   // cache policy of the once-read x stream: 0 default, 2 non-temporal
-#endif
+
 #include <stdint.h>
 #include <math.h>
 
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
                                          16, 0, 0);
       else
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[4 + d - 4] : xfo[d - 4])),
-                                         (LDS_AS void*)(f.xdst + (d - 4) * kFragFloats), 16, 0, LSHRS_X_AUX);
+                                         (LDS_AS void*)(f.xdst + (d - 4) * kFragFloats), 16, 0, 0);   // (aux = 2, non-temporal, measured equal)
     };
     auto issue_half = [&](int hh) {       // exactly 8 DMAs per thread: 4 fragment blocks + 2*M x pieces of half min(hh, lasth)
       const int c = hh < lasth ? hh : lasth;
