@@ -410,6 +410,8 @@ class LSHHasher:
                     te = time.perf_counter()
                     if nxt is None:
                         nxt = fetch(ci)      # (blocking) the previous iteration could not start this copy early
+                    if ci == len(group) - 1:
+                        stats["t_tail_count_ms"] = 1e3 * (time.perf_counter() - t_entry)   # count of the last chunk is here
                     if ci + ahead < len(group):
                         enqueue(ci + ahead)
                     t0 = time.perf_counter()
