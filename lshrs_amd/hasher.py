@@ -308,6 +308,15 @@ class LSHHasher:
 
     # ------------------------------------------------------------------ large batches: overlap the tie-break
     def _hash_device_pipelined(self, x, out, row_flags, ws, tau, stats):
+        try:
+            return self._pipelined_body(x, out, row_flags, ws, tau, stats)
+        except BaseException:
+            # kernels and copies still in flight use buffers owned by the frame that just unwound: let them finish
+            # before the caching allocator can hand that memory to anyone else
+            _native.require_gpu().cuda.synchronize(x.device)
+            raise
+
+    def _pipelined_body(self, x, out, row_flags, ws, tau, stats):
         """Same result as the plain path, for large device-resident batches: the batch is cut into
         chunks of ``pipeline_chunk_rows`` (a whole number of full-chip rounds of the kernel); every chunk's
         kernel and its "gather the tied rows" kernel are enqueued back to back on the caller's stream, and
