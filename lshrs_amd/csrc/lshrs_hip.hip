@@ -11,7 +11,8 @@
 #include <hip/hip_runtime.h>
 // Attribution probes of the split-precision main loop (tools/split_probes.py builds one library per value and reads
 // the in-kernel cycle stamps; results are WRONG keys by design): 1 no fragment reads, 2 no bf16 split, 4 no DMA in the
-// loop, 8 no barrier, 16 no x read-back, 32 contiguous x addresses (PIPE 3), 64 no x pieces (PIPE 3).
+// loop, 8 no barrier, 16 no x read-back, 32 contiguous x addresses (PIPE 3), 64 no x pieces (PIPE 3),
+// 128 every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same registers (power/timing only).
 #ifndef LSHRS_SPLIT_PROBE
 #define LSHRS_SPLIT_PROBE 0
 #endif
@@ -95,8 +96,9 @@ inline int64_t sig_fine_floats(const SigGeom& g) {
 // (hi = bf16(p), mid = bf16(p - hi)) instead of one f32 — same byte size; wide geometry (NT = 8) only.
 inline bool sig_has_split(const SigGeom& g) { return g.nt == 8; }
 inline int64_t sig_split_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
+inline int64_t sig_t16_offset_floats(const SigGeom& g) { return sig_split_offset_floats(g) + sig_image_floats(g); }
 inline int64_t sig_workspace_floats(const SigGeom& g) {
-  return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? sig_image_floats(g) : 0);
+  return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? 2 * sig_image_floats(g) : 0);
 }
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
 
@@ -622,6 +624,15 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
       const int j = k / (3 * M), mt = (k / 3) % M, term = k % 3;
       const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[mt] : hi[mt]);
       const bf16x8 bb = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
+      if (LSHRS_SPLIT_PROBE & 128) {   // power/timing probe: the same FLOPs as two 16x16x32 MFMAs (wrong math)
+        struct Q { f32x4 q[4]; };
+        Q c = __builtin_bit_cast(Q, acc[mt][j0 + j]);
+        const int s0 = (k & 1) * 2;
+        c.q[s0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, c.q[s0], 0, 0, 0);
+        c.q[s0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, c.q[s0 + 1], 0, 0, 0);
+        acc[mt][j0 + j] = __builtin_bit_cast(f32x16, c);
+        return;
+      }
       acc[mt][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[mt][j0 + j], 0, 0, 0);
     };
     // Software pipeline over the stage barrier: every group of 24 MFMAs runs while the LDS reads of the NEXT group
@@ -1195,6 +1206,406 @@ __global__ void scatter_keys_kernel(uint8_t* __restrict__ keys, int num_bands, i
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 on v_mfma_f32_16x16x32_bf16 ("T16").  Same algorithm, same bits, same LDS-DMA staging as the
+// PIPE = 4 path of sig_kernel (x in full 128-byte lines, fragment ring of three 16 KiB stages), but on
+// the 16x16x32 MFMA: at equal cycles per FLOP that shape draws less power, and on random operands the
+// bf16 matrix pipes are power-capped long before they are issue-bound (tools/mfma_power_bench.hip:
+// 32x32x16 runs at 1.5-1.6 GHz, 16x16x32 at 1.8-2.0 GHz = 1.2x the FLOP/s).
+//   wave  = 64 rows (four 16-row tiles) x 256 columns (sixteen 16-column tiles) = 64 accumulator tiles of
+//           4 registers; workgroup = 4 waves, one per SIMD, 256 rows; grid = ceil(n / 256) x column blocks.
+//   stage = (k-tile t of 32, column half ch): 16 KiB of fragments = 8 column tiles x {hi, mid}, 96 MFMAs per
+//           wave (16 cycles each) in two quarters of 48; x is read back and split once per k-tile.
+//   image = image16[cb][t][ct 0..15][part][lane]: 16 bytes = the 8 bf16 of P'[col = 256 cb + 16 ct + (lane & 15)]
+//           [k = 32 t + 8 (lane >> 4) + 0..7]: a stage is 16 KiB contiguous, staged by a linear LDS-DMA copy.
+//   accumulator tile: column = lane & 15, row = 4 (lane >> 4) + register.
+// ------------------------------------------------------------------------------------------
+__global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb,
+                                           int ktiles, int64_t chunks, u16x8* __restrict__ image) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= chunks) return;
+  const int lane = (int)(c & 63);
+  const int part = (int)((c >> 6) & 1);
+  const int ct = (int)((c >> 7) & 15);
+  const int64_t t = c >> 11;
+  const int kt = (int)(t % ktiles);
+  const int cb = (int)(t / ktiles);
+  const int col = cb * 256 + ct * 16 + (lane & 15);
+  const int band = col / (bb * 8);
+  const int bit = col % (bb * 8);
+  const int k0 = kt * kKTile + 8 * (lane >> 4);
+  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (band < num_bands && bit < rows) {
+    const float* src = P + ((int64_t)band * rows + bit) * dim;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (k0 + j < dim) {
+        const float x = src[k0 + j];
+        const uint16_t hi = bf16_rne_bits(x);
+        const float hif = __uint_as_float((uint32_t)hi << 16);
+        v[j] = part == 0 ? hi : bf16_rne_bits(x - hif);
+      }
+    }
+  }
+  image[c] = v;
+}
+
+__global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
+  constexpr int kPHalf = 16 * kFragFloats;        // floats of one fragment stage (16 blocks of 1 KiB)
+  constexpr int kXTile = 256 * kKTile;            // floats of one x tile of the workgroup
+  constexpr int kXWave = 64 * kKTile;
+  constexpr int kRingFloats = 3 * kPHalf + 3 * kXTile;
+  __shared__ __attribute__((aligned(16))) float lds[kRingFloats + 256];
+  struct Bf16Pairs { bf16x2 p[4]; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int cb = blockIdx.y;
+  const int64_t blk_row0 = (int64_t)blockIdx.x * 256;
+  const int64_t row0 = blk_row0 + wave * 64;
+  const int ktiles = args.ktiles;
+  const int stages = 2 * ktiles, lasts = stages - 1;
+  const char* img = reinterpret_cast<const char*>(args.image) + (size_t)cb * ktiles * 32768;
+  const char* xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
+
+  // loop-invariant DMA offsets (see the PIPE = 4 path of sig_kernel for the x landing image and its swizzle)
+  unsigned poff[4], xfo[8], xrd[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) poff[q] = (unsigned)(((4 * q + wave) * 64 + lane) * 16);
+  {
+    const int r8 = lane >> 3, q8 = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t r = row0 + 8 * j + r8;
+      const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;   // clamp: loads stay in bounds, stores are masked
+      xfo[j] = (unsigned)((rl * args.ldx + 4 * (q8 ^ r8 ^ (j & 1))) * 4);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int R = 16 * rt + r16, j = R >> 3, r = R & 7;       // this lane's row of row tile rt: chunks 2g, 2g+1
+#pragma unroll
+      for (int c = 0; c < 2; ++c) xrd[rt][c] = (unsigned)(j * 1024 + (r * 8 + ((2 * g + c) ^ r ^ (j & 1))) * 16);
+    }
+  }
+
+  f32x4 acc[4][16];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) {
+      acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // pin the zeroing HERE: the MFMAs below are inline asm, so hipcc pads no hazard for them - a v_accvgpr_write
+      // rematerialised right in front of the first accumulation would be read too early
+      asm volatile("" : "+a"(acc[rt][ct]));
+    }
+  float ss[4], amax[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) { ss[rt] = 0.f; amax[rt] = 0.f; }
+
+  unsigned long long t_shader = 0, t_real = 0;
+  if (args.clock_probe != nullptr) {
+    t_shader = __builtin_amdgcn_s_memtime();
+    t_real = __builtin_amdgcn_s_memrealtime();
+  }
+
+  struct Dma { const char* pg; const char* xg; float* pdst; float* xdst; int j0; };
+  auto plan = [&](int s) {          // what stage s issues: fragments of stage s+2, x pieces 4(s&1).. of tile (s>>1)+2
+    Dma f;
+    const int ns = s + 2, c = ns < lasts ? ns : lasts;
+    const int nt = (s >> 1) + 2, t = nt < ktiles ? nt : ktiles - 1;
+    f.pg = img + (size_t)c * 16384;
+    f.xg = xblk + (size_t)t * (kKTile * 4);
+    f.pdst = lds + (ns % 3) * kPHalf + wave * kFragFloats;
+    f.j0 = 4 * (s & 1);
+    f.xdst = lds + 3 * kPHalf + (nt % 3) * kXTile + wave * kXWave + f.j0 * kFragFloats;
+    return f;
+  };
+  auto issue = [&](const Dma& f, int d) {
+    if (d < 4)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + 4 * d * kFragFloats),
+                                       16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[d] : xfo[d - 4])),
+                                       (LDS_AS void*)(f.xdst + (d - 4) * kFragFloats), 16, 0, 0);
+  };
+  f32x4 xr[4][2];                           // raw f32 x of one k-tile: [row tile][chunk]
+  auto read_x = [&](int t) {
+    const char* xt = reinterpret_cast<const char*>(lds + 3 * kPHalf + (t % 3) * kXTile + wave * kXWave);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) xr[rt][c] = *reinterpret_cast<const f32x4*>(xt + xrd[rt][c]);
+  };
+  float r0 = 0.f, r1 = 0.f;
+  auto split_step = [&](int q, Bf16Pairs (&hi)[4], Bf16Pairs (&mid)[4]) {     // slice q (0..47) of one k-tile's split
+    const int pair = q / 3, step = q % 3, rt = pair >> 2, pr = pair & 3, c = pr >> 1, e = 2 * (pr & 1);
+    const float v0 = xr[rt][c][e], v1 = xr[rt][c][e + 1];
+    if (step == 0) {
+      const bf16x2 hp = bf16x2{(__bf16)v0, (__bf16)v1};
+      hi[rt].p[pr] = hp;
+      r0 = v0 - (float)hp[0];
+      r1 = v1 - (float)hp[1];
+    } else if (step == 1) {
+      mid[rt].p[pr] = bf16x2{(__bf16)r0, (__bf16)r1};
+    } else {
+      ss[rt] = __builtin_amdgcn_fdot2_f32_bf16(hi[rt].p[pr], hi[rt].p[pr], ss[rt], false);
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax[rt]) : "v"(v0), "v"(v1));
+    }
+  };
+  // Fragments travel in EIGHTHS of a stage: 2 column tiles x {hi, mid} = 4 ds_read_b128 = 16 VGPRs, two buffers.
+  // (Quarters, as in sig_kernel, push this kernel over 256 VGPRs next to its 256 accumulator AGPRs: hipcc then
+  // shuffles accumulators through v_accvgpr moves inside the loop.)
+  auto read_eighth = [&](const float* base, int e, f32x4 (&f)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f[j][0] = *reinterpret_cast<const f32x4*>(base + (((2 * e + j) * 2 + 0) * 64 + lane) * 4);
+      f[j][1] = *reinterpret_cast<const f32x4*>(base + (((2 * e + j) * 2 + 1) * 64 + lane) * 4);
+    }
+  };
+  // MFMA k (0..23) of an eighth: column tile ct0 + k/12, term (k/4) % 3 of xh*ph + xh*pm + xm*ph, row tile k % 4:
+  // consecutive MFMAs go to different accumulator tiles (a 4-pass MFMA's result is not back in time for the next
+  // instruction; hipcc pads dependent neighbours with s_nops)
+  auto mfma_one = [&](int ct0, int k, const f32x4 (&f)[2][2], const Bf16Pairs (&hi)[4], const Bf16Pairs (&mid)[4]) {
+    const int j = k / 12, term = (k / 4) % 3, rt = k % 4;
+    const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[rt] : hi[rt]);
+    const bf16x8 b = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
+    // Inline asm pins the accumulator to AGPRs and to in-place accumulation: left to the builtin, hipcc renames
+    // accumulator tiles between MFMAs (vDst != SrcC) and parks some in VGPRs, i.e. hundreds of v_accvgpr moves and
+    // s_nops per loop body.  Dependent MFMAs are four instructions (64 cycles) apart, beyond the 4-pass hazard window.
+#ifdef LSHRS_T16_BUILTIN
+    acc[rt][ct0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[rt][ct0 + j], 0, 0, 0);
+#else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[rt][ct0 + j]) : "v"(a), "v"(b));
+#endif
+  };
+
+  f32x4 fa[2][2], fb[2][2];
+  Bf16Pairs hs0[4], ms0[4], hs1[4], ms1[4];   // bf16 x of the k-tiles, ping-pong by tile parity
+
+  // One k-tile = two stages (column halves ch), one stage = four eighths E0..E3 of 24 MFMAs.  Every eighth's MFMAs
+  // run while the next eighth's fragments are read; the last eighth of a stage is consumed after the barrier:
+  //   barrier(s) | read E0(s) | MFMA E3(s-1) | read E1(s) [+ raw x of the next tile, ch = 1] | MFMA E0(s) |
+  //              | read E2(s) | MFMA E1(s) + DMA | read E3(s) | MFMA E2(s) + DMA | barrier(s+1)
+  // The next tile's x is read in the second stage of a tile and split (48 slices) under that stage's last two
+  // eighths and the first eighth after the tile boundary: it must be complete before E0 of the new tile.
+  auto stage = [&](int s, const int ch, const bool first, const Bf16Pairs (&hc)[4], const Bf16Pairs (&mc)[4],
+                   const Bf16Pairs (&hp)[4], const Bf16Pairs (&mp)[4], Bf16Pairs (&hn)[4], Bf16Pairs (&mn)[4]) {
+    // hc/mc: this stage's tile; hp/mp: the tile E3(s-1) belongs to; hn/mn: where the split in flight writes
+    const float* st = lds + (s % 3) * kPHalf;
+    read_eighth(st, 0, fa);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      if (!first) mfma_one(8 * (1 - ch) + 6, k, fb, hp, mp);        // E3 of the previous stage (the other column half)
+      if (ch == 0) {                                                  // slices 32..47 of this tile's split (2 per 3 MFMAs)
+        if (k % 3 != 2) split_step(32 + (k / 3) * 2 + k % 3, hn, mn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<4>();                                                  // own fragments of stage s+1 and every older x piece
+    read_eighth(st, 1, fb);
+    if (ch == 1) read_x((s >> 1) + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      mfma_one(8 * ch + 0, k, fa, hc, mc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    read_eighth(st, 2, fa);
+    __builtin_amdgcn_sched_barrier(0);
+    const Dma f = plan(s);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      mfma_one(8 * ch + 2, k, fb, hc, mc);
+      if (ch == 1 && k % 3 != 2) split_step((k / 3) * 2 + k % 3, hn, mn);          // slices 0..15 of the next tile
+      if (k % 6 == 0) issue(f, k / 6);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    read_eighth(st, 3, fb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      mfma_one(8 * ch + 4, k, fa, hc, mc);
+      if (ch == 1 && k % 3 != 2) split_step(16 + (k / 3) * 2 + k % 3, hn, mn);     // slices 16..31
+      if (k % 6 == 0) issue(f, 4 + k / 6);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  // tile t with its sets (hc, mc); the previous tile's (hp, mp) double as the target of the next tile's split
+  auto tile = [&](int t, const bool first, Bf16Pairs (&hc)[4], Bf16Pairs (&mc)[4], Bf16Pairs (&hp)[4], Bf16Pairs (&mp)[4]) {
+    stage(2 * t, 0, first, hc, mc, hp, mp, hc, mc);       // ch 0: E3(s-1) is the previous tile's; the split in flight is this tile's
+    stage(2 * t + 1, 1, false, hc, mc, hc, mc, hp, mp);   // ch 1: E3(s-1) is this tile's; the next tile's split starts (into the other set)
+  };
+
+  {
+    const Dma a0 = plan(-4), a1 = plan(-3), b0 = plan(-2), b1 = plan(-1);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) issue(b0, d);                            // fragments of stage 0
+#pragma unroll
+    for (int d = 4; d < 8; ++d) { issue(a0, d); issue(a1, d); }          // x tile 0
+#pragma unroll
+    for (int d = 0; d < 4; ++d) issue(b1, d);                            // fragments of stage 1
+#pragma unroll
+    for (int d = 4; d < 8; ++d) { issue(b0, d); issue(b1, d); }          // x tile 1
+  }
+  wait_vmcnt<12>();
+  __builtin_amdgcn_s_barrier();
+  read_x(0);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) split_step(q, hs0, ms0);      // tile 0 only: the rest (32..47) rides in stage 0 as for every tile
+  tile(0, true, hs0, ms0, hs1, ms1);
+  int t = 1;
+  for (; t + 1 < ktiles; t += 2) {
+    tile(t, false, hs1, ms1, hs0, ms0);
+    tile(t + 1, false, hs0, ms0, hs1, ms1);
+  }
+  if (t < ktiles) {                                                      // even number of k-tiles: one more, then drain with its set
+    tile(t, false, hs1, ms1, hs0, ms0);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { mfma_one(14, k, fb, hs1, ms1); asm volatile("s_nop 7\n\ts_nop 4"); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { mfma_one(14, k, fb, hs0, ms0); asm volatile("s_nop 7\n\ts_nop 4"); }
+  }
+  // (the wait states after every MFMA of the drain: where the two branches join hipcc may copy accumulator tiles, and
+  //  it does not know that the asm in front of such a copy is an MFMA whose result takes passes to arrive)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the last stage must land before exit
+  __builtin_amdgcn_s_barrier();
+  // Landing point of the accumulators.  hipcc does not know that the asm statements above are MFMAs whose results
+  // take passes to arrive: without this it hoists the epilogue's v_accvgpr_reads to a few instructions behind the
+  // last MFMA (observed: one register of one tile read before its final accumulation).  Volatile asms keep their
+  // order, and every read below depends on the empty asm that follows the wait states.
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) asm volatile("" : "+a"(acc[rt][ct]));
+
+  if (args.clock_probe != nullptr && tid == 0) {
+    const unsigned long long slot = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+    args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
+    args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
+  }
+
+  // ---- row statistics -> stage-1 window per row (as in sig_kernel's split epilogue) -----------------------
+  float* wnd_lds = lds + kRingFloats + wave * 64;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    float s2 = ss[rt] + __shfl_xor(ss[rt], 16);
+    s2 += __shfl_xor(s2, 32);
+    float am = __builtin_fmaxf(amax[rt], __shfl_xor(amax[rt], 16));
+    am = __builtin_fmaxf(am, __shfl_xor(am, 32));
+    const int64_t myrow = row0 + 16 * rt + r16;
+    if (g == 0) {
+      float window = sqrtf(s2) * args.tau * 1.01f;
+      if (am != 0.f && !(am >= 0x1p-60f && am <= 0x1p60f)) window = __builtin_inff();
+      wnd_lds[16 * rt + r16] = window;
+      if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
+        const bool has_nan = s2 != s2;
+        const bool zero = (am <= 1e-8f) && !has_nan;
+        args.row_flags[myrow] = (uint8_t)((zero ? 1 : 0) | (has_nan ? 2 : 0));
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+
+  // ---- sign bits.  One v_cmp per accumulator register = 4 rows (g') x 16 columns: its low 32 bits are rows g' = 0, 1,
+  // its high 32 bits rows g' = 2, 3 of the tile.  Per 32-row group, lane L owns the ROW PAIR p = L / 4 = (rtl, g'-pair,
+  // reg) - rows 16 rtl + 8 g'pair + reg and + 4 - and the 32-column words 2 (L % 4), + 1: the ballot halves of the even
+  // column tile land in A[], of the odd one in B[] (deposit_positive: v_cmp, the two wait states a VALU-written SGPR
+  // needs, two v_writelane), and two VALU ops per word merge the 16-bit halves.  Same instruction count per
+  // accumulator register as the 32x32 epilogue.
+  const float nmax = args.norm_max[cb];
+#pragma unroll
+  for (int G = 0; G < 2; ++G) {
+    uint32_t A[2] = {0u, 0u}, B[2] = {0u, 0u};
+#pragma unroll
+    for (int rtl = 0; rtl < 2; ++rtl) {
+      const int rt = 2 * G + rtl;
+      const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * g);   // rows 16 rt + 4 g + 0..3
+      // wave-uniform-per-lane screen: the largest window of this lane's four rows (a non-finite window - NaN or Inf
+      // in the row, or a magnitude outside the guarded range - makes it +inf: everything goes to the exact test)
+      float tsmax = __builtin_fmaxf(__builtin_fmaxf(wnd[0], wnd[1]), __builtin_fmaxf(wnd[2], wnd[3]));
+      if (!(wnd[0] < __builtin_inff()) || !(wnd[1] < __builtin_inff()) || !(wnd[2] < __builtin_inff()) ||
+          !(wnd[3] < __builtin_inff()))
+        tsmax = __builtin_inff();
+      tsmax *= nmax;
+      tsmax = tsmax > 0.f ? tsmax : -1.f;               // all four rows zero: nothing to re-evaluate
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        float m = __builtin_inff();                     // min |y| over the 2 tiles x 4 registers of this word (NaN dropped:
+                                                        // a NaN y only comes from a row whose window is non-finite)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float y0 = acc[rt][2 * w][reg], y1 = acc[rt][2 * w + 1][reg];
+          const int p0 = 8 * rtl + reg * 2;             // pair (rtl, reg, g'pair = 0); g'pair = 1 is p0 + 1
+          deposit_positive(A[w & 1], y0, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
+          deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
+          asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));
+        }
+        if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0) {   // wave-uniform, a few % of the cells: the exact per-element test
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int ct = 2 * w + half;
+            const float pn = args.norms[cb * 256 + 16 * ct + r16];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              float thr = wnd[reg] * pn;
+              thr = thr > 0.f ? thr : -1.f;                               // zero row / zero-padded column: y is exactly 0
+              const int64_t grow = row0 + 16 * rt + 4 * g + reg;
+              if (!(__builtin_fabsf(acc[rt][ct][reg]) > thr) && grow < args.n) {
+                const int slot = atomicAdd(args.tie_count, 1);
+                if (slot < args.tie_cap) args.tie_list[slot] = (grow << 21) | (int64_t)(cb * 256 + 16 * ct + r16);
+              }
+            }
+          }
+        }
+      }
+    }
+    // lane L: pair p = L / 4 -> rows lo / lo + 4, words 2 (L % 4), + 1
+    const int pr = lane >> 2, wq = 2 * (lane & 3);
+    const int rlo = 16 * (pr >> 3) + 8 * (pr & 1) + ((pr >> 1) & 3);
+    const uint32_t wlo[2] = {(A[0] & 0xFFFFu) | (B[0] << 16), (A[1] & 0xFFFFu) | (B[1] << 16)};
+    const uint32_t whi[2] = {(A[0] >> 16) | (B[0] & 0xFFFF0000u), (A[1] >> 16) | (B[1] & 0xFFFF0000u)};
+    const int byte0 = (cb * 8 + wq) * 4;
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+      const int64_t grow = row0 + 32 * G + rlo + 4 * hl;
+      if (grow < args.n) {
+        uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
+        const uint32_t w0 = hl ? whi[0] : wlo[0], w1 = hl ? whi[1] : wlo[1];
+        if (args.vec_store && byte0 + 8 <= args.row_bytes) {
+          *reinterpret_cast<u32x2*>(dst) = u32x2{w0, w1};
+        } else {
+#pragma unroll
+          for (int bsel = 0; bsel < 4; ++bsel) {
+            if (byte0 + bsel < args.row_bytes) dst[bsel] = (uint8_t)(w0 >> (8 * bsel));
+            if (byte0 + 4 + bsel < args.row_bytes) dst[4 + bsel] = (uint8_t)(w1 >> (8 * bsel));
+          }
+        }
+      }
+    }
+  }
+  if (args.clock_probe != nullptr && tid == 0) {
+    const unsigned long long slot = (unsigned long long)gridDim.y * gridDim.x + (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+    args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
+    args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: cosine of gathered candidates against a query.  One workgroup = one (query, slice of
 // its candidates); the query sits in LDS, each wave streams whole candidate rows (16 B per
 // lane per load, four rows in flight), reduces dot and ||c||^2 across the wave, and lane 0
@@ -1481,7 +1892,7 @@ int lshrs_debug_set_split_m(int m) {
 }
 
 int lshrs_debug_set_split_pipe(int p) {
-  if (p != 3 && p != 4) return LSHRS_E_BADARG;
+  if (p != 3 && p != 4 && p != 6) return LSHRS_E_BADARG;
   g_split_pipe = p;
   return 0;
 }
@@ -1545,6 +1956,9 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     const int64_t schunks = sig_image_floats(g) / 4;  // 16-byte chunks: same count as the f32 image
     hipLaunchKernelGGL(pack_image_bf16_kernel, dim3((unsigned)((schunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
                        rows_per_band, dim, g.bb, g.nt, g.ktiles, schunks, reinterpret_cast<u16x8*>(simage));
+    float* timage = image + sig_t16_offset_floats(g);   // the same values in 16x16x32 fragment order
+    hipLaunchKernelGGL(pack_image_bf16_t16_kernel, dim3((unsigned)((schunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                       rows_per_band, dim, g.bb, g.ktiles, schunks, reinterpret_cast<u16x8*>(timage));
   }
   return -(int)hipGetLastError();
 }
@@ -1649,7 +2063,10 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   if (g_split_m == 2) {
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles, one workgroup per CU
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
-    if (g_split_pipe == 4)
+    if (g_split_pipe == 6) {
+      a.image = base + sig_t16_offset_floats(g);
+      hipLaunchKernelGGL(sig16_kernel, grid, block, 0, s, a);                        // 16x16x32 MFMAs
+    } else if (g_split_pipe == 4)
       hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 4, 2>), grid, block, 0, s, a);   // x staged in full 128-byte lines
     else
       hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);

@@ -83,9 +83,10 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_padded_columns(0, 5) < 0
     # main image (padded columns x dim rounded up to 32) + one norm per padded column + one max-norm per column
     # block (x4); shapes wider than one 32-column tile also carry the fine (one tile per workgroup) image, and
-    # shapes of >= 256 padded columns the bf16 hi/mid image of the split-precision pass (same size again)
-    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (3 * 256 * 768 + 256 + 4 + 8) * 4
-    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (3 * 512 * 1536 + 512 + 4 + 16) * 4
+    # shapes of >= 256 padded columns the bf16 hi/mid images of the split-precision pass, in 32x32x16 and in
+    # 16x16x32 fragment order (same size again, twice)
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (4 * 256 * 768 + 256 + 4 + 8) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (4 * 512 * 1536 + 512 + 4 + 16) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (2 * 128 * 128 + 128 + 4 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0

@@ -1,0 +1,89 @@
+// Bare bf16 MFMA loops on every CU, random operands: v_mfma_f32_32x32x16_bf16 (the shape of the split-precision pass)
+// vs v_mfma_f32_16x16x32_bf16 at equal FLOPs.  Prints time, FLOP/s and the in-kernel shader clock of each.
+// build: hipcc --offload-arch=gfx950 -O3 tools/mfma_power_bench.hip -o /tmp/mfma_power_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int SHAPE>   // 0: 32x32x16, 256 accumulator registers = 16 tiles; 1: 16x16x32, 64 tiles
+__global__ __launch_bounds__(256, 1) void mfma_loop(const bf16x8* __restrict__ ops, float* __restrict__ out, int iters,
+                                                   unsigned long long* stamps) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = ops[(blockIdx.x * 256 + threadIdx.x) * 12 + i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b[i] = ops[(blockIdx.x * 256 + threadIdx.x) * 12 + 4 + i];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float sum = 0.f;
+  if (SHAPE == 0) {
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {            // 48 MFMAs = one stage of the split pass: 3 per accumulator tile
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1], b[t >> 1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t & 1], b[(t >> 1) ^ 1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 + (t & 1)], b[t >> 1], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += acc[i][lane & 15];
+  } else {
+    f32x4 acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half)      // same FLOPs as above per iteration: 2 x 96 MFMAs of half the size... x2
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+          const int c = half * 32 + t;
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t & 3], b[(t >> 2)], acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t & 3], b[(t >> 2) ^ 1], acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(t + 1) & 3], b[(t >> 2)], acc[c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) sum += acc[i][lane & 3];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * 256 + threadIdx.x] = sum;
+  if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+int main() {
+  const int blocks = 256 * 8, iters = 400;
+  std::vector<unsigned short> h((size_t)blocks * 256 * 12 * 8);
+  srand(1);
+  for (auto& v : h) { float f = (float)rand() / RAND_MAX * 2.f - 1.f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+  bf16x8* ops; float* out; unsigned long long* st;
+  hipMalloc(&ops, h.size() * 2); hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&st, (size_t)blocks * 16);
+  hipMemcpy(ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int shape = 0; shape < 2; ++shape)
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      if (shape == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(blocks), dim3(256), 0, 0, ops, out, iters, st);
+      else hipLaunchKernelGGL(mfma_loop<1>, dim3(blocks), dim3(256), 0, 0, ops, out, iters, st);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      std::vector<unsigned long long> hs((size_t)blocks * 2);
+      hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+      double cyc = 0, real = 0; for (int i = 0; i < blocks; ++i) { cyc += hs[2 * i]; real += hs[2 * i + 1]; }
+      // FLOPs: shape 0: 48 MFMAs x 32768 per wave-iteration; shape 1: 192 MFMAs x 16384
+      const double flops = (double)blocks * 4 * iters * (shape == 0 ? 48.0 * 32768 : 192.0 * 16384);
+      printf("%s rep %d: %.3f ms, %.0f TFLOP/s executed, shader clock %.2f GHz, cycles per MFMA %.1f\n",
+             shape == 0 ? "32x32x16" : "16x16x32", rep, ms, flops / ms / 1e9, cyc / real * 0.1,
+             cyc / blocks / iters / (shape == 0 ? 48.0 : 192.0));
+    }
+  return 0;
+}

@@ -6,7 +6,7 @@ Needs hipcc on the GPU box (same image).  usage: split_probes.py [pipe=3|4] [pro
 import ctypes, os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAIN = os.path.join(ROOT, "lshrs_amd/csrc/liblshrs_hip.so")
-NAMES = {0: "baseline", 1: "no fragment reads", 2: "no bf16 split", 4: "no DMA", 8: "no barrier", 16: "no x read-back",
+NAMES = {128: "16x16x32 MFMAs (wrong math)", 0: "baseline", 1: "no fragment reads", 2: "no bf16 split", 4: "no DMA", 8: "no barrier", 16: "no x read-back",
          31: "bare MFMA stream", 64: "no x pieces (pipe 3 only)"}
 
 def child(probe, pipe):
