@@ -405,3 +405,29 @@ def test_split_pass_edge_rows_and_layouts(torch_mod):
     got = hs.hash_device(odd, tie_break="none")
     sl = slice(0, 300)
     assert np.array_equal(got[sl].cpu().numpy(), chain_hash_packed(hs.projections, odd[sl].cpu().numpy()))
+
+
+def test_split_kernel_variants_agree(torch_mod):
+    """Every variant of the split-precision pass kept in the library (x in fragment-shaped pieces / in full lines, one or
+    two row tiles per wave, the 16x16x32 kernel) must give the f32 kernel's raw keys and the same stage-2 tie list size."""
+    torch = torch_mod
+    from lshrs_amd import _native
+
+    lib = _native.load()
+    cases = ((42, 16, 16, 768, 150_000), (7, 16, 32, 1536, 40_000), (3, 32, 8, 96, 180_000), (5, 16, 16, 64, 270_000))
+    try:
+        for (seed, nb, r, dim, n) in cases:
+            x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
+            x[5] = 0.0
+            x[6, 1] = float("nan")
+            want = _hasher(seed, nb, r, dim, precision="f32").hash_device(x, tie_break="none")
+            for pipe, m in ((4, 2), (3, 2), (3, 1), (6, 2)):
+                assert lib.lshrs_debug_set_split_pipe(pipe) == 0 and lib.lshrs_debug_set_split_m(m) == 0
+                hs = _hasher(seed, nb, r, dim)
+                hs.split_min_elems = 0
+                assert hs._split_applies(n)
+                got = hs.hash_device(x, tie_break="none")
+                assert torch.equal(got, want), f"pipe {pipe}, M {m}, shape {(nb, r, dim)}: {int((got != want).sum())} key bytes differ"
+    finally:
+        lib.lshrs_debug_set_split_pipe(4)
+        lib.lshrs_debug_set_split_m(2)
