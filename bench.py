@@ -177,7 +177,7 @@ def main() -> None:
         }
         if split:
             roofline = {
-                "kernel": "sig_kernel<NT=8, ALIGNED, MODE=1, W=4, PIPE=3 (bf16x3 split), M=2>  (stage 1 of the split-precision pass)",
+                "kernel": "sig16_kernel<RT=2, W=8>  (stage 1 of the split-precision pass: bf16x3 on v_mfma_f32_16x16x32_bf16)",
                 "bound": "hbm",
                 "achieved": achieved_gbs,
                 "peak": PEAK_HBM_GBS,

@@ -46,7 +46,7 @@ int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_
 int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles with fragment prefetch
 unsigned long long* g_clock_probe = nullptr;  // diagnostics only (lshrs_debug_set_clock_probe)
 int g_split_m = 2;                // row tiles per wave of the split pass (lshrs_debug_set_split_m)
-int g_split_pipe = 4;             // 3: x in fragment-shaped pieces, 4: x in full 128-byte lines (lshrs_debug_set_split_pipe)
+int g_split_pipe = 7;             // 3: x in fragment-shaped pieces, 4: x in full 128-byte lines, 6 / 7: sig16_kernel<4,4> / <2,8> (lshrs_debug_set_split_pipe)
 hipEvent_t g_split_mid_event = nullptr;       // diagnostics only: recorded once between stage 1 and stage 2
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
@@ -1249,10 +1249,21 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
   image[c] = v;
 }
 
-__global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
+// RT = 16-row tiles per wave, W = waves per workgroup (RT * W = 16: 256 rows per workgroup either way).
+//   <4, 4>: 64 rows per wave, 256 accumulator AGPRs, one wave per SIMD.
+//   <2, 8>: 32 rows per wave, 128 accumulator AGPRs, at most 256 registers -> TWO waves per SIMD that share one
+//           fragment stage: each can issue MFMAs while the other sits in a DMA issue, a barrier or its VALU slices.
+template <int RT, int W>
+__global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
+  static_assert(RT * W == 16 && (RT == 4 || RT == 2), "256 rows per workgroup");
+  constexpr int kWaveRows = 16 * RT;
+  constexpr int kPP = 16 / W;                     // fragment pieces a wave stages per stage
+  constexpr int kXPS = RT;                        // x pieces a wave stages per stage (2 RT per k-tile)
+  constexpr int kE = 6 * RT;                      // MFMAs per eighth: 2 column tiles x 3 terms x RT row tiles
+  constexpr int kSlices = 12 * RT;                // split slices per k-tile: 4 RT pairs x 3 steps
   constexpr int kPHalf = 16 * kFragFloats;        // floats of one fragment stage (16 blocks of 1 KiB)
   constexpr int kXTile = 256 * kKTile;            // floats of one x tile of the workgroup
-  constexpr int kXWave = 64 * kKTile;
+  constexpr int kXWave = kWaveRows * kKTile;
   constexpr int kRingFloats = 3 * kPHalf + 3 * kXTile;
   __shared__ __attribute__((aligned(16))) float lds[kRingFloats + 256];
   struct Bf16Pairs { bf16x2 p[4]; };
@@ -1263,35 +1274,35 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   const int r16 = lane & 15, g = lane >> 4;
   const int cb = blockIdx.y;
   const int64_t blk_row0 = (int64_t)blockIdx.x * 256;
-  const int64_t row0 = blk_row0 + wave * 64;
+  const int64_t row0 = blk_row0 + wave * kWaveRows;
   const int ktiles = args.ktiles;
   const int stages = 2 * ktiles, lasts = stages - 1;
   const char* img = reinterpret_cast<const char*>(args.image) + (size_t)cb * ktiles * 32768;
   const char* xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
 
   // loop-invariant DMA offsets (see the PIPE = 4 path of sig_kernel for the x landing image and its swizzle)
-  unsigned poff[4], xfo[8], xrd[4][2];
+  unsigned poff[kPP], xfo[2 * RT], xrd[RT][2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) poff[q] = (unsigned)(((4 * q + wave) * 64 + lane) * 16);
+  for (int q = 0; q < kPP; ++q) poff[q] = (unsigned)(((W * q + wave) * 64 + lane) * 16);
   {
     const int r8 = lane >> 3, q8 = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 2 * RT; ++j) {
       const int64_t r = row0 + 8 * j + r8;
       const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;   // clamp: loads stay in bounds, stores are masked
       xfo[j] = (unsigned)((rl * args.ldx + 4 * (q8 ^ r8 ^ (j & 1))) * 4);
     }
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int R = 16 * rt + r16, j = R >> 3, r = R & 7;       // this lane's row of row tile rt: chunks 2g, 2g+1
 #pragma unroll
       for (int c = 0; c < 2; ++c) xrd[rt][c] = (unsigned)(j * 1024 + (r * 8 + ((2 * g + c) ^ r ^ (j & 1))) * 16);
     }
   }
 
-  f32x4 acc[4][16];
+  f32x4 acc[RT][16];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ct = 0; ct < 16; ++ct) {
       acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1299,9 +1310,9 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
       // rematerialised right in front of the first accumulation would be read too early
       asm volatile("" : "+a"(acc[rt][ct]));
     }
-  float ss[4], amax[4];
+  float ss[RT], amax[RT];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) { ss[rt] = 0.f; amax[rt] = 0.f; }
+  for (int rt = 0; rt < RT; ++rt) { ss[rt] = 0.f; amax[rt] = 0.f; }
 
   unsigned long long t_shader = 0, t_real = 0;
   if (args.clock_probe != nullptr) {
@@ -1317,28 +1328,28 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
     f.pg = img + (size_t)c * 16384;
     f.xg = xblk + (size_t)t * (kKTile * 4);
     f.pdst = lds + (ns % 3) * kPHalf + wave * kFragFloats;
-    f.j0 = 4 * (s & 1);
+    f.j0 = kXPS * (s & 1);
     f.xdst = lds + 3 * kPHalf + (nt % 3) * kXTile + wave * kXWave + f.j0 * kFragFloats;
     return f;
   };
   auto issue = [&](const Dma& f, int d) {
-    if (d < 4)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + 4 * d * kFragFloats),
+    if (d < kPP)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + W * d * kFragFloats),
                                        16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[d] : xfo[d - 4])),
-                                       (LDS_AS void*)(f.xdst + (d - 4) * kFragFloats), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[kXPS + d - kPP] : xfo[d - kPP])),
+                                       (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, 0);
   };
-  f32x4 xr[4][2];                           // raw f32 x of one k-tile: [row tile][chunk]
+  f32x4 xr[RT][2];                           // raw f32 x of one k-tile: [row tile][chunk]
   auto read_x = [&](int t) {
     const char* xt = reinterpret_cast<const char*>(lds + 3 * kPHalf + (t % 3) * kXTile + wave * kXWave);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int c = 0; c < 2; ++c) xr[rt][c] = *reinterpret_cast<const f32x4*>(xt + xrd[rt][c]);
   };
   float r0 = 0.f, r1 = 0.f;
-  auto split_step = [&](int q, Bf16Pairs (&hi)[4], Bf16Pairs (&mid)[4]) {     // slice q (0..47) of one k-tile's split
+  auto split_step = [&](int q, Bf16Pairs (&hi)[RT], Bf16Pairs (&mid)[RT]) {   // slice q (0..kSlices-1) of one k-tile's split
     const int pair = q / 3, step = q % 3, rt = pair >> 2, pr = pair & 3, c = pr >> 1, e = 2 * (pr & 1);
     const float v0 = xr[rt][c][e], v1 = xr[rt][c][e + 1];
     if (step == 0) {
@@ -1366,8 +1377,8 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   // MFMA k (0..23) of an eighth: column tile ct0 + k/12, term (k/4) % 3 of xh*ph + xh*pm + xm*ph, row tile k % 4:
   // consecutive MFMAs go to different accumulator tiles (a 4-pass MFMA's result is not back in time for the next
   // instruction; hipcc pads dependent neighbours with s_nops)
-  auto mfma_one = [&](int ct0, int k, const f32x4 (&f)[2][2], const Bf16Pairs (&hi)[4], const Bf16Pairs (&mid)[4]) {
-    const int j = k / 12, term = (k / 4) % 3, rt = k % 4;
+  auto mfma_one = [&](int ct0, int k, const f32x4 (&f)[2][2], const Bf16Pairs (&hi)[RT], const Bf16Pairs (&mid)[RT]) {
+    const int j = k / (3 * RT), term = (k / RT) % 3, rt = k % RT;
     const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[rt] : hi[rt]);
     const bf16x8 b = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
     // Inline asm pins the accumulator to AGPRs and to in-place accumulation: left to the builtin, hipcc renames
@@ -1381,7 +1392,7 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   };
 
   f32x4 fa[2][2], fb[2][2];
-  Bf16Pairs hs0[4], ms0[4], hs1[4], ms1[4];   // bf16 x of the k-tiles, ping-pong by tile parity
+  Bf16Pairs hs0[RT], ms0[RT], hs1[RT], ms1[RT];   // bf16 x of the k-tiles, ping-pong by tile parity
 
   // One k-tile = two stages (column halves ch), one stage = four eighths E0..E3 of 24 MFMAs.  Every eighth's MFMAs
   // run while the next eighth's fragments are read; the last eighth of a stage is consumed after the barrier:
@@ -1389,28 +1400,28 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   //              | read E2(s) | MFMA E1(s) + DMA | read E3(s) | MFMA E2(s) + DMA | barrier(s+1)
   // The next tile's x is read in the second stage of a tile and split (48 slices) under that stage's last two
   // eighths and the first eighth after the tile boundary: it must be complete before E0 of the new tile.
-  auto stage = [&](int s, const int ch, const bool first, const Bf16Pairs (&hc)[4], const Bf16Pairs (&mc)[4],
-                   const Bf16Pairs (&hp)[4], const Bf16Pairs (&mp)[4], Bf16Pairs (&hn)[4], Bf16Pairs (&mn)[4]) {
+  auto stage = [&](int s, const int ch, const bool first, const Bf16Pairs (&hc)[RT], const Bf16Pairs (&mc)[RT],
+                   const Bf16Pairs (&hp)[RT], const Bf16Pairs (&mp)[RT], Bf16Pairs (&hn)[RT], Bf16Pairs (&mn)[RT]) {
     // hc/mc: this stage's tile; hp/mp: the tile E3(s-1) belongs to; hn/mn: where the split in flight writes
     const float* st = lds + (s % 3) * kPHalf;
     read_eighth(st, 0, fa);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < kE; ++k) {
       if (!first) mfma_one(8 * (1 - ch) + 6, k, fb, hp, mp);        // E3 of the previous stage (the other column half)
-      if (ch == 0) {                                                  // slices 32..47 of this tile's split (2 per 3 MFMAs)
-        if (k % 3 != 2) split_step(32 + (k / 3) * 2 + k % 3, hn, mn);
+      if (ch == 0) {                                                  // the last third of this tile's split (2 slices per 3 MFMAs)
+        if (k % 3 != 2) split_step(2 * kSlices / 3 + (k / 3) * 2 + k % 3, hn, mn);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
-    wait_vmcnt<4>();                                                  // own fragments of stage s+1 and every older x piece
+    wait_vmcnt<kXPS>();                                               // own fragments of stage s+1 and every older x piece
     read_eighth(st, 1, fb);
     if (ch == 1) read_x((s >> 1) + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < kE; ++k) {
       mfma_one(8 * ch + 0, k, fa, hc, mc);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1420,9 +1431,9 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
     __builtin_amdgcn_sched_barrier(0);
     const Dma f = plan(s);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < kE; ++k) {
       mfma_one(8 * ch + 2, k, fb, hc, mc);
-      if (ch == 1 && k % 3 != 2) split_step((k / 3) * 2 + k % 3, hn, mn);          // slices 0..15 of the next tile
+      if (ch == 1 && k % 3 != 2) split_step((k / 3) * 2 + k % 3, hn, mn);          // first third of the next tile's split
       if (k % 6 == 0) issue(f, k / 6);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1431,10 +1442,10 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
     read_eighth(st, 3, fb);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < kE; ++k) {
       mfma_one(8 * ch + 4, k, fa, hc, mc);
-      if (ch == 1 && k % 3 != 2) split_step(16 + (k / 3) * 2 + k % 3, hn, mn);     // slices 16..31
-      if (k % 6 == 0) issue(f, 4 + k / 6);
+      if (ch == 1 && k % 3 != 2) split_step(kSlices / 3 + (k / 3) * 2 + k % 3, hn, mn);   // second third
+      if (k % 6 == 0) issue(f, kE / 6 + k / 6);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1443,7 +1454,7 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
     __builtin_amdgcn_s_barrier();
   };
   // tile t with its sets (hc, mc); the previous tile's (hp, mp) double as the target of the next tile's split
-  auto tile = [&](int t, const bool first, Bf16Pairs (&hc)[4], Bf16Pairs (&mc)[4], Bf16Pairs (&hp)[4], Bf16Pairs (&mp)[4]) {
+  auto tile = [&](int t, const bool first, Bf16Pairs (&hc)[RT], Bf16Pairs (&mc)[RT], Bf16Pairs (&hp)[RT], Bf16Pairs (&mp)[RT]) {
     stage(2 * t, 0, first, hc, mc, hp, mp, hc, mc);       // ch 0: E3(s-1) is the previous tile's; the split in flight is this tile's
     stage(2 * t + 1, 1, false, hc, mc, hc, mc, hp, mp);   // ch 1: E3(s-1) is this tile's; the next tile's split starts (into the other set)
   };
@@ -1451,19 +1462,19 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   {
     const Dma a0 = plan(-4), a1 = plan(-3), b0 = plan(-2), b1 = plan(-1);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) issue(b0, d);                            // fragments of stage 0
+    for (int d = 0; d < kPP; ++d) issue(b0, d);                                  // fragments of stage 0
 #pragma unroll
-    for (int d = 4; d < 8; ++d) { issue(a0, d); issue(a1, d); }          // x tile 0
+    for (int d = kPP; d < kPP + kXPS; ++d) { issue(a0, d); issue(a1, d); }       // x tile 0
 #pragma unroll
-    for (int d = 0; d < 4; ++d) issue(b1, d);                            // fragments of stage 1
+    for (int d = 0; d < kPP; ++d) issue(b1, d);                                  // fragments of stage 1
 #pragma unroll
-    for (int d = 4; d < 8; ++d) { issue(b0, d); issue(b1, d); }          // x tile 1
+    for (int d = kPP; d < kPP + kXPS; ++d) { issue(b0, d); issue(b1, d); }       // x tile 1
   }
-  wait_vmcnt<12>();
+  wait_vmcnt<kPP + 2 * kXPS>();
   __builtin_amdgcn_s_barrier();
   read_x(0);
 #pragma unroll
-  for (int q = 0; q < 32; ++q) split_step(q, hs0, ms0);      // tile 0 only: the rest (32..47) rides in stage 0 as for every tile
+  for (int q = 0; q < 2 * kSlices / 3; ++q) split_step(q, hs0, ms0);   // tile 0 only: the last third rides in stage 0 as for every tile
   tile(0, true, hs0, ms0, hs1, ms1);
   int t = 1;
   for (; t + 1 < ktiles; t += 2) {
@@ -1473,10 +1484,10 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   if (t < ktiles) {                                                      // even number of k-tiles: one more, then drain with its set
     tile(t, false, hs1, ms1, hs0, ms0);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) { mfma_one(14, k, fb, hs1, ms1); asm volatile("s_nop 7\n\ts_nop 4"); }
+    for (int k = 0; k < kE; ++k) { mfma_one(14, k, fb, hs1, ms1); asm volatile("s_nop 7\n\ts_nop 4"); }
   } else {
 #pragma unroll
-    for (int k = 0; k < 24; ++k) { mfma_one(14, k, fb, hs0, ms0); asm volatile("s_nop 7\n\ts_nop 4"); }
+    for (int k = 0; k < kE; ++k) { mfma_one(14, k, fb, hs0, ms0); asm volatile("s_nop 7\n\ts_nop 4"); }
   }
   // (the wait states after every MFMA of the drain: where the two branches join hipcc may copy accumulator tiles, and
   //  it does not know that the asm in front of such a copy is an MFMA whose result takes passes to arrive)
@@ -1488,7 +1499,7 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   // order, and every read below depends on the empty asm that follows the wait states.
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ct = 0; ct < 16; ++ct) asm volatile("" : "+a"(acc[rt][ct]));
 
@@ -1499,9 +1510,9 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   }
 
   // ---- row statistics -> stage-1 window per row (as in sig_kernel's split epilogue) -----------------------
-  float* wnd_lds = lds + kRingFloats + wave * 64;
+  float* wnd_lds = lds + kRingFloats + wave * kWaveRows;
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float s2 = ss[rt] + __shfl_xor(ss[rt], 16);
     s2 += __shfl_xor(s2, 32);
     float am = __builtin_fmaxf(amax[rt], __shfl_xor(amax[rt], 16));
@@ -1529,7 +1540,7 @@ __global__ __launch_bounds__(256, 1) void sig16_kernel(const SigArgs args) {
   // accumulator register as the 32x32 epilogue.
   const float nmax = args.norm_max[cb];
 #pragma unroll
-  for (int G = 0; G < 2; ++G) {
+  for (int G = 0; G < RT / 2; ++G) {
     uint32_t A[2] = {0u, 0u}, B[2] = {0u, 0u};
 #pragma unroll
     for (int rtl = 0; rtl < 2; ++rtl) {
@@ -1892,7 +1903,7 @@ int lshrs_debug_set_split_m(int m) {
 }
 
 int lshrs_debug_set_split_pipe(int p) {
-  if (p != 3 && p != 4 && p != 6) return LSHRS_E_BADARG;
+  if (p != 3 && p != 4 && p != 6 && p != 7) return LSHRS_E_BADARG;
   g_split_pipe = p;
   return 0;
 }
@@ -2063,9 +2074,12 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   if (g_split_m == 2) {
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles, one workgroup per CU
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
-    if (g_split_pipe == 6) {
+    if (g_split_pipe == 6 || g_split_pipe == 7) {
       a.image = base + sig_t16_offset_floats(g);
-      hipLaunchKernelGGL(sig16_kernel, grid, block, 0, s, a);                        // 16x16x32 MFMAs
+      if (g_split_pipe == 6)
+        hipLaunchKernelGGL((sig16_kernel<4, 4>), grid, block, 0, s, a);               // 16x16x32 MFMAs, one wave per SIMD
+      else
+        hipLaunchKernelGGL((sig16_kernel<2, 8>), grid, dim3(512, 1, 1), 0, s, a);     // ... two waves per SIMD
     } else if (g_split_pipe == 4)
       hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 4, 2>), grid, block, 0, s, a);   // x staged in full 128-byte lines
     else

@@ -414,14 +414,15 @@ def test_split_kernel_variants_agree(torch_mod):
     from lshrs_amd import _native
 
     lib = _native.load()
-    cases = ((42, 16, 16, 768, 150_000), (7, 16, 32, 1536, 40_000), (3, 32, 8, 96, 180_000), (5, 16, 16, 64, 270_000))
+    cases = ((42, 16, 16, 768, 150_000), (7, 16, 32, 1536, 40_000), (3, 32, 8, 96, 180_000), (5, 16, 16, 64, 270_000),
+             (9, 16, 16, 32, 300_001), (11, 32, 16, 160, 70_000))      # 1 .. 48 k-tiles, 256 and 512 key columns
     try:
         for (seed, nb, r, dim, n) in cases:
             x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
             x[5] = 0.0
             x[6, 1] = float("nan")
             want = _hasher(seed, nb, r, dim, precision="f32").hash_device(x, tie_break="none")
-            for pipe, m in ((4, 2), (3, 2), (3, 1), (6, 2)):
+            for pipe, m in ((4, 2), (3, 2), (3, 1), (6, 2), (7, 2)):
                 assert lib.lshrs_debug_set_split_pipe(pipe) == 0 and lib.lshrs_debug_set_split_m(m) == 0
                 hs = _hasher(seed, nb, r, dim)
                 hs.split_min_elems = 0
@@ -429,5 +430,5 @@ def test_split_kernel_variants_agree(torch_mod):
                 got = hs.hash_device(x, tie_break="none")
                 assert torch.equal(got, want), f"pipe {pipe}, M {m}, shape {(nb, r, dim)}: {int((got != want).sum())} key bytes differ"
     finally:
-        lib.lshrs_debug_set_split_pipe(4)
+        lib.lshrs_debug_set_split_pipe(7)
         lib.lshrs_debug_set_split_m(2)
