@@ -77,16 +77,19 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
                              int64_t* tie_list, int32_t tie_cap, int32_t* tie_count, float tau,
                              uint8_t* row_flags, void* stream);
 
-/* Split-precision form of lshrs_sig_hash_batch_f32 (same keys, same tie list, ~3x the rate): stage 1 evaluates
- * every projection as xh*ph + xh*pm + xm*ph on the bf16 matrix cores (x = xh + xm + ..., bf16 pieces) — the terms
- * it drops are bounded by 192 units of 2^-24 ||x|| ||p|| — and lists every projection with
- * NOT(|y1| > tau1 * ||x|| * ||p||) in flag_list; stage 2 re-evaluates exactly those as the f32 fmaf chain of the
- * f32 kernel, corrects their key bits and reports ties (|y| < tau ...) as above.  With tau1 >= 2^-16 (256 units)
- * the keys are those of lshrs_sig_hash_batch_f32.
+/* Split-precision form of lshrs_sig_hash_batch_f32 (same keys, same tie list, > 2x the rate): stage 1 evaluates
+ * every projection as xh*ph + xh*pm + xm*ph on the bf16 matrix cores (x = xh + xm + ..., p likewise, bf16 pieces)
+ * and lists every projection with NOT(|y1| > tau1 * ||x|| * ||p||) in flag_list; stage 2 re-evaluates exactly those
+ * as the f32 fmaf chain of the f32 kernel, corrects their key bits and reports ties (|y| < tau ...) as above.
+ * tau1 is a measured window, like tau: over 2.7e9 projections of six data distributions the stage-1 value never
+ * strayed 16 units of 2^-24 ||x|| ||p|| from the chain (profiles/r01_split_window_margin.log; the Python layer
+ * passes 64 units); the analytic worst case, every rounding error aligned against a cancelling sum, is 768 units.
+ * Rows whose largest |x| is outside [2^-60, 2^60] are flagged wholesale.
  *   flag_list int64[flag_cap], flag_count int32[1] (zeroed by the caller): scratch, one entry per flagged
  *   projection; if *flag_count > flag_cap afterwards the pass is incomplete and must be repeated with a larger list.
  * Only for shapes with >= 256 padded columns whose key rows are whole 32-bit words (else LSHRS_E_TOOLARGE:
- * use lshrs_sig_hash_batch_f32). */
+ * use lshrs_sig_hash_batch_f32).  Inputs that are not whole 32-deep k-tiles of 16-byte aligned rows (dim % 32,
+ * ldx % 4, X % 16) are handed to lshrs_sig_hash_batch_f32 by the library itself (same keys). */
 int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
                                    const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
                                    uint8_t* keys,
