@@ -278,6 +278,24 @@ def main() -> None:
                       f"calls ({dt:.1f} s), host cpu_count={os.cpu_count()}",
         }
         result["speedup_vs_cpu_baseline"] = result["value"] / (m / dt)
+        # for honesty (SURVEY 8d ii): the best a CPU does with the same arithmetic - one batched sgemm on every core
+        # the process may use, then > 0 and packbits (NOT what the reference runs, and not bit-identical to it)
+        pstack = np.concatenate([np.asarray(p, dtype=np.float32) for p in hasher.projections])
+        (xs[:2000] @ pstack.T)
+        t0 = time.perf_counter()
+        bits = (xs @ pstack.T) > 0
+        np.packbits(bits.reshape(m, BANDS, ROWS), axis=2, bitorder="little")
+        dt2 = time.perf_counter() - t0
+        try:
+            from lshrs_amd._hostblas import _core_budget
+            cores = _core_budget()
+        except Exception:  # pragma: no cover
+            cores = os.cpu_count()
+        result["cpu_best_effort"] = {
+            "value": m / dt2, "unit": "vectors/s", "cores": cores, "kind": "port",
+            "sample": f"same {m} rows: one batched X @ P.T (OpenBLAS sgemm, all cores of the process's budget), > 0, packbits "
+                      f"({dt2:.2f} s); not the reference's per-vector path and not bit-identical to it",
+        }
 
     # ---------------- second metric: cosine rerank (config 3), N=1 only ----------------
     if rank == 0 and world == 1 and not args.no_rerank:
