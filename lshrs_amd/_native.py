@@ -138,7 +138,7 @@ def load() -> ctypes.CDLL:
         # tuning knobs for A/B experiments (kernel variants are otherwise chosen inside the library)
         for env, fn in (("LSHRS_SIG_PIPE", "lshrs_debug_set_sig_pipe"), ("LSHRS_SIG_WAVES", "lshrs_debug_set_sig_waves"),
                         ("LSHRS_SIG_FINE", "lshrs_debug_set_sig_fine"), ("LSHRS_SPLIT_M", "lshrs_debug_set_split_m"),
-                        ("LSHRS_SPLIT_PIPE", "lshrs_debug_set_split_pipe")):
+                        ("LSHRS_SPLIT_PIPE", "lshrs_debug_set_split_pipe"), ("LSHRS_FIX_MODE", "lshrs_debug_set_fix_mode")):
             if os.environ.get(env) and hasattr(lib, fn):
                 if getattr(lib, fn)(int(os.environ[env])) != 0:
                     raise NativeLibraryError(f"bad value for {env}")

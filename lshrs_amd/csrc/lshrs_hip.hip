@@ -49,6 +49,7 @@ int g_split_m = 2;                // row tiles per wave of the split pass (lshrs
 int g_split_pipe = 7;             // 3: x in fragment-shaped pieces, 4: x in full 128-byte lines, 6 / 7: sig16_kernel<4,4> / <2,8> (lshrs_debug_set_split_pipe)
 hipEvent_t g_split_mid_event = nullptr;       // diagnostics only: recorded once between stage 1 and stage 2
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
+int g_fix_mode = 1;               // stage 2 of the split pass: 1 = eight flagged projections per wave, 0 = one (lshrs_debug_set_fix_mode)
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
 struct SigGeom {
@@ -1117,6 +1118,85 @@ __global__ __launch_bounds__(64) void sig_fix_kernel(const FixArgs a) {
   }
 }
 
+// The same stage 2 with EIGHT flagged projections per wave (the default).  One wave per projection has all 64 lanes
+// issue the same 2 x dim dependent fmas: at ~5 700 flagged projections per 262 144-row chunk that is 5-6 waves per
+// SIMD x 6 k issue cycles, i.e. the kernel is bound by redundant VALU issue (measured 33 us per chunk).  Here lane
+// (sub, g) = (lane >> 3, lane & 7) works for projection g of the wave's group: the eight 16-byte chunks (sub) of a
+// k-tile of x row g and of hyperplane column g go HBM/L2 -> LDS by LDS-DMA, landing as [k-tile][chunk][g] (one
+// instruction = one k-tile of all eight projections = 1 KiB), and every lane then runs the canonical chain of ITS g
+// from ds_read_b128s that hit eight distinct 16-byte slots (the eight lanes sharing a g read the same slot: broadcast).
+// 1/8 of the waves, the same chain length per wave: one resident round of 768 waves covers a chunk's list.
+constexpr int kFixG = 8;
+constexpr int kFixSlabG = 24;      // k-tiles per slab: 2 x 24 x 8 chunks x 8 projections x 16 B = 48 KiB of LDS per wave
+constexpr int kFixGridG = 768;     // 256 CUs x 3 resident single-wave workgroups
+__global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
+  __shared__ __attribute__((aligned(16))) f32x4 xs[kFixSlabG * 8 * kFixG];
+  __shared__ __attribute__((aligned(16))) f32x4 ps[kFixSlabG * 8 * kFixG];
+  const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
+  const int shh = sub >> 2, sq = sub & 3;           // this lane's chunk of every k-tile: k = 32 t + 16 shh + 4 sq + 0..3
+  const int cnt = min(*a.flag_count, a.flag_cap);
+  const int groups = (cnt + kFixG - 1) / kFixG;
+  const size_t kt_stride = (size_t)a.nt * 4 * kFragFloats;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {   // uniform per wave
+    const int e = grp * kFixG + g;
+    const int64_t item = a.flag_list[e < cnt ? e : grp * kFixG];  // a short last group re-does its first entry, unused
+    const int64_t row = item >> 21;                 // relative to this launch's X / keys
+    const int col_raw = (int)(item & ((1 << 21) - 1));
+    const bool live = e < cnt && col_raw < a.padcols;
+    const int col = col_raw < a.padcols ? col_raw : 0;
+    const int word = col >> 5, c = col & 31;
+    const int cb = word / a.nt, jt = word % a.nt;
+    const float* __restrict__ xg = a.X + row * a.ldx + 16 * shh + 4 * sq;
+    const float* __restrict__ pg =
+        a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats + ((sq * 64) + shh * 32 + c) * 4;
+    float acc = 0.f, ss = 0.f;
+    for (int t0 = 0; t0 < a.ktiles; t0 += kFixSlabG) {
+      const int tiles = a.ktiles - t0 < kFixSlabG ? a.ktiles - t0 : kFixSlabG;
+      for (int i = 0; i < tiles; ++i) {            // nothing lands in a VGPR: every load of the slab is in flight at once
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + (size_t)(t0 + i) * kKTile),
+                                         (LDS_AS void*)(xs + i * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + (size_t)(t0 + i) * kt_stride),
+                                         (LDS_AS void*)(ps + i * 64), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 2
+      for (int t = 0; t < tiles; ++t) {
+        f32x4 p4[2][4], x4[2][4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            x4[hh][q] = xs[(t * 8 + hh * 4 + q) * kFixG + g];
+            p4[hh][q] = ps[(t * 8 + hh * 4 + q) * kFixG + g];
+          }
+        fix_chain_tile(p4, x4, acc, ss);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab has been read before the next one lands on it
+    }
+    if (sub != 0 || !live) continue;
+    uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
+    unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
+    const unsigned int bitmask = 1u << (8 * (unsigned)(addr & 3) + (col & 7));
+    const bool want = acc > 0.f;
+    const bool have = (*kb >> (col & 7)) & 1;
+    if (want != have) {
+      if (want) atomicOr(w32, bitmask);
+      else atomicAnd(w32, ~bitmask);
+    }
+    if (a.tie_list != nullptr) {
+      const float thr = a.tau * sqrtf(ss) * a.norms[col];
+      if (__builtin_fabsf(acc) < thr) {
+        const int slot = atomicAdd(a.tie_count, 1);
+        if (slot < a.tie_cap) {
+          a.tie_list[2 * (int64_t)slot] = (row + a.row_base) * 65536 + word;
+          a.tie_list[2 * (int64_t)slot + 1] = (int64_t)(1u << c);
+        }
+      }
+    }
+  }
+}
+
 template <int NT, int W>
 int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
   const int mode = project ? 2 : (a.tie_list != nullptr ? 1 : 0);
@@ -1915,6 +1995,12 @@ int lshrs_debug_set_split_mid_event(void* event) {
   return 0;
 }
 
+int lshrs_debug_set_fix_mode(int m) {
+  if (m != 0 && m != 1) return LSHRS_E_BADARG;
+  g_fix_mode = m;
+  return 0;
+}
+
 int lshrs_debug_set_sig_fine(int f) {
   if (f < 0 || f > 2) return LSHRS_E_BADARG;
   g_sig_fine = f;
@@ -2115,7 +2201,11 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   f.tie_cap = tie_cap;
   f.tie_count = tie_count;
   f.tau = tau;
-  {
+  if (g_fix_mode != 0) {
+    const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
+    const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
+    hipLaunchKernelGGL(sig_fix8_kernel, grid, block, 0, s, f);
+  } else {
     const int64_t want = (int64_t)flag_cap < kFixGrid ? (int64_t)flag_cap : kFixGrid;
     const dim3 grid((unsigned)(want < 1 ? 1 : want)), block(64);
     hipLaunchKernelGGL(sig_fix_kernel, grid, block, 0, s, f);
