@@ -128,9 +128,16 @@ def main() -> None:
         elapsed = float(t.item())
     # the step cuts its batch into chunks (one signature pass each): time every launch, weight by its rows.
     # Split-precision pass: start..mid = stage 1 (the dominant kernel), mid..end = sig_fix_kernel.
+    # An entry is (start, end, rows, mid) HIP events recorded by the Python driver, or (stage-1 ms, None, rows, fix-up
+    # ms) measured with HIP events on the launch stream by the library's own driver (csrc/pipeline.hip).
     split = bool(events) and all(e[3] is not None for e in events)
-    kernel_ms = [(e[0].elapsed_time(e[3]) if split else e[0].elapsed_time(e[1])) for e in events]
-    fix_ms = [e[3].elapsed_time(e[1]) for e in events] if split else []
+    native = bool(events) and isinstance(events[0][0], float)
+    if native:
+        kernel_ms = [e[0] for e in events]
+        fix_ms = [e[3] for e in events] if split else []
+    else:
+        kernel_ms = [(e[0].elapsed_time(e[3]) if split else e[0].elapsed_time(e[1])) for e in events]
+        fix_ms = [e[3].elapsed_time(e[1]) for e in events] if split else []
     kernel_rows = [e[2] for e in events]
     kernel_ms_total = sum(kernel_ms)
     kernel_ms_mean = kernel_ms_total / max(1, len(kernel_ms))
@@ -236,6 +243,7 @@ def main() -> None:
                 "total_rows": total_rows, "sharding": f"row-sharded x{world}, replicated hyperplanes, no collective",
                 "tie_break": hasher.tie_break, "tau_ulps": hasher.tau_ulps,
                 "precision": hasher.precision, "tau1_ulps": hasher.tau1_ulps, "pipeline_chunk_rows": hasher.pipeline_chunk_rows,
+                "pipeline_driver": stats.get("pipeline", "python"),
             },
             "roofline": roofline,
             "roofline_f32_kernel": None if f32_ms is None else {

@@ -123,6 +123,44 @@ int lshrs_scatter_band_keys_u8(uint8_t* keys, int32_t num_bands, int32_t band_by
                                const int64_t* rows, const int32_t* bands, const uint8_t* patch, int64_t m,
                                void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Native driver of the bit-exact signature path for large device-resident batches — the host side of
+ * LSHRS.index / create_signatures hashing a whole loader batch (lshrs/core/main.py:1125-1143 → lsh.py:136-169)
+ * with the tie-break overlapped: per chunk  signature pass → (side stream) tie entries + their vectors straight
+ * into pinned host memory → `resolve` (the reference's own BLAS call, lshrs_tb_resolve of lshrs_host.h) →
+ * (side stream) scatter of the patched band keys.  The GPU is kept two chunks ahead of the host.
+ * The pipeline object is the one exception to "the library allocates nothing": it owns three slots of device
+ * scratch (tie list, stage-1 list), their pinned host mirrors, one high-priority side stream and its events.
+ * ------------------------------------------------------------------------------------------ */
+
+/* == lshrs_tb_resolve (lshrs_host.h); passed as a pointer so that this library does not link the host engine. */
+typedef int (*lshrs_tie_resolve_fn)(void* engine, const float* planes, int32_t num_bands, int32_t rows_per_band,
+                                    int32_t dim, const int64_t* entries, int64_t n_entries, const float* xstage,
+                                    int64_t ldx, int64_t* out_rows, int32_t* out_bands, uint8_t* out_keys,
+                                    int64_t out_cap, int64_t* n_pairs);
+
+/* Create a pipeline on the CURRENT device for hashers of this shape.  tie_cap / flag_cap: room per chunk for tie
+ * entries / stage-1 entries (flag_cap may be 0 when the split pass will never be asked for).  NULL on failure. */
+void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, int32_t tie_cap, int32_t flag_cap);
+void lshrs_pipe_destroy(void* pipe);
+
+#define LSHRS_PIPE_STATS 12
+/* Hash rows [bounds[c], bounds[c+1]) for c < n_chunks (bounds ascending, bounds[0] = 0) of X into keys, tie-break
+ * included.  Arguments as lshrs_sig_hash_batch_f32 / _split_f32; chunk_split[c] != 0 asks for the split pass on
+ * chunk c.  planes: HOST (num_bands, rows_per_band, dim) f32, the hyperplanes `resolve` multiplies with.
+ * Blocks the calling thread until the last chunk's patches have been enqueued; on return `stream` has been made to
+ * wait for them (no device-wide synchronisation).  One call at a time per pipeline.
+ *   chunk_status[c]  0 done; 1 more ties than tie_cap, 2 more stage-1 entries than flag_cap: keys of that chunk are
+ *                    NOT final, the caller redoes it with room (lshrs_sig_hash_batch_f32 + its own tie-break)
+ *   chunk_ms         optional float[2 * n_chunks]: HIP-event times of (stage 1 | whole pass, fix-up or -1) per chunk
+ *   stats            optional int64[LSHRS_PIPE_STATS]: tie entries, tie pairs, largest stage-1 count, then ns:
+ *                    entry→first launch, Σ enqueue, Σ wait for a chunk, Σ resolve, Σ scatter launch, entry→last
+ *                    chunk exported, total; [10..11] reserved */
+int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* workspace, uint8_t* keys,
+                        uint8_t* row_flags, float tau, float tau1, const int64_t* bounds, const uint8_t* chunk_split,
+                        int32_t n_chunks, lshrs_tie_resolve_fn resolve, void* engine, const float* planes,
+                        int32_t* chunk_status, float* chunk_ms, int64_t* stats, void* stream);
+
 /* Storage-op path: hex[2i], hex[2i+1] = lower-case hex digits of keys[i] — the text
  * `hash_val.hex()` puts into the reference's bucket key `{prefix}:{band}:bucket:{hex}`
  * (lshrs/storage/redis.py:225), for all N x bands keys in one pass. */

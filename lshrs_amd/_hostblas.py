@@ -158,7 +158,13 @@ class TieBreakEngine:
         if not self._handle:
             raise OSError(f"could not map a private copy of {self.blas_path}")
         self.threads = int(self._lib.lshrs_tb_threads(self._handle))
+        # for the native pipeline driver (lshrs_pipe_hash_f32 calls lshrs_tb_resolve through this pointer)
+        self.resolve_fn = ctypes.cast(self._lib.lshrs_tb_resolve, ctypes.c_void_p).value
         self._shape_ok: Dict[Tuple[int, int], bool] = {}
+
+    @property
+    def handle(self) -> int:
+        return self._handle
 
     def close(self) -> None:
         if self._handle:

@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCE = os.path.join(CSRC, "lshrs_hip.hip")
+SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
 LIBRARY = os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 ABI_VERSION = 1
@@ -33,21 +34,34 @@ class NativeLibraryError(RuntimeError):
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP source for gfx950 into the in-tree shared library (and the host tie-break engine)."""
+    """Compile the HIP sources for gfx950 into the in-tree shared library (and the host tie-break engine).
+    One object per translation unit (kernels + C ABI, native pipeline driver), rebuilt only when stale."""
     from . import _hostblas
 
     _hostblas.build(force=force, verbose=verbose)
     with _lock:
-        newest_src = max(os.path.getmtime(SOURCE), os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h")))
-        if not force and os.path.exists(LIBRARY) and os.path.getmtime(LIBRARY) >= newest_src:
-            return LIBRARY
+        header = os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h"))
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, SOURCE,
-               "-o", LIBRARY + ".tmp"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        os.replace(LIBRARY + ".tmp", LIBRARY)
+        objdir = os.path.join(CSRC, "_obj")
+        os.makedirs(objdir, exist_ok=True)
+        objects, relink = [], force or not os.path.exists(LIBRARY)
+        for src in SOURCES:
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            objects.append(obj)
+            if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), header):
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-c", src,
+                       "-o", obj + ".tmp"]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True)
+                os.replace(obj + ".tmp", obj)
+                relink = True
+        if relink or os.path.getmtime(LIBRARY) < max(os.path.getmtime(o) for o in objects):
+            cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objects, "-o", LIBRARY + ".tmp"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(LIBRARY + ".tmp", LIBRARY)
         return LIBRARY
 
 
@@ -85,6 +99,12 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_topk_workspace_bytes.restype = i64
     lib.lshrs_topk_desc_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     lib.lshrs_topk_desc_f32.restype = c.c_int
+    lib.lshrs_pipe_create.argtypes = [i32, i32, i32, i32, i32]
+    lib.lshrs_pipe_create.restype = vp
+    lib.lshrs_pipe_destroy.argtypes = [vp]
+    lib.lshrs_pipe_destroy.restype = None
+    lib.lshrs_pipe_hash_f32.argtypes = [vp, vp, i64, vp, vp, vp, f32, f32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.lshrs_pipe_hash_f32.restype = c.c_int
 
 
 EXPORTS = (
@@ -103,6 +123,9 @@ EXPORTS = (
     "lshrs_l2_normalize_f32",
     "lshrs_topk_workspace_bytes",
     "lshrs_topk_desc_f32",
+    "lshrs_pipe_create",
+    "lshrs_pipe_destroy",
+    "lshrs_pipe_hash_f32",
 )
 
 

@@ -1,0 +1,379 @@
+// pipeline.hip — native driver of the bit-exact signature path for large device-resident batches
+// (C ABI: lshrs_pipe_* in include/lshrs_hip.h; design: DESIGN.md "Host pipeline").
+//
+// Per chunk:   caller's stream : signature pass (split-precision or f32 kernel; lshrs_hip.hip)
+//              side stream     : export_ties_kernel — tie entries, their X rows and both counters written
+//                                straight into pinned host memory (count read on the device: one wait on the
+//                                host instead of count round trip + sized copies)
+//              host            : resolve() = the reference's own BLAS call on the flagged (row, band) pairs
+//                                (lshrs_tb_resolve, liblshrs_host.so), patches land in pinned memory
+//              side stream     : scatter_keys_kernel reads the patches from that pinned memory
+// The GPU is kept two chunks ahead of the host; three slots of scratch rotate.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <chrono>
+#include <new>
+
+#include "lshrs_hip.h"
+
+extern "C" int lshrs_debug_set_split_mid_event(void* event);   // lshrs_hip.hip: recorded once between stage 1 and 2
+
+namespace {
+
+constexpr int kSlots = 3;
+constexpr int kAhead = 2;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Entry e < min(*tie_count, tie_cap): host_entries[e] = tie_list[e], host_rows[e] = X[row of e] (dim floats,
+// contiguous).  host_counts = (ties wanted, stage-1 entries wanted).  All destinations are pinned host memory.
+// One WAVE per entry, few workgroups: the kernel runs beside the next chunk's signature pass, whose workgroups need
+// a CU's whole register file — every CU that holds an export wave is closed to them until that wave retires, and
+// the export is PCIe-bound (~40 us per 262 144-row chunk) however many CUs it sits on.  (512 workgroups cost the
+// signature pass 14 us per chunk; kExportBlocks keep at most that many CUs busy and still saturate the link.)
+constexpr int kExportBlocks = 16;
+template <bool VEC>
+__global__ __launch_bounds__(256) void export_ties_kernel(const float* __restrict__ X, int64_t ldx, int dim,
+                                                          const int64_t* __restrict__ tie_list,
+                                                          const int32_t* __restrict__ counts, int tie_cap,
+                                                          int64_t* __restrict__ host_entries,
+                                                          float* __restrict__ host_rows,
+                                                          int32_t* __restrict__ host_counts) {
+  const int wanted = counts[0];
+  const int cnt = wanted < tie_cap ? wanted : tie_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    host_counts[0] = wanted;
+    host_counts[1] = counts[1];
+  }
+  const int lane = threadIdx.x & 63;
+  const int waves = gridDim.x * (blockDim.x >> 6);
+  for (int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < cnt; e += waves) {
+    const int64_t e0 = tie_list[2 * (int64_t)e], e1 = tie_list[2 * (int64_t)e + 1];
+    if (lane == 0) {
+      host_entries[2 * (int64_t)e] = e0;
+      host_entries[2 * (int64_t)e + 1] = e1;
+    }
+    const float* __restrict__ src = X + (e0 >> 16) * ldx;
+    float* __restrict__ dst = host_rows + (int64_t)e * dim;
+    if (VEC) {
+      const int n4 = dim >> 2;
+      for (int k0 = 0; k0 < n4; k0 += 256) {        // four 16-byte loads per lane in flight, then their stores
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + 64 * j + lane;
+          v[j] = reinterpret_cast<const f32x4*>(src)[k < n4 ? k : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + 64 * j + lane;
+          if (k < n4) reinterpret_cast<f32x4*>(dst)[k] = v[j];
+        }
+      }
+    } else {
+      for (int k = lane; k < dim; k += 64) dst[k] = src[k];
+    }
+  }
+}
+
+struct Slot {
+  int64_t* tie_list = nullptr;     // device
+  int64_t* flag_list = nullptr;    // device
+  int32_t* h_counts = nullptr;     // pinned: (ties wanted, stage-1 entries wanted)
+  int64_t* h_entries = nullptr;    // pinned int64[tie_cap][2]
+  float* h_rows = nullptr;         // pinned float[tie_cap][dim]
+  uint8_t* h_patch = nullptr;      // pinned: rows int64[pairs_cap] | bands int32[pairs_cap] | keys u8[pairs_cap * bb]
+  hipEvent_t fix_done = nullptr, exported = nullptr, scattered = nullptr;
+  hipEvent_t t_start = nullptr, t_mid = nullptr, t_end = nullptr;
+  bool scatter_pending = false;
+};
+
+struct Pipe {
+  int device = 0;
+  int nb = 0, r = 0, dim = 0, bb = 0;
+  int tie_cap = 0, flag_cap = 0;
+  int64_t pairs_cap = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t done = nullptr;
+  int32_t* d_counts = nullptr;     // device int32[2 * counts_cap]: (tie count, stage-1 count) per chunk of a call
+  int counts_cap = 0;
+  int export_blocks = kExportBlocks;
+  Slot slot[kSlots];
+};
+
+inline int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch())
+      .count();
+}
+
+void pipe_free(Pipe* p) {
+  if (p == nullptr) return;
+  for (Slot& s : p->slot) {
+    if (s.tie_list) (void)hipFree(s.tie_list);
+    if (s.flag_list) (void)hipFree(s.flag_list);
+    if (s.h_counts) (void)hipHostFree(s.h_counts);
+    if (s.h_entries) (void)hipHostFree(s.h_entries);
+    if (s.h_rows) (void)hipHostFree(s.h_rows);
+    if (s.h_patch) (void)hipHostFree(s.h_patch);
+    for (hipEvent_t e : {s.fix_done, s.exported, s.scattered, s.t_start, s.t_mid, s.t_end})
+      if (e) (void)hipEventDestroy(e);
+  }
+  if (p->d_counts) (void)hipFree(p->d_counts);
+  if (p->done) (void)hipEventDestroy(p->done);
+  if (p->side) (void)hipStreamDestroy(p->side);
+  delete p;
+}
+
+#define PIPE_TRY(expr)                    \
+  do {                                    \
+    const hipError_t e_ = (expr);         \
+    if (e_ != hipSuccess) {               \
+      rc = -(int)e_;                      \
+      goto fail;                          \
+    }                                     \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, int32_t tie_cap, int32_t flag_cap) {
+  if (num_bands <= 0 || rows_per_band <= 0 || dim <= 0 || tie_cap <= 0 || flag_cap < 0) return nullptr;
+  Pipe* p = new (std::nothrow) Pipe();
+  if (p == nullptr) return nullptr;
+  int rc = 0;
+  p->nb = num_bands;
+  p->r = rows_per_band;
+  p->dim = dim;
+  p->bb = (rows_per_band + 7) / 8;
+  p->tie_cap = tie_cap;
+  p->flag_cap = flag_cap;
+  // a 32-column word of the tie list touches up to 32 / (columns per band) bands
+  {
+    const int per_word = 32 / (8 * p->bb) > 1 ? 32 / (8 * p->bb) : 1;
+    p->pairs_cap = ((int64_t)tie_cap * per_word + 7) / 8 * 8;
+  }
+  if (const char* v = getenv("LSHRS_EXPORT_BLOCKS")) {   // A/B knob
+    const int b = atoi(v);
+    if (b >= 1 && b <= 4096) p->export_blocks = b;
+  }
+  PIPE_TRY(hipGetDevice(&p->device));
+  {
+    int lo = 0, hi = 0;   // (numerically lowest = highest priority)
+    PIPE_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* v = getenv("LSHRS_SIDE_PRIORITY");          // A/B knob: "low" / "normal"; default high
+    const int prio = (v != nullptr && v[0] == 'l') ? lo : ((v != nullptr && v[0] == 'n') ? 0 : hi);
+    PIPE_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio));
+  }
+  PIPE_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+  for (Slot& s : p->slot) {
+    PIPE_TRY(hipMalloc(&s.tie_list, sizeof(int64_t) * 2 * (size_t)tie_cap));
+    if (flag_cap > 0) PIPE_TRY(hipMalloc(&s.flag_list, sizeof(int64_t) * (size_t)flag_cap));
+    PIPE_TRY(hipHostMalloc(&s.h_counts, 64, hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(&s.h_entries, sizeof(int64_t) * 2 * (size_t)tie_cap, hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(&s.h_rows, sizeof(float) * (size_t)tie_cap * dim, hipHostMallocDefault));
+    PIPE_TRY(hipHostMalloc(&s.h_patch, (size_t)(12 + p->bb) * p->pairs_cap, hipHostMallocDefault));
+    PIPE_TRY(hipEventCreateWithFlags(&s.fix_done, hipEventDisableTiming));
+    PIPE_TRY(hipEventCreateWithFlags(&s.exported, hipEventDisableTiming));
+    PIPE_TRY(hipEventCreateWithFlags(&s.scattered, hipEventDisableTiming));
+    PIPE_TRY(hipEventCreate(&s.t_start));
+    PIPE_TRY(hipEventCreate(&s.t_mid));
+    PIPE_TRY(hipEventCreate(&s.t_end));
+  }
+  return p;
+fail:
+  (void)rc;
+  pipe_free(p);
+  return nullptr;
+}
+
+void lshrs_pipe_destroy(void* pipe) {
+  Pipe* p = static_cast<Pipe*>(pipe);
+  if (p == nullptr) return;
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  (void)hipSetDevice(p->device);
+  (void)hipStreamSynchronize(p->side);
+  pipe_free(p);
+  if (have) (void)hipSetDevice(cur);
+}
+
+int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* workspace, uint8_t* keys,
+                        uint8_t* row_flags, float tau, float tau1, const int64_t* bounds, const uint8_t* chunk_split,
+                        int32_t n_chunks, lshrs_tie_resolve_fn resolve, void* engine, const float* planes,
+                        int32_t* chunk_status, float* chunk_ms, int64_t* stats, void* stream) {
+  const int64_t t_entry = now_ns();
+  Pipe* p = static_cast<Pipe*>(pipe);
+  if (p == nullptr || X == nullptr || workspace == nullptr || keys == nullptr || bounds == nullptr ||
+      chunk_split == nullptr || resolve == nullptr || planes == nullptr || chunk_status == nullptr || n_chunks < 0 ||
+      ldx < p->dim)
+    return LSHRS_E_BADARG;
+  if (stats != nullptr)
+    for (int i = 0; i < LSHRS_PIPE_STATS; ++i) stats[i] = 0;
+  if (n_chunks == 0) return 0;
+  if (bounds[0] != 0) return LSHRS_E_BADARG;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (bounds[c + 1] <= bounds[c]) return LSHRS_E_BADARG;
+    if (chunk_split[c] != 0 && p->flag_cap <= 0) return LSHRS_E_BADARG;
+    chunk_status[c] = 0;
+  }
+  hipStream_t main = static_cast<hipStream_t>(stream);
+  const int row_bytes = p->nb * p->bb;
+  const bool vec = (p->dim % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  int rc = 0;
+  int64_t s_ties = 0, s_pairs = 0, s_flagmax = 0, t_head = 0, t_enq = 0, t_wait = 0, t_res = 0, t_scat = 0, t_tail = 0;
+  int enqueued = 0;
+
+  {
+    int cur = 0;
+    PIPE_TRY(hipGetDevice(&cur));
+    if (cur != p->device) return LSHRS_E_BADARG;
+  }
+  if (n_chunks > p->counts_cap) {
+    // (grows only on a batch with more chunks than any before it; nothing of an earlier call is in flight on it:
+    // every export of that call was waited for)
+    if (p->d_counts) (void)hipFree(p->d_counts);
+    p->d_counts = nullptr;
+    p->counts_cap = 0;
+    const int want = n_chunks < 64 ? 64 : n_chunks;
+    PIPE_TRY(hipMalloc(&p->d_counts, sizeof(int32_t) * 2 * (size_t)want));
+    p->counts_cap = want;
+  }
+  PIPE_TRY(hipMemsetAsync(p->d_counts, 0, sizeof(int32_t) * 2 * (size_t)n_chunks, main));
+
+  {
+    auto enqueue = [&](int c) -> int {
+      Slot& s = p->slot[c % kSlots];
+      const int64_t lo = bounds[c], hi = bounds[c + 1];
+      const float* xs = X + lo * ldx;
+      uint8_t* ks = keys + lo * row_bytes;
+      uint8_t* fl = row_flags != nullptr ? row_flags + lo : nullptr;
+      int32_t* cnt = p->d_counts + 2 * (size_t)c;
+      hipError_t e;
+      if (chunk_ms != nullptr) {
+        if ((e = hipEventRecord(s.t_start, main)) != hipSuccess) return -(int)e;
+        if (chunk_split[c]) (void)lshrs_debug_set_split_mid_event(s.t_mid);
+      }
+      int r;
+      if (chunk_split[c])
+        r = lshrs_sig_hash_batch_split_f32(xs, hi - lo, ldx, workspace, p->nb, p->r, p->dim, ks, s.tie_list, p->tie_cap,
+                                           cnt, tau, fl, s.flag_list, p->flag_cap, cnt + 1, tau1, stream);
+      else
+        r = lshrs_sig_hash_batch_f32(xs, hi - lo, ldx, workspace, p->nb, p->r, p->dim, ks, s.tie_list, p->tie_cap, cnt,
+                                     tau, fl, stream);
+      (void)lshrs_debug_set_split_mid_event(nullptr);   // (a split call that fell through to the f32 kernel left it set)
+      if (r != 0) return r;
+      if (chunk_ms != nullptr && (e = hipEventRecord(s.t_end, main)) != hipSuccess) return -(int)e;
+      if ((e = hipEventRecord(s.fix_done, main)) != hipSuccess) return -(int)e;
+      if ((e = hipStreamWaitEvent(p->side, s.fix_done, 0)) != hipSuccess) return -(int)e;
+      const int blocks = p->export_blocks;
+      if (vec)
+        hipLaunchKernelGGL(export_ties_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, p->side, xs, ldx, p->dim,
+                           s.tie_list, cnt, p->tie_cap, s.h_entries, s.h_rows, s.h_counts);
+      else
+        hipLaunchKernelGGL(export_ties_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, p->side, xs, ldx, p->dim,
+                           s.tie_list, cnt, p->tie_cap, s.h_entries, s.h_rows, s.h_counts);
+      if ((e = hipGetLastError()) != hipSuccess) return -(int)e;
+      if ((e = hipEventRecord(s.exported, p->side)) != hipSuccess) return -(int)e;
+      ++enqueued;
+      return 0;
+    };
+
+    for (int c = 0; c < n_chunks && c < kAhead; ++c) {
+      if ((rc = enqueue(c)) != 0) goto fail;
+      if (c == 0) t_head = now_ns() - t_entry;
+    }
+    for (int c = 0; c < n_chunks; ++c) {
+      Slot& s = p->slot[c % kSlots];
+      int64_t t0 = now_ns();
+      PIPE_TRY(hipEventSynchronize(s.exported));
+      int64_t t1 = now_ns();
+      t_wait += t1 - t0;
+      if (c == n_chunks - 1) t_tail = t1 - t_entry;
+      if (chunk_ms != nullptr) {
+        float a = -1.f, b = -1.f;
+        if (chunk_split[c] && hipEventQuery(s.t_mid) == hipSuccess &&
+            hipEventElapsedTime(&a, s.t_start, s.t_mid) == hipSuccess &&
+            hipEventElapsedTime(&b, s.t_mid, s.t_end) == hipSuccess) {
+          chunk_ms[2 * c] = a;
+          chunk_ms[2 * c + 1] = b;
+        } else {
+          (void)hipGetLastError();
+          PIPE_TRY(hipEventElapsedTime(&a, s.t_start, s.t_end));
+          chunk_ms[2 * c] = a;
+          chunk_ms[2 * c + 1] = -1.f;
+        }
+      }
+      if (c + kAhead < n_chunks) {
+        if ((rc = enqueue(c + kAhead)) != 0) goto fail;
+      }
+      t0 = now_ns();
+      t_enq += t0 - t1;
+      const int64_t wanted = s.h_counts[0], flagged = s.h_counts[1];
+      if (flagged > s_flagmax) s_flagmax = flagged;
+      if (chunk_split[c] && flagged > p->flag_cap) {
+        chunk_status[c] = 2;
+        continue;
+      }
+      if (wanted > p->tie_cap) {
+        chunk_status[c] = 1;
+        continue;
+      }
+      if (wanted <= 0) continue;
+      if (s.scatter_pending) {   // (three chunks ago: long finished)
+        PIPE_TRY(hipEventSynchronize(s.scattered));
+        s.scatter_pending = false;
+      }
+      int64_t* p_rows = reinterpret_cast<int64_t*>(s.h_patch);
+      int32_t* p_bands = reinterpret_cast<int32_t*>(s.h_patch + 8 * p->pairs_cap);
+      uint8_t* p_keys = s.h_patch + 12 * p->pairs_cap;
+      int64_t m = 0;
+      const int rr = resolve(engine, planes, p->nb, p->r, p->dim, s.h_entries, wanted, s.h_rows, p->dim, p_rows, p_bands,
+                             p_keys, p->pairs_cap, &m);
+      t1 = now_ns();
+      t_res += t1 - t0;
+      if (rr != 0) {             // (more pairs than the patch slot holds: the caller redoes the chunk with room)
+        chunk_status[c] = 1;
+        continue;
+      }
+      s_ties += wanted;
+      s_pairs += m;
+      if (m > 0) {
+        if ((rc = lshrs_scatter_band_keys_u8(keys + bounds[c] * row_bytes, p->nb, p->bb, p_rows, p_bands, p_keys, m,
+                                             p->side)) != 0)
+          goto fail;
+        PIPE_TRY(hipEventRecord(s.scattered, p->side));
+        s.scatter_pending = true;
+      }
+      t_scat += now_ns() - t1;
+    }
+    PIPE_TRY(hipEventRecord(p->done, p->side));
+    PIPE_TRY(hipStreamWaitEvent(main, p->done, 0));
+  }
+  if (stats != nullptr) {
+    stats[0] = s_ties;
+    stats[1] = s_pairs;
+    stats[2] = s_flagmax;
+    stats[3] = t_head;
+    stats[4] = t_enq;
+    stats[5] = t_wait;
+    stats[6] = t_res;
+    stats[7] = t_scat;
+    stats[8] = t_tail;
+    stats[9] = now_ns() - t_entry;
+  }
+  return 0;
+
+fail:
+  // kernels and exports still in flight use this object's scratch and the caller's buffers: let them finish
+  (void)hipStreamSynchronize(main);
+  (void)hipStreamSynchronize(p->side);
+  for (Slot& s : p->slot) s.scatter_pending = false;
+  (void)hipGetLastError();
+  return rc;
+}
+
+}  // extern "C"

@@ -97,12 +97,12 @@ class LSHHasher:
                   and their spread is ~3 units (profiles/r01_split_window_margin.log).  The analytic worst case
                   (every rounding error aligned against a cancelling sum) is 768 units; a hasher that must be
                   safe against inputs crafted for its own hyperplanes should use precision="f32".
-      tau1_ulps   stage-1 window of the bf16x3 pass, same unit; must stay >= 192 + the f32 rounding allowance
+      pipeline    "native" (default) / "python": who drives the chunks of a device batch of >= 131 072 rows
     """
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps: float = 8.0, precision: str = "bf16x3",
-                 tau1_ulps: float = 64.0, tie_threads: Optional[int] = None) -> None:
+                 tau1_ulps: float = 64.0, tie_threads: Optional[int] = None, pipeline: str = "native") -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -146,6 +146,12 @@ class LSHHasher:
         # kernel (128-row workgroups, two per CU) and of the split pass (256-row workgroups, one per CU): each
         # chunk boundary costs a kernel ramp-down/ramp-up, each chunk a fixed ~60 us of host work
         self.pipeline_chunk_rows = 262_144
+        # who drives the chunks of a large device batch: "native" = the library (csrc/pipeline.hip; needs the host
+        # engine, else the interpreter does it), "python" = this class (_pipelined_body).  Same kernels, same keys.
+        if pipeline not in ("native", "python"):
+            raise ValueError("pipeline must be 'native' or 'python'")
+        self.pipeline = pipeline
+        self._pipes: Dict[tuple, int] = {}
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
@@ -237,7 +243,7 @@ class LSHHasher:
         with self._lock:
             return self._hash_device_locked(x, out, row_flags, mode, host_rows=None)
 
-    def _hash_device_locked(self, x, out, row_flags, mode, host_rows):
+    def _hash_device_locked(self, x, out, row_flags, mode, host_rows, allow_pipeline: bool = True):
         torch = _native.require_gpu()
         lib = _native.load()
         dev = x.device
@@ -253,7 +259,7 @@ class LSHHasher:
             return out
         ws = self._workspace(dev)
         tau = float(self.tau_ulps * _U)
-        if mode == "host" and host_rows is None and n >= max(131_072, self.pipeline_chunk_rows // 2):
+        if allow_pipeline and mode == "host" and host_rows is None and n >= max(131_072, self.pipeline_chunk_rows // 2):
             return self._hash_device_pipelined(x, out, row_flags, ws, tau, stats)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -309,6 +315,9 @@ class LSHHasher:
     # ------------------------------------------------------------------ large batches: overlap the tie-break
     def _hash_device_pipelined(self, x, out, row_flags, ws, tau, stats):
         try:
+            native = self._tie_engine() if self.pipeline == "native" else None
+            if native is not None:
+                return self._pipelined_native(x, out, row_flags, ws, tau, stats, native)
             return self._pipelined_body(x, out, row_flags, ws, tau, stats)
         except BaseException:
             # kernels and copies still in flight use buffers owned by the frame that just unwound: let them finish
@@ -329,17 +338,8 @@ class LSHHasher:
         dev = x.device
         n = int(x.shape[0])
         bb = self.band_bytes
-        ch = self.pipeline_chunk_rows
-        while n < 2 * ch and ch > 65_536:   # mid-size batch: two or three smaller chunks still overlap most of the tie-break
-            ch = max(65_536, ch // 2)
-        cap = ch // 32 + 1024    # tie entries per chunk (measured: ~0.25 % of the rows at tau_ulps = 8); more -> plain path
+        ch, cap, spans = self._pipeline_plan(n)
         window = 16
-        spans = [(lo, min(n, lo + ch)) for lo in range(0, n, ch)]
-        # nothing overlaps the host work of the LAST chunk: keep it small (one full-chip round of the kernel)
-        tail = 65_536
-        if spans[-1][1] - spans[-1][0] >= 2 * tail:
-            lo, hi = spans.pop()
-            spans += [(lo, hi - tail), (hi - tail, hi)]
         overflow = []
         keep = []  # device temporaries stay referenced until the streams have been joined
         with torch.cuda.device(dev):
@@ -488,16 +488,91 @@ class LSHHasher:
             side.synchronize()
             stats["t_drain_ms"] = 1e3 * (time.perf_counter() - t_loop)
             stats["t_total_ms"] = 1e3 * (time.perf_counter() - t_entry)
+        return self._redo_overflowed(x, out, row_flags, overflow, stats)
+
+    def _redo_overflowed(self, x, out, row_flags, overflow, stats):
         for lo, hi in overflow:  # a chunk with more ties than its list holds: redo it on the plain path
             sub = {"n": hi - lo, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
             self.last_stats = sub
             self._hash_device_locked(x[lo:hi], out[lo:hi], row_flags[lo:hi] if row_flags is not None else None,
-                                     "host", None)
+                                     "host", None, allow_pipeline=False)
             for k in ("tie_entries", "tie_pairs"):
                 stats[k] += self.last_stats[k]
             stats["relaunches"] += 1 + self.last_stats["relaunches"]
         self.last_stats = stats
         return out
+
+    def _pipeline_plan(self, n: int):
+        """(chunk rows, tie entries of room per chunk, [(lo, hi) ...]) for a device batch of n rows."""
+        ch = self.pipeline_chunk_rows
+        while n < 2 * ch and ch > 65_536:   # mid-size batch: two or three smaller chunks still overlap most of the tie-break
+            ch = max(65_536, ch // 2)
+        cap = ch // 32 + 1024    # tie entries per chunk (measured: ~0.25 % of the rows at tau_ulps = 8); more -> plain path
+        spans = [(lo, min(n, lo + ch)) for lo in range(0, n, ch)]
+        # nothing overlaps the host work of the LAST chunk: keep it small (one full-chip round of the kernel)
+        tail = 65_536
+        if spans[-1][1] - spans[-1][0] >= 2 * tail:
+            lo, hi = spans.pop()
+            spans += [(lo, hi - tail), (hi - tail, hi)]
+        return ch, cap, spans
+
+    def _native_pipe(self, lib, dev, cap: int, flag_cap: int):
+        """The native pipeline object (lshrs_pipe_*, csrc/pipeline.hip) for this device and these capacities."""
+        key = (dev.index, cap, flag_cap)
+        pipe = self._pipes.get(key)
+        if pipe is None:
+            for old in [k for k in self._pipes if k[0] == dev.index and k[1] == cap]:
+                lib.lshrs_pipe_destroy(self._pipes.pop(old))      # outgrown stage-1 list
+            pipe = lib.lshrs_pipe_create(self.num_bands, self.rows_per_band, self.dim, cap, flag_cap)
+            if not pipe:
+                raise _native.NativeLibraryError("lshrs_pipe_create failed (out of device or pinned host memory?)")
+            self._pipes[key] = pipe
+        return pipe
+
+    def _pipelined_native(self, x, out, row_flags, ws, tau, stats, native):
+        """The pipelined path driven by the library (csrc/pipeline.hip): same chunks, same kernels and the same host
+        engine call per chunk as :meth:`_pipelined_body`, without the interpreter between the launches, with the tie
+        entries and their vectors exported straight into pinned host memory by a kernel on a side stream."""
+        t_entry = time.perf_counter()
+        torch = _native.require_gpu()
+        lib = _native.load()
+        dev = x.device
+        n = int(x.shape[0])
+        ch, cap, spans = self._pipeline_plan(n)
+        split = [self._split_applies(hi - lo) for lo, hi in spans]
+        flag_cap = max(int(self._flag_cap_hint), ch // 4 + 4096) if any(split) else 0
+        eng, planes = native
+        nc = len(spans)
+        bounds = np.array([0] + [hi for _, hi in spans], dtype=np.int64)
+        chunk_split = np.array(split, dtype=np.uint8)
+        status = np.zeros(nc, dtype=np.int32)
+        st = np.zeros(12, dtype=np.int64)
+        timing = self.kernel_events is not None
+        ms = np.full(2 * nc, -1.0, dtype=np.float32) if timing else None
+        with torch.cuda.device(dev):
+            pipe = self._native_pipe(lib, dev, cap, flag_cap)
+            main = torch.cuda.current_stream(dev)
+            rc = lib.lshrs_pipe_hash_f32(
+                pipe, x.data_ptr(), x.stride(0), ws.data_ptr(), out.data_ptr(),
+                row_flags.data_ptr() if row_flags is not None else None, tau, float(self.tau1_ulps * _U),
+                bounds.ctypes.data, chunk_split.ctypes.data, nc, eng.resolve_fn, eng.handle, planes.ctypes.data,
+                status.ctypes.data, ms.ctypes.data if timing else None, st.ctypes.data, main.cuda_stream)
+        _native.check(int(rc), "lshrs_pipe_hash_f32")
+        stats["tie_entries"] += int(st[0])
+        stats["tie_pairs"] += int(st[1])
+        for key, i in (("t_head_ms", 3), ("t_enqueue_ms", 4), ("t_wait_ms", 5), ("t_patch_ms", 6), ("t_scatter_ms", 7),
+                       ("t_tail_count_ms", 8), ("t_native_ms", 9)):
+            stats[key] = float(st[i]) * 1e-6
+        stats["pipeline"] = "native"
+        if timing:
+            for ci, (lo, hi) in enumerate(spans):
+                fix = float(ms[2 * ci + 1])
+                self.kernel_events.append((float(ms[2 * ci]), None, hi - lo, fix if fix >= 0 else None))
+        overflow = [spans[ci] for ci in range(nc) if status[ci] != 0]
+        if any(status[ci] == 2 for ci in range(nc)):
+            self._flag_cap_hint = int(int(st[2]) * 1.25) + 4096
+        stats["t_total_ms"] = 1e3 * (time.perf_counter() - t_entry)
+        return self._redo_overflowed(x, out, row_flags, overflow, stats)
 
     def _tie_pairs_indexed(self, entries: np.ndarray):
         """Like :meth:`_tie_pairs`, plus for every pair the index of an entry that carries the row's vector
@@ -768,12 +843,30 @@ class LSHHasher:
         return vec
 
     # ------------------------------------------------------------------ pickling: host state only
+    def close(self) -> None:
+        """Release the native pipeline objects (device scratch, pinned host buffers, side stream)."""
+        pipes, self._pipes = getattr(self, "_pipes", {}), {}
+        if pipes:
+            try:
+                lib = _native.load()
+                for pipe in pipes.values():
+                    lib.lshrs_pipe_destroy(pipe)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+    def __del__(self):  # pragma: no cover - exercised implicitly
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_lock"] = None
         state["_workspaces"] = {}
         state["_side_streams"] = {}
         state["_pinned_cache"] = {}
+        state["_pipes"] = {}
         state["_host_planes_cache"] = None
         state["kernel_events"] = None
         state["_projections"] = list(self._projections)
@@ -782,6 +875,8 @@ class LSHHasher:
     def __setstate__(self, state):
         self.__dict__.update(state)
         self.__dict__.setdefault("tie_threads", None)
+        self.__dict__.setdefault("pipeline", "native")
+        self.__dict__.setdefault("_pipes", {})
         self.__dict__.setdefault("_host_planes_cache", None)
         self.__dict__.setdefault("_split_range_ok", None)
         self.__dict__.setdefault("split_min_elems", 16 << 20)

@@ -249,6 +249,59 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     h1.pipeline_chunk_rows = 131_072
     assert torch.equal(h1.hash_device(x), piped)
     assert h1.last_stats["tie_pairs"] == stats["tie_pairs"]
+    # who drove the chunks: the library (csrc/pipeline.hip) whenever the host engine exists, else the interpreter;
+    # the other driver gives the same bytes and touches the same pairs
+    from lshrs_amd import _hostblas
+
+    if _hostblas.engine() is not None:
+        assert stats.get("pipeline") == "native"
+        hp = _hasher(42, 16, 16, 768, pipeline="python")
+        hp.pipeline_chunk_rows = 131_072
+        assert torch.equal(hp.hash_device(x), piped)
+        assert hp.last_stats.get("pipeline") != "native" and hp.last_stats["tie_pairs"] == stats["tie_pairs"]
+        # per-chunk HIP-event times come back from the library when asked for
+        h.pipeline_chunk_rows = 131_072
+        h.kernel_events = []
+        assert torch.equal(h.hash_device(x), piped)
+        ev, h.kernel_events = h.kernel_events, None
+        assert [e[2] for e in ev] == [131_072, 131_072, 37_856] and all(0 < e[0] < 50 for e in ev)
+        assert all(e[3] is not None and 0 < e[3] < 50 for e in ev)      # split pass: stage 1 | fix-up
+
+
+def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
+    """The library-driven pipeline on an unaligned view (f32 kernel, scalar export), on a batch with a one-row last
+    chunk, and with a tie list too small for a chunk (that chunk is redone with room): always the plain path's bytes."""
+    torch = torch_mod
+    from lshrs_amd import _hostblas
+
+    if _hostblas.engine() is None:
+        pytest.skip("host tie-break engine unavailable on this box")
+    gen = torch.Generator("cuda").manual_seed(78)
+    # (a) 140 001 rows of a 100-d view with an odd row stride: f32 kernel, scalar loads, chunks of 65 536 + 8 929 + 65 536
+    h = _hasher(5, 8, 12, 100)
+    big = torch.randn(140_001, 103, device="cuda", generator=gen)
+    x = big[:, 1:101]
+    got = h.hash_device(x)
+    assert h.last_stats.get("pipeline") == "native" and h.last_stats["tie_pairs"] > 0
+    h.pipeline_chunk_rows = 10**9
+    assert torch.equal(got, h.hash_device(x))
+    # (b) one row more than two chunks
+    h2 = _hasher(42, 16, 16, 768)
+    h2.pipeline_chunk_rows = 65_536
+    x2 = torch.randn(131_073, 768, device="cuda", generator=gen)
+    got2 = h2.hash_device(x2)
+    assert h2.last_stats.get("pipeline") == "native"
+    h2.pipeline_chunk_rows = 10**9
+    assert torch.equal(got2, h2.hash_device(x2))
+    # (c) a window so wide that every chunk's tie list overflows
+    h3 = _hasher(3, 4, 16, 64, tau_ulps=1e9)
+    x3 = torch.randn(140_000, 64, device="cuda", generator=gen)
+    got3 = h3.hash_device(x3)
+    assert h3.last_stats.get("pipeline") == "native" and h3.last_stats["relaunches"] >= 2
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    sl = slice(65_000, 66_000)
+    assert np.array_equal(got3[sl].cpu().numpy(), hash_batch_literal_packed(h3.projections, x3[sl].cpu().numpy()))
 
 
 def test_tie_list_overflow_is_recovered(torch_mod):

@@ -45,7 +45,8 @@ try:
         if p:
             subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                             "-I" + os.path.join(ROOT, "include"), f"-DLSHRS_SPLIT_PROBE={p}",
-                            os.path.join(ROOT, "lshrs_amd/csrc/lshrs_hip.hip"), "-o", MAIN], check=True)
+                            os.path.join(ROOT, "lshrs_amd/csrc/lshrs_hip.hip"),
+                            os.path.join(ROOT, "lshrs_amd/csrc/pipeline.hip"), "-o", MAIN], check=True)
         else:
             shutil.copy(os.path.join(keep, "main.so"), MAIN)
         r = subprocess.run([sys.executable, __file__, "--child", str(p), str(pipe)], capture_output=True, text=True)
