@@ -77,7 +77,7 @@ struct Engine {
   uint64_t generation = 0;
   std::atomic<uint64_t> gen_atomic{0};     // mirror of generation for the lock-free poll
   std::atomic<bool> stop_atomic{false};
-  int pending = 0;
+  std::atomic<int> pending{0};             // workers still inside the current job
   bool stop = false;
   Job job;
   std::atomic<int64_t> next{0};
@@ -135,9 +135,9 @@ void worker_main(Engine* e, int t) {
       seen = e->generation;
     }
     run_pairs(e, t);
-    {
-      std::lock_guard<std::mutex> lk(e->mu);
-      if (--e->pending == 0) e->cv_done.notify_all();
+    if (e->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+      std::lock_guard<std::mutex> lk(e->mu);   // (the caller may have stopped polling and gone to sleep on cv_done)
+      e->cv_done.notify_all();
     }
   }
 }
@@ -273,7 +273,7 @@ static int run_job(Engine* e, const float* planes, int32_t rows_per_band, int32_
   if (fan_out) {
     {
       std::lock_guard<std::mutex> lk(e->mu);
-      e->pending = (int)e->workers.size();
+      e->pending.store((int)e->workers.size(), std::memory_order_relaxed);
       ++e->generation;
       e->gen_atomic.store(e->generation, std::memory_order_release);
     }
@@ -281,8 +281,15 @@ static int run_job(Engine* e, const float* planes, int32_t rows_per_band, int32_
   }
   run_pairs(e, 0);
   if (fan_out) {
-    std::unique_lock<std::mutex> lk(e->mu);
-    e->cv_done.wait(lk, [&] { return e->pending == 0; });
+    // the workers finish within microseconds of the caller (they share one work queue): poll before sleeping —
+    // a futex wake-up costs as much as a small chunk's whole job
+    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(2000);
+    while (e->pending.load(std::memory_order_acquire) != 0 && std::chrono::steady_clock::now() < spin_until)
+      __builtin_ia32_pause();
+    if (e->pending.load(std::memory_order_acquire) != 0) {
+      std::unique_lock<std::mutex> lk(e->mu);
+      e->cv_done.wait(lk, [&] { return e->pending.load(std::memory_order_acquire) == 0; });
+    }
   }
   return 0;
 }

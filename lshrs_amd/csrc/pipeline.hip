@@ -31,10 +31,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Entry e < min(*tie_count, tie_cap): host_entries[e] = tie_list[e], host_rows[e] = X[row of e] (dim floats,
 // contiguous).  host_counts = (ties wanted, stage-1 entries wanted).  All destinations are pinned host memory.
 // One WAVE per entry, few workgroups: the kernel runs beside the next chunk's signature pass, whose workgroups need
-// a CU's whole register file — every CU that holds an export wave is closed to them until that wave retires, and
-// the export is PCIe-bound (~40 us per 262 144-row chunk) however many CUs it sits on.  (512 workgroups cost the
-// signature pass 14 us per chunk; kExportBlocks keep at most that many CUs busy and still saturate the link.)
-constexpr int kExportBlocks = 16;
+// a CU's whole register file — every CU that holds an export wave is closed to them until that wave retires.
+// Under that pass's HBM stream a wave's dependent loads (entry -> row -> store) take several us each, so the waves
+// must be many enough to take one or two entries each (16 workgroups: 90-110 us per 262 144-row chunk by the
+// kernel trace, which left the host two chunks to resolve after the last kernel; 2: 200 us; 1024: signature pass
+// +2 %); sweep in DESIGN.md.
+constexpr int kExportBlocks = 128;
 template <bool VEC>
 __global__ __launch_bounds__(256) void export_ties_kernel(const float* __restrict__ X, int64_t ldx, int dim,
                                                           const int64_t* __restrict__ tie_list,
@@ -86,8 +88,12 @@ struct Slot {
   int64_t* h_entries = nullptr;    // pinned int64[tie_cap][2]
   float* h_rows = nullptr;         // pinned float[tie_cap][dim]
   uint8_t* h_patch = nullptr;      // pinned: rows int64[pairs_cap] | bands int32[pairs_cap] | keys u8[pairs_cap * bb]
-  hipEvent_t fix_done = nullptr, exported = nullptr, scattered = nullptr;
-  hipEvent_t t_start = nullptr, t_mid = nullptr, t_end = nullptr;
+  hipEvent_t exported = nullptr, scattered = nullptr;
+  // t_end: after the chunk's last kernel on the caller's stream.  ONE event per chunk boundary: it releases the
+  // export on the side stream, ends this chunk's fix-up time and starts the next chunk's stage-1 time (an event
+  // costs the stream ~6 us of dispatch gap; three per boundary were 5 % of a step).  t_mid: between stage 1 and 2,
+  // recorded only when the caller asked for times.
+  hipEvent_t t_mid = nullptr, t_end = nullptr, t_next = nullptr;
   bool scatter_pending = false;
 };
 
@@ -97,7 +103,7 @@ struct Pipe {
   int tie_cap = 0, flag_cap = 0;
   int64_t pairs_cap = 0;
   hipStream_t side = nullptr;
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr, t_begin = nullptr;
   int32_t* d_counts = nullptr;     // device int32[2 * counts_cap]: (tie count, stage-1 count) per chunk of a call
   int counts_cap = 0;
   int export_blocks = kExportBlocks;
@@ -118,11 +124,12 @@ void pipe_free(Pipe* p) {
     if (s.h_entries) (void)hipHostFree(s.h_entries);
     if (s.h_rows) (void)hipHostFree(s.h_rows);
     if (s.h_patch) (void)hipHostFree(s.h_patch);
-    for (hipEvent_t e : {s.fix_done, s.exported, s.scattered, s.t_start, s.t_mid, s.t_end})
+    for (hipEvent_t e : {s.exported, s.scattered, s.t_mid, s.t_end, s.t_next})
       if (e) (void)hipEventDestroy(e);
   }
   if (p->d_counts) (void)hipFree(p->d_counts);
   if (p->done) (void)hipEventDestroy(p->done);
+  if (p->t_begin) (void)hipEventDestroy(p->t_begin);
   if (p->side) (void)hipStreamDestroy(p->side);
   delete p;
 }
@@ -169,6 +176,7 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
     PIPE_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio));
   }
   PIPE_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
+  PIPE_TRY(hipEventCreate(&p->t_begin));
   for (Slot& s : p->slot) {
     PIPE_TRY(hipMalloc(&s.tie_list, sizeof(int64_t) * 2 * (size_t)tie_cap));
     if (flag_cap > 0) PIPE_TRY(hipMalloc(&s.flag_list, sizeof(int64_t) * (size_t)flag_cap));
@@ -176,12 +184,11 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
     PIPE_TRY(hipHostMalloc(&s.h_entries, sizeof(int64_t) * 2 * (size_t)tie_cap, hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(&s.h_rows, sizeof(float) * (size_t)tie_cap * dim, hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(&s.h_patch, (size_t)(12 + p->bb) * p->pairs_cap, hipHostMallocDefault));
-    PIPE_TRY(hipEventCreateWithFlags(&s.fix_done, hipEventDisableTiming));
     PIPE_TRY(hipEventCreateWithFlags(&s.exported, hipEventDisableTiming));
     PIPE_TRY(hipEventCreateWithFlags(&s.scattered, hipEventDisableTiming));
-    PIPE_TRY(hipEventCreate(&s.t_start));
     PIPE_TRY(hipEventCreate(&s.t_mid));
     PIPE_TRY(hipEventCreate(&s.t_end));
+    PIPE_TRY(hipEventCreate(&s.t_next));
   }
   return p;
 fail:
@@ -224,8 +231,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
   const int row_bytes = p->nb * p->bb;
   const bool vec = (p->dim % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   int rc = 0;
-  int64_t s_ties = 0, s_pairs = 0, s_flagmax = 0, t_head = 0, t_enq = 0, t_wait = 0, t_res = 0, t_scat = 0, t_tail = 0;
-  int enqueued = 0;
+  int64_t s_ties = 0, s_pairs = 0, s_flagmax = 0, t_head = 0, t_enq = 0, t_wait = 0, t_res = 0, t_scat = 0, t_tail = 0, t_res_last = 0;
 
   {
     int cur = 0;
@@ -254,7 +260,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       int32_t* cnt = p->d_counts + 2 * (size_t)c;
       hipError_t e;
       if (chunk_ms != nullptr) {
-        if ((e = hipEventRecord(s.t_start, main)) != hipSuccess) return -(int)e;
+        if (c == 0 && (e = hipEventRecord(p->t_begin, main)) != hipSuccess) return -(int)e;
         if (chunk_split[c]) (void)lshrs_debug_set_split_mid_event(s.t_mid);
       }
       int r;
@@ -266,19 +272,28 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
                                      tau, fl, stream);
       (void)lshrs_debug_set_split_mid_event(nullptr);   // (a split call that fell through to the f32 kernel left it set)
       if (r != 0) return r;
-      if (chunk_ms != nullptr && (e = hipEventRecord(s.t_end, main)) != hipSuccess) return -(int)e;
-      if ((e = hipEventRecord(s.fix_done, main)) != hipSuccess) return -(int)e;
-      if ((e = hipStreamWaitEvent(p->side, s.fix_done, 0)) != hipSuccess) return -(int)e;
+      if ((e = hipEventRecord(s.t_end, main)) != hipSuccess) return -(int)e;
+      // The export runs beside the next chunk's signature pass on the side stream — where it gets no CU before that
+      // pass's first round of workgroups retires (~70 us; they take whole register files).  Harmless in mid-batch,
+      // but the export of the last-but-one chunk would arrive when the last kernel is ending and leave the host TWO
+      // chunks to resolve behind the GPU: the last two exports stay on the caller's stream (~11 us of GPU time for
+      // the one, nothing follows the other), which also skips the cross-stream hand-over (~15 us).
+      hipStream_t xstream = (c >= n_chunks - 2) ? main : p->side;
+      if (xstream != main && (e = hipStreamWaitEvent(p->side, s.t_end, 0)) != hipSuccess) return -(int)e;
       const int blocks = p->export_blocks;
       if (vec)
-        hipLaunchKernelGGL(export_ties_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, p->side, xs, ldx, p->dim,
+        hipLaunchKernelGGL(export_ties_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, xstream, xs, ldx, p->dim,
                            s.tie_list, cnt, p->tie_cap, s.h_entries, s.h_rows, s.h_counts);
       else
-        hipLaunchKernelGGL(export_ties_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, p->side, xs, ldx, p->dim,
+        hipLaunchKernelGGL(export_ties_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, xstream, xs, ldx, p->dim,
                            s.tie_list, cnt, p->tie_cap, s.h_entries, s.h_rows, s.h_counts);
       if ((e = hipGetLastError()) != hipSuccess) return -(int)e;
-      if ((e = hipEventRecord(s.exported, p->side)) != hipSuccess) return -(int)e;
-      ++enqueued;
+      if ((e = hipEventRecord(s.exported, xstream)) != hipSuccess) return -(int)e;
+      // an export on the caller's stream sits between this chunk's t_end and the next chunk's stage 1: when times are
+      // asked for, the next chunk's stage-1 clock starts behind it
+      if (chunk_ms != nullptr && xstream == main && c + 1 < n_chunks &&
+          (e = hipEventRecord(s.t_next, main)) != hipSuccess)
+        return -(int)e;
       return 0;
     };
 
@@ -295,14 +310,18 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       if (c == n_chunks - 1) t_tail = t1 - t_entry;
       if (chunk_ms != nullptr) {
         float a = -1.f, b = -1.f;
+        // (the previous chunk's slot is re-armed by the enqueue just below: read before that)
+        hipEvent_t t_start = c == 0 ? p->t_begin
+                                    : (c - 1 >= n_chunks - 2 ? p->slot[(c - 1) % kSlots].t_next
+                                                             : p->slot[(c - 1) % kSlots].t_end);
         if (chunk_split[c] && hipEventQuery(s.t_mid) == hipSuccess &&
-            hipEventElapsedTime(&a, s.t_start, s.t_mid) == hipSuccess &&
+            hipEventElapsedTime(&a, t_start, s.t_mid) == hipSuccess &&
             hipEventElapsedTime(&b, s.t_mid, s.t_end) == hipSuccess) {
           chunk_ms[2 * c] = a;
           chunk_ms[2 * c + 1] = b;
         } else {
           (void)hipGetLastError();
-          PIPE_TRY(hipEventElapsedTime(&a, s.t_start, s.t_end));
+          PIPE_TRY(hipEventElapsedTime(&a, t_start, s.t_end));
           chunk_ms[2 * c] = a;
           chunk_ms[2 * c + 1] = -1.f;
         }
@@ -335,6 +354,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
                              p_keys, p->pairs_cap, &m);
       t1 = now_ns();
       t_res += t1 - t0;
+      if (c == n_chunks - 1) t_res_last = t1 - t0;
       if (rr != 0) {             // (more pairs than the patch slot holds: the caller redoes the chunk with room)
         chunk_status[c] = 1;
         continue;
@@ -364,6 +384,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
     stats[7] = t_scat;
     stats[8] = t_tail;
     stats[9] = now_ns() - t_entry;
+    stats[10] = t_res_last;
   }
   return 0;
 

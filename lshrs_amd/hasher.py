@@ -561,7 +561,7 @@ class LSHHasher:
         stats["tie_entries"] += int(st[0])
         stats["tie_pairs"] += int(st[1])
         for key, i in (("t_head_ms", 3), ("t_enqueue_ms", 4), ("t_wait_ms", 5), ("t_patch_ms", 6), ("t_scatter_ms", 7),
-                       ("t_tail_count_ms", 8), ("t_native_ms", 9)):
+                       ("t_tail_count_ms", 8), ("t_native_ms", 9), ("t_patch_last_ms", 10)):
             stats[key] = float(st[i]) * 1e-6
         stats["pipeline"] = "native"
         if timing:

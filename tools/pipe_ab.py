@@ -43,5 +43,6 @@ for rnd in range(rounds):
             fx = sum(e[3].elapsed_time(e[1]) for e in ev) / 10
         st = h.last_stats
         print(f"{name:7s} {ms:6.3f} ms/step = {n / ms / 1e3:6.1f} M vec/s | stage1 {s1:.3f} fix {fx:.3f} per step | "
-              f"head {st.get('t_head_ms', 0):.3f} tail_count {st.get('t_tail_count_ms', 0):.3f} total {st.get('t_total_ms', 0):.3f}",
+              f"head {st.get('t_head_ms', 0):.3f} tail_count {st.get('t_tail_count_ms', 0):.3f} total {st.get('t_total_ms', 0):.3f} "
+              f"wait {st.get('t_wait_ms', 0):.3f} patch {st.get('t_patch_ms', 0):.3f} (last {st.get('t_patch_last_ms', 0):.3f}) native {st.get('t_native_ms', 0):.3f}",
               flush=True)
