@@ -155,7 +155,8 @@ void lshrs_pipe_destroy(void* pipe);
  *   chunk_ms         optional float[2 * n_chunks]: HIP-event times of (stage 1 | whole pass, fix-up or -1) per chunk
  *   stats            optional int64[LSHRS_PIPE_STATS]: tie entries, tie pairs, largest stage-1 count, then ns:
  *                    entry→first launch, Σ enqueue, Σ wait for a chunk, Σ resolve, Σ scatter launch, entry→last
- *                    chunk exported, total, resolve of the last chunk; [11] reserved */
+ *                    chunk exported, total, resolve of the last chunk; [11] chunks whose speculative
+ *                    device->host copy of the tie vectors fell short and was topped up */
 int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* workspace, uint8_t* keys,
                         uint8_t* row_flags, float tau, float tau1, const int64_t* bounds, const uint8_t* chunk_split,
                         int32_t n_chunks, lshrs_tie_resolve_fn resolve, void* engine, const float* planes,

@@ -84,9 +84,16 @@ __global__ __launch_bounds__(256) void export_ties_kernel(const float* __restric
 struct Slot {
   int64_t* tie_list = nullptr;     // device
   int64_t* flag_list = nullptr;    // device
-  int32_t* h_counts = nullptr;     // pinned: (ties wanted, stage-1 entries wanted)
-  int64_t* h_entries = nullptr;    // pinned int64[tie_cap][2]
-  float* h_rows = nullptr;         // pinned float[tie_cap][dim]
+  // export image, once in device memory (d_*) and once in pinned host memory (h_*):
+  //   head: 64 bytes, int32 (ties wanted, stage-1 entries wanted) | entries int64[tie_cap][2]   (one allocation)
+  //   rows: float[tie_cap][dim]
+  char* d_head = nullptr;
+  float* d_rows = nullptr;
+  char* h_head = nullptr;
+  int32_t* h_counts = nullptr;     // = h_head
+  int64_t* h_entries = nullptr;    // = h_head + 64
+  float* h_rows = nullptr;
+  int64_t copied = 0;              // entries the speculative copy of this chunk covered
   uint8_t* h_patch = nullptr;      // pinned: rows int64[pairs_cap] | bands int32[pairs_cap] | keys u8[pairs_cap * bb]
   hipEvent_t exported = nullptr, scattered = nullptr;
   // t_end: after the chunk's last kernel on the caller's stream.  ONE event per chunk boundary: it releases the
@@ -102,11 +109,13 @@ struct Pipe {
   int nb = 0, r = 0, dim = 0, bb = 0;
   int tie_cap = 0, flag_cap = 0;
   int64_t pairs_cap = 0;
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr, aux = nullptr;
+  double tie_rate = 0.004;         // ties per row seen lately (sizes the speculative copy; measured 0.0026 at tau_ulps = 8)
   hipEvent_t done = nullptr, t_begin = nullptr;
   int32_t* d_counts = nullptr;     // device int32[2 * counts_cap]: (tie count, stage-1 count) per chunk of a call
   int counts_cap = 0;
   int export_blocks = kExportBlocks;
+  int export_main = 2;             // trailing chunks whose export stays on the caller's stream
   Slot slot[kSlots];
 };
 
@@ -120,8 +129,9 @@ void pipe_free(Pipe* p) {
   for (Slot& s : p->slot) {
     if (s.tie_list) (void)hipFree(s.tie_list);
     if (s.flag_list) (void)hipFree(s.flag_list);
-    if (s.h_counts) (void)hipHostFree(s.h_counts);
-    if (s.h_entries) (void)hipHostFree(s.h_entries);
+    if (s.d_head) (void)hipFree(s.d_head);
+    if (s.d_rows) (void)hipFree(s.d_rows);
+    if (s.h_head) (void)hipHostFree(s.h_head);
     if (s.h_rows) (void)hipHostFree(s.h_rows);
     if (s.h_patch) (void)hipHostFree(s.h_patch);
     for (hipEvent_t e : {s.exported, s.scattered, s.t_mid, s.t_end, s.t_next})
@@ -131,6 +141,7 @@ void pipe_free(Pipe* p) {
   if (p->done) (void)hipEventDestroy(p->done);
   if (p->t_begin) (void)hipEventDestroy(p->t_begin);
   if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->aux) (void)hipStreamDestroy(p->aux);
   delete p;
 }
 
@@ -167,6 +178,10 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
     const int b = atoi(v);
     if (b >= 1 && b <= 4096) p->export_blocks = b;
   }
+  if (const char* v = getenv("LSHRS_EXPORT_MAIN")) {     // A/B knob
+    const int b = atoi(v);
+    if (b >= 1) p->export_main = b;
+  }
   PIPE_TRY(hipGetDevice(&p->device));
   {
     int lo = 0, hi = 0;   // (numerically lowest = highest priority)
@@ -175,13 +190,17 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
     const int prio = (v != nullptr && v[0] == 'l') ? lo : ((v != nullptr && v[0] == 'n') ? 0 : hi);
     PIPE_TRY(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio));
   }
+  PIPE_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
   PIPE_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
   PIPE_TRY(hipEventCreate(&p->t_begin));
   for (Slot& s : p->slot) {
     PIPE_TRY(hipMalloc(&s.tie_list, sizeof(int64_t) * 2 * (size_t)tie_cap));
     if (flag_cap > 0) PIPE_TRY(hipMalloc(&s.flag_list, sizeof(int64_t) * (size_t)flag_cap));
-    PIPE_TRY(hipHostMalloc(&s.h_counts, 64, hipHostMallocDefault));
-    PIPE_TRY(hipHostMalloc(&s.h_entries, sizeof(int64_t) * 2 * (size_t)tie_cap, hipHostMallocDefault));
+    PIPE_TRY(hipMalloc(&s.d_head, 64 + sizeof(int64_t) * 2 * (size_t)tie_cap));
+    PIPE_TRY(hipMalloc(&s.d_rows, sizeof(float) * (size_t)tie_cap * dim));
+    PIPE_TRY(hipHostMalloc(&s.h_head, 64 + sizeof(int64_t) * 2 * (size_t)tie_cap, hipHostMallocDefault));
+    s.h_counts = reinterpret_cast<int32_t*>(s.h_head);
+    s.h_entries = reinterpret_cast<int64_t*>(s.h_head + 64);
     PIPE_TRY(hipHostMalloc(&s.h_rows, sizeof(float) * (size_t)tie_cap * dim, hipHostMallocDefault));
     PIPE_TRY(hipHostMalloc(&s.h_patch, (size_t)(12 + p->bb) * p->pairs_cap, hipHostMallocDefault));
     PIPE_TRY(hipEventCreateWithFlags(&s.exported, hipEventDisableTiming));
@@ -231,7 +250,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
   const int row_bytes = p->nb * p->bb;
   const bool vec = (p->dim % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   int rc = 0;
-  int64_t s_ties = 0, s_pairs = 0, s_flagmax = 0, t_head = 0, t_enq = 0, t_wait = 0, t_res = 0, t_scat = 0, t_tail = 0, t_res_last = 0;
+  int64_t s_ties = 0, s_pairs = 0, s_flagmax = 0, t_head = 0, t_enq = 0, t_wait = 0, t_res = 0, t_scat = 0, t_tail = 0, t_res_last = 0, s_topups = 0;
 
   {
     int cur = 0;
@@ -278,20 +297,42 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       // but the export of the last-but-one chunk would arrive when the last kernel is ending and leave the host TWO
       // chunks to resolve behind the GPU: the last two exports stay on the caller's stream (~11 us of GPU time for
       // the one, nothing follows the other), which also skips the cross-stream hand-over (~15 us).
-      hipStream_t xstream = (c >= n_chunks - 2) ? main : p->side;
+      hipStream_t xstream = (c >= n_chunks - p->export_main) ? main : p->side;
+      const bool on_main = xstream == main;
       if (xstream != main && (e = hipStreamWaitEvent(p->side, s.t_end, 0)) != hipSuccess) return -(int)e;
+      // The exports of the last two chunks, on the caller's stream, write pinned host memory themselves (nothing runs
+      // beside them, and it is the shortest way to the host).  Every other export lands in device memory and the
+      // runtime's copy carries a SPECULATIVE prefix of it to the host - sized from the tie rate of the chunks before,
+      // topped up by the host in the rare case it falls short: a kernel that stores to host memory while the
+      // signature pass runs slows that pass down (measured: 70 us per 1M rows; the runtime's copies much less).
+      const bool direct = on_main;
+      int64_t* o_entries = direct ? s.h_entries : reinterpret_cast<int64_t*>(s.d_head + 64);
+      float* o_rows = direct ? s.h_rows : s.d_rows;
+      int32_t* o_counts = direct ? s.h_counts : reinterpret_cast<int32_t*>(s.d_head);
       const int blocks = p->export_blocks;
       if (vec)
         hipLaunchKernelGGL(export_ties_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, xstream, xs, ldx, p->dim,
-                           s.tie_list, cnt, p->tie_cap, s.h_entries, s.h_rows, s.h_counts);
+                           s.tie_list, cnt, p->tie_cap, o_entries, o_rows, o_counts);
       else
         hipLaunchKernelGGL(export_ties_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, xstream, xs, ldx, p->dim,
-                           s.tie_list, cnt, p->tie_cap, s.h_entries, s.h_rows, s.h_counts);
+                           s.tie_list, cnt, p->tie_cap, o_entries, o_rows, o_counts);
       if ((e = hipGetLastError()) != hipSuccess) return -(int)e;
+      if (direct) {
+        s.copied = p->tie_cap;
+      } else {
+        int64_t pred = (int64_t)((double)(hi - lo) * p->tie_rate * 1.5) + 128;
+        if (pred > p->tie_cap) pred = p->tie_cap;
+        s.copied = pred;
+        if ((e = hipMemcpyAsync(s.h_head, s.d_head, 64 + 16 * (size_t)pred, hipMemcpyDeviceToHost, p->side)) != hipSuccess)
+          return -(int)e;
+        if ((e = hipMemcpyAsync(s.h_rows, s.d_rows, sizeof(float) * (size_t)pred * p->dim, hipMemcpyDeviceToHost,
+                                p->side)) != hipSuccess)
+          return -(int)e;
+      }
       if ((e = hipEventRecord(s.exported, xstream)) != hipSuccess) return -(int)e;
       // an export on the caller's stream sits between this chunk's t_end and the next chunk's stage 1: when times are
       // asked for, the next chunk's stage-1 clock starts behind it
-      if (chunk_ms != nullptr && xstream == main && c + 1 < n_chunks &&
+      if (chunk_ms != nullptr && on_main && c + 1 < n_chunks &&
           (e = hipEventRecord(s.t_next, main)) != hipSuccess)
         return -(int)e;
       return 0;
@@ -312,7 +353,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
         float a = -1.f, b = -1.f;
         // (the previous chunk's slot is re-armed by the enqueue just below: read before that)
         hipEvent_t t_start = c == 0 ? p->t_begin
-                                    : (c - 1 >= n_chunks - 2 ? p->slot[(c - 1) % kSlots].t_next
+                                    : (c - 1 >= n_chunks - p->export_main ? p->slot[(c - 1) % kSlots].t_next
                                                              : p->slot[(c - 1) % kSlots].t_end);
         if (chunk_split[c] && hipEventQuery(s.t_mid) == hipSuccess &&
             hipEventElapsedTime(&a, t_start, s.t_mid) == hipSuccess &&
@@ -342,6 +383,16 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
         continue;
       }
       if (wanted <= 0) continue;
+      p->tie_rate = 0.75 * p->tie_rate + 0.25 * (double)wanted / (double)(bounds[c + 1] - bounds[c]);
+      if (wanted > s.copied) {   // the speculative copy fell short: fetch the rest (the export itself is complete)
+        const int64_t more = wanted - s.copied;
+        PIPE_TRY(hipMemcpyAsync(s.h_entries + 2 * s.copied, s.d_head + 64 + 16 * s.copied, 16 * (size_t)more,
+                                hipMemcpyDeviceToHost, p->aux));
+        PIPE_TRY(hipMemcpyAsync(s.h_rows + s.copied * p->dim, s.d_rows + s.copied * p->dim,
+                                sizeof(float) * (size_t)more * p->dim, hipMemcpyDeviceToHost, p->aux));
+        PIPE_TRY(hipStreamSynchronize(p->aux));
+        ++s_topups;
+      }
       if (s.scatter_pending) {   // (three chunks ago: long finished)
         PIPE_TRY(hipEventSynchronize(s.scattered));
         s.scatter_pending = false;
@@ -385,6 +436,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
     stats[8] = t_tail;
     stats[9] = now_ns() - t_entry;
     stats[10] = t_res_last;
+    stats[11] = s_topups;
   }
   return 0;
 

@@ -564,6 +564,7 @@ class LSHHasher:
                        ("t_tail_count_ms", 8), ("t_native_ms", 9), ("t_patch_last_ms", 10)):
             stats[key] = float(st[i]) * 1e-6
         stats["pipeline"] = "native"
+        stats["export_topups"] = int(st[11])     # chunks whose speculative device->host copy fell short
         if timing:
             for ci, (lo, hi) in enumerate(spans):
                 fix = float(ms[2 * ci + 1])

@@ -293,6 +293,21 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     assert h2.last_stats.get("pipeline") == "native"
     h2.pipeline_chunk_rows = 10**9
     assert torch.equal(got2, h2.hash_device(x2))
+    # (b') a first chunk with far more ties than the speculative device->host copy expects (1 % of its rows lie in
+    # the null space of three hyperplanes): the host tops the copy up
+    h4 = _hasher(42, 16, 16, 768)
+    x4 = torch.randn(140_000, 768, device="cuda", generator=gen)
+    pl = np.concatenate([np.asarray(p, dtype=np.float64) for p in h4.projections])[[3, 100, 200]]
+    special = np.arange(0, 65_536, 100)
+    xs = x4[special].cpu().numpy().astype(np.float64)
+    xs -= (xs @ np.linalg.pinv(pl)) @ pl                     # remove the components along the three hyperplanes
+    x4[special] = torch.from_numpy(xs.astype(np.float32)).cuda()
+    got4 = h4.hash_device(x4)
+    st4 = dict(h4.last_stats)
+    assert st4.get("pipeline") == "native" and st4["export_topups"] >= 1 and st4["relaunches"] == 0
+    h4.pipeline_chunk_rows = 10**9
+    assert torch.equal(got4, h4.hash_device(x4))
+    assert h4.last_stats["tie_pairs"] == st4["tie_pairs"] > 3 * special.size - 10
     # (c) a window so wide that every chunk's tie list overflows
     h3 = _hasher(3, 4, 16, 64, tau_ulps=1e9)
     x3 = torch.randn(140_000, 64, device="cuda", generator=gen)
