@@ -58,6 +58,7 @@ struct Job {
   int64_t n_pairs = 0;
   uint8_t* out_keys = nullptr;
   float* out_y = nullptr;  // optional: the projections themselves (tests)
+  int64_t grain = kGrain;
 };
 
 struct PairRec {
@@ -86,7 +87,7 @@ struct Engine {
   std::vector<int32_t> scratch_index;
 };
 
-constexpr int64_t kGrain = 16;  // pairs claimed per atomic fetch
+constexpr int64_t kGrain = 16;  // pairs claimed per atomic fetch (large jobs; a small job is cut finer, Job::grain)
 
 void run_pairs(Engine* e, int t) {
   const Job& j = e->job;
@@ -98,9 +99,9 @@ void run_pairs(Engine* e, int t) {
     y = ybig.data();
   }
   for (;;) {
-    const int64_t lo = e->next.fetch_add(kGrain, std::memory_order_relaxed);
+    const int64_t lo = e->next.fetch_add(j.grain, std::memory_order_relaxed);
     if (lo >= j.n_pairs) break;
-    const int64_t hi = lo + kGrain < j.n_pairs ? lo + kGrain : j.n_pairs;
+    const int64_t hi = lo + j.grain < j.n_pairs ? lo + j.grain : j.n_pairs;
     for (int64_t p = lo; p < hi; ++p) {
       const float* plane = j.planes + (size_t)j.band[p] * j.r * j.dim;
       const float* x = j.xrows + (size_t)j.row_index[p] * j.ldx;
@@ -268,6 +269,13 @@ static int run_job(Engine* e, const float* planes, int32_t rows_per_band, int32_
   e->job.n_pairs = n_pairs;
   e->job.out_keys = out_keys;
   e->job.out_y = out_y;
+  // the last chunk of a batch is a small job on the critical path (~170 pairs): four claims per thread keep the
+  // threads level where grains of 16 would leave some with twice the work of others
+  {
+    const int64_t threads = (int64_t)e->workers.size() + 1;
+    const int64_t fine = n_pairs / (4 * threads);
+    e->job.grain = fine < 1 ? 1 : (fine < kGrain ? fine : kGrain);
+  }
   e->next.store(0, std::memory_order_relaxed);
   const bool fan_out = !e->workers.empty() && n_pairs > 4 * kGrain;  // a handful of pairs is cheaper done here
   if (fan_out) {

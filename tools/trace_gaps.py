@@ -8,7 +8,12 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-n_last:]
+# a step of the native pipeline starts with the fill of its counters: show the last COMPLETE step when there is one
+fills = [i for i, r in enumerate(rows) if "fillBuffer" in r["Kernel_Name"] and (i == 0 or "fillBuffer" not in rows[i - 1]["Kernel_Name"])]
+if len(fills) >= 2 and len(sys.argv) <= 2:
+    rows = rows[fills[-2]:fills[-1]]
+else:
+    rows = rows[-n_last:]
 t0 = int(rows[0]["Start_Timestamp"])
 prev_end = None
 busy = 0
