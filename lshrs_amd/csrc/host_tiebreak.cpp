@@ -48,6 +48,8 @@ using set_threads_fn = void (*)(int);
 
 constexpr int kRowMajor = 101, kNoTrans = 111;
 
+constexpr int64_t kGrain = 16;  // pairs claimed per atomic fetch (large jobs; a small job is cut finer, Job::grain)
+
 struct Job {
   const float* planes = nullptr;
   int r = 0, dim = 0, band_bytes = 0;
@@ -87,7 +89,6 @@ struct Engine {
   std::vector<int32_t> scratch_index;
 };
 
-constexpr int64_t kGrain = 16;  // pairs claimed per atomic fetch (large jobs; a small job is cut finer, Job::grain)
 
 void run_pairs(Engine* e, int t) {
   const Job& j = e->job;

@@ -9,6 +9,7 @@
 // ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 // Attribution probes of the split-precision main loop (tools/split_probes.py builds one library per value and reads
 // the in-kernel cycle stamps; results are WRONG keys by design): 1 no fragment reads, 2 no bf16 split, 4 no DMA in the
 // loop, 8 no barrier, 16 no x read-back, 32 contiguous x addresses (PIPE 3), 64 no x pieces (PIPE 3),
@@ -48,6 +49,9 @@ unsigned long long* g_clock_probe = nullptr;  // diagnostics only (lshrs_debug_s
 int g_split_m = 2;                // row tiles per wave of the split pass (lshrs_debug_set_split_m)
 int g_split_pipe = 7;             // 3: x in fragment-shaped pieces, 4: x in full 128-byte lines, 6 / 7: sig16_kernel<4,4> / <2,8> (lshrs_debug_set_split_pipe)
 hipEvent_t g_split_mid_event = nullptr;       // diagnostics only: recorded once between stage 1 and stage 2
+hipEvent_t g_split_time_events[4] = {nullptr, nullptr, nullptr, nullptr};   // measurement only: start/stop events that ride
+                                              // ON the dispatches of stage 1 and stage 2 (hipExtLaunchKernelGGL): kernel
+                                              // times without an extra packet in the stream; consumed by the next split call
 int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
 int g_fix_mode = 1;               // stage 2 of the split pass: 1 = eight flagged projections per wave, 0 = one (lshrs_debug_set_fix_mode)
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
@@ -1995,6 +1999,14 @@ int lshrs_debug_set_split_mid_event(void* event) {
   return 0;
 }
 
+int lshrs_debug_set_split_time_events(void* k1_start, void* k1_stop, void* k2_start, void* k2_stop) {
+  g_split_time_events[0] = static_cast<hipEvent_t>(k1_start);
+  g_split_time_events[1] = static_cast<hipEvent_t>(k1_stop);
+  g_split_time_events[2] = static_cast<hipEvent_t>(k2_start);
+  g_split_time_events[3] = static_cast<hipEvent_t>(k2_stop);
+  return 0;
+}
+
 int lshrs_debug_set_fix_mode(int m) {
   if (m != 0 && m != 1) return LSHRS_E_BADARG;
   g_fix_mode = m;
@@ -2167,7 +2179,8 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
       if (g_split_pipe == 6)
         hipLaunchKernelGGL((sig16_kernel<4, 4>), grid, block, 0, s, a);               // 16x16x32 MFMAs, one wave per SIMD
       else
-        hipLaunchKernelGGL((sig16_kernel<2, 8>), grid, dim3(512, 1, 1), 0, s, a);     // ... two waves per SIMD
+        hipExtLaunchKernelGGL((sig16_kernel<2, 8>), grid, dim3(512, 1, 1), 0, s, g_split_time_events[0],
+                              g_split_time_events[1], 0, a);                              // ... two waves per SIMD
     } else if (g_split_pipe == 4)
       hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 4, 2>), grid, block, 0, s, a);   // x staged in full 128-byte lines
     else
@@ -2204,12 +2217,13 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   if (g_fix_mode != 0) {
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
-    hipLaunchKernelGGL(sig_fix8_kernel, grid, block, 0, s, f);
+    hipExtLaunchKernelGGL(sig_fix8_kernel, grid, block, 0, s, g_split_time_events[2], g_split_time_events[3], 0, f);
   } else {
     const int64_t want = (int64_t)flag_cap < kFixGrid ? (int64_t)flag_cap : kFixGrid;
     const dim3 grid((unsigned)(want < 1 ? 1 : want)), block(64);
     hipLaunchKernelGGL(sig_fix_kernel, grid, block, 0, s, f);
   }
+  for (hipEvent_t& ev : g_split_time_events) ev = nullptr;
   return -(int)hipGetLastError();
 }
 

@@ -19,7 +19,8 @@
 
 #include "lshrs_hip.h"
 
-extern "C" int lshrs_debug_set_split_mid_event(void* event);   // lshrs_hip.hip: recorded once between stage 1 and 2
+// lshrs_hip.hip: start/stop events that ride on the dispatches of stage 1 and stage 2 of the next split call
+extern "C" int lshrs_debug_set_split_time_events(void* k1_start, void* k1_stop, void* k2_start, void* k2_stop);
 
 namespace {
 
@@ -98,9 +99,9 @@ struct Slot {
   hipEvent_t exported = nullptr, scattered = nullptr;
   // t_end: after the chunk's last kernel on the caller's stream.  ONE event per chunk boundary: it releases the
   // export on the side stream, ends this chunk's fix-up time and starts the next chunk's stage-1 time (an event
-  // costs the stream ~6 us of dispatch gap; three per boundary were 5 % of a step).  t_mid: between stage 1 and 2,
-  // recorded only when the caller asked for times.
-  hipEvent_t t_mid = nullptr, t_end = nullptr, t_next = nullptr;
+  // costs the stream ~6 us of dispatch gap; three per boundary were 5 % of a step).  k1s..k2e: start/stop events
+  // riding on the stage-1 and stage-2 dispatches, armed only when the caller asked for times.
+  hipEvent_t k1s = nullptr, k1e = nullptr, k2s = nullptr, k2e = nullptr, t_end = nullptr, t_next = nullptr;
   bool scatter_pending = false;
 };
 
@@ -134,7 +135,7 @@ void pipe_free(Pipe* p) {
     if (s.h_head) (void)hipHostFree(s.h_head);
     if (s.h_rows) (void)hipHostFree(s.h_rows);
     if (s.h_patch) (void)hipHostFree(s.h_patch);
-    for (hipEvent_t e : {s.exported, s.scattered, s.t_mid, s.t_end, s.t_next})
+    for (hipEvent_t e : {s.exported, s.scattered, s.k1s, s.k1e, s.k2s, s.k2e, s.t_end, s.t_next})
       if (e) (void)hipEventDestroy(e);
   }
   if (p->d_counts) (void)hipFree(p->d_counts);
@@ -205,7 +206,10 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
     PIPE_TRY(hipHostMalloc(&s.h_patch, (size_t)(12 + p->bb) * p->pairs_cap, hipHostMallocDefault));
     PIPE_TRY(hipEventCreateWithFlags(&s.exported, hipEventDisableTiming));
     PIPE_TRY(hipEventCreateWithFlags(&s.scattered, hipEventDisableTiming));
-    PIPE_TRY(hipEventCreate(&s.t_mid));
+    PIPE_TRY(hipEventCreate(&s.k1s));
+    PIPE_TRY(hipEventCreate(&s.k1e));
+    PIPE_TRY(hipEventCreate(&s.k2s));
+    PIPE_TRY(hipEventCreate(&s.k2e));
     PIPE_TRY(hipEventCreate(&s.t_end));
     PIPE_TRY(hipEventCreate(&s.t_next));
   }
@@ -280,7 +284,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       hipError_t e;
       if (chunk_ms != nullptr) {
         if (c == 0 && (e = hipEventRecord(p->t_begin, main)) != hipSuccess) return -(int)e;
-        if (chunk_split[c]) (void)lshrs_debug_set_split_mid_event(s.t_mid);
+        if (chunk_split[c]) (void)lshrs_debug_set_split_time_events(s.k1s, s.k1e, s.k2s, s.k2e);
       }
       int r;
       if (chunk_split[c])
@@ -289,7 +293,8 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       else
         r = lshrs_sig_hash_batch_f32(xs, hi - lo, ldx, workspace, p->nb, p->r, p->dim, ks, s.tie_list, p->tie_cap, cnt,
                                      tau, fl, stream);
-      (void)lshrs_debug_set_split_mid_event(nullptr);   // (a split call that fell through to the f32 kernel left it set)
+      (void)lshrs_debug_set_split_time_events(nullptr, nullptr, nullptr, nullptr);   // (a split call that fell through
+                                                                                     // to the f32 kernel left them set)
       if (r != 0) return r;
       if ((e = hipEventRecord(s.t_end, main)) != hipSuccess) return -(int)e;
       // The export runs beside the next chunk's signature pass on the side stream — where it gets no CU before that
@@ -355,9 +360,10 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
         hipEvent_t t_start = c == 0 ? p->t_begin
                                     : (c - 1 >= n_chunks - p->export_main ? p->slot[(c - 1) % kSlots].t_next
                                                              : p->slot[(c - 1) % kSlots].t_end);
-        if (chunk_split[c] && hipEventQuery(s.t_mid) == hipSuccess &&
-            hipEventElapsedTime(&a, t_start, s.t_mid) == hipSuccess &&
-            hipEventElapsedTime(&b, s.t_mid, s.t_end) == hipSuccess) {
+        // split pass: the two kernels' own start/stop events (they ride on the dispatch packets: exactly what a kernel
+        // trace reports, no packet of their own in the stream); f32 kernel: boundary event to boundary event
+        if (chunk_split[c] && hipEventElapsedTime(&a, s.k1s, s.k1e) == hipSuccess &&
+            hipEventElapsedTime(&b, s.k2s, s.k2e) == hipSuccess) {
           chunk_ms[2 * c] = a;
           chunk_ms[2 * c + 1] = b;
         } else {
