@@ -115,6 +115,8 @@ struct Pipe {
   hipEvent_t done = nullptr, t_begin = nullptr;
   int32_t* d_counts = nullptr;     // device int32[2 * counts_cap]: (tie count, stage-1 count) per chunk of a call
   int counts_cap = 0;
+  int zeroed_chunks = 0;           // leading counter pairs already zeroed (behind `zeroed`) by the end of the last call
+  hipEvent_t zeroed = nullptr;
   int export_blocks = kExportBlocks;
   int export_main = 2;             // trailing chunks whose export stays on the caller's stream
   Slot slot[kSlots];
@@ -141,6 +143,7 @@ void pipe_free(Pipe* p) {
   if (p->d_counts) (void)hipFree(p->d_counts);
   if (p->done) (void)hipEventDestroy(p->done);
   if (p->t_begin) (void)hipEventDestroy(p->t_begin);
+  if (p->zeroed) (void)hipEventDestroy(p->zeroed);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->aux) (void)hipStreamDestroy(p->aux);
   delete p;
@@ -194,6 +197,7 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
   PIPE_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
   PIPE_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
   PIPE_TRY(hipEventCreate(&p->t_begin));
+  PIPE_TRY(hipEventCreateWithFlags(&p->zeroed, hipEventDisableTiming));
   for (Slot& s : p->slot) {
     PIPE_TRY(hipMalloc(&s.tie_list, sizeof(int64_t) * 2 * (size_t)tie_cap));
     if (flag_cap > 0) PIPE_TRY(hipMalloc(&s.flag_list, sizeof(int64_t) * (size_t)flag_cap));
@@ -267,11 +271,18 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
     if (p->d_counts) (void)hipFree(p->d_counts);
     p->d_counts = nullptr;
     p->counts_cap = 0;
+    p->zeroed_chunks = 0;
     const int want = n_chunks < 64 ? 64 : n_chunks;
     PIPE_TRY(hipMalloc(&p->d_counts, sizeof(int32_t) * 2 * (size_t)want));
     p->counts_cap = want;
   }
-  PIPE_TRY(hipMemsetAsync(p->d_counts, 0, sizeof(int32_t) * 2 * (size_t)n_chunks, main));
+  // The counters of a call are zeroed at the END of the call before, on the side stream (two fill kernels and their
+  // dispatch gaps are ~15 us in front of the first signature pass otherwise); only a first or larger batch fills here.
+  if (n_chunks <= p->zeroed_chunks)
+    PIPE_TRY(hipStreamWaitEvent(main, p->zeroed, 0));
+  else
+    PIPE_TRY(hipMemsetAsync(p->d_counts, 0, sizeof(int32_t) * 2 * (size_t)n_chunks, main));
+  p->zeroed_chunks = 0;
 
   {
     auto enqueue = [&](int c) -> int {
@@ -429,6 +440,10 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
     }
     PIPE_TRY(hipEventRecord(p->done, p->side));
     PIPE_TRY(hipStreamWaitEvent(main, p->done, 0));
+    // every counter of this call has been exported: zero them for the next call, off the caller's stream
+    PIPE_TRY(hipMemsetAsync(p->d_counts, 0, sizeof(int32_t) * 2 * (size_t)n_chunks, p->side));
+    PIPE_TRY(hipEventRecord(p->zeroed, p->side));
+    p->zeroed_chunks = n_chunks;
   }
   if (stats != nullptr) {
     stats[0] = s_ties;
@@ -451,6 +466,7 @@ fail:
   (void)hipStreamSynchronize(main);
   (void)hipStreamSynchronize(p->side);
   for (Slot& s : p->slot) s.scatter_pending = false;
+  p->zeroed_chunks = 0;
   (void)hipGetLastError();
   return rc;
 }
