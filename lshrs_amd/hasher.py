@@ -17,6 +17,7 @@ raw kernel bits; ``last_stats`` records how many pairs were touched.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import threading
 import time
@@ -152,6 +153,7 @@ class LSHHasher:
             raise ValueError("pipeline must be 'native' or 'python'")
         self.pipeline = pipeline
         self._pipes: Dict[tuple, int] = {}
+        self._plan_cache: Dict[tuple, tuple] = {}
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
@@ -538,18 +540,29 @@ class LSHHasher:
         lib = _native.load()
         dev = x.device
         n = int(x.shape[0])
-        ch, cap, spans = self._pipeline_plan(n)
-        split = [self._split_applies(hi - lo) for lo, hi in spans]
-        flag_cap = max(int(self._flag_cap_hint), ch // 4 + 4096) if any(split) else 0
         eng, planes = native
-        nc = len(spans)
-        bounds = np.array([0] + [hi for _, hi in spans], dtype=np.int64)
-        chunk_split = np.array(split, dtype=np.uint8)
-        status = np.zeros(nc, dtype=np.int32)
-        st = np.zeros(12, dtype=np.int64)
         timing = self.kernel_events is not None
-        ms = np.full(2 * nc, -1.0, dtype=np.float32) if timing else None
-        with torch.cuda.device(dev):
+        # the plan of a batch size is reused: the interpreter's share of a 1.4 ms step is worth trimming
+        key = (n, self.pipeline_chunk_rows, int(self._flag_cap_hint), self._projection_version, self.precision,
+               self.split_min_rows, self.split_min_elems)
+        plan = self._plan_cache.get(key)
+        if plan is None:
+            ch, cap, spans = self._pipeline_plan(n)
+            split = [self._split_applies(hi - lo) for lo, hi in spans]
+            flag_cap = max(int(self._flag_cap_hint), ch // 4 + 4096) if any(split) else 0
+            nc = len(spans)
+            plan = (spans, cap, flag_cap, nc, np.array([0] + [hi for _, hi in spans], dtype=np.int64),
+                    np.array(split, dtype=np.uint8), np.zeros(nc, dtype=np.int32), np.zeros(12, dtype=np.int64),
+                    np.full(2 * nc, -1.0, dtype=np.float32))
+            if len(self._plan_cache) > 64:
+                self._plan_cache.clear()
+            self._plan_cache[key] = plan
+        spans, cap, flag_cap, nc, bounds, chunk_split, status, st, ms = plan    # (status / st / ms: outputs, rewritten per call)
+        if torch.cuda.current_device() == dev.index:      # (the device context manager costs ~10 us)
+            ctx = contextlib.nullcontext()
+        else:
+            ctx = torch.cuda.device(dev)
+        with ctx:
             pipe = self._native_pipe(lib, dev, cap, flag_cap)
             main = torch.cuda.current_stream(dev)
             rc = lib.lshrs_pipe_hash_f32(
@@ -868,6 +881,7 @@ class LSHHasher:
         state["_side_streams"] = {}
         state["_pinned_cache"] = {}
         state["_pipes"] = {}
+        state["_plan_cache"] = {}
         state["_host_planes_cache"] = None
         state["kernel_events"] = None
         state["_projections"] = list(self._projections)
@@ -878,6 +892,7 @@ class LSHHasher:
         self.__dict__.setdefault("tie_threads", None)
         self.__dict__.setdefault("pipeline", "native")
         self.__dict__.setdefault("_pipes", {})
+        self.__dict__.setdefault("_plan_cache", {})
         self.__dict__.setdefault("_host_planes_cache", None)
         self.__dict__.setdefault("_split_range_ok", None)
         self.__dict__.setdefault("split_min_elems", 16 << 20)
