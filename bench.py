@@ -260,13 +260,15 @@ def main() -> None:
 
     # ---------------- untimed parity check of what was just measured ----------------
     if rank == 0 and not args.no_check:
-        from oracle.lshrs_oracle import hash_batch_literal_packed
+        from oracle.parallel import SharedVectors, hash_shared_literal_packed
 
         hasher.hash_device(x, out=keys)
-        sl = slice(0, 4096)
-        want = hash_batch_literal_packed(hasher.projections, x[sl].cpu().numpy())
-        ok = bool(np.array_equal(keys[sl].cpu().numpy(), want))
-        result["parity_check"] = {"rows": 4096, "bit_exact_vs_oracle": ok}
+        m = min(n, 131_072)                  # the oracle's literal loop on every host core: a second or two
+        with SharedVectors(m, DIM) as sv:
+            sv.array[:] = x[:m].cpu().numpy()
+            want = hash_shared_literal_packed(hasher.projections, sv)
+        ok = bool(np.array_equal(keys[:m].cpu().numpy(), want))
+        result["parity_check"] = {"rows": m, "bit_exact_vs_oracle": ok}
         if not ok:
             raise SystemExit("bench: keys differ from the oracle — result invalid")
 
