@@ -1339,7 +1339,15 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
 //   <4, 4>: 64 rows per wave, 256 accumulator AGPRs, one wave per SIMD.
 //   <2, 8>: 32 rows per wave, 128 accumulator AGPRs, at most 256 registers -> TWO waves per SIMD that share one
 //           fragment stage: each can issue MFMAs while the other sits in a DMA issue, a barrier or its VALU slices.
-template <int RT, int W>
+//   PERSIST (lshrs_debug_set_split_pipe(8); NOT the default): the workgroup walks row tiles blockIdx.x, + gridDim.x,
+//           ... (grid = one workgroup per CU): the first fragments and x tiles of the NEXT row tile are requested
+//           before the epilogue of the current one, so the DMA round trip of the prologue hides behind the sign-bit
+//           extraction, and a workgroup is launched once per CU instead of once per 256 rows.  Measured: the kernel
+//           itself 1.3 % faster (1.080 vs 1.095 ms per 1M x 768), the bit-exact step 10 % SLOWER (1.60 vs 1.44 ms):
+//           no workgroup retires before the kernel ends, so the side-stream kernels of the pipeline (export of the
+//           ties, patch scatter) get no CU for a whole chunk and the host falls a chunk behind.  (Also tried on the
+//           default kernel: s_setprio 1 around the MFMA groups of the two waves sharing a SIMD - no change.)
+template <int RT, int W, bool PERSIST = false>
 __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
   static_assert(RT * W == 16 && (RT == 4 || RT == 2), "256 rows per workgroup");
   constexpr int kWaveRows = 16 * RT;
@@ -1359,18 +1367,23 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
   const int cb = blockIdx.y;
-  const int64_t blk_row0 = (int64_t)blockIdx.x * 256;
-  const int64_t row0 = blk_row0 + wave * kWaveRows;
   const int ktiles = args.ktiles;
   const int stages = 2 * ktiles, lasts = stages - 1;
   const char* img = reinterpret_cast<const char*>(args.image) + (size_t)cb * ktiles * 32768;
-  const char* xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
+  const int row_tiles = (int)((args.n + 255) / 256);
+  int row_tile = blockIdx.x;                 // PERSIST: advanced by gridDim.x per pass of the tile loop below
+  int64_t blk_row0, row0;
+  const char* xblk;
 
-  // loop-invariant DMA offsets (see the PIPE = 4 path of sig_kernel for the x landing image and its swizzle)
+  // DMA offsets (see the PIPE = 4 path of sig_kernel for the x landing image and its swizzle); xfo depends on the row tile
   unsigned poff[kPP], xfo[2 * RT], xrd[RT][2];
 #pragma unroll
   for (int q = 0; q < kPP; ++q) poff[q] = (unsigned)(((W * q + wave) * 64 + lane) * 16);
-  {
+  auto enter_tile = [&](int rtile) {
+    rtile = __builtin_amdgcn_readfirstlane(rtile);   // wave-uniform: keep the tile's scalars on the scalar unit
+    blk_row0 = (int64_t)rtile * 256;
+    row0 = blk_row0 + wave * kWaveRows;
+    xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
     const int r8 = lane >> 3, q8 = lane & 7;
 #pragma unroll
     for (int j = 0; j < 2 * RT; ++j) {
@@ -1378,6 +1391,9 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
       const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;   // clamp: loads stay in bounds, stores are masked
       xfo[j] = (unsigned)((rl * args.ldx + 4 * (q8 ^ r8 ^ (j & 1))) * 4);
     }
+  };
+  enter_tile(row_tile);
+  {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int R = 16 * rt + r16, j = R >> 3, r = R & 7;       // this lane's row of row tile rt: chunks 2g, 2g+1
@@ -1387,18 +1403,20 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
   }
 
   f32x4 acc[RT][16];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < 16; ++ct) {
-      acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // pin the zeroing HERE: the MFMAs below are inline asm, so hipcc pads no hazard for them - a v_accvgpr_write
-      // rematerialised right in front of the first accumulation would be read too early
-      asm volatile("" : "+a"(acc[rt][ct]));
-    }
   float ss[RT], amax[RT];
+  auto zero_tile_state = [&]() {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) { ss[rt] = 0.f; amax[rt] = 0.f; }
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 16; ++ct) {
+        acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // pin the zeroing HERE: the MFMAs below are inline asm, so hipcc pads no hazard for them - a v_accvgpr_write
+        // rematerialised right in front of the first accumulation would be read too early
+        asm volatile("" : "+a"(acc[rt][ct]));
+      }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { ss[rt] = 0.f; amax[rt] = 0.f; }
+  };
 
   unsigned long long t_shader = 0, t_real = 0;
   if (args.clock_probe != nullptr) {
@@ -1545,7 +1563,7 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     stage(2 * t + 1, 1, false, hc, mc, hc, mc, hp, mp);   // ch 1: E3(s-1) is this tile's; the next tile's split starts (into the other set)
   };
 
-  {
+  auto issue_prologue = [&]() {     // the first two stages' fragments and the first two x tiles of the row tile entered
     const Dma a0 = plan(-4), a1 = plan(-3), b0 = plan(-2), b1 = plan(-1);
 #pragma unroll
     for (int d = 0; d < kPP; ++d) issue(b0, d);                                  // fragments of stage 0
@@ -1555,8 +1573,20 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     for (int d = 0; d < kPP; ++d) issue(b1, d);                                  // fragments of stage 1
 #pragma unroll
     for (int d = kPP; d < kPP + kXPS; ++d) { issue(b0, d); issue(b1, d); }       // x tile 1
+  };
+  issue_prologue();
+  for (bool first_pass = true;; first_pass = false) {   // one pass per row tile (a single pass unless PERSIST)
+  zero_tile_state();
+  if (PERSIST) {   // likewise opaque per pass: the fragment addresses of the prologue are the same for every row tile
+#pragma unroll
+    for (int q = 0; q < kPP; ++q) asm volatile("" : "+v"(poff[q]));
   }
-  wait_vmcnt<kPP + 2 * kXPS>();
+  if (PERSIST && !first_pass)
+    // this tile's prologue was issued in front of the previous tile's epilogue, whose own stores and loads are
+    // younger than it in the vmcnt queue: drain (everything landed long ago)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else
+    wait_vmcnt<kPP + 2 * kXPS>();
   __builtin_amdgcn_s_barrier();
   read_x(0);
 #pragma unroll
@@ -1589,12 +1619,27 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
     for (int ct = 0; ct < 16; ++ct) asm volatile("" : "+a"(acc[rt][ct]));
 
-  if (args.clock_probe != nullptr && tid == 0) {
+  if (args.clock_probe != nullptr && tid == 0 && first_pass) {
     const unsigned long long slot = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
     args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
     args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
   }
 
+  // The ring is free (every wave is past the barrier above, every prefetch has landed): request the next row
+  // tile's first stages now, so that they travel while this tile's sign bits are extracted.
+  const int64_t erow0 = row0;            // the epilogue below works on the tile just finished
+  const int next_tile = row_tile + (int)gridDim.x;
+  const bool more = PERSIST && next_tile < row_tiles;
+  if (more) {
+    enter_tile(next_tile);
+    issue_prologue();
+  }
+
+  // (PERSIST) everything the epilogue derives from the lane index is invariant across row tiles; left alone, hipcc
+  // hoists all of it - sixteen 64-bit column indices, key addresses - in front of the tile loop and spills it around
+  // the main loop.  These copies are opaque per pass.
+  int r16e = r16, ge = g, lanee = lane;
+  if (PERSIST) asm volatile("" : "+v"(r16e), "+v"(ge), "+v"(lanee));
   // ---- row statistics -> stage-1 window per row (as in sig_kernel's split epilogue) -----------------------
   float* wnd_lds = lds + kRingFloats + wave * kWaveRows;
 #pragma unroll
@@ -1603,11 +1648,11 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     s2 += __shfl_xor(s2, 32);
     float am = __builtin_fmaxf(amax[rt], __shfl_xor(amax[rt], 16));
     am = __builtin_fmaxf(am, __shfl_xor(am, 32));
-    const int64_t myrow = row0 + 16 * rt + r16;
-    if (g == 0) {
+    const int64_t myrow = erow0 + 16 * rt + r16e;
+    if (ge == 0) {
       float window = sqrtf(s2) * args.tau * 1.01f;
       if (am != 0.f && !(am >= 0x1p-60f && am <= 0x1p60f)) window = __builtin_inff();
-      wnd_lds[16 * rt + r16] = window;
+      wnd_lds[16 * rt + r16e] = window;
       if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
         const bool has_nan = s2 != s2;
         const bool zero = (am <= 1e-8f) && !has_nan;
@@ -1618,9 +1663,9 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
 
-  // ---- sign bits.  One v_cmp per accumulator register = 4 rows (g') x 16 columns: its low 32 bits are rows g' = 0, 1,
-  // its high 32 bits rows g' = 2, 3 of the tile.  Per 32-row group, lane L owns the ROW PAIR p = L / 4 = (rtl, g'-pair,
-  // reg) - rows 16 rtl + 8 g'pair + reg and + 4 - and the 32-column words 2 (L % 4), + 1: the ballot halves of the even
+  // ---- sign bits.  One v_cmp per accumulator register = 4 rows (ge') x 16 columns: its low 32 bits are rows ge' = 0, 1,
+  // its high 32 bits rows ge' = 2, 3 of the tile.  Per 32-row group, lanee L owns the ROW PAIR p = L / 4 = (rtl, ge'-pair,
+  // reg) - rows 16 rtl + 8 ge'pair + reg and + 4 - and the 32-column words 2 (L % 4), + 1: the ballot halves of the even
   // column tile land in A[], of the odd one in B[] (deposit_positive: v_cmp, the two wait states a VALU-written SGPR
   // needs, two v_writelane), and two VALU ops per word merge the 16-bit halves.  Same instruction count per
   // accumulator register as the 32x32 epilogue.
@@ -1631,8 +1676,8 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
     for (int rtl = 0; rtl < 2; ++rtl) {
       const int rt = 2 * G + rtl;
-      const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * g);   // rows 16 rt + 4 g + 0..3
-      // wave-uniform-per-lane screen: the largest window of this lane's four rows (a non-finite window - NaN or Inf
+      const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * ge);   // rows 16 rt + 4 ge + 0..3
+      // wave-uniform-per-lanee screen: the largest window of this lanee's four rows (a non-finite window - NaN or Inf
       // in the row, or a magnitude outside the guarded range - makes it +inf: everything goes to the exact test)
       float tsmax = __builtin_fmaxf(__builtin_fmaxf(wnd[0], wnd[1]), __builtin_fmaxf(wnd[2], wnd[3]));
       if (!(wnd[0] < __builtin_inff()) || !(wnd[1] < __builtin_inff()) || !(wnd[2] < __builtin_inff()) ||
@@ -1647,7 +1692,7 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const float y0 = acc[rt][2 * w][reg], y1 = acc[rt][2 * w + 1][reg];
-          const int p0 = 8 * rtl + reg * 2;             // pair (rtl, reg, g'pair = 0); g'pair = 1 is p0 + 1
+          const int p0 = 8 * rtl + reg * 2;             // pair (rtl, reg, ge'pair = 0); ge'pair = 1 is p0 + 1
           deposit_positive(A[w & 1], y0, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
           deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
           asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));
@@ -1656,30 +1701,30 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int ct = 2 * w + half;
-            const float pn = args.norms[cb * 256 + 16 * ct + r16];
+            const float pn = args.norms[cb * 256 + 16 * ct + r16e];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
               float thr = wnd[reg] * pn;
               thr = thr > 0.f ? thr : -1.f;                               // zero row / zero-padded column: y is exactly 0
-              const int64_t grow = row0 + 16 * rt + 4 * g + reg;
+              const int64_t grow = erow0 + 16 * rt + 4 * ge + reg;
               if (!(__builtin_fabsf(acc[rt][ct][reg]) > thr) && grow < args.n) {
                 const int slot = atomicAdd(args.tie_count, 1);
-                if (slot < args.tie_cap) args.tie_list[slot] = (grow << 21) | (int64_t)(cb * 256 + 16 * ct + r16);
+                if (slot < args.tie_cap) args.tie_list[slot] = (grow << 21) | (int64_t)(cb * 256 + 16 * ct + r16e);
               }
             }
           }
         }
       }
     }
-    // lane L: pair p = L / 4 -> rows lo / lo + 4, words 2 (L % 4), + 1
-    const int pr = lane >> 2, wq = 2 * (lane & 3);
+    // lanee L: pair p = L / 4 -> rows lo / lo + 4, words 2 (L % 4), + 1
+    const int pr = lanee >> 2, wq = 2 * (lanee & 3);
     const int rlo = 16 * (pr >> 3) + 8 * (pr & 1) + ((pr >> 1) & 3);
     const uint32_t wlo[2] = {(A[0] & 0xFFFFu) | (B[0] << 16), (A[1] & 0xFFFFu) | (B[1] << 16)};
     const uint32_t whi[2] = {(A[0] >> 16) | (B[0] & 0xFFFF0000u), (A[1] >> 16) | (B[1] & 0xFFFF0000u)};
     const int byte0 = (cb * 8 + wq) * 4;
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
-      const int64_t grow = row0 + 32 * G + rlo + 4 * hl;
+      const int64_t grow = erow0 + 32 * G + rlo + 4 * hl;
       if (grow < args.n) {
         uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
         const uint32_t w0 = hl ? whi[0] : wlo[0], w1 = hl ? whi[1] : wlo[1];
@@ -1695,11 +1740,19 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
       }
     }
   }
-  if (args.clock_probe != nullptr && tid == 0) {
+  if (args.clock_probe != nullptr && tid == 0 && first_pass) {
     const unsigned long long slot = (unsigned long long)gridDim.y * gridDim.x + (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
     args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
     args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
   }
+  if (!more) break;
+  row_tile = next_tile;
+  // recomputed rather than kept: across the epilogue, the register-hungriest stretch of the kernel, nothing of the
+  // main loop's addressing stays live
+  enter_tile(row_tile);
+  // every wave must be done with this tile's window slots (wnd_lds) before the next pass overwrites them: the barrier
+  // at the top of the pass comes before any such write
+  }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1989,7 +2042,7 @@ int lshrs_debug_set_split_m(int m) {
 }
 
 int lshrs_debug_set_split_pipe(int p) {
-  if (p != 3 && p != 4 && p != 6 && p != 7) return LSHRS_E_BADARG;
+  if (p != 3 && p != 4 && p != 6 && p != 7 && p != 8) return LSHRS_E_BADARG;
   g_split_pipe = p;
   return 0;
 }
@@ -2174,11 +2227,25 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   if (g_split_m == 2) {
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles, one workgroup per CU
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
-    if (g_split_pipe == 6 || g_split_pipe == 7) {
+    if (g_split_pipe == 6 || g_split_pipe == 7 || g_split_pipe == 8) {
       a.image = base + sig_t16_offset_floats(g);
       if (g_split_pipe == 6)
         hipLaunchKernelGGL((sig16_kernel<4, 4>), grid, block, 0, s, a);               // 16x16x32 MFMAs, one wave per SIMD
-      else
+      else if (g_split_pipe == 8) {
+        // persistent: one workgroup per CU (144 KiB of LDS each) walks the row tiles of its column block
+        static int cus = 0;
+        if (cus == 0) {
+          int dev = 0, v = 0;
+          if (hipGetDevice(&dev) == hipSuccess &&
+              hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+          else
+            cus = 256;
+        }
+        const unsigned gx = grid.x < (unsigned)cus ? grid.x : (unsigned)cus;
+        hipExtLaunchKernelGGL((sig16_kernel<2, 8, true>), dim3(gx, grid.y, 1), dim3(512, 1, 1), 0, s,
+                              g_split_time_events[0], g_split_time_events[1], 0, a);
+      } else
         hipExtLaunchKernelGGL((sig16_kernel<2, 8>), grid, dim3(512, 1, 1), 0, s, g_split_time_events[0],
                               g_split_time_events[1], 0, a);                              // ... two waves per SIMD
     } else if (g_split_pipe == 4)

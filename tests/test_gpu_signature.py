@@ -518,7 +518,7 @@ def test_split_kernel_variants_agree(torch_mod):
             x[5] = 0.0
             x[6, 1] = float("nan")
             want = _hasher(seed, nb, r, dim, precision="f32").hash_device(x, tie_break="none")
-            for pipe, m in ((4, 2), (3, 2), (3, 1), (6, 2), (7, 2)):
+            for pipe, m in ((4, 2), (3, 2), (3, 1), (6, 2), (7, 2), (8, 2)):
                 assert lib.lshrs_debug_set_split_pipe(pipe) == 0 and lib.lshrs_debug_set_split_m(m) == 0
                 hs = _hasher(seed, nb, r, dim)
                 hs.split_min_elems = 0
