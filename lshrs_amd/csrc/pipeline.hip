@@ -97,11 +97,11 @@ struct Slot {
   int64_t copied = 0;              // entries the speculative copy of this chunk covered
   uint8_t* h_patch = nullptr;      // pinned: rows int64[pairs_cap] | bands int32[pairs_cap] | keys u8[pairs_cap * bb]
   hipEvent_t exported = nullptr, scattered = nullptr;
-  // t_end: after the chunk's last kernel on the caller's stream.  ONE event per chunk boundary: it releases the
-  // export on the side stream, ends this chunk's fix-up time and starts the next chunk's stage-1 time (an event
-  // costs the stream ~6 us of dispatch gap; three per boundary were 5 % of a step).  k1s..k2e: start/stop events
-  // riding on the stage-1 and stage-2 dispatches, armed only when the caller asked for times.
-  hipEvent_t k1s = nullptr, k1e = nullptr, k2s = nullptr, k2e = nullptr, t_end = nullptr, t_next = nullptr;
+  // t_end: after the chunk's last kernel on the caller's stream; it releases the export on the side stream.  ONE
+  // event packet per chunk boundary (each costs the stream ~6 us of dispatch gap; three per boundary were 5 % of a
+  // step).  k1s..k2e: armed only when the caller asked for times - start/stop events riding on the stage-1 and
+  // stage-2 dispatches of the split pass, or k1s/k1e as markers around the f32 kernel's launch(es).
+  hipEvent_t k1s = nullptr, k1e = nullptr, k2s = nullptr, k2e = nullptr, t_end = nullptr;
   bool scatter_pending = false;
 };
 
@@ -112,7 +112,7 @@ struct Pipe {
   int64_t pairs_cap = 0;
   hipStream_t side = nullptr, aux = nullptr;
   double tie_rate = 0.004;         // ties per row seen lately (sizes the speculative copy; measured 0.0026 at tau_ulps = 8)
-  hipEvent_t done = nullptr, t_begin = nullptr;
+  hipEvent_t done = nullptr;
   int32_t* d_counts = nullptr;     // device int32[2 * counts_cap]: (tie count, stage-1 count) per chunk of a call
   int counts_cap = 0;
   int zeroed_chunks = 0;           // leading counter pairs already zeroed (behind `zeroed`) by the end of the last call
@@ -137,12 +137,11 @@ void pipe_free(Pipe* p) {
     if (s.h_head) (void)hipHostFree(s.h_head);
     if (s.h_rows) (void)hipHostFree(s.h_rows);
     if (s.h_patch) (void)hipHostFree(s.h_patch);
-    for (hipEvent_t e : {s.exported, s.scattered, s.k1s, s.k1e, s.k2s, s.k2e, s.t_end, s.t_next})
+    for (hipEvent_t e : {s.exported, s.scattered, s.k1s, s.k1e, s.k2s, s.k2e, s.t_end})
       if (e) (void)hipEventDestroy(e);
   }
   if (p->d_counts) (void)hipFree(p->d_counts);
   if (p->done) (void)hipEventDestroy(p->done);
-  if (p->t_begin) (void)hipEventDestroy(p->t_begin);
   if (p->zeroed) (void)hipEventDestroy(p->zeroed);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->aux) (void)hipStreamDestroy(p->aux);
@@ -196,7 +195,6 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
   }
   PIPE_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
   PIPE_TRY(hipEventCreateWithFlags(&p->done, hipEventDisableTiming));
-  PIPE_TRY(hipEventCreate(&p->t_begin));
   PIPE_TRY(hipEventCreateWithFlags(&p->zeroed, hipEventDisableTiming));
   for (Slot& s : p->slot) {
     PIPE_TRY(hipMalloc(&s.tie_list, sizeof(int64_t) * 2 * (size_t)tie_cap));
@@ -215,7 +213,6 @@ void* lshrs_pipe_create(int32_t num_bands, int32_t rows_per_band, int32_t dim, i
     PIPE_TRY(hipEventCreate(&s.k2s));
     PIPE_TRY(hipEventCreate(&s.k2e));
     PIPE_TRY(hipEventCreate(&s.t_end));
-    PIPE_TRY(hipEventCreate(&s.t_next));
   }
   return p;
 fail:
@@ -257,6 +254,8 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
   hipStream_t main = static_cast<hipStream_t>(stream);
   const int row_bytes = p->nb * p->bb;
   const bool vec = (p->dim % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  // (the split entry point hands anything else to the f32 kernel itself; deciding it here keeps the timing honest)
+  const bool split_ok = vec && (p->dim % 32 == 0) && ldx < (1 << 20);
   int rc = 0;
   int64_t s_ties = 0, s_pairs = 0, s_flagmax = 0, t_head = 0, t_enq = 0, t_wait = 0, t_res = 0, t_scat = 0, t_tail = 0, t_res_last = 0, s_topups = 0;
 
@@ -293,19 +292,22 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       uint8_t* fl = row_flags != nullptr ? row_flags + lo : nullptr;
       int32_t* cnt = p->d_counts + 2 * (size_t)c;
       hipError_t e;
-      if (chunk_ms != nullptr) {
-        if (c == 0 && (e = hipEventRecord(p->t_begin, main)) != hipSuccess) return -(int)e;
-        if (chunk_split[c]) (void)lshrs_debug_set_split_time_events(s.k1s, s.k1e, s.k2s, s.k2e);
-      }
+      // Times, when asked for.  Split pass: start/stop events that ride on the dispatch packets of its two kernels
+      // (what a kernel trace reports; no packet of their own in the stream).  f32 kernel (one or two launches): a
+      // marker event on either side of the call.
+      const bool split = chunk_split[c] != 0 && split_ok;
       int r;
-      if (chunk_split[c])
+      if (split) {
+        if (chunk_ms != nullptr) (void)lshrs_debug_set_split_time_events(s.k1s, s.k1e, s.k2s, s.k2e);
         r = lshrs_sig_hash_batch_split_f32(xs, hi - lo, ldx, workspace, p->nb, p->r, p->dim, ks, s.tie_list, p->tie_cap,
                                            cnt, tau, fl, s.flag_list, p->flag_cap, cnt + 1, tau1, stream);
-      else
+        (void)lshrs_debug_set_split_time_events(nullptr, nullptr, nullptr, nullptr);
+      } else {
+        if (chunk_ms != nullptr && (e = hipEventRecord(s.k1s, main)) != hipSuccess) return -(int)e;
         r = lshrs_sig_hash_batch_f32(xs, hi - lo, ldx, workspace, p->nb, p->r, p->dim, ks, s.tie_list, p->tie_cap, cnt,
                                      tau, fl, stream);
-      (void)lshrs_debug_set_split_time_events(nullptr, nullptr, nullptr, nullptr);   // (a split call that fell through
-                                                                                     // to the f32 kernel left them set)
+        if (chunk_ms != nullptr && (e = hipEventRecord(s.k1e, main)) != hipSuccess) return -(int)e;
+      }
       if (r != 0) return r;
       if ((e = hipEventRecord(s.t_end, main)) != hipSuccess) return -(int)e;
       // The export runs beside the next chunk's signature pass on the side stream — where it gets no CU before that
@@ -346,11 +348,6 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
           return -(int)e;
       }
       if ((e = hipEventRecord(s.exported, xstream)) != hipSuccess) return -(int)e;
-      // an export on the caller's stream sits between this chunk's t_end and the next chunk's stage 1: when times are
-      // asked for, the next chunk's stage-1 clock starts behind it
-      if (chunk_ms != nullptr && on_main && c + 1 < n_chunks &&
-          (e = hipEventRecord(s.t_next, main)) != hipSuccess)
-        return -(int)e;
       return 0;
     };
 
@@ -366,23 +363,11 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       t_wait += t1 - t0;
       if (c == n_chunks - 1) t_tail = t1 - t_entry;
       if (chunk_ms != nullptr) {
-        float a = -1.f, b = -1.f;
-        // (the previous chunk's slot is re-armed by the enqueue just below: read before that)
-        hipEvent_t t_start = c == 0 ? p->t_begin
-                                    : (c - 1 >= n_chunks - p->export_main ? p->slot[(c - 1) % kSlots].t_next
-                                                             : p->slot[(c - 1) % kSlots].t_end);
-        // split pass: the two kernels' own start/stop events (they ride on the dispatch packets: exactly what a kernel
-        // trace reports, no packet of their own in the stream); f32 kernel: boundary event to boundary event
-        if (chunk_split[c] && hipEventElapsedTime(&a, s.k1s, s.k1e) == hipSuccess &&
-            hipEventElapsedTime(&b, s.k2s, s.k2e) == hipSuccess) {
-          chunk_ms[2 * c] = a;
-          chunk_ms[2 * c + 1] = b;
-        } else {
-          (void)hipGetLastError();
-          PIPE_TRY(hipEventElapsedTime(&a, t_start, s.t_end));
-          chunk_ms[2 * c] = a;
-          chunk_ms[2 * c + 1] = -1.f;
-        }
+        float a = -1.f, b = -1.f;     // (this slot is re-armed three chunks on: read now)
+        PIPE_TRY(hipEventElapsedTime(&a, s.k1s, s.k1e));
+        if (chunk_split[c] != 0 && split_ok) PIPE_TRY(hipEventElapsedTime(&b, s.k2s, s.k2e));
+        chunk_ms[2 * c] = a;
+        chunk_ms[2 * c + 1] = b;
       }
       if (c + kAhead < n_chunks) {
         if ((rc = enqueue(c + kAhead)) != 0) goto fail;

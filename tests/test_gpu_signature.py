@@ -309,8 +309,11 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     h = _hasher(5, 8, 12, 100)
     big = torch.randn(140_001, 103, device="cuda", generator=gen)
     x = big[:, 1:101]
+    h.kernel_events = []                                   # times of the f32 kernel's launches come back too
     got = h.hash_device(x)
+    ev, h.kernel_events = h.kernel_events, None
     assert h.last_stats.get("pipeline") == "native" and h.last_stats["tie_pairs"] > 0
+    assert [e[2] for e in ev] == [65_536, 65_536, 8_929] and all(0 < e[0] < 50 and e[3] is None for e in ev)
     h.pipeline_chunk_rows = 10**9
     assert torch.equal(got, h.hash_device(x))
     # (b) one row more than two chunks
