@@ -309,6 +309,10 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
         if (chunk_ms != nullptr && (e = hipEventRecord(s.k1e, main)) != hipSuccess) return -(int)e;
       }
       if (r != 0) return r;
+      // (Tried: stage 2 of the mid-batch chunks on the side stream, behind the stop event that rides on stage 1's
+      // dispatch, so that the stage-1 kernels follow each other directly.  Correct, and slower - 1.42-1.48 against
+      // 1.39-1.44 ms per step: the fix-up's latency-bound waves, 48 KiB of LDS each, keep whole CUs from the pass
+      // beside them for ~100 us per chunk, far more than the two dispatch gaps they were meant to save.)
       if ((e = hipEventRecord(s.t_end, main)) != hipSuccess) return -(int)e;
       // The export runs beside the next chunk's signature pass on the side stream — where it gets no CU before that
       // pass's first round of workgroups retires (~70 us; they take whole register files).  Harmless in mid-batch,
