@@ -1,13 +1,15 @@
 // pipeline.hip — native driver of the bit-exact signature path for large device-resident batches
 // (C ABI: lshrs_pipe_* in include/lshrs_hip.h; design: DESIGN.md "Host pipeline").
 //
-// Per chunk:   caller's stream : signature pass (split-precision or f32 kernel; lshrs_hip.hip)
-//              side stream     : export_ties_kernel — tie entries, their X rows and both counters written
-//                                straight into pinned host memory (count read on the device: one wait on the
-//                                host instead of count round trip + sized copies)
-//              host            : resolve() = the reference's own BLAS call on the flagged (row, band) pairs
-//                                (lshrs_tb_resolve, liblshrs_host.so), patches land in pinned memory
-//              side stream     : scatter_keys_kernel reads the patches from that pinned memory
+// Per chunk c of n:
+//   caller's stream : signature pass (split-precision or f32 kernel; lshrs_hip.hip)
+//   side stream     : c < n-2: export_ties_kernel gathers the tie entries, their X rows and both counters into a
+//                     device image, and a speculative prefix of it (the count is not known on the host yet) is copied
+//                     to pinned host memory; c >= n-2: the same kernel, on the caller's stream, writes the pinned
+//                     memory itself
+//   host            : one wait, then resolve() = the reference's own BLAS call on the flagged (row, band) pairs
+//                     (lshrs_tb_resolve, liblshrs_host.so); patches land in pinned memory
+//   side stream     : scatter_keys_kernel reads the patches from that pinned memory
 // The GPU is kept two chunks ahead of the host; three slots of scratch rotate.
 
 #include <hip/hip_runtime.h>
@@ -29,38 +31,38 @@ constexpr int kAhead = 2;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Entry e < min(*tie_count, tie_cap): host_entries[e] = tie_list[e], host_rows[e] = X[row of e] (dim floats,
-// contiguous).  host_counts = (ties wanted, stage-1 entries wanted).  All destinations are pinned host memory.
-// One WAVE per entry, few workgroups: the kernel runs beside the next chunk's signature pass, whose workgroups need
-// a CU's whole register file — every CU that holds an export wave is closed to them until that wave retires.
-// Under that pass's HBM stream a wave's dependent loads (entry -> row -> store) take several us each, so the waves
-// must be many enough to take one or two entries each (16 workgroups: 90-110 us per 262 144-row chunk by the
-// kernel trace, which left the host two chunks to resolve after the last kernel; 2: 200 us; 1024: signature pass
-// +2 %); sweep in DESIGN.md.
+// Entry e < min(*tie_count, tie_cap): out_entries[e] = tie_list[e], out_rows[e] = X[row of e] (dim floats,
+// contiguous); out_counts = (ties wanted, stage-1 entries wanted).  The destinations are a device image or pinned host
+// memory (see above).  One WAVE per entry.  Mid-batch the kernel runs beside the next chunk's signature pass, whose
+// workgroups take a CU's whole register file: it gets CUs only as those retire, every CU that holds an export wave
+// is closed to the pass until that wave is done, and under the pass's HBM stream a wave's dependent loads (entry ->
+// row -> store) take several us each - so: enough waves for one or two entries each, not more (measured with host
+// destinations: 2 workgroups 200 us per 262 144-row chunk, 16: 90-110 us, 128: as 16 with a shorter tail, 1024:
+// signature pass +2 %).
 constexpr int kExportBlocks = 128;
 template <bool VEC>
 __global__ __launch_bounds__(256) void export_ties_kernel(const float* __restrict__ X, int64_t ldx, int dim,
                                                           const int64_t* __restrict__ tie_list,
                                                           const int32_t* __restrict__ counts, int tie_cap,
-                                                          int64_t* __restrict__ host_entries,
-                                                          float* __restrict__ host_rows,
-                                                          int32_t* __restrict__ host_counts) {
+                                                          int64_t* __restrict__ out_entries,
+                                                          float* __restrict__ out_rows,
+                                                          int32_t* __restrict__ out_counts) {
   const int wanted = counts[0];
   const int cnt = wanted < tie_cap ? wanted : tie_cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    host_counts[0] = wanted;
-    host_counts[1] = counts[1];
+    out_counts[0] = wanted;
+    out_counts[1] = counts[1];
   }
   const int lane = threadIdx.x & 63;
   const int waves = gridDim.x * (blockDim.x >> 6);
   for (int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < cnt; e += waves) {
     const int64_t e0 = tie_list[2 * (int64_t)e], e1 = tie_list[2 * (int64_t)e + 1];
     if (lane == 0) {
-      host_entries[2 * (int64_t)e] = e0;
-      host_entries[2 * (int64_t)e + 1] = e1;
+      out_entries[2 * (int64_t)e] = e0;
+      out_entries[2 * (int64_t)e + 1] = e1;
     }
     const float* __restrict__ src = X + (e0 >> 16) * ldx;
-    float* __restrict__ dst = host_rows + (int64_t)e * dim;
+    float* __restrict__ dst = out_rows + (int64_t)e * dim;
     if (VEC) {
       const int n4 = dim >> 2;
       for (int k0 = 0; k0 < n4; k0 += 256) {        // four 16-byte loads per lane in flight, then their stores
