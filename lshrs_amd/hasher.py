@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 import threading
 import time
 from typing import Dict, List, Optional, Tuple
@@ -530,6 +531,14 @@ class LSHHasher:
             spans = merged + spans[len(head):]
             cap = 2 * ch // 32 + 1024
             ch = 2 * ch
+        forced = os.environ.get("LSHRS_PLAN")            # experiments: "524288,262144,..." (rows per chunk, must sum to n)
+        if forced:
+            sizes = [int(v) for v in forced.split(",")]
+            if sum(sizes) == n:
+                edges = np.cumsum([0] + sizes)
+                spans = [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:])]
+                ch = max(sizes)
+                cap = ch // 32 + 1024
         return ch, cap, spans
 
     def _native_pipe(self, lib, dev, cap: int, flag_cap: int):
