@@ -128,8 +128,8 @@ int lshrs_scatter_band_keys_u8(uint8_t* keys, int32_t num_bands, int32_t band_by
  * LSHRS.index / create_signatures hashing a whole loader batch (lshrs/core/main.py:1125-1143 → lsh.py:136-169)
  * with the tie-break overlapped: per chunk  signature pass → (side stream) tie entries + their vectors straight
  * into pinned host memory → `resolve` (the reference's own BLAS call, lshrs_tb_resolve of lshrs_host.h) →
- * (side stream) scatter of the patched band keys.  The GPU is kept two chunks ahead of the host.
- * The pipeline object is the one exception to "the library allocates nothing": it owns three slots of device
+ * (side stream) scatter of the patched band keys.  The GPU is kept three chunks ahead of the host.
+ * The pipeline object is the one exception to "the library allocates nothing": it owns four slots of device
  * scratch (tie list, stage-1 list), their pinned host mirrors, one high-priority side stream and its events.
  * ------------------------------------------------------------------------------------------ */
 

@@ -10,7 +10,8 @@
 //   host            : one wait, then resolve() = the reference's own BLAS call on the flagged (row, band) pairs
 //                     (lshrs_tb_resolve, liblshrs_host.so); patches land in pinned memory
 //   side stream     : scatter_keys_kernel reads the patches from that pinned memory
-// The GPU is kept two chunks ahead of the host; three slots of scratch rotate.
+// The GPU is kept three chunks ahead of the host (a 1M-row batch is four chunks: the host never gates a launch);
+// four slots of scratch rotate.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,8 +27,8 @@ extern "C" int lshrs_debug_set_split_time_events(void* k1_start, void* k1_stop, 
 
 namespace {
 
-constexpr int kSlots = 3;
-constexpr int kAhead = 2;
+constexpr int kSlots = 4;
+constexpr int kAhead = 3;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -369,7 +370,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       t_wait += t1 - t0;
       if (c == n_chunks - 1) t_tail = t1 - t_entry;
       if (chunk_ms != nullptr) {
-        float a = -1.f, b = -1.f;     // (this slot is re-armed three chunks on: read now)
+        float a = -1.f, b = -1.f;     // (this slot is re-armed kSlots chunks on: read now)
         PIPE_TRY(hipEventElapsedTime(&a, s.k1s, s.k1e));
         if (chunk_split[c] != 0 && split_ok) PIPE_TRY(hipEventElapsedTime(&b, s.k2s, s.k2e));
         chunk_ms[2 * c] = a;
@@ -401,7 +402,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
         PIPE_TRY(hipStreamSynchronize(p->aux));
         ++s_topups;
       }
-      if (s.scatter_pending) {   // (three chunks ago: long finished)
+      if (s.scatter_pending) {   // (kSlots chunks ago: long finished)
         PIPE_TRY(hipEventSynchronize(s.scattered));
         s.scatter_pending = false;
       }
