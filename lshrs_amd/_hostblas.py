@@ -140,6 +140,9 @@ def _core_budget() -> int:
 def default_threads() -> int:
     """Worker count: half of this process's share of the core budget (the ranks of one node divide it; the workers
     poll between chunks, and the Python thread, the HIP runtime and NumPy need cores too), at most 8."""
+    forced = os.environ.get("LSHRS_TIE_THREADS")
+    if forced:
+        return max(1, min(64, int(forced)))
     ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     return max(1, min(8, _core_budget() // ranks // 2))
 

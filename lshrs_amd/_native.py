@@ -180,8 +180,14 @@ def check(code: int, what: str) -> None:
     raise NativeLibraryError(f"{what}: HIP error {-code}")
 
 
+_torch_ok = None
+
+
 def require_gpu():
     """Return the torch module after checking a GPU is usable; raise loudly otherwise."""
+    global _torch_ok
+    if _torch_ok is not None:          # (checked once per process: this sits on the per-call path of the hasher)
+        return _torch_ok
     import torch
 
     if not torch.cuda.is_available():
@@ -189,4 +195,5 @@ def require_gpu():
             "no MI355X/ROCm device is visible to PyTorch; lshrs_amd computes only on the GPU "
             "(there is no CPU fallback)."
         )
+    _torch_ok = torch
     return torch

@@ -594,20 +594,23 @@ class LSHHasher:
                 bounds.ctypes.data, chunk_split.ctypes.data, nc, eng.resolve_fn, eng.handle, planes.ctypes.data,
                 status.ctypes.data, ms.ctypes.data if timing else None, st.ctypes.data, main.cuda_stream)
         _native.check(int(rc), "lshrs_pipe_hash_f32")
-        stats["tie_entries"] += int(st[0])
-        stats["tie_pairs"] += int(st[1])
+        sv = st.tolist()
+        stats["tie_entries"] += sv[0]
+        stats["tie_pairs"] += sv[1]
         for key, i in (("t_head_ms", 3), ("t_enqueue_ms", 4), ("t_wait_ms", 5), ("t_patch_ms", 6), ("t_scatter_ms", 7),
                        ("t_tail_count_ms", 8), ("t_native_ms", 9), ("t_patch_last_ms", 10)):
-            stats[key] = float(st[i]) * 1e-6
+            stats[key] = sv[i] * 1e-6
         stats["pipeline"] = "native"
-        stats["export_topups"] = int(st[11])     # chunks whose speculative device->host copy fell short
+        stats["export_topups"] = sv[11]     # chunks whose speculative device->host copy fell short
         if timing:
             for ci, (lo, hi) in enumerate(spans):
                 fix = float(ms[2 * ci + 1])
                 self.kernel_events.append((float(ms[2 * ci]), None, hi - lo, fix if fix >= 0 else None))
-        overflow = [spans[ci] for ci in range(nc) if status[ci] != 0]
-        if any(status[ci] == 2 for ci in range(nc)):
-            self._flag_cap_hint = int(int(st[2]) * 1.25) + 4096
+        overflow = []
+        if status.any():
+            overflow = [spans[ci] for ci in range(nc) if status[ci] != 0]
+            if (status == 2).any():
+                self._flag_cap_hint = int(sv[2] * 1.25) + 4096
         stats["t_total_ms"] = 1e3 * (time.perf_counter() - t_entry)
         return self._redo_overflowed(x, out, row_flags, overflow, stats)
 
