@@ -1129,10 +1129,10 @@ __global__ __launch_bounds__(64) void sig_fix_kernel(const FixArgs a) {
 // k-tile of x row g and of hyperplane column g go HBM/L2 -> LDS by LDS-DMA, landing as [k-tile][chunk][g] (one
 // instruction = one k-tile of all eight projections = 1 KiB), and every lane then runs the canonical chain of ITS g
 // from ds_read_b128s that hit eight distinct 16-byte slots (the eight lanes sharing a g read the same slot: broadcast).
-// 1/8 of the waves, the same chain length per wave: one resident round of 768 waves covers a chunk's list.
+// 1/8 of the waves, the same chain length per wave: one resident round of 1536 waves covers even a 524 288-row chunk's list.
 constexpr int kFixG = 8;
-constexpr int kFixSlabG = 24;      // k-tiles per slab: 2 x 24 x 8 chunks x 8 projections x 16 B = 48 KiB of LDS per wave
-constexpr int kFixGridG = 768;     // 256 CUs x 3 resident single-wave workgroups
+constexpr int kFixSlabG = 12;      // k-tiles per slab: 2 x 12 x 8 chunks x 8 projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is two slabs)
+constexpr int kFixGridG = 1536;    // 256 CUs x 6 resident single-wave workgroups (slabs of 24 tiles, 3 per CU: 0.085 ms of fix-ups per 1M rows; 12: 0.074; 8: 0.075)
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 xs[kFixSlabG * 8 * kFixG];
   __shared__ __attribute__((aligned(16))) f32x4 ps[kFixSlabG * 8 * kFixG];
