@@ -1555,7 +1555,9 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
+#if !(LSHRS_SPLIT_PROBE & 8)
     __builtin_amdgcn_s_barrier();
+#endif
   };
   // tile t with its sets (hc, mc); the previous tile's (hp, mp) double as the target of the next tile's split
   auto tile = [&](int t, const bool first, Bf16Pairs (&hc)[RT], Bf16Pairs (&mc)[RT], Bf16Pairs (&hp)[RT], Bf16Pairs (&mp)[RT]) {
