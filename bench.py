@@ -14,7 +14,9 @@ collective in the data path): weak scaling.  Rank 0 prints ONE JSON line.
 
 Also in the line:
   roofline      the dominant kernel of the step alone, timed with HIP events on the launch stream inside
-                the timed region.  The default hasher takes the split-precision pass (bf16 matrix cores +
+                the timed region (start/stop events that ride on the kernel's dispatch packet, set by the
+                library's pipeline driver: the kernel's own duration, every launch of every timed step).
+                The default hasher takes the split-precision pass (bf16 matrix cores +
                 exact f32 fix-up, same bits): its stage-1 kernel is priced against HBM (it has left the f32
                 matrix roof behind; algorithmic bytes = 3 104 B per vector), with both matrix-core views
                 beside it; `roofline_f32_kernel` prices the exact-f32 kernel (precision="f32") against the
