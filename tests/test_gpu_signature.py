@@ -246,6 +246,27 @@ def test_config2_all_1m_rows_byte_identical_to_the_literal_cpu_path(torch_mod):
     assert raw_bits < 200, raw_bits
 
 
+def test_config5_shape_300k_rows_byte_identical_to_the_literal_cpu_path(torch_mod):
+    """BASELINE config 5's shape (1536-d, num_perm 512 -> 16 bands x 32 rows, hasher seed 7; two column blocks in the
+    split pass) on 300k device-generated rows, every band key against the reference-literal loop on every host core."""
+    torch = torch_mod
+    from oracle.parallel import SharedVectors, hash_shared_literal_packed
+
+    n, dim = 300_000, 1536
+    h = _hasher(7, 16, 32, dim)
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    assert h._split_applies(n)
+    got = h.hash_device(x).cpu().numpy()
+    stats = dict(h.last_stats)
+    with SharedVectors(n, dim) as sv:
+        sv.array[:] = x.cpu().numpy()
+        del x
+        want = hash_shared_literal_packed(h.projections, sv)
+    assert got.shape == (n, 16, 4) and stats["relaunches"] == 0 and stats["tie_pairs"] > 500
+    differing_rows = int((got != want).any(axis=(1, 2)).sum())
+    assert differing_rows == 0, f"{differing_rows} of {n} rows differ from the reference-literal CPU path"
+
+
 def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     """Large device batches overlap the host tie-break with later chunks' kernels: same bytes."""
     torch = torch_mod
