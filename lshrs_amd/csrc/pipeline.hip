@@ -371,8 +371,11 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       if (c == n_chunks - 1) t_tail = t1 - t_entry;
       if (chunk_ms != nullptr) {
         float a = -1.f, b = -1.f;     // (this slot is re-armed kSlots chunks on: read now)
-        PIPE_TRY(hipEventElapsedTime(&a, s.k1s, s.k1e));
-        if (chunk_split[c] != 0 && split_ok) PIPE_TRY(hipEventElapsedTime(&b, s.k2s, s.k2e));
+        // Diagnostics must not fail the batch: the split pass picks its events up from a process-wide hook, which a
+        // second hasher timing its own launches from another thread at the same moment can take away (-1 then).
+        if (hipEventElapsedTime(&a, s.k1s, s.k1e) != hipSuccess) a = -1.f;
+        if (chunk_split[c] != 0 && split_ok && hipEventElapsedTime(&b, s.k2s, s.k2e) != hipSuccess) b = -1.f;
+        (void)hipGetLastError();
         chunk_ms[2 * c] = a;
         chunk_ms[2 * c + 1] = b;
       }
