@@ -38,6 +38,13 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
 int lshrs_tb_threads(void* engine);
 void lshrs_tb_destroy(void* engine);
 
+/* One dot product in the summation order of the host BLAS that the GPU's tie replay follows (lshrs_hip.h:
+ * lshrs_sig_hash_batch_split_replay_f32).  model 1: eight interleaved fma chains over k = j (mod 8), reduced as
+ * ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)) - OpenBLAS's 8-lane sgemv_t kernels; n % 8 == 0.  NaN on bad arguments.
+ * Used to check, bit for bit against `projection @ vector` (lshrs/hash/lsh.py:200) of the running process, that the
+ * replay may stand in for the engine below. */
+float lshrs_tb_model_dot(const float* a, const float* x, int64_t n, int32_t model);
+
 /* For pair p in [0, n_pairs): y = planes[band[p]] (rows_per_band x dim, row-major, contiguous) @ xrows[row_index[p]]
  * (row stride ldx floats); out_keys[p*band_bytes ..] = packbits(y > 0, little), band_bytes = ceil(rows_per_band/8).
  * out_y (may be NULL) receives the rows_per_band projections of every pair.  Blocks until done; one call at a

@@ -25,7 +25,7 @@ LIBRARY = os.path.join(_HERE, "csrc", "liblshrs_host.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 ABI_VERSION = 1
 EXPORTS = ("lshrs_host_abi_version", "lshrs_tb_create", "lshrs_tb_threads", "lshrs_tb_destroy", "lshrs_tb_patch",
-           "lshrs_tb_resolve")
+           "lshrs_tb_resolve", "lshrs_tb_model_dot")
 
 # (cblas_sgemv symbol, 64-bit integers?, set_num_threads symbol) in order of preference
 _BLAS_FLAVOURS = (
@@ -82,6 +82,8 @@ def load() -> ctypes.CDLL:
         lib.lshrs_tb_resolve.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_int64,
                                          c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p]
         lib.lshrs_tb_resolve.restype = c.c_int
+        lib.lshrs_tb_model_dot.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_int32]
+        lib.lshrs_tb_model_dot.restype = c.c_float
         if lib.lshrs_host_abi_version() != ABI_VERSION:
             raise OSError(f"{LIBRARY} has a different ABI version; rebuild it")
         _lib = lib
@@ -111,6 +113,52 @@ def numpy_blas() -> Optional[Tuple[str, str, int, str]]:
             if hasattr(handle, sym):
                 return path, sym, ilp64, setter if hasattr(handle, setter) else ""
     return None
+
+
+_order_models: Dict[Tuple[int, int], int] = {}
+
+
+def blas_order_model(planes: np.ndarray) -> int:
+    """Which summation-order model of ``lshrs_tb_model_dot`` (0 = none) reproduces, bit for bit, what this process's
+    NumPy returns for ``P_band @ x`` at this ``(rows_per_band, dim)`` - the licence for the GPU's tie replay
+    (``lshrs_sig_hash_batch_split_replay_f32``) to stand in for the host engine.  Checked on random vectors, on vectors
+    with a wide dynamic range and on vectors built to cancel against a hyperplane (where the order shows), for the
+    first, a middle and the last band, every row of each; cached per shape."""
+    nb, r, dim = planes.shape
+    key = (r, dim)
+    if key in _order_models:
+        return _order_models[key]
+    model = 0
+    try:
+        if dim % 8 == 0 and os.path.exists(LIBRARY):
+            lib = load()
+            rng = np.random.default_rng(20240601)
+            bands = sorted({0, nb // 2, nb - 1})
+            ok = True
+            for b in bands:
+                plane = np.ascontiguousarray(planes[b], dtype=np.float32)
+                xs = [rng.standard_normal(dim) for _ in range(12)]
+                xs += [rng.standard_normal(dim) * np.exp(3.0 * rng.standard_normal(dim)) for _ in range(6)]
+                for i in sorted({0, r // 2, r - 1}):       # nearly orthogonal to row i: y_i is what the order leaves of it
+                    p = plane[i].astype(np.float64)
+                    for _ in range(3):
+                        x = rng.standard_normal(dim)
+                        xs.append(x - (x @ p) / (p @ p) * p)
+                for x in xs:
+                    x32 = np.ascontiguousarray(x, dtype=np.float32)
+                    want = plane @ x32                       # the reference's call (lshrs/hash/lsh.py:200)
+                    got = np.array([lib.lshrs_tb_model_dot(plane[i].ctypes.data, x32.ctypes.data, dim, 1)
+                                    for i in range(r)], dtype=np.float32)
+                    if not np.array_equal(want.view(np.uint32), got.view(np.uint32)):
+                        ok = False
+                        break
+                if not ok:
+                    break
+            model = 1 if ok else 0
+    except OSError:
+        model = 0
+    _order_models[key] = model
+    return model
 
 
 def _core_budget() -> int:

@@ -239,6 +239,21 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
   return e;
 }
 
+// Model of the host BLAS's summation order for one dot product (the order sig_fix8_kernel<true> replays on the GPU).
+// model 1: eight interleaved single-rounded fma chains p_j = sum over k = j (mod 8) of a_k x_k, reduced as
+// ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)); n must be a multiple of 8.  Returns NaN for anything else.
+// The caller (lshrs_amd/hasher.py) compares it bit for bit with `P_band @ x` of the running process before the
+// device replay is allowed to stand in for the host engine.
+float lshrs_tb_model_dot(const float* a, const float* x, int64_t n, int32_t model) {
+  if (model != 1 || a == nullptr || x == nullptr || n <= 0 || n % 8 != 0) return __builtin_nanf("");
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t k = 0; k < n; k += 8)
+    for (int j = 0; j < 8; ++j) p[j] = __builtin_fmaf(a[k + j], x[k + j], p[j]);
+  const float q0 = p[0] + p[4], q1 = p[1] + p[5], q2 = p[2] + p[6], q3 = p[3] + p[7];
+  const float h0 = q0 + q1, h1 = q2 + q3;
+  return h0 + h1;
+}
+
 int lshrs_tb_threads(void* engine) { return engine ? (int)static_cast<Engine*>(engine)->handles.size() : 0; }
 
 void lshrs_tb_destroy(void* engine) {

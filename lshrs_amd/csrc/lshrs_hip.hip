@@ -1017,6 +1017,7 @@ struct FixArgs {
   int tie_cap;
   int* tie_count;
   float tau;
+  int blas_model;         // sig_fix8_kernel<true>: which host-BLAS summation order the tie replay follows (1: see there)
 };
 
 __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f32x4 (&x4)[2][4], float& acc, float& ss) {
@@ -1133,6 +1134,16 @@ __global__ __launch_bounds__(64) void sig_fix_kernel(const FixArgs a) {
 constexpr int kFixG = 8;
 constexpr int kFixSlabG = 12;      // k-tiles per slab: 2 x 12 x 8 chunks x 8 projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is two slabs)
 constexpr int kFixGridG = 1536;    // 256 CUs x 6 resident single-wave workgroups (slabs of 24 tiles, 3 per CU: 0.085 ms of fix-ups per 1M rows; 12: 0.074; 8: 0.075)
+//
+// REPLAY: the tie-break on the device.  A projection whose canonical value is a tie (|y| < tau ||x|| ||p||) gets the
+// sign of the value the HOST BLAS computes for it - the reference's `projection @ vector` (lshrs/hash/lsh.py:200) -
+// by replaying that library's summation order: blas_model 1 = eight interleaved single-rounded fma chains
+// p_j = sum over k = j (mod 8) of a_k x_k, j = 0..7, reduced as ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)) - the
+// 8-lane AVX kernel + vextractf128 / vhaddps / vhaddps of OpenBLAS's sgemv_t (Haswell, Zen and SkylakeX builds;
+// found by search, tools/blas_order/, and checked bit for bit against `P_band @ x` of the running process before a
+// hasher uses it: lshrs_amd/hasher.py).  The eight lanes (sub) that serve one projection - redundant for the
+// canonical chain - each own one p_j, four fmas per k-tile from the slab already in LDS.  No tie list, no host.
+template <bool REPLAY>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 xs[kFixSlabG * 8 * kFixG];
   __shared__ __attribute__((aligned(16))) f32x4 ps[kFixSlabG * 8 * kFixG];
@@ -1153,7 +1164,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     const float* __restrict__ xg = a.X + row * a.ldx + 16 * shh + 4 * sq;
     const float* __restrict__ pg =
         a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats + ((sq * 64) + shh * 32 + c) * 4;
-    float acc = 0.f, ss = 0.f;
+    float acc = 0.f, ss = 0.f, pj = 0.f;
     for (int t0 = 0; t0 < a.ktiles; t0 += kFixSlabG) {
       const int tiles = a.ktiles - t0 < kFixSlabG ? a.ktiles - t0 : kFixSlabG;
       for (int i = 0; i < tiles; ++i) {            // nothing lands in a VGPR: every load of the slab is in flight at once
@@ -1174,21 +1185,43 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
             p4[hh][q] = ps[(t * 8 + hh * 4 + q) * kFixG + g];
           }
         fix_chain_tile(p4, x4, acc, ss);
+        if (REPLAY) {   // k = 32 t + 8 m + sub, m = 0..3: chunk 2 m + (sub >> 2), element sub & 3
+          const float* xf = reinterpret_cast<const float*>(xs);
+          const float* pf = reinterpret_cast<const float*>(ps);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
+            pj = __builtin_fmaf(pf[o], xf[o], pj);
+          }
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab has been read before the next one lands on it
+    }
+    float yb = 0.f;
+    if (REPLAY) {       // (every lane takes part in the shuffles; the result is used by the sub = 0 lanes)
+      const float q = pj + __shfl(pj, (lane + 32) & 63);           // sub 0..3: p_sub + p_(sub+4)
+      const float h = q + __shfl(q, (lane + 8) & 63);              // sub 0: q0 + q1, sub 2: q2 + q3
+      yb = h + __shfl(h, (lane + 16) & 63);                        // sub 0: (q0 + q1) + (q2 + q3)
     }
     if (sub != 0 || !live) continue;
     uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
     unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
     const unsigned int bitmask = 1u << (8 * (unsigned)(addr & 3) + (col & 7));
-    const bool want = acc > 0.f;
+    bool want = acc > 0.f;
+    if (REPLAY) {
+      const float thr = a.tau * sqrtf(ss) * a.norms[col];
+      if (__builtin_fabsf(acc) < thr) {          // a tie: the host BLAS's value decides, as it does in the reference
+        want = yb > 0.f;
+        if (a.tie_count != nullptr) atomicAdd(a.tie_count, 1);
+      }
+    }
     const bool have = (*kb >> (col & 7)) & 1;
     if (want != have) {
       if (want) atomicOr(w32, bitmask);
       else atomicAnd(w32, ~bitmask);
     }
-    if (a.tie_list != nullptr) {
+    if (!REPLAY && a.tie_list != nullptr) {
       const float thr = a.tau * sqrtf(ss) * a.norms[col];
       if (__builtin_fabsf(acc) < thr) {
         const int slot = atomicAdd(a.tie_count, 1);
@@ -2186,10 +2219,12 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
   return 0;
 }
 
-int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
-                                   int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list,
-                                   int32_t tie_cap, int32_t* tie_count, float tau, uint8_t* row_flags,
-                                   int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1, void* stream) {
+// blas_model 0: ties are reported in tie_list (the caller resolves them on the host); > 0: stage 2 resolves them itself
+// by replaying that summation order of the host BLAS (sig_fix8_kernel<true>), tie_list is not used.
+static int split_pass(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                      int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
+                      int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, int32_t flag_cap,
+                      int32_t* flag_count, float tau1, int blas_model, void* stream) {
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
       flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
@@ -2203,9 +2238,11 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
   const bool aligned = (dim % 32 == 0) && (ldx % 4 == 0) && ldx < (1 << 20) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  if (!aligned)  // the split pass is built for whole k-tiles of 16-byte aligned rows; anything else takes the f32 pass (same keys)
+  if (!aligned) {  // the split pass is built for whole k-tiles of 16-byte aligned rows; anything else takes the f32 pass (same keys)
+    if (blas_model != 0) return LSHRS_E_BADARG;   // (the f32 kernel reports ties, it does not resolve them)
     return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
                                     tie_count, tau, row_flags, stream);
+  }
   // stage 1: bf16 x 3 projections -> keys + list of (row, word, mask) inside the stage-1 window
   SigArgs a{};
   a.X = X;
@@ -2283,10 +2320,16 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   f.tie_cap = tie_cap;
   f.tie_count = tie_count;
   f.tau = tau;
-  if (g_fix_mode != 0) {
+  f.blas_model = blas_model;
+  if (blas_model != 0) {
+    f.tie_list = nullptr;
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
-    hipExtLaunchKernelGGL(sig_fix8_kernel, grid, block, 0, s, g_split_time_events[2], g_split_time_events[3], 0, f);
+    hipExtLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, g_split_time_events[2], g_split_time_events[3], 0, f);
+  } else if (g_fix_mode != 0) {
+    const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
+    const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
+    hipExtLaunchKernelGGL(sig_fix8_kernel<false>, grid, block, 0, s, g_split_time_events[2], g_split_time_events[3], 0, f);
   } else {
     const int64_t want = (int64_t)flag_cap < kFixGrid ? (int64_t)flag_cap : kFixGrid;
     const dim3 grid((unsigned)(want < 1 ? 1 : want)), block(64);
@@ -2294,6 +2337,24 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
   }
   for (hipEvent_t& ev : g_split_time_events) ev = nullptr;
   return -(int)hipGetLastError();
+}
+
+int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                                   int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list,
+                                   int32_t tie_cap, int32_t* tie_count, float tau, uint8_t* row_flags,
+                                   int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1, void* stream) {
+  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap, tie_count, tau,
+                    row_flags, flag_list, flag_cap, flag_count, tau1, 0, stream);
+}
+
+int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
+                                          int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
+                                          int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                          int32_t flag_cap, int32_t* flag_count, float tau1, int32_t blas_model,
+                                          void* stream) {
+  if (blas_model != 1 || dim % 8 != 0) return LSHRS_E_BADARG;
+  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, tie_count, tau, row_flags,
+                    flag_list, flag_cap, flag_count, tau1, blas_model, stream);
 }
 
 int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,

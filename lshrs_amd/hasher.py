@@ -100,11 +100,14 @@ class LSHHasher:
                   (every rounding error aligned against a cancelling sum) is 768 units; a hasher that must be
                   safe against inputs crafted for its own hyperplanes should use precision="f32".
       pipeline    "native" (default) / "python": who drives the chunks of a device batch of >= 131 072 rows
+      tie_replay  "auto" (default): batches that take the split pass break their ties on the device (stage 2 replays
+                  the host BLAS's summation order, recognised and verified at first use); "off": host engine only
     """
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps: float = 8.0, precision: str = "bf16x3",
-                 tau1_ulps: float = 64.0, tie_threads: Optional[int] = None, pipeline: str = "native") -> None:
+                 tau1_ulps: float = 64.0, tie_threads: Optional[int] = None, pipeline: str = "native",
+                 tie_replay: str = "auto") -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -154,8 +157,17 @@ class LSHHasher:
         if pipeline not in ("native", "python"):
             raise ValueError("pipeline must be 'native' or 'python'")
         self.pipeline = pipeline
+        # "auto": batches that take the split pass resolve their ties ON THE DEVICE, by replaying the host BLAS's
+        # summation order in stage 2 - provided that order has been recognised on this host (the model is checked
+        # bit for bit against `P_band @ x` of this process, _hostblas.blas_order_model) - and need no chunking, no
+        # export and no host step.  "off": always the host engine / NumPy.  Same bytes either way.
+        if tie_replay not in ("auto", "off"):
+            raise ValueError("tie_replay must be 'auto' or 'off'")
+        self.tie_replay = tie_replay
+        self._replay_model_cache: Optional[Tuple[int, int]] = None
         self._pipes: Dict[tuple, int] = {}
         self._plan_cache: Dict[tuple, tuple] = {}
+        self._replay_scratch: Dict[int, tuple] = {}
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
@@ -263,6 +275,11 @@ class LSHHasher:
             return out
         ws = self._workspace(dev)
         tau = float(self.tau_ulps * _U)
+        if (mode == "host" and host_rows is None and self.tie_replay == "auto" and self._split_applies(n)
+                and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x.stride(0) < (1 << 20)):
+            model = self._replay_model()
+            if model:
+                return self._hash_device_replay(x, out, row_flags, ws, tau, stats, model)
         if allow_pipeline and mode == "host" and host_rows is None and n >= max(131_072, self.pipeline_chunk_rows // 2):
             return self._hash_device_pipelined(x, out, row_flags, ws, tau, stats)
         with torch.cuda.device(dev):
@@ -314,6 +331,65 @@ class LSHHasher:
                                                    bands_dev.data_ptr(), patch_dev.data_ptr(), rows.shape[0], stream),
                     "lshrs_scatter_band_keys_u8")
                 torch.cuda.current_stream(dev).synchronize()  # the small staging tensors die with this frame
+        return out
+
+    # ------------------------------------------------------------------ ties broken on the device
+    def _replay_model(self) -> int:
+        """Summation-order model of the host BLAS for this hasher's shape (0: not recognised -> host engine)."""
+        cached = self._replay_model_cache
+        if cached is None or cached[0] != self._projection_version:
+            planes = self._stacked().reshape(self.num_bands, self.rows_per_band, self.dim)
+            cached = (self._projection_version, int(_hostblas.blas_order_model(planes)))
+            self._replay_model_cache = cached
+        return cached[1]
+
+    def _hash_device_replay(self, x, out, row_flags, ws, tau, stats, model):
+        """One launch of the split pass whose stage 2 also breaks the ties (``lshrs_sig_hash_batch_split_replay_f32``):
+        the keys are the reference's when the stream has run.  The only host step is reading two counters back
+        (stage-1 list overflow -> repeat with room; tied projections -> stats)."""
+        torch = _native.require_gpu()
+        lib = _native.load()
+        dev = x.device
+        n = int(x.shape[0])
+        timing = self.kernel_events is not None
+        ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+        with ctx:
+            cur = torch.cuda.current_stream(dev)
+            flags_ptr = row_flags.data_ptr() if row_flags is not None else None
+            while True:
+                cap = max(int(self._flag_cap_hint), n // 4 + 4096)
+                scratch = self._replay_scratch.get(dev.index)
+                if scratch is None or scratch[0].shape[0] < cap:
+                    scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
+                               torch.zeros(2, dtype=torch.int32, device=dev),
+                               torch.empty(2, dtype=torch.int32).pin_memory())
+                    self._replay_scratch[dev.index] = scratch
+                flag_list, counts, host_counts = scratch
+                counts.zero_()
+                ev = None
+                if timing:
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    for e in ev:
+                        e.record(cur)                    # creates the handles; the library re-arms them on its dispatches
+                    lib.lshrs_debug_set_split_time_events(*(ctypes.c_void_p(e.cuda_event) for e in ev))
+                _native.check(
+                    lib.lshrs_sig_hash_batch_split_replay_f32(
+                        x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
+                        out.data_ptr(), counts[0:1].data_ptr(), tau, flags_ptr, flag_list.data_ptr(), cap,
+                        counts[1:2].data_ptr(), float(self.tau1_ulps * _U), model, cur.cuda_stream),
+                    "lshrs_sig_hash_batch_split_replay_f32")
+                host_counts.copy_(counts, non_blocking=True)
+                cur.synchronize()
+                ties, flagged = int(host_counts[0]), int(host_counts[1])
+                if flagged <= cap:
+                    break
+                self._flag_cap_hint = int(flagged * 1.25) + 4096      # (rows flagged wholesale: NaN / Inf / extreme scales)
+                stats["relaunches"] += 1
+            if timing:
+                self.kernel_events.append((ev[0].elapsed_time(ev[1]), None, n, ev[2].elapsed_time(ev[3])))
+        stats["tie_entries"] = ties
+        stats["tie_pairs"] = ties          # (tied PROJECTIONS here: each decided by the replayed host order)
+        stats["tie_break_engine"] = "device-replay"
         return out
 
     # ------------------------------------------------------------------ large batches: overlap the tie-break
@@ -908,6 +984,8 @@ class LSHHasher:
         state["_pinned_cache"] = {}
         state["_pipes"] = {}
         state["_plan_cache"] = {}
+        state["_replay_scratch"] = {}
+        state["_replay_model_cache"] = None
         state["_host_planes_cache"] = None
         state["kernel_events"] = None
         state["_projections"] = list(self._projections)
@@ -919,6 +997,9 @@ class LSHHasher:
         self.__dict__.setdefault("pipeline", "native")
         self.__dict__.setdefault("_pipes", {})
         self.__dict__.setdefault("_plan_cache", {})
+        self.__dict__.setdefault("_replay_scratch", {})
+        self.__dict__.setdefault("_replay_model_cache", None)
+        self.__dict__.setdefault("tie_replay", "auto")
         self.__dict__.setdefault("pipeline_pair_head", True)
         self.__dict__.setdefault("_host_planes_cache", None)
         self.__dict__.setdefault("_split_range_ok", None)

@@ -235,8 +235,12 @@ def test_config2_all_1m_rows_byte_identical_to_the_literal_cpu_path(torch_mod):
         got = h.hash_device(x).cpu().numpy()
         stats = dict(h.last_stats)
         raw = h.hash_device(x, tie_break="none").cpu().numpy()
+        hh = _hasher(42, 16, 16, dim, tie_replay="off")          # the same batch with the ties broken on the host
+        got_host = hh.hash_device(x).cpu().numpy()
+        host_stats = dict(hh.last_stats)
         del x
         want = hash_shared_literal_packed(h.projections, sv)
+    assert np.array_equal(got_host, got) and host_stats.get("pipeline") in ("native", None)
     assert stats["relaunches"] == 0 and stats["tie_pairs"] > 1000
     differing_rows = int((got != want).any(axis=(1, 2)).sum())
     assert differing_rows == 0, f"{differing_rows} of {n} rows differ from the reference-literal CPU path"
@@ -267,12 +271,55 @@ def test_config5_shape_300k_rows_byte_identical_to_the_literal_cpu_path(torch_mo
     assert differing_rows == 0, f"{differing_rows} of {n} rows differ from the reference-literal CPU path"
 
 
+def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
+    """Default path for batches that take the split pass: stage 2 breaks the ties itself by replaying the host BLAS's
+    summation order (recognised on this host, else this test has nothing to test).  Same bytes as the host engine and
+    as the literal reference - on plain data and on a batch salted with rows that cancel against hyperplanes (1 % of
+    the rows lie in the null space of three of them: thousands of true ties, where the order decides the sign)."""
+    torch = torch_mod
+    from oracle.parallel import SharedVectors, hash_shared_literal_packed
+
+    for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 60_000)):
+        h = _hasher(seed, nb, r, dim)
+        if not h._replay_model():
+            pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+        x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
+        pl = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])[[3, 100, 200]]
+        special = np.arange(0, n, 100)
+        xs = x[special].cpu().numpy().astype(np.float64)
+        xs -= (xs @ np.linalg.pinv(pl)) @ pl
+        x[special] = torch.from_numpy(xs.astype(np.float32)).cuda()
+        flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        got = h.hash_device(x, row_flags=flags)
+        st = dict(h.last_stats)
+        assert st.get("tie_break_engine") == "device-replay" and st["tie_pairs"] > 3 * special.size - 10
+        hh = _hasher(seed, nb, r, dim, tie_replay="off")
+        assert torch.equal(got, hh.hash_device(x)) and hh.last_stats.get("tie_break_engine") is None
+        assert int(flags.sum()) == 0
+        with SharedVectors(n, dim) as sv:
+            sv.array[:] = x.cpu().numpy()
+            want = hash_shared_literal_packed(h.projections, sv)
+        assert np.array_equal(got.cpu().numpy(), want)
+        # timing hooks and the raw mode still work beside it
+        h.kernel_events = []
+        assert torch.equal(h.hash_device(x), got)
+        ev, h.kernel_events = h.kernel_events, None
+        assert len(ev) == 1 and ev[0][2] == n and 0 < ev[0][0] < 50 and 0 < ev[0][3] < 50
+    # a stage-1 list that is too small (every row flagged wholesale: magnitudes outside the guarded range) is noticed
+    # and the pass repeated with room
+    h = _hasher(42, 16, 16, 768)
+    x = torch.randn(40_000, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(3)) * 1e30
+    got = h.hash_device(x)
+    assert h.last_stats.get("tie_break_engine") == "device-replay" and h.last_stats["relaunches"] >= 1
+    assert torch.equal(got, _hasher(42, 16, 16, 768, precision="f32").hash_device(x))
+
+
 def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     """Large device batches overlap the host tie-break with later chunks' kernels: same bytes."""
     torch = torch_mod
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
-    h = _hasher(42, 16, 16, 768)
+    h = _hasher(42, 16, 16, 768, tie_replay="off")     # the host tie-break and its pipeline are what is tested here
     gen = torch.Generator("cuda").manual_seed(77)
     x = torch.randn(300_000, 768, device="cuda", generator=gen)
     flags = torch.zeros(300_000, dtype=torch.uint8, device="cuda")
@@ -294,7 +341,7 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     hs.pipeline_chunk_rows = 131_072
     assert torch.equal(hs.hash_device(x), piped)
     assert hs.last_stats["tie_pairs"] == stats["tie_pairs"]
-    h1 = _hasher(42, 16, 16, 768, tie_threads=1)
+    h1 = _hasher(42, 16, 16, 768, tie_threads=1, tie_replay="off")
     h1.pipeline_chunk_rows = 131_072
     assert torch.equal(h1.hash_device(x), piped)
     assert h1.last_stats["tie_pairs"] == stats["tie_pairs"]
@@ -304,7 +351,7 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
 
     if _hostblas.engine() is not None:
         assert stats.get("pipeline") == "native"
-        hp = _hasher(42, 16, 16, 768, pipeline="python")
+        hp = _hasher(42, 16, 16, 768, pipeline="python", tie_replay="off")
         hp.pipeline_chunk_rows = 131_072
         assert torch.equal(hp.hash_device(x), piped)
         assert hp.last_stats.get("pipeline") != "native" and hp.last_stats["tie_pairs"] == stats["tie_pairs"]
@@ -315,6 +362,8 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
         ev, h.kernel_events = h.kernel_events, None
         assert [e[2] for e in ev] == [131_072, 131_072, 37_856] and all(0 < e[0] < 50 for e in ev)
         assert all(e[3] is not None and 0 < e[3] < 50 for e in ev)      # split pass: stage 1 | fix-up
+    hd = _hasher(42, 16, 16, 768)                      # the default: ties broken on the device when the host's order is known
+    assert torch.equal(hd.hash_device(x), piped)
 
 
 def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
@@ -338,7 +387,7 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     h.pipeline_chunk_rows = 10**9
     assert torch.equal(got, h.hash_device(x))
     # (b) one row more than two chunks
-    h2 = _hasher(42, 16, 16, 768)
+    h2 = _hasher(42, 16, 16, 768, tie_replay="off")
     h2.pipeline_chunk_rows = 65_536
     x2 = torch.randn(131_073, 768, device="cuda", generator=gen)
     got2 = h2.hash_device(x2)
@@ -347,7 +396,7 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     assert torch.equal(got2, h2.hash_device(x2))
     # (b') a first chunk with far more ties than the speculative device->host copy expects (1 % of its rows lie in
     # the null space of three hyperplanes): the host tops the copy up
-    h4 = _hasher(42, 16, 16, 768)
+    h4 = _hasher(42, 16, 16, 768, tie_replay="off")
     x4 = torch.randn(140_000, 768, device="cuda", generator=gen)
     pl = np.concatenate([np.asarray(p, dtype=np.float64) for p in h4.projections])[[3, 100, 200]]
     special = np.arange(0, 65_536, 100)

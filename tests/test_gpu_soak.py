@@ -25,7 +25,7 @@ def test_default_path_equals_plain_f32_path_on_random_batches(torch_mod):
     rng = np.random.default_rng(77)
     shapes = [(16, 16, 768), (16, 32, 1536), (16, 16, 128), (32, 8, 96), (16, 16, 100), (5, 12, 64)]
     hashers = {}
-    seen_split = seen_piped = 0
+    seen_split = seen_piped = seen_replay = 0
     for it in range(24):
         nb, r, dim = shapes[it % len(shapes)]
         n = int((int(rng.integers(1, 5000)), int(rng.integers(60_000, 300_000)), int(rng.integers(300_000, 1_500_000)))[it % 3])
@@ -33,8 +33,8 @@ def test_default_path_equals_plain_f32_path_on_random_batches(torch_mod):
         if (nb, r, dim) not in hashers:
             plain = LSHHasher(nb, r, dim, seed=11, precision="f32")
             plain.pipeline_chunk_rows = 10**9
-            hashers[(nb, r, dim)] = (LSHHasher(nb, r, dim, seed=11), plain)
-        fast, plain = hashers[(nb, r, dim)]
+            hashers[(nb, r, dim)] = (LSHHasher(nb, r, dim, seed=11), plain, LSHHasher(nb, r, dim, seed=11, tie_replay="off"))
+        fast, plain, fast_host = hashers[(nb, r, dim)]
         x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(1000 + it))
         if n > 10:
             x[int(rng.integers(0, n))] = 0.0
@@ -43,9 +43,13 @@ def test_default_path_equals_plain_f32_path_on_random_batches(torch_mod):
         fb = torch.zeros(n, dtype=torch.uint8, device="cuda")
         ka = fast.hash_device(x, row_flags=fa)
         seen_split += bool(fast._split_applies(n))
-        seen_piped += "t_total_ms" in fast.last_stats
+        seen_replay += fast.last_stats.get("tie_break_engine") == "device-replay"
         kb = plain.hash_device(x, row_flags=fb)
         assert torch.equal(ka, kb), f"keys differ: shape {(nb, r, dim)}, n = {n}"
         assert torch.equal(fa, fb), f"row flags differ: shape {(nb, r, dim)}, n = {n}"
-        assert fast.last_stats["tie_pairs"] == plain.last_stats["tie_pairs"]
+        kh = fast_host.hash_device(x)                       # ties broken on the host (chunked when the batch is large)
+        seen_piped += "t_total_ms" in fast_host.last_stats
+        assert torch.equal(kh, kb), f"host tie-break: keys differ: shape {(nb, r, dim)}, n = {n}"
+        assert fast_host.last_stats["tie_pairs"] == plain.last_stats["tie_pairs"]
     assert seen_split >= 6 and seen_piped >= 6        # the batch mix really exercised both
+    assert seen_replay in (0, seen_split)             # (0: this host's BLAS order is not one the replay knows)

@@ -1,0 +1,28 @@
+import ctypes, itertools, numpy as np, sys
+lib = ctypes.CDLL('' + __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'libmodel.so') + '')
+lib.model_dot.restype = ctypes.c_float
+lib.model_dot.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int]*7
+rng = np.random.default_rng(1)
+def trial(r, dim, ntr=40):
+    P = rng.standard_normal((r, dim)).astype(np.float32)
+    X = rng.standard_normal((ntr, dim)).astype(np.float32)
+    ref = np.stack([P @ X[t] for t in range(ntr)])      # the reference's call: sgemv per vector
+    found = []
+    for L, U, fma, at, lt, blk in itertools.product((4, 8, 16, 32), (1, 2, 4, 8), (1, 0), (0, 1), (0, 1, 2), (0, 128, 256, 512, 1024)):
+        if L * U > 256: continue
+        ok_rows = []
+        for i in range(r):
+            good = True
+            for t in range(ntr):
+                v = lib.model_dot(P[i].ctypes.data, X[t].ctypes.data, dim, L, U, fma, at, lt, blk)
+                if np.float32(v).view(np.uint32) != ref[t, i].view(np.uint32):
+                    good = False; break
+            ok_rows.append(good)
+        if any(ok_rows):
+            found.append(((L, U, fma, at, lt, blk), ok_rows))
+    return found
+for r, dim in ((16, 768), (32, 1536), (4, 128), (5, 100)):
+    f = trial(r, dim)
+    print(r, dim, "models matching some rows:", len(f))
+    for m, rows in f[:12]:
+        print("   ", m, "rows ok:", "".join("1" if v else "0" for v in rows))
