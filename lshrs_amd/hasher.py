@@ -132,6 +132,7 @@ class LSHHasher:
         # 20 k rows at 768-d, 8 k at 1536-d, 120 k at 128-d (tools/split_crossover.py)
         self.split_min_rows = 4_096
         self.split_min_elems = 16 << 20
+        self.replay_min_rows = 256      # with the ties broken on the device the split pass pays from here (see _split_applies)
         # host tie-break workers (lshrs_amd/_hostblas.py): None = this process's share of the cores (at most 8),
         # 1 = NumPy's batched matmul on the calling thread.  Same BLAS call either way.
         if tie_threads is not None and int(tie_threads) < 1:
@@ -275,7 +276,7 @@ class LSHHasher:
             return out
         ws = self._workspace(dev)
         tau = float(self.tau_ulps * _U)
-        if (mode == "host" and host_rows is None and self.tie_replay == "auto" and self._split_applies(n)
+        if (mode == "host" and self.tie_replay == "auto" and self._split_applies(n, replay=True)
                 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x.stride(0) < (1 << 20)):
             model = self._replay_model()
             if model:
@@ -364,8 +365,7 @@ class LSHHasher:
                                torch.zeros(2, dtype=torch.int32, device=dev),
                                torch.empty(2, dtype=torch.int32).pin_memory())
                     self._replay_scratch[dev.index] = scratch
-                flag_list, counts, host_counts = scratch
-                counts.zero_()
+                flag_list, counts, host_counts = scratch       # (counts are zero: zeroed at creation and after every read)
                 ev = None
                 if timing:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -379,6 +379,7 @@ class LSHHasher:
                         counts[1:2].data_ptr(), float(self.tau1_ulps * _U), model, cur.cuda_stream),
                     "lshrs_sig_hash_batch_split_replay_f32")
                 host_counts.copy_(counts, non_blocking=True)
+                counts.zero_()                                 # for the next call: runs while the host reads this one's
                 cur.synchronize()
                 ties, flagged = int(host_counts[0]), int(host_counts[1])
                 if flagged <= cap:
@@ -746,9 +747,17 @@ class LSHHasher:
             self._pinned_cache[key] = buf      # at most three chunk sizes exist (pipeline_chunk_rows, /2, /4)
         return buf
 
-    def _split_applies(self, n: int) -> bool:
-        if (self.precision != "bf16x3" or n < self.split_min_rows or n * self.dim < self.split_min_elems
-                or self.dim % 32 != 0):
+    def _split_applies(self, n: int, replay: bool = False) -> bool:
+        """Does a batch of n rows take the split-precision pass?  ``replay``: asked on behalf of the path that also
+        breaks the ties on the device - it has no host step to amortise, and beats "f32 kernel + host tie-break" from
+        a few hundred rows up (85 against 300 us at 512 x 768, tools/replay_crossover.py), so only tiny batches (a
+        query vector: the fine-geometry f32 kernel answers in 35 us) stay off it."""
+        if self.precision != "bf16x3" or self.dim % 32 != 0:
+            return False
+        if replay:
+            if n < self.replay_min_rows:
+                return False
+        elif n < self.split_min_rows or n * self.dim < self.split_min_elems:
             return False
         lib = _native.load()
         if (int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) < 256
@@ -1000,6 +1009,7 @@ class LSHHasher:
         self.__dict__.setdefault("_replay_scratch", {})
         self.__dict__.setdefault("_replay_model_cache", None)
         self.__dict__.setdefault("tie_replay", "auto")
+        self.__dict__.setdefault("replay_min_rows", 256)
         self.__dict__.setdefault("pipeline_pair_head", True)
         self.__dict__.setdefault("_host_planes_cache", None)
         self.__dict__.setdefault("_split_range_ok", None)

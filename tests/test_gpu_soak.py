@@ -52,4 +52,4 @@ def test_default_path_equals_plain_f32_path_on_random_batches(torch_mod):
         assert torch.equal(kh, kb), f"host tie-break: keys differ: shape {(nb, r, dim)}, n = {n}"
         assert fast_host.last_stats["tie_pairs"] == plain.last_stats["tie_pairs"]
     assert seen_split >= 6 and seen_piped >= 6        # the batch mix really exercised both
-    assert seen_replay in (0, seen_split)             # (0: this host's BLAS order is not one the replay knows)
+    assert seen_replay == 0 or seen_replay >= seen_split   # (0: this host's BLAS order is not one the replay knows)
