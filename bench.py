@@ -9,7 +9,9 @@ Metric (BASELINE.json): vectors/sec hashed at dim=768, num_perm=256.  One *step*
 the signature path over one resident batch: every rank hashes ROWS_PER_GPU (default 1 000 000,
 BASELINE config 2) synthetic N(0,1) float32 vectors already in its HBM into (rows, 16, 2) uint8
 band keys in HBM, **including the tie-break that makes the keys byte-identical to the reference**
-(the raw-kernel rate is reported next to it).  Ranks share nothing (replicated hyperplanes, no
+(the raw-kernel rate is reported next to it; `config.tie_break_engine` says who broke the ties: "device-replay" =
+stage 2 of the split pass replaying the host BLAS's summation order, verified against this host's NumPy at first use,
+or "host" = the reference's own BLAS call on the flagged pairs, overlapped chunk by chunk).  Ranks share nothing (replicated hyperplanes, no
 collective in the data path): weak scaling.  Rank 0 prints ONE JSON line.
 
 Also in the line:
@@ -223,8 +225,11 @@ def main() -> None:
             }
         from lshrs_amd import _hostblas
 
-        eng = None if hasher.tie_threads == 1 else _hostblas.engine(hasher.tie_threads)
-        engine_threads = eng.threads if eng is not None else 1
+        if stats.get("tie_break_engine") == "device-replay":
+            eng, engine_threads = None, 0          # ties broken on the device: no host worker takes part in a step
+        else:
+            eng = None if hasher.tie_threads == 1 else _hostblas.engine(hasher.tie_threads)
+            engine_threads = eng.threads if eng is not None else 1
         result = {
             "metric": "vectors/sec hashed (768-d, num_perm=256)",
             "value": total_rows * args.steps / elapsed,
@@ -243,7 +248,8 @@ def main() -> None:
                             "HBM-resident in and out, keys byte-identical to the reference (tie-break included)",
                 "rows_per_gpu": n, "dim": DIM, "num_perm": NUM_PERM, "num_bands": BANDS, "rows_per_band": ROWS,
                 "total_rows": total_rows, "sharding": f"row-sharded x{world}, replicated hyperplanes, no collective",
-                "tie_break": hasher.tie_break, "tau_ulps": hasher.tau_ulps,
+                "tie_break": hasher.tie_break, "tie_break_engine": stats.get("tie_break_engine", "host"),
+                "tau_ulps": hasher.tau_ulps,
                 "precision": hasher.precision, "tau1_ulps": hasher.tau1_ulps, "pipeline_chunk_rows": hasher.pipeline_chunk_rows,
                 "pipeline_driver": stats.get("pipeline", "python"),
             },
