@@ -1,0 +1,71 @@
+"""The licence of the device's tie replay (no GPU): the model of the host BLAS's summation order against this process's
+NumPy.  On a host whose BLAS is of another family the recognition test reports 0 and the hasher keeps the host engine -
+both outcomes are legal; what is asserted is that the check is strict and that a recognised model is exact."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from lshrs_amd import LSHHasher, _hostblas
+
+
+def _model_dot(a, x, model=1):
+    lib = _hostblas.load()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return np.float32(lib.lshrs_tb_model_dot(a.ctypes.data, x.ctypes.data, a.shape[0], model))
+
+
+def test_model_function_is_the_documented_order():
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(64).astype(np.float32)
+    x = rng.standard_normal(64).astype(np.float32)
+    p = np.zeros(8, dtype=np.float32)
+    for k in range(64):                                    # eight interleaved single-rounded fma chains
+        p[k % 8] = np.float32(np.float64(a[k]) * np.float64(x[k]) + np.float64(p[k % 8]))   # exact product, one rounding*
+    q = [np.float32(p[j] + p[j + 4]) for j in range(4)]
+    want = np.float32(np.float32(q[0] + q[1]) + np.float32(q[2] + q[3]))
+    # (* a double holds product + addend of two floats exactly unless their exponents are > 29 apart: not here)
+    assert _model_dot(a, x).view(np.uint32) == want.view(np.uint32)
+    assert np.isnan(_model_dot(a[:60], x[:60]))            # n % 8 != 0
+    assert np.isnan(_model_dot(a, x, model=2))             # unknown model
+
+
+@pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (16, 32, 1536), (16, 4, 128), (4, 12, 32)])
+def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
+    planes = np.random.default_rng(9).standard_normal((nb, r, dim)).astype(np.float32)
+    model = _hostblas.blas_order_model(planes)
+    assert model in (0, 1)
+    if model == 0:
+        pytest.skip("this host's BLAS sums in an order the replay does not know: the host engine stays in charge")
+    rng = np.random.default_rng(10)
+    for t in range(40):                                    # fresh vectors, other bands than the recognition used
+        b = int(rng.integers(0, nb))
+        x = rng.standard_normal(dim).astype(np.float32)
+        if t % 2:                                          # cancel against one row: only the order is left of y
+            p = planes[b, t % r].astype(np.float64)
+            x = (x - (x @ p) / (p @ p) * p).astype(np.float32)
+        want = planes[b] @ x
+        got = np.array([_model_dot(planes[b, i], x) for i in range(r)], dtype=np.float32)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    # the order matters on such data: a plain left-to-right f32 sum does not reproduce the library
+    p = planes[0, 0].astype(np.float64)
+    x = rng.standard_normal(dim)
+    x = (x - (x @ p) / (p @ p) * p).astype(np.float32)
+    seq = np.float32(0)
+    for k in range(dim):
+        seq = np.float32(seq + np.float32(planes[0, 0, k] * x[k]))
+    assert (planes[0] @ x)[0].view(np.uint32) == _model_dot(planes[0, 0], x).view(np.uint32)
+    assert abs(float(seq)) < 1e-3                          # (a tie-sized value either way)
+
+
+def test_shapes_the_model_does_not_cover_are_refused():
+    planes = np.random.default_rng(1).standard_normal((8, 5, 100)).astype(np.float32)
+    assert _hostblas.blas_order_model(planes) == 0         # dim % 8 != 0: the library's tail handling is not modelled
+    h = LSHHasher(8, 5, 100, seed=3)
+    assert h._replay_model() == 0
+    h2 = LSHHasher(16, 16, 768, seed=3, tie_replay="off")
+    assert h2.tie_replay == "off"
+    with pytest.raises(ValueError):
+        LSHHasher(16, 16, 768, tie_replay="maybe")
