@@ -105,12 +105,16 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
  * has run: no tie list, no host step.  Only for callers that have checked the model against their BLAS
  * (lshrs_tb_model_dot in lshrs_host.h vs `P_band @ x`, bit for bit; lshrs_amd/hasher.py does) and for inputs the split
  * pass takes itself (dim % 32 == 0, 16-byte aligned rows; else LSHRS_E_BADARG).
- *   tie_count  optional int32[1], zeroed by the caller: receives the number of projections decided that way. */
+ *   tie_count    optional int32[1], zeroed by the caller: receives the number of projections decided that way.
+ *   host_counts  optional: PINNED HOST int32[2] the device can write (hipHostMalloc / torch pin_memory): a
+ *                single-thread launch behind stage 2 stores (tie_count, flag_count) there and leaves both device
+ *                counters zeroed for the next call - the caller reads them after synchronising the stream
+ *                (flag_count > flag_cap: repeat with room) without a copy or a fill of its own. */
 int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx,
                                           const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
                                           uint8_t* keys, int32_t* tie_count, float tau, uint8_t* row_flags,
                                           int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
-                                          int32_t blas_model, void* stream);
+                                          int32_t blas_model, int32_t* host_counts, void* stream);
 
 /* Diagnostic twin of the above: writes the raw projections instead of their sign bits.
  *   Y (n, ldy) f32 with ldy >= padded columns rounded up to the kernel's column tile

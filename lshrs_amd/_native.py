@@ -82,7 +82,7 @@ def _declare(lib: ctypes.CDLL) -> None:
                                                    f32, vp]
     lib.lshrs_sig_hash_batch_split_f32.restype = c.c_int
     lib.lshrs_sig_hash_batch_split_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, f32,
-                                                          i32, vp]
+                                                          i32, vp, vp]
     lib.lshrs_sig_hash_batch_split_replay_f32.restype = c.c_int
     lib.lshrs_sig_project_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, i64, vp]
     lib.lshrs_sig_project_f32.restype = c.c_int

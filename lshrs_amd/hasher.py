@@ -361,11 +361,14 @@ class LSHHasher:
                 cap = max(int(self._flag_cap_hint), n // 4 + 4096)
                 scratch = self._replay_scratch.get(dev.index)
                 if scratch is None or scratch[0].shape[0] < cap:
+                    pinned = torch.zeros(2, dtype=torch.int32).pin_memory()
                     scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
-                               torch.zeros(2, dtype=torch.int32, device=dev),
-                               torch.empty(2, dtype=torch.int32).pin_memory())
+                               torch.zeros(2, dtype=torch.int32, device=dev),      # tie count | stage-1 count
+                               pinned, pinned.numpy())
                     self._replay_scratch[dev.index] = scratch
-                flag_list, counts, host_counts = scratch       # (counts are zero: zeroed at creation and after every read)
+                # (the device counters are zero: at creation, and the launch that exports them leaves them so)
+                flag_list, counts, pinned, host_counts = scratch
+                cptr = counts.data_ptr()
                 ev = None
                 if timing:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -375,12 +378,10 @@ class LSHHasher:
                 _native.check(
                     lib.lshrs_sig_hash_batch_split_replay_f32(
                         x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
-                        out.data_ptr(), counts[0:1].data_ptr(), tau, flags_ptr, flag_list.data_ptr(), cap,
-                        counts[1:2].data_ptr(), float(self.tau1_ulps * _U), model, cur.cuda_stream),
+                        out.data_ptr(), cptr, tau, flags_ptr, flag_list.data_ptr(), cap, cptr + 4,
+                        float(self.tau1_ulps * _U), model, pinned.data_ptr(), cur.cuda_stream),
                     "lshrs_sig_hash_batch_split_replay_f32")
-                host_counts.copy_(counts, non_blocking=True)
-                counts.zero_()                                 # for the next call: runs while the host reads this one's
-                cur.synchronize()
+                cur.synchronize()      # (the launch behind stage 2 has written both counters into the pinned pair)
                 ties, flagged = int(host_counts[0]), int(host_counts[1])
                 if flagged <= cap:
                     break
