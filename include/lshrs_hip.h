@@ -116,6 +116,20 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
                                           int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
                                           int32_t blas_model, int32_t* host_counts, void* stream);
 
+/* The tie-break on the device for the f32 kernel: behind lshrs_sig_hash_batch_f32 (same X, keys, tie_list, tie_count,
+ * tau, same stream) it decides every reported tie by the host BLAS's value - the tie entries are unpacked into
+ * flag_list (one item per flagged column; flag_count zeroed by the caller) and the stage-2 kernel of the split pass
+ * re-evaluates them: the canonical chain (the f32 kernel's own value) for the tie test, the replayed BLAS order
+ * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  host_counts (optional, pinned host int32[2])
+ * receives (tie entries wanted, items expanded) and both device counters are zeroed; tie entries > tie_cap or items >
+ * flag_cap: repeat the pass with room.  Needs dim % 32 == 0, 16-byte aligned rows and key rows of whole 32-bit words
+ * (else LSHRS_E_TOOLARGE: resolve on the host). */
+int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
+                                       const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                                       uint8_t* keys, const int64_t* tie_list, int32_t tie_cap, int32_t* tie_count,
+                                       float tau, int64_t* flag_list, int32_t flag_cap, int32_t* flag_count,
+                                       int32_t blas_model, int32_t* host_counts, void* stream);
+
 /* Diagnostic twin of the above: writes the raw projections instead of their sign bits.
  *   Y (n, ldy) f32 with ldy >= padded columns rounded up to the kernel's column tile
  *   (lshrs_sig_padded_columns()); column b*8*B + i holds dot(P[b*rows+i], X[row]).

@@ -84,6 +84,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_sig_hash_batch_split_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, f32,
                                                           i32, vp, vp]
     lib.lshrs_sig_hash_batch_split_replay_f32.restype = c.c_int
+    lib.lshrs_sig_resolve_ties_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, i32, vp, i32, vp,
+                                                      vp]
+    lib.lshrs_sig_resolve_ties_replay_f32.restype = c.c_int
     lib.lshrs_sig_project_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, i64, vp]
     lib.lshrs_sig_project_f32.restype = c.c_int
     lib.lshrs_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, vp, vp]
@@ -118,6 +121,7 @@ EXPORTS = (
     "lshrs_sig_hash_batch_f32",
     "lshrs_sig_hash_batch_split_f32",
     "lshrs_sig_hash_batch_split_replay_f32",
+    "lshrs_sig_resolve_ties_replay_f32",
     "lshrs_sig_project_f32",
     "lshrs_gather_rows_f32",
     "lshrs_gather_tied_rows_f32",

@@ -1234,6 +1234,29 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   }
 }
 
+// Tie entries of the f32 kernel, (row * 65536 + word, mask of up to 32 columns), unpacked into the stage-2 list format
+// (row << 21 | padded column), one item per flagged column: what sig_fix8_kernel<true> takes.
+__global__ void expand_ties_kernel(const int64_t* __restrict__ tie_list, const int* __restrict__ tie_count, int tie_cap,
+                                   int padcols, int64_t* __restrict__ flag_list, int flag_cap, int* flag_count) {
+  const int cnt = min(*tie_count, tie_cap);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += gridDim.x * blockDim.x) {
+    const int64_t row = tie_list[2 * (int64_t)e] >> 16;
+    const int word = (int)(tie_list[2 * (int64_t)e] & 0xFFFF);
+    unsigned mask = (unsigned)tie_list[2 * (int64_t)e + 1];
+    const int m = __popc(mask);
+    if (m == 0) continue;
+    int slot = atomicAdd(flag_count, m);
+    while (mask != 0u) {
+      const int c = __ffs(mask) - 1;
+      mask &= mask - 1u;
+      const int col = 32 * word + c;
+      if (slot < flag_cap && col < padcols) flag_list[slot] = (row << 21) | (int64_t)col;
+      else if (slot < flag_cap) flag_list[slot] = (row << 21) | (int64_t)((1 << 21) - 1);   // (skipped by stage 2: column out of range)
+      ++slot;
+    }
+  }
+}
+
 // Hands the two counters of a replay pass to the host (pinned memory) and leaves them zeroed for the next call: one
 // single-thread launch behind stage 2 instead of a copy and a fill.  (Doing it in stage 2 itself, by whichever
 // workgroup finishes last, costs 1 536 contended atomics on one ticket: 58 us.)
@@ -2367,6 +2390,60 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
   if (blas_model != 1 || dim % 8 != 0) return LSHRS_E_BADARG;
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, tie_count, tau, row_flags,
                     flag_list, flag_cap, flag_count, tau1, blas_model, host_counts, stream);
+}
+
+int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                                       int32_t rows_per_band, int32_t dim, uint8_t* keys, const int64_t* tie_list,
+                                       int32_t tie_cap, int32_t* tie_count, float tau, int64_t* flag_list,
+                                       int32_t flag_cap, int32_t* flag_count, int32_t blas_model, int32_t* host_counts,
+                                       void* stream) {
+  if (n == 0) return 0;
+  if (X == nullptr || workspace == nullptr || keys == nullptr || tie_list == nullptr || tie_count == nullptr ||
+      flag_list == nullptr || flag_count == nullptr || tie_cap <= 0 || flag_cap <= 0 || n < 0 || ldx < dim ||
+      !sig_shape_ok(num_bands, rows_per_band, dim) || blas_model != 1)
+    return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  const int row_bytes = num_bands * g.bb;
+  // stage 2 stages whole 32-deep k-tiles of 16-byte aligned rows and patches key bits with 32-bit atomics
+  if (dim % 32 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || row_bytes % 4 != 0 ||
+      (reinterpret_cast<uintptr_t>(keys) & 3) != 0 || n >= ((int64_t)1 << 42))
+    return LSHRS_E_TOOLARGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* base = static_cast<const float*>(workspace);
+  {
+    const int threads = 256;
+    const int blocks = tie_cap < 256 * 64 ? (tie_cap + threads - 1) / threads : 64;
+    hipLaunchKernelGGL(expand_ties_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, tie_list, tie_count, tie_cap,
+                       row_bytes * 8, flag_list, flag_cap, flag_count);
+  }
+  FixArgs f{};
+  f.X = X;
+  f.ldx = ldx;
+  f.dim = dim;
+  f.ktiles = g.ktiles;
+  f.nt = g.nt;
+  f.image = base;
+  f.norms = base + sig_image_floats(g);
+  f.keys = keys;
+  f.row_bytes = row_bytes;
+  f.padcols = row_bytes * 8;
+  f.flag_list = flag_list;
+  f.flag_count = flag_count;
+  f.flag_cap = flag_cap;
+  f.row_base = 0;
+  f.tie_list = nullptr;
+  f.tie_cap = 0;
+  f.tie_count = nullptr;          // (the caller has the number of tie entries already; stage 2 only decides them)
+  f.tau = tau;
+  f.blas_model = blas_model;
+  {
+    const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
+    const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
+    hipLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, f);
+  }
+  if (host_counts != nullptr)
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(1), 0, s, tie_count, flag_count, host_counts);
+  return -(int)hipGetLastError();
 }
 
 int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,

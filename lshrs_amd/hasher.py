@@ -168,7 +168,7 @@ class LSHHasher:
         self._replay_model_cache: Optional[Tuple[int, int]] = None
         self._pipes: Dict[tuple, int] = {}
         self._plan_cache: Dict[tuple, tuple] = {}
-        self._replay_scratch: Dict[int, tuple] = {}
+        self._replay_scratch: Dict[object, tuple] = {}
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
@@ -281,6 +281,11 @@ class LSHHasher:
             model = self._replay_model()
             if model:
                 return self._hash_device_replay(x, out, row_flags, ws, tau, stats, model)
+        if (mode == "host" and self.tie_replay == "auto" and self.dim % 32 == 0
+                and (self.num_bands * self.band_bytes) % 4 == 0 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0):
+            model = self._replay_model()            # (shapes / sizes the split pass does not take: f32 kernel, same replay)
+            if model:
+                return self._hash_device_f32_replay(x, out, row_flags, ws, tau, stats, model)
         if allow_pipeline and mode == "host" and host_rows is None and n >= max(131_072, self.pipeline_chunk_rows // 2):
             return self._hash_device_pipelined(x, out, row_flags, ws, tau, stats)
         with torch.cuda.device(dev):
@@ -391,6 +396,54 @@ class LSHHasher:
                 self.kernel_events.append((ev[0].elapsed_time(ev[1]), None, n, ev[2].elapsed_time(ev[3])))
         stats["tie_entries"] = ties
         stats["tie_pairs"] = ties          # (tied PROJECTIONS here: each decided by the replayed host order)
+        stats["tie_break_engine"] = "device-replay"
+        return out
+
+    def _hash_device_f32_replay(self, x, out, row_flags, ws, tau, stats, model):
+        """The exact-f32 kernel followed by the device's tie replay (``lshrs_sig_resolve_ties_replay_f32``): for batches
+        and shapes the split pass does not take (fewer than 256 key columns, fewer than 256 rows).  Same bytes, no
+        host arithmetic; the host reads two counters back (lists too small -> repeat with room)."""
+        torch = _native.require_gpu()
+        lib = _native.load()
+        dev = x.device
+        n = int(x.shape[0])
+        ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+        with ctx:
+            cur = torch.cuda.current_stream(dev)
+            flags_ptr = row_flags.data_ptr() if row_flags is not None else None
+            cap = min(max(4096, n // 16 + 4096), 2 ** 30)
+            fcap = 2 * cap
+            while True:
+                key = ("f32", dev.index)
+                scratch = self._replay_scratch.get(key)
+                if scratch is None or scratch[0].shape[0] < cap or scratch[1].shape[0] < fcap:
+                    pinned = torch.zeros(2, dtype=torch.int32).pin_memory()
+                    scratch = (torch.empty((cap, 2), dtype=torch.int64, device=dev),
+                               torch.empty((fcap,), dtype=torch.int64, device=dev),
+                               torch.zeros(2, dtype=torch.int32, device=dev), pinned, pinned.numpy())
+                    self._replay_scratch[key] = scratch
+                tie_list, flag_list, counts, pinned, host_counts = scratch
+                tcap, lcap = int(tie_list.shape[0]), int(flag_list.shape[0])
+                cptr = counts.data_ptr()
+                _native.check(
+                    lib.lshrs_sig_hash_batch_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                                 self.rows_per_band, self.dim, out.data_ptr(), tie_list.data_ptr(), tcap,
+                                                 cptr, tau, flags_ptr, cur.cuda_stream),
+                    "lshrs_sig_hash_batch_f32")
+                _native.check(
+                    lib.lshrs_sig_resolve_ties_replay_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
+                                                          self.rows_per_band, self.dim, out.data_ptr(),
+                                                          tie_list.data_ptr(), tcap, cptr, tau, flag_list.data_ptr(),
+                                                          lcap, cptr + 4, model, pinned.data_ptr(), cur.cuda_stream),
+                    "lshrs_sig_resolve_ties_replay_f32")
+                cur.synchronize()
+                wanted, items = int(host_counts[0]), int(host_counts[1])
+                if wanted <= tcap and items <= lcap:
+                    break
+                cap, fcap = max(cap, wanted), max(fcap, 2 * wanted, items)      # the kernels counted what they wanted to write
+                stats["relaunches"] += 1
+        stats["tie_entries"] = wanted
+        stats["tie_pairs"] = items          # (tied projections)
         stats["tie_break_engine"] = "device-replay"
         return out
 

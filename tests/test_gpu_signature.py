@@ -337,7 +337,7 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     assert np.array_equal(piped[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
     # the same batch through the f32 kernel (the default took the split-precision pass), and with the NumPy-only tie-break
     assert h._split_applies(131_072)
-    hs = _hasher(42, 16, 16, 768, precision="f32")
+    hs = _hasher(42, 16, 16, 768, precision="f32", tie_replay="off")
     hs.pipeline_chunk_rows = 131_072
     assert torch.equal(hs.hash_device(x), piped)
     assert hs.last_stats["tie_pairs"] == stats["tie_pairs"]
@@ -364,6 +364,10 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
         assert all(e[3] is not None and 0 < e[3] < 50 for e in ev)      # split pass: stage 1 | fix-up
     hd = _hasher(42, 16, 16, 768)                      # the default: ties broken on the device when the host's order is known
     assert torch.equal(hd.hash_device(x), piped)
+    hf = _hasher(42, 16, 16, 768, precision="f32")     # ... and behind the exact-f32 kernel
+    assert torch.equal(hf.hash_device(x), piped)
+    if hd._replay_model():
+        assert hd.last_stats.get("tie_break_engine") == hf.last_stats.get("tie_break_engine") == "device-replay"
 
 
 def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
@@ -410,7 +414,7 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     assert torch.equal(got4, h4.hash_device(x4))
     assert h4.last_stats["tie_pairs"] == st4["tie_pairs"] > 3 * special.size - 10
     # (c) a window so wide that every chunk's tie list overflows
-    h3 = _hasher(3, 4, 16, 64, tau_ulps=1e9)
+    h3 = _hasher(3, 4, 16, 64, tau_ulps=1e9, tie_replay="off")
     x3 = torch.randn(140_000, 64, device="cuda", generator=gen)
     got3 = h3.hash_device(x3)
     assert h3.last_stats.get("pipeline") == "native" and h3.last_stats["relaunches"] >= 2
@@ -432,10 +436,18 @@ def test_tie_list_overflow_is_recovered(torch_mod):
     got = h.hash_device(torch.from_numpy(x).cuda()).cpu().numpy()
     assert h.last_stats["relaunches"] > 0
     assert np.array_equal(got, hash_batch_literal_packed(h.projections, x))
+    h = _hasher(3, 4, 16, 64, tau_ulps=1e9)             # (a fresh hasher: lists that have grown stay grown)
     h.pipeline_chunk_rows = 131_072                     # plain path: relaunch with a bigger list
     got = h.hash_batch_packed(x)
     assert h.last_stats["relaunches"] > 0
     assert np.array_equal(got, hash_batch_literal_packed(h.projections, x))
+    # (where the host's summation order is known the two runs above had EVERY projection decided by the device's
+    # replay of it; the same with the host deciding)
+    hh = _hasher(3, 4, 16, 64, tau_ulps=1e9, tie_replay="off")
+    hh.pipeline_chunk_rows = 1024
+    got = hh.hash_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert hh.last_stats["relaunches"] > 0 and hh.last_stats.get("tie_break_engine") is None
+    assert np.array_equal(got, hash_batch_literal_packed(hh.projections, x))
 
 
 def test_tie_window_margin(torch_mod):

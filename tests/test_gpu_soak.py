@@ -31,7 +31,7 @@ def test_default_path_equals_plain_f32_path_on_random_batches(torch_mod):
         n = int((int(rng.integers(1, 5000)), int(rng.integers(60_000, 300_000)), int(rng.integers(300_000, 1_500_000)))[it % 3])
         n = min(n, 900_000_000 // dim)
         if (nb, r, dim) not in hashers:
-            plain = LSHHasher(nb, r, dim, seed=11, precision="f32")
+            plain = LSHHasher(nb, r, dim, seed=11, precision="f32", tie_replay="off")
             plain.pipeline_chunk_rows = 10**9
             hashers[(nb, r, dim)] = (LSHHasher(nb, r, dim, seed=11), plain, LSHHasher(nb, r, dim, seed=11, tie_replay="off"))
         fast, plain, fast_host = hashers[(nb, r, dim)]
@@ -47,6 +47,8 @@ def test_default_path_equals_plain_f32_path_on_random_batches(torch_mod):
         kb = plain.hash_device(x, row_flags=fb)
         assert torch.equal(ka, kb), f"keys differ: shape {(nb, r, dim)}, n = {n}"
         assert torch.equal(fa, fb), f"row flags differ: shape {(nb, r, dim)}, n = {n}"
+        kf = LSHHasher(nb, r, dim, seed=11, precision="f32").hash_device(x) if it % 4 == 0 else kb   # f32 kernel + device replay
+        assert torch.equal(kf, kb), f"f32 kernel + device tie replay: keys differ: shape {(nb, r, dim)}, n = {n}"
         kh = fast_host.hash_device(x)                       # ties broken on the host (chunked when the batch is large)
         seen_piped += "t_total_ms" in fast_host.last_stats
         assert torch.equal(kh, kb), f"host tie-break: keys differ: shape {(nb, r, dim)}, n = {n}"

@@ -17,7 +17,7 @@ for it in range(iters):
     key = (nb, r, dim)
     if key not in hashers:
         a = LSHHasher(nb, r, dim, seed=11)
-        b = LSHHasher(nb, r, dim, seed=11, precision="f32"); b.pipeline_chunk_rows = 10**9
+        b = LSHHasher(nb, r, dim, seed=11, precision="f32", tie_replay="off"); b.pipeline_chunk_rows = 10**9
         hashers[key] = (a, b)
     a, b = hashers[key]
     x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(it))
