@@ -430,6 +430,13 @@ class LSHHasher:
                                                  self.rows_per_band, self.dim, out.data_ptr(), tie_list.data_ptr(), tcap,
                                                  cptr, tau, flags_ptr, cur.cuda_stream),
                     "lshrs_sig_hash_batch_f32")
+                if n < 256:
+                    # a query vector or a handful: almost never a tie (2.6 per 1000 vectors) - look at the count before
+                    # spending three more launches on an empty list
+                    wanted = int(counts[0:1].item())
+                    if wanted == 0:
+                        items = 0
+                        break
                 _native.check(
                     lib.lshrs_sig_resolve_ties_replay_f32(x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands,
                                                           self.rows_per_band, self.dim, out.data_ptr(),
