@@ -77,6 +77,40 @@ class _ProjectionList(list):
         return (list, (list(self),))
 
 
+class _PendingKeys:
+    """Handle of :meth:`LSHHasher.hash_device_async`."""
+
+    def __init__(self, hasher: "LSHHasher", x, out, row_flags, state) -> None:
+        self._hasher, self._x, self._out, self._row_flags, self._state = hasher, x, out, row_flags, state
+
+    def done(self) -> bool:
+        return self._state is None or bool(self._state[0].query())
+
+    def _finish_locked(self) -> None:
+        h = self._hasher
+        if self in h._async_pending:
+            h._async_pending.remove(self)
+        state, self._state = self._state, None
+        if state is None:
+            return
+        stats = {"n": int(self._x.shape[0]), "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+        if not h._replay_finish(state, stats):        # the stage-1 list was too small: once more, synchronously, with room
+            h._hash_device_locked(self._x, self._out, self._row_flags, "host", host_rows=None)
+            stats["relaunches"] += h.last_stats.get("relaunches", 0)
+            for k in ("tie_entries", "tie_pairs", "tie_break_engine"):
+                if k in h.last_stats:
+                    stats[k] = h.last_stats[k]
+        h.last_stats = stats
+        self._x = None
+
+    def result(self):
+        """The ``(n, num_bands, band_bytes)`` uint8 keys tensor, final and verified."""
+        if self._state is not None:
+            with self._hasher._lock:
+                self._finish_locked()
+        return self._out
+
+
 class LSHHasher:
     """Sign-random-projection hasher; drop-in for ``lshrs.hash.lsh.LSHHasher``.
 
@@ -169,6 +203,7 @@ class LSHHasher:
         self._pipes: Dict[tuple, int] = {}
         self._plan_cache: Dict[tuple, tuple] = {}
         self._replay_scratch: Dict[object, tuple] = {}
+        self._async_pending: list = []
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
@@ -349,10 +384,10 @@ class LSHHasher:
             self._replay_model_cache = cached
         return cached[1]
 
-    def _hash_device_replay(self, x, out, row_flags, ws, tau, stats, model):
-        """One launch of the split pass whose stage 2 also breaks the ties (``lshrs_sig_hash_batch_split_replay_f32``):
-        the keys are the reference's when the stream has run.  The only host step is reading two counters back
-        (stage-1 list overflow -> repeat with room; tied projections -> stats)."""
+    def _replay_launch(self, x, out, row_flags, ws, tau, model):
+        """Enqueue one split pass with the tie replay on the current stream; returns what `_replay_finish` needs.
+        The two counters of the launch come back through one of four pinned pairs (launches are handed out in turn:
+        at most three may be unfinished, `hash_device_async` sees to that)."""
         torch = _native.require_gpu()
         lib = _native.load()
         dev = x.device
@@ -361,43 +396,97 @@ class LSHHasher:
         ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
         with ctx:
             cur = torch.cuda.current_stream(dev)
-            flags_ptr = row_flags.data_ptr() if row_flags is not None else None
-            while True:
-                cap = max(int(self._flag_cap_hint), n // 4 + 4096)
-                scratch = self._replay_scratch.get(dev.index)
-                if scratch is None or scratch[0].shape[0] < cap:
-                    pinned = torch.zeros(2, dtype=torch.int32).pin_memory()
-                    scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
-                               torch.zeros(2, dtype=torch.int32, device=dev),      # tie count | stage-1 count
-                               pinned, pinned.numpy())
-                    self._replay_scratch[dev.index] = scratch
-                # (the device counters are zero: at creation, and the launch that exports them leaves them so)
-                flag_list, counts, pinned, host_counts = scratch
-                cptr = counts.data_ptr()
-                ev = None
-                if timing:
-                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-                    for e in ev:
-                        e.record(cur)                    # creates the handles; the library re-arms them on its dispatches
-                    lib.lshrs_debug_set_split_time_events(*(ctypes.c_void_p(e.cuda_event) for e in ev))
-                _native.check(
-                    lib.lshrs_sig_hash_batch_split_replay_f32(
-                        x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
-                        out.data_ptr(), cptr, tau, flags_ptr, flag_list.data_ptr(), cap, cptr + 4,
-                        float(self.tau1_ulps * _U), model, pinned.data_ptr(), cur.cuda_stream),
-                    "lshrs_sig_hash_batch_split_replay_f32")
-                cur.synchronize()      # (the launch behind stage 2 has written both counters into the pinned pair)
-                ties, flagged = int(host_counts[0]), int(host_counts[1])
-                if flagged <= cap:
-                    break
-                self._flag_cap_hint = int(flagged * 1.25) + 4096      # (rows flagged wholesale: NaN / Inf / extreme scales)
-                stats["relaunches"] += 1
+            cap = max(int(self._flag_cap_hint), n // 4 + 4096)
+            scratch = self._replay_scratch.get(dev.index)
+            if scratch is None or scratch[0].shape[0] < cap:
+                pinned = torch.zeros((4, 2), dtype=torch.int32).pin_memory()
+                scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
+                           torch.zeros(2, dtype=torch.int32, device=dev),      # tie count | stage-1 count
+                           pinned, pinned.numpy(), [0])
+                self._replay_scratch[dev.index] = scratch
+            # (the device counters are zero: at creation, and the launch that exports them leaves them so)
+            flag_list, counts, pinned, host_counts, turn = scratch
+            slot = turn[0] & 3
+            turn[0] += 1
+            cptr = counts.data_ptr()
+            ev = None
             if timing:
-                self.kernel_events.append((ev[0].elapsed_time(ev[1]), None, n, ev[2].elapsed_time(ev[3])))
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                for e in ev:
+                    e.record(cur)                    # creates the handles; the library re-arms them on its dispatches
+                lib.lshrs_debug_set_split_time_events(*(ctypes.c_void_p(e.cuda_event) for e in ev))
+            _native.check(
+                lib.lshrs_sig_hash_batch_split_replay_f32(
+                    x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
+                    out.data_ptr(), cptr, tau, row_flags.data_ptr() if row_flags is not None else None,
+                    flag_list.data_ptr(), int(flag_list.shape[0]), cptr + 4, float(self.tau1_ulps * _U), model,
+                    pinned[slot].data_ptr(), cur.cuda_stream),
+                "lshrs_sig_hash_batch_split_replay_f32")
+            done = torch.cuda.Event()
+            done.record(cur)
+        return (done, host_counts, slot, int(flag_list.shape[0]), n, ev)
+
+    def _replay_finish(self, state, stats) -> bool:
+        """Wait for a launch of `_replay_launch`; False when its stage-1 list was too small (repeat with room)."""
+        done, host_counts, slot, cap, n, ev = state
+        done.synchronize()      # (the launch behind stage 2 has written both counters into the pinned pair)
+        ties, flagged = int(host_counts[slot, 0]), int(host_counts[slot, 1])
+        if flagged > cap:
+            self._flag_cap_hint = int(flagged * 1.25) + 4096      # (rows flagged wholesale: NaN / Inf / extreme scales)
+            stats["relaunches"] += 1
+            return False
+        if ev is not None and self.kernel_events is not None:
+            self.kernel_events.append((ev[0].elapsed_time(ev[1]), None, n, ev[2].elapsed_time(ev[3])))
         stats["tie_entries"] = ties
         stats["tie_pairs"] = ties          # (tied PROJECTIONS here: each decided by the replayed host order)
         stats["tie_break_engine"] = "device-replay"
+        return True
+
+    def _hash_device_replay(self, x, out, row_flags, ws, tau, stats, model):
+        """One launch of the split pass whose stage 2 also breaks the ties (``lshrs_sig_hash_batch_split_replay_f32``):
+        the keys are the reference's when the stream has run.  The only host step is reading two counters back
+        (stage-1 list overflow -> repeat with room; tied projections -> stats)."""
+        while self._async_pending:      # (their pinned pairs are handed out in turn: verify them before taking more)
+            self._async_pending[0]._finish_locked()
+        while not self._replay_finish(self._replay_launch(x, out, row_flags, ws, tau, model), stats):
+            pass
         return out
+
+    def hash_device_async(self, x, *, out=None, row_flags=None):
+        """:meth:`hash_device` for streaming ingest: enqueue the batch and return a handle at once; ``handle.result()``
+        returns the keys once the launch has been VERIFIED (the one thing the host must look at - whether the stage-1
+        list held - and the repeat with room if it did not), so the host's wake-up and the interpreter overlap the next
+        batch's kernels instead of idling the GPU between batches (~55 us per 1M x 768 batch).  At most three batches
+        stay unverified: a fourth call verifies the oldest first.  Where the device tie replay does not apply the
+        batch is hashed synchronously and the handle is complete on return."""
+        torch = _native.require_gpu()
+        if x.dim() != 2 or x.shape[1] != self.dim:
+            raise ValueError(f"Expected vectors of dimension {self.dim}, received {tuple(x.shape)}")
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise TypeError("hash_device expects a float32 CUDA/ROCm tensor")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        n = int(x.shape[0])
+        with self._lock:
+            while len(self._async_pending) >= 3:
+                self._async_pending[0]._finish_locked()
+            model = 0
+            if (n > 0 and self.tie_break == "host" and self.tie_replay == "auto" and self._split_applies(n, replay=True)
+                    and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x.stride(0) < (1 << 20)):
+                model = self._replay_model()
+            if not model:
+                return _PendingKeys(self, x, self._hash_device_locked(x, out, row_flags, self.tie_break, host_rows=None),
+                                    row_flags, None)
+            bb = self.band_bytes
+            if out is None:
+                out = torch.empty((n, self.num_bands, bb), dtype=torch.uint8, device=x.device)
+            elif out.shape != (n, self.num_bands, bb) or out.dtype != torch.uint8 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous uint8 tensor of shape (n, num_bands, band_bytes)")
+            ws = self._workspace(x.device)
+            state = self._replay_launch(x, out, row_flags, ws, float(self.tau_ulps * _U), model)
+            handle = _PendingKeys(self, x, out, row_flags, state)
+            self._async_pending.append(handle)
+            return handle
 
     def _hash_device_f32_replay(self, x, out, row_flags, ws, tau, stats, model):
         """The exact-f32 kernel followed by the device's tie replay (``lshrs_sig_resolve_ties_replay_f32``): for batches
@@ -1055,6 +1144,7 @@ class LSHHasher:
         state["_pipes"] = {}
         state["_plan_cache"] = {}
         state["_replay_scratch"] = {}
+        state["_async_pending"] = []
         state["_replay_model_cache"] = None
         state["_host_planes_cache"] = None
         state["kernel_events"] = None
@@ -1068,6 +1158,7 @@ class LSHHasher:
         self.__dict__.setdefault("_pipes", {})
         self.__dict__.setdefault("_plan_cache", {})
         self.__dict__.setdefault("_replay_scratch", {})
+        self.__dict__.setdefault("_async_pending", [])
         self.__dict__.setdefault("_replay_model_cache", None)
         self.__dict__.setdefault("tie_replay", "auto")
         self.__dict__.setdefault("replay_min_rows", 256)

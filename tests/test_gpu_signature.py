@@ -314,6 +314,44 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     assert torch.equal(got, _hasher(42, 16, 16, 768, precision="f32").hash_device(x))
 
 
+def test_streaming_entry_point_equals_hash_device(torch_mod):
+    """`hash_device_async`: the batch is enqueued at once, `result()` is the verified keys.  Same bytes as `hash_device`
+    for several batches in flight, for sync and async calls mixed, for a batch whose stage-1 list overflows (verified
+    late, repeated with room) and where the device tie replay does not apply (complete on return)."""
+    torch = torch_mod
+    h = _hasher(42, 16, 16, 768)
+    ref = _hasher(42, 16, 16, 768, tie_replay="off")
+    gen = torch.Generator("cuda").manual_seed(11)
+    xs = [torch.randn(n, 768, device="cuda", generator=gen) for n in (70_000, 300_000, 5_000, 150_000, 90_001, 260_000)]
+    handles = [h.hash_device_async(x) for x in xs]                    # the fourth call verifies the first, and so on
+    assert len(h._async_pending) <= 3
+    mid = h.hash_device(xs[0])                                        # a synchronous call in between drains the rest
+    assert not h._async_pending
+    for x, hd in zip(xs, handles):
+        assert hd.done() and torch.equal(hd.result(), ref.hash_device(x))
+    assert torch.equal(mid, handles[0].result())
+    if h._replay_model():
+        assert h.last_stats.get("tie_break_engine") == "device-replay"
+    # every row outside the guarded range: flagged wholesale, the first launch's list is too small
+    h2 = _hasher(42, 16, 16, 768)
+    big = torch.randn(40_000, 768, device="cuda", generator=gen) * 1e30
+    hd = h2.hash_device_async(big)
+    assert torch.equal(hd.result(), _hasher(42, 16, 16, 768, precision="f32", tie_replay="off").hash_device(big))
+    assert h2.last_stats["relaunches"] >= 1 or not h2._replay_model()
+    # a shape the replay does not cover: hashed synchronously, handle complete
+    h3 = _hasher(5, 8, 12, 100)
+    x3 = torch.randn(3000, 100, device="cuda", generator=gen)
+    hd3 = h3.hash_device_async(x3)
+    assert hd3.done() and torch.equal(hd3.result(), h3.hash_device(x3))
+    # row flags and a caller-provided output travel with the handle
+    flags = torch.zeros(70_000, dtype=torch.uint8, device="cuda")
+    out = torch.empty((70_000, 16, 2), dtype=torch.uint8, device="cuda")
+    xs[0][123] = 0.0
+    got = h.hash_device_async(xs[0], out=out, row_flags=flags).result()
+    assert got.data_ptr() == out.data_ptr() and flags.nonzero().flatten().tolist() == [123]
+    assert torch.equal(got, ref.hash_device(xs[0]))
+
+
 def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     """Large device batches overlap the host tie-break with later chunks' kernels: same bytes."""
     torch = torch_mod
