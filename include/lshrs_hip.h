@@ -98,14 +98,14 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
                                    int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
                                    void* stream);
 
-/* lshrs_sig_hash_batch_split_f32 with the tie-break on the device: a projection that ties (|y| < tau ||x|| ||p||)
- * gets the sign of the value the HOST BLAS computes for it - the reference's `projection @ vector`, lsh.py:200 -
- * because stage 2 replays that library's summation order (blas_model 1: eight interleaved fma chains over k = j mod 8,
+/* lshrs_sig_hash_batch_split_f32 with the tie-break on the device: every projection stage 1 flags (inside its window,
+ * which contains every tie) gets the sign of the value the HOST BLAS computes for it - the reference's
+ * `projection @ vector`, lsh.py:200 - because stage 2 replays that library's summation order (blas_model 1: eight interleaved fma chains over k = j mod 8,
  * reduced ((p0+p4)+(p1+p5))+((p2+p6)+(p3+p7)): OpenBLAS's 8-lane sgemv_t kernels).  The keys are final when the stream
  * has run: no tie list, no host step.  Only for callers that have checked the model against their BLAS
  * (lshrs_tb_model_dot in lshrs_host.h vs `P_band @ x`, bit for bit; lshrs_amd/hasher.py does) and for inputs the split
  * pass takes itself (dim % 32 == 0, 16-byte aligned rows; else LSHRS_E_BADARG).
- *   tie_count    optional int32[1], zeroed by the caller: receives the number of projections decided that way.
+ *   tie_count    optional int32[1], zeroed by the caller: statistics - flagged projections with |y| < tau ||x|| ||p||.
  *   host_counts  optional: PINNED HOST int32[2] the device can write (hipHostMalloc / torch pin_memory): a
  *                single-thread launch behind stage 2 stores (tie_count, flag_count) there and leaves both device
  *                counters zeroed for the next call - the caller reads them after synchronising the stream

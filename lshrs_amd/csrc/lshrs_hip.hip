@@ -1135,14 +1135,14 @@ constexpr int kFixG = 8;
 constexpr int kFixSlabG = 12;      // k-tiles per slab: 2 x 12 x 8 chunks x 8 projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is two slabs)
 constexpr int kFixGridG = 1536;    // 256 CUs x 6 resident single-wave workgroups (slabs of 24 tiles, 3 per CU: 0.085 ms of fix-ups per 1M rows; 12: 0.074; 8: 0.075)
 //
-// REPLAY: the tie-break on the device.  A projection whose canonical value is a tie (|y| < tau ||x|| ||p||) gets the
-// sign of the value the HOST BLAS computes for it - the reference's `projection @ vector` (lshrs/hash/lsh.py:200) -
-// by replaying that library's summation order: blas_model 1 = eight interleaved single-rounded fma chains
+// REPLAY: the tie-break on the device.  Every flagged projection gets the sign of the value the HOST BLAS computes for
+// it - the reference's `projection @ vector` (lshrs/hash/lsh.py:200) - and only that value is computed, by replaying
+// that library's summation order: blas_model 1 = eight interleaved single-rounded fma chains
 // p_j = sum over k = j (mod 8) of a_k x_k, j = 0..7, reduced as ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)) - the
 // 8-lane AVX kernel + vextractf128 / vhaddps / vhaddps of OpenBLAS's sgemv_t (Haswell, Zen and SkylakeX builds;
 // found by search, tools/blas_order/, and checked bit for bit against `P_band @ x` of the running process before a
-// hasher uses it: lshrs_amd/hasher.py).  The eight lanes (sub) that serve one projection - redundant for the
-// canonical chain - each own one p_j, four fmas per k-tile from the slab already in LDS.  No tie list, no host.
+// hasher uses it: lshrs_amd/hasher.py).  The eight lanes (sub) that serve one projection each own one p_j, four fmas
+// per k-tile from the slab in LDS: 96 steps for a 768-deep row where the canonical chain walks 768.  No tie list, no host.
 template <bool REPLAY>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 xs[kFixSlabG * 8 * kFixG];
@@ -1174,25 +1174,34 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
                                          (LDS_AS void*)(ps + i * 64), 16, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll 2
-      for (int t = 0; t < tiles; ++t) {
-        f32x4 p4[2][4], x4[2][4];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x4[hh][q] = xs[(t * 8 + hh * 4 + q) * kFixG + g];
-            p4[hh][q] = ps[(t * 8 + hh * 4 + q) * kFixG + g];
-          }
-        fix_chain_tile(p4, x4, acc, ss);
-        if (REPLAY) {   // k = 32 t + 8 m + sub, m = 0..3: chunk 2 m + (sub >> 2), element sub & 3
-          const float* xf = reinterpret_cast<const float*>(xs);
-          const float* pf = reinterpret_cast<const float*>(ps);
+      if (REPLAY) {
+        // The library's value IS the reference's for every flagged projection, tie or not: the canonical chain (768
+        // dependent fmas per lane) is not needed here, only p_sub: k = 32 t + 8 m + sub, m = 0..3 = chunk
+        // 2 m + (sub >> 2), element sub & 3.  (ss: this lane's share of ||x||^2, for the tie statistics only.)
+        const float* xf = reinterpret_cast<const float*>(xs);
+        const float* pf = reinterpret_cast<const float*>(ps);
+#pragma unroll 4
+        for (int t = 0; t < tiles; ++t) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
-            pj = __builtin_fmaf(pf[o], xf[o], pj);
+            const float xv = xf[o];
+            pj = __builtin_fmaf(pf[o], xv, pj);
+            ss = __builtin_fmaf(xv, xv, ss);
           }
+        }
+      } else {
+#pragma unroll 2
+        for (int t = 0; t < tiles; ++t) {
+          f32x4 p4[2][4], x4[2][4];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              x4[hh][q] = xs[(t * 8 + hh * 4 + q) * kFixG + g];
+              p4[hh][q] = ps[(t * 8 + hh * 4 + q) * kFixG + g];
+            }
+          fix_chain_tile(p4, x4, acc, ss);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab has been read before the next one lands on it
@@ -1202,6 +1211,9 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       const float q = pj + __shfl(pj, (lane + 32) & 63);           // sub 0..3: p_sub + p_(sub+4)
       const float h = q + __shfl(q, (lane + 8) & 63);              // sub 0: q0 + q1, sub 2: q2 + q3
       yb = h + __shfl(h, (lane + 16) & 63);                        // sub 0: (q0 + q1) + (q2 + q3)
+      float s2 = ss + __shfl(ss, (lane + 32) & 63);
+      s2 += __shfl(s2, (lane + 8) & 63);
+      ss = s2 + __shfl(s2, (lane + 16) & 63);
     }
     if (sub != 0 || !live) continue;
     uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
@@ -1210,11 +1222,9 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     const unsigned int bitmask = 1u << (8 * (unsigned)(addr & 3) + (col & 7));
     bool want = acc > 0.f;
     if (REPLAY) {
-      const float thr = a.tau * sqrtf(ss) * a.norms[col];
-      if (__builtin_fabsf(acc) < thr) {          // a tie: the host BLAS's value decides, as it does in the reference
-        want = yb > 0.f;
-        if (a.tie_count != nullptr) atomicAdd(a.tie_count, 1);
-      }
+      want = yb > 0.f;                             // (0, -0 and NaN give 0, as `projections > 0` does: lsh.py:204)
+      if (a.tie_count != nullptr && __builtin_fabsf(yb) < a.tau * sqrtf(ss) * a.norms[col])
+        atomicAdd(a.tie_count, 1);                 // statistics: projections inside the tie window
     }
     const bool have = (*kb >> (col & 7)) & 1;
     if (want != have) {
