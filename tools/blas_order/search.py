@@ -1,5 +1,13 @@
-import ctypes, itertools, numpy as np, sys
-lib = ctypes.CDLL('' + __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'libmodel.so') + '')
+"""In which order does this host's BLAS sum a dot product?  Tries a family of candidate orders (SIMD lanes x independent
+accumulators x fma or not x two reduction trees for the accumulators x three for the lanes x K-blocking; model.c) against
+what NumPy returns for `P @ x` - the reference's call, lshrs/hash/lsh.py:200 - bit for bit, row by row, and prints the
+candidates that reproduce every trial.  On the hosts of round 1 (Intel Xeon and AMD EPYC 9575F, OpenBLAS 0.3.29 "SkylakeX")
+exactly one order survives: 4 lanes x 2 accumulators, fma, adjacent-pair reduction = eight interleaved chains over
+k mod 8 reduced ((p0+p4)+(p1+p5))+((p2+p6)+(p3+p7)).  That order is `lshrs_tb_model_dot(model=1)` and what
+sig_fix8_kernel<true> replays.   build: gcc -O2 -ffp-contract=off -shared -fPIC model.c -o libmodel.so -lm"""
+import ctypes, itertools, os, sys
+import numpy as np
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmodel.so"))
 lib.model_dot.restype = ctypes.c_float
 lib.model_dot.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int]*7
 rng = np.random.default_rng(1)
