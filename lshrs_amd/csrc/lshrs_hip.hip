@@ -102,8 +102,16 @@ inline int64_t sig_fine_floats(const SigGeom& g) {
 inline bool sig_has_split(const SigGeom& g) { return g.nt == 8; }
 inline int64_t sig_split_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
 inline int64_t sig_t16_offset_floats(const SigGeom& g) { return sig_split_offset_floats(g) + sig_image_floats(g); }
+// "Narrow" hashers - 128 to 255 key columns, e.g. the reference's default num_perm = 128 - take the split pass too: on
+// a 16x16x32 fragment image padded with zero hyperplanes to the 256 columns sig16_kernel<2,8> works on (a zero
+// column gives y = +0: never flagged, bit 0, and its key bytes lie beyond row_bytes and are not stored).  Half the
+// matrix work is wasted and it is still 1.5x the exact-f32 kernel.  Own image + 256 norms + their maximum.
+inline bool sig_has_narrow_split(const SigGeom& g) { return g.nt < 8 && g.cb == 1 && g.padcols >= 128; }
+inline int64_t sig_narrow_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
+inline int64_t sig_narrow_image_floats(const SigGeom& g) { return (int64_t)g.ktiles * 8 * 4 * kFragFloats; }
 inline int64_t sig_workspace_floats(const SigGeom& g) {
-  return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? 2 * sig_image_floats(g) : 0);
+  return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? 2 * sig_image_floats(g) : 0) +
+         (sig_has_narrow_split(g) ? sig_narrow_image_floats(g) + 256 + 4 : 0);
 }
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
 
@@ -2193,6 +2201,15 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((f.cb + 63) / 64)), dim3(64), 0, s, norms, 32, f.cb,
                        fimage + sig_image_floats(f));
   }
+  if (sig_has_narrow_split(g)) {
+    float* nimage = image + sig_narrow_offset_floats(g);
+    const int64_t nchunks = sig_narrow_image_floats(g) / 4;
+    hipLaunchKernelGGL(pack_image_bf16_t16_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                       rows_per_band, dim, g.bb, g.ktiles, nchunks, reinterpret_cast<u16x8*>(nimage));
+    float* nnorms = nimage + sig_narrow_image_floats(g);
+    hipLaunchKernelGGL(pack_norm_kernel, dim3(4), dim3(64), 0, s, P, num_bands, rows_per_band, dim, g.bb, 256, nnorms);
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, nnorms, 256, 1, nnorms + 256);
+  }
   if (sig_has_split(g)) {
     float* simage = image + sig_split_offset_floats(g);
     const int64_t schunks = sig_image_floats(g) / 4;  // 16-byte chunks: same count as the f32 image
@@ -2276,7 +2293,8 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
   // the second stage patches key bits with 32-bit atomics: rows must be whole words
-  if (!sig_has_split(g) || row_bytes % 4 != 0 || (reinterpret_cast<uintptr_t>(keys) & 3)) return LSHRS_E_TOOLARGE;
+  const bool narrow = sig_has_narrow_split(g);
+  if ((!sig_has_split(g) && !narrow) || row_bytes % 4 != 0 || (reinterpret_cast<uintptr_t>(keys) & 3)) return LSHRS_E_TOOLARGE;
   if (n >= ((int64_t)1 << 47) || (n + 255) / 256 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
@@ -2296,6 +2314,11 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   a.image = base + sig_split_offset_floats(g);
   a.norms = base + sig_image_floats(g);
   a.norm_max = a.norms + sig_norm_floats(g);
+  if (narrow) {   // the zero-padded 256-column image and its norms
+    a.image = base + sig_narrow_offset_floats(g);
+    a.norms = a.image + sig_narrow_image_floats(g);
+    a.norm_max = a.norms + 256;
+  }
   a.keys = keys;
   a.row_bytes = row_bytes;
   a.vec_store = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(keys) % 16) == 0);
@@ -2306,7 +2329,11 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   a.tau = tau1;
   a.row_flags = row_flags;
   a.clock_probe = g_clock_probe;
-  if (g_split_m == 2) {
+  if (narrow) {
+    const dim3 grid((unsigned)((n + 255) / 256), 1, 1);
+    hipExtLaunchKernelGGL((sig16_kernel<2, 8>), grid, dim3(512, 1, 1), 0, s, g_split_time_events[0],
+                          g_split_time_events[1], 0, a);
+  } else if (g_split_m == 2) {
     constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles, one workgroup per CU
     const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
     if (g_split_pipe == 6 || g_split_pipe == 7 || g_split_pipe == 8) {

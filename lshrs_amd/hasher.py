@@ -910,7 +910,10 @@ class LSHHasher:
         elif n < self.split_min_rows or n * self.dim < self.split_min_elems:
             return False
         lib = _native.load()
-        if (int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) < 256
+        key_cols = 8 * self.num_bands * self.band_bytes
+        # >= 256 key columns, or exactly 128 (the reference's default num_perm = 128 as 8 x 16, config 1's 16 x 4):
+        # those run on a fragment image zero-padded to 256 columns - half the matrix work wasted, still 1.5x the f32 kernel
+        if ((int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) < 256 and key_cols != 128)
                 or (self.num_bands * self.band_bytes) % 4 != 0):
             return False
         # hyperplanes far outside the unit scale (user-assigned matrices) leave the range in which the bf16 split

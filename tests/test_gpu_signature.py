@@ -279,17 +279,18 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     torch = torch_mod
     from oracle.parallel import SharedVectors, hash_shared_literal_packed
 
-    for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 60_000)):
-        h = _hasher(seed, nb, r, dim)
+    for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 60_000), (21, 8, 16, 768, 120_000)):
+        h = _hasher(seed, nb, r, dim)                      # (the last one: the reference's default num_perm = 128)
         if not h._replay_model():
             pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
         x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
-        pl = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])[[3, 100, 200]]
+        pl = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])[[3, 100, nb * r - 56]]
         special = np.arange(0, n, 100)
         xs = x[special].cpu().numpy().astype(np.float64)
         xs -= (xs @ np.linalg.pinv(pl)) @ pl
         x[special] = torch.from_numpy(xs.astype(np.float32)).cuda()
         flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        assert h._split_applies(n, replay=True)
         got = h.hash_device(x, row_flags=flags)
         st = dict(h.last_stats)
         assert st.get("tie_break_engine") == "device-replay" and st["tie_pairs"] > 3 * special.size - 10
@@ -547,6 +548,7 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
     for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 70_000), (3, 32, 8, 96, 70_001),
+                                 (11, 8, 16, 768, 90_000), (12, 16, 4, 128, 150_001),   # 128 key columns: zero-padded image
                                  (3, 32, 8, 100, 70_001)):     # dim % 32 != 0: the f32 kernel takes over
         h32 = _hasher(seed, nb, r, dim, precision="f32")
         hs = _hasher(seed, nb, r, dim, precision="bf16x3")
