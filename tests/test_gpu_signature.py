@@ -548,7 +548,7 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
     for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 70_000), (3, 32, 8, 96, 70_001),
-                                 (11, 8, 16, 768, 90_000), (12, 16, 4, 128, 150_001),   # 128 key columns: zero-padded image
+                                 (11, 8, 16, 768, 90_000), (12, 16, 4, 384, 150_001),   # 128 key columns: zero-padded image
                                  (3, 32, 8, 100, 70_001)):     # dim % 32 != 0: the f32 kernel takes over
         h32 = _hasher(seed, nb, r, dim, precision="f32")
         hs = _hasher(seed, nb, r, dim, precision="bf16x3")
