@@ -87,7 +87,9 @@ def test_pure_host_entry_points(lib):
     # 16x16x32 fragment order (same size again, twice)
     assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (4 * 256 * 768 + 256 + 4 + 8) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (4 * 512 * 1536 + 512 + 4 + 16) * 4
-    assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (2 * 128 * 128 + 128 + 4 + 4) * 4
+    # exactly 128 padded columns: + the 16x16x32 fragment image zero-padded to 256 columns (256 x dim bf16 hi/mid
+    # = 256 x dim floats' worth), its 256 norms and their maximum (x4)
+    assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (2 * 128 * 128 + 128 + 4 + 4 + 256 * 128 + 256 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device
