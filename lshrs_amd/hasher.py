@@ -204,6 +204,7 @@ class LSHHasher:
         self._plan_cache: Dict[tuple, tuple] = {}
         self._replay_scratch: Dict[object, tuple] = {}
         self._async_pending: list = []
+        self._replay_events: Dict[int, list] = {}
         self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
@@ -411,10 +412,20 @@ class LSHHasher:
             cptr = counts.data_ptr()
             ev = None
             if timing:
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-                for e in ev:
-                    e.record(cur)                    # creates the handles; the library re-arms them on its dispatches
-                lib.lshrs_debug_set_split_time_events(*(ctypes.c_void_p(e.cuda_event) for e in ev))
+                # four timing events per launch, from a ring as deep as the pinned pairs (creating and recording them
+                # afresh costs ~20 us of host time per launch - on a 1.2 ms step that is the measurement disturbing
+                # the measured)
+                ring = self._replay_events.get(dev.index)
+                if ring is None:
+                    ring = []
+                    for _ in range(4):
+                        quad = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                        for e in quad:
+                            e.record(cur)            # creates the handles; the library re-arms them on its dispatches
+                        ring.append((quad, tuple(ctypes.c_void_p(e.cuda_event) for e in quad)))
+                    self._replay_events[dev.index] = ring
+                ev, handles = ring[slot]
+                lib.lshrs_debug_set_split_time_events(*handles)
             _native.check(
                 lib.lshrs_sig_hash_batch_split_replay_f32(
                     x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
@@ -1152,6 +1163,7 @@ class LSHHasher:
         state["_plan_cache"] = {}
         state["_replay_scratch"] = {}
         state["_async_pending"] = []
+        state["_replay_events"] = {}
         state["_replay_model_cache"] = None
         state["_host_planes_cache"] = None
         state["kernel_events"] = None
@@ -1166,6 +1178,7 @@ class LSHHasher:
         self.__dict__.setdefault("_plan_cache", {})
         self.__dict__.setdefault("_replay_scratch", {})
         self.__dict__.setdefault("_async_pending", [])
+        self.__dict__.setdefault("_replay_events", {})
         self.__dict__.setdefault("_replay_model_cache", None)
         self.__dict__.setdefault("tie_replay", "auto")
         self.__dict__.setdefault("replay_min_rows", 256)
