@@ -174,6 +174,7 @@ class LSHHasher:
         self.tie_threads = None if tie_threads is None else int(tie_threads)
         self._host_planes_cache: Optional[Tuple[int, np.ndarray]] = None
         self._split_range_ok: Optional[Tuple[int, bool]] = None
+        self._split_shape_ok: Optional[Tuple[int, bool]] = None
         self._device = device
         self._lock = threading.Lock()
         self._projection_version = 0
@@ -385,7 +386,7 @@ class LSHHasher:
             self._replay_model_cache = cached
         return cached[1]
 
-    def _replay_launch(self, x, out, row_flags, ws, tau, model):
+    def _replay_launch(self, x, out, row_flags, ws, tau, model, want_event: bool = False):
         """Enqueue one split pass with the tie replay on the current stream; returns what `_replay_finish` needs.
         The two counters of the launch come back through one of four pinned pairs (launches are handed out in turn:
         at most three may be unfinished, `hash_device_async` sees to that)."""
@@ -433,9 +434,11 @@ class LSHHasher:
                     flag_list.data_ptr(), int(flag_list.shape[0]), cptr + 4, float(self.tau1_ulps * _U), model,
                     pinned[slot].data_ptr(), cur.cuda_stream),
                 "lshrs_sig_hash_batch_split_replay_f32")
-            done = torch.cuda.Event()
-            done.record(cur)
-        return (done, host_counts, slot, int(flag_list.shape[0]), n, ev)
+            done = None
+            if want_event:          # (the synchronous path waits for the stream instead)
+                done = torch.cuda.Event()
+                done.record(cur)
+        return (done if want_event else cur, host_counts, slot, int(flag_list.shape[0]), n, ev)
 
     def _replay_finish(self, state, stats) -> bool:
         """Wait for a launch of `_replay_launch`; False when its stage-1 list was too small (repeat with room)."""
@@ -494,7 +497,7 @@ class LSHHasher:
             elif out.shape != (n, self.num_bands, bb) or out.dtype != torch.uint8 or not out.is_contiguous():
                 raise ValueError("out must be a contiguous uint8 tensor of shape (n, num_bands, band_bytes)")
             ws = self._workspace(x.device)
-            state = self._replay_launch(x, out, row_flags, ws, float(self.tau_ulps * _U), model)
+            state = self._replay_launch(x, out, row_flags, ws, float(self.tau_ulps * _U), model, want_event=True)
             handle = _PendingKeys(self, x, out, row_flags, state)
             self._async_pending.append(handle)
             return handle
@@ -920,6 +923,14 @@ class LSHHasher:
                 return False
         elif n < self.split_min_rows or n * self.dim < self.split_min_elems:
             return False
+        cached = self._split_shape_ok
+        if cached is not None and cached[0] == self._projection_version:
+            return cached[1]
+        ok = self._split_shape_check()
+        self._split_shape_ok = (self._projection_version, ok)
+        return ok
+
+    def _split_shape_check(self) -> bool:
         lib = _native.load()
         key_cols = 8 * self.num_bands * self.band_bytes
         # >= 256 key columns, or exactly 128 (the reference's default num_perm = 128 as 8 x 16, config 1's 16 x 4):
@@ -1185,6 +1196,7 @@ class LSHHasher:
         self.__dict__.setdefault("pipeline_pair_head", True)
         self.__dict__.setdefault("_host_planes_cache", None)
         self.__dict__.setdefault("_split_range_ok", None)
+        self.__dict__.setdefault("_split_shape_ok", None)
         self.__dict__.setdefault("split_min_elems", 16 << 20)
         self._lock = threading.Lock()
         self._projections = _ProjectionList(state["_projections"], self)
