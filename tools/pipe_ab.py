@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two pipeline drivers (interpreter vs library) on the bench workload, interleaved in one process:
+"""A/B of the two drivers of the host tie-break pipeline (interpreter vs library) on the bench workload, interleaved in one process:
 ms per step, stage-1 / fix-up kernel means and the driver's own timers.  usage: pipe_ab.py [rows] [rounds]"""
 import os
 import sys
@@ -15,7 +15,9 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 dev = torch.device("cuda", 0)
 x = torch.randn(n, 768, device=dev, generator=torch.Generator(device=dev).manual_seed(1000))
 keys = torch.empty((n, 16, 2), dtype=torch.uint8, device=dev)
-hs = {name: LSHHasher(16, 16, 768, seed=42, device=0, pipeline=name) for name in ("python", "native")}
+# (tie_replay="off": this tool compares the two drivers of the HOST tie-break path; the default hasher breaks its ties on
+# the device and needs neither)
+hs = {name: LSHHasher(16, 16, 768, seed=42, device=0, pipeline=name, tie_replay="off") for name in ("python", "native")}
 ref = None
 for name, h in hs.items():
     for _ in range(3):
