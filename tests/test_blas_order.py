@@ -69,3 +69,20 @@ def test_shapes_the_model_does_not_cover_are_refused():
     assert h2.tie_replay == "off"
     with pytest.raises(ValueError):
         LSHHasher(16, 16, 768, tie_replay="maybe")
+
+
+def test_hasher_pickles_with_and_without_the_newer_fields():
+    import pickle
+
+    h = LSHHasher(8, 16, 768, seed=3, tie_replay="off", pipeline="python")
+    g = pickle.loads(pickle.dumps(h))
+    assert (g.tie_replay, g.pipeline, g.pipeline_pair_head, g.replay_min_rows) == ("off", "python", True, 256)
+    assert np.array_equal(g.projections[0], h.projections[0]) and g._replay_scratch == {} and g._async_pending == []
+    state = h.__getstate__()                  # a pickle written before these knobs existed
+    for k in ("tie_replay", "_replay_scratch", "_async_pending", "_replay_events", "_plan_cache", "pipeline", "_pipes",
+              "pipeline_pair_head", "replay_min_rows", "_split_shape_ok", "_replay_model_cache"):
+        state.pop(k, None)
+    old = LSHHasher.__new__(LSHHasher)
+    old.__setstate__(state)
+    assert (old.tie_replay, old.pipeline, old.pipeline_pair_head, old.replay_min_rows) == ("auto", "native", True, 256)
+    assert old._replay_model() in (0, 1) and old._plan_cache == {}
