@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr());
- *     the library allocates nothing and frees nothing, and keeps no global mutable state;
+ *     the library allocates nothing and frees nothing (the pipeline object of lshrs_pipe_* is the one exception) and
+ *     keeps no global mutable state: everything a call needs travels in its arguments, so any number of threads may
+ *     call concurrently, each on its own stream and buffers;
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream) and returns immediately: 0 = OK, <0 = -(hipError_t), or one of the
  *     LSHRS_E_* argument errors.  Nothing is thrown across the ABI;
@@ -24,13 +26,40 @@
 extern "C" {
 #endif
 
-#define LSHRS_ABI_VERSION 1
+#define LSHRS_ABI_VERSION 2
 
 #define LSHRS_E_BADARG   (-10001) /* NULL pointer / non-positive size / misaligned workspace */
 #define LSHRS_E_TOOLARGE (-10002) /* shape outside what the kernels support (see each call)  */
 
 /* ABI version of the loaded library (== LSHRS_ABI_VERSION of the header it was built from). */
 int lshrs_abi_version(void);
+
+/* Optional per-call measurement hooks of the signature entry points (NULL = none).  Nothing here changes a result.
+ *   ev_stage*   hipEvent_t handles (created by the caller, timing enabled) that ride ON the dispatch packets of the
+ *               split pass's two kernels (hipExtLaunchKernelGGL start/stop events): the kernels' own durations,
+ *               without an extra packet in the stream.  Ignored by lshrs_sig_hash_batch_f32.
+ *   clock_probe device u64[2 * 2 * workgroups]: the first wide-geometry launch of the call stores per workgroup the
+ *               {shader-clock, 100 MHz} tick counts of its main loop (first half) and of the whole workgroup (second
+ *               half; split pass only): in-kernel clock = ratio x 100 MHz (MI355X_MICROARCH.md, DVFS item 6). */
+typedef struct lshrs_sig_opts {
+  uint32_t struct_bytes;   /* sizeof(lshrs_sig_opts): lets the struct grow without breaking old callers */
+  uint32_t reserved;       /* 0 */
+  void* ev_stage1_start;
+  void* ev_stage1_stop;
+  void* ev_stage2_start;
+  void* ev_stage2_stop;
+  void* clock_probe;
+} lshrs_sig_opts;
+
+/* Device counter block of the replay entry points (int32[LSHRS_SIG_COUNTERS], zeroed by the caller once; every call
+ * that is given host_counts hands it over and leaves it zeroed):
+ *   [0] projections inside the tie window tau (statistics) / tie entries the f32 kernel wanted to write
+ *   [1] list entries wanted (> the list's capacity: the pass is incomplete, repeat it with room)
+ *   [2] float bits: max over the flagged projections of |y_stage1 - y_hostBLAS| in units of 2^-24 ||x|| ||p|| - the
+ *       stage-1 window's margin as measured on THIS batch (split replay only)
+ *   [3] flagged projections whose key bit stage 2 had to change
+ *   [4..7] reserved (0) */
+#define LSHRS_SIG_COUNTERS 8
 
 /* ------------------------------------------------------------------------------------------
  * Signature pass — replaces LSHHasher.hash_vector / hash_batch / _project_and_pack
@@ -75,16 +104,17 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
                              const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
                              uint8_t* keys,
                              int64_t* tie_list, int32_t tie_cap, int32_t* tie_count, float tau,
-                             uint8_t* row_flags, void* stream);
+                             uint8_t* row_flags, const lshrs_sig_opts* opts, void* stream);
 
 /* Split-precision form of lshrs_sig_hash_batch_f32 (same keys, same tie list, > 2x the rate): stage 1 evaluates
  * every projection as xh*ph + xh*pm + xm*ph on the bf16 matrix cores (x = xh + xm + ..., p likewise, bf16 pieces)
  * and lists every projection with NOT(|y1| > tau1 * ||x|| * ||p||) in flag_list; stage 2 re-evaluates exactly those
  * as the f32 fmaf chain of the f32 kernel, corrects their key bits and reports ties (|y| < tau ...) as above.
- * tau1 is a measured window, like tau: over 2.7e9 projections of six data distributions the stage-1 value never
- * strayed 16 units of 2^-24 ||x|| ||p|| from the chain (profiles/r01_split_window_margin.log; the Python layer
- * passes 64 units); the analytic worst case, every rounding error aligned against a cancelling sum, is 768 units.
- * Rows whose largest |x| is outside [2^-60, 2^60] are flagged wholesale.
+ * tau1: the stage-1 window.  Measured, over 2.7e9 projections of six data distributions the stage-1 value never
+ * strayed 16 units of 2^-24 ||x|| ||p|| from the chain (profiles/r01_split_window_margin.log; the Python layer's
+ * default is 64 units and it watches counter [2] of the replay on every batch); its deterministic bound - every
+ * rounding error at its maximum and aligned - is what LSHHasher(tau1_ulps="bound") passes (lshrs_amd/hasher.py,
+ * DESIGN.md §3).  Rows whose largest |x| is outside [2^-60, 2^60] are flagged wholesale.
  *   flag_list int64[flag_cap], flag_count int32[1] (zeroed by the caller): scratch, one entry per flagged
  *   projection; if *flag_count > flag_cap afterwards the pass is incomplete and must be repeated with a larger list.
  * Only for shapes with >= 256 padded columns whose key rows are whole 32-bit words (else LSHRS_E_TOOLARGE:
@@ -96,7 +126,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
                                    int64_t* tie_list, int32_t tie_cap, int32_t* tie_count, float tau,
                                    uint8_t* row_flags,
                                    int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
-                                   void* stream);
+                                   const lshrs_sig_opts* opts, void* stream);
 
 /* lshrs_sig_hash_batch_split_f32 with the tie-break on the device: every projection stage 1 flags (inside its window,
  * which contains every tie) gets the sign of the value the HOST BLAS computes for it - the reference's
@@ -105,29 +135,33 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
  * has run: no tie list, no host step.  Only for callers that have checked the model against their BLAS
  * (lshrs_tb_model_dot in lshrs_host.h vs `P_band @ x`, bit for bit; lshrs_amd/hasher.py does) and for inputs the split
  * pass takes itself (dim % 32 == 0, 16-byte aligned rows; else LSHRS_E_BADARG).
- *   tie_count    optional int32[1], zeroed by the caller: statistics - flagged projections with |y| < tau ||x|| ||p||.
- *   host_counts  optional: PINNED HOST int32[2] the device can write (hipHostMalloc / torch pin_memory): a
- *                single-thread launch behind stage 2 stores (tie_count, flag_count) there and leaves both device
- *                counters zeroed for the next call - the caller reads them after synchronising the stream
- *                (flag_count > flag_cap: repeat with room) without a copy or a fill of its own. */
+ *   counters     int32[LSHRS_SIG_COUNTERS] (see above), zero on entry.
+ *   flag_y       optional float[flag_cap]: the stage-1 value of every list entry; with it stage 2 measures how far
+ *                stage 1 was from the host BLAS on every flagged projection of the batch (counter [2]).
+ *   host_counts  optional: PINNED HOST int32[LSHRS_SIG_COUNTERS] the device can write (hipHostMalloc / torch
+ *                pin_memory): a launch behind stage 2 stores the counters there and leaves the device block zeroed
+ *                for the next call - the caller reads them after synchronising the stream ([1] > flag_cap: repeat
+ *                with room) without a copy or a fill of its own. */
 int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx,
                                           const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
-                                          uint8_t* keys, int32_t* tie_count, float tau, uint8_t* row_flags,
-                                          int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
-                                          int32_t blas_model, int32_t* host_counts, void* stream);
+                                          uint8_t* keys, int32_t* counters, float tau, uint8_t* row_flags,
+                                          int64_t* flag_list, float* flag_y, int32_t flag_cap, float tau1,
+                                          int32_t blas_model, int32_t* host_counts,
+                                          const lshrs_sig_opts* opts, void* stream);
 
 /* The tie-break on the device for the f32 kernel: behind lshrs_sig_hash_batch_f32 (same X, keys, tie_list, tie_count,
  * tau, same stream) it decides every reported tie by the host BLAS's value - the tie entries are unpacked into
  * flag_list (one item per flagged column; flag_count zeroed by the caller) and the stage-2 kernel of the split pass
  * re-evaluates them: the canonical chain (the f32 kernel's own value) for the tie test, the replayed BLAS order
- * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  host_counts (optional, pinned host int32[2])
- * receives (tie entries wanted, items expanded) and both device counters are zeroed; tie entries > tie_cap or items >
- * flag_cap: repeat the pass with room.  Needs dim % 32 == 0, 16-byte aligned rows and key rows of whole 32-bit words
- * (else LSHRS_E_TOOLARGE: resolve on the host). */
+ * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  counters: the int32[LSHRS_SIG_COUNTERS] block
+ * whose element [0] was the f32 kernel's tie_count; [1] receives the items expanded.  host_counts (optional, pinned
+ * host int32[LSHRS_SIG_COUNTERS]) receives the block, which is left zeroed; [0] > tie_cap or [1] > flag_cap: repeat
+ * the pass with room.  Needs dim % 32 == 0, 16-byte aligned rows and key rows of whole 32-bit words (else
+ * LSHRS_E_TOOLARGE: resolve on the host). */
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
                                        const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
-                                       uint8_t* keys, const int64_t* tie_list, int32_t tie_cap, int32_t* tie_count,
-                                       float tau, int64_t* flag_list, int32_t flag_cap, int32_t* flag_count,
+                                       uint8_t* keys, const int64_t* tie_list, int32_t tie_cap, int32_t* counters,
+                                       float tau, int64_t* flag_list, int32_t flag_cap,
                                        int32_t blas_model, int32_t* host_counts, void* stream);
 
 /* Diagnostic twin of the above: writes the raw projections instead of their sign bits.

@@ -115,7 +115,33 @@ def numpy_blas() -> Optional[Tuple[str, str, int, str]]:
     return None
 
 
-_order_models: Dict[Tuple[int, int], int] = {}
+_order_models: Dict[tuple, int] = {}
+_blas_probe: Optional[tuple] = None      # (path, getter function or None), found once per process
+
+
+def blas_signature() -> tuple:
+    """(library path, thread count) of the BLAS this process's NumPy calls, right now.  OpenBLAS picks its sgemv
+    micro-kernels per thread slice, so the summation order of ``P_band @ x`` may change when the thread count does
+    (threadpoolctl, ``openblas_set_num_threads``, a forked worker with another affinity): the order model is
+    licensed per signature and re-verified when it changes.  Costs one C call (~1 us)."""
+    global _blas_probe
+    if _blas_probe is None:
+        found = numpy_blas()
+        getter = None
+        if found is not None:
+            try:
+                handle = ctypes.CDLL(found[0])
+                for sym in ("scipy_openblas_get_num_threads64_", "openblas_get_num_threads64_", "openblas_get_num_threads"):
+                    if hasattr(handle, sym):
+                        getter = getattr(handle, sym)
+                        getter.restype = ctypes.c_int
+                        getter.argtypes = []
+                        break
+            except OSError:
+                getter = None
+        _blas_probe = (found[0] if found is not None else "", getter)
+    path, getter = _blas_probe
+    return (path, int(getter()) if getter is not None else -1, os.getpid())
 
 
 def blas_order_model(planes: np.ndarray) -> int:
@@ -123,9 +149,10 @@ def blas_order_model(planes: np.ndarray) -> int:
     NumPy returns for ``P_band @ x`` at this ``(rows_per_band, dim)`` - the licence for the GPU's tie replay
     (``lshrs_sig_hash_batch_split_replay_f32``) to stand in for the host engine.  Checked on random vectors, on vectors
     with a wide dynamic range and on vectors built to cancel against a hyperplane (where the order shows), for the
-    first, a middle and the last band, every row of each; cached per shape."""
+    first, a middle and the last band, every row of each; cached per (shape, BLAS library, BLAS thread count, process):
+    identity of the keys means identity with THIS process's BLAS as it is configured when the batch is hashed."""
     nb, r, dim = planes.shape
-    key = (r, dim)
+    key = (r, dim) + blas_signature()
     if key in _order_models:
         return _order_models[key]
     model = 0

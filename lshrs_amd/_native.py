@@ -20,7 +20,8 @@ SOURCE = os.path.join(CSRC, "lshrs_hip.hip")
 SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
 LIBRARY = os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-ABI_VERSION = 1
+ABI_VERSION = 2
+SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
 
 E_BADARG = -10001
 E_TOOLARGE = -10002
@@ -76,15 +77,21 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_sig_padded_columns.restype = i32
     lib.lshrs_sig_pack_projections.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.lshrs_sig_pack_projections.restype = c.c_int
-    lib.lshrs_sig_hash_batch_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp]
+    # (X, n, ldx, workspace, bands, rows, dim, keys, tie_list, tie_cap, tie_count, tau, row_flags, opts, stream)
+    lib.lshrs_sig_hash_batch_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp, vp]
     lib.lshrs_sig_hash_batch_f32.restype = c.c_int
+    # (... row_flags, flag_list, flag_cap, flag_count, tau1, opts, stream)
     lib.lshrs_sig_hash_batch_split_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp, i32, vp,
-                                                   f32, vp]
+                                                   f32, vp, vp]
     lib.lshrs_sig_hash_batch_split_f32.restype = c.c_int
-    lib.lshrs_sig_hash_batch_split_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, i32, vp, f32,
-                                                          i32, vp, vp]
+    # (X, n, ldx, workspace, bands, rows, dim, keys, counters, tau, row_flags, flag_list, flag_y, flag_cap, tau1,
+    #  blas_model, host_counts, opts, stream)
+    lib.lshrs_sig_hash_batch_split_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, i32, f32,
+                                                          i32, vp, vp, vp]
     lib.lshrs_sig_hash_batch_split_replay_f32.restype = c.c_int
-    lib.lshrs_sig_resolve_ties_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, i32, vp, i32, vp,
+    # (X, n, ldx, workspace, bands, rows, dim, keys, tie_list, tie_cap, counters, tau, flag_list, flag_cap, blas_model,
+    #  host_counts, stream)
+    lib.lshrs_sig_resolve_ties_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, i32, i32, vp,
                                                       vp]
     lib.lshrs_sig_resolve_ties_replay_f32.restype = c.c_int
     lib.lshrs_sig_project_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, i64, vp]
@@ -166,15 +173,25 @@ def load() -> ctypes.CDLL:
         got = lib.lshrs_abi_version()
         if got != ABI_VERSION:
             raise NativeLibraryError(f"{LIBRARY} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
-        # tuning knobs for A/B experiments (kernel variants are otherwise chosen inside the library)
-        for env, fn in (("LSHRS_SIG_PIPE", "lshrs_debug_set_sig_pipe"), ("LSHRS_SIG_WAVES", "lshrs_debug_set_sig_waves"),
-                        ("LSHRS_SIG_FINE", "lshrs_debug_set_sig_fine"), ("LSHRS_SPLIT_M", "lshrs_debug_set_split_m"),
-                        ("LSHRS_SPLIT_PIPE", "lshrs_debug_set_split_pipe"), ("LSHRS_FIX_MODE", "lshrs_debug_set_fix_mode")):
-            if os.environ.get(env) and hasattr(lib, fn):
-                if getattr(lib, fn)(int(os.environ[env])) != 0:
-                    raise NativeLibraryError(f"bad value for {env}")
         _lib = lib
         return lib
+
+
+class SigOpts(ctypes.Structure):
+    """``lshrs_sig_opts`` of include/lshrs_hip.h: optional per-call measurement hooks (events, clock probe)."""
+
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("ev_stage1_start", ctypes.c_void_p), ("ev_stage1_stop", ctypes.c_void_p),
+                ("ev_stage2_start", ctypes.c_void_p), ("ev_stage2_stop", ctypes.c_void_p),
+                ("clock_probe", ctypes.c_void_p)]
+
+    def __init__(self, events=None, clock_probe=None):
+        super().__init__()
+        self.struct_bytes = ctypes.sizeof(SigOpts)
+        if events is not None:
+            (self.ev_stage1_start, self.ev_stage1_stop, self.ev_stage2_start, self.ev_stage2_stop) = events
+        if clock_probe is not None:
+            self.clock_probe = clock_probe
 
 
 def check(code: int, what: str) -> None:

@@ -10,14 +10,6 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-// Attribution probes of the split-precision main loop (tools/split_probes.py builds one library per value and reads
-// the in-kernel cycle stamps; results are WRONG keys by design): 1 no fragment reads, 2 no bf16 split, 4 no DMA in the
-// loop, 8 no barrier, 16 no x read-back, 32 contiguous x addresses (PIPE 3), 64 no x pieces (PIPE 3),
-// 128 every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same registers (power/timing only).
-#ifndef LSHRS_SPLIT_PROBE
-#define LSHRS_SPLIT_PROBE 0
-#endif
-
 #include <stdint.h>
 #include <math.h>
 
@@ -41,19 +33,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int kKTile = 32;        // k per LDS tile; MFMA step s uses k = s (lanes 0-31) and 16+s (lanes 32-63)
 constexpr int kRowsPerWave = 32;  // one 32-row MFMA tile per wave
-// Waves per workgroup is a template parameter W: 4 (one wave per SIMD, two workgroups per CU, so the two
-// waves sharing a SIMD belong to different workgroups and never wait at the same barrier) or 8.
-int g_sig_waves = 4;              // tuning knobs for A/B runs (lshrs_debug_set_sig_*); not part of the ABI
-int g_sig_pipe = 1;               // 0: two whole-tile buffers, 1: ring of half-tiles with fragment prefetch
-unsigned long long* g_clock_probe = nullptr;  // diagnostics only (lshrs_debug_set_clock_probe)
-int g_split_m = 2;                // row tiles per wave of the split pass (lshrs_debug_set_split_m)
-int g_split_pipe = 7;             // 3: x in fragment-shaped pieces, 4: x in full 128-byte lines, 6 / 7: sig16_kernel<4,4> / <2,8> (lshrs_debug_set_split_pipe)
-hipEvent_t g_split_mid_event = nullptr;       // diagnostics only: recorded once between stage 1 and stage 2
-hipEvent_t g_split_time_events[4] = {nullptr, nullptr, nullptr, nullptr};   // measurement only: start/stop events that ride
-                                              // ON the dispatches of stage 1 and stage 2 (hipExtLaunchKernelGGL): kernel
-                                              // times without an extra packet in the stream; consumed by the next split call
-int g_sig_fine = 1;               // 0: never use the fine geometry, 1: automatic, 2: whenever it exists
-int g_fix_mode = 1;               // stage 2 of the split pass: 1 = eight flagged projections per wave, 0 = one (lshrs_debug_set_fix_mode)
+constexpr int kSigWaves = 4;            // waves per workgroup of the f32 kernel: one per SIMD, two workgroups per CU
 constexpr int kFragFloats = 64 * 4;  // one (column-tile, q) fragment block: 64 lanes x 4 floats = 1 KiB
 
 struct SigGeom {
@@ -97,11 +77,10 @@ inline int64_t sig_fine_floats(const SigGeom& g) {
   const SigGeom f = sig_fine_geom(g);
   return sig_image_floats(f) + sig_normmax_floats(f);
 }
-// Split-precision first pass (PIPE = 3): the same fragment image with every hyperplane entry as two bf16 values
-// (hi = bf16(p), mid = bf16(p - hi)) instead of one f32 — same byte size; wide geometry (NT = 8) only.
+// Split-precision first pass: the fragment image with every hyperplane entry as two bf16 values (hi = bf16(p),
+// mid = bf16(p - hi)) in 16x16x32 fragment order - same byte size as the f32 image; wide geometry (NT = 8) only.
 inline bool sig_has_split(const SigGeom& g) { return g.nt == 8; }
-inline int64_t sig_split_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
-inline int64_t sig_t16_offset_floats(const SigGeom& g) { return sig_split_offset_floats(g) + sig_image_floats(g); }
+inline int64_t sig_t16_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
 // "Narrow" hashers - 128 to 255 key columns, e.g. the reference's default num_perm = 128 - take the split pass too: on
 // a 16x16x32 fragment image padded with zero hyperplanes to the 256 columns sig16_kernel<2,8> works on (a zero
 // column gives y = +0: never flagged, bit 0, and its key bytes lie beyond row_bytes and are not stored).  Half the
@@ -110,7 +89,7 @@ inline bool sig_has_narrow_split(const SigGeom& g) { return g.nt < 8 && g.cb == 
 inline int64_t sig_narrow_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
 inline int64_t sig_narrow_image_floats(const SigGeom& g) { return (int64_t)g.ktiles * 8 * 4 * kFragFloats; }
 inline int64_t sig_workspace_floats(const SigGeom& g) {
-  return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? 2 * sig_image_floats(g) : 0) +
+  return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? sig_image_floats(g) : 0) +
          (sig_has_narrow_split(g) ? sig_narrow_image_floats(g) + 256 + 4 : 0);
 }
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
@@ -162,40 +141,6 @@ __device__ __forceinline__ uint16_t bf16_rne_bits(float f) {
   return (uint16_t)(u >> 16);
 }
 
-// bf16 hi/mid image: block (jt, 2*half + part) of k-tile kt holds, for lane (col c = lane & 31, h = lane >> 5), the 8
-// values part(P'[col][k = 32 kt + 16 half + 8 h + j]), j = 0..7 — one MFMA 32x32x16 B operand per lane.
-__global__ void pack_image_bf16_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb, int nt,
-                                       int ktiles, int64_t chunks, u16x8* __restrict__ image) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= chunks) return;
-  const int lane = (int)(c & 63);
-  const int part = (int)((c >> 6) & 1);
-  const int half = (int)((c >> 7) & 1);
-  int64_t t = c >> 8;
-  const int jt = (int)(t % nt);
-  t /= nt;
-  const int kt = (int)(t % ktiles);
-  const int cb = (int)(t / ktiles);
-  const int col = (cb * nt + jt) * 32 + (lane & 31);
-  const int band = col / (bb * 8);
-  const int bit = col % (bb * 8);
-  const int k0 = kt * kKTile + 16 * half + 8 * (lane >> 5);
-  u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (band < num_bands && bit < rows) {
-    const float* src = P + ((int64_t)band * rows + bit) * dim;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (k0 + j < dim) {
-        const float x = src[k0 + j];
-        const uint16_t hi = bf16_rne_bits(x);
-        const float hif = __uint_as_float((uint32_t)hi << 16);
-        v[j] = part == 0 ? hi : bf16_rne_bits(x - hif);
-      }
-    }
-  }
-  image[c] = v;
-}
-
 __global__ void pack_norm_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb, int cols,
                                  float* __restrict__ norms) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,6 +185,9 @@ struct SigArgs {
   int* tie_count;
   float tau;
   uint8_t* row_flags;
+  // stage 1 of the split pass (sig16_kernel): column blocks in the grid; optional stage-1 value per list entry
+  int ncb;
+  float* flag_y;
   // project mode
   float* Y;
   int64_t ldy;
@@ -247,58 +195,21 @@ struct SigArgs {
   unsigned long long* clock_probe;
 };
 
-template <bool ALIGNED>
-__device__ __forceinline__ void load_x_tile(const float* __restrict__ xrow, int kbase, int dim, f32x4 (&a)[4]) {
-  // lane (i, h) owns k = kbase + 4q + r, q,r in 0..3 (kbase already includes 16*h): 64 contiguous bytes
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int k = kbase + 4 * q;
-    if (ALIGNED) {
-      if (k < dim)
-        a[q] = *reinterpret_cast<const f32x4*>(xrow + k);
-      else
-        a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-      f32x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (k + r < dim) ? xrow[k + r] : 0.f;
-      a[q] = v;
-    }
-  }
-}
 
-template <int NT, int W>
-__device__ __forceinline__ void stage_p_tile(const float* __restrict__ tile, float* lds_buf, int tid) {
-  constexpr int kThreads = W * 64;
-  // NT*4 KiB, linear copy, 16 B per lane per instruction, straight into LDS (no VGPR round trip)
-  constexpr int kChunks = NT * 4 * 64;  // 16-byte chunks
-  const int wave = tid >> 6;
-#pragma unroll
-  for (int base = 0; base < kChunks; base += kThreads) {
-    if (base + wave * 64 < kChunks) {  // wave-uniform
-      const float* g = tile + (size_t)(base + tid) * 4;
-      float* l = lds_buf + (size_t)(base + wave * 64) * 4;  // wave-uniform base; hardware adds lane*16
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)l, 16, 0, 0);
-    }
-  }
-}
-
-// ---- ring-buffered main loop (PIPE = 1) -----------------------------------------------------------
-// Same arithmetic, same summation order as the plain loop; only the staging differs.  A 32-deep k-tile is
-// handled as two HALVES (fragments q = 0,1 then q = 2,3 of every column tile: MFMA steps s = 0..7 and 8..15).
-// Halves go through a ring of three LDS buffers, staged two halves ahead, and the fragments of the next
-// group are read while the current group's MFMAs issue, so no ds_read latency is exposed behind the
+// ---- ring-buffered main loop of the f32 kernel ----------------------------------------------------
+// A 32-deep k-tile is handled as two HALVES (fragments q = 0,1 then q = 2,3 of every column tile: MFMA steps
+// s = 0..7 and 8..15).  Halves go through a ring of three LDS buffers, staged two halves ahead, and the fragments of
+// the next group are read while the current group's MFMAs issue, so no ds_read latency is exposed behind the
 // barrier that ends each half.
-template <int NT, int W>
+template <int NT>
 __device__ __forceinline__ void stage_p_half(const float* __restrict__ tile, int part, float* lds_buf, int tid) {
-  constexpr int kThreads = W * 64;
   constexpr int kBlocks = NT * 2;  // (jt, qq) fragment blocks of 1 KiB in one half
   const int wave = tid >> 6;
   const int lane = tid & 63;
 #pragma unroll
-  for (int base = 0; base < kBlocks; base += kThreads / 64) {
+  for (int base = 0; base < kBlocks; base += kSigWaves) {
     const int blk = base + wave;  // wave-uniform
-    if (kBlocks % (kThreads / 64) == 0 || blk < kBlocks) {
+    if (kBlocks % kSigWaves == 0 || blk < kBlocks) {
       const int jt = blk >> 1, qq = blk & 1;
       const float* g = tile + (size_t)(((jt * 4 + 2 * part + qq) * 64) + lane) * 4;
       float* l = lds_buf + (size_t)blk * kFragFloats;  // wave-uniform base; hardware adds lane*16
@@ -334,56 +245,24 @@ __device__ __forceinline__ void read_frags(const float* lds_buf, int qq, int lan
     b[jt] = *reinterpret_cast<const f32x4*>(lds_buf + ((jt * 2 + qq) * 64 + lane) * 4);
 }
 
-// One fragment group: 4 k-steps x M row tiles x NT column tiles of MFMAs.  Every accumulator tile sees its
-// k-steps in the same order whatever M and NT are (the order oracle/chain_model.c restates).
-template <int NT, int M>
-__device__ __forceinline__ void mfma_group(const f32x4 (&a)[M], const f32x4 (&b)[NT], f32x16 (&acc)[M][NT],
-                                           float (&ss)[M], float (&amax)[M]) {
+// One fragment group: 4 k-steps x NT column tiles of MFMAs.  Every accumulator tile sees its k-steps in the same
+// order whatever NT is (the order oracle/chain_model.c restates).
+template <int NT>
+__device__ __forceinline__ void mfma_group(const f32x4& a, const f32x4 (&b)[NT], f32x16 (&acc)[NT], float& ss,
+                                           float& amax) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
+    const float av = a[r];
+    ss = __builtin_fmaf(av, av, ss);
+    amax = __builtin_fmaxf(amax, __builtin_fabsf(av));
 #pragma unroll
-    for (int mt = 0; mt < M; ++mt) {
-      const float av = a[mt][r];
-      ss[mt] = __builtin_fmaf(av, av, ss[mt]);
-      amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fabsf(av));
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-        acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[mt][jt], 0, 0, 0);
-    }
-  }
-}
-
-// ---- split-precision pass (PIPE = 3 / 4 of sig_kernel, sig16_kernel) --------------------------------------
-// y1 = sum_k (xh*ph + xh*pm + xm*ph) on the bf16 matrix cores (16x the f32 MFMA rate), x = xh + xm + ex split on the
-// fly, p pre-split in the image.  Each dropped term (xm*pm, ex*p, x*ep) is at most 2^-16 |x_k p_k|: 3 * 2^-16 * sum|x p|
-// <= 768 units of 2^-24 ||x|| ||p|| if every one of them were maximal and aligned against a cancelling sum; measured
-// over 2.7e9 projections the deviation from the f32 chain stays below 16 units (profiles/r01_split_window_margin.log).
-// Every projection with |y1| inside the stage-1 window (64 units by default) is re-evaluated by sig_fix_kernel as the
-// exact f32 fmaf chain, so the final bits equal the f32 kernel's.
-__device__ __forceinline__ void split_bf16(const f32x4& lo4, const f32x4& hi4, bf16x8& hi, bf16x8& mid) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = j < 4 ? lo4[j & 3] : hi4[j & 3];
-    const __bf16 h = (__bf16)v;             // v_cvt_pk_bf16_f32: round to nearest even
-    hi[j] = h;
-    mid[j] = (__bf16)(v - (float)h);        // v - h is exact in f32
+    for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[jt][r], acc[jt], 0, 0, 0);
   }
 }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// Stage-1 flag: NOT (|y| > bound) — also true for a NaN y, so a projection that overflowed in bf16 is re-evaluated.
-__device__ __forceinline__ void deposit_not_above(uint32_t& word, float y, float bound, int lane_lo, int lane_hi) {
-  asm("v_cmp_ngt_f32 vcc, |%1|, %2\n\t"
-      "s_nop 1\n\t"
-      "v_writelane_b32 %0, vcc_lo, %3\n\t"
-      "v_writelane_b32 %0, vcc_hi, %4"
-      : "+v"(word)
-      : "v"(y), "v"(bound), "n"(lane_lo), "n"(lane_hi)
-      : "vcc");
 }
 
 // Ballot + deposit in one block.  The 64-lane compare result (VCC: low half = the 32 columns of row rho,
@@ -411,26 +290,19 @@ __device__ __forceinline__ void deposit_abs_below(uint32_t& word, float y, float
       : "vcc");
 }
 
-// MODE 0: keys only, 1: keys + tie list, 2: raw projections (diagnostic)
-// W    waves per workgroup (4 or 8)
-// PIPE 0: two whole-tile LDS buffers; 1: ring of three half-tiles with fragment prefetch
-// M    32-row tiles per wave.  Shipped: M = 1 (128 accumulator registers, two waves per SIMD).  M = 2 (256
-//      accumulator registers, one wave per SIMD) builds and is bit-identical but measured 3 % slower on
-//      MI355X (profiles/r01_kernel_variants_ab.log), so it is not instantiated.
-template <int NT, bool ALIGNED, int MODE, int W, int PIPE, int M>
-__global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigArgs args) {
+// K1f: the exact-f32 signature pass.  MODE 0: keys only, 1: keys + tie list, 2: raw projections (diagnostic).
+// Workgroup = 4 waves (one per SIMD, two workgroups per CU: the two waves sharing a SIMD belong to different
+// workgroups and never wait at the same barrier); each wave owns one 32-row tile x all 32*NT columns of its column
+// block (128 accumulator registers at NT = 8).  Variants measured and dropped in round 1 (8-wave workgroups, two row
+// tiles per wave, whole-tile double buffering): profiles/r01_kernel_variants_ab.log.
+template <int NT, bool ALIGNED, int MODE>
+__global__ __launch_bounds__(kSigWaves * 64, 2) void sig_kernel(const SigArgs args) {
   constexpr bool PROJECT = MODE == 2;
   constexpr int kTileFloats = NT * 4 * kFragFloats;
   constexpr int kHalfFloats = NT * 2 * kFragFloats;
-  // LDS staging: PIPE 0 two whole tiles, PIPE 1 ring of three halves, PIPE 3 ring of four (fragment half + x half) stages
-  constexpr int kStageFloats = PIPE == 4 ? 3 * kHalfFloats + 3 * (W * M * kRowsPerWave * kKTile)
-                               : PIPE == 3 ? (M == 2 ? 4 : 3) * (kHalfFloats + W * M * 2 * kFragFloats)
-                                         : (PIPE != 0 ? 3 * kHalfFloats : 2 * kTileFloats);
-  constexpr int kWaveRows = kRowsPerWave * M;
-  constexpr int kBlockRows = W * kWaveRows;
-  static_assert(M == 1 || PIPE == 1 || PIPE == 3 || PIPE == 4, "two row tiles per wave are only built for the ring loops");
-  constexpr bool SPLIT = PIPE == 3 || PIPE == 4;
-  __shared__ __attribute__((aligned(16))) float lds[kStageFloats + W * kWaveRows];
+  constexpr int kStageFloats = 3 * kHalfFloats;          // ring of three halves
+  constexpr int kBlockRows = kSigWaves * kRowsPerWave;
+  __shared__ __attribute__((aligned(16))) float lds[kStageFloats + kBlockRows];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -438,28 +310,19 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   const int h = lane >> 5;
   const int i = lane & 31;
   const int cb = blockIdx.y;
-  const int64_t row0 = (int64_t)blockIdx.x * kBlockRows + wave * kWaveRows;
+  const int64_t row0 = (int64_t)blockIdx.x * kBlockRows + wave * kRowsPerWave;
   const int dim = args.dim;
   const int ktiles = args.ktiles;
   const float* __restrict__ img = args.image + (size_t)cb * ktiles * kTileFloats;
-  const float* __restrict__ xrow[M];
-#pragma unroll
-  for (int mt = 0; mt < M; ++mt) {
-    const int64_t r = row0 + mt * kRowsPerWave + i;
-    xrow[mt] = args.X + (r < args.n ? r : args.n - 1) * args.ldx;  // clamp: loads stay in bounds, stores are masked
-  }
+  const int64_t xr_ = row0 + i;
+  const float* __restrict__ xrow = args.X + (xr_ < args.n ? xr_ : args.n - 1) * args.ldx;  // clamp: loads stay in bounds, stores are masked
 
-  f32x16 acc[M][NT];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int mt = 0; mt < M; ++mt)
+  for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][jt][r] = 0.f;
-
-  float ss[M], amax[M];  // per row tile: sum of squares / max |x| of this lane's share of its row
-#pragma unroll
-  for (int mt = 0; mt < M; ++mt) { ss[mt] = 0.f; amax[mt] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+  float ss = 0.f, amax = 0.f;  // sum of squares / max |x| of this lane's share of its row
 
   unsigned long long t_shader = 0, t_real = 0;
   if (args.clock_probe != nullptr) {
@@ -467,297 +330,13 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     t_real = __builtin_amdgcn_s_memrealtime();
   }
 
-  if (PIPE == 3 || PIPE == 4) {
-    // One ring stage = one 16-deep half k-tile = one bf16 MFMA k-step: 16 KiB of hyperplane fragments (staged
-    // cooperatively) + 16 KiB of raw f32 x (each lane lands its OWN 2*M pieces of 16 bytes, and later reads them
-    // back from lane*16: LDS is only the landing zone).  Both travel by LDS-DMA, so no VGPR is ever the target of
-    // a pending load and the only vector-memory counter traffic is the 8 DMAs per thread and stage issued below:
-    // the waits are plain counted s_waitcnt vmcnt(16) and nothing is ever drained.  (X loads into registers need
-    // either compiler-tracked loads, which hipcc waits for with vmcnt(0), or asm outputs, which the register
-    // allocator is free to copy or reuse while the load is still in flight.)
-    // One wave per SIMD means nobody else hides memory latency: ring of FOUR stages, prefetch three ahead.
-    static_assert(!SPLIT || (ALIGNED && NT == 8 && W == 4), "the split pass is built for this geometry");
-    // M = 2: 256-row workgroups, one per CU (512 registers per lane), ring of four 32 KiB stages.
-    // M = 1: 128-row workgroups, two per CU (256 registers), ring of three 24 KiB stages: a second, independent
-    //        workgroup on every SIMD fills the other's barrier waits, VALU slices and epilogue with MFMAs.
-    // PIPE = 4 (FULL): x is staged in FULL 128-byte lines - one DMA piece = 8 rows x 128 B (one 32-deep k-tile of 8
-    // rows) instead of 32 rows x 2 half-line chunks; the texture path then touches 8 whole lines per piece, not 64
-    // sixteen-byte fragments of 32 lines (measured: 9 % of the main loop).  x tiles (32 deep) and fragment halves
-    // (16 deep) then live in separate rings of three: 3 x 32 KiB + 3 x 16 KiB = 144 KiB.  The landing image is
-    // XOR-swizzled per 8-lane row group so that the read-back (each lane: its row's two 16-byte chunks of the
-    // current half) is conflict-free for ds_read_b128's 16-lane groups.
-    constexpr bool FULL = PIPE == 4;
-    static_assert(!FULL || M == 2, "full-line x staging is built for two row tiles per wave");
-    constexpr int kXTile = W * M * kRowsPerWave * kKTile;      // floats of one x tile of the workgroup (FULL)
-    constexpr int kXWave = M * kRowsPerWave * kKTile;          // ... of one wave: 8 pieces of 1 KiB
-    constexpr int kRing = FULL ? 3 : (M == 2 ? 4 : 3);  // fragment stages in LDS; prefetch distance kRing - 1
-    constexpr int kDma = 4 + 2 * M;                // DMAs per thread and stage: 4 fragment blocks + 2*M x pieces
-    constexpr int kQuarter = 12 * M;               // MFMAs per quarter (4 column tiles x M row tiles x 3 terms)
-    constexpr int kXHalfFloats = W * M * 2 * kFragFloats;
-    constexpr int kStage = kHalfFloats + kXHalfFloats;
+  {
     const int halves = 2 * ktiles;
-    const int lasth = halves - 1;
-    // X addressing: uniform 64-bit base per workgroup + one 32-bit byte offset per lane and row tile.
-    // The host only takes this pass when dim % 32 == 0, so no piece reaches past its row.
-    const int64_t blk_row0 = (int64_t)blockIdx.x * kBlockRows;
-    const char* xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
-    unsigned xoff[M];
-#pragma unroll
-    for (int mt = 0; mt < M; ++mt) {
-      const int64_t r = row0 + mt * kRowsPerWave + i;
-      const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;   // clamp: loads stay in bounds, stores are masked
-      xoff[mt] = (unsigned)((rl * args.ldx + 8 * h) * 4);
-    }
-    // DMA addressing is loop-invariant per lane (32-bit offsets) on top of uniform bases, and the LDS targets are
-    // computed on the scalar unit: the whole issue block is 8 x (s_mov m0 + global_load_lds) and a few s_adds.
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    unsigned poff[4], xo[M][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int blk = 4 * q + wave_u;             // this wave stages fragment blocks wave, wave+4, wave+8, wave+12
-      poff[q] = (unsigned)((((blk >> 1) * 4 + (blk & 1)) * 64 + lane) * 16);
-    }
-#pragma unroll
-    for (int mt = 0; mt < M; ++mt) { xo[mt][0] = xoff[mt]; xo[mt][1] = xoff[mt] + 16u; }
-    if (LSHRS_SPLIT_PROBE & 32) {   // timing probe: fully coalesced x DMAs (wrong data)
-#pragma unroll
-      for (int mt = 0; mt < M; ++mt) { xo[mt][0] = lane * 16u + mt * 2048u; xo[mt][1] = lane * 16u + mt * 2048u + 1024u; }
-    }
-    // FULL: piece j (0..7) of a wave = rows 8j..8j+7 of its 64; lane l = (r = l>>3, q = l&7) fetches 16-byte chunk
-    // g = q ^ r ^ (j&1) of row 8j + r: an 8-lane group covers one whole 128-byte line (in permuted order).
-    unsigned xfo[8];                       // byte offset of this lane's chunk of piece j, relative to xblk + 128 * tile
-    unsigned xrd[M][2][2];                 // read-back byte offsets inside the wave's tile: [row tile][half][chunk]
-    if (FULL) {
-      const int r8 = lane >> 3, q8 = lane & 7;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int64_t r = row0 + 8 * j + r8;
-        const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;
-        xfo[j] = (unsigned)((rl * args.ldx + 4 * (q8 ^ r8 ^ (j & 1))) * 4);
-      }
-#pragma unroll
-      for (int mt = 0; mt < M; ++mt) {
-        const int R = kRowsPerWave * mt + i, j = R >> 3, r = R & 7;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-            xrd[mt][hf][c] = (unsigned)(j * 1024 + (r * 8 + ((4 * hf + 2 * h + c) ^ r ^ (j & 1))) * 16);
-      }
-    }
-    // FULL: the d-th (0..7) DMA a thread issues in stage hh: fragment blocks of half hh+2, then x pieces
-    // 4*(hh&1) .. +3 of tile (hh>>1)+2 (indices clamped at the end: loaded, never read)
-    struct FullDma {                       // everything uniform about one stage's 8 DMAs, computed once per stage
-      const char* pg;
-      const char* xg;
-      float* pdst;
-      float* xdst;
-      int j0;
-    };
-    auto full_plan = [&](int hh) {
-      FullDma f;
-      const int nh = hh + 2, c = nh < lasth ? nh : lasth;
-      const int nt = (hh >> 1) + 2, t = nt < ktiles ? nt : ktiles - 1;
-      f.pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
-      f.xg = xblk + (size_t)t * (kKTile * 4);
-      f.pdst = lds + (nh % 3) * kHalfFloats + wave_u * kFragFloats;
-      f.j0 = 4 * (hh & 1);
-      f.xdst = lds + 3 * kHalfFloats + (nt % 3) * kXTile + wave_u * kXWave + f.j0 * kFragFloats;
-      return f;
-    };
-    auto issue_full = [&](const FullDma& f, int d) {
-      if (d < 4)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + 4 * d * kFragFloats),
-                                         16, 0, 0);
-      else
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[4 + d - 4] : xfo[d - 4])),
-                                         (LDS_AS void*)(f.xdst + (d - 4) * kFragFloats), 16, 0, 0);   // (aux = 2, non-temporal, measured equal)
-    };
-    auto issue_half = [&](int hh) {       // exactly 8 DMAs per thread: 4 fragment blocks + 2*M x pieces of half min(hh, lasth)
-      const int c = hh < lasth ? hh : lasth;
-      float* st = lds + (hh % kRing) * kStage;
-      const char* pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + poff[q]),
-                                         (LDS_AS void*)(st + (4 * q + wave_u) * kFragFloats), 16, 0, 0);
-      float* xl = st + kHalfFloats + wave_u * (M * 2 * kFragFloats);
-      const char* xg = xblk + (size_t)c * 64;
-#pragma unroll
-      for (int mt = 0; mt < M; ++mt)
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc)
-          __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + xo[mt][pc]),
-                                           (LDS_AS void*)(xl + (mt * 2 + pc) * kFragFloats), 16, 0, 0);
-    };
-    auto read_x = [&](int hh, f32x4 (&v)[2][M]) {
-      if (FULL) {
-        const char* xt = reinterpret_cast<const char*>(lds + 3 * kHalfFloats + ((hh >> 1) % 3) * kXTile + wave_u * kXWave);
-#pragma unroll
-        for (int mt = 0; mt < M; ++mt)
-#pragma unroll
-          for (int pc = 0; pc < 2; ++pc) v[pc][mt] = *reinterpret_cast<const f32x4*>(xt + xrd[mt][hh & 1][pc]);
-        return;
-      }
-      const float* xl = lds + (hh % kRing) * kStage + kHalfFloats + wave_u * (M * 2 * kFragFloats) + lane * 4;
-#pragma unroll
-      for (int mt = 0; mt < M; ++mt)
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) v[pc][mt] = *reinterpret_cast<const f32x4*>(xl + (mt * 2 + pc) * kFragFloats);
-    };
-    // The split of one stage's x (2*M pieces of 4 floats per lane) is cut into 8 pair-slices of three steps each,
-    // so that it can be dealt out one step per MFMA (see stage()).
-    // ss: sum of squares of the bf16 HIGH parts (v_dot2c_f32_bf16, 2 products per instruction): within 0.8 % of
-    // ||x||^2, which only sizes the stage-1 window (the epilogue widens it by 1 %).  amax: exact max |x|.
-    struct Bf16Pairs { bf16x2 p[4]; };
-    float r0 = 0.f, r1 = 0.f;             // residuals of the pair in flight
-    auto split_step = [&](int g, int step, const f32x4 (&v)[2][M], Bf16Pairs (&hi)[M], Bf16Pairs (&mid)[M]) {
-      const int mt = g >> 2, pr = g & 3, pc = pr >> 1, e = 2 * (pr & 1);
-      const float v0 = v[pc][mt][e], v1 = v[pc][mt][e + 1];
-      if (step == 0) {
-        const bf16x2 hp = bf16x2{(__bf16)v0, (__bf16)v1};       // v_cvt_pk_bf16_f32: round to nearest even
-        hi[mt].p[pr] = hp;
-        r0 = v0 - (float)hp[0];                                 // exact in f32
-        r1 = v1 - (float)hp[1];
-      } else if (step == 1) {
-        mid[mt].p[pr] = bf16x2{(__bf16)r0, (__bf16)r1};
-      } else {
-        ss[mt] = __builtin_amdgcn_fdot2_f32_bf16(hi[mt].p[pr], hi[mt].p[pr], ss[mt], false);
-        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax[mt]) : "v"(v0), "v"(v1));
-      }
-    };
-    // Fragments travel in QUARTERS (4 column tiles x {hi, mid} = 8 ds_read_b128 = 32 VGPRs).
-    auto read_quarter = [&](const float* half_base, int j0, f32x4 (&f)[4][2]) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f[j][0] = *reinterpret_cast<const f32x4*>(half_base + (((j0 + j) * 2 + 0) * 64 + lane) * 4);
-        f[j][1] = *reinterpret_cast<const f32x4*>(half_base + (((j0 + j) * 2 + 1) * 64 + lane) * 4);
-      }
-    };
-    // MFMA number k (0..23) of a quarter: column tile j0 + k/6, row tile (k/3)%2, term k%3 of xh*ph + xh*pm + xm*ph
-    auto mfma_one = [&](int j0, int k, const f32x4 (&f)[4][2], const Bf16Pairs (&hi)[M], const Bf16Pairs (&mid)[M]) {
-      const int j = k / (3 * M), mt = (k / 3) % M, term = k % 3;
-      const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[mt] : hi[mt]);
-      const bf16x8 bb = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
-      if (LSHRS_SPLIT_PROBE & 128) {   // power/timing probe: the same FLOPs as two 16x16x32 MFMAs (wrong math)
-        struct Q { f32x4 q[4]; };
-        Q c = __builtin_bit_cast(Q, acc[mt][j0 + j]);
-        const int s0 = (k & 1) * 2;
-        c.q[s0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, c.q[s0], 0, 0, 0);
-        c.q[s0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, c.q[s0 + 1], 0, 0, 0);
-        acc[mt][j0 + j] = __builtin_bit_cast(f32x16, c);
-        return;
-      }
-      acc[mt][j0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[mt][j0 + j], 0, 0, 0);
-    };
-    // Software pipeline over the stage barrier: every group of 24 MFMAs runs while the LDS reads of the NEXT group
-    // are in flight, and every lgkmcnt(0) is taken a whole group after the reads it covers were issued:
-    //   barrier(hh) | read A(hh) | MFMA B(hh-1) + split x(hh) | wait | read B(hh), x(hh+1) | MFMA A(hh) + DMA(hh+3) | wait
-    // (A/B = column tiles 0-3 / 4-7).  B(hh-1) sits in registers across the barrier, so the slot of stage hh-1 is
-    // free for DMA(hh+3) as soon as the barrier is passed.  x pieces are wave-private: reading x(hh+1) only needs
-    // this wave's own vmcnt, not the barrier.
-    // An MFMA holds the vector issue port for 8 of its 32 cycles, so up to ~24 cycles of other instructions ride in
-    // its shadow - but only if they are dealt out one small slice per MFMA: the order below is pinned slice by
-    // slice with sched_barrier (hipcc otherwise clumps them, and a clump hides only its first 24 cycles).
-    f32x4 xr[2][M];
-    f32x4 fa[4][2], fb[4][2];
-    Bf16Pairs ahx[M], amx[M], ahy[M], amy[M];   // bf16 x of the previous / current stage, ping-pong (no copies)
-    auto stage = [&](int hh, const bool first, const Bf16Pairs (&ahp)[M], const Bf16Pairs (&amp)[M],
-                     Bf16Pairs (&ahc)[M], Bf16Pairs (&amc)[M]) {
-      const float* st = FULL ? lds + (hh % 3) * kHalfFloats : lds + (hh % kRing) * kStage;
-      if (!(LSHRS_SPLIT_PROBE & 1)) read_quarter(st, 0, fa);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < kQuarter; ++k) {
-        if (!first) mfma_one(4, k, fb, ahp, amp);
-        if (!(LSHRS_SPLIT_PROBE & 2)) split_step(k / 3, k % 3, xr, ahc, amc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): A(hh), a whole group old
-      __builtin_amdgcn_sched_barrier(0);
-      // this wave's DMAs for stage hh+1 have landed.  Ring of four: the 8 of stage hh+2 may be pending.  FULL: the
-      // fragment blocks of half hh+1 were issued (first) in stage hh-1, the x pieces issued after them may be pending;
-      // every x piece is thereby forced to land two stages after its issue, a tile before it is read.
-      wait_vmcnt<FULL ? 4 : (kRing - 3) * kDma>();
-      if (!(LSHRS_SPLIT_PROBE & 1)) read_quarter(st, 4, fb);
-      if (!(LSHRS_SPLIT_PROBE & 16)) read_x(hh + 1, xr);
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        const FullDma plan = full_plan(hh);
-        const int nh = hh + kRing - 1;
-        const int c = nh < lasth ? nh : lasth;
-        float* nst = lds + (nh % kRing) * kStage;         // the slot of stage hh-1, which every wave has left
-        const char* pg = reinterpret_cast<const char*>(img) + (size_t)(c >> 1) * (kTileFloats * 4) + (c & 1) * 2048;
-        float* xl = nst + kHalfFloats + wave_u * (M * 2 * kFragFloats);
-        const char* xg = xblk + (size_t)c * 64;
-#pragma unroll
-        for (int k = 0; k < kQuarter; ++k) {
-          mfma_one(0, k, fa, ahc, amc);
-          if (!(LSHRS_SPLIT_PROBE & 4) && k % (kQuarter / kDma) == 0) {     // the kDma DMAs of stage hh+kRing-1, spread over the quarter
-            const int d = k / (kQuarter / kDma);
-            if (FULL)
-              issue_full(plan, d);
-            else if (d < 4)
-              __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + poff[d]),
-                                               (LDS_AS void*)(nst + (4 * d + wave_u) * kFragFloats), 16, 0, 0);
-            else if (!(LSHRS_SPLIT_PROBE & 64))
-              __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + xo[(d - 4) >> 1][(d - 4) & 1]),
-                                               (LDS_AS void*)(xl + (d - 4) * kFragFloats), 16, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);       // B(hh) and x(hh+1): a whole group old
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(LSHRS_SPLIT_PROBE & 8)) __builtin_amdgcn_s_barrier();             // everybody's stage hh+1 is in LDS, everybody holds B(hh) in registers
-    };
-    if (FULL) {
-      // fragments of halves 0 and 1, x tiles 0 and 1, in the order the steady state would have issued them:
-      // [P(0), X tile 0 (8 pieces)], [P(1), X tile 1 (8 pieces)]  (issue_full(hh, d) issues for hh+2 / tile (hh>>1)+2)
-      {
-        const FullDma a0 = full_plan(-4), a1 = full_plan(-3), b0 = full_plan(-2), b1 = full_plan(-1);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) issue_full(b0, d);                               // P(0)
-#pragma unroll
-        for (int d = 4; d < 8; ++d) { issue_full(a0, d); issue_full(a1, d); }        // x tile 0: pieces 0-3 and 4-7
-#pragma unroll
-        for (int d = 0; d < 4; ++d) issue_full(b1, d);                               // P(1)
-#pragma unroll
-        for (int d = 4; d < 8; ++d) { issue_full(b0, d); issue_full(b1, d); }        // x tile 1
-      }
-      wait_vmcnt<12>();                          // P(0) and x tile 0 have landed; P(1) and x tile 1 stay in flight
-    } else {
-#pragma unroll
-      for (int pre = 0; pre < kRing - 1; ++pre) issue_half(pre);
-      wait_vmcnt<(kRing - 2) * kDma>();          // stage 0 has landed, the later ones stay in flight
-    }
-    __builtin_amdgcn_s_barrier();
-    read_x(0, xr);
-    stage(0, true, ahx, amx, ahy, amy);
-    int hh = 1;
-    for (; hh + 1 < halves; hh += 2) {          // halves is even: an odd number of stages remains, pairs + one
-      stage(hh, false, ahy, amy, ahx, amx);
-      stage(hh + 1, false, ahx, amx, ahy, amy);
-    }
-    stage(hh, false, ahy, amy, ahx, amx);
-#pragma unroll
-    for (int k = 0; k < kQuarter; ++k) mfma_one(4, k, fb, ahx, amx);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped prefetches past the last stage must land before exit
-    __builtin_amdgcn_s_barrier();
-  } else if (PIPE == 1) {
-    const int halves = 2 * ktiles;
-    f32x4 a_cur[2][M], a_nxt[2][M];  // [qq][row tile]
+    f32x4 a_cur[2], a_nxt[2];
     f32x4 b0[NT], b1[NT];
-    stage_p_half<NT, W>(img, 0, lds, tid);
-    stage_p_half<NT, W>(img, 1, lds + kHalfFloats, tid);
-#pragma unroll
-    for (int mt = 0; mt < M; ++mt) {
-      f32x4 t[2];
-      load_x_half<ALIGNED>(xrow[mt], 16 * h, dim, t);
-      a_cur[0][mt] = t[0];
-      a_cur[1][mt] = t[1];
-    }
+    stage_p_half<NT>(img, 0, lds, tid);
+    stage_p_half<NT>(img, 1, lds + kHalfFloats, tid);
+    load_x_half<ALIGNED>(xrow, 16 * h, dim, a_cur);
     __syncthreads();
     read_frags<NT>(lds, 0, lane, b0);
     // land b0 before the loop, so that on every path into the loop header nothing is pending and the
@@ -767,23 +346,15 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
     for (int hh = 0; hh < halves; ++hh) {
       const float* cur = lds + (hh % 3) * kHalfFloats;
       if (hh + 2 < halves)
-        stage_p_half<NT, W>(img + (size_t)((hh + 2) >> 1) * kTileFloats, (hh + 2) & 1, lds + ((hh + 2) % 3) * kHalfFloats,
-                            tid);
-      if (hh + 1 < halves) {
-#pragma unroll
-        for (int mt = 0; mt < M; ++mt) {
-          f32x4 t[2];
-          load_x_half<ALIGNED>(xrow[mt], ((hh + 1) >> 1) * kKTile + 16 * h + 8 * ((hh + 1) & 1), dim, t);
-          a_nxt[0][mt] = t[0];
-          a_nxt[1][mt] = t[1];
-        }
-      }
+        stage_p_half<NT>(img + (size_t)((hh + 2) >> 1) * kTileFloats, (hh + 2) & 1, lds + ((hh + 2) % 3) * kHalfFloats, tid);
+      if (hh + 1 < halves)
+        load_x_half<ALIGNED>(xrow, ((hh + 1) >> 1) * kKTile + 16 * h + 8 * ((hh + 1) & 1), dim, a_nxt);
       // Issue order is pinned (sched_barrier): left alone, the scheduler sinks each ds_read group down to its
       // first use and the wave then sits out the LDS latency with the matrix pipe idle.
       read_frags<NT>(cur, 1, lane, b1);                       // lands while group 0 issues
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT, M>(a_cur[0], b0, acc, ss, amax);
-      // b1 was issued a whole group (32*M MFMAs) ago: this wait is free, and taking it BEFORE the next reads are
+      mfma_group<NT>(a_cur[0], b0, acc, ss, amax);
+      // b1 was issued a whole group (32 MFMAs) ago: this wait is free, and taking it BEFORE the next reads are
       // issued keeps it from turning into a drain of those reads (hipcc emits lgkmcnt(0), not a counted wait)
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -792,52 +363,11 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
       // half this reads a stale ring slot that nobody uses, which keeps the wait counters branch-free.
       read_frags<NT>(lds + ((hh + 1) % 3) * kHalfFloats, 0, lane, b0);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_group<NT, M>(a_cur[1], b1, acc, ss, amax);
+      mfma_group<NT>(a_cur[1], b1, acc, ss, amax);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
-#pragma unroll
-      for (int mt = 0; mt < M; ++mt) {
-        a_cur[0][mt] = a_nxt[0][mt];
-        a_cur[1][mt] = a_nxt[1][mt];
-      }
-    }
-  } else {
-    f32x4 a_cur[4][M], a_nxt[4][M];
-    stage_p_tile<NT, W>(img, lds, tid);
-#pragma unroll
-    for (int mt = 0; mt < M; ++mt) {
-      f32x4 t[4];
-      load_x_tile<ALIGNED>(xrow[mt], 16 * h, dim, t);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) a_cur[q][mt] = t[q];
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < ktiles; ++kt) {
-      const float* lb = lds + (kt & 1) * kTileFloats;
-      if (kt + 1 < ktiles) {
-        stage_p_tile<NT, W>(img + (size_t)(kt + 1) * kTileFloats, lds + ((kt + 1) & 1) * kTileFloats, tid);
-#pragma unroll
-        for (int mt = 0; mt < M; ++mt) {
-          f32x4 t[4];
-          load_x_tile<ALIGNED>(xrow[mt], (kt + 1) * kKTile + 16 * h, dim, t);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) a_nxt[q][mt] = t[q];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 b[NT];
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
-          b[jt] = *reinterpret_cast<const f32x4*>(lb + ((jt * 4 + q) * 64 + lane) * 4);
-        mfma_group<NT, M>(a_cur[q], b, acc, ss, amax);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int mt = 0; mt < M; ++mt) a_cur[q][mt] = a_nxt[q][mt];
+      a_cur[0] = a_nxt[0];
+      a_cur[1] = a_nxt[1];
     }
   }
 
@@ -850,34 +380,23 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   // accumulator map (32x32 tile): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   if (PROJECT) {
 #pragma unroll
-    for (int mt = 0; mt < M; ++mt)
+    for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + mt * kRowsPerWave + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (row < args.n) args.Y[row * args.ldy + (cb * NT + jt) * 32 + i] = acc[mt][jt][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < args.n) args.Y[row * args.ldy + (cb * NT + jt) * 32 + i] = acc[jt][r];
+      }
     return;
   }
 
   // ---- row statistics: ||x||, zero-vector flag ------------------------------------------
-  float* norm_lds = lds + kStageFloats + wave * kWaveRows;
-#pragma unroll
-  for (int mt = 0; mt < M; ++mt) {
-    float s2 = ss[mt] + __shfl_xor(ss[mt], 32);
-    const float am = __builtin_fmaxf(amax[mt], __shfl_xor(amax[mt], 32));
-    const int64_t myrow = row0 + mt * kRowsPerWave + i;
+  float* norm_lds = lds + kStageFloats + wave * kRowsPerWave;
+  {
+    const float s2 = ss + __shfl_xor(ss, 32);
+    const float am = __builtin_fmaxf(amax, __shfl_xor(amax, 32));
+    const int64_t myrow = row0 + i;
     if (h == 0) {
-      float window = sqrtf(s2) * args.tau;
-      if (SPLIT) {
-        // s2 came from the bf16 high parts (<= 0.8 % off): widen by 1 %.  A row whose largest |x| is outside
-        // [2^-60, 2^60] leaves the range in which x*x and the bf16 split neither underflow nor overflow: re-evaluate
-        // all of its projections (NOT(|y| > +inf) holds for every y).  A true zero row gives y = 0 in both passes.
-        window *= 1.01f;
-        if (am != 0.f && !(am >= 0x1p-60f && am <= 0x1p60f)) window = __builtin_inff();
-      }
-      norm_lds[mt * kRowsPerWave + i] = window;
+      norm_lds[i] = sqrtf(s2) * args.tau;
       if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
         const bool has_nan = s2 != s2;
         const bool zero = (am <= 1e-8f) && !has_nan;
@@ -891,120 +410,93 @@ __global__ __launch_bounds__(W * 64, M == 2 ? 1 : 2) void sig_kernel(const SigAr
   constexpr int WPL = NT >= 2 ? NT / 2 : 1;  // 32-bit words per lane
   constexpr bool want_ties = MODE == 1;
 
+  // ---- sign bits + tie bits of the 32-row tile, one ballot per accumulator register --------------
+  uint32_t kw[WPL], tw[WPL];
 #pragma unroll
-  for (int mt = 0; mt < M; ++mt) {
-    // ---- sign bits + tie bits of one 32-row tile, one ballot per accumulator register --------------
-    uint32_t kw[WPL], tw[WPL];
+  for (int w = 0; w < WPL; ++w) { kw[w] = 0u; tw[w] = 0u; }
+  f32x4 rn[4];
 #pragma unroll
-    for (int w = 0; w < WPL; ++w) { kw[w] = 0u; tw[w] = 0u; }
-    const float* nl = norm_lds + mt * kRowsPerWave;
-    f32x4 rn[4];
+  for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(norm_lds + 8 * g + 4 * h);
+  // wave-uniform screen for ties: |y| < (largest tau*||x|| of the tile's rows) * (largest ||p|| of the block)
+  float screen = 0.f;
+  if (want_ties) {
+    float m = __builtin_fmaxf(__builtin_fmaxf(rn[0][0], rn[0][1]), __builtin_fmaxf(rn[0][2], rn[0][3]));
 #pragma unroll
-    for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(nl + 8 * g + 4 * h);
-    // wave-uniform screen for ties: |y| < (largest tau*||x|| of the tile's rows) * (largest ||p|| of the block)
-    float screen = 0.f;
-    if (want_ties) {
-      float m = __builtin_fmaxf(__builtin_fmaxf(rn[0][0], rn[0][1]), __builtin_fmaxf(rn[0][2], rn[0][3]));
-#pragma unroll
-      for (int g = 1; g < 4; ++g)
-        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(rn[g][0], rn[g][1]), __builtin_fmaxf(rn[g][2], rn[g][3])));
-      m = __builtin_fmaxf(m, __shfl_xor(m, 32));  // lanes of one half hold 16 of the 32 rows
-      // NaN norms (a NaN in x) must not hide the finite rows next to them: fmaxf drops NaNs, so m is the
-      // largest finite norm; rows that are NaN produce NaN projections, which never tie.
-      screen = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))) * args.norm_max[cb];
-      if (SPLIT && !(screen > 0.f)) screen = -1.f;  // all-zero tile: nothing to re-evaluate (NOT(|y| > -1) is false)
-    }
+    for (int g = 1; g < 4; ++g)
+      m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(rn[g][0], rn[g][1]), __builtin_fmaxf(rn[g][2], rn[g][3])));
+    m = __builtin_fmaxf(m, __shfl_xor(m, 32));  // lanes of one half hold 16 of the 32 rows
+    // NaN norms (a NaN in x) must not hide the finite rows next to them: fmaxf drops NaNs, so m is the
+    // largest finite norm; rows that are NaN produce NaN projections, which never tie.
+    screen = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))) * args.norm_max[cb];
+  }
 
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-      uint64_t any = 0;
+  for (int jt = 0; jt < NT; ++jt) {
+    uint64_t any = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float y = acc[jt][r];
+      const int rho = (r & 3) + 8 * (r >> 2);
+      const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
+      const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
+      deposit_positive(kw[jt % WPL], y, l0, l1);   // bit = (y > 0): 0, -0 and NaN give 0 (lsh.py:204)
+      if (want_ties) any |= __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
+    }
+    if (any != 0) {  // wave-uniform, rare (a few % of column tiles): the exact per-element test
+      const float pn = args.norms[(cb * NT + jt) * 32 + i];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float y = acc[mt][jt][r];
+        const float thr = rn[r >> 2][r & 3] * pn;
+        // strict '<': thr == 0 (zero x, zero-padded column) never ties
         const int rho = (r & 3) + 8 * (r >> 2);
-        const int l0 = rho * LPR + jt / WPL;         // lane receiving the word of row rho
-        const int l1 = (rho + 4) * LPR + jt / WPL;   // lane receiving the word of row rho + 4
-        deposit_positive(kw[jt % WPL], y, l0, l1);   // bit = (y > 0): 0, -0 and NaN give 0 (lsh.py:204)
-        if (want_ties)
-          any |= SPLIT ? __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(y) > screen))
-                       : __builtin_amdgcn_ballot_w64(__builtin_fabsf(y) < screen);
-      }
-      if (any != 0) {  // wave-uniform, rare (a few % of column tiles): the exact per-element test
-        const float pn = args.norms[(cb * NT + jt) * 32 + i];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float thr = rn[r >> 2][r & 3] * pn;
-          // strict '<': thr == 0 (zero x, zero-padded column) never ties
-          const int rho = (r & 3) + 8 * (r >> 2);
-          if (SPLIT) {
-            thr = thr > 0.f ? thr : -1.f;  // zero row / zero-padded column: y is exactly 0 in both passes
-            deposit_not_above(tw[jt % WPL], acc[mt][jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
-          } else {
-            deposit_abs_below(tw[jt % WPL], acc[mt][jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
-          }
-        }
-      }
-    }
-
-    // ---- stores: lane L holds words [ (L % LPR) * WPL, +WPL ) of row L / LPR -----------------
-    const int orow = lane / LPR;
-    const int64_t grow = row0 + mt * kRowsPerWave + orow;
-    const bool lane_on = (NT >= 2 || lane < 32) && grow < args.n;
-    const int word0 = cb * NT + (lane % LPR) * WPL;  // first 32-column word this lane holds
-    const int byte0 = word0 * 4;
-    if (lane_on) {
-      uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
-      if (args.vec_store && byte0 + 4 * WPL <= args.row_bytes) {
-        if (WPL == 4) {
-          *reinterpret_cast<u32x4*>(dst) = u32x4{kw[0], kw[1 % WPL], kw[2 % WPL], kw[3 % WPL]};
-        } else if (WPL == 2) {
-          *reinterpret_cast<u32x2*>(dst) = u32x2{kw[0], kw[1 % WPL]};
-        } else {
-          *reinterpret_cast<uint32_t*>(dst) = kw[0];
-        }
-      } else {
-#pragma unroll
-        for (int w = 0; w < WPL; ++w)
-#pragma unroll
-          for (int bsel = 0; bsel < 4; ++bsel)
-            if (byte0 + 4 * w + bsel < args.row_bytes) dst[4 * w + bsel] = (uint8_t)(kw[w] >> (8 * bsel));
-      }
-      if (want_ties) {
-#pragma unroll
-        for (int w = 0; w < WPL; ++w) {
-          if (SPLIT) {
-            // stage 1: one list entry per flagged projection, (row << 21) | padded column, so that stage 2 can
-            // give every one of them a full thread
-            uint32_t m = tw[w];
-            while (m != 0u) {
-              const int bit = __builtin_ctz(m);
-              m &= m - 1u;
-              const int slot = atomicAdd(args.tie_count, 1);
-              if (slot < args.tie_cap) args.tie_list[slot] = (grow << 21) | (int64_t)((word0 + w) * 32 + bit);
-            }
-          } else if (tw[w] != 0u) {
-            const int slot = atomicAdd(args.tie_count, 1);
-            if (slot < args.tie_cap) {
-              args.tie_list[2 * (int64_t)slot] = (grow + args.row_base) * 65536 + (word0 + w);
-              args.tie_list[2 * (int64_t)slot + 1] = (int64_t)tw[w];
-            }
-          }
-        }
+        deposit_abs_below(tw[jt % WPL], acc[jt][r], thr, rho * LPR + jt / WPL, (rho + 4) * LPR + jt / WPL);
       }
     }
   }
-  if (SPLIT && args.clock_probe != nullptr && tid == 0) {   // diagnostics: whole-workgroup cycles incl. the epilogue
-    const unsigned long long slot = (unsigned long long)gridDim.y * gridDim.x + (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
-    args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
-    args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
+
+  // ---- stores: lane L holds words [ (L % LPR) * WPL, +WPL ) of row L / LPR -----------------
+  const int orow = lane / LPR;
+  const int64_t grow = row0 + orow;
+  const bool lane_on = (NT >= 2 || lane < 32) && grow < args.n;
+  const int word0 = cb * NT + (lane % LPR) * WPL;  // first 32-column word this lane holds
+  const int byte0 = word0 * 4;
+  if (lane_on) {
+    uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
+    if (args.vec_store && byte0 + 4 * WPL <= args.row_bytes) {
+      if (WPL == 4) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{kw[0], kw[1 % WPL], kw[2 % WPL], kw[3 % WPL]};
+      } else if (WPL == 2) {
+        *reinterpret_cast<u32x2*>(dst) = u32x2{kw[0], kw[1 % WPL]};
+      } else {
+        *reinterpret_cast<uint32_t*>(dst) = kw[0];
+      }
+    } else {
+#pragma unroll
+      for (int w = 0; w < WPL; ++w)
+#pragma unroll
+        for (int bsel = 0; bsel < 4; ++bsel)
+          if (byte0 + 4 * w + bsel < args.row_bytes) dst[4 * w + bsel] = (uint8_t)(kw[w] >> (8 * bsel));
+    }
+    if (want_ties) {
+#pragma unroll
+      for (int w = 0; w < WPL; ++w) {
+        if (tw[w] != 0u) {
+          const int slot = atomicAdd(args.tie_count, 1);
+          if (slot < args.tie_cap) {
+            args.tie_list[2 * (int64_t)slot] = (grow + args.row_base) * 65536 + (word0 + w);
+            args.tie_list[2 * (int64_t)slot + 1] = (int64_t)tw[w];
+          }
+        }
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// Stage 2 of the split-precision pass: one thread per flagged (row, padded column).  Re-evaluates the
-// projection as the canonical f32 fmaf chain (the order of the f32 MFMA kernel and of oracle/chain_model.c:
+// Stage 2 of the split-precision pass, for every flagged (row, padded column).  Without the replay it re-evaluates
+// the projection as the canonical f32 fmaf chain (the order of the f32 MFMA kernel and of oracle/chain_model.c:
 // per 32-deep k-tile, step s multiplies k = 32t+s then k = 32t+16+s), corrects the key bit if stage 1 had it
-// wrong, and reports the projection as a tie when |y| < tau * ||x|| * ||p||.
+// wrong, and reports the projection as a tie when |y| < tau * ||x|| * ||p||; with it, see sig_fix8_kernel.
 // ------------------------------------------------------------------------------------------
 struct FixArgs {
   const float* X;
@@ -1026,6 +518,9 @@ struct FixArgs {
   int* tie_count;
   float tau;
   int blas_model;         // sig_fix8_kernel<true>: which host-BLAS summation order the tie replay follows (1: see there)
+  const float* flag_y;    // optional: stage-1 value of every list entry (sig16_kernel stores it beside the entry)
+  int* stat_dev;          // optional: max over the flagged projections of |y1 - y_BLAS| in units of 2^-24 ||x|| ||p|| (float bits)
+  int* stat_flips;        // optional: flagged projections whose stage-1 sign differed from the host BLAS's
 };
 
 __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f32x4 (&x4)[2][4], float& acc, float& ss) {
@@ -1039,99 +534,7 @@ __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f3
   }
 }
 
-// Stage 2 of the split-precision pass: the exact f32 chain for every flagged projection.  One WAVE per projection:
-// the 64 lanes fetch the row of x (coalesced) and the column of the f32 hyperplane image (one 16-byte fragment
-// chunk per lane and load) into LDS together, then every lane runs the same serial chain from broadcast LDS reads
-// (the chain cannot be split across lanes: its rounding is the canonical k order).  A thread per projection
-// instead walks 12 latency-bound batches of fully divergent loads (53 us per 260k-row chunk; this: ~10 us).
-// The grid is a fixed number of workgroups that stride over the list (its length is only known on the device).
-constexpr int kFixSlabTiles = 32;   // k-tiles staged per pass: 1024 k = 8 KiB of LDS per wave
-constexpr int kFixGrid = 5120;      // 256 CUs x 20 resident single-wave workgroups (8 KiB of LDS each)
-__global__ __launch_bounds__(64) void sig_fix_kernel(const FixArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[kFixSlabTiles * kKTile];
-  __shared__ __attribute__((aligned(16))) float ps[kFixSlabTiles * kKTile];
-  const int lane = threadIdx.x;
-  const int cnt = min(*a.flag_count, a.flag_cap);
-  const size_t kt_stride = (size_t)a.nt * 4 * kFragFloats;
-  for (int64_t e = blockIdx.x; e < cnt; e += gridDim.x) {   // uniform per wave: every wave reaches the end
-    const int64_t item = a.flag_list[e];
-    const int64_t row = item >> 21;                 // relative to this launch's X / keys
-    const int col = (int)(item & ((1 << 21) - 1));
-    if (col >= a.padcols) continue;
-    const int word = col >> 5, c = col & 31;
-    const float* __restrict__ x = a.X + row * a.ldx;
-    const int cb = word / a.nt, jt = word % a.nt;
-    const float* __restrict__ img = a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats;
-    float acc = 0.f, ss = 0.f;
-    for (int t0 = 0; t0 < a.ktiles; t0 += kFixSlabTiles) {
-      const int tiles = a.ktiles - t0 < kFixSlabTiles ? a.ktiles - t0 : kFixSlabTiles;
-      // Fixed trip counts, unconditional loads from clamped addresses: all of a slab's loads are in flight together
-      // (a loop of unknown length waits for every load before issuing the next one).
-      const int live = tiles * kKTile;
-      float xv[kFixSlabTiles * kKTile / 64];
-      f32x4 pv[kFixSlabTiles * 8 / 64];
-#pragma unroll
-      for (int m = 0; m < kFixSlabTiles * kKTile / 64; ++m) {     // x: 256 contiguous bytes per instruction
-        const int kk = lane + 64 * m, k = t0 * kKTile + kk;
-        xv[m] = x[(kk < live && k < a.dim) ? k : 0];
-      }
-#pragma unroll
-      for (int m = 0; m < kFixSlabTiles * 8 / 64; ++m) {          // p: fragment chunk j = (tile, half, quad)
-        const int j = lane + 64 * m;
-        const int t = j < tiles * 8 ? (j >> 3) : 0, hh = (j >> 2) & 1, q = j & 3;
-        pv[m] = *reinterpret_cast<const f32x4*>(img + (size_t)(t0 + t) * kt_stride + ((q * 64) + hh * 32 + c) * 4);
-      }
-#pragma unroll
-      for (int m = 0; m < kFixSlabTiles * kKTile / 64; ++m) {
-        const int kk = lane + 64 * m, k = t0 * kKTile + kk;
-        if (kk < live) xs[kk] = k < a.dim ? xv[m] : 0.f;
-      }
-#pragma unroll
-      for (int m = 0; m < kFixSlabTiles * 8 / 64; ++m) {
-        const int j = lane + 64 * m;
-        if (j < tiles * 8) *reinterpret_cast<f32x4*>(&ps[(j >> 3) * kKTile + 16 * ((j >> 2) & 1) + 4 * (j & 3)]) = pv[m];
-      }
-      __syncthreads();
-#pragma unroll 2
-      for (int t = 0; t < tiles; ++t) {
-        f32x4 p4[2][4], x4[2][4];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            x4[hh][q] = *reinterpret_cast<const f32x4*>(&xs[t * kKTile + 16 * hh + 4 * q]);
-            p4[hh][q] = *reinterpret_cast<const f32x4*>(&ps[t * kKTile + 16 * hh + 4 * q]);
-          }
-        fix_chain_tile(p4, x4, acc, ss);
-      }
-      __syncthreads();
-    }
-    if (lane != 0) continue;
-  // key bit
-  uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
-  const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
-  unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
-  const unsigned int bitmask = 1u << (8 * (unsigned)(addr & 3) + (col & 7));
-  const bool want = acc > 0.f;
-  const bool have = (*kb >> (col & 7)) & 1;
-  if (want != have) {
-    if (want) atomicOr(w32, bitmask);
-    else atomicAnd(w32, ~bitmask);
-  }
-  if (a.tie_list != nullptr) {
-    const float thr = a.tau * sqrtf(ss) * a.norms[col];
-    if (__builtin_fabsf(acc) < thr) {
-      const int slot = atomicAdd(a.tie_count, 1);
-      if (slot < a.tie_cap) {
-        a.tie_list[2 * (int64_t)slot] = (row + a.row_base) * 65536 + word;
-        a.tie_list[2 * (int64_t)slot + 1] = (int64_t)(1u << c);
-      }
-    }
-  }
-  }
-}
-
-// The same stage 2 with EIGHT flagged projections per wave (the default).  One wave per projection has all 64 lanes
+// EIGHT flagged projections per wave.  One wave per projection (the first version of this kernel) has all 64 lanes
 // issue the same 2 x dim dependent fmas: at ~5 700 flagged projections per 262 144-row chunk that is 5-6 waves per
 // SIMD x 6 k issue cycles, i.e. the kernel is bound by redundant VALU issue (measured 33 us per chunk).  Here lane
 // (sub, g) = (lane >> 3, lane & 7) works for projection g of the wave's group: the eight 16-byte chunks (sub) of a
@@ -1160,6 +563,10 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   const int cnt = min(*a.flag_count, a.flag_cap);
   const int groups = (cnt + kFixG - 1) / kFixG;
   const size_t kt_stride = (size_t)a.nt * 4 * kFragFloats;
+  // statistics are kept per lane and leave the wave once, at the end (one atomic per flagged projection on a single
+  // address serialises the whole kernel as soon as the list is long)
+  int n_ties = 0, n_flips = 0;
+  float max_dev = 0.f;
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {   // uniform per wave
     const int e = grp * kFixG + g;
     const int64_t item = a.flag_list[e < cnt ? e : grp * kFixG];  // a short last group re-does its first entry, unused
@@ -1229,12 +636,18 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
     const unsigned int bitmask = 1u << (8 * (unsigned)(addr & 3) + (col & 7));
     bool want = acc > 0.f;
+    const bool have = (*kb >> (col & 7)) & 1;
     if (REPLAY) {
       want = yb > 0.f;                             // (0, -0 and NaN give 0, as `projections > 0` does: lsh.py:204)
-      if (a.tie_count != nullptr && __builtin_fabsf(yb) < a.tau * sqrtf(ss) * a.norms[col])
-        atomicAdd(a.tie_count, 1);                 // statistics: projections inside the tie window
+      const float scale = sqrtf(ss) * a.norms[col];                        // ||x|| ||p||
+      if (__builtin_fabsf(yb) < a.tau * scale) ++n_ties;                   // statistics: projections inside the tie window
+      if (want != have) ++n_flips;
+      if (a.flag_y != nullptr && scale > 0.f) {
+        // the live margin of stage 1: how far its value was from the host BLAS's, in the units its window is given in
+        const float dev = __builtin_fabsf(a.flag_y[e] - yb) / (scale * 0x1p-24f);
+        if (dev < __builtin_inff()) max_dev = __builtin_fmaxf(max_dev, dev);   // (NaN - a row flagged wholesale - drops out)
+      }
     }
-    const bool have = (*kb >> (col & 7)) & 1;
     if (want != have) {
       if (want) atomicOr(w32, bitmask);
       else atomicAnd(w32, ~bitmask);
@@ -1248,6 +661,19 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
           a.tie_list[2 * (int64_t)slot + 1] = (int64_t)(1u << c);
         }
       }
+    }
+  }
+  if (REPLAY) {
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {        // the results sit in lanes 0..7 (sub = 0)
+      n_ties += __shfl_xor(n_ties, off);
+      n_flips += __shfl_xor(n_flips, off);
+      max_dev = __builtin_fmaxf(max_dev, __shfl_xor(max_dev, off));
+    }
+    if (lane == 0) {
+      if (a.tie_count != nullptr && n_ties != 0) atomicAdd(a.tie_count, n_ties);
+      if (a.stat_flips != nullptr && n_flips != 0) atomicAdd(a.stat_flips, n_flips);
+      if (a.stat_dev != nullptr && max_dev > 0.f) atomicMax(a.stat_dev, __float_as_int(max_dev));
     }
   }
 }
@@ -1275,29 +701,25 @@ __global__ void expand_ties_kernel(const int64_t* __restrict__ tie_list, const i
   }
 }
 
-// Hands the two counters of a replay pass to the host (pinned memory) and leaves them zeroed for the next call: one
-// single-thread launch behind stage 2 instead of a copy and a fill.  (Doing it in stage 2 itself, by whichever
-// workgroup finishes last, costs 1 536 contended atomics on one ticket: 58 us.)
-__global__ void export_counts_kernel(int* tie_count, int* flag_count, int* host_counts) {
-  host_counts[0] = tie_count != nullptr ? *tie_count : 0;
-  host_counts[1] = *flag_count;
-  if (tie_count != nullptr) *tie_count = 0;
-  *flag_count = 0;
+// Hands the counters of a replay pass (LSHRS_SIG_COUNTERS int32: ties, flagged, max deviation, sign flips, ...) to the
+// host (pinned memory) and leaves them zeroed for the next call: one launch behind stage 2 instead of a copy and a
+// fill.  (Doing it in stage 2 itself, by whichever workgroup finishes last, costs 1 536 contended atomics on one
+// ticket: 58 us.)
+__global__ void export_counts_kernel(int* counters, int* host_counts) {
+  const int i = threadIdx.x;
+  if (i < LSHRS_SIG_COUNTERS) {
+    host_counts[i] = counters[i];
+    counters[i] = 0;
+  }
 }
 
-template <int NT, int W>
-int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
+template <int NT>
+int launch_sig(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
   const int mode = project ? 2 : (a.tie_list != nullptr ? 1 : 0);
-  const int block_rows = W * kRowsPerWave;
+  constexpr int block_rows = kSigWaves * kRowsPerWave;
   const dim3 grid((unsigned)((a.n + block_rows - 1) / block_rows), (unsigned)g.cb, 1);
-  const dim3 block(W * 64, 1, 1);
-#define LSHRS_LAUNCH(AL, MD)                                                                    \
-  do {                                                                                          \
-    if (g_sig_pipe != 0)                                                                        \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 1, 1>), grid, block, 0, s, a);             \
-    else                                                                                        \
-      hipLaunchKernelGGL((sig_kernel<NT, AL, MD, W, 0, 1>), grid, block, 0, s, a);             \
-  } while (0)
+  const dim3 block(kSigWaves * 64, 1, 1);
+#define LSHRS_LAUNCH(AL, MD) hipLaunchKernelGGL((sig_kernel<NT, AL, MD>), grid, block, 0, s, a)
   if (aligned) {
     if (mode == 0) LSHRS_LAUNCH(true, 0);
     else if (mode == 1) LSHRS_LAUNCH(true, 1);
@@ -1309,12 +731,6 @@ int launch_sig_w(const SigArgs& a, const SigGeom& g, bool aligned, bool project,
   }
 #undef LSHRS_LAUNCH
   return -(int)hipGetLastError();
-}
-
-template <int NT>
-int launch_sig(const SigArgs& a, const SigGeom& g, bool aligned, bool project, hipStream_t s) {
-  return g_sig_waves == 8 ? launch_sig_w<NT, 8>(a, g, aligned, project, s)
-                          : launch_sig_w<NT, 4>(a, g, aligned, project, s);
 }
 
 int dispatch_sig(const SigArgs& a, const SigGeom& g, bool project, hipStream_t s) {
@@ -1419,21 +835,17 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
   image[c] = v;
 }
 
-// RT = 16-row tiles per wave, W = waves per workgroup (RT * W = 16: 256 rows per workgroup either way).
-//   <4, 4>: 64 rows per wave, 256 accumulator AGPRs, one wave per SIMD.
-//   <2, 8>: 32 rows per wave, 128 accumulator AGPRs, at most 256 registers -> TWO waves per SIMD that share one
-//           fragment stage: each can issue MFMAs while the other sits in a DMA issue, a barrier or its VALU slices.
-//   PERSIST (lshrs_debug_set_split_pipe(8); NOT the default): the workgroup walks row tiles blockIdx.x, + gridDim.x,
-//           ... (grid = one workgroup per CU): the first fragments and x tiles of the NEXT row tile are requested
-//           before the epilogue of the current one, so the DMA round trip of the prologue hides behind the sign-bit
-//           extraction, and a workgroup is launched once per CU instead of once per 256 rows.  Measured: the kernel
-//           itself 1.3 % faster (1.080 vs 1.095 ms per 1M x 768), the bit-exact step 10 % SLOWER (1.60 vs 1.44 ms):
-//           no workgroup retires before the kernel ends, so the side-stream kernels of the pipeline (export of the
-//           ties, patch scatter) get no CU for a whole chunk and the host falls a chunk behind.  (Also tried on the
-//           default kernel: s_setprio 1 around the MFMA groups of the two waves sharing a SIMD - no change.)
-template <int RT, int W, bool PERSIST = false>
-__global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
-  static_assert(RT * W == 16 && (RT == 4 || RT == 2), "256 rows per workgroup");
+// Stage 1 of the split-precision pass.  RT = 2 sixteen-row tiles per wave, W = 8 waves per workgroup (256 rows):
+// 32 rows per wave, 128 accumulator AGPRs, at most 256 registers -> TWO waves per SIMD that share one fragment stage:
+// each can issue MFMAs while the other sits in a DMA issue, a barrier or its VALU slices.  (Measured and dropped in
+// round 1: 64 rows per wave / one wave per SIMD, a persistent variant, the 32x32x16 MFMA shape - DESIGN.md §5.)
+// Grid: one dimension, blockIdx.x -> (row tile, column block) with the column blocks of one row tile eight workgroup
+// ids apart: workgroups are dealt round-robin over the 8 XCDs, so the `cb` passes over the same 256 rows run on the
+// SAME XCD at about the same time and the second one reads x from that XCD's L2 instead of HBM (config 5: 512 key
+// columns = two column blocks).
+constexpr int kS1ListCap = 8192;   // flagged projections a workgroup stages in LDS before its ONE global append
+__global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
+  constexpr int RT = 2, W = 8;
   constexpr int kWaveRows = 16 * RT;
   constexpr int kPP = 16 / W;                     // fragment pieces a wave stages per stage
   constexpr int kXPS = RT;                        // x pieces a wave stages per stage (2 RT per k-tile)
@@ -1443,31 +855,35 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
   constexpr int kXTile = 256 * kKTile;            // floats of one x tile of the workgroup
   constexpr int kXWave = kWaveRows * kKTile;
   constexpr int kRingFloats = 3 * kPHalf + 3 * kXTile;
-  __shared__ __attribute__((aligned(16))) float lds[kRingFloats + 256];
+  static_assert(3 * kS1ListCap <= kRingFloats, "the epilogue's list stage reuses the ring");
+  __shared__ __attribute__((aligned(16))) float lds[kRingFloats + 256 + 4];
   struct Bf16Pairs { bf16x2 p[4]; };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
-  const int cb = blockIdx.y;
+  // blockIdx.x = ((group * ncb + cb) * 8 + xcd slot): row tile = group * 8 + slot
+  const int ncb = args.ncb;
+  const int bid = blockIdx.x;
+  const int cb = (bid >> 3) % ncb;
+  const int row_tile = ((bid >> 3) / ncb) * 8 + (bid & 7);
+  if ((int64_t)row_tile * 256 >= args.n) return;     // (whole workgroup: the grid is padded to a multiple of 8 row tiles)
   const int ktiles = args.ktiles;
   const int stages = 2 * ktiles, lasts = stages - 1;
   const char* img = reinterpret_cast<const char*>(args.image) + (size_t)cb * ktiles * 32768;
-  const int row_tiles = (int)((args.n + 255) / 256);
-  int row_tile = blockIdx.x;                 // PERSIST: advanced by gridDim.x per pass of the tile loop below
-  int64_t blk_row0, row0;
-  const char* xblk;
+  const int64_t blk_row0 = (int64_t)row_tile * 256;
+  const int64_t row0 = blk_row0 + wave * kWaveRows;
+  const char* xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
 
-  // DMA offsets (see the PIPE = 4 path of sig_kernel for the x landing image and its swizzle); xfo depends on the row tile
+  // DMA offsets.  x is staged in FULL 128-byte lines: piece j (0..3) of a wave = rows 8j..8j+7 of its 32; lane
+  // l = (r = l>>3, q = l&7) fetches 16-byte chunk q ^ r ^ (j&1) of row 8j + r, so an 8-lane group covers one whole
+  // line (in permuted order) and the read-back (each lane: its row's two chunks of the k-tile quarter it feeds) is
+  // conflict-free for ds_read_b128's 16-lane groups.
   unsigned poff[kPP], xfo[2 * RT], xrd[RT][2];
 #pragma unroll
   for (int q = 0; q < kPP; ++q) poff[q] = (unsigned)(((W * q + wave) * 64 + lane) * 16);
-  auto enter_tile = [&](int rtile) {
-    rtile = __builtin_amdgcn_readfirstlane(rtile);   // wave-uniform: keep the tile's scalars on the scalar unit
-    blk_row0 = (int64_t)rtile * 256;
-    row0 = blk_row0 + wave * kWaveRows;
-    xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
+  {
     const int r8 = lane >> 3, q8 = lane & 7;
 #pragma unroll
     for (int j = 0; j < 2 * RT; ++j) {
@@ -1475,9 +891,6 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
       const int64_t rl = (r < args.n ? r : args.n - 1) - blk_row0;   // clamp: loads stay in bounds, stores are masked
       xfo[j] = (unsigned)((rl * args.ldx + 4 * (q8 ^ r8 ^ (j & 1))) * 4);
     }
-  };
-  enter_tile(row_tile);
-  {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int R = 16 * rt + r16, j = R >> 3, r = R & 7;       // this lane's row of row tile rt: chunks 2g, 2g+1
@@ -1501,7 +914,6 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { ss[rt] = 0.f; amax[rt] = 0.f; }
   };
-
   unsigned long long t_shader = 0, t_real = 0;
   if (args.clock_probe != nullptr) {
     t_shader = __builtin_amdgcn_s_memtime();
@@ -1639,9 +1051,7 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
-#if !(LSHRS_SPLIT_PROBE & 8)
     __builtin_amdgcn_s_barrier();
-#endif
   };
   // tile t with its sets (hc, mc); the previous tile's (hp, mp) double as the target of the next tile's split
   auto tile = [&](int t, const bool first, Bf16Pairs (&hc)[RT], Bf16Pairs (&mc)[RT], Bf16Pairs (&hp)[RT], Bf16Pairs (&mp)[RT]) {
@@ -1661,18 +1071,8 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     for (int d = kPP; d < kPP + kXPS; ++d) { issue(b0, d); issue(b1, d); }       // x tile 1
   };
   issue_prologue();
-  for (bool first_pass = true;; first_pass = false) {   // one pass per row tile (a single pass unless PERSIST)
   zero_tile_state();
-  if (PERSIST) {   // likewise opaque per pass: the fragment addresses of the prologue are the same for every row tile
-#pragma unroll
-    for (int q = 0; q < kPP; ++q) asm volatile("" : "+v"(poff[q]));
-  }
-  if (PERSIST && !first_pass)
-    // this tile's prologue was issued in front of the previous tile's epilogue, whose own stores and loads are
-    // younger than it in the vmcnt queue: drain (everything landed long ago)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else
-    wait_vmcnt<kPP + 2 * kXPS>();
+  wait_vmcnt<kPP + 2 * kXPS>();
   __builtin_amdgcn_s_barrier();
   read_x(0);
 #pragma unroll
@@ -1705,28 +1105,29 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
     for (int ct = 0; ct < 16; ++ct) asm volatile("" : "+a"(acc[rt][ct]));
 
-  if (args.clock_probe != nullptr && tid == 0 && first_pass) {
-    const unsigned long long slot = (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (args.clock_probe != nullptr && tid == 0) {
+    const unsigned long long slot = (unsigned long long)blockIdx.x;
     args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
     args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
   }
 
-  // The ring is free (every wave is past the barrier above, every prefetch has landed): request the next row
-  // tile's first stages now, so that they travel while this tile's sign bits are extracted.
-  const int64_t erow0 = row0;            // the epilogue below works on the tile just finished
-  const int next_tile = row_tile + (int)gridDim.x;
-  const bool more = PERSIST && next_tile < row_tiles;
-  if (more) {
-    enter_tile(next_tile);
-    issue_prologue();
-  }
-
-  // (PERSIST) everything the epilogue derives from the lane index is invariant across row tiles; left alone, hipcc
-  // hoists all of it - sixteen 64-bit column indices, key addresses - in front of the tile loop and spills it around
-  // the main loop.  These copies are opaque per pass.
+  // The ring is free (every wave is past the barrier above, every prefetch has landed): the epilogue stages the
+  // workgroup's flagged projections in it - list entries and their stage-1 values - and appends them to the global
+  // list with ONE atomic per workgroup.  (One atomic per flagged projection on the single global counter serialises:
+  // at a 870-unit window - 300 k flagged projections per 1M rows - it tripled the kernel's time.)
+  // Everything the epilogue derives from the lane index is loop-invariant: left alone, hipcc computes it in front of
+  // the main loop and carries (or spills) it across.  These copies are opaque: the epilogue's addressing starts here.
   int r16e = r16, ge = g, lanee = lane;
-  if (PERSIST) asm volatile("" : "+v"(r16e), "+v"(ge), "+v"(lanee));
-  // ---- row statistics -> stage-1 window per row (as in sig_kernel's split epilogue) -----------------------
+  asm volatile("" : "+v"(r16e), "+v"(ge), "+v"(lanee));
+  int64_t* l_list = reinterpret_cast<int64_t*>(lds);
+  float* l_y = lds + 2 * kS1ListCap;
+  int* l_count = reinterpret_cast<int*>(lds + kRingFloats + 256);   // [0] staged + overflowed entries, [1] global base
+  if (tid == 0) l_count[0] = 0;
+
+  // ---- row statistics -> stage-1 window per row -----------------------------------------------------------------
+  // s2 came from the bf16 high parts (<= 0.8 % off): widen by 1 %.  A row whose largest |x| is outside [2^-60, 2^60]
+  // leaves the range in which x*x and the bf16 split neither underflow nor overflow: all of its projections are
+  // re-evaluated (NOT(|y| > +inf) holds for every y).  A true zero row gives y = 0 in both passes.
   float* wnd_lds = lds + kRingFloats + wave * kWaveRows;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -1734,7 +1135,7 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     s2 += __shfl_xor(s2, 32);
     float am = __builtin_fmaxf(amax[rt], __shfl_xor(amax[rt], 16));
     am = __builtin_fmaxf(am, __shfl_xor(am, 32));
-    const int64_t myrow = erow0 + 16 * rt + r16e;
+    const int64_t myrow = row0 + 16 * rt + r16e;
     if (ge == 0) {
       float window = sqrtf(s2) * args.tau * 1.01f;
       if (am != 0.f && !(am >= 0x1p-60f && am <= 0x1p60f)) window = __builtin_inff();
@@ -1749,22 +1150,19 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
 
-  // ---- sign bits.  One v_cmp per accumulator register = 4 rows (ge') x 16 columns: its low 32 bits are rows ge' = 0, 1,
-  // its high 32 bits rows ge' = 2, 3 of the tile.  Per 32-row group, lanee L owns the ROW PAIR p = L / 4 = (rtl, ge'-pair,
-  // reg) - rows 16 rtl + 8 ge'pair + reg and + 4 - and the 32-column words 2 (L % 4), + 1: the ballot halves of the even
-  // column tile land in A[], of the odd one in B[] (deposit_positive: v_cmp, the two wait states a VALU-written SGPR
-  // needs, two v_writelane), and two VALU ops per word merge the 16-bit halves.  Same instruction count per
-  // accumulator register as the 32x32 epilogue.
+  // ---- sign bits.  One v_cmp per accumulator register = 4 rows (g') x 16 columns: its low 32 bits are rows g' = 0, 1,
+  // its high 32 bits rows g' = 2, 3 of the tile.  Lane L owns the ROW PAIR p = L / 4 = (rtl, g'-pair, reg) - rows
+  // 16 rtl + 8 g'pair + reg and + 4 - and the 32-column words 2 (L % 4), + 1: the ballot halves of the even column
+  // tile land in A[], of the odd one in B[] (deposit_positive: v_cmp, the two wait states a VALU-written SGPR needs,
+  // two v_writelane), and two VALU ops per word merge the 16-bit halves.
   const float nmax = args.norm_max[cb];
-#pragma unroll
-  for (int G = 0; G < RT / 2; ++G) {
+  {
     uint32_t A[2] = {0u, 0u}, B[2] = {0u, 0u};
 #pragma unroll
-    for (int rtl = 0; rtl < 2; ++rtl) {
-      const int rt = 2 * G + rtl;
-      const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * ge);   // rows 16 rt + 4 ge + 0..3
-      // wave-uniform-per-lanee screen: the largest window of this lanee's four rows (a non-finite window - NaN or Inf
-      // in the row, or a magnitude outside the guarded range - makes it +inf: everything goes to the exact test)
+    for (int rt = 0; rt < 2; ++rt) {
+      const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * ge);   // rows 16 rt + 4 g + 0..3
+      // per-lane screen: the largest window of this lane's four rows (a non-finite window - NaN or Inf in the row, or
+      // a magnitude outside the guarded range - makes it +inf: everything goes to the exact test)
       float tsmax = __builtin_fmaxf(__builtin_fmaxf(wnd[0], wnd[1]), __builtin_fmaxf(wnd[2], wnd[3]));
       if (!(wnd[0] < __builtin_inff()) || !(wnd[1] < __builtin_inff()) || !(wnd[2] < __builtin_inff()) ||
           !(wnd[3] < __builtin_inff()))
@@ -1778,12 +1176,12 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const float y0 = acc[rt][2 * w][reg], y1 = acc[rt][2 * w + 1][reg];
-          const int p0 = 8 * rtl + reg * 2;             // pair (rtl, reg, ge'pair = 0); ge'pair = 1 is p0 + 1
+          const int p0 = 8 * rt + reg * 2;              // pair (rt, reg, g'pair = 0); g'pair = 1 is p0 + 1
           deposit_positive(A[w & 1], y0, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
           deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
           asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));
         }
-        if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0) {   // wave-uniform, a few % of the cells: the exact per-element test
+        if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0) {   // wave-uniform: the exact per-element test
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int ct = 2 * w + half;
@@ -1792,17 +1190,31 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
             for (int reg = 0; reg < 4; ++reg) {
               float thr = wnd[reg] * pn;
               thr = thr > 0.f ? thr : -1.f;                               // zero row / zero-padded column: y is exactly 0
-              const int64_t grow = erow0 + 16 * rt + 4 * ge + reg;
-              if (!(__builtin_fabsf(acc[rt][ct][reg]) > thr) && grow < args.n) {
-                const int slot = atomicAdd(args.tie_count, 1);
-                if (slot < args.tie_cap) args.tie_list[slot] = (grow << 21) | (int64_t)(cb * 256 + 16 * ct + r16e);
+              const int64_t grow = row0 + 16 * rt + 4 * ge + reg;
+              const float yv = acc[rt][ct][reg];
+              if (!(__builtin_fabsf(yv) > thr) && grow < args.n) {
+                const int64_t entry = (grow << 21) | (int64_t)(cb * 256 + 16 * ct + r16e);
+                // the stage-1 value travels with the entry: stage 2 measures |y1 - y_BLAS| on every flagged projection
+                // (rows flagged wholesale carry no usable y1: NaN, skipped by that statistic)
+                const float ykeep = wnd[reg] < __builtin_inff() ? yv : __builtin_nanf("");
+                const int pos = atomicAdd(l_count, 1);                    // LDS atomic
+                if (pos < kS1ListCap) {
+                  l_list[pos] = entry;
+                  l_y[pos] = ykeep;
+                } else {                                                  // LDS stage full (rows flagged wholesale): straight out
+                  const int slot = atomicAdd(args.tie_count, 1);
+                  if (slot < args.tie_cap) {
+                    args.tie_list[slot] = entry;
+                    if (args.flag_y != nullptr) args.flag_y[slot] = ykeep;
+                  }
+                }
               }
             }
           }
         }
       }
     }
-    // lanee L: pair p = L / 4 -> rows lo / lo + 4, words 2 (L % 4), + 1
+    // lane L: pair p = L / 4 -> rows lo / lo + 4, words 2 (L % 4), + 1
     const int pr = lanee >> 2, wq = 2 * (lanee & 3);
     const int rlo = 16 * (pr >> 3) + 8 * (pr & 1) + ((pr >> 1) & 3);
     const uint32_t wlo[2] = {(A[0] & 0xFFFFu) | (B[0] << 16), (A[1] & 0xFFFFu) | (B[1] << 16)};
@@ -1810,7 +1222,7 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
     const int byte0 = (cb * 8 + wq) * 4;
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
-      const int64_t grow = erow0 + 32 * G + rlo + 4 * hl;
+      const int64_t grow = row0 + rlo + 4 * hl;
       if (grow < args.n) {
         uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
         const uint32_t w0 = hl ? whi[0] : wlo[0], w1 = hl ? whi[1] : wlo[1];
@@ -1826,19 +1238,27 @@ __global__ __launch_bounds__(64 * W, 1) void sig16_kernel(const SigArgs args) {
       }
     }
   }
-  if (args.clock_probe != nullptr && tid == 0 && first_pass) {
-    const unsigned long long slot = (unsigned long long)gridDim.y * gridDim.x + (unsigned long long)blockIdx.y * gridDim.x + blockIdx.x;
+
+  // ---- the workgroup's flagged projections: one global append ------------------------------------------------------
+  __syncthreads();
+  const int staged = l_count[0] < kS1ListCap ? l_count[0] : kS1ListCap;
+  if (staged > 0) {                                     // (workgroup-uniform)
+    if (tid == 0) l_count[1] = atomicAdd(args.tie_count, staged);
+    __syncthreads();
+    const int base = l_count[1];
+    for (int e = tid; e < staged; e += 64 * W) {
+      const int slot = base + e;
+      if (slot < args.tie_cap) {
+        args.tie_list[slot] = l_list[e];
+        if (args.flag_y != nullptr) args.flag_y[slot] = l_y[e];
+      }
+    }
+  }
+  if (args.clock_probe != nullptr && tid == 0) {
+    const unsigned long long slot = (unsigned long long)gridDim.x + (unsigned long long)blockIdx.x;
     args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
     args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
   }
-  if (!more) break;
-  row_tile = next_tile;
-  // recomputed rather than kept: across the epilogue, the register-hungriest stretch of the kernel, nothing of the
-  // main loop's addressing stays live
-  enter_tile(row_tile);
-  // every wave must be done with this tile's window slots (wnd_lds) before the next pass overwrites them: the barrier
-  // at the top of the pass comes before any such write
-  }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2100,63 +1520,27 @@ inline int64_t topk_pad(int64_t c) {
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+namespace {
+struct Opts {            // the caller's lshrs_sig_opts, or all-null
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long* clock_probe = nullptr;
+};
+inline Opts read_opts(const lshrs_sig_opts* o) {
+  Opts r;
+  if (o != nullptr && o->struct_bytes >= sizeof(lshrs_sig_opts)) {
+    r.ev[0] = static_cast<hipEvent_t>(o->ev_stage1_start);
+    r.ev[1] = static_cast<hipEvent_t>(o->ev_stage1_stop);
+    r.ev[2] = static_cast<hipEvent_t>(o->ev_stage2_start);
+    r.ev[3] = static_cast<hipEvent_t>(o->ev_stage2_stop);
+    r.clock_probe = static_cast<unsigned long long*>(o->clock_probe);
+  }
+  return r;
+}
+}  // namespace
+
 extern "C" {
 
 int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
-
-// Tuning aid for A/B measurements (not declared in the public header): 4 or 8 waves per workgroup.
-int lshrs_debug_set_sig_waves(int w) {
-  if (w != 4 && w != 8) return LSHRS_E_BADARG;
-  g_sig_waves = w;
-  return 0;
-}
-int lshrs_debug_set_sig_pipe(int p) {
-  if (p < 0 || p > 1) return LSHRS_E_BADARG;
-  g_sig_pipe = p;
-  return 0;
-}
-// Diagnostics: device buffer of 2 x (number of workgroups) u64 that the next wide-geometry launches fill with
-// the shader-clock and 100 MHz tick counts of each workgroup's main loop (NULL switches it off).
-int lshrs_debug_set_clock_probe(void* device_buffer) {
-  g_clock_probe = static_cast<unsigned long long*>(device_buffer);
-  return 0;
-}
-int lshrs_debug_set_split_m(int m) {
-  if (m != 1 && m != 2) return LSHRS_E_BADARG;
-  g_split_m = m;
-  return 0;
-}
-
-int lshrs_debug_set_split_pipe(int p) {
-  if (p != 3 && p != 4 && p != 6 && p != 7 && p != 8) return LSHRS_E_BADARG;
-  g_split_pipe = p;
-  return 0;
-}
-
-int lshrs_debug_set_split_mid_event(void* event) {
-  g_split_mid_event = static_cast<hipEvent_t>(event);
-  return 0;
-}
-
-int lshrs_debug_set_split_time_events(void* k1_start, void* k1_stop, void* k2_start, void* k2_stop) {
-  g_split_time_events[0] = static_cast<hipEvent_t>(k1_start);
-  g_split_time_events[1] = static_cast<hipEvent_t>(k1_stop);
-  g_split_time_events[2] = static_cast<hipEvent_t>(k2_start);
-  g_split_time_events[3] = static_cast<hipEvent_t>(k2_stop);
-  return 0;
-}
-
-int lshrs_debug_set_fix_mode(int m) {
-  if (m != 0 && m != 1) return LSHRS_E_BADARG;
-  g_fix_mode = m;
-  return 0;
-}
-
-int lshrs_debug_set_sig_fine(int f) {
-  if (f < 0 || f > 2) return LSHRS_E_BADARG;
-  g_sig_fine = f;
-  return 0;
-}
 
 static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
   if (num_bands <= 0 || rows <= 0 || dim <= 0) return false;
@@ -2211,11 +1595,8 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, nnorms, 256, 1, nnorms + 256);
   }
   if (sig_has_split(g)) {
-    float* simage = image + sig_split_offset_floats(g);
     const int64_t schunks = sig_image_floats(g) / 4;  // 16-byte chunks: same count as the f32 image
-    hipLaunchKernelGGL(pack_image_bf16_kernel, dim3((unsigned)((schunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
-                       rows_per_band, dim, g.bb, g.nt, g.ktiles, schunks, reinterpret_cast<u16x8*>(simage));
-    float* timage = image + sig_t16_offset_floats(g);   // the same values in 16x16x32 fragment order
+    float* timage = image + sig_t16_offset_floats(g);   // hi / mid bf16 parts in 16x16x32 fragment order
     hipLaunchKernelGGL(pack_image_bf16_t16_kernel, dim3((unsigned)((schunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
                        rows_per_band, dim, g.bb, g.ktiles, schunks, reinterpret_cast<u16x8*>(timage));
   }
@@ -2224,7 +1605,7 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
 
 int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
                              int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
-                             int32_t* tie_count, float tau, uint8_t* row_flags, void* stream) {
+                             int32_t* tie_count, float tau, uint8_t* row_flags, const lshrs_sig_opts* opts, void* stream) {
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim ||
       !sig_shape_ok(num_bands, rows_per_band, dim))
@@ -2263,28 +1644,31 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
     a.tie_count = tie_count;
     a.tau = tau;
     a.row_flags = row_flags != nullptr ? row_flags + lo : nullptr;
-    a.clock_probe = (lo == 0 && !fine) ? g_clock_probe : nullptr;
+    a.clock_probe = (lo == 0 && !fine) ? read_opts(opts).clock_probe : nullptr;
     return dispatch_sig(a, gg, false, s);
   };
   // Whole rounds of NT-wide workgroups first; what is left (less than one round) takes the fine geometry when
   // that finishes sooner than one more full-length, mostly idle round.
-  const bool fine_ok = sig_has_fine(g) && g_sig_fine != 0 && g.tiles32 <= 65535;
+  const bool fine_ok = sig_has_fine(g) && g.tiles32 <= 65535;
   const int64_t n_main = (n / kRoundRows) * kRoundRows;
   const int64_t tail = n - n_main;
   if (n_main > 0) {
     const int rc = launch(0, n_main, false);
     if (rc != 0) return rc;
   }
-  if (tail > 0) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || sig_prefer_fine(g, tail)));
+  if (tail > 0) return launch(n_main, n, fine_ok && sig_prefer_fine(g, tail));
   return 0;
 }
 
 // blas_model 0: ties are reported in tie_list (the caller resolves them on the host); > 0: stage 2 resolves them itself
 // by replaying that summation order of the host BLAS (sig_fix8_kernel<true>), tie_list is not used.
+// stat_dev / stat_flips / flag_y: the replay's live-margin statistics (NULL: not kept).
 static int split_pass(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
                       int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
-                      int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, int32_t flag_cap,
-                      int32_t* flag_count, float tau1, int blas_model, int32_t* host_counts, void* stream) {
+                      int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, float* flag_y,
+                      int32_t flag_cap, int32_t* flag_count, float tau1, int blas_model, int32_t* stat_dev,
+                      int32_t* stat_flips, int32_t* counters, int32_t* host_counts, const lshrs_sig_opts* opts,
+                      void* stream) {
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
       flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
@@ -2295,26 +1679,31 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   // the second stage patches key bits with 32-bit atomics: rows must be whole words
   const bool narrow = sig_has_narrow_split(g);
   if ((!sig_has_split(g) && !narrow) || row_bytes % 4 != 0 || (reinterpret_cast<uintptr_t>(keys) & 3)) return LSHRS_E_TOOLARGE;
-  if (n >= ((int64_t)1 << 47) || (n + 255) / 256 > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
+  const int64_t row_tiles = (n + 255) / 256;
+  const int64_t wgs = (row_tiles + 7) / 8 * 8 * g.cb;
+  if (n >= ((int64_t)1 << 42) || wgs > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const Opts o = read_opts(opts);
   const float* base = static_cast<const float*>(workspace);
   const bool aligned = (dim % 32 == 0) && (ldx % 4 == 0) && ldx < (1 << 20) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   if (!aligned) {  // the split pass is built for whole k-tiles of 16-byte aligned rows; anything else takes the f32 pass (same keys)
     if (blas_model != 0) return LSHRS_E_BADARG;   // (the f32 kernel reports ties, it does not resolve them)
     return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
-                                    tie_count, tau, row_flags, stream);
+                                    tie_count, tau, row_flags, opts, stream);
   }
-  // stage 1: bf16 x 3 projections -> keys + list of (row, word, mask) inside the stage-1 window
+  // stage 1: bf16 x 3 projections -> keys + list of the projections inside the stage-1 window (+ their values)
   SigArgs a{};
   a.X = X;
   a.n = n;
   a.ldx = ldx;
   a.dim = dim;
   a.ktiles = g.ktiles;
-  a.image = base + sig_split_offset_floats(g);
+  a.ncb = g.cb;
+  a.image = base + sig_t16_offset_floats(g);
   a.norms = base + sig_image_floats(g);
   a.norm_max = a.norms + sig_norm_floats(g);
   if (narrow) {   // the zero-padded 256-column image and its norms
+    a.ncb = 1;
     a.image = base + sig_narrow_offset_floats(g);
     a.norms = a.image + sig_narrow_image_floats(g);
     a.norm_max = a.norms + 256;
@@ -2324,53 +1713,17 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   a.vec_store = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(keys) % 16) == 0);
   a.row_base = 0;
   a.tie_list = flag_list;
+  a.flag_y = flag_y;
   a.tie_cap = flag_cap;
   a.tie_count = flag_count;
   a.tau = tau1;
   a.row_flags = row_flags;
-  a.clock_probe = g_clock_probe;
-  if (narrow) {
-    const dim3 grid((unsigned)((n + 255) / 256), 1, 1);
-    hipExtLaunchKernelGGL((sig16_kernel<2, 8>), grid, dim3(512, 1, 1), 0, s, g_split_time_events[0],
-                          g_split_time_events[1], 0, a);
-  } else if (g_split_m == 2) {
-    constexpr int kRows = 4 * kRowsPerWave * 2;  // W = 4 waves x two 32-row tiles, one workgroup per CU
-    const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
-    if (g_split_pipe == 6 || g_split_pipe == 7 || g_split_pipe == 8) {
-      a.image = base + sig_t16_offset_floats(g);
-      if (g_split_pipe == 6)
-        hipLaunchKernelGGL((sig16_kernel<4, 4>), grid, block, 0, s, a);               // 16x16x32 MFMAs, one wave per SIMD
-      else if (g_split_pipe == 8) {
-        // persistent: one workgroup per CU (144 KiB of LDS each) walks the row tiles of its column block
-        static int cus = 0;
-        if (cus == 0) {
-          int dev = 0, v = 0;
-          if (hipGetDevice(&dev) == hipSuccess &&
-              hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            cus = v;
-          else
-            cus = 256;
-        }
-        const unsigned gx = grid.x < (unsigned)cus ? grid.x : (unsigned)cus;
-        hipExtLaunchKernelGGL((sig16_kernel<2, 8, true>), dim3(gx, grid.y, 1), dim3(512, 1, 1), 0, s,
-                              g_split_time_events[0], g_split_time_events[1], 0, a);
-      } else
-        hipExtLaunchKernelGGL((sig16_kernel<2, 8>), grid, dim3(512, 1, 1), 0, s, g_split_time_events[0],
-                              g_split_time_events[1], 0, a);                              // ... two waves per SIMD
-    } else if (g_split_pipe == 4)
-      hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 4, 2>), grid, block, 0, s, a);   // x staged in full 128-byte lines
-    else
-      hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 2>), grid, block, 0, s, a);
-  } else {
-    constexpr int kRows = 4 * kRowsPerWave;      // W = 4 waves x one 32-row tile, two workgroups per CU
-    const dim3 grid((unsigned)((n + kRows - 1) / kRows), (unsigned)g.cb, 1), block(256, 1, 1);
-    hipLaunchKernelGGL((sig_kernel<8, true, 1, 4, 3, 1>), grid, block, 0, s, a);
+  a.clock_probe = o.clock_probe;
+  {
+    const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), 1, 1);
+    hipExtLaunchKernelGGL(sig16_kernel, grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
   }
-  if (g_split_mid_event != nullptr) {   // bench.py times stage 1 alone with it
-    (void)hipEventRecord(g_split_mid_event, s);
-    g_split_mid_event = nullptr;
-  }
-  // stage 2: exact f32 chain for the flagged projections
+  // stage 2: the flagged projections, one by one
   FixArgs f{};
   f.X = X;
   f.ldx = ldx;
@@ -2391,49 +1744,49 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.tie_count = tie_count;
   f.tau = tau;
   f.blas_model = blas_model;
+  const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
+  const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
   if (blas_model != 0) {
     f.tie_list = nullptr;
-    const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
-    const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
-    hipExtLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, g_split_time_events[2], g_split_time_events[3], 0, f);
-    if (host_counts != nullptr)
-      hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(1), 0, s, tie_count, flag_count, host_counts);
-  } else if (g_fix_mode != 0) {
-    const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
-    const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
-    hipExtLaunchKernelGGL(sig_fix8_kernel<false>, grid, block, 0, s, g_split_time_events[2], g_split_time_events[3], 0, f);
+    f.flag_y = flag_y;
+    f.stat_dev = stat_dev;
+    f.stat_flips = stat_flips;
+    hipExtLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+    if (host_counts != nullptr && counters != nullptr)
+      hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts);
   } else {
-    const int64_t want = (int64_t)flag_cap < kFixGrid ? (int64_t)flag_cap : kFixGrid;
-    const dim3 grid((unsigned)(want < 1 ? 1 : want)), block(64);
-    hipLaunchKernelGGL(sig_fix_kernel, grid, block, 0, s, f);
+    hipExtLaunchKernelGGL(sig_fix8_kernel<false>, grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
   }
-  for (hipEvent_t& ev : g_split_time_events) ev = nullptr;
   return -(int)hipGetLastError();
 }
 
 int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
                                    int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list,
                                    int32_t tie_cap, int32_t* tie_count, float tau, uint8_t* row_flags,
-                                   int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1, void* stream) {
+                                   int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
+                                   const lshrs_sig_opts* opts, void* stream) {
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap, tie_count, tau,
-                    row_flags, flag_list, flag_cap, flag_count, tau1, 0, nullptr, stream);
+                    row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, nullptr, nullptr,
+                    opts, stream);
 }
 
 int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
                                           int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
-                                          int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list,
-                                          int32_t flag_cap, int32_t* flag_count, float tau1, int32_t blas_model,
-                                          int32_t* host_counts, void* stream) {
-  if (blas_model != 1 || dim % 8 != 0) return LSHRS_E_BADARG;
-  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, tie_count, tau, row_flags,
-                    flag_list, flag_cap, flag_count, tau1, blas_model, host_counts, stream);
+                                          int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                          float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
+                                          int32_t* host_counts, const lshrs_sig_opts* opts, void* stream) {
+  if (blas_model != 1 || dim % 8 != 0 || counters == nullptr) return LSHRS_E_BADARG;
+  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
+                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters + 2, counters + 3, counters,
+                    host_counts, opts, stream);
 }
 
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
                                        int32_t rows_per_band, int32_t dim, uint8_t* keys, const int64_t* tie_list,
-                                       int32_t tie_cap, int32_t* tie_count, float tau, int64_t* flag_list,
-                                       int32_t flag_cap, int32_t* flag_count, int32_t blas_model, int32_t* host_counts,
-                                       void* stream) {
+                                       int32_t tie_cap, int32_t* counters, float tau, int64_t* flag_list,
+                                       int32_t flag_cap, int32_t blas_model, int32_t* host_counts, void* stream) {
+  int32_t* tie_count = counters;                          // [0] tie entries the f32 kernel wanted to write
+  int32_t* flag_count = counters != nullptr ? counters + 1 : nullptr;   // [1] items expanded from them
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || tie_list == nullptr || tie_count == nullptr ||
       flag_list == nullptr || flag_count == nullptr || tie_cap <= 0 || flag_cap <= 0 || n < 0 || ldx < dim ||
@@ -2473,13 +1826,14 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   f.tie_count = nullptr;          // (the caller has the number of tie entries already; stage 2 only decides them)
   f.tau = tau;
   f.blas_model = blas_model;
+  f.stat_flips = counters + 3;
   {
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
     hipLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, f);
   }
   if (host_counts != nullptr)
-    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(1), 0, s, tie_count, flag_count, host_counts);
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts);
   return -(int)hipGetLastError();
 }
 
@@ -2509,13 +1863,13 @@ int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* wo
     a.ldy = ldy;
     return dispatch_sig(a, gg, true, s);
   };
-  const bool fine_ok = sig_has_fine(g) && g_sig_fine != 0 && g.tiles32 <= 65535;
+  const bool fine_ok = sig_has_fine(g) && g.tiles32 <= 65535;
   const int64_t n_main = (n / kRoundRows) * kRoundRows;
   if (n_main > 0) {
     const int rc = launch(0, n_main, false);
     if (rc != 0) return rc;
   }
-  if (n > n_main) return launch(n_main, n, fine_ok && (g_sig_fine == 2 || sig_prefer_fine(g, n - n_main)));
+  if (n > n_main) return launch(n_main, n, fine_ok && sig_prefer_fine(g, n - n_main));
   return 0;
 }
 

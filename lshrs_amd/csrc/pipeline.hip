@@ -22,9 +22,6 @@
 
 #include "lshrs_hip.h"
 
-// lshrs_hip.hip: start/stop events that ride on the dispatches of stage 1 and stage 2 of the next split call
-extern "C" int lshrs_debug_set_split_time_events(void* k1_start, void* k1_stop, void* k2_start, void* k2_stop);
-
 namespace {
 
 constexpr int kSlots = 4;
@@ -301,14 +298,19 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       const bool split = chunk_split[c] != 0 && split_ok;
       int r;
       if (split) {
-        if (chunk_ms != nullptr) (void)lshrs_debug_set_split_time_events(s.k1s, s.k1e, s.k2s, s.k2e);
+        lshrs_sig_opts o{};
+        o.struct_bytes = sizeof(o);
+        o.ev_stage1_start = s.k1s;
+        o.ev_stage1_stop = s.k1e;
+        o.ev_stage2_start = s.k2s;
+        o.ev_stage2_stop = s.k2e;
         r = lshrs_sig_hash_batch_split_f32(xs, hi - lo, ldx, workspace, p->nb, p->r, p->dim, ks, s.tie_list, p->tie_cap,
-                                           cnt, tau, fl, s.flag_list, p->flag_cap, cnt + 1, tau1, stream);
-        (void)lshrs_debug_set_split_time_events(nullptr, nullptr, nullptr, nullptr);
+                                           cnt, tau, fl, s.flag_list, p->flag_cap, cnt + 1, tau1,
+                                           chunk_ms != nullptr ? &o : nullptr, stream);
       } else {
         if (chunk_ms != nullptr && (e = hipEventRecord(s.k1s, main)) != hipSuccess) return -(int)e;
         r = lshrs_sig_hash_batch_f32(xs, hi - lo, ldx, workspace, p->nb, p->r, p->dim, ks, s.tie_list, p->tie_cap, cnt,
-                                     tau, fl, stream);
+                                     tau, fl, nullptr, stream);
         if (chunk_ms != nullptr && (e = hipEventRecord(s.k1e, main)) != hipSuccess) return -(int)e;
       }
       if (r != 0) return r;
@@ -371,8 +373,7 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
       if (c == n_chunks - 1) t_tail = t1 - t_entry;
       if (chunk_ms != nullptr) {
         float a = -1.f, b = -1.f;     // (this slot is re-armed kSlots chunks on: read now)
-        // Diagnostics must not fail the batch: the split pass picks its events up from a process-wide hook, which a
-        // second hasher timing its own launches from another thread at the same moment can take away (-1 then).
+        // Diagnostics must not fail the batch.
         if (hipEventElapsedTime(&a, s.k1s, s.k1e) != hipSuccess) a = -1.f;
         if (chunk_split[c] != 0 && split_ok && hipEventElapsedTime(&b, s.k2s, s.k2e) != hipSuccess) b = -1.f;
         (void)hipGetLastError();

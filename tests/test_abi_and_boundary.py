@@ -38,7 +38,7 @@ def test_header_and_library_agree(lib):
     assert sorted(_native.EXPORTS) == names, "python binding list and header drifted apart"
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 1
+    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 2
     m = re.search(r"#define\s+LSHRS_ABI_VERSION\s+(\d+)", open(HEADER).read())
     assert int(m.group(1)) == lib.lshrs_abi_version()
 
@@ -83,19 +83,29 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_padded_columns(0, 5) < 0
     # main image (padded columns x dim rounded up to 32) + one norm per padded column + one max-norm per column
     # block (x4); shapes wider than one 32-column tile also carry the fine (one tile per workgroup) image, and
-    # shapes of >= 256 padded columns the bf16 hi/mid images of the split-precision pass, in 32x32x16 and in
-    # 16x16x32 fragment order (same size again, twice)
-    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (4 * 256 * 768 + 256 + 4 + 8) * 4
-    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (4 * 512 * 1536 + 512 + 4 + 16) * 4
+    # shapes of >= 256 padded columns the bf16 hi/mid image of the split-precision pass in 16x16x32 fragment order
+    # (same size again)
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (3 * 256 * 768 + 256 + 4 + 8) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (3 * 512 * 1536 + 512 + 4 + 16) * 4
     # exactly 128 padded columns: + the 16x16x32 fragment image zero-padded to 256 columns (256 x dim bf16 hi/mid
     # = 256 x dim floats' worth), its 256 norms and their maximum (x4)
     assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (2 * 128 * 128 + 128 + 4 + 4 + 256 * 128 + 256 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (32 * 32 + 32 + 4) * 4
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device
-    assert lib.lshrs_sig_hash_batch_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None) == -10001
+    assert lib.lshrs_sig_hash_batch_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None, None) == -10001
     assert lib.lshrs_sig_hash_batch_split_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None, 0, None,
-                                              0.0, None) == -10001
+                                              0.0, None, None) == -10001
+    assert lib.lshrs_sig_hash_batch_split_replay_f32(None, 5, 32, None, 1, 1, 32, None, None, 0.0, None, None, None, 0, 0.0,
+                                                     1, None, None, None) == -10001
+    # the measurement hooks travel in the call: the struct the binding passes is the header's
+    text = open(HEADER).read()
+    fields = re.search(r"typedef struct lshrs_sig_opts \{(.*?)\} lshrs_sig_opts;", text, flags=re.S).group(1)
+    names = re.findall(r"(\w+);", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
+    from lshrs_amd import _native
+    assert names == [f[0] for f in _native.SigOpts._fields_]
+    assert ctypes.sizeof(_native.SigOpts) == 8 + 5 * ctypes.sizeof(ctypes.c_void_p)
+    assert int(re.search(r"#define\s+LSHRS_SIG_COUNTERS\s+(\d+)", text).group(1)) == _native.SIG_COUNTERS
     assert lib.lshrs_topk_desc_f32(None, 1, 5, 3, None, None, None, None) == -10001
     assert lib.lshrs_topk_workspace_bytes(10, 1000) == 0
     assert lib.lshrs_topk_workspace_bytes(3, 40_000) == 3 * 65536 * 8

@@ -517,27 +517,19 @@ def test_launch_plan_main_rounds_plus_fine_tail(torch_mod):
     from oracle.build import chain_hash_packed, chain_project
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
-    lib = _native.load()
-    h = _hasher(42, 16, 16, 768)
+    h = _hasher(42, 16, 16, 768, precision="f32")
     x = np.random.default_rng(4242).standard_normal((70_000, 768)).astype(np.float32)
     xd = torch.from_numpy(x).cuda()
     y = h.project_device(xd).cpu().numpy()
     for sl in (slice(0, 256), slice(65_400, 65_700), slice(69_700, 70_000)):
         assert np.array_equal(y[sl], chain_project(h.projections, x[sl]))
-    try:
-        outs = {}
-        for mode in (0, 1, 2):                    # never / automatic / always fine
-            assert lib.lshrs_debug_set_sig_fine(mode) == 0
-            outs[mode] = (h.hash_device(xd, tie_break="none").cpu().numpy(), h.hash_device(xd).cpu().numpy(),
-                          dict(h.last_stats))
-    finally:
-        lib.lshrs_debug_set_sig_fine(1)
-    for mode in (0, 2):
-        assert np.array_equal(outs[mode][0], outs[1][0]) and np.array_equal(outs[mode][1], outs[1][1])
-        assert outs[mode][2]["tie_pairs"] == outs[1][2]["tie_pairs"]
+    raw, final = h.hash_device(xd, tie_break="none").cpu().numpy(), h.hash_device(xd).cpu().numpy()
+    # the same rows hashed as a batch that is one tail only (fine geometry throughout) give the same bytes
+    tail = h.hash_device(xd[65_536:], tie_break="none").cpu().numpy()
+    assert np.array_equal(tail, raw[65_536:])
     sl = slice(64_000, 68_000)
-    assert np.array_equal(outs[1][0][sl], chain_hash_packed(h.projections, x[sl]))
-    assert np.array_equal(outs[1][1][sl], hash_batch_literal_packed(h.projections, x[sl]))
+    assert np.array_equal(raw[sl], chain_hash_packed(h.projections, x[sl]))
+    assert np.array_equal(final[sl], hash_batch_literal_packed(h.projections, x[sl]))
 
 
 def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
@@ -628,28 +620,181 @@ def test_split_pass_edge_rows_and_layouts(torch_mod):
     assert np.array_equal(got[sl].cpu().numpy(), chain_hash_packed(hs.projections, odd[sl].cpu().numpy()))
 
 
-def test_split_kernel_variants_agree(torch_mod):
-    """Every variant of the split-precision pass kept in the library (x in fragment-shaped pieces / in full lines, one or
-    two row tiles per wave, the 16x16x32 kernel) must give the f32 kernel's raw keys and the same stage-2 tie list size."""
+def test_split_kernel_gives_the_f32_keys_on_every_shape(torch_mod):
+    """Stage 1 of the split-precision pass (sig16_kernel) + the canonical stage 2 must give the f32 kernel's raw keys on
+    1 .. 48 k-tiles, 256 and 512 key columns (two column blocks: the XCD-paired grid), partial last row tiles."""
     torch = torch_mod
-    from lshrs_amd import _native
-
-    lib = _native.load()
     cases = ((42, 16, 16, 768, 150_000), (7, 16, 32, 1536, 40_000), (3, 32, 8, 96, 180_000), (5, 16, 16, 64, 270_000),
-             (9, 16, 16, 32, 300_001), (11, 32, 16, 160, 70_000))      # 1 .. 48 k-tiles, 256 and 512 key columns
-    try:
-        for (seed, nb, r, dim, n) in cases:
-            x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
-            x[5] = 0.0
-            x[6, 1] = float("nan")
-            want = _hasher(seed, nb, r, dim, precision="f32").hash_device(x, tie_break="none")
-            for pipe, m in ((4, 2), (3, 2), (3, 1), (6, 2), (7, 2), (8, 2)):
-                assert lib.lshrs_debug_set_split_pipe(pipe) == 0 and lib.lshrs_debug_set_split_m(m) == 0
-                hs = _hasher(seed, nb, r, dim)
-                hs.split_min_elems = 0
-                assert hs._split_applies(n)
-                got = hs.hash_device(x, tie_break="none")
-                assert torch.equal(got, want), f"pipe {pipe}, M {m}, shape {(nb, r, dim)}: {int((got != want).sum())} key bytes differ"
-    finally:
-        lib.lshrs_debug_set_split_pipe(7)
-        lib.lshrs_debug_set_split_m(2)
+             (9, 16, 16, 32, 300_001), (11, 32, 16, 160, 70_000), (13, 48, 16, 64, 2_049))
+    for (seed, nb, r, dim, n) in cases:
+        x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
+        x[5] = 0.0
+        x[6, 1] = float("nan")
+        want = _hasher(seed, nb, r, dim, precision="f32").hash_device(x, tie_break="none")
+        hs = _hasher(seed, nb, r, dim)
+        hs.split_min_elems = 0
+        hs.split_min_rows = 0
+        assert hs._split_applies(n)
+        got = hs.hash_device(x, tie_break="none")
+        assert torch.equal(got, want), f"shape {(nb, r, dim)}: {int((got != want).sum())} key bytes differ"
+
+
+def _structured_batches(torch, h, n, dim):
+    """Inputs the round-1 margin measurements did not cover: what real embeddings look like and
+    what an adversary would try."""
+    g = torch.Generator("cuda").manual_seed(77)
+    P = torch.from_numpy(np.concatenate([np.asarray(p, dtype=np.float32) for p in h.projections])).cuda()
+    out = {}
+    x = torch.randn(n, dim, device="cuda", generator=g)
+    out["unit_norm"] = x / x.norm(dim=1, keepdim=True)
+    basis = torch.randn(8, dim, device="cuda", generator=g)
+    out["rank8"] = torch.randn(n, 8, device="cuda", generator=g) @ basis
+    out["int8_grid"] = torch.randint(-127, 128, (n, dim), device="cuda", generator=g).float() / 127.0
+    out["constant_sign"] = torch.rand(n, dim, device="cuda", generator=g) + 0.01
+    out["heavy_tail"] = torch.randn(n, dim, device="cuda", generator=g) * torch.exp(2.0 * torch.randn(n, dim, device="cuda", generator=g))
+    # planted: rows whose projection on a chosen hyperplane sits at +-60..70 units of 2^-24 ||x|| ||p|| - right at the
+    # edge of the default window, where a stage-1 error of a few units decides whether the projection is flagged
+    x = torch.randn(n, dim, device="cuda", generator=g).double()
+    cols = torch.randint(0, P.shape[0], (n,), device="cuda", generator=g)
+    p = P[cols].double()
+    y = (x * p).sum(1)
+    xn, pn = x.norm(dim=1), p.norm(dim=1)
+    target = (60.0 + 10.0 * torch.rand(n, device="cuda", generator=g).double()) * 2.0 ** -24 * xn * pn
+    target = target * torch.where(torch.rand(n, device="cuda", generator=g) < 0.5, -1.0, 1.0)
+    x = x + ((target - y) / (pn * pn))[:, None] * p
+    out["planted_edge"] = x.float()
+    return out
+
+
+def test_split_window_margin(torch_mod):
+    """How far is stage 1 of the split pass (bf16 x 3 on the matrix cores) from the HOST BLAS's value of the same
+    projection, on the box that runs the tests?  Two measurements per structured batch:
+      * the hasher's own live statistic - max |y1 - y_BLAS| over every flagged projection, in window units;
+      * directly, against NumPy's `P_band @ x` (the reference's call) on a sample of rows: no projection whose stage-1
+        sign differs from the reference's may lie outside the default window - i.e. the keys are the reference's.
+    The default window (64 units) must hold a 2x margin over everything seen, and the guard must not have fired."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    n, dim = 120_000, 768
+    h = _hasher(42, 16, 16, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    worst = {}
+    for name, x in _structured_batches(torch, h, n, dim).items():
+        assert h._split_applies(n, replay=True)
+        keys = h.hash_device(x)
+        st = dict(h.last_stats)
+        assert st["tie_break_engine"] == "device-replay" and st["flagged"] > 0
+        worst[name] = st["max_dev_units"]
+        assert st["margin_escalations"] == 0, (name, st)
+        sl = slice(0, 6_000)
+        want = hash_batch_literal_packed(h.projections, x[sl].cpu().numpy())
+        assert np.array_equal(keys[sl].cpu().numpy(), want), name
+    assert max(worst.values()) * 2 <= h.tau1_ulps, worst
+    # the planted batch really sits at the edge: a third or more of its planted projections are inside the window
+    h.hash_device(_structured_batches(torch, h, n, dim)["planted_edge"])
+    assert h.last_stats["flagged"] > n // 4
+
+
+def test_margin_guard_escalates_to_the_bound_window(torch_mod):
+    """A window smaller than the stage-1 noise (2 units) must trip the guard on the first batch: the batch is hashed
+    again with the deterministic bound, the hasher stays there, and the keys are the reference's."""
+    torch = torch_mod
+    from lshrs_amd.hasher import bound_tau1_ulps
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    n, dim = 100_000, 768
+    h = _hasher(42, 16, 16, dim, tau1_ulps=2.0)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    keys = h.hash_device(x)
+    st = dict(h.last_stats)
+    assert st["margin_escalations"] == 1 and h.window_mode["tau1"] == "bound" and h.tau1_ulps >= bound_tau1_ulps(dim)
+    assert st["flagged"] > 20_000 and st["relaunches"] >= 1
+    sl = slice(40_000, 46_000)
+    assert np.array_equal(keys[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
+    # a hasher built with the bound from the start gives the same bytes, as does the default one
+    hb = _hasher(42, 16, 16, dim, tau1_ulps="bound", tau_ulps="bound")
+    assert torch.equal(hb.hash_device(x), keys) and hb.last_stats["margin_escalations"] == 0
+    assert torch.equal(_hasher(42, 16, 16, dim).hash_device(x), keys)
+    # ... and small batches (f32 kernel, bound tie window: every projection within dim + dim/8 + 3 units is replayed)
+    small = x[:300].contiguous()
+    assert np.array_equal(hb.hash_device(small).cpu().numpy(),
+                          hash_batch_literal_packed(hb.projections, small.cpu().numpy()))
+
+
+def test_two_hashers_two_streams_two_threads_with_kernel_events(torch_mod):
+    """The ABI keeps no state between calls: two hashers timing their own launches (kernel_events on) from two threads
+    on two streams get their own events, their own scratch and the right keys."""
+    import threading
+
+    torch = torch_mod
+    n, dim = 90_000, 768
+    xs = [torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(s)) for s in (1, 2)]
+    hashers = [_hasher(42, 16, 16, dim), _hasher(7, 16, 16, dim)]
+    want = [h.hash_device(x).clone() for h, x in zip(hashers, xs)]
+    torch.cuda.synchronize()
+    got, errors = [None, None], []
+
+    def work(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                hashers[i].kernel_events = []
+                for _ in range(6):
+                    out = hashers[i].hash_device(xs[i])
+                got[i] = (out.clone(), list(hashers[i].kernel_events))
+                hashers[i].kernel_events = None
+            stream.synchronize()
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        assert torch.equal(got[i][0], want[i])
+        ev = got[i][1]
+        assert len(ev) == 6 and all(0.0 < e[0] < 50.0 and 0.0 < e[3] < 50.0 for e in ev), ev
+
+
+def test_mfma_bf16_step_error(torch_mod):
+    """The per-instruction error the deterministic stage-1 bound charges (hasher.MFMA_BF16_ERR_UNITS) against what the
+    matrix cores of THIS box do: v_mfma_f32_16x16x32_bf16 on random, wide-range, cancelling and sticky-bit operands
+    (tools/probes/mfma_probe.*), compared with the exact rational sum."""
+    import ctypes
+    import subprocess
+    import sys
+    from fractions import Fraction
+
+    from lshrs_amd.hasher import MFMA_BF16_ERR_UNITS
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools", "probes"))
+    import mfma_probe
+
+    so = os.path.join(root, "tools", "probes", "mfma_probe.so")
+    if not os.path.exists(so):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared",
+                        os.path.join(root, "tools", "probes", "mfma_probe.hip"), "-o", so], check=True)
+    lib = ctypes.CDLL(so)
+    lib.mfma_probe_run.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int]
+    A, B, C, L = mfma_probe.build_tests(1, np.random.default_rng(99))
+    D = np.zeros(len(C), dtype=np.float32)
+    assert lib.mfma_probe_run(A.ctypes.data, B.ctypes.data, C.ctypes.data, D.ctypes.data, len(C), 1) == 0
+    a = (A.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    b = (B.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    worst = 0.0
+    for t in range(0, len(C), 3):      # (exact rational arithmetic: a third of the 10k cases keeps this to seconds)
+        prods = [Fraction(float(a[t, k])) * Fraction(float(b[t, k])) for k in range(32)]
+        exact = sum(prods) + Fraction(float(C[t]))
+        mag = sum(abs(p) for p in prods) + abs(Fraction(float(C[t])))
+        if mag == 0:
+            continue
+        worst = max(worst, float(abs(Fraction(float(D[t])) - exact) / (mag * Fraction(1, 2 ** 24))))
+    assert 0.0 < worst * 2 <= MFMA_BF16_ERR_UNITS, worst

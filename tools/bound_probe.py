@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Stage-1 window sweep on the GPU box: step time, stage-1 / stage-2 kernel times and flagged projections per window."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from lshrs_amd import LSHHasher
+
+
+def main():
+    n, dim = 1_000_000, 768
+    dev = torch.device("cuda", 0)
+    x = torch.randn(n, dim, device=dev, generator=torch.Generator(device=dev).manual_seed(1000))
+    out = []
+    for tau1 in (64.0, 128.0, 256.0, 512.0, "bound"):
+        h = LSHHasher(16, 16, dim, seed=42, tau1_ulps=tau1)
+        keys = h.hash_device(x)
+        h.hash_device(x, out=keys)
+        h.kernel_events = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            h.hash_device(x, out=keys)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        ev = h.kernel_events
+        h.kernel_events = None
+        row = {"tau1_ulps": h.tau1_ulps, "ms_per_step": 1e3 * dt, "stage1_ms": sum(e[0] for e in ev) / len(ev),
+               "stage2_ms": sum(e[3] for e in ev) / len(ev), "stats": dict(h.last_stats)}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+
+
+if __name__ == "__main__":
+    main()
