@@ -439,7 +439,7 @@ class LSHHasher:
             cur = torch.cuda.current_stream(dev)
             cap = max(int(self._flag_cap_hint), n // 4 + 4096)
             if self.tau1_ulps > 256.0:      # a wide (e.g. "bound") window flags ~1.3e-6 of the projections per unit
-                cap = max(cap, int(n * self.num_bands * self.rows_per_band * self.tau1_ulps * 2.0e-6) + 4096)
+                cap = max(cap, int(n * self.num_bands * self.rows_per_band * min(self.tau1_ulps, 4096.0) * 2.0e-6) + 4096)
             skey = (dev.index, cur.cuda_stream)
             scratch = self._replay_scratch.get(skey)
             if scratch is None or scratch[0].shape[0] < cap:
@@ -545,27 +545,31 @@ class LSHHasher:
             raise TypeError("hash_device expects a float32 CUDA/ROCm tensor")
         if x.stride(1) != 1:
             x = x.contiguous()
-        n = int(x.shape[0])
         with self._lock:
-            while len(self._async_pending) >= 3:
-                self._async_pending[0]._finish_locked()
-            model = 0
-            if (n > 0 and self.tie_break == "host" and self.tie_replay == "auto" and self._split_applies(n, replay=True)
-                    and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x.stride(0) < (1 << 20)):
-                model = self._replay_model()
-            if not model:
-                return _PendingKeys(self, x, self._hash_device_locked(x, out, row_flags, self.tie_break, host_rows=None),
-                                    row_flags, None)
-            bb = self.band_bytes
-            if out is None:
-                out = torch.empty((n, self.num_bands, bb), dtype=torch.uint8, device=x.device)
-            elif out.shape != (n, self.num_bands, bb) or out.dtype != torch.uint8 or not out.is_contiguous():
-                raise ValueError("out must be a contiguous uint8 tensor of shape (n, num_bands, band_bytes)")
-            ws = self._workspace(x.device)
-            state = self._replay_launch(x, out, row_flags, ws, float(self.tau_ulps * _U), model, want_event=True)
-            handle = _PendingKeys(self, x, out, row_flags, state)
-            self._async_pending.append(handle)
-            return handle
+            return self._hash_device_async_locked(x, out, row_flags)
+
+    def _hash_device_async_locked(self, x, out, row_flags):
+        torch = _native.require_gpu()
+        n = int(x.shape[0])
+        while len(self._async_pending) >= 3:
+            self._async_pending[0]._finish_locked()
+        model = 0
+        if (n > 0 and self.tie_break == "host" and self.tie_replay == "auto" and self._split_applies(n, replay=True)
+                and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x.stride(0) < (1 << 20)):
+            model = self._replay_model()
+        if not model:
+            return _PendingKeys(self, x, self._hash_device_locked(x, out, row_flags, self.tie_break, host_rows=None),
+                                row_flags, None)
+        bb = self.band_bytes
+        if out is None:
+            out = torch.empty((n, self.num_bands, bb), dtype=torch.uint8, device=x.device)
+        elif out.shape != (n, self.num_bands, bb) or out.dtype != torch.uint8 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous uint8 tensor of shape (n, num_bands, band_bytes)")
+        ws = self._workspace(x.device)
+        state = self._replay_launch(x, out, row_flags, ws, float(self.tau_ulps * _U), model, want_event=True)
+        handle = _PendingKeys(self, x, out, row_flags, state)
+        self._async_pending.append(handle)
+        return handle
 
     def _hash_device_f32_replay(self, x, out, row_flags, ws, tau, stats, model):
         """The exact-f32 kernel followed by the device's tie replay (``lshrs_sig_resolve_ties_replay_f32``): for batches
@@ -1033,7 +1037,7 @@ class LSHHasher:
         if split:
             cap = max(int(self._flag_cap_hint), n // 4 + 4096)
             if self.tau1_ulps > 256.0:
-                cap = max(cap, int(n * self.num_bands * self.rows_per_band * self.tau1_ulps * 2.0e-6) + 4096)
+                cap = max(cap, int(n * self.num_bands * self.rows_per_band * min(self.tau1_ulps, 4096.0) * 2.0e-6) + 4096)
             flag_list = torch.empty((cap,), dtype=torch.int64, device=dev)
             if flag_count is None:   # (the pipelined path zeroes one counter per chunk in a single fill)
                 flag_count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -1141,10 +1145,17 @@ class LSHHasher:
         return patch
 
     # ------------------------------------------------------------------ host-facing API
-    def hash_batch_packed(self, vectors, *, return_row_flags: bool = False, chunk_rows: int = 262_144,
-                          tie_break: Optional[str] = None):
+    def hash_batch_packed(self, vectors, *, return_row_flags: bool = False, chunk_rows: int = 131_072,
+                          tie_break: Optional[str] = None, pin: str = "auto"):
         """Hash host vectors; returns a NumPy ``(n, num_bands, band_bytes)`` uint8 array
-        (the reference's ``bytes`` keys side by side) and, on request, the per-row flag byte."""
+        (the reference's ``bytes`` keys side by side) and, on request, the per-row flag byte.
+
+        Host-resident input is bound by the PCIe link (63 GB/s spec = 20.5 M vec/s at 768-d), not by the kernel, so
+        large batches are streamed: chunk i+1 crosses the link on a copy stream while chunk i is hashed and the keys
+        of chunk i-1 travel back on a third stream, through two device buffers and two pinned key buffers per hasher.
+        ``pin``: "auto" page-locks a large pageable source array in place for the duration of the call
+        (``hipHostRegister``; the DMA engines then read it directly instead of going through the runtime's staging
+        copies), "never" leaves it to the runtime; a source that is already pinned is used as it is."""
         torch = _native.require_gpu()
         arr = np.asarray(vectors, dtype=np.float32)
         if arr.ndim != 2:
@@ -1156,13 +1167,17 @@ class LSHHasher:
             arr = arr.copy()
         n = arr.shape[0]
         mode = self.tie_break if tie_break is None else tie_break
-        keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
-        flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
         dev = self._torch_device()
-        total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
         with self._lock:
-            for lo in range(0, n, chunk_rows):
-                hi = min(n, lo + chunk_rows)
+            streamed = (n >= 2 * 16_384 and mode == "host" and self.tie_replay == "auto"
+                        and self._split_applies(16_384, replay=True) and bool(self._replay_model()))
+            if streamed:
+                return self._hash_host_streamed(arr, return_row_flags, max(16_384, int(chunk_rows)), dev, pin)
+            keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
+            flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
+            total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+            for lo in range(0, n, 262_144):
+                hi = min(n, lo + 262_144)
                 chunk = arr[lo:hi]
                 x = torch.from_numpy(chunk).to(dev)
                 fl = torch.empty(hi - lo, dtype=torch.uint8, device=dev) if return_row_flags else None
@@ -1174,6 +1189,112 @@ class LSHHasher:
                     total[k] += self.last_stats.get(k, 0)
         self.last_stats = total
         return (keys, flags) if return_row_flags else keys
+
+    def _stream_buffers(self, dev, rows: int):
+        """Two device input buffers, two device key / flag buffers and their pinned host mirrors, three streams."""
+        torch = _native.require_gpu()
+        key = ("stream", dev.index, rows)
+        buf = self._pinned_cache.get(key)
+        if buf is None:
+            for old in [k for k in self._pinned_cache if k[0] == "stream" and k[1] == dev.index]:
+                del self._pinned_cache[old]
+            nb, bb = self.num_bands, self.band_bytes
+            buf = {
+                "x": [torch.empty((rows, self.dim), dtype=torch.float32, device=dev) for _ in range(2)],
+                "k": [torch.empty((rows, nb, bb), dtype=torch.uint8, device=dev) for _ in range(2)],
+                "f": [torch.empty((rows,), dtype=torch.uint8, device=dev) for _ in range(2)],
+                "kh": [torch.empty((rows, nb, bb), dtype=torch.uint8).pin_memory() for _ in range(2)],
+                "fh": [torch.empty((rows,), dtype=torch.uint8).pin_memory() for _ in range(2)],
+                "copy": torch.cuda.Stream(device=dev), "compute": torch.cuda.Stream(device=dev),
+                "back": torch.cuda.Stream(device=dev),
+            }
+            self._pinned_cache[key] = buf
+        return buf
+
+    def _hash_host_streamed(self, arr: np.ndarray, want_flags: bool, chunk_rows: int, dev, pin: str):
+        torch = _native.require_gpu()
+        n = arr.shape[0]
+        keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
+        flags = np.empty(n, dtype=np.uint8) if want_flags else None
+        total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0, "flagged": 0,
+                 "max_dev_units": 0.0}
+        src = torch.from_numpy(arr)
+        registered = False
+        if pin == "auto" and not src.is_pinned() and arr.nbytes >= (64 << 20):
+            # page-lock the caller's array where it lies (undone below): the copy engines read it directly
+            registered = int(torch.cuda.cudart().cudaHostRegister(arr.ctypes.data, arr.nbytes, 0)) == 0
+        total["source"] = "pinned" if src.is_pinned() else ("registered" if registered else "pageable")
+        buf = self._stream_buffers(dev, chunk_rows)
+        copy_s, comp_s, back_s = buf["copy"], buf["compute"], buf["back"]
+        caller = torch.cuda.current_stream(dev)
+        for st in (copy_s, comp_s, back_s):
+            st.wait_stream(caller)
+        spans = [(lo, min(n, lo + chunk_rows)) for lo in range(0, n, chunk_rows)]
+        x_free = [None, None]      # event: the pass that read x buffer b has finished
+        k_free = [None, None]      # event: the keys of buffer b have reached the host
+        hashed, landed = [], []    # (handle, span, slot) in flight on the GPU / on their way back
+
+        def land(item):
+            ev, (lo, hi), b = item
+            ev.synchronize()
+            keys[lo:hi] = buf["kh"][b][:hi - lo].numpy()
+            if flags is not None:
+                flags[lo:hi] = buf["fh"][b][:hi - lo].numpy()
+
+        def send_back(item):
+            handle, (lo, hi), b = item
+            with torch.cuda.stream(comp_s):
+                if handle._state is not None:        # verify (repeats the chunk with room / with the bound window if it must)
+                    handle._finish_locked()
+            while len(landed) > 1:                   # (the pinned key buffer b is about to be overwritten: empty it first)
+                land(landed.pop(0))
+            st = self.last_stats
+            for k in ("tie_entries", "tie_pairs", "relaunches", "flagged"):
+                total[k] += st.get(k, 0)
+            total["max_dev_units"] = max(total["max_dev_units"], st.get("max_dev_units", 0.0))
+            x_free[b] = torch.cuda.Event()
+            x_free[b].record(comp_s)
+            back_s.wait_stream(comp_s)
+            with torch.cuda.stream(back_s):
+                buf["kh"][b][:hi - lo].copy_(buf["k"][b][:hi - lo], non_blocking=True)
+                if flags is not None:
+                    buf["fh"][b][:hi - lo].copy_(buf["f"][b][:hi - lo], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(back_s)
+            k_free[b] = ev
+            landed.append((ev, (lo, hi), b))
+
+        try:
+            for i, (lo, hi) in enumerate(spans):
+                b = i & 1
+                if x_free[b] is not None:
+                    copy_s.wait_event(x_free[b])
+                with torch.cuda.stream(copy_s):
+                    buf["x"][b][:hi - lo].copy_(src[lo:hi], non_blocking=True)
+                    h2d = torch.cuda.Event()
+                    h2d.record(copy_s)
+                comp_s.wait_event(h2d)
+                if k_free[b] is not None:
+                    comp_s.wait_event(k_free[b])       # (the keys this pass overwrites have left the device)
+                with torch.cuda.stream(comp_s):
+                    handle = self._hash_device_async_locked(buf["x"][b][:hi - lo], buf["k"][b][:hi - lo],
+                                                            buf["f"][b][:hi - lo] if flags is not None else None)
+                hashed.append((handle, (lo, hi), b))
+                if len(hashed) > 1:
+                    send_back(hashed.pop(0))
+            while hashed:
+                send_back(hashed.pop(0))
+            while landed:
+                land(landed.pop(0))
+            caller.wait_stream(comp_s)
+        finally:
+            if registered:
+                torch.cuda.synchronize(dev)
+                torch.cuda.cudart().cudaHostUnregister(arr.ctypes.data)
+        total["tie_break_engine"] = "device-replay"
+        total["margin_escalations"] = self.margin_escalations
+        self.last_stats = total
+        return (keys, flags) if want_flags else keys
 
     def hash_vector(self, vector) -> HashSignatures:
         """One vector -> ``HashSignatures`` (reference: lsh.py:96-134)."""

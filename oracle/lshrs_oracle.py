@@ -256,3 +256,35 @@ def expected_limit(n: int, top_p: float, top_k=None) -> int:
     if top_k is not None:
         lim = min(lim, top_k)
     return lim
+
+
+# --------------------------------------------------------------------------
+# orchestrator ingest loop (timed as the end-to-end CPU baseline; also checks LSHRS.index in tests)
+# --------------------------------------------------------------------------
+
+def index_literal(storage, indices, vectors, projections: Sequence[np.ndarray], dim: int, buffer_size: int = 10_000) -> int:
+    """lshrs/core/main.py:495-518 (index) -> :386-411 (ingest) -> :1050-1086 (_prepare_vector), lsh.py:96-134
+    (hash_vector), :1113-1143 (_enqueue_operations, _flush_buffer_if_needed), :413-434 (flush): one vector at a time,
+    ``num_bands`` operations appended per vector, the whole buffer handed to ``storage.batch_add`` at the first vector
+    boundary where it holds ``buffer_size`` operations, and once more at the end.  Returns the number of flushes."""
+    arr = np.asarray(vectors, dtype=np.float32)
+    if arr.ndim != 2 or arr.shape[1] != dim:
+        raise ValueError(f"Vectors must have shape (n, {dim}); received {arr.shape}")
+    buffer: list = []
+    flushes = 0
+    for idx, vec in zip(indices, arr):
+        idx = int(idx)
+        if idx < 0:
+            raise ValueError("index must be non-negative")
+        v = prepare_vector(vec, dim)
+        signatures = hash_vector_literal(projections, v, dim)
+        for band_id, hash_val in enumerate(signatures):
+            buffer.append((band_id, hash_val, idx))
+        if len(buffer) >= buffer_size:
+            storage.batch_add(list(buffer))
+            buffer.clear()
+            flushes += 1
+    if buffer:
+        storage.batch_add(list(buffer))
+        flushes += 1
+    return flushes
