@@ -233,6 +233,20 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
  * (lshrs/storage/redis.py:225), for all N x bands keys in one pass. */
 int lshrs_keys_to_hex_u8(const uint8_t* keys, int64_t nbytes, uint8_t* hex, void* stream);
 
+/* Storage-op path, grouping: what the reference does one `(band, key, id)` tuple and one SADD at a time
+ * (LSHRS._enqueue_operations, lshrs/core/main.py:1113-1128; RedisStorage.batch_add, lshrs/storage/redis.py:348-416)
+ * as a CSR over the buckets of a whole batch - a counting sort per band on the device, for keys of 1 or 2 bytes
+ * (band_bytes > 2: LSHRS_E_TOOLARGE, the caller groups on the host).  bin = band << (8 * band_bytes) | key, the key's
+ * bytes read little-endian; the bucket of a bin is `{prefix}:{band}:bucket:{key bytes as hex}` (redis.py:187-225).
+ *   lshrs_bucket_histogram_u8  counts int32[num_bands << (8 * band_bytes)], zeroed by the caller: members per bin
+ *   lshrs_bucket_scatter_u8    offsets int64[bins] = exclusive prefix sum of counts; cursors int32[bins] zeroed by the
+ *                              caller (scratch); members int64[n * num_bands]: the ids of bin b are
+ *                              members[offsets[b] .. offsets[b] + counts[b]), in unspecified order (buckets are sets). */
+int lshrs_bucket_histogram_u8(const uint8_t* keys, int64_t n, int32_t num_bands, int32_t band_bytes, int32_t* counts,
+                              void* stream);
+int lshrs_bucket_scatter_u8(const uint8_t* keys, const int64_t* ids, int64_t n, int32_t num_bands, int32_t band_bytes,
+                            const int64_t* offsets, int32_t* cursors, int64_t* members, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Cosine rerank — replaces cosine_similarity / top_k_cosine (lshrs/utils/similarity.py:80-90,
  * 157-183) and the per-candidate l2_norm (lshrs/utils/norm.py:48-61).

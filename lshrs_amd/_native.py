@@ -104,6 +104,10 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_scatter_band_keys_u8.restype = c.c_int
     lib.lshrs_keys_to_hex_u8.argtypes = [vp, i64, vp, vp]
     lib.lshrs_keys_to_hex_u8.restype = c.c_int
+    lib.lshrs_bucket_histogram_u8.argtypes = [vp, i64, i32, i32, vp, vp]
+    lib.lshrs_bucket_histogram_u8.restype = c.c_int
+    lib.lshrs_bucket_scatter_u8.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp]
+    lib.lshrs_bucket_scatter_u8.restype = c.c_int
     lib.lshrs_cosine_batch_f32.argtypes = [vp, i64, i64, i32, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.lshrs_cosine_batch_f32.restype = c.c_int
     lib.lshrs_l2_normalize_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp]
@@ -134,6 +138,8 @@ EXPORTS = (
     "lshrs_gather_tied_rows_f32",
     "lshrs_scatter_band_keys_u8",
     "lshrs_keys_to_hex_u8",
+    "lshrs_bucket_histogram_u8",
+    "lshrs_bucket_scatter_u8",
     "lshrs_cosine_batch_f32",
     "lshrs_l2_normalize_f32",
     "lshrs_topk_workspace_bytes",

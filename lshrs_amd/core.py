@@ -32,6 +32,7 @@ import numpy as np
 
 from .bandrows import get_optimal_config
 from .hasher import LSHHasher
+from .packed_ops import bucket_csr as _bucket_csr
 from .similarity import rerank_padded as _rerank_padded
 from .similarity import top_k_cosine
 from .storage import BucketOperation, default_storage
@@ -45,6 +46,29 @@ __all__ = ["LSHRS", "lshrs"]
 
 _FORMAT_VERSION = "0.1.1a4"  # on-disk format version string the reference writes (main.py:882)
 _ZERO_MSG = "Cannot index zero vector - norm undefined. Check embeddings for corruption."
+
+
+class _DeferredStorage:
+    """What an unpickled index holds until somebody touches the storage: the reference builds a ``RedisStorage`` inside
+    ``__setstate__`` (lazy TCP, lshrs/core/main.py:1010-1044); here the client may not even be importable in the
+    process that unpickles (a GPU worker that only hashes), so the storage is resolved on first use."""
+
+    def __init__(self, redis_config: Dict[str, Any]) -> None:
+        object.__setattr__(self, "_cfg", dict(redis_config))
+        object.__setattr__(self, "_real", None)
+
+    def _resolve(self):
+        if self._real is None:
+            rc = self._cfg
+            object.__setattr__(self, "_real", default_storage(
+                host=rc["host"], port=rc["port"], db=rc["db"], password=rc["password"],
+                decode_responses=rc["decode_responses"], prefix=rc["prefix"], max_connections=rc["max_connections"]))
+        return self._real
+
+    def __getattr__(self, item):
+        if item in ("batch_add_csr", "batch_add_packed", "get_buckets_many") and self._real is None:
+            raise AttributeError(item)          # (capability probes must not open a connection)
+        return getattr(self._resolve(), item)
 
 
 class LSHRS:
@@ -163,12 +187,23 @@ class LSHRS:
                 "Number of vectors does not match number of indices "
                 f"(received {arr.shape[0]} vectors for {len(indices)} indices)")
 
-        ids = [int(i) for i in indices]
+        packed = self._packed_ingest and (hasattr(self._storage, "batch_add_csr") or hasattr(self._storage, "batch_add_packed"))
+        if packed:
+            id_arr = np.asarray(indices)
+            id_arr = id_arr.astype(np.int64) if id_arr.dtype.kind in "iuf" else np.array([int(i) for i in indices], dtype=np.int64)
+            ids = id_arr
+        else:
+            ids = [int(i) for i in indices]
+            id_arr = None
         keys, flags = self._hasher.hash_batch_packed(arr, return_row_flags=True)
 
         # first row the per-vector loop of the reference would have choked on, and why
         stop, error = len(ids), None
-        neg = next((j for j, i in enumerate(ids) if i < 0), None)
+        if id_arr is not None:
+            negs = np.flatnonzero(id_arr < 0)
+            neg = int(negs[0]) if negs.size else None
+        else:
+            neg = next((j for j, i in enumerate(ids) if i < 0), None)
         zero_rows = np.flatnonzero(flags & 1)
         zero = int(zero_rows[0]) if zero_rows.size else None
         if neg is not None and (zero is None or neg <= zero):
@@ -176,14 +211,19 @@ class LSHRS:
         elif zero is not None:
             stop, error = zero, ValueError(_ZERO_MSG)
 
-        if self._packed_ingest and hasattr(self._storage, "batch_add_packed"):
+        if packed:
             # array path: same buckets, same members, no per-operation Python objects.
             # Anything already buffered goes first so the storage sees operations in the original order.
             self.flush()
-            per_call = max(1, -(-self._buffer_size // keys.shape[1]))  # vectors per storage call ~ buffer_size ops
-            for lo in range(0, stop, per_call):
-                hi = min(stop, lo + per_call)
-                self._storage.batch_add_packed(ids[lo:hi], keys[lo:hi])
+            if hasattr(self._storage, "batch_add_csr"):
+                # the whole batch (the rows in front of a bad one) as ONE bucket CSR, grouped on the device
+                if stop:
+                    self._storage.batch_add_csr(_bucket_csr(id_arr[:stop], keys[:stop]))
+            else:
+                per_call = max(1, -(-self._buffer_size // keys.shape[1]))  # vectors per storage call ~ buffer_size ops
+                for lo in range(0, stop, per_call):
+                    hi = min(stop, lo + per_call)
+                    self._storage.batch_add_packed(id_arr[lo:hi], keys[lo:hi])
             if error is not None:
                 raise error
             return
@@ -292,10 +332,7 @@ class LSHRS:
         keys, flags = self._hasher.hash_batch_packed(arr, return_row_flags=True)
         if (flags & 1).any():
             raise ValueError(_ZERO_MSG)
-        ordered_ids: List[List[int]] = []
-        for qi in range(nq):
-            counts = self._candidate_counts_from_keys(keys[qi])
-            ordered_ids.append([idx for idx, _ in sorted(counts.items(), key=lambda item: (-item[1], item[0]))])
+        ordered_ids = self._ordered_candidates_many(keys)
         if top_p is None:
             return [ids if top_k is None else ids[:top_k] for ids in ordered_ids]
 
@@ -398,16 +435,36 @@ class LSHRS:
         """Config + hyperplanes; buffer is flushed, fetch function and storage are not carried
         (reference: main.py:989-1008)."""
         self.flush()
-        return {"config": self._config.copy(), "redis_config": self._redis_config.copy(),
-                "projections": [np.asarray(m, dtype=np.float32) for m in self._hasher.projections]}
+        state = {"config": self._config.copy(), "redis_config": self._redis_config.copy(),
+                 "projections": [np.asarray(m, dtype=np.float32) for m in self._hasher.projections]}
+        # extras the reference's __setstate__ ignores (it reads the three keys above): what this build needs to come
+        # back on the same device with the same windows and ingest mode
+        h = self._hasher
+        state["lshrs_amd"] = {
+            "packed_ingest": self._packed_ingest,
+            "device": getattr(h, "_device", None) if isinstance(getattr(h, "_device", None), (int, str, type(None))) else str(h._device),
+            "hasher_kwargs": {k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard", "pipeline",
+                                                          "tie_threads") if hasattr(h, k)},
+            "windows": {"tau_ulps": "bound" if getattr(h, "window_mode", {}).get("tau") == "bound" else getattr(h, "tau_ulps", 8.0),
+                        "tau1_ulps": "bound" if getattr(h, "window_mode", {}).get("tau1") == "bound" else getattr(h, "tau1_ulps", 64.0)},
+        }
+        return state
 
     def __setstate__(self, state: Dict[str, Any]) -> None:
         cfg, rc = state["config"], state["redis_config"]
+        extra = state.get("lshrs_amd", {})
+        hasher = None
+        if extra:
+            hk = dict(extra.get("hasher_kwargs", {}))
+            hk.update(extra.get("windows", {}))
+            hasher = LSHHasher(num_bands=cfg["num_bands"], rows_per_band=cfg["rows_per_band"], dim=cfg["dim"],
+                               seed=cfg["seed"], device=extra.get("device"), **hk)
         restored = self.__class__(
             dim=cfg["dim"], num_perm=cfg["num_perm"], num_bands=cfg["num_bands"], rows_per_band=cfg["rows_per_band"],
             similarity_threshold=cfg["similarity_threshold"], buffer_size=cfg["buffer_size"], vector_fetch_fn=None,
             redis_host=rc["host"], redis_port=rc["port"], redis_db=rc["db"], redis_password=rc["password"],
-            redis_prefix=rc["prefix"], decode_responses=rc["decode_responses"], seed=cfg["seed"])
+            redis_prefix=rc["prefix"], decode_responses=rc["decode_responses"], seed=cfg["seed"], hasher=hasher,
+            packed_ingest=bool(extra.get("packed_ingest", False)), storage=_DeferredStorage(rc))
         self.__dict__ = restored.__dict__
         self._hasher.projections = [np.asarray(m, dtype=np.float32) for m in state["projections"]]
 
@@ -427,6 +484,41 @@ class LSHRS:
             for candidate in self._storage.get_bucket(band_id, band_keys[band_id].tobytes()):
                 counts[candidate] = counts.get(candidate, 0) + 1
         return counts
+
+    def _ordered_candidates_many(self, keys: np.ndarray) -> List[List[int]]:
+        """For every query: the stored ids that share at least one band bucket with it, ordered by (-collisions, id) -
+        ``_candidate_counts`` + the sort of ``query`` (lshrs/core/main.py:1088-1111, :614) for a whole batch, as array
+        work: bucket members are gathered as flat (query, member) pairs, one sort counts the collisions, one orders the
+        candidates.  No Python object per member."""
+        nq, nb = keys.shape[0], keys.shape[1]
+        if hasattr(self._storage, "get_buckets_many"):
+            q, m = self._storage.get_buckets_many(keys)
+        else:   # the reference's storage interface: one bucket read per (query, band), members concatenated
+            qs, ms = [], []
+            for qi in range(nq):
+                for band_id in range(nb):
+                    mem = self._storage.get_bucket(band_id, keys[qi, band_id].tobytes())
+                    if mem:
+                        ms.append(np.fromiter((int(v) for v in mem), dtype=np.int64, count=len(mem)))
+                        qs.append(np.full(len(mem), qi, dtype=np.int64))
+            q = np.concatenate(qs) if qs else np.empty(0, np.int64)
+            m = np.concatenate(ms) if ms else np.empty(0, np.int64)
+        out: List[List[int]] = [[] for _ in range(nq)]
+        if q.size == 0:
+            return out
+        order = np.lexsort((m, q))                           # by query, then member
+        q, m = q[order], m[order]
+        first = np.r_[True, (q[1:] != q[:-1]) | (m[1:] != m[:-1])]
+        starts = np.flatnonzero(first)
+        counts = np.diff(np.r_[starts, q.shape[0]])
+        uq, um = q[starts], m[starts]
+        rank = np.lexsort((um, -counts, uq))                 # by query, then -collisions, then id
+        uq, um = uq[rank], um[rank]
+        bounds = np.searchsorted(uq, np.arange(nq + 1))
+        flat = um.tolist()
+        for qi in range(nq):
+            out[qi] = flat[bounds[qi]:bounds[qi + 1]]
+        return out
 
     def _enqueue_packed(self, index: int, band_keys: np.ndarray) -> None:
         ops = [(b, band_keys[b].tobytes(), index) for b in range(band_keys.shape[0])]

@@ -782,6 +782,40 @@ __global__ void keys_to_hex_kernel(const uint8_t* __restrict__ keys, int64_t nby
   }
 }
 
+// Storage-op path: the (band, key) buckets of a batch as a CSR, by a counting sort per band.  One thread
+// per vector: its key row is one contiguous read, its num_bands bucket indices go through atomics on a table of
+// num_bands << (8 * band_bytes) bins (4 MB at 16 bands x 16-bit keys: L2-resident).  bin = band << (8 B) | key, the key
+// read little-endian (key bytes = bin & 0xFF, (bin >> 8) & 0xFF).
+template <int BB>
+__global__ void bucket_histogram_kernel(const uint8_t* __restrict__ keys, int64_t n, int num_bands,
+                                        int32_t* __restrict__ counts) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const uint8_t* k = keys + row * (int64_t)num_bands * BB;
+  for (int b = 0; b < num_bands; ++b) {
+    const unsigned key = BB == 1 ? (unsigned)k[b] : ((unsigned)k[2 * b] | ((unsigned)k[2 * b + 1] << 8));
+    atomicAdd(counts + (((size_t)b << (8 * BB)) | key), 1);
+  }
+}
+
+// members[offsets[bin] + (arrival order within the bin)] = ids[row]: the order inside a bucket is unspecified (the
+// buckets are sets - SADD, lshrs/storage/redis.py:408-416).
+template <int BB>
+__global__ void bucket_scatter_kernel(const uint8_t* __restrict__ keys, const int64_t* __restrict__ ids, int64_t n,
+                                      int num_bands, const int64_t* __restrict__ offsets, int32_t* __restrict__ cursors,
+                                      int64_t* __restrict__ members) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const uint8_t* k = keys + row * (int64_t)num_bands * BB;
+  const int64_t id = ids[row];
+  for (int b = 0; b < num_bands; ++b) {
+    const unsigned key = BB == 1 ? (unsigned)k[b] : ((unsigned)k[2 * b] | ((unsigned)k[2 * b + 1] << 8));
+    const size_t bin = ((size_t)b << (8 * BB)) | key;
+    const int pos = atomicAdd(cursors + bin, 1);
+    members[offsets[bin] + pos] = id;
+  }
+}
+
 __global__ void scatter_keys_kernel(uint8_t* __restrict__ keys, int num_bands, int bb, const int64_t* __restrict__ rows,
                                     const int32_t* __restrict__ bands, const uint8_t* __restrict__ patch, int64_t m) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1902,6 +1936,36 @@ int lshrs_keys_to_hex_u8(const uint8_t* keys, int64_t nbytes, uint8_t* hex, void
   if ((threads + 255) / 256 > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
   hipLaunchKernelGGL(keys_to_hex_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), keys, nbytes, hex);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_bucket_histogram_u8(const uint8_t* keys, int64_t n, int32_t num_bands, int32_t band_bytes, int32_t* counts,
+                              void* stream) {
+  if (n == 0) return 0;
+  if (keys == nullptr || counts == nullptr || n < 0 || num_bands <= 0) return LSHRS_E_BADARG;
+  if (band_bytes < 1 || band_bytes > 2 || num_bands > 32768 || (n + 255) / 256 > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (band_bytes == 1)
+    hipLaunchKernelGGL(bucket_histogram_kernel<1>, grid, block, 0, s, keys, n, num_bands, counts);
+  else
+    hipLaunchKernelGGL(bucket_histogram_kernel<2>, grid, block, 0, s, keys, n, num_bands, counts);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_bucket_scatter_u8(const uint8_t* keys, const int64_t* ids, int64_t n, int32_t num_bands, int32_t band_bytes,
+                            const int64_t* offsets, int32_t* cursors, int64_t* members, void* stream) {
+  if (n == 0) return 0;
+  if (keys == nullptr || ids == nullptr || offsets == nullptr || cursors == nullptr || members == nullptr || n < 0 ||
+      num_bands <= 0)
+    return LSHRS_E_BADARG;
+  if (band_bytes < 1 || band_bytes > 2 || num_bands > 32768 || (n + 255) / 256 > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (band_bytes == 1)
+    hipLaunchKernelGGL(bucket_scatter_kernel<1>, grid, block, 0, s, keys, ids, n, num_bands, offsets, cursors, members);
+  else
+    hipLaunchKernelGGL(bucket_scatter_kernel<2>, grid, block, 0, s, keys, ids, n, num_bands, offsets, cursors, members);
   return -(int)hipGetLastError();
 }
 

@@ -8,21 +8,122 @@ same bucket key text ``{prefix}:{band}:bucket:{hex}``, the same members — but 
   * ``hex_keys``          all N x bands key texts in one device pass (``lshrs_keys_to_hex_u8``);
   * ``group_by_bucket``   per band, the distinct keys and the ids that fall into each (NumPy, no Python loop
                           over vectors);
+  * ``bucket_csr``        the same grouping as ONE compressed-row structure for the whole batch - distinct buckets,
+                          their offsets, the member ids bucket by bucket - built by a counting sort per band on the
+                          device (``lshrs_bucket_histogram_u8`` / ``lshrs_bucket_scatter_u8``; keys of 1 or 2 bytes)
+                          or by NumPy sorts (wider keys): no Python object per vector, per operation or per bucket;
   * ``RedisPackedWriter`` one ``SADD key m1 m2 ...`` per *bucket* through the reference's own
                           ``RedisStorage.pipeline()`` / ``bucket_key()`` (same set contents as one SADD per
                           member, far fewer commands);
-  * ``InMemoryStorage.batch_add_packed`` (in storage.py) consumes the same groups.
+  * ``InMemoryStorage.batch_add_packed`` / ``batch_add_csr`` (in storage.py) consume the same groups.
 """
 
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Iterator, List, Sequence, Tuple
 
 import numpy as np
 
 from . import _native
 
-__all__ = ["hex_keys", "hex_keys_device", "group_by_bucket", "RedisPackedWriter"]
+__all__ = ["hex_keys", "hex_keys_device", "group_by_bucket", "bucket_csr", "BucketCSR", "RedisPackedWriter"]
+
+
+@dataclass
+class BucketCSR:
+    """The buckets one batch touches.  Bucket ``g`` is ``(bands[g], key_bytes[g].tobytes())`` and holds
+    ``members[offsets[g]:offsets[g + 1]]`` (order inside a bucket unspecified: buckets are sets).  Buckets are sorted
+    by ``codes`` = band << (8 * band_bytes) | little-endian key, which is what lookups bisect on."""
+
+    band_bytes: int
+    bands: np.ndarray        # (m,) int32
+    key_bytes: np.ndarray    # (m, band_bytes) uint8
+    codes: np.ndarray        # (m,) int64 for band_bytes <= 6, else None
+    offsets: np.ndarray      # (m + 1,) int64
+    members: np.ndarray      # (n * num_bands,) int64
+    vectors: int
+
+    def __len__(self) -> int:
+        return int(self.bands.shape[0])
+
+
+def key_codes(keys: np.ndarray) -> np.ndarray:
+    """(..., bands, B) key bytes -> (..., bands) int64 codes ``band << 8B | little-endian key`` (B <= 6)."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint8)
+    nb, bb = keys.shape[-2], keys.shape[-1]
+    if bb > 6:
+        raise ValueError("key codes need band keys of at most 6 bytes")
+    code = np.zeros(keys.shape[:-1], dtype=np.int64)
+    for j in range(bb):
+        code |= keys[..., j].astype(np.int64) << (8 * j)
+    return code | (np.arange(nb, dtype=np.int64) << (8 * bb))
+
+
+def _csr_host(id_arr: np.ndarray, keys: np.ndarray) -> BucketCSR:
+    n, nb, bb = keys.shape
+    if bb <= 6:
+        codes = key_codes(keys).reshape(-1)                      # vector-major, band-minor
+        order = np.argsort(codes, kind="stable")
+        sc = codes[order]
+        starts = np.flatnonzero(np.r_[True, sc[1:] != sc[:-1]])
+        ucodes = sc[starts]
+        bands = (ucodes >> (8 * bb)).astype(np.int32)
+        kb = np.empty((ucodes.shape[0], bb), dtype=np.uint8)
+        for j in range(bb):
+            kb[:, j] = (ucodes >> (8 * j)) & 0xFF
+        members = np.repeat(id_arr, nb)[order]
+        return BucketCSR(bb, bands, kb, ucodes, np.r_[starts, n * nb].astype(np.int64), members, n)
+    parts = [(band, key, mem) for band, key, mem in group_by_bucket(id_arr, keys)]
+    bands = np.array([p[0] for p in parts], dtype=np.int32)
+    kb = np.frombuffer(b"".join(p[1] for p in parts), dtype=np.uint8).reshape(-1, bb).copy()
+    lens = np.array([len(p[2]) for p in parts], dtype=np.int64)
+    return BucketCSR(bb, bands, kb, None, np.r_[0, np.cumsum(lens)].astype(np.int64),
+                     np.concatenate([p[2] for p in parts]) if parts else np.empty(0, np.int64), n)
+
+
+def bucket_csr(ids: Sequence[int], keys, *, device=None) -> BucketCSR:
+    """Group a batch's ``(n, bands, B)`` keys into buckets: one :class:`BucketCSR`.  ``B <= 2`` (every BASELINE config
+    but config 5): counting sort on the device; wider keys: NumPy sorts on the host.  ``keys`` may be the NumPy array
+    ``hash_batch_packed`` returns or the device tensor ``hash_device`` returns."""
+    torch = _native.require_gpu()
+    id_arr = np.ascontiguousarray(np.asarray(ids, dtype=np.int64))
+    on_dev = isinstance(keys, torch.Tensor)
+    n, nb, bb = (int(v) for v in keys.shape)
+    if id_arr.shape[0] != n:
+        raise ValueError("ids and keys disagree in length")
+    if n == 0 or bb > 2:
+        host_keys = keys.cpu().numpy() if on_dev else np.ascontiguousarray(keys, dtype=np.uint8)
+        return _csr_host(id_arr, host_keys)
+    lib = _native.load()
+    if on_dev:
+        kd = keys.contiguous()
+        dev = kd.device
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        kd = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.uint8)).to(dev)
+    bins = nb << (8 * bb)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        idd = torch.from_numpy(id_arr).to(dev)
+        counts = torch.zeros(bins, dtype=torch.int32, device=dev)
+        _native.check(lib.lshrs_bucket_histogram_u8(kd.data_ptr(), n, nb, bb, counts.data_ptr(), stream),
+                      "lshrs_bucket_histogram_u8")
+        ends = torch.cumsum(counts, 0, dtype=torch.int64)
+        offsets = ends - counts
+        cursors = torch.zeros(bins, dtype=torch.int32, device=dev)
+        members = torch.empty(n * nb, dtype=torch.int64, device=dev)
+        _native.check(lib.lshrs_bucket_scatter_u8(kd.data_ptr(), idd.data_ptr(), n, nb, bb, offsets.data_ptr(),
+                                                  cursors.data_ptr(), members.data_ptr(), stream),
+                      "lshrs_bucket_scatter_u8")
+        counts_h = counts.cpu().numpy()
+        members_h = members.cpu().numpy()
+    live = np.flatnonzero(counts_h).astype(np.int64)             # ascending bin = ascending code
+    kb = np.empty((live.shape[0], bb), dtype=np.uint8)
+    for j in range(bb):
+        kb[:, j] = (live >> (8 * j)) & 0xFF
+    return BucketCSR(bb, (live >> (8 * bb)).astype(np.int32), kb, live,
+                     np.r_[0, np.cumsum(counts_h[live], dtype=np.int64)].astype(np.int64), members_h, n)
 
 
 def hex_keys_device(keys):
@@ -100,6 +201,19 @@ class RedisPackedWriter:
                 name = self.storage.bucket_key(band, key_bytes)
                 for lo in range(0, len(members), self.max_members):
                     pipe.sadd(name, *[int(m) for m in members[lo:lo + self.max_members]])
+                    commands += 1
+        return commands
+
+    def batch_add_csr(self, csr: BucketCSR) -> int:
+        """The same commands from a :class:`BucketCSR`: key texts by ``bucket_key`` (the reference's format), members
+        as array slices."""
+        commands = 0
+        with self.storage.pipeline() as pipe:
+            for g in range(len(csr)):
+                name = self.storage.bucket_key(int(csr.bands[g]), csr.key_bytes[g].tobytes())
+                lo, hi = int(csr.offsets[g]), int(csr.offsets[g + 1])
+                for a in range(lo, hi, self.max_members):
+                    pipe.sadd(name, *csr.members[a:min(hi, a + self.max_members)].tolist())
                     commands += 1
         return commands
 

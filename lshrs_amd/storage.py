@@ -17,6 +17,8 @@ from __future__ import annotations
 import threading
 from typing import Dict, Iterable, List, Set, Tuple
 
+import numpy as np
+
 BucketOperation = Tuple[int, bytes, int]  # (band_id, band key, vector index) — redis.py:37
 
 __all__ = ["BucketOperation", "InMemoryStorage", "default_storage"]
@@ -32,6 +34,7 @@ class InMemoryStorage:
         self._fail_on_flush = fail_on_flush
         self.batches: List[List[BucketOperation]] = []
         self.packed_batches: List[Tuple[int, int]] = []   # (vectors, distinct buckets) per batch_add_packed call
+        self._segments: list = []                         # BucketCSR of every batch_add_csr call (array-backed buckets)
         self.closed = False
 
     # key format of the reference (redis.py:187-225)
@@ -44,7 +47,71 @@ class InMemoryStorage:
 
     def get_bucket(self, band_id: int, hash_val: bytes) -> Set[int]:
         with self._lock:
-            return set(self._buckets.get(self.bucket_key(band_id, hash_val), ()))
+            out = set(self._buckets.get(self.bucket_key(band_id, hash_val), ()))
+            segments = list(self._segments)
+        key = bytes(hash_val)
+        for seg in segments:
+            if len(key) != seg.band_bytes or len(seg) == 0:
+                continue
+            if seg.codes is not None:
+                code = (int(band_id) << (8 * seg.band_bytes)) | int.from_bytes(key, "little")
+                g = int(np.searchsorted(seg.codes, code))
+                hit = g < len(seg) and int(seg.codes[g]) == code
+            else:
+                cand = np.flatnonzero((seg.bands == band_id) & (seg.key_bytes == np.frombuffer(key, np.uint8)).all(axis=1))
+                hit, g = cand.size > 0, int(cand[0]) if cand.size else 0
+            if hit:
+                out.update(seg.members[seg.offsets[g]:seg.offsets[g + 1]].tolist())
+        return out
+
+    def get_buckets_many(self, keys) -> Tuple[np.ndarray, np.ndarray]:
+        """Every member of every bucket a batch of queries touches, as two flat arrays ``(query index, member id)`` - one
+        pair per (query, band, member) - without a Python object per member (the collision count of
+        ``LSHRS._candidate_counts``, lshrs/core/main.py:1101-1109, then is one sort).  ``keys``: (q, bands, B) uint8."""
+        from .packed_ops import key_codes
+
+        keys = np.ascontiguousarray(keys, dtype=np.uint8)
+        nq, nb, bb = keys.shape
+        qs, ms = [], []
+        with self._lock:
+            segments = list(self._segments)
+            loose = bool(self._buckets)
+        if loose:                                       # buckets built from op tuples: dict lookups, per (query, band)
+            for qi in range(nq):
+                for b in range(nb):
+                    mem = self._buckets.get(self.bucket_key(b, keys[qi, b].tobytes()))
+                    if mem:
+                        ms.append(np.fromiter(mem, dtype=np.int64, count=len(mem)))
+                        qs.append(np.full(len(mem), qi, dtype=np.int64))
+        codes = key_codes(keys).reshape(-1) if bb <= 6 else None
+        qidx = np.repeat(np.arange(nq, dtype=np.int64), nb)
+        for seg in segments:
+            if seg.band_bytes != bb or len(seg) == 0:
+                continue
+            if codes is None or seg.codes is None:
+                for qi in range(nq):
+                    for b in range(nb):
+                        mem = self.get_bucket(b, keys[qi, b].tobytes())
+                        if mem:
+                            ms.append(np.fromiter(mem, dtype=np.int64, count=len(mem)))
+                            qs.append(np.full(len(mem), qi, dtype=np.int64))
+                return (np.concatenate(qs) if qs else np.empty(0, np.int64),
+                        np.concatenate(ms) if ms else np.empty(0, np.int64))
+            g = np.searchsorted(seg.codes, codes)
+            g[g >= len(seg)] = 0
+            hit = seg.codes[g] == codes
+            g, q = g[hit], qidx[hit]
+            lo = seg.offsets[g]
+            lens = seg.offsets[g + 1] - lo
+            total = int(lens.sum())
+            if total == 0:
+                continue
+            # positions lo[i] .. lo[i] + lens[i] for every hit i, concatenated
+            starts = np.cumsum(lens) - lens
+            pos = np.arange(total, dtype=np.int64) - np.repeat(starts, lens) + np.repeat(lo, lens)
+            ms.append(seg.members[pos])
+            qs.append(np.repeat(q, lens))
+        return (np.concatenate(qs) if qs else np.empty(0, np.int64), np.concatenate(ms) if ms else np.empty(0, np.int64))
 
     def batch_add(self, operations: Iterable[BucketOperation]) -> None:
         ops = list(operations)
@@ -68,20 +135,59 @@ class InMemoryStorage:
             for band, key_bytes, members in groups:
                 self._buckets.setdefault(self.bucket_key(band, key_bytes), set()).update(members.tolist())
 
+    def batch_add_csr(self, csr) -> None:
+        """A whole batch's buckets as one :class:`lshrs_amd.packed_ops.BucketCSR`: kept as arrays (an O(1) append; no
+        Python object per member or per bucket), consulted by ``get_bucket`` / ``get_buckets_many`` by bisection."""
+        if self._fail_on_flush:
+            raise ConnectionError("simulated storage failure")
+        with self._lock:
+            self.packed_batches.append((int(csr.vectors), len(csr)))
+            self._segments.append(csr)
+
     def remove_indices(self, indices: Iterable[int]) -> None:
         gone = {int(i) for i in indices}
         with self._lock:
             for members in self._buckets.values():
                 members -= gone
+            if self._segments:
+                from .packed_ops import BucketCSR
+
+                gone_arr = np.fromiter(gone, dtype=np.int64, count=len(gone))
+                kept = []
+                for seg in self._segments:
+                    keep = ~np.isin(seg.members, gone_arr)
+                    if keep.all():
+                        kept.append(seg)
+                        continue
+                    lens = np.add.reduceat(keep.astype(np.int64), seg.offsets[:-1]) if len(seg) else np.empty(0, np.int64)
+                    lens[seg.offsets[:-1] == seg.offsets[1:]] = 0
+                    live = lens > 0
+                    kept.append(BucketCSR(seg.band_bytes, seg.bands[live], seg.key_bytes[live],
+                                          None if seg.codes is None else seg.codes[live],
+                                          np.r_[0, np.cumsum(lens[live])].astype(np.int64), seg.members[keep], seg.vectors))
+                self._segments = kept
 
     def clear(self) -> None:
         with self._lock:
             self._buckets.clear()
+            self._segments = []
 
     def close(self) -> None:
         self.closed = True
 
     # conveniences for tests / stats
+    def bucket_contents(self) -> Dict[str, Set[int]]:
+        """Every non-empty bucket, ``{prefix}:{band}:bucket:{hex}`` -> set of ids (op-tuple buckets and array segments
+        merged)."""
+        with self._lock:
+            out = {k: set(v) for k, v in self._buckets.items() if v}
+            segments = list(self._segments)
+        for seg in segments:
+            for g in range(len(seg)):
+                name = self.bucket_key(int(seg.bands[g]), seg.key_bytes[g].tobytes())
+                out.setdefault(name, set()).update(seg.members[seg.offsets[g]:seg.offsets[g + 1]].tolist())
+        return out
+
     @property
     def total_operations(self) -> int:
         with self._lock:

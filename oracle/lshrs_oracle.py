@@ -288,3 +288,37 @@ def index_literal(storage, indices, vectors, projections: Sequence[np.ndarray], 
         storage.batch_add(list(buffer))
         flushes += 1
     return flushes
+
+
+def query_literal(storage, projections: Sequence[np.ndarray], dim: int, vector, *, top_k=10, top_p=None, fetch=None):
+    """lshrs/core/main.py:524-658 (query) with :1088-1111 (_candidate_counts) inlined: hash the query, read one bucket
+    per band, count collisions per stored id, order by (-count, id); without ``top_p`` the first ``top_k`` ids, with it
+    the candidates reranked by ``top_k_cosine`` and cut to ``max(1, ceil(n * top_p))`` (and ``top_k``)."""
+    import math
+
+    q = prepare_vector(vector, dim)
+    counts: dict = {}
+    for band_id, hash_val in enumerate(hash_vector_literal(projections, q, dim)):
+        for candidate in storage.get_bucket(band_id, hash_val):
+            counts[candidate] = counts.get(candidate, 0) + 1
+    if not counts:
+        return []
+    ordered = sorted(counts.items(), key=lambda item: (-item[1], item[0]))
+    if top_p is None:
+        if top_k is None:
+            top_k = len(ordered)
+        if top_k <= 0:
+            raise ValueError("top_k must be greater than zero when provided")
+        return [idx for idx, _ in ordered[:top_k]]
+    if not 0 < top_p <= 1:
+        raise ValueError("top_p must be within the range (0, 1]")
+    candidate_indices = [idx for idx, _ in ordered]
+    arr = np.asarray(fetch(candidate_indices), dtype=np.float32)
+    ranked = top_k_cosine(q, arr, k=len(candidate_indices))
+    scored = [(candidate_indices[pos], score) for pos, score in ranked]
+    limit = max(1, math.ceil(len(scored) * top_p))
+    if top_k is not None:
+        if top_k <= 0:
+            raise ValueError("top_k must be greater than zero when provided")
+        limit = min(limit, top_k)
+    return scored[:limit]

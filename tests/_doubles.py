@@ -38,6 +38,11 @@ def make_cpu_lshrs(monkeypatch, **kw):
     kw["hasher"] = OracleBackedHasher(nb, r, dim, kw.get("seed", 42))
     monkeypatch.setattr(core, "top_k_cosine", O.top_k_cosine)
     monkeypatch.setattr(core, "_rerank_padded", oracle_rerank_padded)
+    from lshrs_amd import packed_ops
+
+    # (the device counting sort needs a GPU; the host grouping builds the same structure)
+    monkeypatch.setattr(core, "_bucket_csr", lambda ids, keys: packed_ops._csr_host(
+        np.ascontiguousarray(np.asarray(ids, dtype=np.int64)), np.ascontiguousarray(keys, dtype=np.uint8)))
     return LSHRS(**kw)
 
 

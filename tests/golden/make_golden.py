@@ -18,6 +18,7 @@ inputs, and stores inputs' seeds + the reference's outputs as data:
   g5_orchestration.json LSHRS.index batches, get_top_k / get_above_p results, error timing
   g6_autoconfig.json    get_optimal_config table
   g7_saved_index/       an index directory written by the reference's save_to_disk
+  g8_queries_768.json   100 queries against 3 000 clustered 768-d vectors (num_perm 256): query() results
 
 Fixtures are data only (inputs are regenerated from seeds by the tests).
 """
@@ -263,6 +264,29 @@ def main() -> None:
                     "batches": [len(b) for b in store4.batches], "ops_sha256": h.hexdigest(),
                     "top_k_row0": idx4.get_top_k(x1[0], topk=5)}
         json.dump(g5, open(os.path.join(OUT, "g5_orchestration.json"), "w"), indent=1)
+
+        # ---- G8 queries at the headline shape: 3 000 clustered 768-d vectors, 100 queries ----------
+        # (inputs are regenerated from the seeds below, only the reference's answers are stored)
+        rng8 = np.random.default_rng(801)
+        centers = rng8.standard_normal((300, 768)).astype(np.float32)
+        data8 = (np.repeat(centers, 10, axis=0) + 0.3 * rng8.standard_normal((3000, 768))).astype(np.float32)
+        store8 = MockStorage()
+        idx8 = LSHRS(dim=768, num_perm=256, storage=store8, buffer_size=10_000, seed=42,
+                     vector_fetch_fn=lambda ids: data8[np.asarray(ids)])
+        idx8.index(list(range(3000)), data8)
+        qrows = rng8.choice(3000, 100, replace=False)
+        queries8 = (data8[qrows] + 0.05 * rng8.standard_normal((100, 768))).astype(np.float32)
+        h8 = hashlib.sha256()
+        for batch in store8.batches:
+            for b, k, i in batch:
+                h8.update(bytes([b]) + k + int(i).to_bytes(4, "little"))
+        g8 = {"seed": 801, "num_bands": idx8._hasher.num_bands, "rows_per_band": idx8._hasher.rows_per_band,
+              "ops_sha256": h8.hexdigest(), "query_rows": [int(v) for v in qrows],
+              "top_k_10": [idx8.query(qv, top_k=10, top_p=None) for qv in queries8],
+              "top_k_all": [idx8.query(qv, top_k=None, top_p=None) for qv in queries8],
+              "above_p_half": [[[int(i), float(s)] for i, s in idx8.query(qv, top_k=None, top_p=0.5)] for qv in queries8],
+              "topk3_topp1": [[[int(i), float(s)] for i, s in idx8.query(qv, top_k=3, top_p=1.0)] for qv in queries8]}
+        json.dump(g8, open(os.path.join(OUT, "g8_queries_768.json"), "w"))
 
         # ---- G7 persistence: an index directory written by the reference itself ---------------
         import shutil

@@ -776,7 +776,7 @@ def test_mfma_bf16_step_error(torch_mod):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools", "probes"))
-    import mfma_probe
+    import mfma_probe_run as mfma_probe
 
     so = os.path.join(root, "tools", "probes", "mfma_probe.so")
     if not os.path.exists(so):

@@ -154,3 +154,42 @@ def test_chain_model_agrees_with_blas_up_to_rounding():
     diff_rows = (a != b).any(axis=(1, 2))
     assert (np.abs(y64).min(axis=1)[diff_rows] < 1e-3).all()
     assert diff_rows.sum() <= 2
+
+
+def g8_inputs():
+    rng8 = np.random.default_rng(801)
+    centers = rng8.standard_normal((300, 768)).astype(np.float32)
+    data = (np.repeat(centers, 10, axis=0) + 0.3 * rng8.standard_normal((3000, 768))).astype(np.float32)
+    qrows = rng8.choice(3000, 100, replace=False)
+    queries = (data[qrows] + 0.05 * rng8.standard_normal((100, 768))).astype(np.float32)
+    return data, qrows, queries
+
+
+def test_g8_queries_at_768d(golden_dir):
+    """The oracle's restatement of index() + query() against what the reference itself answered for 100 queries on
+    3 000 clustered 768-d vectors (tests/golden/make_golden.py, G8) - the pin of SURVEY §8f-2's path."""
+    import hashlib
+
+    from lshrs_amd import InMemoryStorage
+
+    g8 = json.load(open(os.path.join(golden_dir, "g8_queries_768.json")))
+    data, qrows, queries = g8_inputs()
+    assert [int(v) for v in qrows] == g8["query_rows"]
+    P = O.make_projections(g8["num_bands"], g8["rows_per_band"], 768, 42)
+    store = InMemoryStorage()
+    O.index_literal(store, list(range(3000)), data, P, 768, 10_000)
+    h = hashlib.sha256()
+    for batch in store.batches:
+        for b, k, i in batch:
+            h.update(bytes([b]) + k + int(i).to_bytes(4, "little"))
+    if h.hexdigest() != g8["ops_sha256"]:
+        pytest.skip("this CPU's BLAS rounds a near-zero projection of the g8 data differently from the build container's")
+    fetch = lambda ids: data[np.asarray(ids)]  # noqa: E731
+    for qi, q in enumerate(queries):
+        assert O.query_literal(store, P, 768, q, top_k=10) == g8["top_k_10"][qi]
+        assert O.query_literal(store, P, 768, q, top_k=None) == g8["top_k_all"][qi]
+        got = O.query_literal(store, P, 768, q, top_k=None, top_p=0.5, fetch=fetch)
+        assert [i for i, _ in got] == [i for i, _ in g8["above_p_half"][qi]]
+        assert np.abs(np.array([s for _, s in got]) - np.array([s for _, s in g8["above_p_half"][qi]])).max() <= 1e-6
+        got = O.query_literal(store, P, 768, q, top_k=3, top_p=1.0, fetch=fetch)
+        assert [i for i, _ in got] == [i for i, _ in g8["topk3_topp1"][qi]]

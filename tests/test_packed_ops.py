@@ -39,13 +39,11 @@ def test_packed_ingest_builds_the_same_buckets(monkeypatch):
     idx.ingest(9999, data[0])                       # something buffered: must be flushed before the packed batch
     idx.index(list(range(700)), data)
     assert packed.batches and packed.batches[0][0][2] == 9999
-    assert [n for n, _ in packed.packed_batches] == [100] * 7           # ~buffer_size operations per storage call
+    assert [n for n, _ in packed.packed_batches] == [700]               # the whole batch as one bucket CSR
     expect = {k: set(v) for k, v in plain._buckets.items()}
-    for key in packed._buckets:
-        expect.setdefault(key, set())
     for b, kb, i in packed.batches[0]:
-        expect[packed.bucket_key(b, kb)].add(i)
-    assert packed._buckets == expect
+        expect.setdefault(packed.bucket_key(b, kb), set()).add(i)
+    assert packed.bucket_contents() == expect
     assert idx.get_top_k(data[5], topk=1) == [5] or 9999 in idx.get_top_k(data[0], topk=2)
     # error timing: rows before the bad one are stored, then the same error
     bad = data[:10].copy()
@@ -54,7 +52,7 @@ def test_packed_ingest_builds_the_same_buckets(monkeypatch):
     with pytest.raises(ValueError, match="zero vector"):
         make_cpu_lshrs(monkeypatch, dim=32, num_bands=4, rows_per_band=4, num_perm=16, storage=store,
                        packed_ingest=True).index(list(range(10)), bad)
-    assert {i for s in store._buckets.values() for i in s} == set(range(6))
+    assert {i for s in store.bucket_contents().values() for i in s} == set(range(6))
 
 
 class FakePipeline:
@@ -117,3 +115,28 @@ def test_hex_kernel_equals_bytes_hex():
     assert [h.decode() for h in hex_keys(every).reshape(-1)] == [f"{v:02x}" for v in range(256)]
     dev = hex_keys_device(torch.from_numpy(every).cuda())
     assert dev.shape == (16, 16, 2) and dev.is_cuda
+
+
+@pytest.mark.gpu
+def test_device_bucket_csr_equals_host_grouping():
+    """lshrs_bucket_histogram_u8 / lshrs_bucket_scatter_u8 (counting sort per band) against the NumPy grouping: same
+    buckets, same member sets, offsets consistent; keys of 1 and 2 bytes on the device, wider ones on the host."""
+    import torch
+
+    from lshrs_amd.packed_ops import _csr_host, bucket_csr
+
+    rng = np.random.default_rng(17)
+    for (n, nb, bb, hi) in ((200_000, 16, 2, 256), (50_000, 16, 1, 16), (1, 3, 2, 256), (4097, 5, 2, 4), (3000, 16, 4, 256)):
+        keys = rng.integers(0, hi, size=(n, nb, bb), dtype=np.uint8)
+        ids = rng.permutation(10 * n + 5)[:n].astype(np.int64)
+        want = _csr_host(ids, keys)
+        for source in (keys, torch.from_numpy(keys).cuda()):
+            got = bucket_csr(ids, source)
+            assert len(got) == len(want) and got.vectors == n and got.band_bytes == bb
+            assert np.array_equal(got.bands, want.bands) and np.array_equal(got.key_bytes, want.key_bytes)
+            assert np.array_equal(got.offsets, want.offsets) and got.members.shape == (n * nb,)
+            for g in rng.choice(len(want), size=min(len(want), 300), replace=False):
+                lo, hi_ = want.offsets[g], want.offsets[g + 1]
+                assert sorted(got.members[lo:hi_].tolist()) == sorted(want.members[lo:hi_].tolist())
+            assert np.array_equal(np.sort(got.members), np.sort(want.members))
+    assert len(bucket_csr(np.empty(0, np.int64), np.empty((0, 16, 2), np.uint8))) == 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run hand-made operands through v_mfma_f32_16x16x32_{f16,bf16} (tools/probes/mfma_probe.hip) and save the raw results
-for offline modelling (tools/probes/mfma_model.py).  GPU box only:  python tools/probes/mfma_probe.py gpurun_out/mfma_probe.npz"""
+for offline modelling (tools/probes/mfma_model.py).  GPU box only:  python tools/probes/mfma_probe_run.py gpurun_out/mfma_probe.npz"""
 import ctypes
 import os
 import sys
