@@ -88,10 +88,14 @@ inline int64_t sig_t16_offset_floats(const SigGeom& g) { return sig_main_floats(
 inline bool sig_has_narrow_split(const SigGeom& g) { return g.nt < 8 && g.cb == 1 && g.padcols >= 128; }
 inline int64_t sig_narrow_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
 inline int64_t sig_narrow_image_floats(const SigGeom& g) { return (int64_t)g.ktiles * 8 * 4 * kFragFloats; }
-inline int64_t sig_workspace_floats(const SigGeom& g) {
+// Stage 2 reads whole hyperplanes: a plain row-major copy P'[padded column][32 * ktiles] (zero rows / zero tail), so
+// that a k-tile of a column is ONE 128-byte line (in the fragment image it is eight 16-byte pieces of eight lines).
+inline int64_t sig_rowmajor_floats(const SigGeom& g) { return (int64_t)g.cb * g.nt * 32 * g.ktiles * kKTile; }
+inline int64_t sig_rowmajor_offset_floats(const SigGeom& g) {
   return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? sig_image_floats(g) : 0) +
          (sig_has_narrow_split(g) ? sig_narrow_image_floats(g) + 256 + 4 : 0);
 }
+inline int64_t sig_workspace_floats(const SigGeom& g) { return sig_rowmajor_offset_floats(g) + sig_rowmajor_floats(g); }
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
 
 // Which geometry finishes a partial round (m < kRoundRows rows) sooner?  Cost model fitted to
@@ -139,6 +143,15 @@ __device__ __forceinline__ uint16_t bf16_rne_bits(float f) {
   uint32_t u = __float_as_uint(f);
   u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
   return (uint16_t)(u >> 16);
+}
+
+__global__ void pack_rowmajor_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb, int cols,
+                                     int ldp, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)cols * ldp) return;
+  const int col = (int)(t / ldp), k = (int)(t % ldp);
+  const int band = col / (bb * 8), bit = col % (bb * 8);
+  out[t] = (band < num_bands && bit < rows && k < dim) ? P[((int64_t)band * rows + bit) * dim + k] : 0.f;
 }
 
 __global__ void pack_norm_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb, int cols,
@@ -503,8 +516,7 @@ struct FixArgs {
   int64_t ldx;
   int dim;
   int ktiles;
-  int nt;                 // column tiles per column block of the f32 image
-  const float* image;     // f32 fragment image (wide geometry)
+  const float* prow;      // hyperplanes row-major: P'[padded column][ldp], ldp = 32 * ktiles
   const float* norms;
   uint8_t* keys;
   int row_bytes;
@@ -543,8 +555,9 @@ __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f3
 // from ds_read_b128s that hit eight distinct 16-byte slots (the eight lanes sharing a g read the same slot: broadcast).
 // 1/8 of the waves, the same chain length per wave: one resident round of 1536 waves covers even a 524 288-row chunk's list.
 constexpr int kFixG = 8;
-constexpr int kFixSlabG = 12;      // k-tiles per slab: 2 x 12 x 8 chunks x 8 projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is two slabs)
-constexpr int kFixGridG = 1536;    // 256 CUs x 6 resident single-wave workgroups (slabs of 24 tiles, 3 per CU: 0.085 ms of fix-ups per 1M rows; 12: 0.074; 8: 0.075)
+constexpr int kFixSlabG = 6;       // k-tiles per slab; two slabs are resident (one being read, one landing): 2 x 2 x 6 x 8 chunks x 8
+                                   // projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is four slabs)
+constexpr int kFixGridG = 1536;    // 256 CUs x 6 resident single-wave workgroups
 //
 // REPLAY: the tie-break on the device.  Every flagged projection gets the sign of the value the HOST BLAS computes for
 // it - the reference's `projection @ vector` (lshrs/hash/lsh.py:200) - and only that value is computed, by replaying
@@ -554,48 +567,77 @@ constexpr int kFixGridG = 1536;    // 256 CUs x 6 resident single-wave workgroup
 // found by search, tools/blas_order/, and checked bit for bit against `P_band @ x` of the running process before a
 // hasher uses it: lshrs_amd/hasher.py).  The eight lanes (sub) that serve one projection each own one p_j, four fmas
 // per k-tile from the slab in LDS: 96 steps for a 768-deep row where the canonical chain walks 768.  No tie list, no host.
+//
+// The slabs are double-buffered across the whole list: while slab u is read, slab u + 1 - the next slab of the same
+// eight projections or the first slab of the wave's next eight - is landing (2 x kFixSlabG LDS-DMAs per slab, always
+// exactly that many, so the waits are counted: "all but the youngest 2 x kFixSlabG").
 template <bool REPLAY>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
-  __shared__ __attribute__((aligned(16))) f32x4 xs[kFixSlabG * 8 * kFixG];
-  __shared__ __attribute__((aligned(16))) f32x4 ps[kFixSlabG * 8 * kFixG];
+  __shared__ __attribute__((aligned(16))) f32x4 xs[2][kFixSlabG * 8 * kFixG];
+  __shared__ __attribute__((aligned(16))) f32x4 ps[2][kFixSlabG * 8 * kFixG];
   const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
   const int shh = sub >> 2, sq = sub & 3;           // this lane's chunk of every k-tile: k = 32 t + 16 shh + 4 sq + 0..3
   const int cnt = min(*a.flag_count, a.flag_cap);
   const int groups = (cnt + kFixG - 1) / kFixG;
-  const size_t kt_stride = (size_t)a.nt * 4 * kFragFloats;
+  const size_t ldp = (size_t)a.ktiles * kKTile;
+  const int slabs = (a.ktiles + kFixSlabG - 1) / kFixSlabG;
   // statistics are kept per lane and leave the wave once, at the end (one atomic per flagged projection on a single
   // address serialises the whole kernel as soon as the list is long)
   int n_ties = 0, n_flips = 0;
   float max_dev = 0.f;
-  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {   // uniform per wave
-    const int e = grp * kFixG + g;
-    const int64_t item = a.flag_list[e < cnt ? e : grp * kFixG];  // a short last group re-does its first entry, unused
-    const int64_t row = item >> 21;                 // relative to this launch's X / keys
+  struct Item { int64_t row; int col; bool live; const float* xg; const float* pg; int e; };
+  auto fetch = [&](int grp) {                       // list entry g of group grp (a short last group re-does its first entry, unused)
+    Item it;
+    it.e = grp * kFixG + g;
+    const int64_t item = a.flag_list[it.e < cnt ? it.e : grp * kFixG];
+    it.row = item >> 21;                            // relative to this launch's X / keys
     const int col_raw = (int)(item & ((1 << 21) - 1));
-    const bool live = e < cnt && col_raw < a.padcols;
-    const int col = col_raw < a.padcols ? col_raw : 0;
+    it.live = it.e < cnt && col_raw < a.padcols;
+    it.col = col_raw < a.padcols ? col_raw : 0;
+    it.xg = a.X + it.row * a.ldx + 16 * shh + 4 * sq;
+    it.pg = a.prow + (size_t)it.col * ldp + 16 * shh + 4 * sq;
+    return it;
+  };
+  auto issue = [&](const Item& it, int slab, int buf) {   // nothing lands in a VGPR; tiles past the row's end re-fetch its last
+#pragma unroll
+    for (int i = 0; i < kFixSlabG; ++i) {
+      const int t = slab * kFixSlabG + i < a.ktiles ? slab * kFixSlabG + i : a.ktiles - 1;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.xg + (size_t)t * kKTile), (LDS_AS void*)(xs[buf] + i * 64),
+                                       16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.pg + (size_t)t * kKTile), (LDS_AS void*)(ps[buf] + i * 64),
+                                       16, 0, 0);
+    }
+  };
+  int grp = blockIdx.x;                             // uniform per wave
+  if (grp < groups) {
+  Item cur = fetch(grp);
+  issue(cur, 0, 0);
+  int buf = 0;
+  for (;;) {
+    const int nxt_grp = grp + (int)gridDim.x;
+    const bool has_next = nxt_grp < groups;
+    Item nxt = cur;
+    if (has_next) nxt = fetch(nxt_grp);             // (older than every DMA issued below: it is here when they are)
+    const int64_t row = cur.row;
+    const int col = cur.col, e = cur.e;
+    const bool live = cur.live;
     const int word = col >> 5, c = col & 31;
-    const int cb = word / a.nt, jt = word % a.nt;
-    const float* __restrict__ xg = a.X + row * a.ldx + 16 * shh + 4 * sq;
-    const float* __restrict__ pg =
-        a.image + ((size_t)cb * a.ktiles * a.nt + jt) * 4 * kFragFloats + ((sq * 64) + shh * 32 + c) * 4;
     float acc = 0.f, ss = 0.f, pj = 0.f;
-    for (int t0 = 0; t0 < a.ktiles; t0 += kFixSlabG) {
-      const int tiles = a.ktiles - t0 < kFixSlabG ? a.ktiles - t0 : kFixSlabG;
-      for (int i = 0; i < tiles; ++i) {            // nothing lands in a VGPR: every load of the slab is in flight at once
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + (size_t)(t0 + i) * kKTile),
-                                         (LDS_AS void*)(xs + i * 64), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + (size_t)(t0 + i) * kt_stride),
-                                         (LDS_AS void*)(ps + i * 64), 16, 0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int sl = 0; sl < slabs; ++sl) {
+      const int tiles = a.ktiles - sl * kFixSlabG < kFixSlabG ? a.ktiles - sl * kFixSlabG : kFixSlabG;
+      bool more = true;
+      if (sl + 1 < slabs) issue(cur, sl + 1, buf ^ 1);
+      else if (has_next) issue(nxt, 0, buf ^ 1);
+      else more = false;
+      if (more) wait_vmcnt<2 * kFixSlabG>();        // this slab has landed, the next one is on its way
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (REPLAY) {
         // The library's value IS the reference's for every flagged projection, tie or not: the canonical chain (768
         // dependent fmas per lane) is not needed here, only p_sub: k = 32 t + 8 m + sub, m = 0..3 = chunk
         // 2 m + (sub >> 2), element sub & 3.  (ss: this lane's share of ||x||^2, for the tie statistics only.)
-        const float* xf = reinterpret_cast<const float*>(xs);
-        const float* pf = reinterpret_cast<const float*>(ps);
-#pragma unroll 4
+        const float* xf = reinterpret_cast<const float*>(xs[buf]);
+        const float* pf = reinterpret_cast<const float*>(ps[buf]);
+#pragma unroll 3
         for (int t = 0; t < tiles; ++t) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
@@ -613,13 +655,14 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
           for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              x4[hh][q] = xs[(t * 8 + hh * 4 + q) * kFixG + g];
-              p4[hh][q] = ps[(t * 8 + hh * 4 + q) * kFixG + g];
+              x4[hh][q] = xs[buf][(t * 8 + hh * 4 + q) * kFixG + g];
+              p4[hh][q] = ps[buf][(t * 8 + hh * 4 + q) * kFixG + g];
             }
           fix_chain_tile(p4, x4, acc, ss);
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab has been read before the next one lands on it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab has been read before the one after next lands on it
+      buf ^= 1;
     }
     float yb = 0.f;
     if (REPLAY) {       // (every lane takes part in the shuffles; the result is used by the sub = 0 lanes)
@@ -630,7 +673,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       s2 += __shfl(s2, (lane + 8) & 63);
       ss = s2 + __shfl(s2, (lane + 16) & 63);
     }
-    if (sub != 0 || !live) continue;
+    if (sub == 0 && live) {
     uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
     unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
@@ -662,7 +705,12 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
         }
       }
     }
+    }   // sub == 0 && live
+    if (!has_next) break;
+    cur = nxt;
+    grp = nxt_grp;
   }
+  }   // grp < groups
   if (REPLAY) {
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) {        // the results sit in lanes 0..7 (sub = 0)
@@ -1628,6 +1676,12 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     hipLaunchKernelGGL(pack_norm_kernel, dim3(4), dim3(64), 0, s, P, num_bands, rows_per_band, dim, g.bb, 256, nnorms);
     hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, nnorms, 256, 1, nnorms + 256);
   }
+  {
+    const int ldp = g.ktiles * kKTile;
+    const int64_t total = (int64_t)cols * ldp;
+    hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                       rows_per_band, dim, g.bb, cols, ldp, image + sig_rowmajor_offset_floats(g));
+  }
   if (sig_has_split(g)) {
     const int64_t schunks = sig_image_floats(g) / 4;  // 16-byte chunks: same count as the f32 image
     float* timage = image + sig_t16_offset_floats(g);   // hi / mid bf16 parts in 16x16x32 fragment order
@@ -1763,8 +1817,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.ldx = ldx;
   f.dim = dim;
   f.ktiles = g.ktiles;
-  f.nt = g.nt;
-  f.image = base;
+  f.prow = base + sig_rowmajor_offset_floats(g);
   f.norms = a.norms;
   f.keys = keys;
   f.row_bytes = row_bytes;
@@ -1845,8 +1898,7 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   f.ldx = ldx;
   f.dim = dim;
   f.ktiles = g.ktiles;
-  f.nt = g.nt;
-  f.image = base;
+  f.prow = base + sig_rowmajor_offset_floats(g);
   f.norms = base + sig_image_floats(g);
   f.keys = keys;
   f.row_bytes = row_bytes;

@@ -62,6 +62,9 @@ def key_codes(keys: np.ndarray) -> np.ndarray:
 
 def _csr_host(id_arr: np.ndarray, keys: np.ndarray) -> BucketCSR:
     n, nb, bb = keys.shape
+    if n == 0:
+        return BucketCSR(bb, np.empty(0, np.int32), np.empty((0, bb), np.uint8), np.empty(0, np.int64) if bb <= 6 else None,
+                         np.zeros(1, np.int64), np.empty(0, np.int64), 0)
     if bb <= 6:
         codes = key_codes(keys).reshape(-1)                      # vector-major, band-minor
         order = np.argsort(codes, kind="stable")
