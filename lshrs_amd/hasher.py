@@ -170,7 +170,7 @@ class LSHHasher:
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps=8.0, precision: str = "bf16x3",
-                 tau1_ulps=64.0, tie_threads: Optional[int] = None, pipeline: str = "native",
+                 tau1_ulps=128.0, tie_threads: Optional[int] = None, pipeline: str = "native",
                  tie_replay: str = "auto", margin_guard: float = 0.5) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:

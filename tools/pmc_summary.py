@@ -3,7 +3,7 @@
 usage: pmc_summary.py <dir> [<dir> ...]  -> markdown table on stdout"""
 import csv, glob, os, sys, collections
 
-KEEP = ("sig_kernel", "sig16_kernel", "sig_fix_kernel", "sig_fix8_kernel", "export_ties", "cosine_kernel", "topk_kernel", "elementwise_kernel", "copy", "gather_tied")
+KEEP = ("sig_kernel", "sig16_kernel", "sig_fix8_kernel", "export_ties", "cosine_kernel", "topk_kernel", "copy", "bucket_")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
