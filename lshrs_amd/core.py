@@ -166,10 +166,10 @@ class LSHRS:
         if index < 0:
             raise ValueError("index must be non-negative")
         arr = self._check_dim(vector)
-        keys, flags = self._hasher.hash_batch_packed(arr.reshape(1, -1), return_row_flags=True)
-        if flags[0] & 1:
+        keys, flag = self._hash_one(arr)
+        if flag & 1:
             raise ValueError(_ZERO_MSG)
-        self._enqueue_packed(int(index), keys[0])
+        self._enqueue_packed(int(index), keys)
         self._flush_buffer_if_needed()
 
     def index(self, indices: Sequence[int], vectors: Optional[np.ndarray] = None) -> None:
@@ -266,10 +266,10 @@ class LSHRS:
               ) -> Union[List[int], List[Tuple[int, float]]]:
         """Band-collision candidates, optionally reranked by cosine (reference: main.py:524-658)."""
         query_vector = self._check_dim(vector)
-        keys, flags = self._hasher.hash_batch_packed(query_vector.reshape(1, -1), return_row_flags=True)
-        if flags[0] & 1:
+        keys, flag = self._hash_one(query_vector)
+        if flag & 1:
             raise ValueError(_ZERO_MSG)
-        counts = self._candidate_counts_from_keys(keys[0])
+        counts = self._candidate_counts_from_keys(keys)
         if not counts:
             return []
         ordered = sorted(counts.items(), key=lambda item: (-item[1], item[0]))
@@ -476,6 +476,14 @@ class LSHRS:
         if arr.shape[0] != self._dim:
             raise ValueError(f"Vector must have dimension {self._dim}; received {arr.shape[0]}")
         return arr
+
+    def _hash_one(self, arr: np.ndarray):
+        """(keys (bands, B), row flag) of one vector; concurrent callers share a launch where the hasher can coalesce."""
+        one = getattr(self._hasher, "hash_one_packed", None)
+        if one is not None:
+            return one(arr)
+        keys, flags = self._hasher.hash_batch_packed(arr.reshape(1, -1), return_row_flags=True)
+        return keys[0], int(flags[0])
 
     def _candidate_counts_from_keys(self, band_keys: np.ndarray) -> Dict[int, int]:
         """Collision count per stored id over the query's band buckets (reference: main.py:1088-1111)."""

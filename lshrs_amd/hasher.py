@@ -100,6 +100,16 @@ class _ProjectionList(list):
         return (list, (list(self),))
 
 
+class _OneRequest:
+    """A single-vector call waiting to be hashed (see :meth:`LSHHasher.hash_one_packed`)."""
+
+    __slots__ = ("vec", "keys", "flag", "error", "event", "lead")
+
+    def __init__(self, vec) -> None:
+        self.vec, self.keys, self.flag, self.error, self.lead = vec, None, 0, None, False
+        self.event = threading.Event()
+
+
 class _PendingKeys:
     """Handle of :meth:`LSHHasher.hash_device_async`."""
 
@@ -214,6 +224,9 @@ class LSHHasher:
         self._split_shape_ok: Optional[Tuple[int, bool]] = None
         self._device = device
         self._lock = threading.Lock()
+        self._one_lock = threading.Lock()
+        self._one_queue: list = []
+        self._one_leader = False
         self._projection_version = 0
         self._workspaces: Dict[int, Tuple[int, object]] = {}
         self.last_stats: Dict[str, int] = {}
@@ -1296,11 +1309,56 @@ class LSHHasher:
         self.last_stats = total
         return (keys, flags) if want_flags else keys
 
+    def hash_one_packed(self, vec: np.ndarray):
+        """One validated ``(dim,)`` float32 vector -> ``(keys (num_bands, band_bytes) uint8, row flag)``.
+
+        A single vector costs the GPU path a host->device copy, a launch and a copy back (~85 us; the reference's 16
+        small ``sgemv`` calls take ~36 us on the same host, 64 vectors 2.3 ms against 0.1 ms here - ``bench.py``
+        ``small_n``), and callers of ``ingest`` / ``get_top_k`` may come from many threads at once
+        (tests/test_concurrency.py of the reference).  Concurrent single-vector calls are therefore COALESCED: the first
+        caller to arrive becomes the leader and hashes everything that is queued - its own vector and those of the
+        threads that arrived while the previous launch was in flight - in one launch; when it is done and more have
+        queued, it hands the lead to the first of them.  One launch per wave of callers instead of one each."""
+        req = _OneRequest(vec)
+        with self._one_lock:
+            self._one_queue.append(req)
+            lead = not self._one_leader
+            if lead:
+                self._one_leader = True
+        if not lead:
+            req.event.wait()
+            if not req.lead:
+                if req.error is not None:
+                    raise req.error
+                return req.keys, req.flag
+        with self._one_lock:
+            batch, self._one_queue = self._one_queue, []
+        try:
+            keys, flags = self.hash_batch_packed(np.stack([r.vec for r in batch]), return_row_flags=True)
+            for i, r in enumerate(batch):
+                r.keys, r.flag = keys[i], int(flags[i])
+        except BaseException as exc:  # noqa: BLE001 - every caller of the batch sees what went wrong
+            for r in batch:
+                r.error = exc
+        for r in batch:
+            if r is not req:
+                r.event.set()
+        with self._one_lock:
+            if self._one_queue:
+                nxt = self._one_queue[0]
+                nxt.lead = True
+                nxt.event.set()
+            else:
+                self._one_leader = False
+        if req.error is not None:
+            raise req.error
+        return req.keys, req.flag
+
     def hash_vector(self, vector) -> HashSignatures:
         """One vector -> ``HashSignatures`` (reference: lsh.py:96-134)."""
         vec = self._validate_vector(vector)
-        packed = self.hash_batch_packed(vec.reshape(1, -1))
-        return HashSignatures(tuple(packed[0, b].tobytes() for b in range(self.num_bands)))
+        keys, _ = self.hash_one_packed(vec)
+        return HashSignatures(tuple(keys[b].tobytes() for b in range(self.num_bands)))
 
     def hash_batch(self, vectors) -> List[HashSignatures]:
         """``(n, dim)`` -> list of ``HashSignatures`` (reference: lsh.py:136-169)."""
@@ -1360,6 +1418,9 @@ class LSHHasher:
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_lock"] = None
+        state["_one_lock"] = None
+        state["_one_queue"] = []
+        state["_one_leader"] = False
         state["_workspaces"] = {}
         state["_side_streams"] = {}
         state["_pinned_cache"] = {}
@@ -1395,4 +1456,7 @@ class LSHHasher:
         self.__dict__.setdefault("margin_escalations", 0)
         self.__dict__.setdefault("window_mode", {"tau": "measured", "tau1": "measured"})
         self._lock = threading.Lock()
+        self._one_lock = threading.Lock()
+        self._one_queue = []
+        self._one_leader = False
         self._projections = _ProjectionList(state["_projections"], self)

@@ -798,3 +798,68 @@ def test_mfma_bf16_step_error(torch_mod):
             continue
         worst = max(worst, float(abs(Fraction(float(D[t])) - exact) / (mag * Fraction(1, 2 ** 24))))
     assert 0.0 < worst * 2 <= MFMA_BF16_ERR_UNITS, worst
+
+
+def test_streamed_host_input_equals_device_path(torch_mod):
+    """hash_batch_packed on a large host array: chunks cross PCIe on a copy stream while the previous one is hashed and
+    the one before that travels back (two pinned key buffers, source page-locked in place) - same bytes and flags as
+    hashing the whole batch on the device, with odd chunk sizes, a ragged tail, zero / NaN rows on chunk borders."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    n, dim = 150_001, 768
+    h = _hasher(42, 16, 16, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    x = np.random.default_rng(5).standard_normal((n, dim)).astype(np.float32)
+    x[0] = 0.0
+    x[16_384] = 0.0
+    x[16_383, 5] = np.nan
+    x[n - 1] = 1e-9
+    want = h.hash_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    for chunk, pin in ((16_384, "auto"), (50_000, "never"), (131_072, "auto")):
+        keys, flags = h.hash_batch_packed(x, return_row_flags=True, chunk_rows=chunk, pin=pin)
+        assert h.last_stats["source"] in ("registered", "pinned", "pageable") and h.last_stats["n"] == n
+        assert np.array_equal(keys, want), (chunk, pin)
+        assert set(np.flatnonzero(flags & 1).tolist()) == {0, 16_384, n - 1} and set(np.flatnonzero(flags & 2).tolist()) == {16_383}
+    assert np.array_equal(h.hash_batch_packed(x), want)
+    sl = slice(130_000, 133_000)
+    assert np.array_equal(want[sl], hash_batch_literal_packed(h.projections, x[sl]))
+    # a torch pinned source is used as it is
+    xp = torch.from_numpy(x).pin_memory()
+    assert np.array_equal(h.hash_batch_packed(xp.numpy()), want) and h.last_stats["source"] == "pinned"
+
+
+def test_concurrent_single_vector_calls_share_launches(torch_mod):
+    """hash_vector / hash_one_packed from many threads: every caller gets its own vector's keys (the reference's), and
+    the callers that arrive while a launch is in flight are hashed together by the next one."""
+    import threading
+
+    from oracle.lshrs_oracle import hash_vector_literal
+
+    h = _hasher(42, 16, 16, 768)
+    x = np.random.default_rng(8).standard_normal((256, 768)).astype(np.float32)
+    got, errors = [None] * 256, []
+    launches = []
+    real = h.hash_batch_packed
+
+    def counting(vectors, **kw):
+        launches.append(len(vectors))
+        return real(vectors, **kw)
+
+    h.hash_batch_packed = counting
+
+    def work(t):
+        try:
+            for i in range(t, 256, 16):
+                got[i] = h.hash_vector(x[i])
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for i in range(256):
+        assert tuple(got[i]) == hash_vector_literal(h.projections, x[i], 768), i
+    assert sum(launches) == 256 and len(launches) < 256 and max(launches) > 1, launches[:20]
