@@ -18,7 +18,8 @@ REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SOURCE = os.path.join(CSRC, "lshrs_hip.hip")
 SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
-LIBRARY = os.path.join(CSRC, "liblshrs_hip.so")
+# (LSHRS_HIP_LIBRARY: load another build of the same ABI instead - A/B measurements of compiler flags, tools/ab_build.py)
+LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 ABI_VERSION = 2
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
