@@ -863,3 +863,35 @@ def test_concurrent_single_vector_calls_share_launches(torch_mod):
     for i in range(256):
         assert tuple(got[i]) == hash_vector_literal(h.projections, x[i], 768), i
     assert sum(launches) == 256 and len(launches) < 256 and max(launches) > 1, launches[:20]
+
+
+def test_config5_full_size_5m_rows(torch_mod):
+    """BASELINE config 5 at FULL size on the device: 5M x 1536-d (30.7 GB resident), num_perm 512 -> 16 bands x 32 rows
+    (two column blocks per row tile, paired on one XCD).  50 000 rows against the reference-literal loop on every host
+    core; the rest through size-independent properties: hashing again gives the same bytes, a slice hashed alone gives
+    the bytes it has inside the batch, the same rows at another offset give the same keys, no list overflow, no guard
+    trip, and the measured stage-1 deviation is inside half the window."""
+    torch = torch_mod
+    from oracle.parallel import SharedVectors, hash_shared_literal_packed
+
+    n, dim = 5_000_000, 1536
+    h = _hasher(7, 16, 32, dim)
+    x = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    g = torch.Generator("cuda").manual_seed(55)
+    for lo in range(0, n, 500_000):
+        x[lo:lo + 500_000].normal_(generator=g)
+    x[4_999_000:5_000_000] = x[1_000:2_000]                     # the same vectors at two places of the batch
+    keys = h.hash_device(x)
+    st = dict(h.last_stats)
+    assert keys.shape == (n, 16, 4) and st["relaunches"] == 0 and st["margin_escalations"] == 0
+    assert st["tie_break_engine"] == "device-replay" and st["flagged"] > 100_000
+    assert st["max_dev_units"] * 2 <= h.tau1_ulps, st
+    assert torch.equal(h.hash_device(x), keys)                                            # idempotent
+    assert torch.equal(keys[4_999_000:], keys[1_000:2_000])                               # position-independent
+    assert torch.equal(h.hash_device(x[3_000_000:3_200_000]), keys[3_000_000:3_200_000])  # batch-independent
+    m = 50_000
+    with SharedVectors(m, dim) as sv:
+        sv.array[:] = x[2_500_000:2_500_000 + m].cpu().numpy()
+        want = hash_shared_literal_packed(h.projections, sv)
+    got = keys[2_500_000:2_500_000 + m].cpu().numpy()
+    assert int((got != want).any(axis=(1, 2)).sum()) == 0

@@ -95,3 +95,28 @@ def test_delete_and_clear_follow_the_reference():
     assert idx._buffer == [] and store.total_operations == 12 and store._buckets == {}
     assert idx.stats() == {"dimension": 32, "num_perm": 16, "num_bands": 4, "rows_per_band": 4, "buffer_size": 1000,
                            "similarity_threshold": 0.5, "redis_prefix": "lsh"}
+
+
+def test_pickle_carries_device_windows_and_ingest_mode_and_defers_the_storage():
+    """What this build adds to the pickle (under a key the reference's __setstate__ never reads): the GPU index, the
+    window modes, the ingest mode.  Unpickling must not need the Redis client: the storage is resolved on first use."""
+    from lshrs_amd import LSHHasher
+
+    idx = LSHRS(dim=64, num_bands=8, rows_per_band=16, num_perm=128, storage=InMemoryStorage(), seed=5,
+                packed_ingest=True, hasher=LSHHasher(8, 16, 64, seed=5, device=3, tau1_ulps="bound", tau_ulps=16.0,
+                                                     margin_guard=0.25, tie_replay="off"))
+    state = idx.__getstate__()
+    assert set(state) >= {"config", "redis_config", "projections"}            # the reference's three keys, untouched
+    clone = pickle.loads(pickle.dumps(idx))                                    # (no redis in this image: must not raise)
+    h = clone._hasher
+    assert clone._packed_ingest is True and h._device == 3 and h.window_mode == {"tau": "measured", "tau1": "bound"}
+    assert h.tau_ulps == 16.0 and h.tau1_ulps == idx._hasher.tau1_ulps and h.margin_guard == 0.25 and h.tie_replay == "off"
+    assert all(np.array_equal(a, b) for a, b in zip(h.projections, idx._hasher.projections))
+    assert not hasattr(clone._storage, "batch_add_csr")                         # capability probes do not open a connection
+    with pytest.raises(RuntimeError, match="RedisStorage"):
+        clone._storage.get_bucket(0, b"\x00\x00")                              # first real use resolves it (and says why it cannot)
+    # a state written by the reference (no extra key) still loads
+    del state["lshrs_amd"]
+    plain = LSHRS.__new__(LSHRS)
+    plain.__setstate__(state)
+    assert plain._packed_ingest is False and plain._hasher.window_mode["tau1"] == "measured"
