@@ -1186,6 +1186,10 @@ class LSHHasher:
                         and self._split_applies(16_384, replay=True) and bool(self._replay_model()))
             if streamed:
                 return self._hash_host_streamed(arr, return_row_flags, max(16_384, int(chunk_rows)), dev, pin)
+            if 0 < n <= self._small_rows and mode == "host":
+                got = self._hash_small_locked(arr, dev)
+                if got is not None:
+                    return got if return_row_flags else got[0]
             keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
             flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
             total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
@@ -1202,6 +1206,70 @@ class LSHHasher:
                     total[k] += self.last_stats.get(k, 0)
         self.last_stats = total
         return (keys, flags) if return_row_flags else keys
+
+    _small_rows = 128
+
+    def _hash_small_locked(self, arr: np.ndarray, dev):
+        """A query vector or a handful (``ingest``, ``get_top_k``, ``hash_vector``): one kernel launch, one copy back,
+        ONE wait.  The rows are copied into pinned host memory and the f32 kernel reads them from there (3 KB over
+        PCIe: no staging copy, no allocation); keys, row flags and the tie counter share one device buffer that comes
+        back in a single asynchronous copy.  Ties (2.6 per 1 000 vectors) take the device replay afterwards.  Returns
+        None where the device tie replay does not apply (the general path then does the work)."""
+        torch = _native.require_gpu()
+        lib = _native.load()
+        n = arr.shape[0]
+        rb = self.num_bands * self.band_bytes
+        if self.tie_replay != "auto" or self.dim % 32 != 0 or rb % 4 != 0 or not self._replay_model():
+            return None
+        key = ("small", dev.index)
+        buf = self._pinned_cache.get(key)
+        cap = self._small_rows
+        if buf is None:
+            tail = (cap * rb + cap + 31) // 32 * 32              # keys | flags | pad, then the counter block
+            with torch.cuda.device(dev):
+                dev_out = torch.zeros(tail + 4 * _native.SIG_COUNTERS, dtype=torch.uint8, device=dev)
+            pin_out = torch.zeros(tail + 4 * _native.SIG_COUNTERS, dtype=torch.uint8).pin_memory()
+            pin_x = torch.zeros((cap, self.dim), dtype=torch.float32).pin_memory()
+            buf = (dev_out, pin_out, pin_out.numpy(), pin_x, pin_x.numpy(), tail,
+                   torch.empty((4096, 2), dtype=torch.int64, device=dev), torch.empty((8192,), dtype=torch.int64, device=dev),
+                   torch.zeros(_native.SIG_COUNTERS, dtype=torch.int32).pin_memory())
+            self._pinned_cache[key] = buf
+        dev_out, pin_out, host_out, pin_x, host_x, tail, tie_list, flag_list, pin_counts = buf
+        ws = self._workspace(dev)
+        host_x[:n] = arr
+        tau = float(self.tau_ulps * _U)
+        ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+        with ctx:
+            cur = torch.cuda.current_stream(dev)
+            base = dev_out.data_ptr()
+            _native.check(
+                lib.lshrs_sig_hash_batch_f32(pin_x.data_ptr(), n, self.dim, ws.data_ptr(), self.num_bands, self.rows_per_band,
+                                             self.dim, base, tie_list.data_ptr(), int(tie_list.shape[0]), base + tail, tau,
+                                             base + cap * rb, None, cur.cuda_stream), "lshrs_sig_hash_batch_f32")
+            pin_out.copy_(dev_out, non_blocking=True)
+            cur.synchronize()
+            ties = int(host_out[tail:tail + 4].view(np.int32)[0])
+            stats = {"n": n, "tie_entries": ties, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0,
+                     "tie_break_engine": "device-replay"}
+            if ties:
+                if ties > int(tie_list.shape[0]):           # pathological rows: the general path has room for them
+                    dev_out[tail:].zero_()
+                    return None
+                _native.check(
+                    lib.lshrs_sig_resolve_ties_replay_f32(pin_x.data_ptr(), n, self.dim, ws.data_ptr(), self.num_bands,
+                                                          self.rows_per_band, self.dim, base, tie_list.data_ptr(),
+                                                          int(tie_list.shape[0]), base + tail, tau, flag_list.data_ptr(),
+                                                          int(flag_list.shape[0]), self._replay_model(), pin_counts.data_ptr(),
+                                                          cur.cuda_stream), "lshrs_sig_resolve_ties_replay_f32")
+                pin_out.copy_(dev_out, non_blocking=True)
+                cur.synchronize()                           # (the export left the device counters zeroed)
+                if int(pin_counts[1]) > int(flag_list.shape[0]):
+                    return None
+                stats["tie_pairs"] = int(pin_counts[1])
+        keys = host_out[:n * rb].reshape(n, self.num_bands, self.band_bytes).copy()
+        flags = host_out[cap * rb:cap * rb + n].copy()
+        self.last_stats = stats
+        return keys, flags
 
     def _stream_buffers(self, dev, rows: int):
         """Two device input buffers, two device key / flag buffers and their pinned host mirrors, three streams."""
