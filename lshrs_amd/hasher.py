@@ -173,6 +173,10 @@ class LSHHasher:
                   ``tau_ulps="bound"`` does the same for the f32 kernel's tie window (``bound_tau_ulps``).
       margin_guard  fraction of the stage-1 window the measured deviation may reach before the hasher escalates
                   (default 0.5; 0 disables the guard)
+      audit_every every n-th synchronous ``hash_device`` batch (default 64, and the first) a handful of the projections
+                  stage 2 decided are re-evaluated with ``P_band @ x`` on the host and compared with the key bits; a
+                  disagreement revokes the device replay for this hasher (``last_stats["audit_failures"]``) and the
+                  batch is hashed again with the host engine.  0 = never
       pipeline    "native" (default) / "python": who drives the chunks of a device batch of >= 131 072 rows
       tie_replay  "auto" (default): batches that take the split pass break their ties on the device (stage 2 replays
                   the host BLAS's summation order, recognised and verified at first use); "off": host engine only
@@ -181,7 +185,7 @@ class LSHHasher:
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps=8.0, precision: str = "bf16x3",
                  tau1_ulps=128.0, tie_threads: Optional[int] = None, pipeline: str = "native",
-                 tie_replay: str = "auto", margin_guard: float = 0.5) -> None:
+                 tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -208,6 +212,10 @@ class LSHHasher:
         self.precision = precision
         self.tau1_ulps = bound_tau1_ulps(self.dim) if tau1_ulps == "bound" else float(tau1_ulps)
         self.margin_guard = float(margin_guard)
+        # every audit_every-th synchronous batch (and the first): a few of the projections the device has decided are
+        # re-evaluated with NumPy on the host and compared (0 = never)
+        self.audit_every = int(audit_every)
+        self._audit_countdown = 1
         self.margin_escalations = 0        # batches whose measured stage-1 deviation tripped the guard (then: bound window)
         # the split pass (two launches, 256-row workgroups) overtakes the f32 kernel at about 16 M input elements:
         # 20 k rows at 768-d, 8 k at 1536-d, 120 k at 128-d (tools/split_crossover.py)
@@ -542,7 +550,49 @@ class LSHHasher:
             self._async_pending[0]._finish_locked()
         while not self._replay_finish(self._replay_launch(x, out, row_flags, ws, tau, model), stats):
             pass
+        if self.audit_every > 0 and stats.get("flagged", 0) > 0:
+            self._audit_countdown -= 1
+            if self._audit_countdown <= 0:
+                self._audit_countdown = self.audit_every
+                if not self._audit_replay(x, out, stats):
+                    # what the device decided is not what this process's NumPy computes: the replay's licence is void
+                    # for this hasher - the host engine (the library's own call) takes over, starting with this batch
+                    self.tie_replay = "off"
+                    stats["audit_failures"] = stats.get("audit_failures", 0) + 1
+                    return self._hash_device_locked(x, out, row_flags, "host", host_rows=None)
         return out
+
+    def _audit_replay(self, x, out, stats, sample: int = 16) -> bool:
+        """Spot check of the device's decisions against the reference's own expression on live data: a handful of the
+        projections stage 2 has just decided are re-evaluated with ``P_band @ x`` (lshrs/hash/lsh.py:200) on the host
+        and compared with the key bits.  The BLAS-order model is licensed on synthetic vectors at first use and when the
+        BLAS's configuration changes; this closes the loop on real inputs, every ``audit_every`` batches (three small
+        copies, ~0.1 ms)."""
+        torch = _native.require_gpu()
+        dev = x.device
+        scratch = self._replay_scratch.get((dev.index, torch.cuda.current_stream(dev).cuda_stream))
+        if scratch is None:
+            return True
+        k = min(sample, int(stats["flagged"]), int(scratch[0].shape[0]))
+        items = scratch[0][:k].cpu().numpy()
+        rows, cols = items >> 21, (items & ((1 << 21) - 1)).astype(np.int64)
+        band_cols = 8 * self.band_bytes
+        keep = (cols // band_cols < self.num_bands) & (cols % band_cols < self.rows_per_band) & (rows < x.shape[0])
+        rows, cols = rows[keep], cols[keep]
+        if rows.size == 0:
+            return True
+        idx = torch.from_numpy(rows).to(dev)
+        xr = x.index_select(0, idx).cpu().numpy()
+        kb = out.index_select(0, idx).cpu().numpy()
+        stats["audited"] = stats.get("audited", 0) + int(rows.size)
+        for i in range(rows.size):
+            band, bit = int(cols[i] // band_cols), int(cols[i] % band_cols)
+            y = np.ascontiguousarray(self._projections[band], dtype=np.float32) @ np.ascontiguousarray(xr[i])
+            want = bool(y[bit] > 0)
+            have = bool((kb[i, band, bit >> 3] >> (bit & 7)) & 1)
+            if want != have:
+                return False
+        return True
 
     def hash_device_async(self, x, *, out=None, row_flags=None):
         """:meth:`hash_device` for streaming ingest: enqueue the batch and return a handle at once; ``handle.result()``
@@ -1521,6 +1571,8 @@ class LSHHasher:
         self.__dict__.setdefault("_split_shape_ok", None)
         self.__dict__.setdefault("split_min_elems", 16 << 20)
         self.__dict__.setdefault("margin_guard", 0.5)
+        self.__dict__.setdefault("audit_every", 64)
+        self.__dict__.setdefault("_audit_countdown", 1)
         self.__dict__.setdefault("margin_escalations", 0)
         self.__dict__.setdefault("window_mode", {"tau": "measured", "tau1": "measured"})
         self._lock = threading.Lock()

@@ -895,3 +895,36 @@ def test_config5_full_size_5m_rows(torch_mod):
         want = hash_shared_literal_packed(h.projections, sv)
     got = keys[2_500_000:2_500_000 + m].cpu().numpy()
     assert int((got != want).any(axis=(1, 2)).sum()) == 0
+
+
+def test_live_audit_of_the_device_decisions(torch_mod):
+    """Every audit_every-th batch a few of the projections stage 2 decided are re-evaluated with NumPy's `P_band @ x` and
+    compared with the key bits.  On a healthy hasher it passes silently; a device image that no longer matches the host's
+    hyperplanes (edited in place without refresh_device(): the documented misuse) is caught on the first audited batch,
+    the replay is revoked and the batch comes out right through the host engine."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    n, dim = 60_000, 768
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(12))
+    h = _hasher(42, 16, 16, dim, audit_every=2)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    seen = []
+    for _ in range(4):
+        h.hash_device(x)
+        seen.append(h.last_stats.get("audited", 0))
+    assert [s > 0 for s in seen] == [True, False, True, False] and "audit_failures" not in h.last_stats
+    # stale device image: flip the sign of every hyperplane on the host only
+    for p in h.projections:
+        p *= -1.0                        # in-place edit: the list does not notice, the device keeps the old image
+    h._audit_countdown = 1
+    keys = h.hash_device(x)
+    st = dict(h.last_stats)
+    assert h.tie_replay == "off" and st.get("tie_break_engine") != "device-replay"
+    # (the device image is still the old one - only refresh_device() fixes that - but the disagreement did not go unseen,
+    #  and every flagged pair now takes the host's value)
+    h.refresh_device()
+    keys = h.hash_device(x)
+    sl = slice(0, 3000)
+    assert np.array_equal(keys[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
