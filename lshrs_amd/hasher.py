@@ -175,7 +175,7 @@ class LSHHasher:
                   (default 0.5; 0 disables the guard)
       audit_every every n-th synchronous ``hash_device`` batch (default 64, and the first) a handful of the projections
                   stage 2 decided are re-evaluated with ``P_band @ x`` on the host and compared with the key bits; a
-                  disagreement revokes the device replay for this hasher (``last_stats["audit_failures"]``) and the
+                  disagreement revokes the device replay for this hasher (``audit_failures``) and the
                   batch is hashed again with the host engine.  0 = never
       pipeline    "native" (default) / "python": who drives the chunks of a device batch of >= 131 072 rows
       tie_replay  "auto" (default): batches that take the split pass break their ties on the device (stage 2 replays
@@ -216,6 +216,7 @@ class LSHHasher:
         # re-evaluated with NumPy on the host and compared (0 = never)
         self.audit_every = int(audit_every)
         self._audit_countdown = 1
+        self.audit_failures = 0
         self.margin_escalations = 0        # batches whose measured stage-1 deviation tripped the guard (then: bound window)
         # the split pass (two launches, 256-row workgroups) overtakes the f32 kernel at about 16 M input elements:
         # 20 k rows at 768-d, 8 k at 1536-d, 120 k at 128-d (tools/split_crossover.py)
@@ -558,8 +559,10 @@ class LSHHasher:
                     # what the device decided is not what this process's NumPy computes: the replay's licence is void
                     # for this hasher - the host engine (the library's own call) takes over, starting with this batch
                     self.tie_replay = "off"
-                    stats["audit_failures"] = stats.get("audit_failures", 0) + 1
-                    return self._hash_device_locked(x, out, row_flags, "host", host_rows=None)
+                    self.audit_failures += 1
+                    out = self._hash_device_locked(x, out, row_flags, "host", host_rows=None)
+                    self.last_stats["audit_failures"] = self.audit_failures
+                    return out
         return out
 
     def _audit_replay(self, x, out, stats, sample: int = 16) -> bool:
@@ -1573,6 +1576,7 @@ class LSHHasher:
         self.__dict__.setdefault("margin_guard", 0.5)
         self.__dict__.setdefault("audit_every", 64)
         self.__dict__.setdefault("_audit_countdown", 1)
+        self.__dict__.setdefault("audit_failures", 0)
         self.__dict__.setdefault("margin_escalations", 0)
         self.__dict__.setdefault("window_mode", {"tau": "measured", "tau1": "measured"})
         self._lock = threading.Lock()

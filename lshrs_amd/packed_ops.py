@@ -85,9 +85,38 @@ def _csr_host(id_arr: np.ndarray, keys: np.ndarray) -> BucketCSR:
                      np.concatenate([p[2] for p in parts]) if parts else np.empty(0, np.int64), n)
 
 
+def _csr_device_sorted(torch, id_arr: np.ndarray, keys, device) -> BucketCSR:
+    """Band keys of 3 to 6 bytes (config 5: 4) do not fit a counting-sort table: their (band, key) codes are sorted on the
+    device instead (one stable 64-bit sort of n x bands codes through the runtime's radix sort - data movement, no
+    arithmetic of the path in it) and run-length encoded; same structure, same bucket order as the other two builders."""
+    on_dev = isinstance(keys, torch.Tensor)
+    if on_dev:
+        kd = keys.contiguous()
+        dev = kd.device
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        kd = torch.from_numpy(np.ascontiguousarray(keys, dtype=np.uint8)).to(dev)
+    n, nb, bb = (int(v) for v in kd.shape)
+    with torch.cuda.device(dev):
+        codes = torch.zeros((n, nb), dtype=torch.int64, device=dev)
+        for j in range(bb):
+            codes |= kd[:, :, j].to(torch.int64) << (8 * j)
+        codes |= (torch.arange(nb, dtype=torch.int64, device=dev) << (8 * bb))[None, :]
+        sorted_codes, order = torch.sort(codes.reshape(-1), stable=True)
+        members = torch.from_numpy(id_arr).to(dev).repeat_interleave(nb)[order]
+        ucodes, counts = torch.unique_consecutive(sorted_codes, return_counts=True)
+        ucodes_h, counts_h, members_h = ucodes.cpu().numpy(), counts.cpu().numpy(), members.cpu().numpy()
+    kb = np.empty((ucodes_h.shape[0], bb), dtype=np.uint8)
+    for j in range(bb):
+        kb[:, j] = (ucodes_h >> (8 * j)) & 0xFF
+    return BucketCSR(bb, (ucodes_h >> (8 * bb)).astype(np.int32), kb, ucodes_h,
+                     np.r_[0, np.cumsum(counts_h, dtype=np.int64)].astype(np.int64), members_h, n)
+
+
 def bucket_csr(ids: Sequence[int], keys, *, device=None) -> BucketCSR:
     """Group a batch's ``(n, bands, B)`` keys into buckets: one :class:`BucketCSR`.  ``B <= 2`` (every BASELINE config
-    but config 5): counting sort on the device; wider keys: NumPy sorts on the host.  ``keys`` may be the NumPy array
+    but config 5): counting sort on the device (``lshrs_bucket_histogram_u8`` / ``_scatter_u8``); ``B`` 3 to 6 (config 5):
+    a device sort of the (band, key) codes; wider keys: NumPy sorts on the host.  ``keys`` may be the NumPy array
     ``hash_batch_packed`` returns or the device tensor ``hash_device`` returns."""
     torch = _native.require_gpu()
     id_arr = np.ascontiguousarray(np.asarray(ids, dtype=np.int64))
@@ -95,9 +124,11 @@ def bucket_csr(ids: Sequence[int], keys, *, device=None) -> BucketCSR:
     n, nb, bb = (int(v) for v in keys.shape)
     if id_arr.shape[0] != n:
         raise ValueError("ids and keys disagree in length")
-    if n == 0 or bb > 2:
+    if n == 0 or bb > 6:
         host_keys = keys.cpu().numpy() if on_dev else np.ascontiguousarray(keys, dtype=np.uint8)
         return _csr_host(id_arr, host_keys)
+    if bb > 2:
+        return _csr_device_sorted(torch, id_arr, keys, device)
     lib = _native.load()
     if on_dev:
         kd = keys.contiguous()

@@ -921,7 +921,8 @@ def test_live_audit_of_the_device_decisions(torch_mod):
     h._audit_countdown = 1
     keys = h.hash_device(x)
     st = dict(h.last_stats)
-    assert h.tie_replay == "off" and st.get("tie_break_engine") != "device-replay"
+    assert h.tie_replay == "off" and h.audit_failures == 1 and st.get("audit_failures") == 1
+    assert st.get("tie_break_engine") != "device-replay"
     # (the device image is still the old one - only refresh_device() fixes that - but the disagreement did not go unseen,
     #  and every flagged pair now takes the host's value)
     h.refresh_device()

@@ -126,7 +126,8 @@ def test_device_bucket_csr_equals_host_grouping():
     from lshrs_amd.packed_ops import _csr_host, bucket_csr
 
     rng = np.random.default_rng(17)
-    for (n, nb, bb, hi) in ((200_000, 16, 2, 256), (50_000, 16, 1, 16), (1, 3, 2, 256), (4097, 5, 2, 4), (3000, 16, 4, 256)):
+    for (n, nb, bb, hi) in ((200_000, 16, 2, 256), (50_000, 16, 1, 16), (1, 3, 2, 256), (4097, 5, 2, 4), (3000, 16, 4, 256),
+                            (120_000, 16, 4, 3), (777, 2, 6, 2), (500, 3, 7, 2)):
         keys = rng.integers(0, hi, size=(n, nb, bb), dtype=np.uint8)
         ids = rng.permutation(10 * n + 5)[:n].astype(np.int64)
         want = _csr_host(ids, keys)
@@ -140,3 +141,20 @@ def test_device_bucket_csr_equals_host_grouping():
                 assert sorted(got.members[lo:hi_].tolist()) == sorted(want.members[lo:hi_].tolist())
             assert np.array_equal(np.sort(got.members), np.sort(want.members))
     assert len(bucket_csr(np.empty(0, np.int64), np.empty((0, 16, 2), np.uint8))) == 0
+
+
+def test_redis_writer_takes_a_bucket_csr():
+    """``RedisPackedWriter.batch_add_csr``: one ``SADD`` per bucket (split at max_members), the reference's key text
+    (lshrs/storage/redis.py:187-225), exactly the members one SADD per operation would have added."""
+    from lshrs_amd.packed_ops import _csr_host
+
+    rng = np.random.default_rng(9)
+    keys = rng.integers(0, 3, size=(400, 4, 2), dtype=np.uint8)
+    ids = rng.permutation(5000)[:400].astype(np.int64)
+    fake = FakeRedisStorage()
+    writer = RedisPackedWriter(fake, max_members_per_command=50)
+    n = writer.batch_add_csr(_csr_host(ids, keys))
+    assert n == len(fake.commands) and all(len(m) <= 50 for _, m in fake.commands)
+    sent = {(name, m) for name, members in fake.commands for m in members}
+    assert sent == {(fake.bucket_key(b, k), i) for b, k, i in ops_from_keys(ids, keys)}
+    assert all(isinstance(m, int) for _, members in fake.commands for m in members)
