@@ -929,3 +929,36 @@ def test_live_audit_of_the_device_decisions(torch_mod):
     keys = h.hash_device(x)
     sl = slice(0, 3000)
     assert np.array_equal(keys[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
+
+
+def test_split_window_margin_with_assigned_hyperplanes(torch_mod):
+    """Hyperplanes that did not come from the Gaussian stream (`load_from_disk` / `__setstate__` assign whatever was saved):
+    an int8 grid, heavy-tailed rows, a rank-4 family.  Whatever stage 1's deviation turns out to be on them, the keys are
+    the reference's - either because the default window holds (and the live statistic says by how much) or because the
+    guard moved the hasher to the deterministic bound."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    n, dim, nb, r = 80_000, 768, 16, 16
+    rng = np.random.default_rng(99)
+    families = {
+        "int8_grid": rng.integers(-127, 128, size=(nb, r, dim)).astype(np.float32) / 64.0,
+        "heavy_tail": (rng.standard_normal((nb, r, dim)) * np.exp(2.0 * rng.standard_normal((nb, r, dim)))).astype(np.float32),
+        "rank4": (rng.standard_normal((nb, r, 4)) @ rng.standard_normal((4, dim))).astype(np.float32),
+    }
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(31))
+    xu = x / x.norm(dim=1, keepdim=True)
+    for name, planes in families.items():
+        h = _hasher(1, nb, r, dim)
+        h.projections = [planes[b].copy() for b in range(nb)]
+        if not h._replay_model():
+            pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+        for data in (x, xu):
+            keys = h.hash_device(data)
+            st = dict(h.last_stats)
+            assert st["tie_break_engine"] == "device-replay", (name, st)
+            assert st["margin_escalations"] == 0 or h.window_mode["tau1"] == "bound"
+            sl = slice(10_000, 14_000)
+            want = hash_batch_literal_packed(h.projections, data[sl].cpu().numpy())
+            assert np.array_equal(keys[sl].cpu().numpy(), want), name
+        assert st["max_dev_units"] * 2 <= h.tau1_ulps, (name, st)
