@@ -177,7 +177,8 @@ class LSHHasher:
                   stage 2 decided are re-evaluated with ``P_band @ x`` on the host and compared with the key bits; a
                   disagreement revokes the device replay for this hasher (``audit_failures``) and the
                   batch is hashed again with the host engine.  0 = never
-      pipeline    "native" (default) / "python": who drives the chunks of a device batch of >= 131 072 rows
+      pipeline    "native" (default): large device batches whose ties the HOST breaks are chunked and overlapped by the
+                  library's driver; "python": one pass, then NumPy (the round-1 interpreter-driven chunking is gone)
       tie_replay  "auto" (default): batches that take the split pass break their ties on the device (stage 2 replays
                   the host BLAS's summation order, recognised and verified at first use); "off": host engine only
     """
@@ -247,8 +248,8 @@ class LSHHasher:
         # chunk boundary costs a kernel ramp-down/ramp-up, each chunk a fixed ~60 us of host work
         self.pipeline_chunk_rows = 262_144
         self.pipeline_pair_head = True     # long batches: full-size chunks at the head are launched two at a time
-        # who drives the chunks of a large device batch: "native" = the library (csrc/pipeline.hip; needs the host
-        # engine, else the interpreter does it), "python" = this class (_pipelined_body).  Same kernels, same keys.
+        # large device batches whose ties the host breaks: "native" = chunked and overlapped by the library
+        # (csrc/pipeline.hip; needs the host engine), "python" = one pass, then NumPy on the flagged pairs.  Same keys.
         if pipeline not in ("native", "python"):
             raise ValueError("pipeline must be 'native' or 'python'")
         self.pipeline = pipeline
@@ -265,7 +266,6 @@ class LSHHasher:
         self._replay_scratch: Dict[object, tuple] = {}
         self._async_pending: list = []
         self._replay_events: Dict[int, list] = {}
-        self._side_streams: Dict[int, object] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
         self._flag_cap_hint = 0
         # hyperplanes: one generator, num_bands float64 draws cast to float32 (lsh.py:93-94)
@@ -699,181 +699,19 @@ class LSHHasher:
 
     # ------------------------------------------------------------------ large batches: overlap the tie-break
     def _hash_device_pipelined(self, x, out, row_flags, ws, tau, stats):
+        """Large device batches whose ties the HOST breaks (BLAS order not recognised, ``tie_replay="off"``): chunked by
+        the library's own driver (csrc/pipeline.hip) with the host engine's work overlapped; without the engine
+        (``pipeline="python"``, ``tie_threads=1``, a BLAS it cannot map) the plain path: one pass, then NumPy."""
         try:
             native = self._tie_engine() if self.pipeline == "native" else None
             if native is not None:
                 return self._pipelined_native(x, out, row_flags, ws, tau, stats, native)
-            return self._pipelined_body(x, out, row_flags, ws, tau, stats)
+            return self._hash_device_locked(x, out, row_flags, "host", None, allow_pipeline=False)
         except BaseException:
             # kernels and copies still in flight use buffers owned by the frame that just unwound: let them finish
             # before the caching allocator can hand that memory to anyone else
             _native.require_gpu().cuda.synchronize(x.device)
             raise
-
-    def _pipelined_body(self, x, out, row_flags, ws, tau, stats):
-        """Same result as the plain path, for large device-resident batches: the batch is cut into
-        chunks of ``pipeline_chunk_rows`` (a whole number of full-chip rounds of the kernel); every chunk's
-        kernel and its "gather the tied rows" kernel are enqueued back to back on the caller's stream, and
-        while the GPU works through them the host resolves the ties of the chunks already finished
-        (count / entries / vectors come back over a side stream into two alternating pinned buffers,
-        patches go out over it)."""
-        t_entry = time.perf_counter()
-        torch = _native.require_gpu()
-        lib = _native.load()
-        dev = x.device
-        n = int(x.shape[0])
-        bb = self.band_bytes
-        ch, cap, spans = self._pipeline_plan(n)
-        window = 16
-        overflow = []
-        keep = []  # device temporaries stay referenced until the streams have been joined
-        with torch.cuda.device(dev):
-            main = torch.cuda.current_stream(dev)
-            # two in-order side streams: the tiny count copies are all enqueued up front (each behind its own
-            # chunk), so the bulk copies / patches must not queue behind them
-            cstream = self._side_stream(dev, 0)
-            side = self._side_stream(dev, 1)
-            pin_cnt, pin_entries, pin_rows, pin_fcnt, pin_patch, dev_patch, pairs_cap = self._pinned(dev, cap, window)
-            native = self._tie_engine()
-            slot_free = [None, None]   # event after which a patch staging slot may be overwritten
-            for w0 in range(0, len(spans), window):
-                group = spans[w0:w0 + window]
-                lists = torch.empty((len(group), cap, 2), dtype=torch.int64, device=dev)
-                counts = torch.zeros((2 * len(group),), dtype=torch.int32, device=dev)   # tie counts | stage-1 counts
-                fcounts = counts[len(group):]
-                stage = torch.empty((len(group), cap, self.dim), dtype=torch.float32, device=dev)
-                keep += [lists, counts, stage]
-                ready = []
-                split_flags = []
-
-                def enqueue(ci):
-                    """Chunk ci's signature pass + "gather the tied rows" on the caller's stream, its counters' copy on
-                    the count stream."""
-                    lo, hi = group[ci]
-                    xs, os_ = x[lo:hi], out[lo:hi]
-                    flags_ptr = row_flags[lo:hi].data_ptr() if row_flags is not None else None
-                    flag = self._launch_sig(torch, lib, dev, xs.data_ptr(), hi - lo, x.stride(0), ws.data_ptr(),
-                                            self.num_bands, self.rows_per_band, self.dim, os_.data_ptr(),
-                                            lists[ci].data_ptr(), cap, counts[ci:ci + 1].data_ptr(), tau, flags_ptr,
-                                            main.cuda_stream, flag_count=fcounts[ci:ci + 1])
-                    split_flags.append(flag)
-                    if flag is not None:
-                        keep.append(flag)
-                    _native.check(
-                        lib.lshrs_gather_tied_rows_f32(xs.data_ptr(), x.stride(0), self.dim, lists[ci].data_ptr(),
-                                                       counts[ci:ci + 1].data_ptr(), cap, stage[ci].data_ptr(),
-                                                       main.cuda_stream), "lshrs_gather_tied_rows_f32")
-                    done = torch.cuda.Event()
-                    done.record(main)
-                    cstream.wait_event(done)
-                    with torch.cuda.stream(cstream):
-                        pin_cnt[ci:ci + 1].copy_(counts[ci:ci + 1], non_blocking=True)
-                        if flag is not None:
-                            pin_fcnt[ci:ci + 1].copy_(flag[0], non_blocking=True)
-                        copied = torch.cuda.Event()
-                        copied.record(cstream)
-                    ready.append((copied, done))
-
-                # the GPU is kept two chunks ahead of the host: enqueueing everything first would let the host start on
-                # chunk 0 only after ~70 us of launch work per chunk, and finish that much after the GPU
-                ahead = 2
-                for ci in range(min(ahead, len(group))):
-                    enqueue(ci)
-                    if ci == 0 and w0 == 0:
-                        stats["t_head_ms"] = 1e3 * (time.perf_counter() - t_entry)
-
-                def fetch(ci):
-                    """Wait for chunk ci's count, start the D2H of its entries + vectors into slot ci & 1."""
-                    ready[ci][0].synchronize()
-                    cnt = int(pin_cnt[ci])
-                    if split_flags[ci] is not None and int(pin_fcnt[ci]) > split_flags[ci][1]:
-                        self._flag_cap_hint = int(int(pin_fcnt[ci]) * 1.25) + 4096
-                        cnt = cap + 1          # stage-1 list overflowed: the chunk is redone on the plain path
-                    landed = None
-                    if 0 < cnt <= cap:
-                        side.wait_event(ready[ci][1])
-                        with torch.cuda.stream(side):
-                            pin_entries[ci & 1, :cnt].copy_(lists[ci, :cnt], non_blocking=True)
-                            pin_rows[ci & 1, :cnt].copy_(stage[ci, :cnt], non_blocking=True)
-                            landed = torch.cuda.Event()
-                            landed.record(side)
-                    return cnt, landed
-
-                nxt = fetch(0)
-                for ci, (lo, hi) in enumerate(group):
-                    te = time.perf_counter()
-                    if nxt is None:
-                        nxt = fetch(ci)      # (blocking) the previous iteration could not start this copy early
-                    if ci == len(group) - 1:
-                        stats["t_tail_count_ms"] = 1e3 * (time.perf_counter() - t_entry)   # count of the last chunk is here
-                    if ci + ahead < len(group):
-                        enqueue(ci + ahead)
-                    t0 = time.perf_counter()
-                    stats["t_enqueue_ms"] = stats.get("t_enqueue_ms", 0.0) + 1e3 * (t0 - te)
-                    cnt, landed = nxt
-                    # start the next chunk's copy now if its count is already here (it then runs while this chunk's
-                    # ties are resolved) - but never WAIT for the next chunk before resolving this one
-                    nxt = fetch(ci + 1) if ci + 1 < len(group) and ready[ci + 1][0].query() else None
-                    stats["t_fetch_ms"] = stats.get("t_fetch_ms", 0.0) + 1e3 * (time.perf_counter() - t0)
-                    if cnt > cap:
-                        overflow.append((lo, hi))
-                        continue
-                    stats["tie_entries"] += cnt
-                    if cnt == 0:
-                        continue
-                    landed.synchronize()
-                    t1 = time.perf_counter()
-                    if native is not None:
-                        # decode + sgemv + layout in one native call, straight from / into pinned memory
-                        slot = ci & 1
-                        if slot_free[slot] is not None:
-                            slot_free[slot].synchronize()
-                        base = pin_patch[slot].data_ptr()
-                        m = native[0].resolve(native[1], pin_entries[slot].data_ptr(), cnt, pin_rows[slot].data_ptr(),
-                                              self.dim, base, base + 8 * pairs_cap, base + 12 * pairs_cap, pairs_cap)
-                        stats["tie_pairs"] += m
-                        t3 = time.perf_counter()
-                        used = 12 * pairs_cap + m * bb
-                        with torch.cuda.stream(side):
-                            dev_patch[slot, :used].copy_(pin_patch[slot, :used], non_blocking=True)
-                            dbase = dev_patch[slot].data_ptr()
-                            _native.check(
-                                lib.lshrs_scatter_band_keys_u8(out[lo:hi].data_ptr(), self.num_bands, bb, dbase,
-                                                               dbase + 8 * pairs_cap, dbase + 12 * pairs_cap, m,
-                                                               side.cuda_stream), "lshrs_scatter_band_keys_u8")
-                            slot_free[slot] = torch.cuda.Event()
-                            slot_free[slot].record(side)
-                        t4 = time.perf_counter()
-                        for key, dt in (("t_wait_ms", t1 - t0), ("t_patch_ms", t3 - t1), ("t_scatter_ms", t4 - t3)):
-                            stats[key] = stats.get(key, 0.0) + 1e3 * dt
-                        continue
-                    entries = pin_entries[ci & 1, :cnt].numpy()
-                    rows, bands, xindex = self._tie_pairs_indexed(entries)
-                    stats["tie_pairs"] += int(rows.shape[0])
-                    t2 = time.perf_counter()
-                    patch = self._tie_patches(pin_rows[ci & 1, :cnt].numpy(), xindex, bands)
-                    t3 = time.perf_counter()
-                    with torch.cuda.stream(side):
-                        rows_dev = torch.from_numpy(rows).to(dev)
-                        bands_dev = torch.from_numpy(bands).to(dev)
-                        patch_dev = torch.from_numpy(patch).to(dev)
-                        keep += [rows_dev, bands_dev, patch_dev]
-                        _native.check(
-                            lib.lshrs_scatter_band_keys_u8(out[lo:hi].data_ptr(), self.num_bands, bb,
-                                                           rows_dev.data_ptr(), bands_dev.data_ptr(),
-                                                           patch_dev.data_ptr(), rows.shape[0], side.cuda_stream),
-                            "lshrs_scatter_band_keys_u8")
-                    t4 = time.perf_counter()
-                    for key, dt in (("t_wait_ms", t1 - t0), ("t_pairs_ms", t2 - t1), ("t_patch_ms", t3 - t2),
-                                    ("t_scatter_ms", t4 - t3)):
-                        stats[key] = stats.get(key, 0.0) + 1e3 * dt
-            t_loop = time.perf_counter()
-            main.wait_stream(side)
-            main.wait_stream(cstream)
-            side.synchronize()
-            stats["t_drain_ms"] = 1e3 * (time.perf_counter() - t_loop)
-            stats["t_total_ms"] = 1e3 * (time.perf_counter() - t_entry)
-        return self._redo_overflowed(x, out, row_flags, overflow, stats)
 
     def _redo_overflowed(self, x, out, row_flags, overflow, stats):
         for lo, hi in overflow:  # a chunk with more ties than its list holds: redo it on the plain path
@@ -937,7 +775,7 @@ class LSHHasher:
 
     def _pipelined_native(self, x, out, row_flags, ws, tau, stats, native):
         """The pipelined path driven by the library (csrc/pipeline.hip): same chunks, same kernels and the same host
-        engine call per chunk as :meth:`_pipelined_body`, without the interpreter between the launches, with the tie
+        engine call per chunk, without the interpreter between the launches, with the tie
         entries and their vectors exported straight into pinned host memory by a kernel on a side stream."""
         t_entry = time.perf_counter()
         torch = _native.require_gpu()
@@ -994,62 +832,6 @@ class LSHHasher:
                 self._flag_cap_hint = int(sv[2] * 1.25) + 4096
         stats["t_total_ms"] = 1e3 * (time.perf_counter() - t_entry)
         return self._redo_overflowed(x, out, row_flags, overflow, stats)
-
-    def _tie_pairs_indexed(self, entries: np.ndarray):
-        """Like :meth:`_tie_pairs`, plus for every pair the index of an entry that carries the row's vector
-        (the device stages one vector per entry).  Sorted by band.  Band widths of 8, 16 or 32 columns
-        (rows_per_band <= 32) never give duplicate pairs, so no de-duplication pass is needed there."""
-        band_cols = 8 * self.band_bytes
-        if band_cols not in (8, 16, 32):
-            rows, bands = self._tie_pairs(entries)
-            erow = entries[:, 0] >> 16
-            order = np.argsort(erow, kind="stable")
-            return rows, bands, order[np.searchsorted(erow[order], rows)]
-        erow = entries[:, 0] >> 16
-        words = entries[:, 0] & 0xFFFF
-        masks = entries[:, 1]
-        per_word = 32 // band_cols
-        sub_mask = (1 << band_cols) - 1
-        r_parts, b_parts, e_parts = [], [], []
-        idx = np.arange(entries.shape[0], dtype=np.int64)
-        for sub in range(per_word):
-            band = words * per_word + sub
-            hit = (((masks >> (sub * band_cols)) & sub_mask) != 0) & (band < self.num_bands)
-            r_parts.append(erow[hit])
-            b_parts.append(band[hit])
-            e_parts.append(idx[hit])
-        rows = np.concatenate(r_parts)
-        bands = np.concatenate(b_parts).astype(np.int32)
-        eidx = np.concatenate(e_parts)
-        order = np.argsort(bands, kind="stable")
-        return rows[order].astype(np.int64), bands[order], eidx[order]
-
-    def _side_stream(self, dev, which: int = 0):
-        torch = _native.require_gpu()
-        s = self._side_streams.get((dev.index, which))
-        if s is None:
-            s = torch.cuda.Stream(device=dev)
-            self._side_streams[(dev.index, which)] = s
-        return s
-
-    def _pinned(self, dev, cap: int, window: int):
-        torch = _native.require_gpu()
-        key = (dev.index, cap, window)
-        buf = self._pinned_cache.get(key)
-        if buf is None:
-            # patch staging (native resolve): per slot rows int64[pairs] | bands int32[pairs] | keys u8[pairs * bb];
-            # a 32-column word of the tie list touches up to 32 / (columns per band) bands
-            pairs_cap = (cap * max(1, 32 // (8 * self.band_bytes)) + 7) // 8 * 8
-            slot_bytes = (12 + self.band_bytes) * pairs_cap
-            buf = (torch.empty((window,), dtype=torch.int32).pin_memory(),
-                   torch.empty((2, cap, 2), dtype=torch.int64).pin_memory(),
-                   torch.empty((2, cap, self.dim), dtype=torch.float32).pin_memory(),
-                   torch.empty((window,), dtype=torch.int32).pin_memory(),
-                   torch.empty((2, slot_bytes), dtype=torch.uint8).pin_memory(),
-                   torch.empty((2, slot_bytes), dtype=torch.uint8, device=dev),
-                   pairs_cap)
-            self._pinned_cache[key] = buf      # at most three chunk sizes exist (pipeline_chunk_rows, /2, /4)
-        return buf
 
     def _split_applies(self, n: int, replay: bool = False) -> bool:
         """Does a batch of n rows take the split-precision pass?  ``replay``: asked on behalf of the path that also
@@ -1543,7 +1325,6 @@ class LSHHasher:
         state["_one_queue"] = []
         state["_one_leader"] = False
         state["_workspaces"] = {}
-        state["_side_streams"] = {}
         state["_pinned_cache"] = {}
         state["_pipes"] = {}
         state["_plan_cache"] = {}

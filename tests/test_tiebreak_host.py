@@ -135,19 +135,3 @@ def test_host_engine_survives_a_fork():
         time.sleep(0.05)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
 
-
-@pytest.mark.parametrize("nb,r", [(16, 16), (16, 4), (16, 32), (5, 12), (2, 24), (4, 64)])
-def test_indexed_pairs_agree_with_plain_pairs(nb, r):
-    h = LSHHasher(nb, r, 32, seed=1)
-    rng = np.random.default_rng(nb * 7 + r)
-    words_max = (nb * 8 * h.band_bytes + 31) // 32
-    m = 2000
-    rows = rng.choice(100_000, m, replace=False)
-    words = rng.integers(0, words_max, m)
-    masks = np.where(rng.random(m) < 0.8, 1 << rng.integers(0, 32, m), rng.integers(1, 2**32, m))
-    ent = np.stack([(rows << 16) | words, masks], axis=1).astype(np.int64)
-    r1, b1 = h._tie_pairs(ent)
-    r2, b2, e2 = h._tie_pairs_indexed(ent)
-    assert sorted(zip(b1.tolist(), r1.tolist())) == sorted(zip(b2.tolist(), r2.tolist()))
-    assert (np.diff(b2) >= 0).all()                 # sorted by band: _tie_patches slices per band
-    assert ((ent[e2, 0] >> 16) == r2).all()         # every pair points at an entry holding its row

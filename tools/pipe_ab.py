@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two drivers of the host tie-break pipeline (interpreter vs library) on the bench workload, interleaved in one process:
+"""A/B of the host tie-break path with and without the library's chunk driver (pipeline="python": one pass, then NumPy) on the bench workload, interleaved in one process:
 ms per step, stage-1 / fix-up kernel means and the driver's own timers.  usage: pipe_ab.py [rows] [rounds]"""
 import os
 import sys
