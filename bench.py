@@ -227,6 +227,7 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    hasher.kernel_events = []          # (the warm-up steps are steps like the timed ones: their event ring is built here)
     for _ in range(args.warmup):
         hasher.hash_device(x, out=keys)
     elapsed, events, _ = timed_steps(torch, hasher, x, keys, args.steps, args.async_steps, barrier)
