@@ -302,3 +302,23 @@ def test_query_many_equals_looping_query(monkeypatch):
         idx.query_many(queries, top_k=None, top_p=2.0)
     empty = small(monkeypatch, storage=InMemoryStorage(), vector_fetch_fn=lambda ids: data[np.asarray(ids)])
     assert empty.query_many(queries[:3], top_k=None, top_p=0.5) == [[], [], []]
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_array_collision_counting_equals_the_per_member_loop(monkeypatch, packed):
+    """`_ordered_candidates_many` (flat (query, member) pairs, one sort to count, one to order) against the reference's
+    per-member dictionary loop + sort (lshrs/core/main.py:1101-1109, :614), on stores built from op tuples and from a
+    bucket CSR, with crowded buckets, ties in the counts and arbitrary 64-bit ids."""
+    rng = np.random.default_rng(0)
+    idx = make_cpu_lshrs(monkeypatch, dim=16, num_bands=6, rows_per_band=3, num_perm=18, packed_ingest=packed)
+    data = rng.standard_normal((3000, 16)).astype(np.float32)
+    ids = (rng.permutation(10**6)[:3000].astype(np.int64) * 4_000_003).tolist()
+    idx.index(ids[:2000], data[:2000])
+    idx.index(ids[2000:], data[2000:])                       # two CSR segments / more batches
+    queries = rng.standard_normal((150, 16)).astype(np.float32)
+    keys, _ = idx._hasher.hash_batch_packed(queries, return_row_flags=True)
+    many = idx._ordered_candidates_many(keys)
+    for i in range(len(queries)):
+        counts = idx._candidate_counts_from_keys(keys[i])
+        assert many[i] == [k for k, _ in sorted(counts.items(), key=lambda it: (-it[1], it[0]))]
+    assert max(len(m) for m in many) > 50
