@@ -126,7 +126,7 @@ class _PendingKeys:
         state, self._state = self._state, None
         if state is None:
             return
-        stats = {"n": int(self._x.shape[0]), "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+        stats = {"n": int(self._x.shape[0]), "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
         if not h._replay_finish(state, stats):        # the stage-1 list was too small: once more, synchronously, with room
             h._hash_device_locked(self._x, self._out, self._row_flags, "host", host_rows=None)
             stats["relaunches"] += h.last_stats.get("relaunches", 0)
@@ -366,7 +366,7 @@ class LSHHasher:
             out = torch.empty((n, self.num_bands, bb), dtype=torch.uint8, device=dev)
         elif out.shape != (n, self.num_bands, bb) or out.dtype != torch.uint8 or not out.is_contiguous():
             raise ValueError("out must be a contiguous uint8 tensor of shape (n, num_bands, band_bytes)")
-        stats = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+        stats = {"n": n, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
         self.last_stats = stats
         if n == 0:
             return out
@@ -715,7 +715,7 @@ class LSHHasher:
 
     def _redo_overflowed(self, x, out, row_flags, overflow, stats):
         for lo, hi in overflow:  # a chunk with more ties than its list holds: redo it on the plain path
-            sub = {"n": hi - lo, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+            sub = {"n": hi - lo, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
             self.last_stats = sub
             self._hash_device_locked(x[lo:hi], out[lo:hi], row_flags[lo:hi] if row_flags is not None else None,
                                      "host", None, allow_pipeline=False)
@@ -1027,7 +1027,7 @@ class LSHHasher:
                     return got if return_row_flags else got[0]
             keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
             flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
-            total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0}
+            total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
             for lo in range(0, n, 262_144):
                 hi = min(n, lo + 262_144)
                 chunk = arr[lo:hi]
@@ -1084,7 +1084,7 @@ class LSHHasher:
             pin_out.copy_(dev_out, non_blocking=True)
             cur.synchronize()
             ties = int(host_out[tail:tail + 4].view(np.int32)[0])
-            stats = {"n": n, "tie_entries": ties, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0,
+            stats = {"n": n, "tie_entries": ties, "tie_pairs": 0, "relaunches": 0,
                      "tie_break_engine": "device-replay"}
             if ties:
                 if ties > int(tie_list.shape[0]):           # pathological rows: the general path has room for them
@@ -1132,7 +1132,7 @@ class LSHHasher:
         n = arr.shape[0]
         keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
         flags = np.empty(n, dtype=np.uint8) if want_flags else None
-        total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "tie_flips": 0, "relaunches": 0, "flagged": 0,
+        total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0, "flagged": 0,
                  "max_dev_units": 0.0}
         src = torch.from_numpy(arr)
         registered = False
