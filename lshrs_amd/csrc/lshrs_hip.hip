@@ -1056,11 +1056,12 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
       f[j][1] = *reinterpret_cast<const f32x4*>(base + (((2 * e + j) * 2 + 1) * 64 + lane) * 4);
     }
   };
-  // MFMA k (0..23) of an eighth: column tile ct0 + k/12, term (k/4) % 3 of xh*ph + xh*pm + xm*ph, row tile k % 4:
-  // consecutive MFMAs go to different accumulator tiles (a 4-pass MFMA's result is not back in time for the next
-  // instruction; hipcc pads dependent neighbours with s_nops)
+  // MFMA k (0..11) of an eighth: term k / 4 of xh*ph + xh*pm + xm*ph, column tile ct0 + (k / 2) % 2, row tile k % 2: the
+  // four accumulator tiles of the eighth take turns, so two MFMAs on the same tile are four instructions (64 cycles)
+  // apart.  (Two apart - tile order (j, term, rt) - the result of a 4-pass MFMA is not back in time and hipcc pads every
+  // other MFMA with an s_nop: 33 per k-tile and wave.)  Every tile still sees its terms in the order 0, 1, 2.
   auto mfma_one = [&](int ct0, int k, const f32x4 (&f)[2][2], const Bf16Pairs (&hi)[RT], const Bf16Pairs (&mid)[RT]) {
-    const int j = k / (3 * RT), term = (k / RT) % 3, rt = k % RT;
+    const int term = k / (2 * RT), j = (k / RT) % 2, rt = k % RT;
     const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[rt] : hi[rt]);
     const bf16x8 b = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
     // Inline asm pins the accumulator to AGPRs and to in-place accumulation: left to the builtin, hipcc renames
