@@ -51,10 +51,12 @@ def bound_tau_ulps(dim: int) -> float:
 def bound_tau1_ulps(dim: int) -> float:
     """Deterministic bound, same units, on |y1 - y_BLAS| for the split pass: three dropped bf16 cross terms
     (3 * 2^-16 (1 + 2^-7) sum|x p| = 774 units), one MFMA_BF16_ERR_UNITS per matrix instruction of the projection's
-    accumulator (3 per 32-deep k-tile, each relative to |C| + its own products: (3 dim/32 + 1) of them in all) and the
-    host BLAS's own rounding (dim/8 + 3).  The kernel widens the window by 1 % for its ||x|| estimate itself."""
+    accumulator (3 per 32-deep k-tile, each relative to |C| + its own products, where |C| is at most the sum of the
+    absolute values of everything accumulated so far, itself at most (1 + 2^-8)^2 (1 + 2^-7) sum|x p|: (3 dim/32 + 1)
+    x 1.02 of them in all) and the host BLAS's own rounding (dim/8 + 3).  The kernel widens the window by 1 % for its
+    ||x|| estimate itself (taken from the bf16 high parts: >= (1 - 2^-8) ||x||)."""
     n_mfma = 3 * ((dim + 31) // 32)
-    return 768.0 * (1.0 + 2.0 ** -7) + MFMA_BF16_ERR_UNITS * (n_mfma + 1) + float((dim + 7) // 8 + 3)
+    return 768.0 * (1.0 + 2.0 ** -7) + 1.02 * MFMA_BF16_ERR_UNITS * (n_mfma + 1) + float((dim + 7) // 8 + 3)
 
 
 class _ProjectionList(list):
@@ -168,7 +170,7 @@ class LSHHasher:
                   batch (tens of thousands per 1M rows; ``last_stats["max_dev_units"]``), and a batch in which it
                   exceeds ``margin_guard`` x the window is hashed again with the deterministic bound, which the
                   hasher then keeps (``last_stats["margin_escalations"]``).  "bound": use that bound from the
-                  start (``bound_tau1_ulps(dim)``: 1 457 units at 768-d) - keys identical to the reference by
+                  start (``bound_tau1_ulps(dim)``: 1 469 units at 768-d) - keys identical to the reference by
                   construction under the stated per-instruction error of the bf16 MFMA, at ~0.6x the rate.
                   ``tau_ulps="bound"`` does the same for the f32 kernel's tie window (``bound_tau_ulps``).
       margin_guard  fraction of the stage-1 window the measured deviation may reach before the hasher escalates
