@@ -473,6 +473,10 @@ class LSHHasher:
                            torch.zeros(nc, dtype=torch.int32, device=dev),     # LSHRS_SIG_COUNTERS block
                            pinned, pinned.numpy(), [0],
                            torch.empty((cap,), dtype=torch.float32, device=dev))   # stage-1 value of every list entry
+                if len(self._replay_scratch) >= 16 and not self._async_pending:
+                    # a caller that keeps making new streams must not pile up lists: nothing is in flight, start over
+                    self._replay_scratch.clear()
+                    self._replay_events.clear()
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
             flag_list, counts, pinned, host_counts, turn, flag_y = scratch
