@@ -845,6 +845,10 @@ def test_concurrent_single_vector_calls_share_launches(torch_mod):
 
     def counting(vectors, **kw):
         launches.append(len(vectors))
+        if len(launches) == 1:
+            import time
+
+            time.sleep(0.05)          # hold the first leader: everybody else queues up behind it, whatever the scheduler does
         return real(vectors, **kw)
 
     h.hash_batch_packed = counting
