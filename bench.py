@@ -178,6 +178,11 @@ def timed_steps(torch, hasher, x, keys, steps, use_async, barrier):
 
 def main() -> None:
     args = parse()
+    # ONE JSON line on stdout, whatever the libraries underneath choose to print there (gloo announces its connections
+    # on stdout): everything else this process writes to fd 1 goes to stderr, the line itself to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -401,7 +406,8 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    os.close(real_stdout)
 
 
 def bench_sustained(torch, hasher, x, keys, seconds, barrier):
