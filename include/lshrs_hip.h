@@ -112,7 +112,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
  * as the f32 fmaf chain of the f32 kernel, corrects their key bits and reports ties (|y| < tau ...) as above.
  * tau1: the stage-1 window.  Measured, over 2.7e9 projections of six data distributions the stage-1 value never
  * strayed 16 units of 2^-24 ||x|| ||p|| from the chain (profiles/r01_split_window_margin.log; the Python layer's
- * default is 64 units and it watches counter [2] of the replay on every batch); its deterministic bound - every
+ * default is 128 units and it watches counter [2] of the replay on every batch); its deterministic bound - every
  * rounding error at its maximum and aligned - is what LSHHasher(tau1_ulps="bound") passes (lshrs_amd/hasher.py,
  * DESIGN.md §3).  Rows whose largest |x| is outside [2^-60, 2^60] are flagged wholesale.
  *   flag_list int64[flag_cap], flag_count int32[1] (zeroed by the caller): scratch, one entry per flagged
@@ -164,7 +164,28 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
                                        float tau, int64_t* flag_list, int32_t flag_cap,
                                        int32_t blas_model, int32_t* host_counts, void* stream);
 
-/* Diagnostic twin of the above: writes the raw projections instead of their sign bits.
+/* A query vector or a handful (LSHRS.ingest / get_top_k / LSHHasher.hash_vector - lshrs/core/main.py:405,1101 - the
+ * reference's one-vector-per-call pattern): every projection of every row is evaluated as the HOST BLAS evaluates it
+ * (blas_model 1, as in lshrs_sig_hash_batch_split_replay_f32; same precondition: the caller has checked the model
+ * against its BLAS), so the keys are the reference's with no first pass, no tie list and no second launch; one
+ * workgroup per key byte, one memory round trip deep.
+ *   X, keys, row_flags  as for lshrs_sig_hash_batch_f32; each may be device memory or PINNED host memory the device can
+ *                address (a few rows: x is then read over PCIe once per key byte, the keys are stored straight to the host).
+ *   counters     DEVICE int32, zeroed once when allocated.  With host_done: [64 * (1 + LSHRS_SMALL_MAX_ROWS)] (tie count
+ *                and completion tickets), left zeroed by every call.  Without: int32[1], the tie count, which only grows.
+ *   host_done    optional PINNED HOST int32[2]: when the last workgroup has stored its byte, [0] receives the number of
+ *                projections inside the tie window (a statistic: they are decided like all others) and then [1] := epoch,
+ *                after a system-scope fence - a caller that polls [1] for its epoch needs neither a copy nor a stream
+ *                wait to read keys and flags it placed in pinned memory.  NULL: wait on the stream instead.
+ * n <= LSHRS_SMALL_MAX_ROWS, dim % 32 == 0, dim <= 1536, 16-byte aligned rows (else LSHRS_E_TOOLARGE: use the batch
+ * entry points). */
+#define LSHRS_SMALL_MAX_ROWS 256
+int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx,
+                                    const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
+                                    uint8_t* keys, uint8_t* row_flags, int32_t* counters, float tau,
+                                    int32_t blas_model, int32_t* host_done, int32_t epoch, void* stream);
+
+/* Diagnostic twin of lshrs_sig_hash_batch_f32: writes the raw projections instead of their sign bits.
  *   Y (n, ldy) f32 with ldy >= padded columns rounded up to the kernel's column tile
  *   (lshrs_sig_padded_columns()); column b*8*B + i holds dot(P[b*rows+i], X[row]).
  * Used by the parity tests to compare the MFMA chain with the CPU chain model bit for bit. */

@@ -23,6 +23,7 @@ LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hi
 INCLUDE = os.path.join(REPO_ROOT, "include")
 ABI_VERSION = 2
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
+SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
 
 E_BADARG = -10001
 E_TOOLARGE = -10002
@@ -95,6 +96,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_sig_resolve_ties_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, i32, i32, vp,
                                                       vp]
     lib.lshrs_sig_resolve_ties_replay_f32.restype = c.c_int
+    # (X, n, ldx, workspace, bands, rows, dim, keys, row_flags, counters, tau, blas_model, host_done, epoch, stream)
+    lib.lshrs_sig_hash_small_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, vp, f32, i32, vp, i32, vp]
+    lib.lshrs_sig_hash_small_replay_f32.restype = c.c_int
     lib.lshrs_sig_project_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, i64, vp]
     lib.lshrs_sig_project_f32.restype = c.c_int
     lib.lshrs_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, vp, vp]
@@ -134,6 +138,7 @@ EXPORTS = (
     "lshrs_sig_hash_batch_split_f32",
     "lshrs_sig_hash_batch_split_replay_f32",
     "lshrs_sig_resolve_ties_replay_f32",
+    "lshrs_sig_hash_small_replay_f32",
     "lshrs_sig_project_f32",
     "lshrs_gather_rows_f32",
     "lshrs_gather_tied_rows_f32",

@@ -269,6 +269,7 @@ class LSHHasher:
         self._async_pending: list = []
         self._replay_events: Dict[int, list] = {}
         self._pinned_cache: Dict[tuple, tuple] = {}
+        self._small_epoch = 0
         self._flag_cap_hint = 0
         # hyperplanes: one generator, num_bands float64 draws cast to float32 (lsh.py:93-94)
         gen = np.random.default_rng(seed)
@@ -1048,68 +1049,97 @@ class LSHHasher:
         self.last_stats = total
         return (keys, flags) if return_row_flags else keys
 
-    _small_rows = 128
+    _small_rows = 128                 # batches up to this many host rows take the one-launch path below
+    _small_poll_bytes = 128           # ... up to this many KEY BYTES (= workgroups) return through the polled epoch word
+    _small_direct_bytes = 2 << 20     # ... and x is read by the kernel straight from pinned host memory while the key
+                                      #     bytes' reads of it (one per key byte and row) stay below this many bytes
+                                      #     (both thresholds: profiles/r02_small_latency.log)
 
     def _hash_small_locked(self, arr: np.ndarray, dev):
-        """A query vector or a handful (``ingest``, ``get_top_k``, ``hash_vector``): one kernel launch, one copy back,
-        ONE wait.  The rows are copied into pinned host memory and the f32 kernel reads them from there (3 KB over
-        PCIe: no staging copy, no allocation); keys, row flags and the tie counter share one device buffer that comes
-        back in a single asynchronous copy.  Ties (2.6 per 1 000 vectors) take the device replay afterwards.  Returns
-        None where the device tie replay does not apply (the general path then does the work)."""
+        """A query vector or a handful (``ingest``, ``get_top_k``, ``hash_vector``: the reference's one-vector-per-call
+        pattern, lshrs/core/main.py:405,1101): ONE kernel launch.  Every projection is evaluated the way the host BLAS
+        evaluates it (``lshrs_sig_hash_small_replay_f32``: the replay that decides the flagged projections of a large
+        batch, applied to all of them), so the keys are the reference's with no first pass and no tie list.  The rows
+        are copied into pinned host memory; a few are read by the kernel from there (3 KB per key byte over PCIe), more
+        go to the device in one asynchronous copy first.  Up to ``_small_poll_bytes`` key bytes the kernel stores keys and row
+        flags straight into pinned host memory and its last workgroup publishes this call's epoch there - the host
+        polls that word: no copy back, no stream wait; above, one asynchronous copy back and one wait (the per-workgroup
+        system-scope fences of the polled form cost more than they save there).  Returns None where the replay does not
+        apply (host tie-break engine, ``dim % 32``, ``dim > 1536``): the general path then does the work."""
         torch = _native.require_gpu()
         lib = _native.load()
         n = arr.shape[0]
         rb = self.num_bands * self.band_bytes
-        if self.tie_replay != "auto" or self.dim % 32 != 0 or rb % 4 != 0 or not self._replay_model():
+        if self.tie_replay != "auto" or self.dim % 32 != 0 or self.dim > 1536:
+            return None
+        model = self._replay_model()
+        if not model:
             return None
         key = ("small", dev.index)
         buf = self._pinned_cache.get(key)
         cap = self._small_rows
         if buf is None:
-            tail = (cap * rb + cap + 31) // 32 * 32              # keys | flags | pad, then the counter block
-            with torch.cuda.device(dev):
-                dev_out = torch.zeros(tail + 4 * _native.SIG_COUNTERS, dtype=torch.uint8, device=dev)
-            pin_out = torch.zeros(tail + 4 * _native.SIG_COUNTERS, dtype=torch.uint8).pin_memory()
+            tail = (cap * rb + cap + 15) // 16 * 16              # keys | flags | pad, then 4 int32: ties (device form), done[2]
+            pin_out = torch.zeros(tail + 16, dtype=torch.uint8).pin_memory()
             pin_x = torch.zeros((cap, self.dim), dtype=torch.float32).pin_memory()
-            buf = (dev_out, pin_out, pin_out.numpy(), pin_x, pin_x.numpy(), tail,
-                   torch.empty((4096, 2), dtype=torch.int64, device=dev), torch.empty((8192,), dtype=torch.int64, device=dev),
-                   torch.zeros(_native.SIG_COUNTERS, dtype=torch.int32).pin_memory())
+            with torch.cuda.device(dev):
+                x_dev = torch.empty((cap, self.dim), dtype=torch.float32, device=dev)
+                dev_out = torch.zeros(tail + 16, dtype=torch.uint8, device=dev)
+                counters = torch.zeros(64 * (1 + _native.SMALL_MAX_ROWS), dtype=torch.int32, device=dev)
+                torch.cuda.current_stream(dev).synchronize()
+            host_out = pin_out.numpy()
+            buf = {"pin_out": pin_out, "host_out": host_out, "words": host_out[tail:tail + 16].view(np.int32),
+                   "pin_x": pin_x, "host_x": pin_x.numpy(), "x_dev": x_dev, "dev_out": dev_out, "counters": counters,
+                   "tail": tail, "ties_seen": 0}
             self._pinned_cache[key] = buf
-        dev_out, pin_out, host_out, pin_x, host_x, tail, tie_list, flag_list, pin_counts = buf
+        pin_out, host_out, words, pin_x, x_dev = buf["pin_out"], buf["host_out"], buf["words"], buf["pin_x"], buf["x_dev"]
+        tail = buf["tail"]
         ws = self._workspace(dev)
-        host_x[:n] = arr
-        tau = float(self.tau_ulps * _U)
+        buf["host_x"][:n] = arr
+        poll = n * rb <= self._small_poll_bytes
         ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
         with ctx:
             cur = torch.cuda.current_stream(dev)
-            base = dev_out.data_ptr()
-            _native.check(
-                lib.lshrs_sig_hash_batch_f32(pin_x.data_ptr(), n, self.dim, ws.data_ptr(), self.num_bands, self.rows_per_band,
-                                             self.dim, base, tie_list.data_ptr(), int(tie_list.shape[0]), base + tail, tau,
-                                             base + cap * rb, None, cur.cuda_stream), "lshrs_sig_hash_batch_f32")
-            pin_out.copy_(dev_out, non_blocking=True)
-            cur.synchronize()
-            ties = int(host_out[tail:tail + 4].view(np.int32)[0])
-            stats = {"n": n, "tie_entries": ties, "tie_pairs": 0, "relaunches": 0,
-                     "tie_break_engine": "device-replay"}
-            if ties:
-                if ties > int(tie_list.shape[0]):           # pathological rows: the general path has room for them
-                    dev_out[tail:].zero_()
-                    return None
+            if n * rb * self.dim * 4 <= self._small_direct_bytes:
+                x_ptr = pin_x.data_ptr()
+            else:
+                x_dev[:n].copy_(pin_x[:n], non_blocking=True)
+                x_ptr = x_dev.data_ptr()
+            tau = float(self.tau_ulps * _U)
+            if poll:
+                epoch = self._small_epoch = self._small_epoch % 0x7FFFFFF0 + 1
+                base = pin_out.data_ptr()
                 _native.check(
-                    lib.lshrs_sig_resolve_ties_replay_f32(pin_x.data_ptr(), n, self.dim, ws.data_ptr(), self.num_bands,
-                                                          self.rows_per_band, self.dim, base, tie_list.data_ptr(),
-                                                          int(tie_list.shape[0]), base + tail, tau, flag_list.data_ptr(),
-                                                          int(flag_list.shape[0]), self._replay_model(), pin_counts.data_ptr(),
-                                                          cur.cuda_stream), "lshrs_sig_resolve_ties_replay_f32")
+                    lib.lshrs_sig_hash_small_replay_f32(x_ptr, n, self.dim, ws.data_ptr(), self.num_bands,
+                                                        self.rows_per_band, self.dim, base, base + cap * rb,
+                                                        buf["counters"].data_ptr(), tau, model, base + tail + 4, epoch,
+                                                        cur.cuda_stream), "lshrs_sig_hash_small_replay_f32")
+                spins = 0
+                while words[2] != epoch:                         # (~20 us; the stream wait is the fallback, not the path)
+                    spins += 1
+                    if spins > 20_000:
+                        cur.synchronize()
+                        if words[2] != epoch:
+                            raise _native.NativeLibraryError("lshrs_sig_hash_small_replay_f32 finished without "
+                                                             "publishing its epoch")
+                ties = int(words[1])
+            else:
+                dev_out = buf["dev_out"]
+                base = dev_out.data_ptr()                        # (counter [0] lives in the block that comes back: it only grows)
+                _native.check(
+                    lib.lshrs_sig_hash_small_replay_f32(x_ptr, n, self.dim, ws.data_ptr(), self.num_bands,
+                                                        self.rows_per_band, self.dim, base, base + cap * rb, base + tail,
+                                                        tau, model, None, 0, cur.cuda_stream),
+                    "lshrs_sig_hash_small_replay_f32")
                 pin_out.copy_(dev_out, non_blocking=True)
-                cur.synchronize()                           # (the export left the device counters zeroed)
-                if int(pin_counts[1]) > int(flag_list.shape[0]):
-                    return None
-                stats["tie_pairs"] = int(pin_counts[1])
+                cur.synchronize()
+                seen = int(words[0])
+                ties = (seen - buf["ties_seen"]) & 0x7FFFFFFF
+                buf["ties_seen"] = seen
         keys = host_out[:n * rb].reshape(n, self.num_bands, self.band_bytes).copy()
         flags = host_out[cap * rb:cap * rb + n].copy()
-        self.last_stats = stats
+        self.last_stats = {"n": n, "tie_entries": ties, "tie_pairs": ties, "relaunches": 0,
+                           "tie_break_engine": "device-replay", "path": "small-replay"}
         return keys, flags
 
     def _stream_buffers(self, dev, rows: int):
@@ -1332,6 +1362,7 @@ class LSHHasher:
         state["_one_leader"] = False
         state["_workspaces"] = {}
         state["_pinned_cache"] = {}
+        state["_small_epoch"] = 0
         state["_pipes"] = {}
         state["_plan_cache"] = {}
         state["_replay_scratch"] = {}
@@ -1362,6 +1393,7 @@ class LSHHasher:
         self.__dict__.setdefault("split_min_elems", 16 << 20)
         self.__dict__.setdefault("margin_guard", 0.5)
         self.__dict__.setdefault("audit_every", 64)
+        self.__dict__.setdefault("_small_epoch", 0)
         self.__dict__.setdefault("_audit_countdown", 1)
         self.__dict__.setdefault("audit_failures", 0)
         self.__dict__.setdefault("margin_escalations", 0)

@@ -966,3 +966,43 @@ def test_split_window_margin_with_assigned_hyperplanes(torch_mod):
             want = hash_batch_literal_packed(h.projections, data[sl].cpu().numpy())
             assert np.array_equal(keys[sl].cpu().numpy(), want), name
         assert st["max_dev_units"] * 2 <= h.tau1_ulps, (name, st)
+
+
+@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (42, 16, 4, 128), (11, 3, 5, 64), (7, 16, 32, 1536),
+                                           (5, 8, 16, 1024), (2, 1, 1, 32)])
+def test_small_batches_take_the_direct_replay_and_are_the_reference_keys(torch_mod, seed, nb, r, dim):
+    """One vector or a handful: every projection is the replayed host-BLAS value (lshrs_sig_hash_small_replay_f32).
+    Keys = the literal restatement of the reference (same host BLAS) on every row, including rows whose projections
+    are exact zeros, NaN, Inf and tiny; flags as the batch kernels give them; the epoch word is how the call returns."""
+    from oracle.lshrs_oracle import hash_batch_literal_packed, is_zero_vector_rows
+
+    h = _hasher(seed, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("host BLAS summation order not recognised: the small path is the general one here")
+    rng = np.random.default_rng(900 + dim + r)
+    for n in (1, 2, 8, 9, 31, 128):
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        if n >= 8:
+            x[1] = 0.0                                   # y = 0 everywhere: bit 0
+            x[2] = 1e-9                                  # "zero vector" by the orchestrator's test, hashed all the same
+            x[3, 7] = np.nan
+            x[4, 5] = np.inf
+            x[5] *= 1e-30
+            x[6] = np.asarray(h.projections[0][0]) * -1.0   # anti-parallel to a hyperplane
+            x[7] = -0.0
+        keys, flags = h.hash_batch_packed(x, return_row_flags=True)
+        assert h.last_stats.get("path") == "small-replay", h.last_stats
+        with np.errstate(all="ignore"):
+            want = hash_batch_literal_packed(h.projections, x)
+        assert np.array_equal(keys, want), (n, np.nonzero((keys != want).any(axis=(1, 2)))[0])
+        assert np.array_equal((flags & 1).astype(bool), is_zero_vector_rows(x))
+        assert np.array_equal((flags & 2) != 0, np.isnan(x).any(axis=1))
+        # the batch path gives the same bytes for the same rows
+        big = h.hash_device(torch_mod.from_numpy(np.tile(x, (max(1, 300 // n), 1))).cuda()).cpu().numpy()
+        assert np.array_equal(big[:n], keys)
+    # many calls in a row: the epoch advances, nothing stale is returned
+    xs = rng.standard_normal((50, dim)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        want = hash_batch_literal_packed(h.projections, xs)
+    for i in range(50):
+        assert np.array_equal(h.hash_batch_packed(xs[i:i + 1])[0], want[i])
