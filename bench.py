@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--rows-per-gpu", type=int, default=0, help="0 = the BASELINE config for this N (see the docstring)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained run (0 = skip)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=150_000, help="rows of the workload the CPU baseline hashes")
+    ap.add_argument("--cpu-sample-rows", type=int, default=300_000, help="rows of the workload the CPU baseline hashes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rerank", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the (untimed) parity check against the oracle")
