@@ -427,7 +427,39 @@ def bench_sustained(torch, hasher, x, keys, seconds, barrier):
            "stage2_kernel_ms_mean": sum(k2) / max(1, len(k2)), "in_kernel_clock_GHz": clock}
     if k1:
         out["roofline"] = stage1_roofline(out["stage1_kernel_ms_mean"], n, DIM, NUM_PERM, "sig16_kernel, sustained")
+    out["two_streams"] = bench_two_streams(torch, hasher, x, keys, steps // 2)
     return out
+
+
+def bench_two_streams(torch, hasher, x, keys, steps):
+    """The same batches through the streaming entry point on two alternating streams: 1 M rows are 15.26 rounds of
+    workgroups, so the last round of stage 1 runs on a quarter of the chip and stage 2 waits behind it; on a second stream
+    the next batch's workgroups take the CUs that tail leaves idle.  Throughput only: kernels of two batches overlap, so
+    per-kernel durations (and the roofline fraction derived from them) are not meaningful in this mode."""
+    n = int(x.shape[0])
+    dev = x.device
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = [keys, torch.empty_like(keys)]
+
+    def run(k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        handles = []
+        for i in range(k):
+            with torch.cuda.stream(streams[i % 2]):
+                handles.append(hasher.hash_device_async(x, out=outs[i % 2]))
+            if len(handles) > 2:
+                handles.pop(0).result()
+        for h in handles:
+            h.result()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(30)
+    elapsed = run(steps)
+    return {"value": n * steps / elapsed, "unit": "vectors/s", "steps": steps, "ms_per_step_mean": 1e3 * elapsed / steps,
+            "entry_point": "hash_device_async, consecutive batches on two alternating streams, every batch verified",
+            "keys_equal": bool(torch.equal(outs[0], outs[1]))}
 
 
 def bench_bound(torch, np, x, keys, local_dev, steps, barrier):
