@@ -568,6 +568,8 @@ def bench_e2e(torch, np, x, local_dev):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         out[label] = m / best
+        if packed:
+            out["query_many"] = bench_query_many(torch, np, idx, x[:rows], host)
     m = 20_000
     t0 = time.perf_counter()
     index_literal(InMemoryStorage(), ids[:m].tolist(), host[:m], LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(),
@@ -575,6 +577,32 @@ def bench_e2e(torch, np, x, local_dev):
     out["cpu_reference_literal_index"] = m / (time.perf_counter() - t0)
     out["note"] = ("host NumPy vectors -> buckets in InMemoryStorage; index_packed = keys grouped into buckets on the "
                    "device and handed over as arrays, index_op_tuples = the reference's (band, key, id) tuples")
+    return out
+
+
+def bench_query_many(torch, np, idx, corpus, host):
+    """10 000 queries (noisy copies of stored rows, as config 3's) through the public batched API against
+    the index bench_e2e just built - one signature launch, array collision counting, one rerank launch on the
+    device-resident corpus - beside the reference's per-query flow restated literally (oracle) on a sample."""
+    from oracle.lshrs_oracle import query_literal
+
+    rows = int(corpus.shape[0])
+    rng = np.random.default_rng(7)
+    nq = 10_000
+    pick = rng.choice(rows, nq, replace=False)
+    q = host[pick] + 0.1 * rng.standard_normal((nq, DIM)).astype(np.float32)
+    # bench_e2e stored every vector under ids + 1e7 and ids + 2e7 (and the first 100 000 under ids): id % 1e7 = its row
+    out = {"queries": nq, "stored_ids": 2 * rows + 100_000, "unit": "queries/s"}
+    idx.query_many(q[:200], top_k=10)
+    t0 = time.perf_counter()
+    got = idx.query_many(q, top_k=10)
+    out["top_k_10"] = nq / (time.perf_counter() - t0)
+    out["source_row_among_first_three"] = float(np.mean([bool(g) and pick[i] in [v % 10_000_000 for v in g[:3]] for i, g in enumerate(got)]))
+    lit = 40
+    t0 = time.perf_counter()
+    want = [query_literal(idx._storage, idx._hasher.projections, DIM, v, top_k=10) for v in q[:lit]]
+    out["top_k_10_cpu_reference_literal"] = lit / (time.perf_counter() - t0)
+    out["equal_to_reference_literal_on_sample"] = bool(want == got[:lit])
     return out
 
 

@@ -21,6 +21,8 @@ tests/golden/g5_orchestration.json holds the reference's own batches for these c
 
 from __future__ import annotations
 
+import contextlib
+import gc
 import json
 import logging
 import math
@@ -33,7 +35,7 @@ import numpy as np
 from .bandrows import get_optimal_config
 from .hasher import LSHHasher
 from .packed_ops import bucket_csr as _bucket_csr
-from .similarity import rerank_padded as _rerank_padded
+from .similarity import rerank_padded_arrays as _rerank_padded
 from .similarity import top_k_cosine
 from .storage import BucketOperation, default_storage
 
@@ -69,6 +71,35 @@ class _DeferredStorage:
         if item in ("batch_add_csr", "batch_add_packed", "get_buckets_many") and self._real is None:
             raise AttributeError(item)          # (capability probes must not open a connection)
         return getattr(self._resolve(), item)
+
+
+@contextlib.contextmanager
+def _gc_paused():
+    """Building millions of small result objects: the cyclic collector's passes over them are 40 % of the time and can
+    free nothing (ints, floats and tuples of them)."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
+def _ragged_positions(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Concatenation of ``arange(starts[i], starts[i] + lens[i])`` over i."""
+    total = int(lens.sum())
+    return np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens) + np.repeat(starts, lens)
+
+
+def _split_rows(flat: list, lens: np.ndarray) -> List[list]:
+    """A flat Python list cut into consecutive pieces of the given lengths."""
+    ends = np.cumsum(lens).tolist()
+    out, lo = [], 0
+    for hi in ends:
+        out.append(flat[lo:hi])
+        lo = hi
+    return out
 
 
 class LSHRS:
@@ -332,46 +363,50 @@ class LSHRS:
         keys, flags = self._hasher.hash_batch_packed(arr, return_row_flags=True)
         if (flags & 1).any():
             raise ValueError(_ZERO_MSG)
-        ordered_ids = self._ordered_candidates_many(keys)
+        um, bounds = self._ordered_candidates_arrays(keys)
+        lens = np.diff(bounds)
         if top_p is None:
-            return [ids if top_k is None else ids[:top_k] for ids in ordered_ids]
+            keep = lens if top_k is None else np.minimum(lens, top_k)
+            with _gc_paused():
+                return _split_rows(um[_ragged_positions(bounds[:-1], keep)].tolist(), keep)
 
         # rerank every non-empty candidate list in one launch: a (q, c_max) index matrix padded with -1
         # (out-of-range entries score NaN, which the device sort places last)
+        c_max = int(lens.max()) if nq else 0
+        if c_max == 0:
+            return [[] for _ in range(nq)]
+        rows = np.repeat(np.arange(nq, dtype=np.int64), lens)
+        cols = np.arange(um.shape[0], dtype=np.int64) - np.repeat(bounds[:-1], lens)
+        cand_ids = np.full((nq, c_max), -1, dtype=np.int64)
+        cand_ids[rows, cols] = um
         if corpus is None:
             fetch = self._require_vector_fetch_fn()
-            blocks, offsets, total = [], [], 0
-            for ids in ordered_ids:
-                offsets.append(total)
-                if ids:
-                    got = np.asarray(fetch(ids), dtype=np.float32)
-                    if got.ndim != 2 or got.shape[1] != self._dim:
-                        raise ValueError(f"Fetched vectors must have shape (n, {self._dim}); received {got.shape}")
-                    if got.shape[0] != len(ids):
-                        raise ValueError("vector_fetch_fn returned mismatched batch size "
-                                         f"(expected {len(ids)}, received {got.shape[0]})")
-                    blocks.append(got)
-                    total += len(ids)
-            table = np.concatenate(blocks, axis=0) if blocks else np.zeros((1, self._dim), dtype=np.float32)
-        c_max = max((len(ids) for ids in ordered_ids), default=0)
-        if c_max == 0:
-            return [[] for _ in ordered_ids]
-        cand = np.full((nq, c_max), -1, dtype=np.int64)
-        for qi, ids in enumerate(ordered_ids):
-            if ids:
-                cand[qi, :len(ids)] = ids if corpus is not None else np.arange(offsets[qi], offsets[qi] + len(ids))
-        ranked = _rerank_padded(arr, corpus if corpus is not None else table, cand)
-        out: List[List[Tuple[int, float]]] = []
-        for qi, ids in enumerate(ordered_ids):
-            if not ids:
-                out.append([])
-                continue
-            scored = [(ids[pos], score) for pos, score in ranked[qi][:len(ids)]]
-            limit = max(1, math.ceil(len(scored) * top_p))
-            if top_k is not None:
-                limit = min(limit, top_k)
-            out.append(scored[:limit])
-        return out
+            blocks = []
+            for qi in np.flatnonzero(lens):
+                ids = um[bounds[qi]:bounds[qi + 1]].tolist()
+                got = np.asarray(fetch(ids), dtype=np.float32)
+                if got.ndim != 2 or got.shape[1] != self._dim:
+                    raise ValueError(f"Fetched vectors must have shape (n, {self._dim}); received {got.shape}")
+                if got.shape[0] != len(ids):
+                    raise ValueError("vector_fetch_fn returned mismatched batch size "
+                                     f"(expected {len(ids)}, received {got.shape[0]})")
+                blocks.append(got)
+            table = np.concatenate(blocks, axis=0)
+            cand = np.full((nq, c_max), -1, dtype=np.int64)
+            cand[rows, cols] = np.arange(um.shape[0], dtype=np.int64)     # row of `table` = position in the flat list
+        else:
+            table, cand = corpus, cand_ids
+        order, scores = _rerank_padded(arr, table, cand)                   # (q, c_max): positions, descending scores
+        keep = np.maximum(1, np.ceil(lens * top_p).astype(np.int64))       # (reference: main.py:652-657)
+        keep[lens == 0] = 0
+        if top_k is not None:
+            keep = np.minimum(keep, top_k)
+        krows = np.repeat(np.arange(nq, dtype=np.int64), keep)
+        kcols = np.arange(int(keep.sum()), dtype=np.int64) - np.repeat(np.cumsum(keep) - keep, keep)
+        ids = cand_ids[krows, order[krows, kcols]]
+        with _gc_paused():
+            pairs = list(zip(ids.tolist(), scores[krows, kcols].astype(np.float64).tolist()))
+            return _split_rows(pairs, keep)
 
     # ------------------------------------------------------------------ storage pass-throughs
     def delete(self, indices: Union[int, Sequence[int]]) -> None:
@@ -493,11 +528,12 @@ class LSHRS:
                 counts[candidate] = counts.get(candidate, 0) + 1
         return counts
 
-    def _ordered_candidates_many(self, keys: np.ndarray) -> List[List[int]]:
+    def _ordered_candidates_arrays(self, keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """For every query: the stored ids that share at least one band bucket with it, ordered by (-collisions, id) -
         ``_candidate_counts`` + the sort of ``query`` (lshrs/core/main.py:1088-1111, :614) for a whole batch, as array
         work: bucket members are gathered as flat (query, member) pairs, one sort counts the collisions, one orders the
-        candidates.  No Python object per member."""
+        candidates.  Returns ``(ids, bounds)``: query ``i``'s candidates are ``ids[bounds[i]:bounds[i + 1]]``.  No Python
+        object per member."""
         nq, nb = keys.shape[0], keys.shape[1]
         if hasattr(self._storage, "get_buckets_many"):
             q, m = self._storage.get_buckets_many(keys)
@@ -511,22 +547,34 @@ class LSHRS:
                         qs.append(np.full(len(mem), qi, dtype=np.int64))
             q = np.concatenate(qs) if qs else np.empty(0, np.int64)
             m = np.concatenate(ms) if ms else np.empty(0, np.int64)
-        out: List[List[int]] = [[] for _ in range(nq)]
         if q.size == 0:
-            return out
-        order = np.lexsort((m, q))                           # by query, then member
-        q, m = q[order], m[order]
-        first = np.r_[True, (q[1:] != q[:-1]) | (m[1:] != m[:-1])]
-        starts = np.flatnonzero(first)
-        counts = np.diff(np.r_[starts, q.shape[0]])
-        uq, um = q[starts], m[starts]
-        rank = np.lexsort((um, -counts, uq))                 # by query, then -collisions, then id
-        uq, um = uq[rank], um[rank]
-        bounds = np.searchsorted(uq, np.arange(nq + 1))
-        flat = um.tolist()
-        for qi in range(nq):
-            out[qi] = flat[bounds[qi]:bounds[qi + 1]]
-        return out
+            return np.empty(0, np.int64), np.zeros(nq + 1, dtype=np.int64)
+        qbits, cbits = max(1, int(nq - 1).bit_length()), int(nb).bit_length()
+        mbits = 63 - qbits - cbits
+        if int(m.min()) >= 0 and int(m.max()) < (1 << mbits):
+            # one 64-bit key per pair: (query, member), then (query, bands - collisions, member): two plain sorts
+            pair = np.sort((q << mbits) | m)
+            first = np.r_[True, pair[1:] != pair[:-1]]
+            starts = np.flatnonzero(first)
+            counts = np.diff(np.r_[starts, pair.shape[0]])
+            uniq = pair[starts]
+            uq, um = uniq >> mbits, uniq & ((1 << mbits) - 1)
+            ranked = np.sort((uq << (mbits + cbits)) | ((nb - counts) << mbits) | um)
+            uq, um = ranked >> (mbits + cbits), ranked & ((1 << mbits) - 1)
+        else:
+            order = np.lexsort((m, q))                           # by query, then member
+            q, m = q[order], m[order]
+            first = np.r_[True, (q[1:] != q[:-1]) | (m[1:] != m[:-1])]
+            starts = np.flatnonzero(first)
+            counts = np.diff(np.r_[starts, q.shape[0]])
+            uq, um = q[starts], m[starts]
+            rank = np.lexsort((um, -counts, uq))                 # by query, then -collisions, then id
+            uq, um = uq[rank], um[rank]
+        return um, np.searchsorted(uq, np.arange(nq + 1)).astype(np.int64)
+
+    def _ordered_candidates_many(self, keys: np.ndarray) -> List[List[int]]:
+        um, bounds = self._ordered_candidates_arrays(keys)
+        return _split_rows(um.tolist(), np.diff(bounds))
 
     def _enqueue_packed(self, index: int, band_keys: np.ndarray) -> None:
         ops = [(b, band_keys[b].tobytes(), index) for b in range(band_keys.shape[0])]

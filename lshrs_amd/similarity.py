@@ -210,11 +210,12 @@ def rerank_batch(queries, corpus, cand_idx, *, k: int, return_tensors: bool = Fa
     return [[(int(p), float(v)) for p, v in zip(o[i], s[i])] for i in range(o.shape[0])]
 
 
-def rerank_padded(queries, corpus, cand_idx):
-    """Ragged batched rerank: ``cand_idx`` is ``(q, c_max)`` int64 with ``-1`` padding after each query's
-    candidates.  Returns, per query, ``[(position, score), ...]`` over its *valid* candidates in descending
-    score (padding scores NaN on the device and sorts last, so it is simply cut off).  Zero-norm vectors raise
-    like the reference; an index outside the corpus raises ``IndexError``."""
+def rerank_padded_arrays(queries, corpus, cand_idx):
+    """Ragged batched rerank, arrays out: ``cand_idx`` is ``(q, c_max)`` int64 with ``-1`` padding after each query's
+    candidates.  Returns ``(order, scores)``, both ``(q, c_max)`` NumPy arrays: ``order[i, j]`` = position (column of
+    ``cand_idx``) of query i's j-th best candidate, ``scores[i, j]`` its cosine, descending; padding scores NaN on the
+    device and sorts last, so row i is meaningful up to its number of valid candidates.  Zero-norm vectors raise like
+    the reference; an index outside the corpus raises ``IndexError``."""
     torch = _native.require_gpu()
 
     def dev(a, dtype):
@@ -230,6 +231,14 @@ def rerank_padded(queries, corpus, cand_idx):
     if bool(((status == 2) & valid).any()):
         raise IndexError("candidate index out of range of the corpus")
     order, sorted_scores = topk_desc_device(scores, int(d_i.shape[1]))
-    counts = valid.sum(dim=1).cpu().numpy()
-    o, s = order.cpu().numpy(), sorted_scores.cpu().numpy()
-    return [[(int(p), float(v)) for p, v in zip(o[i, :counts[i]], s[i, :counts[i]])] for i in range(o.shape[0])]
+    return order.cpu().numpy(), sorted_scores.cpu().numpy()
+
+
+def rerank_padded(queries, corpus, cand_idx):
+    """:func:`rerank_padded_arrays` as Python objects: per query ``[(position, score), ...]`` over its valid candidates,
+    descending."""
+    order, scores = rerank_padded_arrays(queries, corpus, cand_idx)
+    idx = cand_idx.cpu().numpy() if hasattr(cand_idx, "cpu") else np.asarray(cand_idx)
+    counts = (idx >= 0).sum(axis=1)
+    return [[(int(p), float(v)) for p, v in zip(order[i, :counts[i]], scores[i, :counts[i]])]
+            for i in range(order.shape[0])]

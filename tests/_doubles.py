@@ -47,11 +47,17 @@ def make_cpu_lshrs(monkeypatch, **kw):
 
 
 def oracle_rerank_padded(queries, corpus, cand_idx):
-    """CPU stand-in for lshrs_amd.similarity.rerank_padded: the oracle's top_k_cosine per query."""
+    """CPU stand-in for lshrs_amd.similarity.rerank_padded_arrays: the oracle's top_k_cosine per query, as the
+    ``(order, scores)`` matrices (rows padded with position 0 / NaN behind the valid candidates)."""
     corpus = np.asarray(corpus, dtype=np.float32)
-    out = []
+    cand_idx = np.asarray(cand_idx)
+    order = np.zeros(cand_idx.shape, dtype=np.int32)
+    scores = np.full(cand_idx.shape, np.nan, dtype=np.float32)
     for qi in range(len(queries)):
-        idx = np.asarray(cand_idx[qi])
+        idx = cand_idx[qi]
         idx = idx[idx >= 0]
-        out.append(O.top_k_cosine(queries[qi], corpus[idx], k=len(idx)) if len(idx) else [])
-    return out
+        if len(idx):
+            ranked = O.top_k_cosine(queries[qi], corpus[idx], k=len(idx))
+            order[qi, :len(ranked)] = [p for p, _ in ranked]
+            scores[qi, :len(ranked)] = [v for _, v in ranked]
+    return order, scores

@@ -304,15 +304,19 @@ def test_query_many_equals_looping_query(monkeypatch):
     assert empty.query_many(queries[:3], top_k=None, top_p=0.5) == [[], [], []]
 
 
+@pytest.mark.parametrize("id_kind", ["composite-key sorts", "wide ids: lexsort"])
 @pytest.mark.parametrize("packed", [False, True])
-def test_array_collision_counting_equals_the_per_member_loop(monkeypatch, packed):
+def test_array_collision_counting_equals_the_per_member_loop(monkeypatch, packed, id_kind):
     """`_ordered_candidates_many` (flat (query, member) pairs, one sort to count, one to order) against the reference's
     per-member dictionary loop + sort (lshrs/core/main.py:1101-1109, :614), on stores built from op tuples and from a
     bucket CSR, with crowded buckets, ties in the counts and arbitrary 64-bit ids."""
     rng = np.random.default_rng(0)
     idx = make_cpu_lshrs(monkeypatch, dim=16, num_bands=6, rows_per_band=3, num_perm=18, packed_ingest=packed)
     data = rng.standard_normal((3000, 16)).astype(np.float32)
-    ids = (rng.permutation(10**6)[:3000].astype(np.int64) * 4_000_003).tolist()
+    ids = rng.permutation(10**6)[:3000].astype(np.int64) * 4_000_003
+    if id_kind.startswith("wide"):
+        ids = ids * 1_000_003                                # past the bits a (query, count, id) key leaves for the id
+    ids = ids.tolist()
     idx.index(ids[:2000], data[:2000])
     idx.index(ids[2000:], data[2000:])                       # two CSR segments / more batches
     queries = rng.standard_normal((150, 16)).astype(np.float32)
