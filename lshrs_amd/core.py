@@ -300,21 +300,24 @@ class LSHRS:
         keys, flag = self._hash_one(query_vector)
         if flag & 1:
             raise ValueError(_ZERO_MSG)
-        counts = self._candidate_counts_from_keys(keys)
-        if not counts:
+        if getattr(self._storage, "prefers_batched_lookup", False):
+            # array-backed buckets: one vectorised lookup for all bands and two sorts instead of a Python loop per member
+            candidate_indices = self._ordered_candidates_arrays(keys[None])[0].tolist()
+        else:
+            counts = self._candidate_counts_from_keys(keys)
+            candidate_indices = [idx for idx, _ in sorted(counts.items(), key=lambda item: (-item[1], item[0]))]
+        if not candidate_indices:
             return []
-        ordered = sorted(counts.items(), key=lambda item: (-item[1], item[0]))
 
         if top_p is None:
             if top_k is None:
-                top_k = len(ordered)
+                top_k = len(candidate_indices)
             if top_k <= 0:
                 raise ValueError("top_k must be greater than zero when provided")
-            return [idx for idx, _ in ordered[:top_k]]
+            return candidate_indices[:top_k]
 
         if not 0 < top_p <= 1:
             raise ValueError("top_p must be within the range (0, 1]")
-        candidate_indices = [idx for idx, _ in ordered]
         fetched = self._require_vector_fetch_fn()(candidate_indices)
         arr = np.asarray(fetched, dtype=np.float32)
         if arr.ndim != 2 or arr.shape[1] != self._dim:

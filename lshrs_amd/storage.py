@@ -64,6 +64,12 @@ class InMemoryStorage:
                 out.update(seg.members[seg.offsets[g]:seg.offsets[g + 1]].tolist())
         return out
 
+    @property
+    def prefers_batched_lookup(self) -> bool:
+        """True once buckets live in array segments (``batch_add_csr``): a query then reads all its bands' buckets
+        through :meth:`get_buckets_many` rather than one :meth:`get_bucket` per band."""
+        return bool(self._segments)
+
     def get_buckets_many(self, keys) -> Tuple[np.ndarray, np.ndarray]:
         """Every member of every bucket a batch of queries touches, as two flat arrays ``(query index, member id)`` - one
         pair per (query, band, member) - without a Python object per member (the collision count of
