@@ -177,7 +177,7 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
  *                projections inside the tie window (a statistic: they are decided like all others) and then [1] := epoch,
  *                after a system-scope fence - a caller that polls [1] for its epoch needs neither a copy nor a stream
  *                wait to read keys and flags it placed in pinned memory.  NULL: wait on the stream instead.
- * n <= LSHRS_SMALL_MAX_ROWS, dim % 32 == 0, dim <= 1536, 16-byte aligned rows (else LSHRS_E_TOOLARGE: use the batch
+ * n <= LSHRS_SMALL_MAX_ROWS, dim % 32 == 0, dim <= 4096, 16-byte aligned rows (else LSHRS_E_TOOLARGE: use the batch
  * entry points). */
 #define LSHRS_SMALL_MAX_ROWS 256
 int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx,

@@ -2034,7 +2034,7 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx, cons
     return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
-  if (dim % 32 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || g.ktiles > 48 ||
+  if (dim % 32 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || g.ktiles > 128 ||
       n > LSHRS_SMALL_MAX_ROWS || n * row_bytes > 0x7fffffffLL)
     return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2055,7 +2055,8 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx, cons
   a.tau = tau;
   const dim3 grid((unsigned)(n * row_bytes)), block(64);
   if (g.ktiles <= 24) hipLaunchKernelGGL(sig_small_kernel<24>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(sig_small_kernel<48>, grid, block, 0, s, a);
+  else if (g.ktiles <= 48) hipLaunchKernelGGL(sig_small_kernel<48>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(sig_small_kernel<128>, grid, block, 0, s, a);      // 144 KiB of LDS: one workgroup per CU
   return -(int)hipGetLastError();
 }
 

@@ -1065,12 +1065,12 @@ class LSHHasher:
         flags straight into pinned host memory and its last workgroup publishes this call's epoch there - the host
         polls that word: no copy back, no stream wait; above, one asynchronous copy back and one wait (the per-workgroup
         system-scope fences of the polled form cost more than they save there).  Returns None where the replay does not
-        apply (host tie-break engine, ``dim % 32``, ``dim > 1536``): the general path then does the work."""
+        apply (host tie-break engine, ``dim % 32``, ``dim > 4096``): the general path then does the work."""
         torch = _native.require_gpu()
         lib = _native.load()
         n = arr.shape[0]
         rb = self.num_bands * self.band_bytes
-        if self.tie_replay != "auto" or self.dim % 32 != 0 or self.dim > 1536:
+        if self.tie_replay != "auto" or self.dim % 32 != 0 or self.dim > 4096:
             return None
         model = self._replay_model()
         if not model:

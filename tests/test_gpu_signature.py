@@ -969,7 +969,7 @@ def test_split_window_margin_with_assigned_hyperplanes(torch_mod):
 
 
 @pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (42, 16, 4, 128), (11, 3, 8, 64), (7, 16, 32, 1536),
-                                           (5, 8, 16, 1024), (2, 1, 12, 32)])
+                                           (5, 8, 16, 1024), (2, 1, 12, 32), (3, 16, 16, 3072), (4, 4, 8, 4096)])
 def test_small_batches_take_the_direct_replay_and_are_the_reference_keys(torch_mod, seed, nb, r, dim):
     """One vector or a handful: every projection is the replayed host-BLAS value (lshrs_sig_hash_small_replay_f32).
     Keys = the literal restatement of the reference (same host BLAS) on every row, including rows whose projections
