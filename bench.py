@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle-steps", type=int, default=40,
+                    help="untimed steps in front of the warm-up: after an idle period the chip's power controller clamps "
+                         "launches 3..20 (up to 1.49 ms against 1.03: profiles/r02_step_transient.log); the settled rate "
+                         "is the one a job sees.  0 = time the transient, as round 1 did")
     ap.add_argument("--rows-per-gpu", type=int, default=0, help="0 = the BASELINE config for this N (see the docstring)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained run (0 = skip)")
@@ -233,8 +237,9 @@ def main() -> None:
         torch.cuda.synchronize(dev)
 
     hasher.kernel_events = []          # (the warm-up steps are steps like the timed ones: their event ring is built here)
-    for _ in range(args.warmup):
+    for _ in range(args.settle_steps + args.warmup):
         hasher.hash_device(x, out=keys)
+    hasher.kernel_events.clear()
     elapsed, events, _ = timed_steps(torch, hasher, x, keys, args.steps, args.async_steps, barrier)
     stats = dict(hasher.last_stats)
     my_ms = 1e3 * elapsed / args.steps
@@ -302,6 +307,7 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": args.settle_steps,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",

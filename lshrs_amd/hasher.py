@@ -59,6 +59,17 @@ def bound_tau1_ulps(dim: int) -> float:
     return 768.0 * (1.0 + 2.0 ** -7) + 1.02 * MFMA_BF16_ERR_UNITS * (n_mfma + 1) + float((dim + 7) // 8 + 3)
 
 
+def escalated_window(window: float, max_dev: float, dim: int) -> Tuple[float, str]:
+    """The stage-1 window after a batch whose measured deviation came within the guard of `window`: at least twice as
+    wide and at least four times the deviation seen; once that reaches the deterministic bound, the bound (and the
+    mode says so).  Returns (window in units, "widened" | "bound")."""
+    wider = max(2.0 * window, 4.0 * max_dev)
+    bound = bound_tau1_ulps(dim)
+    if wider >= bound:
+        return max(bound, 4.0 * max_dev), "bound"
+    return wider, "widened"
+
+
 class _ProjectionList(list):
     """``list`` of per-band hyperplane matrices that notices item re-assignment."""
 
@@ -167,9 +178,11 @@ class LSHHasher:
                   of six data distributions (one built from bf16 rounding boundaries) no deviation reached 16,
                   and their spread is ~3 units (profiles/r01_split_window_margin.log) - and the margin is not
                   taken on trust: stage 2 measures |y_stage1 - y_hostBLAS| on EVERY flagged projection of every
-                  batch (tens of thousands per 1M rows; ``last_stats["max_dev_units"]``), and a batch in which it
-                  exceeds ``margin_guard`` x the window is hashed again with the deterministic bound, which the
-                  hasher then keeps (``last_stats["margin_escalations"]``).  "bound": use that bound from the
+                  batch (tens of thousands per 1M rows; ``last_stats["max_dev_units"]``; largest seen on any of 14
+                  input families: 15.3), and a batch in which it exceeds ``margin_guard`` x the window is hashed
+                  again with a window at least twice as wide and four times that deviation, which the hasher then
+                  keeps - up to the deterministic bound (``escalated_window``, ``last_stats["margin_escalations"]``,
+                  ``window_mode``).  "bound": use that bound from the
                   start (``bound_tau1_ulps(dim)``: 1 469 units at 768-d) - keys identical to the reference by
                   construction under the stated per-instruction error of the bf16 MFMA, at ~0.6x the rate.
                   ``tau_ulps="bound"`` does the same for the f32 kernel's tie window (``bound_tau_ulps``).
@@ -187,7 +200,7 @@ class LSHHasher:
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps=8.0, precision: str = "bf16x3",
-                 tau1_ulps=128.0, tie_threads: Optional[int] = None, pipeline: str = "native",
+                 tau1_ulps=64.0, tie_threads: Optional[int] = None, pipeline: str = "native",
                  tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
@@ -532,9 +545,8 @@ class LSHHasher:
             return False
         stats["max_dev_units"] = max(max_dev, stats.get("max_dev_units", 0.0))
         if self.margin_guard > 0.0 and max_dev > self.margin_guard * window and self.window_mode["tau1"] != "bound":
-            # the measured margin of this batch is not what the default window assumes: the bound, from here on
-            self.window_mode["tau1"] = "bound"
-            self.tau1_ulps = max(bound_tau1_ulps(self.dim), 4.0 * max_dev)
+            # the measured margin of this batch is not what the window assumes: a wider one, from here on
+            self.tau1_ulps, self.window_mode["tau1"] = escalated_window(window, max_dev, self.dim)
             self.margin_escalations += 1
             stats["relaunches"] += 1
             stats["margin_escalations"] = self.margin_escalations

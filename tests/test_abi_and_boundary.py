@@ -170,3 +170,19 @@ def test_hasher_constructor_and_projection_seam():
     assert all(np.array_equal(a, b) for a, b in zip(h2.projections, h.projections))
     with pytest.raises(ValueError, match="dimension"):
         h._validate_vector(np.ones(5))
+
+
+def test_window_escalation_policy():
+    """`escalated_window`: at least twice the window, at least four times the deviation seen, the deterministic bound as
+    the ceiling (and then the mode says "bound")."""
+    from lshrs_amd.hasher import bound_tau1_ulps, escalated_window
+
+    assert escalated_window(64.0, 40.0, 768) == (160.0, "widened")
+    assert escalated_window(64.0, 10.0, 768) == (128.0, "widened")
+    assert escalated_window(1024.0, 100.0, 768) == (bound_tau1_ulps(768), "bound")
+    assert escalated_window(64.0, 500.0, 768) == (2000.0, "bound")
+    w, mode, steps = 64.0, "measured", 0
+    while mode != "bound":                      # a deviation that keeps sitting at the guard walks up to the bound
+        w, mode = escalated_window(w, 0.51 * w, 768)
+        steps += 1
+    assert steps <= 6 and w >= bound_tau1_ulps(768)
