@@ -12,15 +12,21 @@ BLAS's summation order for every projection inside the stage-1 window; `config.t
 them).  Workload: N = 1 -> BASELINE config 2 (1M x 768); N > 1 -> BASELINE config 4 (10M x 768 sharded: 1.25M rows per
 GPU at N = 8; `--scaling weak` keeps 1.25M per GPU at every N, `--scaling strong` divides the 10M).  Ranks share
 nothing (replicated hyperplanes, no collective in the data path).  Rank 0 prints ONE JSON line.
+Timing: `--settle-steps` (default 40, in the line) untimed steps, then W untimed warm-up steps, then exactly K steps
+between barrier + synchronize on both sides, max over ranks.  The settling steps exist because this kernel is
+power-limited: after an idle period the power controller clamps launches 3..20 (profiles/r02_step_transient.log), so K = 20
+steps right behind 5 warm-up steps measure that transient, not the rate a job sees; `--settle-steps 0` gives that figure.
 
 Also in the line (N = 1 unless noted):
   roofline      the dominant kernel (stage 1 of the split pass, sig16_kernel), timed with HIP events that ride on its
                 dispatch packets inside the timed region, priced against the LARGER of its two floors - the bf16
                 matrix roof (it executes 3 bf16 MFMAs per algorithmic multiply-add) - with the HBM view beside it;
-  sustained     the same step repeated for >= 2 s: p50 / p95 step time, kernel mean, in-kernel shader clock;
+  sustained     the same step repeated for >= 2 s: p50 / p95 step time, kernel mean, in-kernel shader clock; and
+                `two_streams`: consecutive batches through hash_device_async on alternating streams;
   bound_mode    the same step with the deterministic stage-1 window (tau1_ulps="bound");
   c5            BASELINE config 5 (5M x 1536, num_perm 512) on one GPU with its own roofline and parity check;
-  e2e_ingest    LSHRS.index() from host memory into an in-memory store, beside the reference-literal loop;
+  e2e_ingest    LSHRS.index() from host memory into an in-memory store, beside the reference-literal loop, and
+                query_many() of 10 000 queries against that index beside the reference-literal per-query flow;
   host_fed      hash_batch_packed from host memory (PCIe-inclusive; every rank at N > 1);
   small_n       p50 latency of hash_vector / LSHRS.ingest / get_top_k beside the reference-literal CPU call;
   cpu_baseline  the oracle's literal restatement of the reference timed on this host on a bounded prefix;
