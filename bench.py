@@ -145,7 +145,7 @@ def in_kernel_clock(torch, hasher, x, keys):
     ws = hasher._workspace(x.device)
     cap = n // 4 + 4096
     flag_list = torch.empty(cap, dtype=torch.int64, device=x.device)
-    counters = torch.zeros(_native.SIG_COUNTERS, dtype=torch.int32, device=x.device)
+    counters = torch.zeros(_native.SIG_DEVICE_COUNTERS, dtype=torch.int32, device=x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     _native.check(lib.lshrs_sig_hash_batch_split_replay_f32(
         x.data_ptr(), n, x.stride(0), ws.data_ptr(), hasher.num_bands, hasher.rows_per_band, hasher.dim, keys.data_ptr(),

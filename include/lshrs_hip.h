@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSHRS_ABI_VERSION 2
+#define LSHRS_ABI_VERSION 3
 
 #define LSHRS_E_BADARG   (-10001) /* NULL pointer / non-positive size / misaligned workspace */
 #define LSHRS_E_TOOLARGE (-10002) /* shape outside what the kernels support (see each call)  */
@@ -51,8 +51,10 @@ typedef struct lshrs_sig_opts {
   void* clock_probe;
 } lshrs_sig_opts;
 
-/* Device counter block of the replay entry points (int32[LSHRS_SIG_COUNTERS], zeroed by the caller once; every call
- * that is given host_counts hands it over and leaves it zeroed):
+/* Counters of the replay entry points.  The caller owns a DEVICE block int32[LSHRS_SIG_DEVICE_COUNTERS], zeroed once when
+ * allocated; its first LSHRS_SIG_COUNTERS words are the counters below, the rest is where the workgroups of stage 2 leave
+ * their statistics (one slot each: no atomics on shared words).  A launch behind stage 2 folds those in, stores the
+ * LSHRS_SIG_COUNTERS counters to host_counts (pinned host memory, when given) and leaves the whole block zeroed:
  *   [0] projections inside the tie window tau (statistics) / tie entries the f32 kernel wanted to write
  *   [1] list entries wanted (> the list's capacity: the pass is incomplete, repeat it with room)
  *   [2] float bits: max over the flagged projections of |y_stage1 - y_hostBLAS| in units of 2^-24 ||x|| ||p|| - the
@@ -60,6 +62,7 @@ typedef struct lshrs_sig_opts {
  *   [3] flagged projections whose key bit stage 2 had to change
  *   [4..7] reserved (0) */
 #define LSHRS_SIG_COUNTERS 8
+#define LSHRS_SIG_DEVICE_COUNTERS (LSHRS_SIG_COUNTERS + 3 * 1536)
 
 /* ------------------------------------------------------------------------------------------
  * Signature pass — replaces LSHHasher.hash_vector / hash_batch / _project_and_pack
@@ -135,7 +138,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
  * has run: no tie list, no host step.  Only for callers that have checked the model against their BLAS
  * (lshrs_tb_model_dot in lshrs_host.h vs `P_band @ x`, bit for bit; lshrs_amd/hasher.py does) and for inputs the split
  * pass takes itself (dim % 32 == 0, 16-byte aligned rows; else LSHRS_E_BADARG).
- *   counters     int32[LSHRS_SIG_COUNTERS] (see above), zero on entry.
+ *   counters     DEVICE int32[LSHRS_SIG_DEVICE_COUNTERS] (see above), zero on entry.
  *   flag_y       optional float[flag_cap]: the stage-1 value of every list entry; with it stage 2 measures how far
  *                stage 1 was from the host BLAS on every flagged projection of the batch (counter [2]).
  *   host_counts  optional: PINNED HOST int32[LSHRS_SIG_COUNTERS] the device can write (hipHostMalloc / torch
@@ -153,7 +156,7 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
  * tau, same stream) it decides every reported tie by the host BLAS's value - the tie entries are unpacked into
  * flag_list (one item per flagged column; flag_count zeroed by the caller) and the stage-2 kernel of the split pass
  * re-evaluates them: the canonical chain (the f32 kernel's own value) for the tie test, the replayed BLAS order
- * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  counters: the int32[LSHRS_SIG_COUNTERS] block
+ * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  counters: the int32[LSHRS_SIG_DEVICE_COUNTERS] block
  * whose element [0] was the f32 kernel's tie_count; [1] receives the items expanded.  host_counts (optional, pinned
  * host int32[LSHRS_SIG_COUNTERS]) receives the block, which is left zeroed; [0] > tie_cap or [1] > flag_cap: repeat
  * the pass with room.  Needs dim % 32 == 0, 16-byte aligned rows and key rows of whole 32-bit words (else

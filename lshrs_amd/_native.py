@@ -21,8 +21,9 @@ SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
 # (LSHRS_HIP_LIBRARY: load another build of the same ABI instead - A/B measurements of compiler flags, tools/ab_build.py)
 LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-ABI_VERSION = 2
+ABI_VERSION = 3
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
+SIG_DEVICE_COUNTERS = SIG_COUNTERS + 3 * 1536      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
 
 E_BADARG = -10001

@@ -531,8 +531,10 @@ struct FixArgs {
   float tau;
   int blas_model;         // sig_fix8_kernel<true>: which host-BLAS summation order the tie replay follows (1: see there)
   const float* flag_y;    // optional: stage-1 value of every list entry (sig16_kernel stores it beside the entry)
-  int* stat_dev;          // optional: max over the flagged projections of |y1 - y_BLAS| in units of 2^-24 ||x|| ||p|| (float bits)
-  int* stat_flips;        // optional: flagged projections whose stage-1 sign differed from the host BLAS's
+  int count_ties;         // sig_fix8_kernel<true>: report the projections inside the tie window in partials[0] (else 0)
+  int* partials;          // sig_fix8_kernel<true>: int32[3 * gridDim.x], per workgroup: projections inside the tie window,
+                          // flagged projections whose stage-1 sign differed from the host BLAS's, and (float bits) the max
+                          // over its flagged projections of |y1 - y_BLAS| in units of 2^-24 ||x|| ||p||
 };
 
 __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f32x4 (&x4)[2][4], float& acc, float& ss) {
@@ -718,10 +720,13 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       n_flips += __shfl_xor(n_flips, off);
       max_dev = __builtin_fmaxf(max_dev, __shfl_xor(max_dev, off));
     }
+    // One plain store per workgroup into its own slot; the launch behind this kernel folds the slots into the counters.
+    // (Atomics on the three counters - 1 536 waves on one address each - were 28 of this kernel's 50 us at 22 k entries.)
     if (lane == 0) {
-      if (a.tie_count != nullptr && n_ties != 0) atomicAdd(a.tie_count, n_ties);
-      if (a.stat_flips != nullptr && n_flips != 0) atomicAdd(a.stat_flips, n_flips);
-      if (a.stat_dev != nullptr && max_dev > 0.f) atomicMax(a.stat_dev, __float_as_int(max_dev));
+      int* p = a.partials + 3 * blockIdx.x;
+      p[0] = a.count_ties ? n_ties : 0;
+      p[1] = n_flips;
+      p[2] = __float_as_int(max_dev);
     }
   }
 }
@@ -749,15 +754,37 @@ __global__ void expand_ties_kernel(const int64_t* __restrict__ tie_list, const i
   }
 }
 
-// Hands the counters of a replay pass (LSHRS_SIG_COUNTERS int32: ties, flagged, max deviation, sign flips, ...) to the
-// host (pinned memory) and leaves them zeroed for the next call: one launch behind stage 2 instead of a copy and a
-// fill.  (Doing it in stage 2 itself, by whichever workgroup finishes last, costs 1 536 contended atomics on one
-// ticket: 58 us.)
-__global__ void export_counts_kernel(int* counters, int* host_counts) {
-  const int i = threadIdx.x;
-  if (i < LSHRS_SIG_COUNTERS) {
-    host_counts[i] = counters[i];
-    counters[i] = 0;
+// Behind stage 2 of a replay pass: folds the per-workgroup statistics (nparts slots of 3 ints behind the
+// LSHRS_SIG_COUNTERS counters: ties, sign flips, max deviation) into the counters, hands the counters to the host (pinned
+// memory) and leaves the whole block zeroed for the next call: one single-wave launch instead of a copy and a fill.
+// Without host_counts the folded counters stay in the device block (the caller copies it).
+__global__ void export_counts_kernel(int* counters, int* host_counts, int nparts) {
+  const int lane = threadIdx.x;
+  int* parts = counters + LSHRS_SIG_COUNTERS;
+  int ties = 0, flips = 0, dev = 0;
+  for (int i = lane; i < nparts; i += 64) {
+    ties += parts[3 * i];
+    flips += parts[3 * i + 1];
+    dev = max(dev, parts[3 * i + 2]);                // (non-negative floats order like their bits)
+    parts[3 * i] = parts[3 * i + 1] = parts[3 * i + 2] = 0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    ties += __shfl_xor(ties, off);
+    flips += __shfl_xor(flips, off);
+    dev = max(dev, __shfl_xor(dev, off));
+  }
+  if (lane < LSHRS_SIG_COUNTERS) {
+    int v = counters[lane];
+    if (lane == 0) v += ties;
+    if (lane == 2) v = max(v, dev);
+    if (lane == 3) v += flips;
+    if (host_counts != nullptr) {
+      host_counts[lane] = v;
+      counters[lane] = 0;
+    } else {
+      counters[lane] = v;
+    }
   }
 }
 
@@ -1851,13 +1878,12 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
 
 // blas_model 0: ties are reported in tie_list (the caller resolves them on the host); > 0: stage 2 resolves them itself
 // by replaying that summation order of the host BLAS (sig_fix8_kernel<true>), tie_list is not used.
-// stat_dev / stat_flips / flag_y: the replay's live-margin statistics (NULL: not kept).
+// counters (replay only): the LSHRS_SIG_DEVICE_COUNTERS block; flag_y: the stage-1 value of every list entry (may be NULL).
 static int split_pass(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
                       int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
                       int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, float* flag_y,
-                      int32_t flag_cap, int32_t* flag_count, float tau1, int blas_model, int32_t* stat_dev,
-                      int32_t* stat_flips, int32_t* counters, int32_t* host_counts, const lshrs_sig_opts* opts,
-                      void* stream) {
+                      int32_t flag_cap, int32_t* flag_count, float tau1, int blas_model, int32_t* counters,
+                      int32_t* host_counts, const lshrs_sig_opts* opts, void* stream) {
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
       flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
@@ -1937,11 +1963,10 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   if (blas_model != 0) {
     f.tie_list = nullptr;
     f.flag_y = flag_y;
-    f.stat_dev = stat_dev;
-    f.stat_flips = stat_flips;
+    f.partials = counters + LSHRS_SIG_COUNTERS;
+    f.count_ties = 1;
     hipExtLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
-    if (host_counts != nullptr && counters != nullptr)
-      hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts);
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
   } else {
     hipExtLaunchKernelGGL(sig_fix8_kernel<false>, grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
   }
@@ -1954,8 +1979,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
                                    int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
                                    const lshrs_sig_opts* opts, void* stream) {
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap, tie_count, tau,
-                    row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, nullptr, nullptr,
-                    opts, stream);
+                    row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, opts, stream);
 }
 
 int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
@@ -1965,8 +1989,7 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
                                           int32_t* host_counts, const lshrs_sig_opts* opts, void* stream) {
   if (blas_model != 1 || dim % 8 != 0 || counters == nullptr) return LSHRS_E_BADARG;
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
-                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters + 2, counters + 3, counters,
-                    host_counts, opts, stream);
+                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, opts, stream);
 }
 
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
@@ -2013,14 +2036,13 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   f.tie_count = nullptr;          // (the caller has the number of tie entries already; stage 2 only decides them)
   f.tau = tau;
   f.blas_model = blas_model;
-  f.stat_flips = counters + 3;
+  f.partials = counters + LSHRS_SIG_COUNTERS;
   {
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
     hipLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, f);
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
   }
-  if (host_counts != nullptr)
-    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts);
   return -(int)hipGetLastError();
 }
 

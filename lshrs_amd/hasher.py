@@ -484,7 +484,7 @@ class LSHHasher:
                 nc = _native.SIG_COUNTERS
                 pinned = torch.zeros((4, nc), dtype=torch.int32).pin_memory()
                 scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
-                           torch.zeros(nc, dtype=torch.int32, device=dev),     # LSHRS_SIG_COUNTERS block
+                           torch.zeros(_native.SIG_DEVICE_COUNTERS, dtype=torch.int32, device=dev),   # counters + stage-2 slots
                            pinned, pinned.numpy(), [0],
                            torch.empty((cap,), dtype=torch.float32, device=dev))   # stage-1 value of every list entry
                 if len(self._replay_scratch) >= 16 and not self._async_pending:
@@ -677,7 +677,7 @@ class LSHHasher:
                     pinned = torch.zeros(_native.SIG_COUNTERS, dtype=torch.int32).pin_memory()
                     scratch = (torch.empty((cap, 2), dtype=torch.int64, device=dev),
                                torch.empty((fcap,), dtype=torch.int64, device=dev),
-                               torch.zeros(_native.SIG_COUNTERS, dtype=torch.int32, device=dev), pinned, pinned.numpy())
+                               torch.zeros(_native.SIG_DEVICE_COUNTERS, dtype=torch.int32, device=dev), pinned, pinned.numpy())
                     self._replay_scratch[key] = scratch
                 tie_list, flag_list, counts, pinned, host_counts = scratch
                 tcap, lcap = int(tie_list.shape[0]), int(flag_list.shape[0])
