@@ -588,24 +588,31 @@ class LSHHasher:
         """Spot check of the device's decisions against the reference's own expression on live data: a handful of the
         projections stage 2 has just decided are re-evaluated with ``P_band @ x`` (lshrs/hash/lsh.py:200) on the host
         and compared with the key bits.  The BLAS-order model is licensed on synthetic vectors at first use and when the
-        BLAS's configuration changes; this closes the loop on real inputs, every ``audit_every`` batches (three small
-        copies, ~0.1 ms)."""
+        BLAS's configuration changes; this closes the loop on real inputs, every ``audit_every`` batches (a few small
+        device ops and one copy)."""
         torch = _native.require_gpu()
         dev = x.device
         scratch = self._replay_scratch.get((dev.index, torch.cuda.current_stream(dev).cuda_stream))
         if scratch is None:
             return True
         k = min(sample, int(stats["flagged"]), int(scratch[0].shape[0]))
-        items = scratch[0][:k].cpu().numpy()
+        if k <= 0:
+            return True
+        # list entries, their rows of x and of the keys: gathered on the device, ONE copy to the host
+        items_d = scratch[0][:k]
+        rows_d = (items_d >> 21).clamp_(0, int(x.shape[0]) - 1)
+        nx, nk = k * self.dim * 4, k * self.num_bands * self.band_bytes
+        packed = torch.cat([items_d.view(torch.uint8), x.index_select(0, rows_d).reshape(-1).view(torch.uint8),
+                            out.index_select(0, rows_d).reshape(-1)]).cpu().numpy()
+        items = packed[:8 * k].view(np.int64)
+        xr = packed[8 * k:8 * k + nx].view(np.float32).reshape(k, self.dim)
+        kb = packed[8 * k + nx:8 * k + nx + nk].reshape(k, self.num_bands, self.band_bytes)
         rows, cols = items >> 21, (items & ((1 << 21) - 1)).astype(np.int64)
         band_cols = 8 * self.band_bytes
         keep = (cols // band_cols < self.num_bands) & (cols % band_cols < self.rows_per_band) & (rows < x.shape[0])
-        rows, cols = rows[keep], cols[keep]
+        rows, cols, xr, kb = rows[keep], cols[keep], xr[keep], kb[keep]
         if rows.size == 0:
             return True
-        idx = torch.from_numpy(rows).to(dev)
-        xr = x.index_select(0, idx).cpu().numpy()
-        kb = out.index_select(0, idx).cpu().numpy()
         stats["audited"] = stats.get("audited", 0) + int(rows.size)
         for i in range(rows.size):
             band, bit = int(cols[i] // band_cols), int(cols[i] % band_cols)
