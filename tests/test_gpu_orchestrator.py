@@ -269,3 +269,16 @@ def test_packed_index_reproduces_the_reference_buckets_and_error_timing(g5):
         for b, khex, i in batch:
             stored.setdefault(store2.bucket_key(b, bytes.fromhex(khex)), set()).add(i)
     assert store2.bucket_contents() == stored          # rows 0..6, nothing of row 7 or later
+
+
+def test_random_api_sequences_equal_the_literal_flow():
+    """Randomised index / ingest / delete / get_top_k / get_above_p / query_many sequences through LSHRS (tuple and packed
+    ingest, five shapes) against the reference's flow restated literally over a second store (tools/soak_api.py)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "soak_api", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_api.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    checks, bad = soak.run(5, seed=77, steps=24, verbose=False)
+    assert checks >= 40 and bad == 0

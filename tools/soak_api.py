@@ -9,10 +9,6 @@ import numpy as np
 from lshrs_amd import LSHRS, InMemoryStorage
 from oracle.lshrs_oracle import index_literal, query_literal
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rng = np.random.default_rng(2025)
-bad = checks = 0
-t0 = time.time()
 
 
 def same_scored(a, b):
@@ -28,62 +24,72 @@ def same_scored(a, b):
     return True
 
 
-for rnd in range(rounds):
-    dim, nb, r = [(768, 16, 16), (128, 16, 4), (1536, 16, 32), (64, 8, 8), (256, 16, 16)][rnd % 5]
-    packed = bool(rnd % 2)
-    centers = rng.standard_normal((40, dim)).astype(np.float32)
-    def draw(m):
-        c = centers[rng.integers(0, len(centers), m)]
-        return (c + 0.25 * rng.standard_normal((m, dim))).astype(np.float32)
-    table = {}
-    fetch = lambda ids: np.stack([table[int(i)] for i in ids])
-    a_store, b_store = InMemoryStorage(), InMemoryStorage()
-    idx = LSHRS(dim=dim, num_bands=nb, rows_per_band=r, num_perm=nb * r, storage=a_store, packed_ingest=packed,
-                vector_fetch_fn=fetch, buffer_size=int(rng.choice([64, 1000, 10_000])))
-    planes = idx._hasher.projections
-    next_id = 0
-    for step in range(30):
-        op = rng.choice(["index", "ingest", "delete", "top_k", "above_p", "many", "many_p"], p=[.2, .1, .1, .2, .15, .15, .1])
-        if op == "index":
-            m = int(rng.integers(1, 3000))
-            ids = np.arange(next_id, next_id + m, dtype=np.int64); next_id += m
-            vecs = draw(m)
-            for i, v in zip(ids, vecs): table[int(i)] = v
-            idx.index(ids if packed else ids.tolist(), vecs); idx.flush()
-            index_literal(b_store, ids.tolist(), vecs, planes, dim, 10_000)
-        elif op == "ingest":
-            v = draw(1)[0]; table[next_id] = v
-            idx.ingest(next_id, v); idx.flush()
-            index_literal(b_store, [next_id], v[None], planes, dim, 10_000); next_id += 1
-        elif op == "delete" and next_id > 10:
-            gone = rng.choice(next_id, size=min(next_id, int(rng.integers(1, 20))), replace=False).tolist()
-            idx.delete(gone); b_store.remove_indices(gone)
-        elif next_id:
-            q = draw(int(rng.integers(1, 40)))
-            if op == "top_k":
-                k = int(rng.integers(1, 30))
-                got = [idx.get_top_k(v, topk=k) for v in q[:5]]
-                want = [query_literal(b_store, planes, dim, v, top_k=k) for v in q[:5]]
-                ok = got == want
-            elif op == "above_p":
-                p = float(rng.choice([0.2, 0.5, 1.0]))
-                got = [idx.get_above_p(v, p=p) for v in q[:4]]
-                want = [query_literal(b_store, planes, dim, v, top_k=None, top_p=p, fetch=fetch) for v in q[:4]]
-                ok = all(same_scored(g, w) for g, w in zip(got, want))
-            elif op == "many":
-                k = int(rng.integers(1, 30))
-                ok = idx.query_many(q, top_k=k) == [query_literal(b_store, planes, dim, v, top_k=k) for v in q]
-            else:
-                p = float(rng.choice([0.3, 1.0])); k = None if rng.random() < 0.5 else int(rng.integers(1, 10))
-                got = idx.query_many(q, top_k=k, top_p=p)
-                want = [query_literal(b_store, planes, dim, v, top_k=k, top_p=p, fetch=fetch) for v in q]
-                ok = all(same_scored(g, w) for g, w in zip(got, want))
-            checks += 1; bad += not ok
-            if not ok:
-                print(f"MISMATCH round {rnd} step {step} op {op}", flush=True)
-    same = a_store.bucket_contents() == b_store.bucket_contents()
-    bad += not same
-    print(f"round {rnd:2d} shape {(nb, r, dim)} packed={packed} ids={next_id} buckets equal: {same}; checks so far {checks}, mismatches {bad}", flush=True)
-    idx.close()
-print(f"soak_api: {rounds} rounds, {checks} query checks, {bad} mismatches, {time.time() - t0:.1f} s")
-sys.exit(1 if bad else 0)
+def run(rounds: int, seed: int = 2025, steps: int = 30, verbose: bool = True):
+    rng = np.random.default_rng(seed)
+    bad = checks = 0
+    for rnd in range(rounds):
+        dim, nb, r = [(768, 16, 16), (128, 16, 4), (1536, 16, 32), (64, 8, 8), (256, 16, 16)][rnd % 5]
+        packed = bool(rnd % 2)
+        centers = rng.standard_normal((40, dim)).astype(np.float32)
+        def draw(m):
+            c = centers[rng.integers(0, len(centers), m)]
+            return (c + 0.25 * rng.standard_normal((m, dim))).astype(np.float32)
+        table = {}
+        fetch = lambda ids: np.stack([table[int(i)] for i in ids])
+        a_store, b_store = InMemoryStorage(), InMemoryStorage()
+        idx = LSHRS(dim=dim, num_bands=nb, rows_per_band=r, num_perm=nb * r, storage=a_store, packed_ingest=packed,
+                    vector_fetch_fn=fetch, buffer_size=int(rng.choice([64, 1000, 10_000])))
+        planes = idx._hasher.projections
+        next_id = 0
+        for step in range(steps):
+            op = rng.choice(["index", "ingest", "delete", "top_k", "above_p", "many", "many_p"], p=[.2, .1, .1, .2, .15, .15, .1])
+            if op == "index":
+                m = int(rng.integers(1, 3000))
+                ids = np.arange(next_id, next_id + m, dtype=np.int64); next_id += m
+                vecs = draw(m)
+                for i, v in zip(ids, vecs): table[int(i)] = v
+                idx.index(ids if packed else ids.tolist(), vecs); idx.flush()
+                index_literal(b_store, ids.tolist(), vecs, planes, dim, 10_000)
+            elif op == "ingest":
+                v = draw(1)[0]; table[next_id] = v
+                idx.ingest(next_id, v); idx.flush()
+                index_literal(b_store, [next_id], v[None], planes, dim, 10_000); next_id += 1
+            elif op == "delete" and next_id > 10:
+                gone = rng.choice(next_id, size=min(next_id, int(rng.integers(1, 20))), replace=False).tolist()
+                idx.delete(gone); b_store.remove_indices(gone)
+            elif next_id:
+                q = draw(int(rng.integers(1, 40)))
+                if op == "top_k":
+                    k = int(rng.integers(1, 30))
+                    got = [idx.get_top_k(v, topk=k) for v in q[:5]]
+                    want = [query_literal(b_store, planes, dim, v, top_k=k) for v in q[:5]]
+                    ok = got == want
+                elif op == "above_p":
+                    p = float(rng.choice([0.2, 0.5, 1.0]))
+                    got = [idx.get_above_p(v, p=p) for v in q[:4]]
+                    want = [query_literal(b_store, planes, dim, v, top_k=None, top_p=p, fetch=fetch) for v in q[:4]]
+                    ok = all(same_scored(g, w) for g, w in zip(got, want))
+                elif op == "many":
+                    k = int(rng.integers(1, 30))
+                    ok = idx.query_many(q, top_k=k) == [query_literal(b_store, planes, dim, v, top_k=k) for v in q]
+                else:
+                    p = float(rng.choice([0.3, 1.0])); k = None if rng.random() < 0.5 else int(rng.integers(1, 10))
+                    got = idx.query_many(q, top_k=k, top_p=p)
+                    want = [query_literal(b_store, planes, dim, v, top_k=k, top_p=p, fetch=fetch) for v in q]
+                    ok = all(same_scored(g, w) for g, w in zip(got, want))
+                checks += 1; bad += not ok
+                if not ok:
+                    print(f"MISMATCH round {rnd} step {step} op {op}", flush=True)
+        same = a_store.bucket_contents() == b_store.bucket_contents()
+        bad += not same
+        if verbose: print(f"round {rnd:2d} shape {(nb, r, dim)} packed={packed} ids={next_id} buckets equal: {same}; checks so far {checks}, mismatches {bad}", flush=True)
+        idx.close()
+    return checks, bad
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    t0 = time.time()
+    checks, bad = run(rounds)
+    print(f"soak_api: {rounds} rounds, {checks} query checks, {bad} mismatches, {time.time() - t0:.1f} s")
+    sys.exit(1 if bad else 0)
