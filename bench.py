@@ -21,7 +21,8 @@ Also in the line (N = 1 unless noted):
   roofline      the dominant kernel (stage 1 of the split pass, sig16_kernel), timed with HIP events that ride on its
                 dispatch packets inside the timed region, priced against the LARGER of its two floors - the bf16
                 matrix roof (it executes 3 bf16 MFMAs per algorithmic multiply-add) - with the HBM view beside it;
-  sustained     the same step repeated for >= 2 s: p50 / p95 step time, kernel mean, in-kernel shader clock; and
+  sustained     the same step repeated for >= 2 s: p50 / p95 step time, kernel mean, in-kernel shader clock, socket power
+                against the package power cap (rocm-smi, one reading mid-run); and
                 `two_streams`: consecutive batches through hash_device_async on alternating streams;
   bound_mode    the same step with the deterministic stage-1 window (tau1_ulps="bound");
   c5            BASELINE config 5 (5M x 1536, num_perm 512) on one GPU with its own roofline and parity check;
@@ -422,6 +423,24 @@ def main() -> None:
     os.close(real_stdout)
 
 
+def sample_power(device_index: int):
+    """Socket power, package power cap and shader clock as rocm-smi reports them (read-only; None where it is absent)."""
+    import re
+    import subprocess
+
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower"],
+                             capture_output=True, text=True, timeout=10).stdout
+    except Exception:   # noqa: BLE001 - a missing or slow tool must not cost the bench its line
+        return None
+    def grab(pattern):
+        m = re.search(pattern, out)
+        return float(m.group(1)) if m else None
+    return {"socket_power_W": grab(r"Socket Graphics Package Power \(W\):\s*([0-9.]+)"),
+            "power_cap_W": grab(r"Max Graphics Package Power \(W\):\s*([0-9.]+)"),
+            "sclk_MHz": grab(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)")}
+
+
 def bench_sustained(torch, hasher, x, keys, seconds, barrier):
     """The headline step back to back for >= `seconds`: what the kernel holds once the chip has settled its clock."""
     if seconds <= 0:
@@ -429,7 +448,13 @@ def bench_sustained(torch, hasher, x, keys, seconds, barrier):
     n = int(x.shape[0])
     elapsed, events, _ = timed_steps(torch, hasher, x, keys, 50, False, barrier)      # calibrate
     steps = max(200, int(seconds / (elapsed / 50)) + 1)
+    import threading
+
+    power = []
+    sampler = threading.Thread(target=lambda: (time.sleep(0.5 * seconds), power.append(sample_power(x.device.index or 0))))
+    sampler.start()                                       # one reading in the middle of the run, from a second thread
     elapsed, events, step_ms = timed_steps(torch, hasher, x, keys, steps, False, barrier)
+    sampler.join()
     k1 = [e[0] for e in events if isinstance(e[0], float)]
     k2 = [e[3] for e in events if isinstance(e[0], float) and e[3] is not None]
     clock = in_kernel_clock(torch, hasher, x, keys)
@@ -439,6 +464,7 @@ def bench_sustained(torch, hasher, x, keys, seconds, barrier):
            "stage2_kernel_ms_mean": sum(k2) / max(1, len(k2)), "in_kernel_clock_GHz": clock}
     if k1:
         out["roofline"] = stage1_roofline(out["stage1_kernel_ms_mean"], n, DIM, NUM_PERM, "sig16_kernel, sustained")
+    out["power_mid_run"] = power[0] if power else None
     out["two_streams"] = bench_two_streams(torch, hasher, x, keys, steps // 2)
     return out
 
