@@ -1015,3 +1015,40 @@ def test_small_batches_take_the_direct_replay_and_are_the_reference_keys(torch_m
         want = hash_batch_literal_packed(h.projections, xs)
     for i in range(50):
         assert np.array_equal(h.hash_batch_packed(xs[i:i + 1])[0], want[i])
+
+
+def test_unrecognised_host_blas_takes_the_host_engine_everywhere(torch_mod, monkeypatch):
+    """The branch a host with an unknown BLAS summation order takes (`blas_order_model` -> 0): no device replay anywhere
+    - single vectors, small batches, host arrays (streamed), device batches small and large, the streaming entry point -
+    every tie goes to the host engine (the reference's own sgemv), and the keys are still the reference's."""
+    torch = torch_mod
+    from lshrs_amd import _hostblas
+    from oracle.lshrs_oracle import hash_batch_literal_packed, hash_vector_literal
+
+    monkeypatch.setattr(_hostblas, "blas_order_model", lambda planes: 0)
+    h = _hasher(42, 16, 16, 768)
+    assert h._replay_model() == 0
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((150_000, 768)).astype(np.float32)
+    pl = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])[[5, 77, 200]]
+    special = np.arange(0, x.shape[0], 50)
+    xs = x[special].astype(np.float64)
+    xs -= (xs @ np.linalg.pinv(pl)) @ pl                  # rows in the null space of three hyperplanes: true ties
+    x[special] = xs.astype(np.float32)
+    want = hash_batch_literal_packed(h.projections, x[:40_000])
+    assert h.hash_vector(x[0]).as_tuple() == hash_vector_literal(h.projections, x[0], 768)
+    assert h.last_stats.get("path") != "small-replay"
+    assert np.array_equal(h.hash_batch_packed(x[:100]), want[:100])
+    assert np.array_equal(h.hash_batch_packed(x[:40_000], chunk_rows=16_384), want)
+    xd = torch.from_numpy(x).cuda()
+    assert np.array_equal(h.hash_device(xd[:300]).cpu().numpy(), want[:300])
+    keys = h.hash_device(xd)
+    st = dict(h.last_stats)
+    assert st.get("tie_break_engine") != "device-replay" and st["tie_pairs"] > 2 * special.size, st
+    assert np.array_equal(keys[:40_000].cpu().numpy(), want)
+    assert torch.equal(h.hash_device_async(xd).result(), keys)
+    # same bytes as a hasher that recognises the order (when this host's is recognised)
+    monkeypatch.undo()
+    h2 = _hasher(42, 16, 16, 768)
+    if h2._replay_model():
+        assert torch.equal(h2.hash_device(xd), keys) and h2.last_stats.get("tie_break_engine") == "device-replay"
