@@ -1052,3 +1052,4 @@ def test_unrecognised_host_blas_takes_the_host_engine_everywhere(torch_mod, monk
     h2 = _hasher(42, 16, 16, 768)
     if h2._replay_model():
         assert torch.equal(h2.hash_device(xd), keys) and h2.last_stats.get("tie_break_engine") == "device-replay"
+
