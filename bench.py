@@ -519,24 +519,27 @@ def bench_bound(torch, np, x, keys, local_dev, steps, barrier):
 
 
 def bench_f32(torch, x, keys, local_dev):
+    """The exact-f32 kernel on the same batch (raw keys, one launch per call): settled like the headline (30 untimed
+    launches - the first launches after an idle period are clamped, profiles/r02_step_transient.log), then 60 timed."""
     from lshrs_amd import LSHHasher
 
     n = int(x.shape[0])
     h32 = LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_dev, precision="f32")
-    h32.hash_device(x, out=keys, tie_break="none")
-    ev = []
-    for _ in range(5):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+    for _ in range(30):
         h32.hash_device(x, out=keys, tie_break="none")
-        b.record()
-        ev.append((a, b))
+    reps = 60
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        h32.hash_device(x, out=keys, tie_break="none")
+    b.record()
     torch.cuda.synchronize()
-    f32_ms = sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+    f32_ms = a.elapsed_time(b) / reps
     tf = 2.0 * DIM * NUM_PERM * n / (f32_ms * 1e-3) / 1e12
     return {"kernel": "sig_kernel<NT=8, ALIGNED, MODE=0> (precision='f32', raw keys, one launch of the whole batch)",
             "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
-            "kernel_ms": f32_ms, "vectors_per_s": n / (f32_ms * 1e-3)}
+            "kernel_ms": f32_ms, "vectors_per_s": n / (f32_ms * 1e-3),
+            "note": "mean over 60 back-to-back calls (launch gaps included) behind 30 settling calls"}
 
 
 def bench_small_n(torch, np, hasher, x):
