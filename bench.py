@@ -15,7 +15,8 @@ nothing (replicated hyperplanes, no collective in the data path).  Rank 0 prints
 Timing: `--settle-steps` (default 40, in the line) untimed steps, then W untimed warm-up steps, then exactly K steps
 between barrier + synchronize on both sides, max over ranks.  The settling steps exist because this kernel is
 power-limited: after an idle period the power controller clamps launches 3..20 (profiles/r02_step_transient.log), so K = 20
-steps right behind 5 warm-up steps measure that transient, not the rate a job sees; `--settle-steps 0` gives that figure.
+steps right behind 5 warm-up steps measure that transient, not the rate a job sees; that figure is in the line too
+(`first_steps_after_idle`), and `--settle-steps 0` makes it the headline.
 
 Also in the line (N = 1 unless noted):
   roofline      the dominant kernel (stage 1 of the split pass, sig16_kernel), timed with HIP events that ride on its
@@ -244,6 +245,21 @@ def main() -> None:
         torch.cuda.synchronize(dev)
 
     hasher.kernel_events = []          # (the warm-up steps are steps like the timed ones: their event ring is built here)
+    after_idle = None
+    if args.settle_steps > 0:
+        # what K steps right behind W warm-up steps measure when the chip comes from idle (round 1's line): reported
+        # beside the settled figure, and part of the settling
+        for _ in range(args.warmup):
+            hasher.hash_device(x, out=keys)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hasher.hash_device(x, out=keys)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        after_idle = {"value": n * world * args.steps / dt, "unit": "vectors/s", "ms_per_step": 1e3 * dt / args.steps,
+                      "note": "this rank's first %d steps behind %d warm-up steps, before the settling steps (x world size)"
+                              % (args.steps, args.warmup)}
     for _ in range(args.settle_steps + args.warmup):
         hasher.hash_device(x, out=keys)
     hasher.kernel_events.clear()
@@ -315,6 +331,7 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "settle_steps": args.settle_steps,
+            "first_steps_after_idle": after_idle,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
