@@ -115,7 +115,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
  * as the f32 fmaf chain of the f32 kernel, corrects their key bits and reports ties (|y| < tau ...) as above.
  * tau1: the stage-1 window.  Measured, over 2.7e9 projections of six data distributions the stage-1 value never
  * strayed 16 units of 2^-24 ||x|| ||p|| from the chain (profiles/r01_split_window_margin.log; the Python layer's
- * default is 64 units and it watches counter [2] of the replay on every batch, widening the window when the deviation comes within half of it); its deterministic bound - every
+ * default is 64 x sqrt(768 / dim) units and it watches counter [2] of the replay on every batch, widening the window when the deviation comes within half of it); its deterministic bound - every
  * rounding error at its maximum and aligned - is what LSHHasher(tau1_ulps="bound") passes (lshrs_amd/hasher.py,
  * DESIGN.md §3).  Rows whose largest |x| is outside [2^-60, 2^60] are flagged wholesale.
  *   flag_list int64[flag_cap], flag_count int32[1] (zeroed by the caller): scratch, one entry per flagged

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import math
 import os
 import threading
 import time
@@ -57,6 +58,16 @@ def bound_tau1_ulps(dim: int) -> float:
     ||x|| estimate itself (taken from the bf16 high parts: >= (1 - 2^-8) ||x||)."""
     n_mfma = 3 * ((dim + 31) // 32)
     return 768.0 * (1.0 + 2.0 ** -7) + 1.02 * MFMA_BF16_ERR_UNITS * (n_mfma + 1) + float((dim + 7) // 8 + 3)
+
+
+def default_tau1_ulps(dim: int) -> float:
+    """The default stage-1 window: 64 units at 768-d, scaled by sqrt(768 / dim).  Stage 1's deviation from the host BLAS
+    is a random walk over the dim products relative to ||x|| ||p||: measured (tools/window_by_dim.py,
+    profiles/r02_window_by_dim.log) its maximum over 1e5 .. 3e5 flagged projections of Gaussian, unit-norm and
+    heavy-tailed data is 15 .. 20 units x sqrt(768 / dim) at every dimension from 32 to 4096 - so this window is 3.2 .. 4.3
+    times the largest deviation seen at any of them, the guard (half of it) 1.6 .. 2.1 times, and the flagged fraction
+    (8.5e-5 of the projections) is the same at every dimension."""
+    return 64.0 * math.sqrt(768.0 / float(dim))
 
 
 def escalated_window(window: float, max_dev: float, dim: int) -> Tuple[float, str]:
@@ -174,10 +185,11 @@ class LSHHasher:
                   columns, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass — bf16 matrix
                   cores, then the exact f32 chain for every projection inside the stage-1 window — everything
                   else the f32 kernel; the keys are the same either way.  "f32": always the f32 kernel.
-      tau1_ulps   stage-1 window of the split pass, in the units of tau_ulps.  Default 64: over 2.7e9 projections
-                  of six data distributions (one built from bf16 rounding boundaries) no deviation reached 16,
-                  and their spread is ~3 units (profiles/r01_split_window_margin.log) - and the margin is not
-                  taken on trust: stage 2 measures |y_stage1 - y_hostBLAS| on EVERY flagged projection of every
+      tau1_ulps   stage-1 window of the split pass, in the units of tau_ulps.  Default (None): 64 x sqrt(768 / dim)
+                  (``default_tau1_ulps``: stage 1's deviation is a random walk over the dim products, measured at 15-20
+                  units x sqrt(768 / dim) at most from 32-d to 4096-d, profiles/r02_window_by_dim.log; at 768-d over
+                  2.7e9 projections of six data distributions none reached 16, profiles/r01_split_window_margin.log) -
+                  and the margin is not taken on trust: stage 2 measures |y_stage1 - y_hostBLAS| on EVERY flagged projection of every
                   batch (tens of thousands per 1M rows; ``last_stats["max_dev_units"]``; largest seen on any of 14
                   input families: 15.3), and a batch in which it exceeds ``margin_guard`` x the window is hashed
                   again with a window at least twice as wide and four times that deviation, which the hasher then
@@ -200,7 +212,7 @@ class LSHHasher:
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps=8.0, precision: str = "bf16x3",
-                 tau1_ulps=64.0, tie_threads: Optional[int] = None, pipeline: str = "native",
+                 tau1_ulps=None, tie_threads: Optional[int] = None, pipeline: str = "native",
                  tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
@@ -226,7 +238,8 @@ class LSHHasher:
         # "bf16x3": large batches take the split-precision first pass (bf16 matrix cores, >2x the rate) followed by
         # the exact f32 chain for every projection inside the stage-1 window; same keys as "f32" 
         self.precision = precision
-        self.tau1_ulps = bound_tau1_ulps(self.dim) if tau1_ulps == "bound" else float(tau1_ulps)
+        self.tau1_ulps = (bound_tau1_ulps(self.dim) if tau1_ulps == "bound" else
+                          default_tau1_ulps(self.dim) if tau1_ulps is None else float(tau1_ulps))
         self.margin_guard = float(margin_guard)
         # every audit_every-th synchronous batch (and the first): a few of the projections the device has decided are
         # re-evaluated with NumPy on the host and compared (0 = never)
