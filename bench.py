@@ -482,6 +482,9 @@ def bench_sustained(torch, hasher, x, keys, seconds, barrier):
     if k1:
         out["roofline"] = stage1_roofline(out["stage1_kernel_ms_mean"], n, DIM, NUM_PERM, "sig16_kernel, sustained")
     out["power_mid_run"] = power[0] if power else None
+    if power and power[0] and power[0].get("socket_power_W"):
+        # at the power cap the rate IS energy per vector: socket power / vectors per second
+        out["energy_per_vector_uJ"] = 1e6 * power[0]["socket_power_W"] / out["value"]
     out["two_streams"] = bench_two_streams(torch, hasher, x, keys, steps // 2)
     return out
 
