@@ -48,6 +48,34 @@ class BucketCSR:
         return int(self.bands.shape[0])
 
 
+def merge_csr(segments) -> "BucketCSR":
+    """Several :class:`BucketCSR` with codes (``band_bytes <= 6``, all equal) folded into one: the union of their buckets,
+    every bucket's members concatenated in segment order.  Array work only - O(members + buckets log buckets)."""
+    segs = [s for s in segments if len(s)]
+    if not segs:
+        return segments[0]
+    bb = segs[0].band_bytes
+    codes = np.concatenate([s.codes for s in segs])
+    lens = np.concatenate([np.diff(s.offsets) for s in segs])
+    uniq, inv = np.unique(codes, return_inverse=True)
+    order = np.argsort(inv, kind="stable")                   # old buckets by new bucket, segment order inside
+    new_lens = np.bincount(inv, weights=lens, minlength=uniq.shape[0]).astype(np.int64)
+    new_off = np.r_[0, np.cumsum(new_lens)].astype(np.int64)
+    # where every old bucket's members go: the running sum of the lengths of the old buckets sorted before it
+    sorted_lens = lens[order]
+    dst_start = np.empty(lens.shape[0], dtype=np.int64)
+    dst_start[order] = np.cumsum(sorted_lens) - sorted_lens  # (laid out in exactly that order)
+    members = np.empty(int(new_off[-1]), dtype=np.int64)
+    src = np.concatenate([s.members for s in segs])
+    total = int(lens.sum())
+    pos = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens) + np.repeat(dst_start, lens)
+    members[pos] = src
+    kb = np.empty((uniq.shape[0], bb), dtype=np.uint8)
+    for j in range(bb):
+        kb[:, j] = (uniq >> (8 * j)) & 0xFF
+    return BucketCSR(bb, (uniq >> (8 * bb)).astype(np.int32), kb, uniq, new_off, members, sum(int(s.vectors) for s in segs))
+
+
 def key_codes(keys: np.ndarray) -> np.ndarray:
     """(..., bands, B) key bytes -> (..., bands) int64 codes ``band << 8B | little-endian key`` (B <= 6)."""
     keys = np.ascontiguousarray(keys, dtype=np.uint8)

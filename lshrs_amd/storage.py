@@ -45,8 +45,22 @@ class InMemoryStorage:
         with self._lock:
             self._buckets.setdefault(self.bucket_key(band_id, hash_val), set()).add(int(index))
 
+    compact_above = 32     # array segments a lookup tolerates before it folds them into one (many small index() calls)
+
+    def _compact_locked(self) -> None:
+        """Fold the array segments into one per key width (lookups cost one bisection per segment)."""
+        from .packed_ops import merge_csr
+
+        by_width: Dict[int, list] = {}
+        rest = []
+        for seg in self._segments:
+            (by_width.setdefault(seg.band_bytes, []) if seg.codes is not None else rest).append(seg)
+        self._segments = [merge_csr(group) if len(group) > 1 else group[0] for group in by_width.values()] + rest
+
     def get_bucket(self, band_id: int, hash_val: bytes) -> Set[int]:
         with self._lock:
+            if len(self._segments) > self.compact_above:
+                self._compact_locked()
             out = set(self._buckets.get(self.bucket_key(band_id, hash_val), ()))
             segments = list(self._segments)
         key = bytes(hash_val)
@@ -80,6 +94,8 @@ class InMemoryStorage:
         nq, nb, bb = keys.shape
         qs, ms = [], []
         with self._lock:
+            if len(self._segments) > self.compact_above:
+                self._compact_locked()
             segments = list(self._segments)
             loose = bool(self._buckets)
         if loose:                                       # buckets built from op tuples: dict lookups, per (query, band)

@@ -158,3 +158,43 @@ def test_redis_writer_takes_a_bucket_csr():
     sent = {(name, m) for name, members in fake.commands for m in members}
     assert sent == {(fake.bucket_key(b, k), i) for b, k, i in ops_from_keys(ids, keys)}
     assert all(isinstance(m, int) for _, members in fake.commands for m in members)
+
+
+def test_array_segments_are_compacted_and_stay_equal_to_the_tuple_store():
+    """Many small packed batches: past `compact_above` segments a lookup folds them into one (merge_csr); contents,
+    single lookups, batched lookups and deletions stay equal to a store fed the same operations as tuples."""
+    from lshrs_amd import InMemoryStorage
+    from lshrs_amd.packed_ops import _csr_host, merge_csr
+
+    rng = np.random.default_rng(11)
+    a, b = InMemoryStorage(), InMemoryStorage()
+    a.compact_above = 6
+    next_id = 0
+    for batch in range(25):
+        n = int(rng.integers(1, 400))
+        keys = rng.integers(0, 6, size=(n, 5, 2), dtype=np.uint8)          # few distinct keys: crowded, shared buckets
+        ids = np.arange(next_id, next_id + n, dtype=np.int64) * 7 + 3
+        next_id += n
+        a.batch_add_csr(_csr_host(ids, keys))
+        b.batch_add([(band, keys[i, band].tobytes(), int(ids[i])) for i in range(n) for band in range(5)])
+        if batch % 6 == 5:
+            gone = rng.choice(next_id, size=20, replace=False) * 7 + 3
+            a.remove_indices(gone.tolist()); b.remove_indices(gone.tolist())
+        q = rng.integers(0, 6, size=(9, 5, 2), dtype=np.uint8)
+        for qi in range(9):
+            for band in range(5):
+                assert a.get_bucket(band, q[qi, band].tobytes()) == b.get_bucket(band, q[qi, band].tobytes())
+        qa, ma = a.get_buckets_many(q)
+        qb, mb = b.get_buckets_many(q)
+        assert sorted(zip(qa.tolist(), ma.tolist())) == sorted(zip(qb.tolist(), mb.tolist()))
+        assert len(a._segments) <= a.compact_above + 1
+    assert a.bucket_contents() == b.bucket_contents()
+    # the merge on its own: union of buckets, members concatenated
+    segs = [_csr_host(np.arange(50, dtype=np.int64) + 100 * s, rng.integers(0, 3, size=(50, 2, 1), dtype=np.uint8)) for s in range(4)]
+    merged = merge_csr(segs)
+    want = {}
+    for sgm in segs:
+        for g in range(len(sgm)):
+            want.setdefault(int(sgm.codes[g]), []).extend(sgm.members[sgm.offsets[g]:sgm.offsets[g + 1]].tolist())
+    got = {int(merged.codes[g]): merged.members[merged.offsets[g]:merged.offsets[g + 1]].tolist() for g in range(len(merged))}
+    assert got == want and merged.vectors == 200 and np.all(np.diff(merged.codes) > 0)
