@@ -37,6 +37,8 @@ def run(rounds: int, seed: int = 2025, steps: int = 30, verbose: bool = True):
         table = {}
         fetch = lambda ids: np.stack([table[int(i)] for i in ids])
         a_store, b_store = InMemoryStorage(), InMemoryStorage()
+        if rnd % 3 == 1:
+            a_store.compact_above = 3          # (exercise the folding of array segments)
         idx = LSHRS(dim=dim, num_bands=nb, rows_per_band=r, num_perm=nb * r, storage=a_store, packed_ingest=packed,
                     vector_fetch_fn=fetch, buffer_size=int(rng.choice([64, 1000, 10_000])))
         planes = idx._hasher.projections
