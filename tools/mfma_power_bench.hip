@@ -7,10 +7,11 @@
 #include <cstring>
 #include <vector>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE>   // 0: 32x32x16, 256 accumulator registers = 16 tiles; 1: 16x16x32, 64 tiles
+template <int SHAPE>   // 0: 32x32x16, 256 accumulator registers = 16 tiles; 1: 16x16x32, 64 tiles; 2: 16x16x32 f16 (same bits reinterpreted)
 __global__ __launch_bounds__(256, 1) void mfma_loop(const bf16x8* __restrict__ ops, float* __restrict__ out, int iters,
                                                    unsigned long long* stamps) {
   const int lane = threadIdx.x & 63;
@@ -47,9 +48,15 @@ __global__ __launch_bounds__(256, 1) void mfma_loop(const bf16x8* __restrict__ o
 #pragma unroll
         for (int t = 0; t < 32; ++t) {
           const int c = half * 32 + t;
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t & 3], b[(t >> 2)], acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t & 3], b[(t >> 2) ^ 1], acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(t + 1) & 3], b[(t >> 2)], acc[c], 0, 0, 0);
+          if (SHAPE == 1) {
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t & 3], b[(t >> 2)], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t & 3], b[(t >> 2) ^ 1], acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(t + 1) & 3], b[(t >> 2)], acc[c], 0, 0, 0);
+          } else {
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[t & 3]), __builtin_bit_cast(f16x8, b[(t >> 2)]), acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[t & 3]), __builtin_bit_cast(f16x8, b[(t >> 2) ^ 1]), acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(t + 1) & 3]), __builtin_bit_cast(f16x8, b[(t >> 2)]), acc[c], 0, 0, 0);
+          }
         }
     }
 #pragma unroll
@@ -60,20 +67,26 @@ __global__ __launch_bounds__(256, 1) void mfma_loop(const bf16x8* __restrict__ o
   if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-int main() {
+int main(int argc, char** argv) {
   const int blocks = 256 * 8, iters = 400;
   std::vector<unsigned short> h((size_t)blocks * 256 * 12 * 8);
   srand(1);
-  for (auto& v : h) { float f = (float)rand() / RAND_MAX * 2.f - 1.f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+  const bool f16_ops = argc > 1 && !strcmp(argv[1], "f16");     // operands that are N(0,1)-like in the format under test
+  for (auto& v : h) {
+    float f = (float)rand() / RAND_MAX * 2.f - 1.f;
+    if (f16_ops) { _Float16 hf = (_Float16)f; memcpy(&v, &hf, 2); }
+    else { unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
+  }
   bf16x8* ops; float* out; unsigned long long* st;
   hipMalloc(&ops, h.size() * 2); hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&st, (size_t)blocks * 16);
   hipMemcpy(ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int shape = 0; shape < 2; ++shape)
-    for (int rep = 0; rep < 3; ++rep) {
+  for (int shape = f16_ops ? 2 : 0; shape < (f16_ops ? 3 : 2); ++shape)
+    for (int rep = 0; rep < 12; ++rep) {
       hipEventRecord(e0);
       if (shape == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(blocks), dim3(256), 0, 0, ops, out, iters, st);
-      else hipLaunchKernelGGL(mfma_loop<1>, dim3(blocks), dim3(256), 0, 0, ops, out, iters, st);
+      else if (shape == 1) hipLaunchKernelGGL(mfma_loop<1>, dim3(blocks), dim3(256), 0, 0, ops, out, iters, st);
+      else hipLaunchKernelGGL(mfma_loop<2>, dim3(blocks), dim3(256), 0, 0, ops, out, iters, st);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       std::vector<unsigned long long> hs((size_t)blocks * 2);
@@ -82,7 +95,7 @@ int main() {
       // FLOPs: shape 0: 48 MFMAs x 32768 per wave-iteration; shape 1: 192 MFMAs x 16384
       const double flops = (double)blocks * 4 * iters * (shape == 0 ? 48.0 * 32768 : 192.0 * 16384);
       printf("%s rep %d: %.3f ms, %.0f TFLOP/s executed, shader clock %.2f GHz, cycles per MFMA %.1f\n",
-             shape == 0 ? "32x32x16" : "16x16x32", rep, ms, flops / ms / 1e9, cyc / real * 0.1,
+             shape == 0 ? "32x32x16 bf16" : shape == 1 ? "16x16x32 bf16" : "16x16x32 f16", rep, ms, flops / ms / 1e9, cyc / real * 0.1,
              cyc / blocks / iters / (shape == 0 ? 48.0 : 192.0));
     }
   return 0;
