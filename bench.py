@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline step (+ parity): no sustained / bound / c5 / e2e / small-n / f32 lines")
     ap.add_argument("--tau1", default=None, help="stage-1 window of the timed hasher (number or 'bound')")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous, one barrier and the JSON line only - no GPU work (exercises the launcher on a CPU box)")
     ap.add_argument("--backend", default=os.environ.get("LSHRS_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals on one GPU)")
     return ap.parse_args()
@@ -136,8 +138,6 @@ def in_kernel_clock(torch, hasher, x, keys):
     import ctypes
 
     from lshrs_amd import _native
-    from lshrs_amd.hasher import _U
-
     lib = _native.load()
     n = int(x.shape[0])
     wgs = (n + 255) // 256
@@ -151,8 +151,8 @@ def in_kernel_clock(torch, hasher, x, keys):
     stream = torch.cuda.current_stream(x.device).cuda_stream
     _native.check(lib.lshrs_sig_hash_batch_split_replay_f32(
         x.data_ptr(), n, x.stride(0), ws.data_ptr(), hasher.num_bands, hasher.rows_per_band, hasher.dim, keys.data_ptr(),
-        counters.data_ptr(), float(hasher.tau_ulps * _U), None, flag_list.data_ptr(), None, cap,
-        float(hasher.tau1_ulps * _U), 1, None, ctypes.byref(opts), stream), "clock probe launch")
+        counters.data_ptr(), hasher._tau_arg(), None, flag_list.data_ptr(), None, cap,
+        hasher._tau1_arg(), 1, None, ctypes.byref(opts), stream), "clock probe launch")
     torch.cuda.synchronize(x.device)
     st = stamps[:2 * ((n + 255) // 256)].view(-1, 2).cpu().numpy()
     st = st[st[:, 1] > 0]
@@ -163,7 +163,9 @@ def in_kernel_clock(torch, hasher, x, keys):
     return float(np.median(st[:, 0] / st[:, 1])) * 0.1     # ticks per 100 MHz tick -> GHz
 
 
-def timed_steps(torch, hasher, x, keys, steps, use_async, barrier):
+def timed_steps(torch, hasher, x, keys, steps, use_async, barrier, min_seconds=0.0):
+    """Exactly `steps` steps between two barriers - or, with `min_seconds`, steps until that much wall time has gone by
+    (and at least `steps`).  Returns (seconds, kernel events, per-step host ms)."""
     pending = []
 
     def step():
@@ -177,7 +179,7 @@ def timed_steps(torch, hasher, x, keys, steps, use_async, barrier):
     hasher.kernel_events = []
     barrier()
     marks = [time.perf_counter()]
-    for _ in range(steps):
+    while len(marks) <= steps or marks[-1] - marks[0] < min_seconds:
         step()
         marks.append(time.perf_counter())
     while pending:
@@ -188,13 +190,68 @@ def timed_steps(torch, hasher, x, keys, steps, use_async, barrier):
     return elapsed, events, [1e3 * (b - a) for a, b in zip(marks[:-1], marks[1:])]
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process becomes the launcher.  It starts N
+    fresh rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run sets
+    them, rendezvous on 127.0.0.1), BEFORE anything here has imported torch or touched a GPU, relays rank 0's one JSON
+    line, and fails if any rank fails.  (Never an exec: the children are ordinary subprocesses.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LSHRS_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        failed = next((p.returncode for p in procs if p.poll() not in (None, 0)), None)
+    if failed is not None:                     # one rank is gone: the others would wait at a barrier for ever
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        sys.stderr.write(f"bench: rank exit codes {[p.returncode for p in procs]}\n")
+        return failed if 0 < failed < 256 else 1
+    reader.join()
+    line = chunks[0] if chunks else b""
+    sys.stdout.buffer.write(line)
+    sys.stdout.flush()
+    return 0
+
+
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     # ONE JSON line on stdout, whatever the libraries underneath choose to print there (gloo announces its connections
     # on stdout): everything else this process writes to fd 1 goes to stderr, the line itself to the real stdout
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.dry_run:
+        import torch.distributed as dist
+
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+            dist.destroy_process_group()
+        if int(os.environ.get("RANK", "0")) == 0:
+            os.write(real_stdout, (json.dumps({"dry_run": True, "n_gpus": world, "self_launched":
+                                               bool(os.environ.get("LSHRS_BENCH_SELF_LAUNCHED"))}) + "\n").encode())
+        return
     import numpy as np
     import torch
 
@@ -204,8 +261,6 @@ def main() -> None:
     distributed = world > 1
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and not distributed:
-        raise SystemExit("for --gpus > 1 launch through torch.distributed.run (one rank per GPU)")
     local_dev = local_rank % max(1, torch.cuda.device_count())   # (== local_rank on a real N-GPU node)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -463,14 +518,15 @@ def bench_sustained(torch, hasher, x, keys, seconds, barrier):
     if seconds <= 0:
         return None
     n = int(x.shape[0])
-    elapsed, events, _ = timed_steps(torch, hasher, x, keys, 50, False, barrier)      # calibrate
-    steps = max(200, int(seconds / (elapsed / 50)) + 1)
     import threading
 
     power = []
     sampler = threading.Thread(target=lambda: (time.sleep(0.5 * seconds), power.append(sample_power(x.device.index or 0))))
     sampler.start()                                       # one reading in the middle of the run, from a second thread
-    elapsed, events, step_ms = timed_steps(torch, hasher, x, keys, steps, False, barrier)
+    # time-based: steps until `seconds` of wall time have gone by (round 2 sized the run from 50 calibration steps that
+    # included slow ones and stopped at 1.27 s)
+    elapsed, events, step_ms = timed_steps(torch, hasher, x, keys, 200, False, barrier, min_seconds=seconds)
+    steps = len(step_ms)
     sampler.join()
     k1 = [e[0] for e in events if isinstance(e[0], float)]
     k2 = [e[3] for e in events if isinstance(e[0], float) and e[3] is not None]
@@ -706,12 +762,14 @@ def bench_rerank(torch, dev, corpus, np, with_cpu: bool):
     """BASELINE config 3: corpus = the 1M x 768 vectors resident on the device, 10k queries x 1k candidates."""
     from lshrs_amd.similarity import cosine_scores_device, topk_desc_device
 
-    gen = torch.Generator(device=dev).manual_seed(7)
     m = corpus.shape[0]
     q, c = 10_000, 1_000
-    qrows = torch.randperm(m, device=dev, generator=gen)[:q]
-    queries = corpus[qrows] + 0.1 * torch.randn(q, DIM, device=dev, generator=gen)
-    cidx = torch.randint(0, m, (q, c), device=dev, generator=gen)
+    # SURVEY §8(d): queries = rows default_rng(7).choice(m, q, replace=False) + 0.1 N(0,1) noise (same generator),
+    # candidates = default_rng(8).integers(0, m, (q, c)) - drawn on the host with NumPy, as specified
+    rng7, rng8 = np.random.default_rng(7), np.random.default_rng(8)
+    qrows = torch.from_numpy(rng7.choice(m, q, replace=False)).to(dev)
+    queries = corpus[qrows] + torch.from_numpy((0.1 * rng7.standard_normal((q, DIM))).astype(np.float32)).to(dev)
+    cidx = torch.from_numpy(rng8.integers(0, m, (q, c), dtype=np.int64)).to(dev)
 
     def one():
         scores, status, qstatus = cosine_scores_device(corpus, queries, cidx)
@@ -751,14 +809,37 @@ def bench_rerank(torch, dev, corpus, np, with_cpu: bool):
         from oracle.lshrs_oracle import top_k_cosine
 
         nq = 100
-        qh = queries[:nq].cpu().numpy()
-        ch = [corpus[cidx[i]].cpu().numpy() for i in range(nq)]
+        pick = np.random.default_rng(9).choice(q, nq, replace=False)          # the 100 sampled queries
+        qh = queries[torch.from_numpy(pick).to(dev)].cpu().numpy()
+        ch = [corpus[cidx[int(i)]].cpu().numpy() for i in pick]
         t0 = time.perf_counter()
-        for i in range(nq):
-            top_k_cosine(qh[i], ch[i], k=c)
+        answers = [top_k_cosine(qh[j], ch[j], k=c) for j in range(nq)]
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": nq * c / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
                                "sample": f"{nq} of the 10k queries x 1k candidates, reference-literal top_k_cosine ({dt:.1f} s)"}
+        # ... and the answers are the parity check of the measured pass: |score difference| <= 1e-5, same
+        # order wherever the reference's neighbouring scores are more than 2e-5 apart
+        scores, status, qstatus = cosine_scores_device(corpus, queries, cidx)
+        order, sorted_scores = topk_desc_device(scores, c)
+        g_scores = scores[torch.from_numpy(pick).to(dev)].cpu().numpy()
+        g_order = order[torch.from_numpy(pick).to(dev)].cpu().numpy()
+        max_diff, order_ok, ranks_compared = 0.0, True, 0
+        for j in range(nq):
+            ref_order = np.array([i for i, _ in answers[j]], dtype=np.int64)
+            ref_sorted = np.array([v for _, v in answers[j]], dtype=np.float64)
+            ref_scores = np.empty(c)
+            ref_scores[ref_order] = ref_sorted
+            max_diff = max(max_diff, float(np.abs(g_scores[j].astype(np.float64) - ref_scores).max()))
+            gap = np.diff(ref_sorted)                                          # (negative: descending)
+            clear = np.r_[gap[0] < -2e-5, (gap[:-1] < -2e-5) & (gap[1:] < -2e-5), gap[-1] < -2e-5]
+            ranks_compared += int(clear.sum())
+            order_ok = order_ok and bool(np.array_equal(g_order[j][clear], ref_order[clear]))
+        out["parity_check"] = {"queries": nq, "max_abs_score_diff": max_diff, "tolerance": 1e-5,
+                               "within_tolerance": max_diff <= 1e-5, "order_equal_where_gap_gt_2e-5": order_ok,
+                               "ranks_compared": ranks_compared,
+                               "inputs": "default_rng(7) query rows + noise, default_rng(8) candidates, default_rng(9) sample"}
+        if max_diff > 1e-5 or not order_ok:
+            raise SystemExit("bench: rerank differs from the reference-literal top_k_cosine - result invalid")
     return out
 
 

@@ -21,7 +21,7 @@ SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
 # (LSHRS_HIP_LIBRARY: load another build of the same ABI instead - A/B measurements of compiler flags, tools/ab_build.py)
 LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-ABI_VERSION = 3
+ABI_VERSION = 4
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
 SIG_DEVICE_COUNTERS = SIG_COUNTERS + 3 * 1536      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
@@ -80,6 +80,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_sig_padded_columns.restype = i32
     lib.lshrs_sig_pack_projections.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.lshrs_sig_pack_projections.restype = c.c_int
+    # (workspace, bands, rows, dim, coef_a, coef_b, coef_tie, stream)
+    lib.lshrs_sig_set_window.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.lshrs_sig_set_window.restype = c.c_int
     # (X, n, ldx, workspace, bands, rows, dim, keys, tie_list, tie_cap, tie_count, tau, row_flags, opts, stream)
     lib.lshrs_sig_hash_batch_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, vp, vp]
     lib.lshrs_sig_hash_batch_f32.restype = c.c_int
@@ -135,6 +138,7 @@ EXPORTS = (
     "lshrs_sig_workspace_bytes",
     "lshrs_sig_padded_columns",
     "lshrs_sig_pack_projections",
+    "lshrs_sig_set_window",
     "lshrs_sig_hash_batch_f32",
     "lshrs_sig_hash_batch_split_f32",
     "lshrs_sig_hash_batch_split_replay_f32",

@@ -68,6 +68,8 @@ class _DeferredStorage:
         return self._real
 
     def __getattr__(self, item):
+        if item in ("_real", "_cfg") or (item.startswith("__") and item.endswith("__")):
+            raise AttributeError(item)          # (copy / pickle probe an instance whose __init__ has not run: no recursion)
         if item in ("batch_add_csr", "batch_add_packed", "get_buckets_many") and self._real is None:
             raise AttributeError(item)          # (capability probes must not open a connection)
         return getattr(self._resolve(), item)
@@ -559,7 +561,7 @@ class LSHRS:
             pair = np.sort((q << mbits) | m)
             first = np.r_[True, pair[1:] != pair[:-1]]
             starts = np.flatnonzero(first)
-            counts = np.diff(np.r_[starts, pair.shape[0]])
+            counts = np.minimum(np.diff(np.r_[starts, pair.shape[0]]), nb)     # (a band counts once: buckets are sets)
             uniq = pair[starts]
             uq, um = uniq >> mbits, uniq & ((1 << mbits) - 1)
             ranked = np.sort((uq << (mbits + cbits)) | ((nb - counts) << mbits) | um)
@@ -569,7 +571,7 @@ class LSHRS:
             q, m = q[order], m[order]
             first = np.r_[True, (q[1:] != q[:-1]) | (m[1:] != m[:-1])]
             starts = np.flatnonzero(first)
-            counts = np.diff(np.r_[starts, q.shape[0]])
+            counts = np.minimum(np.diff(np.r_[starts, q.shape[0]]), nb)
             uq, um = q[starts], m[starts]
             rank = np.lexsort((um, -counts, uq))                 # by query, then -collisions, then id
             uq, um = uq[rank], um[rank]

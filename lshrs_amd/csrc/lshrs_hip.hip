@@ -95,7 +95,25 @@ inline int64_t sig_rowmajor_offset_floats(const SigGeom& g) {
   return sig_main_floats(g) + sig_fine_floats(g) + (sig_has_split(g) ? sig_image_floats(g) : 0) +
          (sig_has_narrow_split(g) ? sig_narrow_image_floats(g) + 256 + 4 : 0);
 }
-inline int64_t sig_workspace_floats(const SigGeom& g) { return sig_rowmajor_offset_floats(g) + sig_rowmajor_floats(g); }
+// Window block (lshrs_sig_set_window): per padded column the coefficients of the PROVEN stage-1 window of the split pass
+// (wa, wb: |y1 - y_host| <= ||x_hi|| wa + ||x_mid|| wb) and of the proven tie window of the f32 chain (wt), each zero-padded
+// to at least 256 columns (the narrow split image), followed by their maxima per column block of the main geometry and,
+// for wt, per 32-column tile of the fine geometry.
+inline int64_t sig_window_offset_floats(const SigGeom& g) { return sig_rowmajor_offset_floats(g) + sig_rowmajor_floats(g); }
+inline int64_t sig_window_cols(const SigGeom& g) { const int64_t c = (int64_t)g.cb * g.nt * 32; return c < 256 ? 256 : c; }
+inline int64_t sig_window_floats(const SigGeom& g) {
+  return 3 * sig_window_cols(g) + 3 * sig_normmax_floats(g) + sig_normmax_floats(sig_fine_geom(g));
+}
+struct SigWindow { const float *wa, *wb, *wt, *wamax, *wbmax, *wtmax, *wtmax_fine; };
+inline SigWindow sig_window(const float* base, const SigGeom& g) {
+  SigWindow w;
+  const float* p = base + sig_window_offset_floats(g);
+  const int64_t wc = sig_window_cols(g), cbp = sig_normmax_floats(g);
+  w.wa = p; w.wb = p + wc; w.wt = p + 2 * wc;
+  w.wamax = p + 3 * wc; w.wbmax = w.wamax + cbp; w.wtmax = w.wbmax + cbp; w.wtmax_fine = w.wtmax + cbp;
+  return w;
+}
+inline int64_t sig_workspace_floats(const SigGeom& g) { return sig_window_offset_floats(g) + sig_window_floats(g); }
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
 
 // Which geometry finishes a partial round (m < kRoundRows rows) sooner?  Cost model fitted to
@@ -176,6 +194,25 @@ __global__ void pack_normmax_kernel(const float* __restrict__ norms, int cols_pe
   out[b] = m;
 }
 
+__global__ void fill_kernel(float* __restrict__ dst, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+// coefficient arrays over the key columns (band-major, num_bands x rows) -> padded columns (zero elsewhere)
+__global__ void window_scatter_kernel(const float* __restrict__ ca, const float* __restrict__ cb_, const float* __restrict__ ct,
+                                      int num_bands, int rows, int bb, int wcols, float* __restrict__ wa,
+                                      float* __restrict__ wb, float* __restrict__ wt) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= wcols) return;
+  const int band = col / (bb * 8), bit = col % (bb * 8);
+  const bool live = band < num_bands && bit < rows;
+  const int j = band * rows + bit;
+  wa[col] = live ? ca[j] : 0.f;
+  wb[col] = live ? cb_[j] : 0.f;
+  wt[col] = live ? ct[j] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------
@@ -201,6 +238,14 @@ struct SigArgs {
   // stage 1 of the split pass (sig16_kernel): column blocks in the grid; optional stage-1 value per list entry
   int ncb;
   float* flag_y;
+  // ... its window: |y1| <= tau ||x_hi|| wa[col] + tau_b ||x_mid|| wb[col] goes to stage 2.  Proven window: tau = tau_b = 1
+  // and the coefficient arrays of lshrs_sig_set_window; a caller-chosen window of tau1 units: tau = tau1, tau_b = 0,
+  // wa = the column norms.  (wamax / wbmax: per column block, for the wave-uniform screen.)
+  const float* wa;
+  const float* wb;
+  const float* wamax;
+  const float* wbmax;
+  float tau_b;
   // project mode
   float* Y;
   int64_t ldy;
@@ -518,6 +563,7 @@ struct FixArgs {
   int ktiles;
   const float* prow;      // hyperplanes row-major: P'[padded column][ldp], ldp = 32 * ktiles
   const float* norms;
+  const float* tie_coef;  // per padded column: the tie window is tau * ||x|| * tie_coef[col] (the norms, or the proven coefficients)
   uint8_t* keys;
   int row_bytes;
   int padcols;            // valid padded columns = row_bytes * 8
@@ -685,7 +731,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     if (REPLAY) {
       want = yb > 0.f;                             // (0, -0 and NaN give 0, as `projections > 0` does: lsh.py:204)
       const float scale = sqrtf(ss) * a.norms[col];                        // ||x|| ||p||
-      if (__builtin_fabsf(yb) < a.tau * scale) ++n_ties;                   // statistics: projections inside the tie window
+      if (__builtin_fabsf(yb) < a.tau * sqrtf(ss) * a.tie_coef[col]) ++n_ties;   // statistics: projections inside the tie window
       if (want != have) ++n_flips;
       if (a.flag_y != nullptr && scale > 0.f) {
         // the live margin of stage 1: how far its value was from the host BLAS's, in the units its window is given in
@@ -698,7 +744,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       else atomicAnd(w32, ~bitmask);
     }
     if (!REPLAY && a.tie_list != nullptr) {
-      const float thr = a.tau * sqrtf(ss) * a.norms[col];
+      const float thr = a.tau * sqrtf(ss) * a.tie_coef[col];
       if (__builtin_fabsf(acc) < thr) {
         const int slot = atomicAdd(a.tie_count, 1);
         if (slot < a.tie_cap) {
@@ -1065,7 +1111,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   constexpr int kXWave = kWaveRows * kKTile;
   constexpr int kRingFloats = 3 * kPHalf + 3 * kXTile;
   static_assert(3 * kS1ListCap <= kRingFloats, "the epilogue's list stage reuses the ring");
-  __shared__ __attribute__((aligned(16))) float lds[kRingFloats + 256 + 4];
+  __shared__ __attribute__((aligned(16))) float lds[kRingFloats + 512 + 4];     // + two windows per row + list counters
   struct Bf16Pairs { bf16x2 p[4]; };
 
   const int tid = threadIdx.x;
@@ -1109,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   }
 
   f32x4 acc[RT][16];
-  float ss[RT], amax[RT];
+  float ss[RT], sm[RT], amax[RT];      // ||x_hi||^2, ||x_mid||^2 (both from the bf16 pieces the MFMAs consume), max |x|
   auto zero_tile_state = [&]() {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -1121,7 +1167,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
         asm volatile("" : "+a"(acc[rt][ct]));
       }
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) { ss[rt] = 0.f; amax[rt] = 0.f; }
+    for (int rt = 0; rt < RT; ++rt) { ss[rt] = 0.f; sm[rt] = 0.f; amax[rt] = 0.f; }
   };
   unsigned long long t_shader = 0, t_real = 0;
   if (args.clock_probe != nullptr) {
@@ -1170,6 +1216,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
       mid[rt].p[pr] = bf16x2{(__bf16)r0, (__bf16)r1};
     } else {
       ss[rt] = __builtin_amdgcn_fdot2_f32_bf16(hi[rt].p[pr], hi[rt].p[pr], ss[rt], false);
+      sm[rt] = __builtin_amdgcn_fdot2_f32_bf16(mid[rt].p[pr], mid[rt].p[pr], sm[rt], false);
       asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax[rt]) : "v"(v0), "v"(v1));
     }
   };
@@ -1331,25 +1378,31 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   asm volatile("" : "+v"(r16e), "+v"(ge), "+v"(lanee));
   int64_t* l_list = reinterpret_cast<int64_t*>(lds);
   float* l_y = lds + 2 * kS1ListCap;
-  int* l_count = reinterpret_cast<int*>(lds + kRingFloats + 256);   // [0] staged + overflowed entries, [1] global base
+  int* l_count = reinterpret_cast<int*>(lds + kRingFloats + 512);   // [0] staged + overflowed entries, [1] global base
   if (tid == 0) l_count[0] = 0;
 
-  // ---- row statistics -> stage-1 window per row -----------------------------------------------------------------
-  // s2 came from the bf16 high parts (<= 0.8 % off): widen by 1 %.  A row whose largest |x| is outside [2^-60, 2^60]
-  // leaves the range in which x*x and the bf16 split neither underflow nor overflow: all of its projections are
-  // re-evaluated (NOT(|y| > +inf) holds for every y).  A true zero row gives y = 0 in both passes.
+  // ---- row statistics -> the two factors of the stage-1 window per row ------------------------------------------------
+  // ||x_hi|| and ||x_mid|| are sums over the very bf16 values the matrix instructions consumed (f32 accumulation: + 0.1 %,
+  // which also covers what separates ||x_hi|| + ||x_mid|| from ||x||).  A row whose largest |x| is outside
+  // [2^-32, 2^32] leaves the range in which the squares and the split neither underflow nor overflow: all of its
+  // projections are re-evaluated (NOT(|y| > +inf) holds for every y).  A true zero row gives y = 0 in both passes.
   float* wnd_lds = lds + kRingFloats + wave * kWaveRows;
+  float* wnb_lds = lds + kRingFloats + 256 + wave * kWaveRows;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     float s2 = ss[rt] + __shfl_xor(ss[rt], 16);
     s2 += __shfl_xor(s2, 32);
+    float m2 = sm[rt] + __shfl_xor(sm[rt], 16);
+    m2 += __shfl_xor(m2, 32);
     float am = __builtin_fmaxf(amax[rt], __shfl_xor(amax[rt], 16));
     am = __builtin_fmaxf(am, __shfl_xor(am, 32));
     const int64_t myrow = row0 + 16 * rt + r16e;
     if (ge == 0) {
-      float window = sqrtf(s2) * args.tau * 1.01f;
-      if (am != 0.f && !(am >= 0x1p-60f && am <= 0x1p60f)) window = __builtin_inff();
+      float window = sqrtf(s2) * args.tau * 1.001f;
+      if (am != 0.f && !(am >= 0x1p-32f && am <= 0x1p32f)) window = __builtin_inff();
       wnd_lds[16 * rt + r16e] = window;
+      const float wb_ = sqrtf(m2) * args.tau_b * 1.001f;
+      wnb_lds[16 * rt + r16e] = wb_ < __builtin_inff() ? wb_ : 0.f;      // (NaN / Inf rows: the first factor decides)
       if (cb == 0 && args.row_flags != nullptr && myrow < args.n) {
         const bool has_nan = s2 != s2;
         const bool zero = (am <= 1e-8f) && !has_nan;
@@ -1365,19 +1418,21 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   // 16 rtl + 8 g'pair + reg and + 4 - and the 32-column words 2 (L % 4), + 1: the ballot halves of the even column
   // tile land in A[], of the odd one in B[] (deposit_positive: v_cmp, the two wait states a VALU-written SGPR needs,
   // two v_writelane), and two VALU ops per word merge the 16-bit halves.
-  const float nmax = args.norm_max[cb];
+  const float amax_cb = args.wamax[cb], bmax_cb = args.wbmax[cb];
   {
     uint32_t A[2] = {0u, 0u}, B[2] = {0u, 0u};
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * ge);   // rows 16 rt + 4 g + 0..3
+      const f32x4 wnb = *reinterpret_cast<const f32x4*>(wnb_lds + 16 * rt + 4 * ge);
       // per-lane screen: the largest window of this lane's four rows (a non-finite window - NaN or Inf in the row, or
       // a magnitude outside the guarded range - makes it +inf: everything goes to the exact test)
       float tsmax = __builtin_fmaxf(__builtin_fmaxf(wnd[0], wnd[1]), __builtin_fmaxf(wnd[2], wnd[3]));
       if (!(wnd[0] < __builtin_inff()) || !(wnd[1] < __builtin_inff()) || !(wnd[2] < __builtin_inff()) ||
           !(wnd[3] < __builtin_inff()))
         tsmax = __builtin_inff();
-      tsmax *= nmax;
+      tsmax = tsmax * amax_cb +
+              __builtin_fmaxf(__builtin_fmaxf(wnb[0], wnb[1]), __builtin_fmaxf(wnb[2], wnb[3])) * bmax_cb;
       tsmax = tsmax > 0.f ? tsmax : -1.f;               // all four rows zero: nothing to re-evaluate
 #pragma unroll
       for (int w = 0; w < 8; ++w) {
@@ -1395,10 +1450,10 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int ct = 2 * w + half;
-            const float pn = args.norms[cb * 256 + 16 * ct + r16e];
+            const float pa = args.wa[cb * 256 + 16 * ct + r16e], pb = args.wb[cb * 256 + 16 * ct + r16e];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-              float thr = wnd[reg] * pn;
+              float thr = wnd[reg] * pa + wnb[reg] * pb;
               thr = thr > 0.f ? thr : -1.f;                               // zero row / zero-padded column: y is exactly 0
               const int64_t grow = row0 + 16 * rt + 4 * ge + reg;
               const float yv = acc[rt][ct][reg];
@@ -1816,6 +1871,38 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     hipLaunchKernelGGL(pack_image_bf16_t16_kernel, dim3((unsigned)((schunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
                        rows_per_band, dim, g.bb, g.ktiles, schunks, reinterpret_cast<u16x8*>(timage));
   }
+  {
+    // the window block until lshrs_sig_set_window fills it: coefficients so large that a pass asking for the proven
+    // window sends EVERY projection to the exact decision (slow and right, never fast and wrong)
+    const int64_t wf = sig_window_floats(g);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((wf + 255) / 256)), dim3(256), 0, s, image + sig_window_offset_floats(g),
+                       wf, 1e30f);
+  }
+  return -(int)hipGetLastError();
+}
+
+int lshrs_sig_set_window(void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim, const float* coef_a,
+                         const float* coef_b, const float* coef_tie, void* stream) {
+  if (workspace == nullptr || coef_a == nullptr || coef_b == nullptr || coef_tie == nullptr ||
+      !sig_shape_ok(num_bands, rows_per_band, dim))
+    return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* base = static_cast<float*>(workspace);
+  const SigWindow w = sig_window(base, g);
+  const int wc = (int)sig_window_cols(g);
+  hipLaunchKernelGGL(window_scatter_kernel, dim3((unsigned)((wc + 63) / 64)), dim3(64), 0, s, coef_a, coef_b, coef_tie,
+                     num_bands, rows_per_band, g.bb, wc, const_cast<float*>(w.wa), const_cast<float*>(w.wb),
+                     const_cast<float*>(w.wt));
+  // maxima per column block of the main geometry (a narrow hasher has one block; its zero-padded tail adds nothing)
+  const int per_block = g.nt * 32;
+  const dim3 mg((unsigned)((g.cb + 63) / 64)), mb(64);
+  hipLaunchKernelGGL(pack_normmax_kernel, mg, mb, 0, s, w.wa, per_block, g.cb, const_cast<float*>(w.wamax));
+  hipLaunchKernelGGL(pack_normmax_kernel, mg, mb, 0, s, w.wb, per_block, g.cb, const_cast<float*>(w.wbmax));
+  hipLaunchKernelGGL(pack_normmax_kernel, mg, mb, 0, s, w.wt, per_block, g.cb, const_cast<float*>(w.wtmax));
+  const SigGeom f = sig_fine_geom(g);
+  hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((f.cb + 63) / 64)), dim3(64), 0, s, w.wt, 32, f.cb,
+                     const_cast<float*>(w.wtmax_fine));
   return -(int)hipGetLastError();
 }
 
@@ -1850,6 +1937,11 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
       a.image = base;
       a.norm_max = a.norms + sig_norm_floats(g);
     }
+    if (!(tau > 0.f)) {      // LSHRS_WINDOW_PROVEN: the tie window of lshrs_sig_set_window (coefficient per column, factor 1)
+      const SigWindow w = sig_window(base, g);
+      a.norms = w.wt;
+      a.norm_max = fine ? w.wtmax_fine : w.wtmax;
+    }
     a.keys = keys + lo * row_bytes;
     a.row_bytes = row_bytes;
     const int wpl_bytes = gg.nt >= 2 ? 2 * gg.nt : 4;  // bytes one lane stores
@@ -1858,7 +1950,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
     a.tie_list = tie_list;
     a.tie_cap = tie_cap;
     a.tie_count = tie_count;
-    a.tau = tau;
+    a.tau = tau > 0.f ? tau : 1.0f;
     a.row_flags = row_flags != nullptr ? row_flags + lo : nullptr;
     a.clock_probe = (lo == 0 && !fine) ? read_opts(opts).clock_probe : nullptr;
     return dispatch_sig(a, gg, false, s);
@@ -1931,7 +2023,19 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   a.flag_y = flag_y;
   a.tie_cap = flag_cap;
   a.tie_count = flag_count;
-  a.tau = tau1;
+  if (tau1 > 0.f) {                 // a window of tau1 units of ||x|| ||p||, the caller's responsibility
+    a.tau = tau1;
+    a.tau_b = 0.f;
+    a.wa = a.wb = a.norms;
+    a.wamax = a.wbmax = a.norm_max;
+  } else {                          // LSHRS_WINDOW_PROVEN: ||x_hi|| wa + ||x_mid|| wb (lshrs_sig_set_window)
+    const SigWindow w = sig_window(base, g);
+    a.tau = a.tau_b = 1.0f;
+    a.wa = w.wa;
+    a.wb = w.wb;
+    a.wamax = w.wamax;
+    a.wbmax = w.wbmax;
+  }
   a.row_flags = row_flags;
   a.clock_probe = o.clock_probe;
   {
@@ -1956,7 +2060,8 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.tie_list = tie_list;
   f.tie_cap = tie_cap;
   f.tie_count = tie_count;
-  f.tau = tau;
+  f.tau = tau > 0.f ? tau : 1.0f;
+  f.tie_coef = tau > 0.f ? a.norms : sig_window(base, g).wt;      // (proven tie window: coefficient per column, factor 1)
   f.blas_model = blas_model;
   const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
   const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
@@ -2034,7 +2139,8 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   f.tie_list = nullptr;
   f.tie_cap = 0;
   f.tie_count = nullptr;          // (the caller has the number of tie entries already; stage 2 only decides them)
-  f.tau = tau;
+  f.tau = tau > 0.f ? tau : 1.0f;
+  f.tie_coef = tau > 0.f ? f.norms : sig_window(base, g).wt;
   f.blas_model = blas_model;
   f.partials = counters + LSHRS_SIG_COUNTERS;
   {

@@ -60,6 +60,85 @@ def bound_tau1_ulps(dim: int) -> float:
     return 768.0 * (1.0 + 2.0 ** -7) + 1.02 * MFMA_BF16_ERR_UNITS * (n_mfma + 1) + float((dim + 7) // 8 + 3)
 
 
+def _bf16_rne(v: np.ndarray) -> np.ndarray:
+    """float32 -> nearest-even bf16, returned as float32 (finite inputs)."""
+    u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def window_coefficients(planes: np.ndarray, blas_model: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray, dict]:
+    """The PROVEN windows of the signature pass, as per-hyperplane coefficients (float64 arithmetic, rounded up to float32):
+
+        stage 1 of the split pass:   |y1 - y_target|      <= ||x_hi|| * coef_a[j] + ||x_mid|| * coef_b[j]
+        the f32 kernel's fmaf chain: |y_chain - y_host|   <= ||x|| * coef_tie[j]
+
+    ``x_hi = bf16(x)``, ``x_mid = bf16(x - x_hi)`` (their norms are what ``sig16_kernel`` accumulates, from the values it
+    feeds the matrix cores); ``y_target`` is what decides a flagged projection: the host BLAS's value as stage 2 replays
+    it (``blas_model`` 1: eight interleaved fma chains + a three-level tree, `_hostblas.blas_order_model`) or, without a
+    recognised order (``blas_model`` 0: stage 2 evaluates the f32 chain and the host engine decides the ties), the chain.
+    Every term is an elementwise error bound summed by Cauchy-Schwarz against a per-hyperplane constant:
+
+    * the products the bf16x3 split drops: ``x p - (x_hi p_hi + x_hi p_mid + x_mid p_hi) = x_mid p_mid + (x_hi + x_mid) e_p
+      + e_x p``, with ``|e_x,k| <= 2^-8 |x_mid,k|`` (half an ulp of the middle piece);
+    * ``v_mfma_f32_16x16x32_bf16`` (oracle/mfma_model.c, bit-exact on > 1e6 probes): per STEP of eight products the result
+      is within ``8 * 2^(E-24) <= 8 u max|a_k b_k|`` (seven truncated products and the accumulator) plus
+      ``(1 + 2^-7) u |accumulator|`` (the rounding, and the 2^(e_C - 31) cut of the product sum) of exact; the accumulator
+      after step s is at most the sum of the |products| of steps <= s, so a product in step s(k) of S is charged
+      ``S - s(k)`` roundings: weights that fall linearly along k - ``||p o n||`` is ~ S / sqrt(3) ||p||, not S ||p||;
+    * the target's own rounding: product k of the BLAS's chain j passes ``dim/8 - k//8 + 3`` single roundings (model 1),
+      of the f32 chain ``K - position(k)`` - again weights that fall along k; an unknown order: ``dim + 1``.
+
+    Returns ``(coef_a, coef_b, coef_tie, info)``; ``info["window_units"]``: the stage-1 window of a row with
+    ``||x_mid|| = 0.4 * 2^-8 ||x||`` (Gaussian-like data) in units of 2^-24 ||x|| ||p||, averaged over the hyperplanes."""
+    P = np.ascontiguousarray(planes, dtype=np.float32)
+    num, dim = P.shape
+    K = (dim + 31) // 32 * 32
+    p32 = np.zeros((num, K), dtype=np.float32)
+    p32[:, :dim] = P
+    ph32 = _bf16_rne(p32)
+    pm32 = _bf16_rne(p32 - ph32)
+    p, ph, pm = p32.astype(np.float64), ph32.astype(np.float64), pm32.astype(np.float64)
+    ep = p - ph - pm
+    k = np.arange(K)
+    t, g = k // 32, (k % 32) // 8
+    S = 12 * (K // 32)
+    n0 = (S - (12 * t + g)).astype(np.float64)          # roundings a product of term 0 / 1 / 2 is part of
+    n1 = (S - (12 * t + 4 + g)).astype(np.float64)
+    n2 = (S - (12 * t + 8 + g)).astype(np.float64)
+    norm = lambda a: np.sqrt((a * a).sum(axis=1))       # noqa: E731
+    u, R = _U, 1.0 + 2.0 ** -7
+    # the order of the f32 kernel's chain (oracle/chain_model.c): k = 32 t + 16 h + s sits at position 32 t + 2 s + h
+    m_chain = (K - (32 * t + 2 * (k % 16) + (k % 32) // 16)).astype(np.float64)
+    if blas_model == 1 and dim % 8 == 0:
+        m_host = np.where(k < dim, dim // 8 - k // 8 + 3, 0).astype(np.float64)
+    else:
+        m_host = np.where(k < dim, dim + 1, 0).astype(np.float64)
+    m_target = m_host if blas_model == 1 else m_chain
+    a_mfma = u * R * (norm(ph * n0) + norm(pm * n1)) + 8.0 * u * (norm(ph) + norm(pm))
+    b_mfma = u * R * norm(ph * n2) + 8.0 * u * norm(ph)
+    a_cross = norm(ep)
+    b_cross = norm(pm) + norm(ep) + 2.0 ** -8 * norm(p)
+    a_tgt = u * norm(p * m_target)
+    slack = 1.0 + 1e-3 + 4.0 * K * u                    # second-order terms ((1+u)^m - 1 vs m u, errors of errors)
+    coef_a = (a_mfma + a_cross + a_tgt) * slack
+    coef_b = (b_mfma + b_cross + (1.0 + 2.0 ** -8) * a_tgt) * slack
+    coef_tie = u * (norm(p * m_chain) + norm(p * m_host)) * slack
+    def up(a):          # to float32, rounded up; an all-zero hyperplane keeps 0 (its y is exactly 0: never flagged)
+        f = a.astype(np.float32)
+        return np.where(a > 0, np.nextafter(f, np.float32(np.inf)), np.float32(0)).astype(np.float32)
+    pn = norm(p)
+    live = pn > 0
+    unit = u * np.where(live, pn, 1.0)
+    info = {"window_units": float(((coef_a + 0.4 * 2.0 ** -8 * coef_b) / unit)[live].mean()) if live.any() else 0.0,
+            "window_units_worst_case_row": float(((coef_a + 2.0 ** -8 * coef_b) / unit)[live].max()) if live.any() else 0.0,
+            "tie_units": float((coef_tie / unit)[live].mean()) if live.any() else 0.0,
+            "terms_units": {"dropped_products": float(((a_cross + 0.4 * 2.0 ** -8 * b_cross) / unit)[live].mean()),
+                            "mfma": float(((a_mfma + 0.4 * 2.0 ** -8 * b_mfma) / unit)[live].mean()),
+                            "target_rounding": float((a_tgt / unit)[live].mean())} if live.any() else {}}
+    return up(coef_a), up(coef_b), up(coef_tie), info
+
+
 def default_tau1_ulps(dim: int) -> float:
     """The default stage-1 window: 64 units at 768-d, scaled by sqrt(768 / dim).  Stage 1's deviation from the host BLAS
     is a random walk over the dim products relative to ||x|| ||p||: measured (tools/window_by_dim.py,
@@ -139,17 +218,20 @@ class _PendingKeys:
 
     def __init__(self, hasher: "LSHHasher", x, out, row_flags, state) -> None:
         self._hasher, self._x, self._out, self._row_flags, self._state = hasher, x, out, row_flags, state
+        self._stats = dict(hasher.last_stats) if state is None else None     # (a handle that was complete on creation)
 
     def done(self) -> bool:
         return self._state is None or bool(self._state[0].query())
 
-    def _finish_locked(self) -> None:
+    def _finish_locked(self):
+        """Verify the launch (repeat it where it must be repeated); returns THIS batch's statistics - `last_stats` of the
+        hasher may already be another batch's by the time the caller looks (a repeat finishes what is pending)."""
         h = self._hasher
         if self in h._async_pending:
             h._async_pending.remove(self)
         state, self._state = self._state, None
         if state is None:
-            return
+            return self._stats
         stats = {"n": int(self._x.shape[0]), "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
         if not h._replay_finish(state, stats):        # the stage-1 list was too small: once more, synchronously, with room
             h._hash_device_locked(self._x, self._out, self._row_flags, "host", host_rows=None)
@@ -158,7 +240,9 @@ class _PendingKeys:
                 if k in h.last_stats:
                     stats[k] = h.last_stats[k]
         h.last_stats = stats
+        self._stats = stats
         self._x = None
+        return stats
 
     def result(self):
         """The ``(n, num_bands, band_bytes)`` uint8 keys tensor, final and verified."""
@@ -211,7 +295,7 @@ class LSHHasher:
     """
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
-                 tie_break: str = "host", tau_ulps=8.0, precision: str = "bf16x3",
+                 tie_break: str = "host", tau_ulps=None, precision: str = "bf16x3",
                  tau1_ulps=None, tie_threads: Optional[int] = None, pipeline: str = "native",
                  tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64) -> None:
         # messages: lshrs/hash/lsh.py:78-83
@@ -231,15 +315,22 @@ class LSHHasher:
         self.tie_break = tie_break
         for name, value in (("tau_ulps", tau_ulps), ("tau1_ulps", tau1_ulps)):
             if isinstance(value, str) and value != "bound":
-                raise ValueError(f"{name} must be a number or 'bound'")
-        self.window_mode = {"tau": "bound" if tau_ulps == "bound" else "measured",
-                            "tau1": "bound" if tau1_ulps == "bound" else "measured"}
-        self.tau_ulps = bound_tau_ulps(self.dim) if tau_ulps == "bound" else float(tau_ulps)
+                raise ValueError(f"{name} must be a number, None or 'bound'")
+        # "bound" (the default, also what None means): the PROVEN windows - per-hyperplane coefficients derived by
+        # `window_coefficients`, handed to the library once per (hyperplanes, BLAS model): nothing is decided in stage 1
+        # that could come out differently on the host.  A number: a window of that many units of 2^-24 ||x|| ||p||, a
+        # statistical statement about the data ("measured"; the stage-1 one is watched by the margin guard).
+        self.window_mode = {"tau": "bound" if tau_ulps in (None, "bound") else "measured",
+                            "tau1": "bound" if tau1_ulps in (None, "bound") else "measured"}
+        # (in "bound" mode these two hold the TYPICAL size of the proven window in the same units - for list capacities
+        #  and reports; the kernels get LSHRS_WINDOW_PROVEN and use the coefficients.  Refined once the hyperplanes exist.)
+        self.tau_ulps = bound_tau_ulps(self.dim) if tau_ulps in (None, "bound") else float(tau_ulps)
         # "bf16x3": large batches take the split-precision first pass (bf16 matrix cores, >2x the rate) followed by
-        # the exact f32 chain for every projection inside the stage-1 window; same keys as "f32" 
+        # the exact decision for every projection inside the stage-1 window; same keys as "f32" 
         self.precision = precision
-        self.tau1_ulps = (bound_tau1_ulps(self.dim) if tau1_ulps == "bound" else
-                          default_tau1_ulps(self.dim) if tau1_ulps is None else float(tau1_ulps))
+        self.tau1_ulps = bound_tau1_ulps(self.dim) if tau1_ulps in (None, "bound") else float(tau1_ulps)
+        self.window_info: Dict[str, object] = {}
+        self._window_set: Dict[int, tuple] = {}
         self.margin_guard = float(margin_guard)
         # every audit_every-th synchronous batch (and the first): a few of the projections the device has decided are
         # re-evaluated with NumPy on the host and compared (0 = never)
@@ -341,7 +432,9 @@ class LSHHasher:
         if self._device is None:
             return torch.device("cuda", torch.cuda.current_device())
         dev = torch.device(self._device) if not isinstance(self._device, int) else torch.device("cuda", self._device)
-        if dev.index is None:
+        if dev.index is None or dev.index >= torch.cuda.device_count():
+            # (no index, or one this process does not have - an index unpickled on a worker with fewer GPUs or pinned to
+            #  another one: the current device, as a hasher built without `device` uses)
             dev = torch.device("cuda", torch.cuda.current_device())
         return dev
 
@@ -365,7 +458,42 @@ class LSHHasher:
                 "lshrs_sig_pack_projections")
             torch.cuda.current_stream(dev).synchronize()  # p_dev may be freed after this
         self._workspaces[dev.index] = (self._projection_version, ws)
+        self._window_set.pop(dev.index, None)     # (a fresh workspace: its window block sends everything to the exact decision)
         return ws
+
+    def _tau_arg(self) -> float:
+        """The tie window as the library takes it: LSHRS_WINDOW_PROVEN (0) or tau_ulps * 2^-24."""
+        return 0.0 if self.window_mode["tau"] == "bound" else float(self.tau_ulps * _U)
+
+    def _tau1_arg(self) -> float:
+        return 0.0 if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps * _U)
+
+    def _ensure_window(self, dev, ws, model: int) -> None:
+        """Hand the proven windows' coefficients for these hyperplanes and this decision engine (BLAS order model, 0 = f32
+        chain + host engine) to the library, once per (device, hyperplanes, model)."""
+        if "bound" not in self.window_mode.values():
+            return
+        key = (self._projection_version, int(model))
+        if self._window_set.get(dev.index) == key:
+            return
+        torch = _native.require_gpu()
+        lib = _native.load()
+        ca, cb, ct, info = window_coefficients(self._stacked(), int(model))
+        with torch.cuda.device(dev):
+            if dev.index in self._window_set:
+                torch.cuda.synchronize(dev)       # (a pass that reads the previous coefficients may still be running)
+            coef = torch.from_numpy(np.stack([ca, cb, ct])).to(dev)
+            stream = torch.cuda.current_stream(dev)
+            _native.check(lib.lshrs_sig_set_window(ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
+                                                   coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
+                                                   stream.cuda_stream), "lshrs_sig_set_window")
+            stream.synchronize()                  # coef may be freed after this
+        self._window_set[dev.index] = key
+        self.window_info = info
+        if self.window_mode["tau1"] == "bound":
+            self.tau1_ulps = float(info["window_units"])
+        if self.window_mode["tau"] == "bound":
+            self.tau_ulps = float(info["tie_units"])
 
     # ------------------------------------------------------------------ core: device -> device
     def hash_device(self, x, *, out=None, row_flags=None, tie_break: Optional[str] = None):
@@ -400,7 +528,9 @@ class LSHHasher:
         if n == 0:
             return out
         ws = self._workspace(dev)
-        tau = float(self.tau_ulps * _U)
+        model_now = self._replay_model() if (mode == "host" and self.tie_replay == "auto") else 0
+        self._ensure_window(dev, ws, model_now)
+        tau = self._tau_arg()
         if (mode == "host" and self.tie_replay == "auto" and self._split_applies(n, replay=True)
                 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0 and x.stride(0) < (1 << 20)):
             model = self._replay_model()
@@ -530,7 +660,7 @@ class LSHHasher:
                     lib.lshrs_sig_hash_batch_split_replay_f32(
                         x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
                         out.data_ptr(), counts.data_ptr(), tau, row_flags.data_ptr() if row_flags is not None else None,
-                        flag_list.data_ptr(), flag_y.data_ptr(), int(flag_list.shape[0]), float(self.tau1_ulps * _U),
+                        flag_list.data_ptr(), flag_y.data_ptr(), int(flag_list.shape[0]), self._tau1_arg(),
                         model, pinned[slot].data_ptr(), ctypes.byref(opts) if opts is not None else None,
                         cur.cuda_stream),
                     "lshrs_sig_hash_batch_split_replay_f32")
@@ -542,7 +672,8 @@ class LSHHasher:
             if want_event:          # (the synchronous path waits for the stream instead)
                 done = torch.cuda.Event()
                 done.record(cur)
-        return (done if want_event else cur, host_counts, slot, int(flag_list.shape[0]), n, ev, float(self.tau1_ulps))
+        return (done if want_event else cur, host_counts, slot, int(flag_list.shape[0]), n, ev,
+                float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps))
 
     def _replay_finish(self, state, stats) -> bool:
         """Wait for a launch of `_replay_launch`; False when it must be repeated: its stage-1 list was too small (more
@@ -557,9 +688,23 @@ class LSHHasher:
             stats["relaunches"] += 1
             return False
         stats["max_dev_units"] = max(max_dev, stats.get("max_dev_units", 0.0))
-        if self.margin_guard > 0.0 and max_dev > self.margin_guard * window and self.window_mode["tau1"] != "bound":
-            # the measured margin of this batch is not what the window assumes: a wider one, from here on
-            self.tau1_ulps, self.window_mode["tau1"] = escalated_window(window, max_dev, self.dim)
+        if window == float("inf"):
+            # proven window: what stage 2 measured on every flagged projection can only be INSIDE it - anything else is a
+            # bug in the bound or in the arithmetic model it rests on, and must not pass silently
+            worst = float(self.window_info.get("window_units_worst_case_row", float("inf")))
+            if max_dev > worst:
+                raise _native.NativeLibraryError(
+                    f"stage 1 strayed {max_dev:.1f} units from the host's value, outside the proven window "
+                    f"({worst:.1f} units at most): the window's premises do not hold on this device")
+        elif (self.margin_guard > 0.0 and max_dev > self.margin_guard * window
+                and window < bound_tau1_ulps(self.dim)):
+            # the measured margin of this batch is not what the window IT WAS LAUNCHED WITH assumes (another batch in
+            # flight may have widened the hasher's window since): hash it again, and only ever widen the hasher's window
+            wider, mode = escalated_window(window, max_dev, self.dim)
+            if self.window_mode["tau1"] != "bound" and wider > self.tau1_ulps:
+                self.tau1_ulps, self.window_mode["tau1"] = wider, mode      # ("bound": the proven window from here on)
+                if mode == "bound":
+                    self._window_set.clear()
             self.margin_escalations += 1
             stats["relaunches"] += 1
             stats["margin_escalations"] = self.margin_escalations
@@ -570,7 +715,8 @@ class LSHHasher:
         stats["tie_pairs"] = ties          # (tied PROJECTIONS here: each decided by the replayed host order)
         stats["flagged"] = flagged         # projections inside the stage-1 window: every one decided by stage 2
         stats["sign_flips"] = flips        # ... of which stage 1 had the sign wrong
-        stats["tau1_ulps"] = window
+        stats["tau1_ulps"] = self.tau1_ulps if window == float("inf") else window
+        stats["window"] = "proven" if window == float("inf") else "measured"
         stats["margin_escalations"] = self.margin_escalations
         stats["tie_break_engine"] = "device-replay"
         return True
@@ -582,7 +728,7 @@ class LSHHasher:
         while self._async_pending:      # (their pinned pairs are handed out in turn: verify them before taking more)
             self._async_pending[0]._finish_locked()
         while not self._replay_finish(self._replay_launch(x, out, row_flags, ws, tau, model), stats):
-            pass
+            self._ensure_window(x.device, ws, model)      # (a guard that has just moved the hasher to the proven window)
         if self.audit_every > 0 and stats.get("flagged", 0) > 0:
             self._audit_countdown -= 1
             if self._audit_countdown <= 0:
@@ -671,7 +817,8 @@ class LSHHasher:
         elif out.shape != (n, self.num_bands, bb) or out.dtype != torch.uint8 or not out.is_contiguous():
             raise ValueError("out must be a contiguous uint8 tensor of shape (n, num_bands, band_bytes)")
         ws = self._workspace(x.device)
-        state = self._replay_launch(x, out, row_flags, ws, float(self.tau_ulps * _U), model, want_event=True)
+        self._ensure_window(x.device, ws, model)
+        state = self._replay_launch(x, out, row_flags, ws, self._tau_arg(), model, want_event=True)
         handle = _PendingKeys(self, x, out, row_flags, state)
         self._async_pending.append(handle)
         return handle
@@ -848,7 +995,7 @@ class LSHHasher:
             main = torch.cuda.current_stream(dev)
             rc = lib.lshrs_pipe_hash_f32(
                 pipe, x.data_ptr(), x.stride(0), ws.data_ptr(), out.data_ptr(),
-                row_flags.data_ptr() if row_flags is not None else None, tau, float(self.tau1_ulps * _U),
+                row_flags.data_ptr() if row_flags is not None else None, tau, self._tau1_arg(),
                 bounds.ctypes.data, chunk_split.ctypes.data, nc, eng.resolve_fn, eng.handle, planes.ctypes.data,
                 status.ctypes.data, ms.ctypes.data if timing else None, st.ctypes.data, main.cuda_stream)
         _native.check(int(rc), "lshrs_pipe_hash_f32")
@@ -930,7 +1077,7 @@ class LSHHasher:
                 flag_count = torch.zeros(1, dtype=torch.int32, device=dev)
             flag = (flag_count, cap, flag_list)
             call = lambda opts: lib.lshrs_sig_hash_batch_split_f32(  # noqa: E731
-                *args[:-1], flag_list.data_ptr(), cap, flag_count.data_ptr(), float(self.tau1_ulps * _U), opts, args[-1])
+                *args[:-1], flag_list.data_ptr(), cap, flag_count.data_ptr(), self._tau1_arg(), opts, args[-1])
             name = "lshrs_sig_hash_batch_split_f32"
         else:
             call = lambda opts: lib.lshrs_sig_hash_batch_f32(*args[:-1], opts, args[-1])  # noqa: E731
@@ -1137,7 +1284,7 @@ class LSHHasher:
             else:
                 x_dev[:n].copy_(pin_x[:n], non_blocking=True)
                 x_ptr = x_dev.data_ptr()
-            tau = float(self.tau_ulps * _U)
+            tau = float(8.0 * _U)        # (this kernel decides every projection itself; tau only feeds its tie statistic)
             if poll:
                 epoch = self._small_epoch = self._small_epoch % 0x7FFFFFF0 + 1
                 base = pin_out.data_ptr()
@@ -1227,12 +1374,10 @@ class LSHHasher:
 
         def send_back(item):
             handle, (lo, hi), b = item
-            with torch.cuda.stream(comp_s):
-                if handle._state is not None:        # verify (repeats the chunk with room / with the bound window if it must)
-                    handle._finish_locked()
+            with torch.cuda.stream(comp_s):         # verify (repeats the chunk with room / with a wider window if it must)
+                st = handle._finish_locked() or {}
             while len(landed) > 1:                   # (the pinned key buffer b is about to be overwritten: empty it first)
                 land(landed.pop(0))
-            st = self.last_stats
             for k in ("tie_entries", "tie_pairs", "relaunches", "flagged"):
                 total[k] += st.get(k, 0)
             total["max_dev_units"] = max(total["max_dev_units"], st.get("max_dev_units", 0.0))
@@ -1393,6 +1538,7 @@ class LSHHasher:
         state["_one_queue"] = []
         state["_one_leader"] = False
         state["_workspaces"] = {}
+        state["_window_set"] = {}
         state["_pinned_cache"] = {}
         state["_small_epoch"] = 0
         state["_pipes"] = {}
@@ -1430,6 +1576,8 @@ class LSHHasher:
         self.__dict__.setdefault("audit_failures", 0)
         self.__dict__.setdefault("margin_escalations", 0)
         self.__dict__.setdefault("window_mode", {"tau": "measured", "tau1": "measured"})
+        self.__dict__.setdefault("window_info", {})
+        self._window_set = {}
         self._lock = threading.Lock()
         self._one_lock = threading.Lock()
         self._one_queue = []

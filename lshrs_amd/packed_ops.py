@@ -27,7 +27,7 @@ import numpy as np
 
 from . import _native
 
-__all__ = ["hex_keys", "hex_keys_device", "group_by_bucket", "bucket_csr", "BucketCSR", "RedisPackedWriter"]
+__all__ = ["hex_keys", "hex_keys_device", "group_by_bucket", "bucket_csr", "BucketCSR", "dedupe_csr", "RedisPackedWriter"]
 
 
 @dataclass
@@ -43,14 +43,43 @@ class BucketCSR:
     offsets: np.ndarray      # (m + 1,) int64
     members: np.ndarray      # (n * num_bands,) int64
     vectors: int
+    distinct: bool = False   # True once no bucket lists a member twice (buckets are SETS: lshrs/storage/redis.py:408-416 SADD)
 
     def __len__(self) -> int:
         return int(self.bands.shape[0])
 
 
+def ids_are_distinct(id_arr: np.ndarray) -> bool:
+    """No id twice in a batch?  One pass when the ids ascend (the usual case), one sort otherwise."""
+    if id_arr.shape[0] < 2 or bool((id_arr[1:] > id_arr[:-1]).all()):
+        return True
+    return int(np.unique(id_arr).shape[0]) == int(id_arr.shape[0])
+
+
+def dedupe_csr(csr: "BucketCSR") -> "BucketCSR":
+    """Set semantics for an array bucket list: every member at most once per bucket (the reference's buckets are Redis
+    sets - an id indexed twice collides once per band, lshrs/core/main.py:1101-1109).  One sort of (bucket, member)."""
+    if csr.distinct or len(csr) == 0:
+        csr.distinct = True
+        return csr
+    lens = np.diff(csr.offsets)
+    bucket = np.repeat(np.arange(len(csr), dtype=np.int64), lens)
+    order = np.lexsort((csr.members, bucket))
+    b, m = bucket[order], csr.members[order]
+    keep = np.r_[True, (b[1:] != b[:-1]) | (m[1:] != m[:-1])]
+    if keep.all():
+        csr.distinct = True
+        return csr
+    b, m = b[keep], m[keep]
+    new_lens = np.bincount(b, minlength=len(csr)).astype(np.int64)
+    return BucketCSR(csr.band_bytes, csr.bands, csr.key_bytes, csr.codes, np.r_[0, np.cumsum(new_lens)].astype(np.int64),
+                     m, csr.vectors, True)
+
+
 def merge_csr(segments) -> "BucketCSR":
     """Several :class:`BucketCSR` with codes (``band_bytes <= 6``, all equal) folded into one: the union of their buckets,
-    every bucket's members concatenated in segment order.  Array work only - O(members + buckets log buckets)."""
+    every bucket's members concatenated in segment order, then each member once per bucket (an id indexed in two calls
+    is in its bucket ONCE: set semantics).  Array work only."""
     segs = [s for s in segments if len(s)]
     if not segs:
         return segments[0]
@@ -73,7 +102,8 @@ def merge_csr(segments) -> "BucketCSR":
     kb = np.empty((uniq.shape[0], bb), dtype=np.uint8)
     for j in range(bb):
         kb[:, j] = (uniq >> (8 * j)) & 0xFF
-    return BucketCSR(bb, (uniq >> (8 * bb)).astype(np.int32), kb, uniq, new_off, members, sum(int(s.vectors) for s in segs))
+    return dedupe_csr(BucketCSR(bb, (uniq >> (8 * bb)).astype(np.int32), kb, uniq, new_off, members,
+                                sum(int(s.vectors) for s in segs)))
 
 
 def key_codes(keys: np.ndarray) -> np.ndarray:
@@ -152,11 +182,14 @@ def bucket_csr(ids: Sequence[int], keys, *, device=None) -> BucketCSR:
     n, nb, bb = (int(v) for v in keys.shape)
     if id_arr.shape[0] != n:
         raise ValueError("ids and keys disagree in length")
-    if n == 0 or bb > 6:
-        host_keys = keys.cpu().numpy() if on_dev else np.ascontiguousarray(keys, dtype=np.uint8)
-        return _csr_host(id_arr, host_keys)
-    if bb > 2:
-        return _csr_device_sorted(torch, id_arr, keys, device)
+    if n == 0 or bb > 6 or bb > 2:
+        if n == 0 or bb > 6:
+            host_keys = keys.cpu().numpy() if on_dev else np.ascontiguousarray(keys, dtype=np.uint8)
+            csr = _csr_host(id_arr, host_keys)
+        else:
+            csr = _csr_device_sorted(torch, id_arr, keys, device)
+        csr.distinct = ids_are_distinct(id_arr)
+        return csr if csr.distinct else dedupe_csr(csr)
     lib = _native.load()
     if on_dev:
         kd = keys.contiguous()
@@ -184,8 +217,10 @@ def bucket_csr(ids: Sequence[int], keys, *, device=None) -> BucketCSR:
     kb = np.empty((live.shape[0], bb), dtype=np.uint8)
     for j in range(bb):
         kb[:, j] = (live >> (8 * j)) & 0xFF
-    return BucketCSR(bb, (live >> (8 * bb)).astype(np.int32), kb, live,
-                     np.r_[0, np.cumsum(counts_h[live], dtype=np.int64)].astype(np.int64), members_h, n)
+    csr = BucketCSR(bb, (live >> (8 * bb)).astype(np.int32), kb, live,
+                    np.r_[0, np.cumsum(counts_h[live], dtype=np.int64)].astype(np.int64), members_h, n,
+                    ids_are_distinct(id_arr))
+    return csr if csr.distinct else dedupe_csr(csr)      # (an id twice in one batch: once per bucket, as SADD leaves it)
 
 
 def hex_keys_device(keys):

@@ -86,43 +86,45 @@ class InMemoryStorage:
 
     def get_buckets_many(self, keys) -> Tuple[np.ndarray, np.ndarray]:
         """Every member of every bucket a batch of queries touches, as two flat arrays ``(query index, member id)`` - one
-        pair per (query, band, member) - without a Python object per member (the collision count of
+        pair per (query, band, member), a member counted ONCE per band however many times and through whichever calls it
+        was indexed (buckets are sets) - without a Python object per member (the collision count of
         ``LSHRS._candidate_counts``, lshrs/core/main.py:1101-1109, then is one sort).  ``keys``: (q, bands, B) uint8."""
         from .packed_ops import key_codes
 
         keys = np.ascontiguousarray(keys, dtype=np.uint8)
         nq, nb, bb = keys.shape
-        qs, ms = [], []
+        qs, bs, ms = [], [], []
         with self._lock:
             if len(self._segments) > self.compact_above:
                 self._compact_locked()
-            segments = list(self._segments)
-            loose = bool(self._buckets)
-        if loose:                                       # buckets built from op tuples: dict lookups, per (query, band)
-            for qi in range(nq):
-                for b in range(nb):
-                    mem = self._buckets.get(self.bucket_key(b, keys[qi, b].tobytes()))
-                    if mem:
-                        ms.append(np.fromiter(mem, dtype=np.int64, count=len(mem)))
-                        qs.append(np.full(len(mem), qi, dtype=np.int64))
-        codes = key_codes(keys).reshape(-1) if bb <= 6 else None
-        qidx = np.repeat(np.arange(nq, dtype=np.int64), nb)
-        for seg in segments:
-            if seg.band_bytes != bb or len(seg) == 0:
-                continue
-            if codes is None or seg.codes is None:
-                for qi in range(nq):
+            segments = [s for s in self._segments if s.band_bytes == bb and len(s)]
+            array_path = bb <= 6 and all(seg.codes is not None for seg in segments)
+            if self._buckets and array_path:            # buckets built from op tuples: dict lookups per (query, band),
+                for qi in range(nq):                    # under the lock (writers mutate these sets)
                     for b in range(nb):
-                        mem = self.get_bucket(b, keys[qi, b].tobytes())
+                        mem = self._buckets.get(self.bucket_key(b, keys[qi, b].tobytes()))
                         if mem:
                             ms.append(np.fromiter(mem, dtype=np.int64, count=len(mem)))
                             qs.append(np.full(len(mem), qi, dtype=np.int64))
-                return (np.concatenate(qs) if qs else np.empty(0, np.int64),
-                        np.concatenate(ms) if ms else np.empty(0, np.int64))
+                            bs.append(np.full(len(mem), b, dtype=np.int64))
+        if not array_path:                              # wide keys: get_bucket merges every source into one set per bucket
+            for qi in range(nq):
+                for b in range(nb):
+                    mem = self.get_bucket(b, keys[qi, b].tobytes())
+                    if mem:
+                        ms.append(np.fromiter(mem, dtype=np.int64, count=len(mem)))
+                        qs.append(np.full(len(mem), qi, dtype=np.int64))
+            return (np.concatenate(qs) if qs else np.empty(0, np.int64),
+                    np.concatenate(ms) if ms else np.empty(0, np.int64))
+        sources = 1 if qs else 0
+        codes = key_codes(keys).reshape(-1)
+        qidx = np.repeat(np.arange(nq, dtype=np.int64), nb)
+        bidx = np.tile(np.arange(nb, dtype=np.int64), nq)
+        for seg in segments:
             g = np.searchsorted(seg.codes, codes)
             g[g >= len(seg)] = 0
             hit = seg.codes[g] == codes
-            g, q = g[hit], qidx[hit]
+            g, q, b = g[hit], qidx[hit], bidx[hit]
             lo = seg.offsets[g]
             lens = seg.offsets[g + 1] - lo
             total = int(lens.sum())
@@ -133,7 +135,19 @@ class InMemoryStorage:
             pos = np.arange(total, dtype=np.int64) - np.repeat(starts, lens) + np.repeat(lo, lens)
             ms.append(seg.members[pos])
             qs.append(np.repeat(q, lens))
-        return (np.concatenate(qs) if qs else np.empty(0, np.int64), np.concatenate(ms) if ms else np.empty(0, np.int64))
+            bs.append(np.repeat(b, lens))
+            sources += 1 if seg.distinct else 2         # (a segment that may list a member twice counts as two)
+        if not qs:
+            return np.empty(0, np.int64), np.empty(0, np.int64)
+        q, m = np.concatenate(qs), np.concatenate(ms)
+        if sources > 1:
+            # the same id may sit in the same bucket through two sources (indexed twice): once per (query, band)
+            b = np.concatenate(bs)
+            order = np.lexsort((m, b, q))
+            q, b, m = q[order], b[order], m[order]
+            keep = np.r_[True, (q[1:] != q[:-1]) | (b[1:] != b[:-1]) | (m[1:] != m[:-1])]
+            q, m = q[keep], m[keep]
+        return q, m
 
     def batch_add(self, operations: Iterable[BucketOperation]) -> None:
         ops = list(operations)
@@ -162,6 +176,9 @@ class InMemoryStorage:
         Python object per member or per bucket), consulted by ``get_bucket`` / ``get_buckets_many`` by bisection."""
         if self._fail_on_flush:
             raise ConnectionError("simulated storage failure")
+        from .packed_ops import dedupe_csr
+
+        csr = dedupe_csr(csr)                            # (no-op for the builders' output: they mark it distinct)
         with self._lock:
             self.packed_batches.append((int(csr.vectors), len(csr)))
             self._segments.append(csr)
@@ -186,7 +203,8 @@ class InMemoryStorage:
                     live = lens > 0
                     kept.append(BucketCSR(seg.band_bytes, seg.bands[live], seg.key_bytes[live],
                                           None if seg.codes is None else seg.codes[live],
-                                          np.r_[0, np.cumsum(lens[live])].astype(np.int64), seg.members[keep], seg.vectors))
+                                          np.r_[0, np.cumsum(lens[live])].astype(np.int64), seg.members[keep], seg.vectors,
+                                          seg.distinct))
                 self._segments = kept
 
     def clear(self) -> None:

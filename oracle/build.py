@@ -1,4 +1,5 @@
-"""Build + load the C part of the oracle (oracle/chain_model.c → oracle/_build/libchain_model.so).
+"""Build + load the C parts of the oracle (oracle/chain_model.c → oracle/_build/libchain_model.so, oracle/mfma_model.c →
+oracle/_build/libmfma_model.so).
 
 TEST INFRASTRUCTURE ONLY.  gcc, no dependencies.  ``-ffp-contract=off`` so the
 compiler neither fuses nor splits anything: every rounding in the model is an
@@ -100,5 +101,61 @@ def cosine_f64(query, candidates) -> np.ndarray:
     return s
 
 
+# ---- oracle/mfma_model.c: the arithmetic of v_mfma_f32_16x16x32_{bf16,f16} and of the split pass's accumulator -----------
+_MFMA_SRC = os.path.join(_HERE, "mfma_model.c")
+_MFMA_OUT = os.path.join(_OUT_DIR, "libmfma_model.so")
+_mfma_lib = None
+
+
+def build_mfma(force: bool = False) -> str:
+    with _lock:
+        if not force and os.path.exists(_MFMA_OUT) and os.path.getmtime(_MFMA_OUT) >= os.path.getmtime(_MFMA_SRC):
+            return _MFMA_OUT
+        os.makedirs(_OUT_DIR, exist_ok=True)
+        cmd = ["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", _MFMA_SRC, "-o",
+               _MFMA_OUT + ".tmp", "-lm"]
+        subprocess.run(cmd, check=True)
+        os.replace(_MFMA_OUT + ".tmp", _MFMA_OUT)
+        return _MFMA_OUT
+
+
+def load_mfma() -> ctypes.CDLL:
+    global _mfma_lib
+    if _mfma_lib is None:
+        lib = ctypes.CDLL(build_mfma())
+        lib.lshrs_mfma16_model_batch.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int64]
+        lib.lshrs_mfma16_model_batch.restype = None
+        lib.lshrs_split_stage1_model.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        lib.lshrs_split_stage1_model.restype = ctypes.c_float
+        lib.lshrs_split_stage1_model_batch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                       ctypes.c_int, ctypes.c_void_p]
+        lib.lshrs_split_stage1_model_batch.restype = None
+        _mfma_lib = lib
+    return _mfma_lib
+
+
+def mfma16_model(kind: int, a_bits, b_bits, c) -> np.ndarray:
+    """D of one v_mfma_f32_16x16x32 output element per case: kind 0 = f16, 1 = bf16; a_bits, b_bits (n, 32) uint16."""
+    lib = load_mfma()
+    A = np.ascontiguousarray(a_bits, dtype=np.uint16)
+    B = np.ascontiguousarray(b_bits, dtype=np.uint16)
+    C = _f32(c)
+    D = np.zeros(C.shape[0], dtype=np.float32)
+    lib.lshrs_mfma16_model_batch(int(kind), A.ctypes.data, B.ctypes.data, C.ctypes.data, D.ctypes.data, C.shape[0])
+    return D
+
+
+def split_stage1_model(projections, vectors) -> np.ndarray:
+    """(n, num_perm) f32: the value stage 1 of the split pass (sig16_kernel) holds for every projection - the bf16x3
+    split and the instruction model above, k-tile by k-tile, terms in the kernel's order."""
+    lib = load_mfma()
+    x = _f32(vectors)
+    p = _stack(projections)
+    y = np.empty((x.shape[0], p.shape[0]), dtype=np.float32)
+    lib.lshrs_split_stage1_model_batch(x.ctypes.data, x.shape[0], p.ctypes.data, p.shape[0], x.shape[1], y.ctypes.data)
+    return y
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_mfma(force=True))

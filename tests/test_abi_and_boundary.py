@@ -38,7 +38,7 @@ def test_header_and_library_agree(lib):
     assert sorted(_native.EXPORTS) == names, "python binding list and header drifted apart"
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 3
+    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 4
     m = re.search(r"#define\s+LSHRS_ABI_VERSION\s+(\d+)", open(HEADER).read())
     assert int(m.group(1)) == lib.lshrs_abi_version()
 
@@ -85,12 +85,15 @@ def test_pure_host_entry_points(lib):
     # block (x4); shapes wider than one 32-column tile also carry the fine (one tile per workgroup) image, and
     # shapes of >= 256 padded columns the bf16 hi/mid image of the split-precision pass in 16x16x32 fragment order
     # (same size again); every shape: + the plain row-major copy stage 2 reads (padded columns x dim rounded up to 32)
-    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (4 * 256 * 768 + 256 + 4 + 8) * 4
-    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (4 * 512 * 1536 + 512 + 4 + 16) * 4
+    # + the window block: three coefficients per padded column (at least 256), their maxima per column block (x4, three
+    # times) and per 32-column tile
+    assert lib.lshrs_sig_workspace_bytes(16, 16, 768) == (4 * 256 * 768 + 256 + 4 + 8 + 3 * 256 + 12 + 8) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (4 * 512 * 1536 + 512 + 4 + 16 + 3 * 512 + 12 + 16) * 4
     # exactly 128 padded columns: + the 16x16x32 fragment image zero-padded to 256 columns (256 x dim bf16 hi/mid
     # = 256 x dim floats' worth), its 256 norms and their maximum (x4)
-    assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (3 * 128 * 128 + 128 + 4 + 4 + 256 * 128 + 256 + 4) * 4
-    assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (2 * 32 * 32 + 32 + 4) * 4
+    assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (3 * 128 * 128 + 128 + 4 + 4 + 256 * 128 + 256 + 4 + 3 * 256 + 12 + 4) * 4
+    assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (2 * 32 * 32 + 32 + 4 + 3 * 256 + 12 + 4) * 4
+    assert lib.lshrs_sig_set_window(None, 16, 16, 768, None, None, None, None) == -10001
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device
     assert lib.lshrs_sig_hash_batch_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None, None) == -10001

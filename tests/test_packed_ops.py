@@ -198,3 +198,77 @@ def test_array_segments_are_compacted_and_stay_equal_to_the_tuple_store():
             want.setdefault(int(sgm.codes[g]), []).extend(sgm.members[sgm.offsets[g]:sgm.offsets[g + 1]].tolist())
     got = {int(merged.codes[g]): merged.members[merged.offsets[g]:merged.offsets[g + 1]].tolist() for g in range(len(merged))}
     assert got == want and merged.vectors == 200 and np.all(np.diff(merged.codes) > 0)
+
+
+def test_array_buckets_are_sets_like_the_references_redis_sets():
+    """an id indexed twice - in one batch, in two batches, or once as an op tuple and once in an array
+    segment - is in its bucket ONCE (SADD, lshrs/storage/redis.py:408-416), so a query counts it once per band
+    (lshrs/core/main.py:1101-1109).  The array-fed store against the tuple-fed one."""
+    from lshrs_amd.packed_ops import _csr_host, dedupe_csr, merge_csr
+    from lshrs_amd.storage import InMemoryStorage
+
+    rng = np.random.default_rng(11)
+    nb, bb = 4, 1
+    keys = rng.integers(0, 3, (12, nb, bb)).astype(np.uint8)
+    ids = np.array([5, 5, 7, 9, 9, 9, 1, 2, 3, 4, 6, 8], dtype=np.int64)
+    keys[1], keys[4], keys[5] = keys[0], keys[3], keys[3]                # a re-indexed id carries the same vector
+    tuple_store, array_store, mixed = InMemoryStorage(), InMemoryStorage(), InMemoryStorage()
+
+    def feed_tuples(store, id_arr, key_arr):
+        store.batch_add([(b, key_arr[i, b].tobytes(), int(id_arr[i])) for i in range(len(id_arr)) for b in range(nb)])
+
+    for rep in range(3):                                                 # ... and the whole batch three times over
+        feed_tuples(tuple_store, ids, keys)
+        array_store.batch_add_csr(_csr_host(ids, keys))                  # (the host builder: no GPU in this test)
+        (feed_tuples if rep == 1 else lambda s, i, k: s.batch_add_csr(_csr_host(i, k)))(mixed, ids, keys)
+    assert array_store.bucket_contents() == tuple_store.bucket_contents() == mixed.bucket_contents()
+    for store in (array_store, mixed):
+        for seg in store._segments:
+            assert seg.distinct
+            for g in range(len(seg)):
+                mem = seg.members[seg.offsets[g]:seg.offsets[g + 1]]
+                assert len(set(mem.tolist())) == len(mem)
+    q = keys[[0, 3, 6, 7]]
+    want_q, want_m = tuple_store.get_buckets_many(q)
+    want = sorted(zip(want_q.tolist(), want_m.tolist()))
+    for store in (array_store, mixed):
+        gq, gm = store.get_buckets_many(q)
+        assert sorted(zip(gq.tolist(), gm.tolist())) == want
+        # every (query, member) pair at most once per band: never more than nb times in all
+        pairs, counts = np.unique(np.stack([gq, gm], axis=1), axis=0, return_counts=True)
+        assert counts.max() <= nb
+    # folding the segments keeps the sets
+    merged = merge_csr(list(array_store._segments))
+    assert merged.distinct and int(np.diff(merged.offsets).sum()) == sum(len(v) for v in tuple_store.bucket_contents().values())
+    assert dedupe_csr(merged) is merged
+
+
+def test_reindexed_ids_rank_like_the_tuple_fed_store():
+    """The ordered candidates of a query (collision count, then id: lshrs/core/main.py:614) with ids indexed several
+    times: array-fed == tuple-fed, and no candidate is lost (the packed sort key of `_ordered_candidates_arrays` went
+    negative when a count exceeded num_bands)."""
+    from lshrs_amd.core import LSHRS
+    from lshrs_amd.packed_ops import _csr_host
+    from lshrs_amd.storage import InMemoryStorage
+
+    rng = np.random.default_rng(12)
+    nb, bb = 4, 1
+    keys = rng.integers(0, 2, (3, nb, bb)).astype(np.uint8)
+    ids = np.array([10, 11, 12], dtype=np.int64)
+    a, t = InMemoryStorage(), InMemoryStorage()
+    for _ in range(3):
+        a.batch_add_csr(_csr_host(ids, keys))
+        t.batch_add([(b, keys[i, b].tobytes(), int(ids[i])) for i in range(3) for b in range(nb)])
+    one = _csr_host(np.array([5, 5, 7], dtype=np.int64), keys)           # an id twice inside one batch
+    from lshrs_amd.packed_ops import dedupe_csr
+    a.batch_add_csr(one)
+    t.batch_add([(b, keys[i, b].tobytes(), int(v)) for i, v in enumerate((5, 5, 7)) for b in range(nb)])
+
+    class _Shell(LSHRS):                                                  # only the candidate ordering is under test
+        def __init__(self, storage):
+            self._storage = storage
+
+    got = _Shell(a)._ordered_candidates_many(keys[:2])
+    want = _Shell(t)._ordered_candidates_many(keys[:2])
+    assert got == want and all(len(g) > 0 for g in got)
+    assert {10, 5} <= set(got[0])

@@ -119,4 +119,13 @@ def test_pickle_carries_device_windows_and_ingest_mode_and_defers_the_storage():
     del state["lshrs_amd"]
     plain = LSHRS.__new__(LSHRS)
     plain.__setstate__(state)
-    assert plain._packed_ingest is False and plain._hasher.window_mode["tau1"] == "measured"
+    assert plain._packed_ingest is False and plain._hasher.window_mode["tau1"] == "bound"       # (the default: the proven window)
+    # a storage proxy whose __init__ has not run (copy / pickle build instances that way) must not recurse
+    import copy
+
+    from lshrs_amd.core import _DeferredStorage
+
+    bare = _DeferredStorage.__new__(_DeferredStorage)
+    with pytest.raises(AttributeError):
+        bare._real
+    assert copy.copy(clone._storage)._cfg == clone._storage._cfg

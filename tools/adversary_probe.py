@@ -15,7 +15,8 @@ from tests._adversary import adversarial_row, describe  # noqa: E402
 
 def main():
     dim = int(sys.argv[1]) if len(sys.argv) > 1 else 768
-    modes = [("default", {}), ("window64", {"tau1_ulps": 64.0 * (768.0 / dim) ** 0.5}), ("bound", {"tau1_ulps": "bound"})]
+    modes = [("default (proven window)", {}), ("window64, no guard", {"tau1_ulps": 64.0 * (768.0 / dim) ** 0.5, "margin_guard": 0.0}),
+             ("window64 + guard", {"tau1_ulps": 64.0 * (768.0 / dim) ** 0.5})]
     for name, kw in modes:
         h = LSHHasher(16, 16, dim, seed=42, **kw)
         rng = np.random.default_rng(3)
