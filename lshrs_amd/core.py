@@ -136,6 +136,7 @@ class LSHRS:
         hasher: Any = None,
         device: Any = None,
         packed_ingest: bool = False,
+        devices: Optional[Sequence[int]] = None,
     ) -> None:
         if dim <= 0:
             raise ValueError("Vector dimensionality must be greater than zero")
@@ -159,7 +160,7 @@ class LSHRS:
         self._vector_fetch_fn = vector_fetch_fn
         self._packed_ingest = bool(packed_ingest)
         self._hasher = hasher if hasher is not None else LSHHasher(
-            num_bands=num_bands, rows_per_band=rows_per_band, dim=dim, seed=seed, device=device)
+            num_bands=num_bands, rows_per_band=rows_per_band, dim=dim, seed=seed, device=device, devices=devices)
         self._storage = storage if storage is not None else default_storage(
             host=redis_host, port=redis_port, db=redis_db, password=redis_password,
             decode_responses=decode_responses, prefix=redis_prefix, max_connections=redis_max_connections)
@@ -483,8 +484,9 @@ class LSHRS:
         state["lshrs_amd"] = {
             "packed_ingest": self._packed_ingest,
             "device": getattr(h, "_device", None) if isinstance(getattr(h, "_device", None), (int, str, type(None))) else str(h._device),
-            "hasher_kwargs": {k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard", "pipeline",
-                                                          "tie_threads", "audit_every") if hasattr(h, k)},
+            "hasher_kwargs": {**{k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard", "pipeline",
+                                                            "tie_threads", "audit_every") if hasattr(h, k)},
+                              **({"devices": list(h._devices)} if getattr(h, "_devices", None) else {})},
             "windows": {"tau_ulps": "bound" if getattr(h, "window_mode", {}).get("tau") == "bound" else getattr(h, "tau_ulps", 8.0),
                         "tau1_ulps": "bound" if getattr(h, "window_mode", {}).get("tau1") == "bound" else getattr(h, "tau1_ulps", 64.0)},
         }

@@ -1216,7 +1216,9 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
       mid[rt].p[pr] = bf16x2{(__bf16)r0, (__bf16)r1};
     } else {
       ss[rt] = __builtin_amdgcn_fdot2_f32_bf16(hi[rt].p[pr], hi[rt].p[pr], ss[rt], false);
+#ifndef LSHRS_AB_NO_XMID_NORM          // (A/B builds only, tools/ab_build.py: what ||x_mid||^2 costs stage 1; keys are wrong without it)
       sm[rt] = __builtin_amdgcn_fdot2_f32_bf16(mid[rt].p[pr], mid[rt].p[pr], sm[rt], false);
+#endif
       asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax[rt]) : "v"(v0), "v"(v1));
     }
   };

@@ -23,7 +23,7 @@ import math
 import os
 import threading
 import time
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -292,12 +292,15 @@ class LSHHasher:
                   library's driver; "python": one pass, then NumPy (the round-1 interpreter-driven chunking is gone)
       tie_replay  "auto" (default): batches that take the split pass break their ties on the device (stage 2 replays
                   the host BLAS's summation order, recognised and verified at first use); "off": host engine only
+      devices     in-process multi-device ingestion: host batches of >= 32 768 rows per device are cut into one row slice
+                  per entry, hashed concurrently (one thread + hasher per entry), keys returned in row order
     """
 
     def __init__(self, num_bands: int, rows_per_band: int, dim: int, seed: int = 42, *, device=None,
                  tie_break: str = "host", tau_ulps=None, precision: str = "bf16x3",
                  tau1_ulps=None, tie_threads: Optional[int] = None, pipeline: str = "native",
-                 tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64) -> None:
+                 tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64,
+                 devices: Optional[Sequence[int]] = None) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -313,6 +316,23 @@ class LSHHasher:
         self.rows_per_band = int(rows_per_band)
         self.dim = int(dim)
         self.tie_break = tie_break
+        # In-process multi-device ingestion: host batches handed to `hash_batch_packed` are cut into one
+        # contiguous row slice per entry of `devices`, each slice hashed by a worker thread through a hasher of its own
+        # (own device, streams, scratch; the same hyperplanes), the keys land in one array in the original row order.  No
+        # collective, nothing shared but the read-only hyperplanes.  An index may appear twice ([0, 0]: two slices in
+        # flight on one device).  Everything else - device tensors, single vectors - runs on devices[0].
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None and (len(self._devices) == 0 or any(d < 0 for d in self._devices)):
+            raise ValueError("devices must be a non-empty sequence of device indices")
+        if self._devices is not None and device is None:
+            device = self._devices[0]
+        self._ctor_kwargs = dict(tie_break=tie_break, tau_ulps=tau_ulps, precision=precision, tau1_ulps=tau1_ulps,
+                                 tie_threads=tie_threads, pipeline=pipeline, tie_replay=tie_replay, margin_guard=margin_guard,
+                                 audit_every=audit_every)
+        self._seed = seed
+        self._children: Optional[list] = None
+        self._pool = None
+        self.multi_device_min_rows = 32_768      # per slice: below this a batch stays on devices[0]
         for name, value in (("tau_ulps", tau_ulps), ("tau1_ulps", tau1_ulps)):
             if isinstance(value, str) and value != "bound":
                 raise ValueError(f"{name} must be a number, None or 'bound'")
@@ -1201,6 +1221,9 @@ class LSHHasher:
             arr = arr.copy()
         n = arr.shape[0]
         mode = self.tie_break if tie_break is None else tie_break
+        if (self._devices is not None and len(self._devices) > 1 and tie_break is None
+                and n >= self.multi_device_min_rows * len(self._devices)):
+            return self._hash_multi_device(arr, return_row_flags, chunk_rows, pin)
         dev = self._torch_device()
         with self._lock:
             streamed = (n >= 2 * 16_384 and mode == "host" and self.tie_replay == "auto"
@@ -1227,6 +1250,51 @@ class LSHHasher:
                     total[k] += self.last_stats.get(k, 0)
         self.last_stats = total
         return (keys, flags) if return_row_flags else keys
+
+    def _hash_multi_device(self, arr: np.ndarray, want_flags: bool, chunk_rows: int, pin: str):
+        """One contiguous row slice per entry of ``devices``, each through its own hasher on its own thread; keys (and
+        row flags) of all slices in one array, in the original row order (the caller enqueues storage operations from
+        it exactly as from a single-device result: lshrs/core/main.py:442-518 sees no difference)."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        torch = _native.require_gpu()
+        devs = self._devices
+        with self._lock:
+            if self._children is None:
+                self._children = [LSHHasher(self.num_bands, self.rows_per_band, self.dim, self._seed, device=d,
+                                            **self._ctor_kwargs) for d in devs]
+                self._child_version = [-1] * len(devs)
+                self._pool = ThreadPoolExecutor(max_workers=len(devs), thread_name_prefix="lshrs-dev")
+            for i, c in enumerate(self._children):        # the hyperplanes are the parent's (assignable: load_from_disk)
+                if self._child_version[i] != self._projection_version:
+                    c.projections = [np.asarray(p) for p in self._projections]
+                    self._child_version[i] = self._projection_version
+            n = arr.shape[0]
+            keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
+            flags = np.empty(n, dtype=np.uint8) if want_flags else None
+            per = -(-n // len(devs))
+            per = -(-per // 256) * 256                        # whole 256-row workgroup tiles per slice
+            spans = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
+
+            def work(i):
+                lo, hi = spans[i]
+                child = self._children[i]
+                with torch.cuda.device(devs[i]):
+                    got = child.hash_batch_packed(arr[lo:hi], return_row_flags=want_flags, chunk_rows=chunk_rows, pin=pin)
+                if want_flags:
+                    keys[lo:hi], flags[lo:hi] = got
+                else:
+                    keys[lo:hi] = got
+                return dict(child.last_stats)
+
+            stats = [f.result() for f in [self._pool.submit(work, i) for i in range(len(spans))]]
+            total = {"n": n, "devices": [devs[i] for i in range(len(spans))], "per_device": stats}
+            for k in ("tie_entries", "tie_pairs", "relaunches", "flagged", "margin_escalations"):
+                total[k] = sum(int(st.get(k, 0)) for st in stats)
+            total["max_dev_units"] = max(float(st.get("max_dev_units", 0.0)) for st in stats)
+            total["tie_break_engine"] = stats[0].get("tie_break_engine")
+            self.last_stats = total
+        return (keys, flags) if want_flags else keys
 
     _small_rows = 128                 # batches up to this many host rows take the one-launch path below
     _small_poll_bytes = 128           # ... up to this many KEY BYTES (= workgroups) return through the polled epoch word
@@ -1516,6 +1584,12 @@ class LSHHasher:
     # ------------------------------------------------------------------ pickling: host state only
     def close(self) -> None:
         """Release the native pipeline objects (device scratch, pinned host buffers, side stream)."""
+        pool, self._pool = getattr(self, "_pool", None), None
+        if pool is not None:
+            pool.shutdown(wait=False)
+        for child in getattr(self, "_children", None) or ():
+            child.close()
+        self._children = None
         pipes, self._pipes = getattr(self, "_pipes", {}), {}
         if pipes:
             try:
@@ -1538,6 +1612,8 @@ class LSHHasher:
         state["_one_queue"] = []
         state["_one_leader"] = False
         state["_workspaces"] = {}
+        state["_children"] = None
+        state["_pool"] = None
         state["_window_set"] = {}
         state["_pinned_cache"] = {}
         state["_small_epoch"] = 0
@@ -1577,6 +1653,12 @@ class LSHHasher:
         self.__dict__.setdefault("margin_escalations", 0)
         self.__dict__.setdefault("window_mode", {"tau": "measured", "tau1": "measured"})
         self.__dict__.setdefault("window_info", {})
+        self.__dict__.setdefault("_devices", None)
+        self.__dict__.setdefault("_children", None)
+        self.__dict__.setdefault("_pool", None)
+        self.__dict__.setdefault("_seed", 42)
+        self.__dict__.setdefault("_ctor_kwargs", {})
+        self.__dict__.setdefault("multi_device_min_rows", 32_768)
         self._window_set = {}
         self._lock = threading.Lock()
         self._one_lock = threading.Lock()

@@ -89,7 +89,8 @@ def test_c2_shape_64k_rows_bit_exact_with_ties_exercised(torch_mod):
     ref = hash_batch_literal_packed(h.projections, x)
     assert np.array_equal(keys, ref)
     assert stats["tie_pairs"] > 0, "tie window never hit: threshold or flagging broken"
-    assert stats["tie_pairs"] < 65536 * 16 * 1e-3
+    # (projections inside the PROVEN tie window of the f32 chain, ~500 units: 6e-4 of them; round 2's 8-unit window: 1e-5)
+    assert stats["tie_pairs"] < 65536 * 256 * 2e-3
     # and the raw kernel differs from the host BLAS in at most a handful of those places
     raw = h.hash_batch_packed(x, tie_break="none")
     differing = int((raw != ref).any(axis=2).sum())
