@@ -76,7 +76,8 @@ def window_coefficients(planes: np.ndarray, blas_model: int) -> Tuple[np.ndarray
     ``x_hi = bf16(x)``, ``x_mid = bf16(x - x_hi)`` (their norms are what ``sig16_kernel`` accumulates, from the values it
     feeds the matrix cores); ``y_target`` is what decides a flagged projection: the host BLAS's value as stage 2 replays
     it (``blas_model`` 1: eight interleaved fma chains + a three-level tree, `_hostblas.blas_order_model`) or, without a
-    recognised order (``blas_model`` 0: stage 2 evaluates the f32 chain and the host engine decides the ties), the chain.
+    recognised order (``blas_model`` 0: stage 2 evaluates the f32 chain and the host engine decides the ties), the host's
+    value by way of the chain (both distances: whatever stage 1 does not flag must have the HOST's sign).
     Every term is an elementwise error bound summed by Cauchy-Schwarz against a per-hyperplane constant:
 
     * the products the bf16x3 split drops: ``x p - (x_hi p_hi + x_hi p_mid + x_mid p_hi) = x_mid p_mid + (x_hi + x_mid) e_p
@@ -114,12 +115,14 @@ def window_coefficients(planes: np.ndarray, blas_model: int) -> Tuple[np.ndarray
         m_host = np.where(k < dim, dim // 8 - k // 8 + 3, 0).astype(np.float64)
     else:
         m_host = np.where(k < dim, dim + 1, 0).astype(np.float64)
-    m_target = m_host if blas_model == 1 else m_chain
+    # what stage 1's value is measured against is what finally DECIDES a projection it does not flag: the replayed BLAS
+    # value (model 1), or - stage 2 evaluating the chain and the host engine deciding the ties - the host's value by way of
+    # the chain (model 0: both distances; the stage-1 window then contains the tie window, as it must)
     a_mfma = u * R * (norm(ph * n0) + norm(pm * n1)) + 8.0 * u * (norm(ph) + norm(pm))
     b_mfma = u * R * norm(ph * n2) + 8.0 * u * norm(ph)
     a_cross = norm(ep)
     b_cross = norm(pm) + norm(ep) + 2.0 ** -8 * norm(p)
-    a_tgt = u * norm(p * m_target)
+    a_tgt = u * norm(p * m_host) if blas_model == 1 else u * (norm(p * m_chain) + norm(p * m_host))
     slack = 1.0 + 1e-3 + 4.0 * K * u                    # second-order terms ((1+u)^m - 1 vs m u, errors of errors)
     coef_a = (a_mfma + a_cross + a_tgt) * slack
     coef_b = (b_mfma + b_cross + (1.0 + 2.0 ** -8) * a_tgt) * slack

@@ -1,0 +1,55 @@
+"""`python bench.py --gpus N` must launch its own rank processes: the driver invokes bench.py as a plain
+script; with N > 1 and no launcher around it the script starts N fresh rank processes itself, before importing torch or
+touching a GPU, relays rank 0's one JSON line and fails when a rank fails.  CPU only (`--dry-run`: rendezvous + one gloo
+barrier, no GPU work)."""
+
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_self_launch_two_ranks_one_json_line():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300,
+                         env=_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout                      # ONE line on stdout, whatever gloo prints (it goes to stderr)
+    assert json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "self_launched": True}
+
+
+def test_launcher_form_still_works():
+    """The driver's multi-GPU form: torch.distributed.run around the same script (ranks do not self-launch again)."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29713", BENCH, "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "self_launched": False}
+
+
+def test_a_failing_rank_fails_the_launch_quickly():
+    """No GPU in the build container: every rank dies at `torch.cuda.set_device`; the parent must notice, stop the others
+    and exit non-zero instead of waiting at a rendezvous.  (On a GPU box the two ranks would run: skipped there.)"""
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("needs a box without a GPU")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--steps", "1", "--no-extras"],
+                         capture_output=True, text=True, timeout=300, env=_env())
+    assert out.returncode != 0 and out.stdout.strip() == "" and "rank exit codes" in out.stderr
+    assert time.time() - t0 < 120

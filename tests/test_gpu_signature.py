@@ -359,7 +359,10 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     torch = torch_mod
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
-    h = _hasher(42, 16, 16, 768, tie_replay="off")     # the host tie-break and its pipeline are what is tested here
+    # the host tie-break and its pipeline are what is tested here - with round 2's narrow (measured) windows, so that the
+    # chunks' lists are as short as the pipeline's capacities assume; the proven windows on this route: next test
+    MEASURED = dict(tau_ulps=8.0, tau1_ulps=64.0)
+    h = _hasher(42, 16, 16, 768, tie_replay="off", **MEASURED)
     gen = torch.Generator("cuda").manual_seed(77)
     x = torch.randn(300_000, 768, device="cuda", generator=gen)
     flags = torch.zeros(300_000, dtype=torch.uint8, device="cuda")
@@ -377,11 +380,11 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
     assert np.array_equal(piped[sl].cpu().numpy(), hash_batch_literal_packed(h.projections, x[sl].cpu().numpy()))
     # the same batch through the f32 kernel (the default took the split-precision pass), and with the NumPy-only tie-break
     assert h._split_applies(131_072)
-    hs = _hasher(42, 16, 16, 768, precision="f32", tie_replay="off")
+    hs = _hasher(42, 16, 16, 768, precision="f32", tie_replay="off", **MEASURED)
     hs.pipeline_chunk_rows = 131_072
     assert torch.equal(hs.hash_device(x), piped)
     assert hs.last_stats["tie_pairs"] == stats["tie_pairs"]
-    h1 = _hasher(42, 16, 16, 768, tie_threads=1, tie_replay="off")
+    h1 = _hasher(42, 16, 16, 768, tie_threads=1, tie_replay="off", **MEASURED)
     h1.pipeline_chunk_rows = 131_072
     assert torch.equal(h1.hash_device(x), piped)
     assert h1.last_stats["tie_pairs"] == stats["tie_pairs"]
@@ -391,7 +394,7 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
 
     if _hostblas.engine() is not None:
         assert stats.get("pipeline") == "native"
-        hp = _hasher(42, 16, 16, 768, pipeline="python", tie_replay="off")
+        hp = _hasher(42, 16, 16, 768, pipeline="python", tie_replay="off", **MEASURED)
         hp.pipeline_chunk_rows = 131_072
         assert torch.equal(hp.hash_device(x), piped)
         assert hp.last_stats.get("pipeline") != "native" and hp.last_stats["tie_pairs"] == stats["tie_pairs"]
@@ -410,6 +413,33 @@ def test_pipelined_path_equals_plain_path_and_oracle(torch_mod):
         assert hd.last_stats.get("tie_break_engine") == hf.last_stats.get("tie_break_engine") == "device-replay"
 
 
+def test_host_engine_route_with_the_proven_windows(torch_mod):
+    """A host whose BLAS order the replay does not know (tie_replay="off" stands in for it) with the DEFAULT windows: stage 1
+    flags everything within its proven distance from the host's value by way of the chain, stage 2 evaluates the chain, the
+    projections inside the proven tie window go to the host engine (the library's own sgemv).  Slower than the measured
+    windows - thousands of pairs per thousand rows - and byte-identical to the reference by construction; adversarial rows
+    included."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+    from tests._adversary import adversarial_row
+
+    h = _hasher(42, 16, 16, 768, tie_replay="off")
+    assert h.window_mode == {"tau": "bound", "tau1": "bound"}
+    x = np.random.default_rng(21).standard_normal((140_000, 768)).astype(np.float32)
+    for i in range(32):
+        x[1_000 + 4_000 * i] = adversarial_row(h.projections[i % 16][(5 * i) % 16], 20.0 if i % 2 else -20.0, seed=i)
+    got = h.hash_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    st = dict(h.last_stats)
+    assert st.get("tie_break_engine") != "device-replay" and st["tie_pairs"] > 10_000
+    for lo in (0, 64_000, 128_000):
+        assert np.array_equal(got[lo:lo + 6_000], hash_batch_literal_packed(h.projections, x[lo:lo + 6_000]))
+    rows = [1_000 + 4_000 * i for i in range(32)]
+    assert np.array_equal(got[rows], hash_batch_literal_packed(h.projections, x[rows]))
+    assert h.window_info["window_units"] > 1_000                    # (chain + any-order host term: ~1 580 units at 768-d)
+    small = h.hash_device(torch.from_numpy(x[:300]).cuda()).cpu().numpy()      # the f32 kernel + host engine, proven tie window
+    assert np.array_equal(small, got[:300])
+
+
 def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     """The library-driven pipeline on an unaligned view (f32 kernel, scalar export), on a batch with a one-row last
     chunk, and with a tie list too small for a chunk (that chunk is redone with room): always the plain path's bytes."""
@@ -420,7 +450,8 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
         pytest.skip("host tie-break engine unavailable on this box")
     gen = torch.Generator("cuda").manual_seed(78)
     # (a) 140 001 rows of a 100-d view with an odd row stride: f32 kernel, scalar loads, chunks of 65 536 + 8 929 + 65 536
-    h = _hasher(5, 8, 12, 100)
+    MEASURED = dict(tau_ulps=8.0, tau1_ulps=64.0)      # (the pipeline's mechanics, at the list lengths its capacities assume)
+    h = _hasher(5, 8, 12, 100, **MEASURED)
     big = torch.randn(140_001, 103, device="cuda", generator=gen)
     x = big[:, 1:101]
     h.kernel_events = []                                   # times of the f32 kernel's launches come back too
@@ -431,7 +462,7 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     h.pipeline_chunk_rows = 10**9
     assert torch.equal(got, h.hash_device(x))
     # (b) one row more than two chunks
-    h2 = _hasher(42, 16, 16, 768, tie_replay="off")
+    h2 = _hasher(42, 16, 16, 768, tie_replay="off", **MEASURED)
     h2.pipeline_chunk_rows = 65_536
     x2 = torch.randn(131_073, 768, device="cuda", generator=gen)
     got2 = h2.hash_device(x2)
@@ -440,7 +471,7 @@ def test_native_pipeline_odd_shapes_and_overflow(torch_mod):
     assert torch.equal(got2, h2.hash_device(x2))
     # (b') a first chunk with far more ties than the speculative device->host copy expects (1 % of its rows lie in
     # the null space of three hyperplanes): the host tops the copy up
-    h4 = _hasher(42, 16, 16, 768, tie_replay="off")
+    h4 = _hasher(42, 16, 16, 768, tie_replay="off", **MEASURED)
     x4 = torch.randn(140_000, 768, device="cuda", generator=gen)
     pl = np.concatenate([np.asarray(p, dtype=np.float64) for p in h4.projections])[[3, 100, 200]]
     special = np.arange(0, 65_536, 100)
@@ -852,7 +883,7 @@ def _stage1_values(torch, h, x):
     return y
 
 
-@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (7, 16, 32, 1536), (3, 8, 16, 256)])
+@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (7, 16, 32, 1536), (3, 16, 16, 256)])
 def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     """Stage 1 of the split pass, projection by projection, against oracle/mfma_model.c's accumulator: the bf16 split of
     x and p (round to nearest even, exact residual), per 32-deep k-tile the three instructions xh*ph, xh*pm, xm*ph in

@@ -31,9 +31,14 @@ def test_default_path_equals_plain_f32_path_on_random_batches(torch_mod):
         n = int((int(rng.integers(1, 5000)), int(rng.integers(60_000, 300_000)), int(rng.integers(300_000, 1_500_000)))[it % 3])
         n = min(n, 900_000_000 // dim)
         if (nb, r, dim) not in hashers:
-            plain = LSHHasher(nb, r, dim, seed=11, precision="f32", tie_replay="off")
+            # the two host-route hashers with round 2's measured windows (the mechanics under test: chunking, overlap, lists;
+            # the proven windows on that route: tests/test_gpu_signature.py::test_host_engine_route_with_the_proven_windows);
+            # `fast` is the default hasher: proven windows, ties replayed on the device
+            measured = dict(tau_ulps=8.0, tau1_ulps=64.0)
+            plain = LSHHasher(nb, r, dim, seed=11, precision="f32", tie_replay="off", **measured)
             plain.pipeline_chunk_rows = 10**9
-            hashers[(nb, r, dim)] = (LSHHasher(nb, r, dim, seed=11), plain, LSHHasher(nb, r, dim, seed=11, tie_replay="off"))
+            hashers[(nb, r, dim)] = (LSHHasher(nb, r, dim, seed=11), plain,
+                                     LSHHasher(nb, r, dim, seed=11, tie_replay="off", **measured))
         fast, plain, fast_host = hashers[(nb, r, dim)]
         x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(1000 + it))
         if n > 10:

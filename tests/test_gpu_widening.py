@@ -50,7 +50,7 @@ def test_parquet_file_to_buckets_through_the_hip_hasher(torch_mod, tmp_path, n, 
         if not packed and n > 10_000:
             continue                                          # (op tuples: 16 Python objects per vector - the small cases)
         idx = LSHRS(dim=dim, num_perm=num_perm, storage=InMemoryStorage(), packed_ingest=packed, buffer_size=4_000)
-        idx.create_signatures(format="parquet", path=path, batch_size=batch)
+        idx.create_signatures(format="parquet", source=path, batch_size=batch)
         idx.flush()
         want = InMemoryStorage()
         for bi, bv in iter_parquet_vectors_literal(path, batch_size=batch):

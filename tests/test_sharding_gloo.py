@@ -88,3 +88,64 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
     single_ops = [op for batch in single.batches for op in batch]
     sharded_ops = [op for _, _, ops in gathered for op in ops]
     assert sharded_ops == single_ops          # rank-major concatenation == original row order
+
+
+def _engine_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """Both ranks of a node build their host tie-break engine AT THE SAME TIME (LOCAL_WORLD_SIZE = 2 halves each one's
+    worker budget) and patch the same (row, band) pairs while the other does."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    os.environ.pop("LSHRS_TIE_THREADS", None)
+    import pickle
+
+    import torch.distributed as dist
+
+    from lshrs_amd import _hostblas
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        planes = rng.standard_normal((4, 16, 256)).astype(np.float32)
+        xs = rng.standard_normal((3_000, 256)).astype(np.float32)
+        rows = rng.integers(0, 3_000, 20_000).astype(np.int32)
+        bands = np.sort(rng.integers(0, 4, 20_000)).astype(np.int32)
+        dist.barrier()
+        eng = _hostblas.engine()
+        info = {"budget": _hostblas._core_budget(), "default_threads": _hostblas.default_threads(),
+                "threads": None if eng is None else eng.threads}
+        keys = None
+        if eng is not None:
+            assert eng.shape_trusted(planes)
+            dist.barrier()                                       # both engines exist: now both work at once
+            keys = eng.patch(planes, xs, rows, bands)
+        want = np.stack([np.packbits((planes[b] @ xs[r]) > 0, bitorder="little") for r, b in zip(rows, bands)])
+        info["equal_numpy"] = None if keys is None else bool(np.array_equal(keys, want))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (info, None if keys is None else keys.tobytes()))
+        if rank == 0:
+            pickle.dump(gathered, open(os.path.join(out_dir, "engines.pkl"), "wb"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_run_their_host_engines_side_by_side(tmp_path):
+    """a deployment whose BLAS the replay does not know runs the host engine on every rank; the ranks
+    of a node divide the core budget (`_hostblas.default_threads`, LOCAL_WORLD_SIZE) - here two gloo ranks build their
+    engines under that division and patch the same pairs concurrently: same bytes on both, equal to NumPy's
+    `P_band @ x` (the reference's call, lshrs/hash/lsh.py:200)."""
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_engine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    (i0, k0), (i1, k1) = pickle.load(open(tmp_path / "engines.pkl", "rb"))
+    assert i0["budget"] == i1["budget"] and i0["default_threads"] == i1["default_threads"]
+    assert i0["default_threads"] == max(1, min(8, i0["budget"] // 2 // 2))          # halved by LOCAL_WORLD_SIZE = 2
+    if i0["threads"] is None:
+        pytest.skip(f"no engine on this host (budget {i0['budget']} cores over 2 ranks: NumPy's own call is used)")
+    assert i0["threads"] == i1["threads"] == i0["default_threads"]
+    assert i0["equal_numpy"] and i1["equal_numpy"] and k0 == k1

@@ -25,6 +25,10 @@ FAMILIES = [
     ("four_c", 4, 6, "wide"), ("eight_0", 8, 6, "zero"), ("eight_c", 8, 6, "wide"), ("eight_n", 8, 0, "narrow"),
     ("g2_c", 16, 6, "wide"), ("full_n", 32, 0, "narrow"), ("full_w", 32, 6, "wide"), ("full_big_c", 32, 2, "big"),
     ("full_chain", 32, 1, "chain"),
+    # accumulators next to a power of two, products sized to carry the sum across it (either way): the cancellation /
+    # carry cases in which the adder's width below the accumulator's last place shows
+    ("cross_dn_1", 1, 0, "cross_dn"), ("cross_dn_8", 8, 2, "cross_dn"), ("cross_up_1", 1, 0, "cross_up"),
+    ("cross_up_8", 8, 2, "cross_up"), ("cross_dn_full", 32, 2, "cross_dn"), ("cancel_deep", 8, 1, "cancel_deep"),
 ]
 CASES_PER_FAMILY = 40_000
 
@@ -41,6 +45,23 @@ def family(name, kind, seed=0):
     b = quant(rng.standard_normal((n, 32)) * 2.0 ** eb, kind)
     a[:, m:] = 0.0
     b[:, m:] = 0.0
+    if ckind in ("cross_dn", "cross_up", "cancel_deep"):
+        e = rng.integers(-4, 13, n).astype(np.float64)
+        d = rng.integers(3, 15, n).astype(np.float64)             # the products sit 2^-d below the accumulator
+        sc = 2.0 ** np.floor((e - d) / 2.0)
+        a = quant(a * sc[:, None], kind)
+        b = quant(b * (2.0 ** (e - d) / sc)[:, None], kind)
+        a[:, m:] = 0.0
+        b[:, m:] = 0.0
+        sgn = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+        if ckind == "cross_dn":                                   # just above 2^e: a negative product sum drops a binade
+            c = sgn * 2.0 ** e * (1.0 + rng.random(n) * 2.0 ** -(d - 1))
+        elif ckind == "cross_up":                                 # just below 2^(e+1)
+            c = sgn * 2.0 ** e * (2.0 - rng.random(n) * 2.0 ** -(d - 1))
+        else:                                                     # the product sum nearly cancels the accumulator
+            s8 = (a * b).sum(axis=1)
+            c = -s8 * (1.0 + rng.standard_normal(n) * 2.0 ** -rng.integers(2, 12, n))
+        return a, b, c.astype(np.float32)
     if ckind == "zero":
         c = np.zeros(n)
     elif ckind == "wide":

@@ -14,12 +14,13 @@ import mfma_cases as mc  # noqa: E402
 
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/mfma_probe2.npz"
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     lib = ctypes.CDLL(os.path.join(HERE, "mfma_probe.so"))
     lib.mfma_probe_run.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int]
     res = {}
     for kind, fmt in ((0, "f16"), (1, "bf16")):
         for fam in mc.FAMILIES:
-            a, b, c = mc.family(fam[0], kind)
+            a, b, c = mc.family(fam[0], kind, seed=seed)
             A, B = np.ascontiguousarray(mc.to_bits(a, kind)), np.ascontiguousarray(mc.to_bits(b, kind))
             D = np.zeros(len(c), dtype=np.float32)
             rc = lib.mfma_probe_run(A.ctypes.data, B.ctypes.data, c.ctypes.data, D.ctypes.data, len(c), kind)
