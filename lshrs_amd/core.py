@@ -484,7 +484,7 @@ class LSHRS:
         state["lshrs_amd"] = {
             "packed_ingest": self._packed_ingest,
             "device": getattr(h, "_device", None) if isinstance(getattr(h, "_device", None), (int, str, type(None))) else str(h._device),
-            "hasher_kwargs": {**{k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard", "pipeline",
+            "hasher_kwargs": {**{k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard",
                                                             "tie_threads", "audit_every") if hasattr(h, k)},
                               **({"devices": list(h._devices)} if getattr(h, "_devices", None) else {})},
             "windows": {"tau_ulps": "bound" if getattr(h, "window_mode", {}).get("tau") == "bound" else getattr(h, "tau_ulps", 8.0),
@@ -498,6 +498,7 @@ class LSHRS:
         hasher = None
         if extra:
             hk = dict(extra.get("hasher_kwargs", {}))
+            hk.pop("pipeline", None)               # (an option of earlier rounds: the interpreter-driven chunking is gone)
             hk.update(extra.get("windows", {}))
             hasher = LSHHasher(num_bands=cfg["num_bands"], rows_per_band=cfg["rows_per_band"], dim=cfg["dim"],
                                seed=cfg["seed"], device=extra.get("device"), **hk)

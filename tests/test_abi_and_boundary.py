@@ -191,3 +191,34 @@ def test_window_escalation_policy():
         w, mode = escalated_window(w, 0.51 * w, 768)
         steps += 1
     assert steps <= 6 and w >= bound_tau1_ulps(768)
+
+
+def test_route_table():
+    """One row per route of `LSHHasher._route` - the single place that decides how a device batch is hashed (VERDICT r2
+    item 8: the former `if` ladder).  Pure host logic: no GPU."""
+    from lshrs_amd import LSHHasher, _hostblas
+
+    names = [r[0] for r in LSHHasher.ROUTES]
+    assert names == ["raw", "split+replay", "f32+replay", "host-engine pipelined", "plain"]
+    h = LSHHasher(16, 16, 768, seed=42)
+    ok = dict(aligned=True, short_stride=True, host_rows=False)
+    assert h._route(10_000, "none", **ok) == ("raw", 0)
+    licensed = bool(h._replay_model())
+    if licensed:                                   # this host's BLAS order is one the replay knows
+        assert h._route(1_000_000, "host", **ok) == ("split+replay", 1)
+        assert h._route(256, "host", **ok) == ("split+replay", 1)
+        assert h._route(255, "host", **ok) == ("f32+replay", 1)                      # below replay_min_rows
+        assert h._route(1_000_000, "host", aligned=True, short_stride=False, host_rows=False) == ("f32+replay", 1)
+        assert LSHHasher(16, 4, 128, seed=1)._route(1_000_000, "host", **ok) == ("f32+replay", 1)   # 128 key columns, short rows
+        assert LSHHasher(5, 12, 64, seed=1)._route(5_000, "host", **ok) == ("plain", 0)             # 10 key bytes: not whole words
+        assert LSHHasher(16, 16, 100, seed=1)._route(5_000, "host", **ok) == ("plain", 0)           # dim % 32 != 0
+    off = LSHHasher(16, 16, 768, seed=42, tie_replay="off")
+    big = off._route(1_000_000, "host", **ok)
+    assert big == (("host-engine pipelined", 0) if off._tie_engine() is not None else ("plain", 0))
+    assert off._route(1_000_000, "host", aligned=True, short_stride=True, host_rows=True) == ("plain", 0)
+    assert off._route(100_000, "host", **ok) == ("plain", 0)
+    assert off._route(1_000_000, "host", allow_pipeline=False, **ok) == ("plain", 0)
+    unaligned = h._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False)
+    assert unaligned[0] in ("host-engine pipelined", "plain") and unaligned[1] == 0
+    with pytest.raises(TypeError):
+        LSHHasher(16, 16, 768, pipeline="python")  # (the interpreter-driven route of rounds 1-2 is gone)

@@ -74,9 +74,9 @@ def test_shapes_the_model_does_not_cover_are_refused():
 def test_hasher_pickles_with_and_without_the_newer_fields():
     import pickle
 
-    h = LSHHasher(8, 16, 768, seed=3, tie_replay="off", pipeline="python")
+    h = LSHHasher(8, 16, 768, seed=3, tie_replay="off")
     g = pickle.loads(pickle.dumps(h))
-    assert (g.tie_replay, g.pipeline, g.pipeline_pair_head, g.replay_min_rows) == ("off", "python", True, 256)
+    assert (g.tie_replay, g.pipeline_pair_head, g.replay_min_rows) == ("off", True, 256)
     assert np.array_equal(g.projections[0], h.projections[0]) and g._replay_scratch == {} and g._async_pending == []
     state = h.__getstate__()                  # a pickle written before these knobs existed
     for k in ("tie_replay", "_replay_scratch", "_async_pending", "_replay_events", "_plan_cache", "pipeline", "_pipes",
@@ -84,5 +84,5 @@ def test_hasher_pickles_with_and_without_the_newer_fields():
         state.pop(k, None)
     old = LSHHasher.__new__(LSHHasher)
     old.__setstate__(state)
-    assert (old.tie_replay, old.pipeline, old.pipeline_pair_head, old.replay_min_rows) == ("auto", "native", True, 256)
+    assert (old.tie_replay, old.pipeline_pair_head, old.replay_min_rows) == ("auto", True, 256)
     assert old._replay_model() in (0, 1) and old._plan_cache == {}
