@@ -62,7 +62,7 @@ typedef struct lshrs_sig_opts {
  *   [3] flagged projections whose key bit stage 2 had to change
  *   [4..7] reserved (0) */
 #define LSHRS_SIG_COUNTERS 8
-#define LSHRS_SIG_DEVICE_COUNTERS (LSHRS_SIG_COUNTERS + 3 * 1536)
+#define LSHRS_SIG_DEVICE_COUNTERS (LSHRS_SIG_COUNTERS + 3 * 4096)
 
 /* ------------------------------------------------------------------------------------------
  * Signature pass — replaces LSHHasher.hash_vector / hash_batch / _project_and_pack

@@ -603,9 +603,16 @@ __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f3
 // from ds_read_b128s that hit eight distinct 16-byte slots (the eight lanes sharing a g read the same slot: broadcast).
 // 1/8 of the waves, the same chain length per wave: one resident round of 1536 waves covers even a 524 288-row chunk's list.
 constexpr int kFixG = 8;
-constexpr int kFixSlabG = 6;       // k-tiles per slab; two slabs are resident (one being read, one landing): 2 x 2 x 6 x 8 chunks x 8
+#ifndef LSHRS_FIX_SLAB
+#define LSHRS_FIX_SLAB 6
+#endif
+#ifndef LSHRS_FIX_GRID
+#define LSHRS_FIX_GRID 1536
+#endif
+constexpr int kFixSlabG = LSHRS_FIX_SLAB;       // k-tiles per slab; two slabs are resident (one being read, one landing): 2 x 2 x 6 x 8 chunks x 8
                                    // projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is four slabs)
-constexpr int kFixGridG = 1536;    // 256 CUs x 6 resident single-wave workgroups
+constexpr int kFixGridG = LSHRS_FIX_GRID;    // 256 CUs x 6 resident single-wave workgroups
+static_assert(LSHRS_SIG_COUNTERS + 3 * kFixGridG <= LSHRS_SIG_DEVICE_COUNTERS, "stage 2's per-workgroup slots must fit the counter block");
 //
 // REPLAY: the tie-break on the device.  Every flagged projection gets the sign of the value the HOST BLAS computes for
 // it - the reference's `projection @ vector` (lshrs/hash/lsh.py:200) - and only that value is computed, by replaying
@@ -1390,6 +1397,12 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   // projections are re-evaluated (NOT(|y| > +inf) holds for every y).  A true zero row gives y = 0 in both passes.
   float* wnd_lds = lds + kRingFloats + wave * kWaveRows;
   float* wnb_lds = lds + kRingFloats + 256 + wave * kWaveRows;
+  // the window coefficients of this column block, staged once (behind the list stage, which owns the first 3 x kS1ListCap
+  // floats of the ring): with the proven window the exact test below runs on a third of the 32-column words, and a
+  // global load in front of each of its compares is latency two waves per SIMD cannot hide
+  float* coef_lds = lds + 3 * kS1ListCap;
+  static_assert(3 * kS1ListCap + 512 <= kRingFloats, "coefficients behind the list stage");
+  coef_lds[tid] = tid < 256 ? args.wa[cb * 256 + tid] : args.wb[cb * 256 + tid - 256];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     float s2 = ss[rt] + __shfl_xor(ss[rt], 16);
@@ -1452,7 +1465,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int ct = 2 * w + half;
-            const float pa = args.wa[cb * 256 + 16 * ct + r16e], pb = args.wb[cb * 256 + 16 * ct + r16e];
+            const float pa = coef_lds[16 * ct + r16e], pb = coef_lds[256 + 16 * ct + r16e];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
               float thr = wnd[reg] * pa + wnb[reg] * pb;

@@ -75,6 +75,33 @@ def adversarial_row(p: np.ndarray, target_units: float = 20.0, seed: int = 0) ->
     return x
 
 
+def tent_row(p: np.ndarray, target_units: float = 5.0, seed: int = 0) -> np.ndarray:
+    """A row whose partial sums against ``p`` climb over the first half of k (every product positive) and come back down
+    over the second (every product negative) to ``target_units`` of 2^-24 ||x|| ||p||: the accumulator is as large as a
+    near-zero projection allows for as many steps as possible - the case the two-sided charge of the matrix instruction's
+    roundings (lshrs_amd.hasher.window_coefficients) is about."""
+    p = np.asarray(p, dtype=np.float32)
+    dim = p.shape[0]
+    rng = np.random.default_rng(seed)
+    p64 = p.astype(np.float64)
+    mag = np.abs(rng.standard_normal(dim)) + 0.25
+    sgn = np.where(np.arange(dim) < dim // 2, 1.0, -1.0) * np.where(p64 >= 0, 1.0, -1.0)
+    up = float((mag[:dim // 2] * np.abs(p64[:dim // 2])).sum())
+    down = float((mag[dim // 2:] * np.abs(p64[dim // 2:])).sum())
+    mag[dim // 2:] *= up / down
+    x = (sgn * mag).astype(np.float32)
+    unit = 2.0 ** -24 * float(np.linalg.norm(x.astype(np.float64)) * np.linalg.norm(p64))
+    order = np.argsort(-np.abs(p64))                         # tune the elements with the largest |p_k|: coarse to fine
+    for k in order[:64]:
+        y = float(x.astype(np.float64) @ p64)
+        if abs(y - target_units * unit) < 0.5 * unit:
+            break
+        new = np.float32(x[k] - (y - target_units * unit) / p64[k])
+        if new != 0 and np.sign(new) == np.sign(x[k]):
+            x[k] = new
+    return x
+
+
 def describe(x: np.ndarray, p: np.ndarray) -> dict:
     x64, p64 = np.asarray(x, dtype=np.float64), np.asarray(p, dtype=np.float64)
     unit = 2.0 ** -24 * float(np.linalg.norm(x64) * np.linalg.norm(p64))

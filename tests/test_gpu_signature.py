@@ -887,7 +887,7 @@ def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     accumulation order, its split and the instruction model together, on Gaussian, wide-range and adversarial rows."""
     torch = torch_mod
     from oracle.build import split_stage1_model
-    from tests._adversary import adversarial_row
+    from tests._adversary import adversarial_row, tent_row
 
     h = _hasher(seed, nb, r, dim, tau1_ulps=1e12, margin_guard=0.0, audit_every=0)
     if not h._replay_model():
@@ -899,6 +899,8 @@ def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     x[200:300] *= np.float32(2.0 ** -20)
     for i in range(300, 332):
         x[i] = adversarial_row(h.projections[i % nb][i % r], 20.0, seed=i)
+    for i in range(332, 364):                                    # partial sums as large as a near-zero projection allows
+        x[i] = tent_row(h.projections[i % nb][(3 * i) % r], 5.0, seed=i)
     y = _stage1_values(torch, h, torch.from_numpy(x).cuda())
     want = split_stage1_model(h.projections, x)                                           # (n, nb * r)
     bb8 = 8 * h.band_bytes
@@ -918,7 +920,7 @@ def test_adversarial_rows_and_the_proven_window(torch_mod):
       and its keys are the reference's, as are the deterministic-bound spelling's and the streamed host path's."""
     torch = torch_mod
     from oracle.lshrs_oracle import hash_batch_literal_packed
-    from tests._adversary import adversarial_row, describe
+    from tests._adversary import adversarial_row, describe, tent_row
 
     for dim, nb, r, seed in ((768, 16, 16, 42), (1536, 16, 32, 7)):
         h = _hasher(seed, nb, r, dim)
@@ -933,6 +935,8 @@ def test_adversarial_rows_and_the_proven_window(torch_mod):
                 row = 17 + 31 * len(targets)
                 x[row] = adversarial_row(sign * h.projections[band][bit], 20.0, seed=i)
                 targets.append((row, band, bit))
+        for i in range(64):                                   # ... and rows whose partial sums peak in the middle of k
+            x[3_000 + 7 * i] = tent_row(h.projections[i % nb][(5 * i) % r], (-1.0) ** i * (0.5 + i % 7), seed=i)
         d = describe(x[targets[0][0]], h.projections[targets[0][1]][targets[0][2]])
         assert d["dropped_ex_p_units"] > 100.0 and 10.0 < d["y_units"] < 30.0, d
         want = hash_batch_literal_packed(h.projections, x)
