@@ -1462,6 +1462,10 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
           asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));
         }
         if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0) {   // wave-uniform: the exact per-element test
+          // With the proven window this runs on a quarter of the words: first the eight comparisons, branch-free, into a
+          // mask; only the lane that holds a flagged projection (one, seldom two of the wave) enters the append.
+          unsigned hits = 0u;
+          float ys[8];
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int ct = 2 * w + half;
@@ -1470,13 +1474,20 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
             for (int reg = 0; reg < 4; ++reg) {
               float thr = wnd[reg] * pa + wnb[reg] * pb;
               thr = thr > 0.f ? thr : -1.f;                               // zero row / zero-padded column: y is exactly 0
+              ys[4 * half + reg] = acc[rt][ct][reg];
+              hits |= (!(__builtin_fabsf(ys[4 * half + reg]) > thr) ? 1u : 0u) << (4 * half + reg);
+            }
+          }
+          if (hits != 0u) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int reg = q & 3, ct = 2 * w + (q >> 2);
               const int64_t grow = row0 + 16 * rt + 4 * ge + reg;
-              const float yv = acc[rt][ct][reg];
-              if (!(__builtin_fabsf(yv) > thr) && grow < args.n) {
+              if (((hits >> q) & 1u) != 0u && grow < args.n) {
                 const int64_t entry = (grow << 21) | (int64_t)(cb * 256 + 16 * ct + r16e);
                 // the stage-1 value travels with the entry: stage 2 measures |y1 - y_BLAS| on every flagged projection
                 // (rows flagged wholesale carry no usable y1: NaN, skipped by that statistic)
-                const float ykeep = wnd[reg] < __builtin_inff() ? yv : __builtin_nanf("");
+                const float ykeep = wnd[reg] < __builtin_inff() ? ys[q] : __builtin_nanf("");
                 const int pos = atomicAdd(l_count, 1);                    // LDS atomic
                 if (pos < kS1ListCap) {
                   l_list[pos] = entry;
