@@ -27,7 +27,8 @@ Also in the line (N = 1 unless noted):
                 against the package power cap (rocm-smi, one reading mid-run); and
                 `two_streams`: consecutive batches through hash_device_async on alternating streams;
   measured_window_mode   the same step with round 2's default (a 64-unit window + guard): statistical, not proven;
-  host_engine_mode       the same step with the device tie replay off (what an unrecognised host BLAS runs);
+  host_engine_mode       the same step with the device tie replay off (what an unrecognised host BLAS runs), with the proven
+                         windows and (`host_engine_mode_measured_windows`) with round 2's measured ones;
   c5            BASELINE config 5 (5M x 1536, num_perm 512) on one GPU with its own roofline and parity check;
   e2e_ingest    LSHRS.index() from host memory into an in-memory store, beside the reference-literal loop, and
                 query_many() of 10 000 queries against that index beside the reference-literal per-query flow;
@@ -59,7 +60,7 @@ CONFIG4_TOTAL_ROWS = 10_000_000
 
 def pmc_traffic(kernel: str, field: str, units: float):
     """HBM bytes per launch measured by the PMC passes committed under profiles/ (None if absent)."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)[kernel][field] * units, name
@@ -393,7 +394,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
-            "dtype": "bf16x3 + f32 fix-up (bit-exact f32 sign result)",
+            "dtype": "bf16x3 on the matrix cores + f32 replay of the host BLAS inside the proven window (bit-exact f32 sign result)",
             "data": "synthetic",
             "config": {
                 "workload": workload + "; f32 N(0,1) vectors, num_perm=256 (16 bands x 16 rows), HBM-resident in and out, "
@@ -405,7 +406,10 @@ def main() -> None:
                 "per_rank_ms_per_step": per_rank_ms,
                 "tie_break": hasher.tie_break, "tie_break_engine": stats.get("tie_break_engine", "host"),
                 "tau_ulps": hasher.tau_ulps, "precision": hasher.precision, "tau1_ulps": hasher.tau1_ulps,
-                "window_mode": dict(hasher.window_mode), "margin_guard": hasher.margin_guard,
+                "window_mode": dict(hasher.window_mode), "window_info": dict(hasher.window_info),
+                "margin_guard": hasher.margin_guard,
+                "host_work_inside_timed_steps": f"per step: one pinned-counter read; every {hasher.audit_every}th step the live "
+                                                "audit (one small D2H copy + 16 NumPy sgemv calls of the reference's own expression)",
                 "step_entry_point": "hash_device" if not args.async_steps else "hash_device_async (each step verified while the next one runs; all verified inside the timed region)",
             },
             "roofline": roofline,
@@ -428,6 +432,11 @@ def main() -> None:
                 "slicing) runs - stage 2 evaluates the f32 chain, the ties inside the proven tie window go to the host "
                 "engine (the library's own sgemv on several cores), chunks overlapped by csrc/pipeline.hip",
                 tie_replay="off")),
+            ("host_engine_mode_measured_windows", lambda: bench_variant(
+                torch, x, keys, local_dev, args.steps, barrier,
+                "tie_replay='off' with round 2's measured windows (tau1_ulps=64, tau_ulps=8): what that route costs when the "
+                "windows are a statistical statement instead of a proven one - a few thousand tied pairs per step for the "
+                "host instead of a few hundred thousand", tie_replay="off", tau1_ulps=64.0, tau_ulps=8.0)),
             ("roofline_f32_kernel", lambda: bench_f32(torch, x, keys, local_dev)),
             ("small_n", lambda: bench_small_n(torch, np, hasher, x)),
             ("host_fed", lambda: bench_host_fed(torch, np, hasher, x, 500_000)),
