@@ -20,8 +20,12 @@ out = {"note": "HBM bytes per unit from this round's rocprofv3 --pmc passes (FET
                "FETCH_SIZE KiB x 2 (gfx950 correction) + WRITE_SIZE KiB; calibration: the device copy below"}
 cp = [v for k, v in t.items() if "copyBuffer" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
 if cp:
-    out["calibration_copy"] = {"fetch_KiB_counter": cp[0]["FETCH_SIZE"], "write_KiB_counter": cp[0]["WRITE_SIZE"],
-                               "note": "pmc_target.py copies 1M x 768 f32 (3.0e6 KiB) and 2.5M x 1536 f32 (1.5e7 KiB): mean over both"}
+    big = max(cp, key=lambda v: v["FETCH_SIZE"])           # (the runtime's small internal copies share the kernel name)
+    out["calibration_copy"] = {"dispatches": big["dispatches"], "fetch_KiB_counter": big["FETCH_SIZE"],
+                               "write_KiB_counter": big["WRITE_SIZE"],
+                               "expected_KiB_each_way": (3 * 3.0e6 + 2 * 1.5e7) / 5,
+                               "note": "pmc_target.py copies 1M x 768 f32 (3.0e6 KiB) three times and 2.5M x 1536 f32 (1.5e7 KiB) "
+                                       "twice: the mean is 7.8e6 KiB each way - WRITE_SIZE reads it exactly, FETCH_SIZE half of it"}
 for label, name, grid, rows, alg, unit in (
         ("sig16_kernel", "sig16_kernel", (1_000_000 + 255) // 256 // 8 * 8 * 512 + (8 * 512 if ((1_000_000 + 255) // 256) % 8 else 0), 1_000_000, 3104, "row"),
         ("sig16_kernel_c5", "sig16_kernel", None, 2_500_000, 6208, "row"),
