@@ -604,7 +604,11 @@ def bench_variant(torch, x, keys, local_dev, steps, barrier, label, **kw):
 
     n = int(x.shape[0])
     hv = LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_dev, **kw)
-    for _ in range(30):
+    t0 = time.perf_counter()
+    hv.hash_device(x, out=keys)
+    torch.cuda.synchronize()
+    first = time.perf_counter() - t0
+    for _ in range(30 if first < 0.02 else 2):           # settled like the headline (a route that takes 0.25 s per step: twice)
         hv.hash_device(x, out=keys)
     elapsed, events, step_ms = timed_steps(torch, hv, x, keys, steps, False, barrier)
     st = dict(hv.last_stats)
