@@ -9,7 +9,7 @@ Metric (BASELINE.json): vectors/sec hashed at dim=768, num_perm=256.  One *step*
 one resident batch: every rank hashes its rows of synthetic N(0,1) float32 vectors already in its HBM into
 (rows, 16, 2) uint8 band keys in HBM, **byte-identical to the reference by construction**: stage 1 decides a projection
 only when its value is outside the PROVEN window (the distance stage 1 can have from the host's value, bounded from a
-bit-exact model of the matrix instruction: lshrs_amd.hasher.window_coefficients), stage 2 replays the host BLAS's
+bit-exact model of the matrix instruction: lshrs_amd.windows.window_coefficients), stage 2 replays the host BLAS's
 summation order for every other one (`config.tie_break_engine` says who decided them).  Workload: N = 1 -> BASELINE config 2 (1M x 768); N > 1 -> BASELINE config 4 (10M x 768 sharded: 1.25M rows per
 GPU at N = 8; `--scaling weak` keeps 1.25M per GPU at every N, `--scaling strong` divides the 10M).  Ranks share
 nothing (replicated hyperplanes, no collective in the data path).  Rank 0 prints ONE JSON line.

@@ -119,7 +119,7 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx,
  *        |y1 - y_host| <= ||x_hi|| * coef_a[j] + ||x_mid|| * coef_b[j]
  * with x_hi = bf16(x), x_mid = bf16(x - x_hi) (norms accumulated by stage 1 from the very values the matrix cores
  * consume, widened by 0.1 %).  Likewise the f32 kernel's single fmaf chain against the host: |y - y_host| <= ||x|| coef_tie[j].
- * The caller derives the coefficients from the hyperplanes (lshrs_amd/hasher.py `window_coefficients`, float64, rounded
+ * The caller derives the coefficients from the hyperplanes (lshrs_amd/windows.py `window_coefficients`, float64, rounded
  * up) and hands them over here; until it does, a pass that asks for the proven window sends every projection to the
  * exact decision.
  *   coef_a, coef_b, coef_tie   DEVICE float[num_bands * rows_per_band], band-major like P.

@@ -79,7 +79,7 @@ def tent_row(p: np.ndarray, target_units: float = 5.0, seed: int = 0) -> np.ndar
     """A row whose partial sums against ``p`` climb over the first half of k (every product positive) and come back down
     over the second (every product negative) to ``target_units`` of 2^-24 ||x|| ||p||: the accumulator is as large as a
     near-zero projection allows for as many steps as possible - the case the two-sided charge of the matrix instruction's
-    roundings (lshrs_amd.hasher.window_coefficients) is about."""
+    roundings (lshrs_amd.windows.window_coefficients) is about."""
     p = np.asarray(p, dtype=np.float32)
     dim = p.shape[0]
     rng = np.random.default_rng(seed)

@@ -1,5 +1,5 @@
 """CPU tests of the arithmetic model behind the proven stage-1 window (oracle/mfma_model.c) and of the window itself
-(lshrs_amd.hasher.window_coefficients).  No GPU: the instruction's results come from tests/golden/g9_mfma_probe.npz -
+(lshrs_amd.windows.window_coefficients).  No GPU: the instruction's results come from tests/golden/g9_mfma_probe.npz -
 raw outputs of v_mfma_f32_16x16x32_{bf16,f16} recorded on an MI355X by tools/probes/mfma_probe2_run.py (seeded operand
 families of tools/probes/mfma_cases.py, the first 2 000 cases of each) and tools/probes/mfma_probe_run.py (hand-made cases,
 operands stored).  The GPU suite repeats the comparison live on the box it runs on (tests/test_gpu_signature.py)."""
