@@ -4,15 +4,13 @@ Same constructor, attributes, methods and error messages as the reference class
 (lshrs/hash/lsh.py:51-247); the arithmetic runs in ``csrc/lshrs_hip.hip`` through
 the C ABI of ``include/lshrs_hip.h``.  There is no CPU hashing path in here.
 
-Bit-exactness.  The reference's bits are ``sign(sgemv_f32(P_band, x))`` as rounded
-by the *host's* BLAS; the kernel evaluates the same dot products as a single-rounded
-fmaf chain on the f32 matrix cores.  Two correctly-rounded f32 evaluations of one dot
-product can only disagree in sign when |y| is inside their rounding noise, so the
-kernel reports every projection with ``|y| < tau * ||x|| * ||p||`` (a few per 1000
-vectors) and this class re-evaluates exactly those (row, band) pairs with the
-reference's own expression, ``projection @ vector`` — the same NumPy call on the same
-host-resident hyperplanes — and patches the bytes.  ``tie_break="none"`` returns the
-raw kernel bits; ``last_stats`` records how many pairs were touched.
+Bit-exactness.  The reference's bits are ``sign(sgemv_f32(P_band, x))`` as rounded by the *host's* BLAS.
+Every route here is a fast first evaluation, a WINDOW that contains every projection whose sign could differ from the
+host's, and an exact decision for what is inside it - the host BLAS's own value, replayed on the device in the library's
+summation order (licensed by a bit-for-bit check against this process's NumPy) or, where that order is not recognised,
+computed by the library itself on the host.  The windows are PROVEN by default (``lshrs_amd/windows.py``): nothing is left
+to the first evaluation that could come out differently on the host.  ``tie_break="none"`` returns the raw kernel bits;
+``last_stats`` says which route a batch took and how many projections were decided exactly.
 """
 
 from __future__ import annotations
@@ -135,31 +133,22 @@ class LSHHasher:
       device      torch device index / ``torch.device`` (default: current device at call time)
       tie_break   "host" (default: bytes equal the reference on this host), or "none" (raw kernel bits)
       tie_threads host tie-break workers: None = auto (this process's share of the cores, at most 8), 1 = NumPy only
-      tau_ulps    tie threshold in units of float32 roundoff: |y| < tau_ulps * 2^-24 * ||x|| * ||p||.
-                  Default 8: measured on MI355X + host OpenBLAS (1.2M x 256 projections, Gaussian /
-                  all-positive / 5 %-sparse data, dim 128-1536) the two evaluations of a near-zero
-                  projection differ by at most 1.2 of those units (rms 0.3) and every sign disagreement
-                  had |y| <= 0.41; tests/test_gpu_signature.py re-checks the margin on the box it runs on.
-                  Raise it (e.g. 2*dim for the deterministic worst-case bound) for adversarial inputs.
-      precision   "bf16x3" (default): batches of >= 16 M elements (21 846 rows at 768-d) whose shape allows it (dim % 32 == 0, >= 256 key
-                  columns, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass — bf16 matrix
-                  cores, then the exact f32 chain for every projection inside the stage-1 window — everything
-                  else the f32 kernel; the keys are the same either way.  "f32": always the f32 kernel.
-      tau1_ulps   stage-1 window of the split pass, in the units of tau_ulps.  Default (None): 64 x sqrt(768 / dim)
-                  (``default_tau1_ulps``: stage 1's deviation is a random walk over the dim products, measured at 15-20
-                  units x sqrt(768 / dim) at most from 32-d to 4096-d, profiles/r02_window_by_dim.log; at 768-d over
-                  2.7e9 projections of six data distributions none reached 16, profiles/r01_split_window_margin.log) -
-                  and the margin is not taken on trust: stage 2 measures |y_stage1 - y_hostBLAS| on EVERY flagged projection of every
-                  batch (tens of thousands per 1M rows; ``last_stats["max_dev_units"]``; largest seen on any of 14
-                  input families: 15.3), and a batch in which it exceeds ``margin_guard`` x the window is hashed
-                  again with a window at least twice as wide and four times that deviation, which the hasher then
-                  keeps - up to the deterministic bound (``escalated_window``, ``last_stats["margin_escalations"]``,
-                  ``window_mode``).  "bound": use that bound from the
-                  start (``bound_tau1_ulps(dim)``: 1 469 units at 768-d) - keys identical to the reference by
-                  construction under the stated per-instruction error of the bf16 MFMA, at ~0.6x the rate.
-                  ``tau_ulps="bound"`` does the same for the f32 kernel's tie window (``bound_tau_ulps``).
-      margin_guard  fraction of the stage-1 window the measured deviation may reach before the hasher escalates
-                  (default 0.5; 0 disables the guard)
+      precision   "bf16x3" (default): batches whose shape allows it (dim % 32 == 0, >= 256 key columns - or 128 with
+                  dim >= 384 -, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass - bf16 matrix cores,
+                  then the exact decision for every projection inside the stage-1 window - everything else the f32
+                  kernel; the keys are the same either way.  "f32": always the f32 kernel.
+      tau1_ulps   stage-1 window of the split pass.  Default (None, or "bound"): the PROVEN window - per-hyperplane
+                  coefficients (``windows.window_coefficients``) times the norms of the two bf16 pieces of the row, which
+                  stage 1 measures: 339 units of 2^-24 ||x|| ||p|| on Gaussian rows at 768-d, more for a row whose
+                  residual is larger (``window_info``, ``last_stats["tau1_ulps"]``).  Stage 2 still measures
+                  |y_stage1 - y_hostBLAS| on every flagged projection (``last_stats["max_dev_units"]``): a value outside the
+                  window raises.  A number: a window of that many units - round 2's default was 64 x sqrt(768 / dim), 3-4x
+                  the largest deviation seen on any input family, watched by ``margin_guard``; it is ~9 % faster and a
+                  statistical statement: rows built for the purpose (tests/_adversary.py) get past it AND past the guard.
+      tau_ulps    tie window of the f32 kernel's fmaf chain against the host, same convention: proven by default (281 units
+                  at 768-d), a number for a measured one (round 2: 8).
+      margin_guard  (numeric windows only) fraction of the window the measured deviation may reach before the batch is hashed
+                  again with a wider one - up to the proven window (default 0.5; 0 disables the guard)
       audit_every every n-th synchronous ``hash_device`` batch (default 64, and the first) a handful of the projections
                   stage 2 decided are re-evaluated with ``P_band @ x`` on the host and compared with the key bits; a
                   disagreement revokes the device replay for this hasher (``audit_failures``) and the
