@@ -947,6 +947,10 @@ class LSHHasher:
         if ((int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) < 256 and key_cols != 128)
                 or (self.num_bands * self.band_bytes) % 4 != 0):
             return False
+        if self.dim > 8192:
+            # the proven window widens the row norms stage 1 accumulates in f32 by 0.1 %: enough for the rounding of up to
+            # ~8 k terms (4 k dot2 steps x 2^-23); longer rows keep the f32 kernel
+            return False
         if key_cols == 128 and self.dim < 384:
             # short vectors: the padded pass's 256-column epilogue outweighs its matrix rate (1M x 128, 16 x 4:
             # 0.36 ms against 0.32 ms for the f32 kernel; 1M x 768, 8 x 16: 1.18 against 1.71 ms)
