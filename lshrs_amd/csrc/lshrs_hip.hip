@@ -657,10 +657,14 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
 #pragma unroll
     for (int i = 0; i < kFixSlabG; ++i) {
       const int t = slab * kFixSlabG + i < a.ktiles ? slab * kFixSlabG + i : a.ktiles - 1;
+#ifndef LSHRS_AB_FIX_NO_X        // (A/B builds only: which of the two streams bounds stage 2 - wrong keys by design)
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.xg + (size_t)t * kKTile), (LDS_AS void*)(xs[buf] + i * 64),
                                        16, 0, 0);
+#endif
+#ifndef LSHRS_AB_FIX_NO_P
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.pg + (size_t)t * kKTile), (LDS_AS void*)(ps[buf] + i * 64),
                                        16, 0, 0);
+#endif
     }
   };
   int grp = blockIdx.x;                             // uniform per wave
@@ -684,7 +688,11 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       if (sl + 1 < slabs) issue(cur, sl + 1, buf ^ 1);
       else if (has_next) issue(nxt, 0, buf ^ 1);
       else more = false;
+#if defined(LSHRS_AB_FIX_NO_X) || defined(LSHRS_AB_FIX_NO_P)
+      if (more) wait_vmcnt<kFixSlabG>();
+#else
       if (more) wait_vmcnt<2 * kFixSlabG>();        // this slab has landed, the next one is on its way
+#endif
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (REPLAY) {
         // The library's value IS the reference's for every flagged projection, tie or not: the canonical chain (768
