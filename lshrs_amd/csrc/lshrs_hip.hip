@@ -651,6 +651,12 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     it.col = col_raw < a.padcols ? col_raw : 0;
     it.xg = a.X + it.row * a.ldx + 16 * shh + 4 * sq;
     it.pg = a.prow + (size_t)it.col * ldp + 16 * shh + 4 * sq;
+#ifdef LSHRS_AB_FIX_SAME_P        // (A/B builds only: what a list sorted by column would make of the hyperplane stream - wrong keys by design)
+    {
+      const int c0 = (int)(a.flag_list[grp * kFixG < cnt ? grp * kFixG : 0] & ((1 << 21) - 1));
+      it.pg = a.prow + (size_t)(c0 < a.padcols ? c0 : 0) * ldp + 16 * shh + 4 * sq;
+    }
+#endif
     return it;
   };
   auto issue = [&](const Item& it, int slab, int buf) {   // nothing lands in a VGPR; tiles past the row's end re-fetch its last
