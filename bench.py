@@ -25,7 +25,8 @@ Also in the line (N = 1 unless noted):
                 matrix roof (it executes 3 bf16 MFMAs per algorithmic multiply-add) - with the HBM view beside it;
   sustained     the same step repeated for >= 2 s: p50 / p95 step time, kernel mean, in-kernel shader clock, socket power
                 against the package power cap (rocm-smi, one reading mid-run); and
-                `two_streams`: consecutive batches through hash_device_async on alternating streams;
+                `async_one_stream` / `two_streams`: consecutive batches through hash_device_async on one stream
+                (no kernel overlaps another) / on two alternating streams;
   measured_window_mode   the same step with round 2's default (a 64-unit window + guard): statistical, not proven;
   host_engine_mode       the same step with the device tie replay off (what an unrecognised host BLAS runs), with the proven
                          windows and (`host_engine_mode_measured_windows`) with round 2's measured ones;
@@ -562,6 +563,12 @@ def bench_sustained(torch, hasher, x, keys, seconds, barrier):
     if power and power[0] and power[0].get("socket_power_W"):
         # at the power cap the rate IS energy per vector: socket power / vectors per second
         out["energy_per_vector_uJ"] = 1e6 * power[0]["socket_power_W"] / out["value"]
+    # the streaming entry point on ONE stream (the next batch launched before the previous one is verified; no kernel
+    # overlaps another): what hiding the host's wake-up and launch alone is worth
+    el2, _, ms2 = timed_steps(torch, hasher, x, keys, 200, True, barrier, min_seconds=0.5 * seconds)
+    out["async_one_stream"] = {"value": n * len(ms2) / el2, "unit": "vectors/s", "steps": len(ms2),
+                               "ms_per_step_mean": 1e3 * el2 / len(ms2),
+                               "entry_point": "hash_device_async, depth 2, one stream, every batch verified"}
     out["two_streams"] = bench_two_streams(torch, hasher, x, keys, steps // 2)
     return out
 
