@@ -622,6 +622,9 @@ def test_split_pass_edge_rows_and_layouts(torch_mod):
         10: torch.randn(dim, generator=torch.Generator().manual_seed(3)) * 1e-42,       # subnormals
         11: torch.randn(dim, generator=torch.Generator().manual_seed(4)) * torch.logspace(-20, 20, dim),
         12: torch.full((dim,), 1e-9), 13: torch.full((dim,), 1.0),
+        # a wide dynamic range INSIDE the range guard (max |x| < 2^32): the proven window must hold with elements 18 decades apart
+        14: torch.randn(dim, generator=torch.Generator().manual_seed(5)) * torch.logspace(-9, 9, dim),
+        15: torch.randn(dim, generator=torch.Generator().manual_seed(6)) * torch.logspace(9, -9, dim) * 1e-9,
     }
     for i, v in special.items():
         x[i] = v.to(torch.float32).cuda()
