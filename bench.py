@@ -377,6 +377,15 @@ def main() -> None:
             roofline.update({"fix_kernel_ms_mean": sum(fix_ms) / max(1, len(fix_ms)), "launches_timed": len(kernel_ms),
                              "launches_per_step": len(kernel_ms) / max(1, args.steps),
                              "kernel_ms_per_step": sum(kernel_ms) / max(1, args.steps)})
+            flagged = stats.get("flagged")
+            if flagged and fix_ms:
+                # the second kernel of a step: per flagged projection one x row (HBM) and one hyperplane row (L2), 4 dim bytes each
+                s2 = sum(fix_ms) / len(fix_ms)
+                roofline["stage2"] = {"kernel": "sig_fix8_kernel<true> (the exact decision: host-BLAS order replayed per flagged projection)",
+                                      "flagged_projections": flagged, "kernel_ms_mean": s2, "bound": "hbm (row gather)",
+                                      "x_rows_GBps": flagged * 4.0 * DIM / (s2 * 1e-3) / 1e9,
+                                      "x_plus_hyperplane_rows_GBps": flagged * 8.0 * DIM / (s2 * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                      "frac_x_rows_of_hbm_peak": flagged * 4.0 * DIM / (s2 * 1e-3) / 1e9 / PEAK_HBM_GBS}
         else:
             tf = 2.0 * DIM * NUM_PERM * rows_per_launch_mean / (kernel_ms_mean * 1e-3) / 1e12
             roofline = {"kernel": "sig_kernel<NT=8, ALIGNED, MODE=1>", "bound": "mfma", "achieved": tf,
