@@ -118,3 +118,15 @@ def test_window_coefficients_of_degenerate_hyperplanes():
     assert ca[0] == 0 and cb[0] == 0 and ct[0] == 0               # a zero hyperplane: y is exactly 0, never flagged
     assert (ca[1:3] > 0).all() and np.isfinite(ca).all() and np.isfinite(cb).all()
     assert ca.dtype == np.float32
+
+
+def test_a_short_adversarial_search_stays_inside_the_window():
+    """tools/window_search.py for a few hundred iterations (the long runs: profiles/r03_window_search.log): rows mutated to
+    maximise |y1 - y_host| / window never get past 1 - and do get well past what random rows reach."""
+    import subprocess
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "window_search.py"), "3", "128", "300"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-1500:]
+    best = float(out.stdout.split("best ratio")[1].split()[0])
+    assert 0.1 < best < 1.0, out.stdout
