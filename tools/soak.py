@@ -3,14 +3,15 @@
 from one row to 1.6 M, zero and NaN rows, and - on the 768-d and 1536-d shapes - rows built against the window (residual
 aligned with a hyperplane; partial sums that peak mid-way: tests/_adversary.py).  Every result is compared on the GPU with
 an independent first pass: the exact-f32 kernel (a single fmaf chain per projection, proven tie window) decided by the same
-replay, which the parity tests pin to the reference.   python tools/soak.py [batches]"""
+replay, which the parity tests pin to the reference.   python tools/soak.py [batches [seed]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from lshrs_amd import LSHHasher
 from tests._adversary import adversarial_row, tent_row
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(2024)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # another seed: other batches, other planted rows
+rng = np.random.default_rng(2024 + seed)
 shapes = [(16, 16, 768), (16, 32, 1536), (16, 16, 128), (32, 8, 96), (16, 16, 100), (16, 16, 768)]
 hashers = {}
 t0 = time.time(); rows = 0; bad = 0; planted = 0; worst_used = 0.0
@@ -22,7 +23,7 @@ for it in range(iters):
     if key not in hashers:
         hashers[key] = (LSHHasher(nb, r, dim, seed=11), LSHHasher(nb, r, dim, seed=11, precision="f32"))
     a, b = hashers[key]
-    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(it))
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(1_000_003 * seed + it))
     if it % 3 == 0: x *= float(2.0 ** rng.integers(-12, 13))
     if it % 5 == 0 and n > 10: x[int(rng.integers(0, n))] = 0.0
     if it % 7 == 0 and n > 10: x[int(rng.integers(0, n)), int(rng.integers(0, dim))] = float("nan")
@@ -30,7 +31,7 @@ for it in range(iters):
         m = 48
         rows_at = rng.choice(n, m, replace=False)
         adv = np.stack([(adversarial_row if j % 2 else tent_row)(a.projections[j % nb][(7 * j + it) % r],
-                                                                  float(rng.choice([20.0, -20.0, 3.0, -3.0])), seed=1000 * it + j)
+                                                                  float(rng.choice([20.0, -20.0, 3.0, -3.0])), seed=1000 * it + j + 7919 * seed)
                         for j in range(m)])
         x[torch.from_numpy(rows_at).cuda()] = torch.from_numpy(adv).cuda()
         planted += m
