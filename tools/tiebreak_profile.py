@@ -6,7 +6,8 @@ import numpy as np, torch
 from lshrs_amd import LSHHasher
 
 for (nb, r, dim, seed) in [(16, 16, 768, 42), (16, 32, 1536, 7)]:
-    h = LSHHasher(nb, r, dim, seed=seed, tie_replay="off")      # (the host tie-break path is what this tool looks at)
+    # (the host tie-break path with MEASURED windows is what this tool looks at: numbers, not the proven default)
+    h = LSHHasher(nb, r, dim, seed=seed, tie_replay="off", tau_ulps=32.0, tau1_ulps=64.0)
     x = torch.randn(1_000_000, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
     out = torch.empty((1_000_000, nb, h.band_bytes), dtype=torch.uint8, device="cuda")
     for label, chunk, tau in (("pipelined tau=32", 131072, 32.0), ("plain tau=32", 10**9, 32.0),
