@@ -67,6 +67,40 @@ __global__ __launch_bounds__(256, 1) void mfma_loop(const bf16x8* __restrict__ o
   if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// v_mfma_i32_16x16x64_i8: the same cycles as the bf16 16x16x32 form at twice the K (the exact-accumulation alternative: six
+// int8 digit products per multiply-add instead of three bf16 terms).  Same loop shape as SHAPE 1.
+__global__ __launch_bounds__(256, 1) void mfma_loop_i8(const i32x4* __restrict__ ops, int* __restrict__ out, int iters,
+                                                      unsigned long long* stamps) {
+  const int lane = threadIdx.x & 63;
+  i32x4 a[4], b[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = ops[(blockIdx.x * 256 + threadIdx.x) * 12 + i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) b[i] = ops[(blockIdx.x * 256 + threadIdx.x) * 12 + 4 + i];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  i32x4 acc[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) acc[i] = i32x4{0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        const int c = half * 32 + t;
+        acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t & 3], b[(t >> 2)], acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t & 3], b[(t >> 2) ^ 1], acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[(t + 1) & 3], b[(t >> 2)], acc[c], 0, 0, 0);
+      }
+  }
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) sum += acc[i][lane & 3];
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[blockIdx.x * 256 + threadIdx.x] = sum;
+  if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 int main(int argc, char** argv) {
   const int blocks = 256 * 8, iters = 400;
   std::vector<unsigned short> h((size_t)blocks * 256 * 12 * 8);
@@ -81,6 +115,21 @@ int main(int argc, char** argv) {
   hipMalloc(&ops, h.size() * 2); hipMalloc(&out, (size_t)blocks * 256 * 4); hipMalloc(&st, (size_t)blocks * 16);
   hipMemcpy(ops, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  if (argc > 1 && !strcmp(argv[1], "i8")) {        // random int8 operands (the bytes of the random bf16 pattern)
+    for (int rep = 0; rep < 12; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(mfma_loop_i8, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const i32x4*>(ops), reinterpret_cast<int*>(out), iters, st);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      std::vector<unsigned long long> hs((size_t)blocks * 2);
+      hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
+      double cyc = 0, real = 0; for (int i = 0; i < blocks; ++i) { cyc += hs[2 * i]; real += hs[2 * i + 1]; }
+      const double ops_n = (double)blocks * 4 * iters * 192.0 * 32768;     // 16 x 16 x 64 x 2 per instruction
+      printf("16x16x64 i8 rep %d: %.3f ms, %.0f TOP/s executed, shader clock %.2f GHz, cycles per MFMA %.1f\n", rep, ms,
+             ops_n / ms / 1e9, cyc / real * 0.1, cyc / blocks / iters / 192.0);
+    }
+    return 0;
+  }
   for (int shape = f16_ops ? 2 : 0; shape < (f16_ops ? 3 : 2); ++shape)
     for (int rep = 0; rep < 12; ++rep) {
       hipEventRecord(e0);
