@@ -154,10 +154,12 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
 
 /* lshrs_sig_hash_batch_split_f32 with the tie-break on the device: every projection stage 1 flags (inside its window,
  * which contains every tie) gets the sign of the value the HOST BLAS computes for it - the reference's
- * `projection @ vector`, lsh.py:200 - because stage 2 replays that library's summation order (blas_model 1: eight interleaved fma chains over k = j mod 8,
- * reduced ((p0+p4)+(p1+p5))+((p2+p6)+(p3+p7)): OpenBLAS's 8-lane sgemv_t kernels).  The keys are final when the stream
- * has run: no tie list, no host step.  Only for callers that have checked the model against their BLAS
- * (lshrs_tb_model_dot in lshrs_host.h vs `P_band @ x`, bit for bit; lshrs_amd/hasher.py does) and for inputs the split
+ * `projection @ vector`, lsh.py:200 - because stage 2 replays that library's summation order (blas_model 1 = OpenBLAS's
+ * sgemv_t on x86-64, row by row of the band: the rows it takes four at a time are eight interleaved fma chains over
+ * k = j mod 8, reduced ((p0+p4)+(p1+p5))+((p2+p6)+(p3+p7)); the rows_per_band % 4 rows left over go through its unfused
+ * 4x2 / 4x1 kernels; the vector in blocks of 4096 elements - lshrs_tb_model_row_dot in lshrs_host.h states it).  The keys
+ * are final when the stream has run: no tie list, no host step.  Only for callers that have checked the model against
+ * their BLAS (lshrs_tb_model_row_dot vs `P_band @ x`, bit for bit; lshrs_amd/_hostblas.py does) and for inputs the split
  * pass takes itself (dim % 32 == 0, 16-byte aligned rows; else LSHRS_E_BADARG).
  *   counters     DEVICE int32[LSHRS_SIG_DEVICE_COUNTERS] (see above), zero on entry.
  *   flag_y       optional float[flag_cap]: the stage-1 value of every list entry; with it stage 2 measures how far

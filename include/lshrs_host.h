@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LSHRS_HOST_ABI_VERSION 1
+#define LSHRS_HOST_ABI_VERSION 2
 #define LSHRS_HOST_E_BADARG (-1)
 
 int lshrs_host_abi_version(void);
@@ -39,10 +39,15 @@ int lshrs_tb_threads(void* engine);
 void lshrs_tb_destroy(void* engine);
 
 /* One dot product in the summation order of the host BLAS that the GPU's tie replay follows (lshrs_hip.h:
- * lshrs_sig_hash_batch_split_replay_f32).  model 1: eight interleaved fma chains over k = j (mod 8), reduced as
- * ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)) - OpenBLAS's 8-lane sgemv_t kernels; n % 8 == 0.  NaN on bad arguments.
- * Used to check, bit for bit against `projection @ vector` (lshrs/hash/lsh.py:200) of the running process, that the
- * replay may stand in for the engine below. */
+ * lshrs_sig_hash_batch_split_replay_f32), for row `row` of a band of `rows_per_band` hyperplanes - what
+ * `projection @ vector` (lshrs/hash/lsh.py:200) computes for that row.  model 1 = OpenBLAS's sgemv_t on x86-64: rows in
+ * groups of four through the 8-lane kernel (eight interleaved fma chains over k = j (mod 8), reduced as
+ * ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7))); of the rows_per_band % 4 rows left over, a pair through the 4x2 kernel (four
+ * chains over k = l (mod 4), multiply and add in two roundings, reduced (v0+v1) + (v2+v3)) and a single one through the 4x1
+ * kernel (the eight chains, unfused); the vector consumed in blocks of 4096, each block's sum added to y.  n % 8 == 0.
+ * NaN on bad arguments.  Used to check, bit for bit against NumPy in the running process, that the replay may stand in for
+ * the engine below.  lshrs_tb_model_dot: row 0 of a four-row band. */
+float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band);
 float lshrs_tb_model_dot(const float* a, const float* x, int64_t n, int32_t model);
 
 /* For pair p in [0, n_pairs): y = planes[band[p]] (rows_per_band x dim, row-major, contiguous) @ xrows[row_index[p]]

@@ -23,9 +23,9 @@ REPO_ROOT = os.path.dirname(_HERE)
 SOURCE = os.path.join(_HERE, "csrc", "host_tiebreak.cpp")
 LIBRARY = os.path.join(_HERE, "csrc", "liblshrs_host.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-ABI_VERSION = 1
+ABI_VERSION = 2
 EXPORTS = ("lshrs_host_abi_version", "lshrs_tb_create", "lshrs_tb_threads", "lshrs_tb_destroy", "lshrs_tb_patch",
-           "lshrs_tb_resolve", "lshrs_tb_model_dot")
+           "lshrs_tb_resolve", "lshrs_tb_model_dot", "lshrs_tb_model_row_dot")
 
 # (cblas_sgemv symbol, 64-bit integers?, set_num_threads symbol) in order of preference
 _BLAS_FLAVOURS = (
@@ -84,6 +84,8 @@ def load() -> ctypes.CDLL:
         lib.lshrs_tb_resolve.restype = c.c_int
         lib.lshrs_tb_model_dot.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_int32]
         lib.lshrs_tb_model_dot.restype = c.c_float
+        lib.lshrs_tb_model_row_dot.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32]
+        lib.lshrs_tb_model_row_dot.restype = c.c_float
         if lib.lshrs_host_abi_version() != ABI_VERSION:
             raise OSError(f"{LIBRARY} has a different ABI version; rebuild it")
         _lib = lib
@@ -144,13 +146,24 @@ def blas_signature() -> tuple:
     return (path, int(getter()) if getter is not None else -1, os.getpid())
 
 
+def blas_row_kinds(rows_per_band: int) -> np.ndarray:
+    """Which of OpenBLAS's sgemv_t micro-kernels computes each row of an r-row band (``lshrs_tb_model_row_dot``): 0 = the
+    8-lane fma kernel (rows in groups of four), 1 = the 4x2 kernel (a pair of left-over rows), 2 = the 4x1 kernel (a single
+    left-over row, or the third of three)."""
+    r = int(rows_per_band)
+    r4 = r & ~3
+    j = np.arange(r)
+    return np.where(j < r4, 0, np.where(((r & 3) == 1) | (j - r4 == 2), 2, 1)).astype(np.int32)
+
+
 def blas_order_model(planes: np.ndarray) -> int:
-    """Which summation-order model of ``lshrs_tb_model_dot`` (0 = none) reproduces, bit for bit, what this process's
+    """Which summation-order model of ``lshrs_tb_model_row_dot`` (0 = none) reproduces, bit for bit, what this process's
     NumPy returns for ``P_band @ x`` at this ``(rows_per_band, dim)`` - the licence for the GPU's tie replay
     (``lshrs_sig_hash_batch_split_replay_f32``) to stand in for the host engine.  Checked on random vectors, on vectors
     with a wide dynamic range and on vectors built to cancel against a hyperplane (where the order shows), for the
-    first, a middle and the last band, every row of each; cached per (shape, BLAS library, BLAS thread count, process):
-    identity of the keys means identity with THIS process's BLAS as it is configured when the batch is hashed."""
+    first, a middle and the last band, every row of each (a band of 13 rows goes through three different kernels of the
+    library); cached per (shape, BLAS library, BLAS thread count, process): identity of the keys means identity with THIS
+    process's BLAS as it is configured when the batch is hashed."""
     nb, r, dim = planes.shape
     key = (r, dim) + blas_signature()
     if key in _order_models:
@@ -161,20 +174,25 @@ def blas_order_model(planes: np.ndarray) -> int:
             lib = load()
             rng = np.random.default_rng(20240601)
             bands = sorted({0, nb // 2, nb - 1})
+            kinds = blas_row_kinds(r)
+            # rows to cancel against: the first, a middle one, the last, and the first row of every kernel kind
+            targets = sorted({0, r // 2, r - 1} | {int(np.argmax(kinds == k)) for k in set(kinds.tolist())})
             ok = True
             for b in bands:
                 plane = np.ascontiguousarray(planes[b], dtype=np.float32)
                 xs = [rng.standard_normal(dim) for _ in range(12)]
                 xs += [rng.standard_normal(dim) * np.exp(3.0 * rng.standard_normal(dim)) for _ in range(6)]
-                for i in sorted({0, r // 2, r - 1}):       # nearly orthogonal to row i: y_i is what the order leaves of it
+                for i in targets:                              # nearly orthogonal to row i: y_i is what the order leaves of it
                     p = plane[i].astype(np.float64)
+                    if not (p @ p) > 0:
+                        continue
                     for _ in range(3):
                         x = rng.standard_normal(dim)
                         xs.append(x - (x @ p) / (p @ p) * p)
                 for x in xs:
                     x32 = np.ascontiguousarray(x, dtype=np.float32)
                     want = plane @ x32                       # the reference's call (lshrs/hash/lsh.py:200)
-                    got = np.array([lib.lshrs_tb_model_dot(plane[i].ctypes.data, x32.ctypes.data, dim, 1)
+                    got = np.array([lib.lshrs_tb_model_row_dot(plane[i].ctypes.data, x32.ctypes.data, dim, 1, i, r)
                                     for i in range(r)], dtype=np.float32)
                     if not np.array_equal(want.view(np.uint32), got.view(np.uint32)):
                         ok = False

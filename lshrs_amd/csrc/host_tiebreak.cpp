@@ -240,18 +240,64 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
 }
 
 // Model of the host BLAS's summation order for one dot product (the order sig_fix8_kernel<true> replays on the GPU).
-// model 1: eight interleaved single-rounded fma chains p_j = sum over k = j (mod 8) of a_k x_k, reduced as
-// ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)); n must be a multiple of 8.  Returns NaN for anything else.
-// The caller (lshrs_amd/hasher.py) compares it bit for bit with `P_band @ x` of the running process before the
-// device replay is allowed to stand in for the host engine.
+// model 1 = OpenBLAS's sgemv_t on x86-64 (Haswell / Zen / SkylakeX builds), as `P_band @ x` of an r-row band reaches it:
+//   * rows are taken four at a time by the 8-lane AVX kernel ("kind 0"): eight interleaved single-rounded fma chains
+//     p_j = sum over k = j (mod 8) of a_k x_k, reduced as ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7));
+//   * the r mod 4 rows that are left go through the SSE kernels, which multiply and add in two roundings: a pair of rows
+//     through the 4x2 kernel ("kind 1": four chains over k = l (mod 4), reduced (v0+v1) + (v2+v3)), a single row -
+//     the only one left, or the third of three - through the 4x1 kernel ("kind 2": the eight chains and the tree of
+//     kind 0, unfused);
+//   * the vector is consumed in blocks of 4096 elements: every block's sum is reduced on its own and added to y.
+// n must be a multiple of 8.  Found by search (tools/blas_order/); the caller (lshrs_amd/_hostblas.py) compares it bit for
+// bit with `P_band @ x` of the running process, row kind by row kind, before the device replay may stand in for the host.
+static inline int tb_row_kind(int row, int rows) {
+  const int r4 = rows & ~3;
+  if (row < r4) return 0;
+  return ((rows & 3) == 1 || row - r4 == 2) ? 2 : 1;
+}
+
+float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band) {
+  if (model != 1 || a == nullptr || x == nullptr || n <= 0 || n % 8 != 0 || row < 0 || row >= rows_per_band)
+    return __builtin_nanf("");
+  const int kind = tb_row_kind(row, rows_per_band);
+  float y = 0.f;
+  for (int64_t k0 = 0; k0 < n; k0 += 4096) {
+    const int64_t kn = n - k0 < 4096 ? n - k0 : 4096;
+    const float* ab = a + k0;
+    const float* xb = x + k0;
+    float s;
+    if (kind == 1) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int64_t k = 0; k < kn; k += 4)
+        for (int l = 0; l < 4; ++l) {
+          const volatile float prod = ab[k + l] * xb[k + l];      // (volatile: two roundings, whatever the compiler's flags)
+          v[l] = v[l] + prod;
+        }
+      s = (v[0] + v[1]) + (v[2] + v[3]);
+    } else {
+      float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (kind == 0) {
+        for (int64_t k = 0; k < kn; k += 8)
+          for (int j = 0; j < 8; ++j) p[j] = __builtin_fmaf(ab[k + j], xb[k + j], p[j]);
+      } else {
+        for (int64_t k = 0; k < kn; k += 8)
+          for (int j = 0; j < 8; ++j) {
+            const volatile float prod = ab[k + j] * xb[k + j];
+            p[j] = p[j] + prod;
+          }
+      }
+      const float q0 = p[0] + p[4], q1 = p[1] + p[5], q2 = p[2] + p[6], q3 = p[3] + p[7];
+      const float h0 = q0 + q1, h1 = q2 + q3;
+      s = h0 + h1;
+    }
+    y = k0 == 0 ? s : y + s;
+  }
+  return y;
+}
+
+// (a row of the 8-lane kernel: what every row of a band of 4, 8, 12 ... rows is)
 float lshrs_tb_model_dot(const float* a, const float* x, int64_t n, int32_t model) {
-  if (model != 1 || a == nullptr || x == nullptr || n <= 0 || n % 8 != 0) return __builtin_nanf("");
-  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int64_t k = 0; k < n; k += 8)
-    for (int j = 0; j < 8; ++j) p[j] = __builtin_fmaf(a[k + j], x[k + j], p[j]);
-  const float q0 = p[0] + p[4], q1 = p[1] + p[5], q2 = p[2] + p[6], q3 = p[3] + p[7];
-  const float h0 = q0 + q1, h1 = q2 + q3;
-  return h0 + h1;
+  return lshrs_tb_model_row_dot(a, x, n, model, 0, 4);
 }
 
 int lshrs_tb_threads(void* engine) { return engine ? (int)static_cast<Engine*>(engine)->handles.size() : 0; }

@@ -85,7 +85,10 @@ inline int64_t sig_t16_offset_floats(const SigGeom& g) { return sig_main_floats(
 // a 16x16x32 fragment image padded with zero hyperplanes to the 256 columns sig16_kernel<2,8> works on (a zero
 // column gives y = +0: never flagged, bit 0, and its key bytes lie beyond row_bytes and are not stored).  Half the
 // matrix work is wasted and it is still 1.5x the exact-f32 kernel.  Own image + 256 norms + their maximum.
-inline bool sig_has_narrow_split(const SigGeom& g) { return g.nt < 8 && g.cb == 1 && g.padcols >= 128; }
+// (128 .. 224 key columns: four to seven 32-column tiles - the f32 kernel's geometry is then one or two column blocks of
+// NT = 4, the narrow image one block of 256 either way; its window maxima live in the last slot of the maxima arrays.)
+inline bool sig_has_narrow_split(const SigGeom& g) { return g.nt < 8 && g.padcols >= 128; }
+constexpr int kNarrowMaxSlot = 3;           // sig_normmax_floats(g) >= 4 and a narrow hasher has at most two column blocks
 inline int64_t sig_narrow_offset_floats(const SigGeom& g) { return sig_main_floats(g) + sig_fine_floats(g); }
 inline int64_t sig_narrow_image_floats(const SigGeom& g) { return (int64_t)g.ktiles * 8 * 4 * kFragFloats; }
 // Stage 2 reads whole hyperplanes: a plain row-major copy P'[padded column][32 * ktiles] (zero rows / zero tail), so
@@ -576,12 +579,42 @@ struct FixArgs {
   int* tie_count;
   float tau;
   int blas_model;         // sig_fix8_kernel<true>: which host-BLAS summation order the tie replay follows (1: see there)
+  int rows_per_band;      // ... and what it needs to know which of the library's kernels computes a column: the band's rows
+  int band_cols;          //     and its padded width (8 * band_bytes)
   const float* flag_y;    // optional: stage-1 value of every list entry (sig16_kernel stores it beside the entry)
   int count_ties;         // sig_fix8_kernel<true>: report the projections inside the tie window in partials[0] (else 0)
   int* partials;          // sig_fix8_kernel<true>: int32[3 * gridDim.x], per workgroup: projections inside the tie window,
                           // flagged projections whose stage-1 sign differed from the host BLAS's, and (float bits) the max
                           // over its flagged projections of |y1 - y_BLAS| in units of 2^-24 ||x|| ||p||
 };
+
+// The host BLAS's left-over rows (blas_row_kind != 0) multiply and add in TWO roundings: never contracted into an fma.
+__device__ __forceinline__ float mul_then_add(float acc, float a, float b) {
+#pragma clang fp contract(off)
+  const float prod = a * b;
+  return acc + prod;
+}
+
+// Which of OpenBLAS's sgemv_t kernels computes row j of a band of `rows` hyperplanes (lshrs_host.h, lshrs_tb_model_row_dot):
+// 0 = the 8-lane fma kernel (rows in groups of four; also the zero rows a band is padded with), 1 = the 4x2 kernel (a
+// pair of left-over rows: four unfused chains), 2 = the 4x1 kernel (a single left-over row, or the third: eight unfused chains).
+__device__ __forceinline__ int blas_row_kind(int j, int rows) {
+  const int r4 = rows & ~3;
+  if (j < r4 || j >= rows) return 0;
+  return ((rows & 3) == 1 || j - r4 == 2) ? 2 : 1;
+}
+
+// The library's reduction of a lane group's chains (lane = 8 sub + g; every lane takes part, sub = 0 holds the result):
+// kinds 0 and 2: ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)); kind 1 (chains in sub 0..3, mirrored in 4..7): (v0+v1) + (v2+v3).
+__device__ __forceinline__ float blas_reduce(float pj, int kind, int lane) {
+  const float o = __shfl(pj, (lane + 32) & 63);
+  const float q = kind == 1 ? pj : pj + o;
+  const float h = q + __shfl(q, (lane + 8) & 63);
+  return h + __shfl(h, (lane + 16) & 63);
+}
+
+constexpr int kBlasBlockTiles = 128;     // the library consumes the vector in blocks of 4096 elements, each reduced on its own
+static inline bool blas_general(int rows_per_band, int ktiles) { return (rows_per_band & 3) != 0 || ktiles > kBlasBlockTiles; }
 
 __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f32x4 (&x4)[2][4], float& acc, float& ss) {
 #pragma unroll
@@ -620,13 +653,18 @@ static_assert(LSHRS_SIG_COUNTERS + 3 * kFixGridG <= LSHRS_SIG_DEVICE_COUNTERS, "
 // p_j = sum over k = j (mod 8) of a_k x_k, j = 0..7, reduced as ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7)) - the
 // 8-lane AVX kernel + vextractf128 / vhaddps / vhaddps of OpenBLAS's sgemv_t (Haswell, Zen and SkylakeX builds;
 // found by search, tools/blas_order/, and checked bit for bit against `P_band @ x` of the running process before a
-// hasher uses it: lshrs_amd/hasher.py).  The eight lanes (sub) that serve one projection each own one p_j, four fmas
+// hasher uses it: lshrs_amd/_hostblas.py).  The eight lanes (sub) that serve one projection each own one p_j, four fmas
 // per k-tile from the slab in LDS: 96 steps for a 768-deep row where the canonical chain walks 768.  No tie list, no host.
+// That kernel takes a band's rows four at a time; the rows_per_band % 4 rows left over and vectors longer than the
+// library's 4096-element block are the GENERAL variant's (blas_row_kind, mul_then_add, kBlasBlockTiles).
 //
 // The slabs are double-buffered across the whole list: while slab u is read, slab u + 1 - the next slab of the same
 // eight projections or the first slab of the wave's next eight - is landing (2 x kFixSlabG LDS-DMAs per slab, always
 // exactly that many, so the waits are counted: "all but the youngest 2 x kFixSlabG").
-template <bool REPLAY>
+// GENERAL (REPLAY only): bands whose rows are not a multiple of four and vectors longer than one block of the library -
+// the lanes look up their column's kernel kind, kind-1 lanes walk both halves of every 8-element step, and the partial
+// sums are reduced and added up at every block boundary.  The common shapes (16 x 16 x 768 ...) keep the plain loop.
+template <bool REPLAY, bool GENERAL = false>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 xs[2][kFixSlabG * 8 * kFixG];
   __shared__ __attribute__((aligned(16))) f32x4 ps[2][kFixSlabG * 8 * kFixG];
@@ -687,7 +725,9 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     const int col = cur.col, e = cur.e;
     const bool live = cur.live;
     const int word = col >> 5, c = col & 31;
-    float acc = 0.f, ss = 0.f, pj = 0.f;
+    float acc = 0.f, ss = 0.f, pj = 0.f, ytot = 0.f;
+    bool blocks_done = false;
+    const int kind = GENERAL ? blas_row_kind(col % a.band_cols, a.rows_per_band) : 0;
     for (int sl = 0; sl < slabs; ++sl) {
       const int tiles = a.ktiles - sl * kFixSlabG < kFixSlabG ? a.ktiles - sl * kFixSlabG : kFixSlabG;
       bool more = true;
@@ -706,14 +746,41 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
         // 2 m + (sub >> 2), element sub & 3.  (ss: this lane's share of ||x||^2, for the tie statistics only.)
         const float* xf = reinterpret_cast<const float*>(xs[buf]);
         const float* pf = reinterpret_cast<const float*>(ps[buf]);
+        if (!GENERAL) {
 #pragma unroll 3
-        for (int t = 0; t < tiles; ++t) {
+          for (int t = 0; t < tiles; ++t) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
-            const float xv = xf[o];
-            pj = __builtin_fmaf(pf[o], xv, pj);
-            ss = __builtin_fmaf(xv, xv, ss);
+            for (int m = 0; m < 4; ++m) {
+              const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
+              const float xv = xf[o];
+              pj = __builtin_fmaf(pf[o], xv, pj);
+              ss = __builtin_fmaf(xv, xv, ss);
+            }
+          }
+        } else {
+          for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
+              const float xv = xf[o];
+              ss = __builtin_fmaf(xv, xv, ss);
+              if (kind == 1) {              // chain l = sub & 3 takes k = 8 m + l, then k = 8 m + 4 + l
+                const int o0 = ((t * 8 + 2 * m) * kFixG + g) * 4 + (sub & 3), o1 = o0 + kFixG * 4;
+                pj = mul_then_add(pj, pf[o0], xf[o0]);
+                pj = mul_then_add(pj, pf[o1], xf[o1]);
+              } else if (kind == 2) {
+                pj = mul_then_add(pj, pf[o], xv);
+              } else {
+                pj = __builtin_fmaf(pf[o], xv, pj);
+              }
+            }
+            const int tile = sl * kFixSlabG + t + 1;      // (uniform: every lane of the wave is at the same k-tile)
+            if ((tile % kBlasBlockTiles) == 0 && tile < a.ktiles) {
+              const float sblk = blas_reduce(pj, kind, lane);
+              ytot = blocks_done ? ytot + sblk : sblk;
+              blocks_done = true;
+              pj = 0.f;
+            }
           }
         }
       } else {
@@ -735,9 +802,9 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     }
     float yb = 0.f;
     if (REPLAY) {       // (every lane takes part in the shuffles; the result is used by the sub = 0 lanes)
-      const float q = pj + __shfl(pj, (lane + 32) & 63);           // sub 0..3: p_sub + p_(sub+4)
-      const float h = q + __shfl(q, (lane + 8) & 63);              // sub 0: q0 + q1, sub 2: q2 + q3
-      yb = h + __shfl(h, (lane + 16) & 63);                        // sub 0: (q0 + q1) + (q2 + q3)
+      // sub 0..3: p_sub + p_(sub+4); sub 0: q0 + q1, sub 2: q2 + q3; sub 0: (q0 + q1) + (q2 + q3)
+      yb = blas_reduce(pj, kind, lane);
+      if (GENERAL && blocks_done) yb = ytot + yb;
       float s2 = ss + __shfl(ss, (lane + 32) & 63);
       s2 += __shfl(s2, (lane + 8) & 63);
       ss = s2 + __shfl(s2, (lane + 16) & 63);
@@ -883,9 +950,11 @@ struct SmallArgs {
   int epoch;
   int n;
   float tau;
+  int rows_per_band;      // (which of the library's kernels computes a column: blas_row_kind)
+  int band_cols;
 };
 
-template <int KT>
+template <int KT, bool GENERAL>
 __global__ __launch_bounds__(64) void sig_small_kernel(const SmallArgs a) {
   static_assert(KT % 8 == 0, "the x row lands in whole 64-chunk instructions");
   __shared__ __attribute__((aligned(16))) f32x4 ps[KT * 64];
@@ -907,19 +976,27 @@ __global__ __launch_bounds__(64) void sig_small_kernel(const SmallArgs a) {
   const float* xf = reinterpret_cast<const float*>(xs);
   const float* pf = reinterpret_cast<const float*>(ps);
   float pj = 0.f, ss = 0.f, am = 0.f;
+  const int kind = GENERAL ? blas_row_kind(col % a.band_cols, a.rows_per_band) : 0;
   for (int t = 0; t < a.ktiles; ++t) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {                   // k = 32 t + 8 m + sub: chunk 2 m + (sub >> 2), element sub & 3
       const int o = t * 8 + 2 * m + (sub >> 2);
       const float xv = xf[o * 4 + (sub & 3)];
-      pj = __builtin_fmaf(pf[(o * kFixG + g) * 4 + (sub & 3)], xv, pj);
+      const float pv = pf[(o * kFixG + g) * 4 + (sub & 3)];
+      if (GENERAL && kind == 1) {                   // chain l = sub & 3: k = 8 m + l, then k = 8 m + 4 + l
+        const int o0 = t * 8 + 2 * m, o1 = o0 + 1;
+        pj = mul_then_add(pj, pf[(o0 * kFixG + g) * 4 + (sub & 3)], xf[o0 * 4 + (sub & 3)]);
+        pj = mul_then_add(pj, pf[(o1 * kFixG + g) * 4 + (sub & 3)], xf[o1 * 4 + (sub & 3)]);
+      } else if (GENERAL && kind == 2) {
+        pj = mul_then_add(pj, pv, xv);
+      } else {
+        pj = __builtin_fmaf(pv, xv, pj);
+      }
       ss = __builtin_fmaf(xv, xv, ss);
       am = __builtin_fmaxf(am, __builtin_fabsf(xv));
     }
   }
-  const float q = pj + __shfl(pj, (lane + 32) & 63);               // the library's reduction: see sig_fix8_kernel
-  const float h = q + __shfl(q, (lane + 8) & 63);
-  const float yb = h + __shfl(h, (lane + 16) & 63);
+  const float yb = blas_reduce(pj, kind, lane);                    // the library's reduction: see sig_fix8_kernel
   float s2 = ss + __shfl(ss, (lane + 32) & 63);
   s2 += __shfl(s2, (lane + 8) & 63);
   s2 += __shfl(s2, (lane + 16) & 63);
@@ -1943,6 +2020,10 @@ int lshrs_sig_set_window(void* workspace, int32_t num_bands, int32_t rows_per_ba
   const SigGeom f = sig_fine_geom(g);
   hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((f.cb + 63) / 64)), dim3(64), 0, s, w.wt, 32, f.cb,
                      const_cast<float*>(w.wtmax_fine));
+  if (sig_has_narrow_split(g)) {            // the narrow image is ONE block of 256 columns
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, w.wa, 256, 1, const_cast<float*>(w.wamax) + kNarrowMaxSlot);
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, w.wb, 256, 1, const_cast<float*>(w.wbmax) + kNarrowMaxSlot);
+  }
   return -(int)hipGetLastError();
 }
 
@@ -2073,8 +2154,8 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     a.tau = a.tau_b = 1.0f;
     a.wa = w.wa;
     a.wb = w.wb;
-    a.wamax = w.wamax;
-    a.wbmax = w.wbmax;
+    a.wamax = narrow ? w.wamax + kNarrowMaxSlot : w.wamax;
+    a.wbmax = narrow ? w.wbmax + kNarrowMaxSlot : w.wbmax;
   }
   a.row_flags = row_flags;
   a.clock_probe = o.clock_probe;
@@ -2103,6 +2184,8 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.tau = tau > 0.f ? tau : 1.0f;
   f.tie_coef = tau > 0.f ? a.norms : sig_window(base, g).wt;      // (proven tie window: coefficient per column, factor 1)
   f.blas_model = blas_model;
+  f.rows_per_band = rows_per_band;
+  f.band_cols = 8 * g.bb;
   const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
   const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
   if (blas_model != 0) {
@@ -2110,10 +2193,13 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     f.flag_y = flag_y;
     f.partials = counters + LSHRS_SIG_COUNTERS;
     f.count_ties = 1;
-    hipExtLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+    if (blas_general(rows_per_band, g.ktiles))
+      hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+    else
+      hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
   } else {
-    hipExtLaunchKernelGGL(sig_fix8_kernel<false>, grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+    hipExtLaunchKernelGGL((sig_fix8_kernel<false, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
   }
   return -(int)hipGetLastError();
 }
@@ -2182,11 +2268,14 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   f.tau = tau > 0.f ? tau : 1.0f;
   f.tie_coef = tau > 0.f ? f.norms : sig_window(base, g).wt;
   f.blas_model = blas_model;
+  f.rows_per_band = rows_per_band;
+  f.band_cols = 8 * g.bb;
   f.partials = counters + LSHRS_SIG_COUNTERS;
   {
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
-    hipLaunchKernelGGL(sig_fix8_kernel<true>, grid, block, 0, s, f);
+    if (blas_general(rows_per_band, g.ktiles)) hipLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, f);
+    else hipLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, f);
     hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
   }
   return -(int)hipGetLastError();
@@ -2221,10 +2310,18 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx, cons
   a.epoch = epoch;
   a.n = (int)n;
   a.tau = tau;
+  a.rows_per_band = rows_per_band;
+  a.band_cols = 8 * g.bb;
   const dim3 grid((unsigned)(n * row_bytes)), block(64);
-  if (g.ktiles <= 24) hipLaunchKernelGGL(sig_small_kernel<24>, grid, block, 0, s, a);
-  else if (g.ktiles <= 48) hipLaunchKernelGGL(sig_small_kernel<48>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(sig_small_kernel<128>, grid, block, 0, s, a);      // 144 KiB of LDS: one workgroup per CU
+  if ((rows_per_band & 3) == 0) {
+    if (g.ktiles <= 24) hipLaunchKernelGGL((sig_small_kernel<24, false>), grid, block, 0, s, a);
+    else if (g.ktiles <= 48) hipLaunchKernelGGL((sig_small_kernel<48, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sig_small_kernel<128, false>), grid, block, 0, s, a);      // 144 KiB of LDS: one workgroup per CU
+  } else {
+    if (g.ktiles <= 24) hipLaunchKernelGGL((sig_small_kernel<24, true>), grid, block, 0, s, a);
+    else if (g.ktiles <= 48) hipLaunchKernelGGL((sig_small_kernel<48, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((sig_small_kernel<128, true>), grid, block, 0, s, a);
+  }
   return -(int)hipGetLastError();
 }
 

@@ -122,8 +122,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
       device      torch device index / ``torch.device`` (default: current device at call time)
       tie_break   "host" (default: bytes equal the reference on this host), or "none" (raw kernel bits)
       tie_threads host tie-break workers: None = auto (this process's share of the cores, at most 8), 1 = NumPy only
-      precision   "bf16x3" (default): batches whose shape allows it (dim % 32 == 0, >= 256 key columns - or 128 with
-                  dim >= 384 -, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass - bf16 matrix cores,
+      precision   "bf16x3" (default): batches whose shape allows it (dim % 32 == 0, >= 256 key columns - or 128 .. 224
+                  with dim >= 384 -, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass - bf16 matrix cores,
                   then the exact decision for every projection inside the stage-1 window - everything else the f32
                   kernel; the keys are the same either way.  "f32": always the f32 kernel.
       tau1_ulps   stage-1 window of the split pass.  Default (None, or "bound"): the PROVEN window - per-hyperplane
@@ -203,6 +203,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         self.tau1_ulps = bound_tau1_ulps(self.dim) if tau1_ulps in (None, "bound") else float(tau1_ulps)
         self.window_info: Dict[str, object] = {}
         self._window_set: Dict[int, tuple] = {}
+        self._window_coef_cache: Dict[tuple, tuple] = {}
         self.margin_guard = float(margin_guard)
         # every audit_every-th synchronous batch (and the first): a few of the projections the device has decided are
         # re-evaluated with NumPy on the host and compared (0 = never)
@@ -345,11 +346,17 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             return
         torch = _native.require_gpu()
         lib = _native.load()
-        ca, cb, ct, info = window_coefficients(self._stacked(), int(model))
+        cached = self._window_coef_cache.get(key)         # (a hasher that alternates between engines derives each once)
+        if cached is None:
+            ca, cb, ct, info = window_coefficients(self._stacked(), int(model), self.rows_per_band)
+            cached = (np.stack([ca, cb, ct]), info)
+            self._window_coef_cache = {k: v for k, v in self._window_coef_cache.items() if k[0] == key[0]}
+            self._window_coef_cache[key] = cached
+        coef_host, info = cached
         with torch.cuda.device(dev):
             if dev.index in self._window_set:
                 torch.cuda.synchronize(dev)       # (a pass that reads the previous coefficients may still be running)
-            coef = torch.from_numpy(np.stack([ca, cb, ct])).to(dev)
+            coef = torch.from_numpy(coef_host).to(dev)
             stream = torch.cuda.current_stream(dev)
             _native.check(lib.lshrs_sig_set_window(ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
                                                    coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(),
@@ -398,7 +405,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         route, model = self._route(n, mode, aligned=x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0,
                                    short_stride=x.stride(0) < (1 << 20), host_rows=host_rows is not None,
                                    allow_pipeline=allow_pipeline)
-        self._ensure_window(dev, ws, model)
+        if route != "raw":                     # (the raw bits consult no window)
+            self._ensure_window(dev, ws, model)
         tau = self._tau_arg()
         stats["route"] = route
         if route == "split+replay":
@@ -464,7 +472,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         # name                     taken when (first match wins)
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
         ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 32 == 0, "
-                                   ">= 256 key columns or 128 with dim >= 384, hyperplane norms in range), 16-byte aligned rows"),
+                                   ">= 256 key columns or 128 .. 224 with dim >= 384, hyperplane norms in range), 16-byte aligned rows"),
         ("f32+replay",             "host BLAS order recognised, dim % 32 == 0, key rows of whole 32-bit words, aligned rows: small "
                                    "batches and shapes the split pass does not take"),
         ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists: chunks "
@@ -797,18 +805,17 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         return ok
 
     def _split_shape_check(self) -> bool:
-        lib = _native.load()
         key_cols = 8 * self.num_bands * self.band_bytes
-        # >= 256 key columns, or exactly 128 (the reference's default num_perm = 128 as 8 x 16, config 1's 16 x 4):
-        # those run on a fragment image zero-padded to 256 columns - half the matrix work wasted, still 1.5x the f32 kernel
-        if ((int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) < 256 and key_cols != 128)
-                or (self.num_bands * self.band_bytes) % 4 != 0):
+        # >= 256 key columns - or 128 .. 224 (the reference's default num_perm = 128 as 8 x 16, config 1's 16 x 4, its
+        # docstring's 20 x 6): those run on a fragment image zero-padded to 256 columns - up to half the matrix work wasted,
+        # still 1.5x the f32 kernel; key rows of whole 32-bit words (stage 2 patches bits with 32-bit atomics)
+        if key_cols < 128 or (self.num_bands * self.band_bytes) % 4 != 0:
             return False
         if self.dim > 8192:
             # the proven window widens the row norms stage 1 accumulates in f32 by 0.1 %: enough for the rounding of up to
             # ~8 k terms (4 k dot2 steps x 2^-23); longer rows keep the f32 kernel
             return False
-        if key_cols == 128 and self.dim < 384:
+        if key_cols < 225 and self.dim < 384:
             # short vectors: the padded pass's 256-column epilogue outweighs its matrix rate (1M x 128, 16 x 4:
             # 0.36 ms against 0.32 ms for the f32 kernel; 1M x 768, 8 x 16: 1.18 against 1.71 ms)
             return False
@@ -888,6 +895,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         state["_children"] = None
         state["_pool"] = None
         state["_window_set"] = {}
+        state["_window_coef_cache"] = {}
         state["_pinned_cache"] = {}
         state["_small_epoch"] = 0
         state["_pipes"] = {}
@@ -932,6 +940,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         self.__dict__.setdefault("_ctor_kwargs", {})
         self.__dict__.setdefault("multi_device_min_rows", 32_768)
         self._window_set = {}
+        self._window_coef_cache = {}
         self._lock = threading.Lock()
         self._one_lock = threading.Lock()
         self._one_queue = []

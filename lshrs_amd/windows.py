@@ -53,7 +53,30 @@ def _bf16_rne(v: np.ndarray) -> np.ndarray:
     return u.astype(np.uint32).view(np.float32)
 
 
-def window_coefficients(planes: np.ndarray, blas_model: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray, dict]:
+def host_roundings(dim: int, K: int, kinds: np.ndarray) -> np.ndarray:
+    """How many single roundings product k of row i passes in the host BLAS's evaluation (model 1, `lshrs_tb_model_row_dot`),
+    as an ``(rows, K)`` array (0 beyond ``dim``): the vector goes block by block (4096 elements); inside a block a product of
+    the 8-lane fma kernel (kind 0) is rounded by its own chain step and every later one, ``block/8 - kk//8``, then by the three
+    levels of the tree; the unfused kernels round the product itself once more (kind 2: same chains; kind 1: four chains of
+    ``block/4`` steps and a two-level tree); every block after the first adds one rounding to everything before it and to
+    itself.  (The chains' own sums are not small, so there is no two-sided charge here.)"""
+    k = np.arange(K)
+    block = k // 4096
+    nblk = (dim + 4095) // 4096
+    kk = k - 4096 * block
+    blen = np.minimum(4096, dim - 4096 * block)                     # length of the block k sits in
+    later = np.where(nblk > 1, nblk - np.maximum(block, 1), 0)      # additions of block sums this product is part of
+    fused = blen // 8 - kk // 8 + 3 + later
+    m = np.empty((len(kinds), K), dtype=np.float64)
+    m[kinds == 0] = fused
+    m[kinds == 2] = fused + 1
+    m[kinds == 1] = blen // 4 - kk // 4 + 2 + 1 + later
+    m[:, k >= dim] = 0.0
+    return m
+
+
+def window_coefficients(planes: np.ndarray, blas_model: int, rows_per_band: int = 0
+                        ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, dict]:
     """The PROVEN windows of the signature pass, as per-hyperplane coefficients (float64 arithmetic, rounded up to float32):
 
         stage 1 of the split pass:   |y1 - y_target|      <= ||x_hi|| * coef_a[j] + ||x_mid|| * coef_b[j]
@@ -61,7 +84,9 @@ def window_coefficients(planes: np.ndarray, blas_model: int) -> Tuple[np.ndarray
 
     ``x_hi = bf16(x)``, ``x_mid = bf16(x - x_hi)`` (their norms are what ``sig16_kernel`` accumulates, from the values it
     feeds the matrix cores); ``y_target`` is what decides a flagged projection: the host BLAS's value as stage 2 replays
-    it (``blas_model`` 1: eight interleaved fma chains + a three-level tree, `_hostblas.blas_order_model`) or, without a
+    it (``blas_model`` 1: eight interleaved fma chains + a three-level tree for the rows the library takes four at a time,
+    its unfused kernels for the ``rows_per_band % 4`` rows left over in every band - ``planes`` is the bands stacked, 0 = all
+    rows of the first kind -, blocks of 4096 elements: `_hostblas.blas_order_model`, `host_roundings`) or, without a
     recognised order (``blas_model`` 0: stage 2 evaluates the f32 chain and the host engine decides the ties), the host's
     value by way of the chain (both distances: whatever stage 1 does not flag must have the HOST's sign).
     Every term is an elementwise error bound summed by Cauchy-Schwarz against a per-hyperplane constant:
@@ -73,8 +98,8 @@ def window_coefficients(planes: np.ndarray, blas_model: int) -> Tuple[np.ndarray
       ``(1 + 2^-6) u max(|accumulator|, |result|)`` (the rounding and the adder's two cuts below the last place) of exact; the
       accumulator after step s is at most the sum of the |products| of steps <= s AND at most |y1| + those of steps > s, so
       a product in step s(k) of S is charged ``|s(k) - S/2|`` roundings: ``||p o c||`` is ~ S / (2 sqrt 3) ||p||, not S ||p||;
-    * the target's own rounding: product k of the BLAS's chain j passes ``dim/8 - k//8 + 3`` single roundings (model 1; the
-      chains' own sums are not small, so no two-sided charge there), of the f32 chain ``|position(k) - K/2|`` (two-sided
+    * the target's own rounding: product k of the BLAS's chain j passes ``dim/8 - k//8 + 3`` single roundings (model 1, a
+      row of the 8-lane kernel; `host_roundings` has the other rows), of the f32 chain ``|position(k) - K/2|`` (two-sided
       again: the chain's final value is the one under test); an unknown order: ``dim + 1``.
 
     Returns ``(coef_a, coef_b, coef_tie, info)``; ``info["window_units"]``: the stage-1 window of a row with
@@ -109,7 +134,15 @@ def window_coefficients(planes: np.ndarray, blas_model: int) -> Tuple[np.ndarray
     pos = 32 * t + 2 * (k % 16) + (k % 32) // 16
     m_chain = np.where(pos < K // 2, K // 2 - pos, pos - K // 2 + 1).astype(np.float64)
     if blas_model == 1 and dim % 8 == 0:
-        m_host = np.where(k < dim, dim // 8 - k // 8 + 3, 0).astype(np.float64)
+        r = int(rows_per_band)
+        if r > 0:
+            if num % r:
+                raise ValueError("planes must be whole bands of rows_per_band hyperplanes")
+            j, r4 = np.arange(num) % r, r & ~3
+            kinds = np.where(j < r4, 0, np.where(((r & 3) == 1) | (j - r4 == 2), 2, 1))
+        else:
+            kinds = np.zeros(num, dtype=np.int64)
+        m_host = host_roundings(dim, K, kinds)
     else:
         m_host = np.where(k < dim, dim + 1, 0).astype(np.float64)
     # what stage 1's value is measured against is what finally DECIDES a projection it does not flag: the replayed BLAS

@@ -92,6 +92,9 @@ def test_pure_host_entry_points(lib):
     # exactly 128 padded columns: + the 16x16x32 fragment image zero-padded to 256 columns (256 x dim bf16 hi/mid
     # = 256 x dim floats' worth), its 256 norms and their maximum (x4)
     assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (3 * 128 * 128 + 128 + 4 + 4 + 256 * 128 + 256 + 4 + 3 * 256 + 12 + 4) * 4
+    # 160 padded columns (the reference's docstring example, 20 x 6): the f32 kernel's two column blocks of 128, five fine
+    # tiles, and the same 256-column narrow image
+    assert lib.lshrs_sig_workspace_bytes(20, 6, 128) == ((256 + 160 + 256 + 256) * 128 + 256 + 4 + 8 + 256 + 4 + 3 * 256 + 12 + 8) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (2 * 32 * 32 + 32 + 4 + 3 * 256 + 12 + 4) * 4
     assert lib.lshrs_sig_set_window(None, 16, 16, 768, None, None, None, None) == -10001
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0

@@ -17,6 +17,51 @@ def _model_dot(a, x, model=1):
     return np.float32(lib.lshrs_tb_model_dot(a.ctypes.data, x.ctypes.data, a.shape[0], model))
 
 
+def _model_row_dot(a, x, row, rows, model=1):
+    lib = _hostblas.load()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return np.float32(lib.lshrs_tb_model_row_dot(a.ctypes.data, x.ctypes.data, a.shape[0], model, row, rows))
+
+
+def _literal_row_dot(a, x, kind):
+    """The order lshrs_host.h documents, spelled out: kind 0 eight fma chains, kind 2 the same chains with the product
+    rounded on its own, kind 1 four such chains; blocks of 4096 elements, each block's sum added to y."""
+    f = np.float32
+    y = None
+    for k0 in range(0, a.shape[0], 4096):
+        ab, xb = a[k0:k0 + 4096], x[k0:k0 + 4096]
+        lanes = 4 if kind == 1 else 8
+        p = np.zeros(lanes, dtype=np.float32)
+        for k in range(ab.shape[0]):
+            if kind == 0:           # (a double holds product + addend exactly unless their exponents are > 29 apart: not here)
+                p[k % lanes] = f(np.float64(ab[k]) * np.float64(xb[k]) + np.float64(p[k % lanes]))
+            else:
+                p[k % lanes] = f(p[k % lanes] + f(ab[k] * xb[k]))
+        if kind == 1:
+            s = f(f(p[0] + p[1]) + f(p[2] + p[3]))
+        else:
+            q = [f(p[j] + p[j + 4]) for j in range(4)]
+            s = f(f(q[0] + q[1]) + f(q[2] + q[3]))
+        y = s if y is None else f(y + s)
+    return y
+
+
+def test_row_kinds_and_blocks_are_the_documented_order():
+    assert _hostblas.blas_row_kinds(16).tolist() == [0] * 16
+    assert _hostblas.blas_row_kinds(5).tolist() == [0, 0, 0, 0, 2]
+    assert _hostblas.blas_row_kinds(6).tolist() == [0, 0, 0, 0, 1, 1]
+    assert _hostblas.blas_row_kinds(7).tolist() == [0, 0, 0, 0, 1, 1, 2]
+    assert _hostblas.blas_row_kinds(3).tolist() == [1, 1, 2]
+    rng = np.random.default_rng(6)
+    for dim in (64, 4096 + 64):
+        a = rng.standard_normal(dim).astype(np.float32)
+        x = rng.standard_normal(dim).astype(np.float32)
+        for row, kind in enumerate(_hostblas.blas_row_kinds(7).tolist()):
+            assert _model_row_dot(a, x, row, 7).view(np.uint32) == _literal_row_dot(a, x, kind).view(np.uint32), (dim, row)
+    assert np.isnan(_model_row_dot(a, x, 7, 7)) and np.isnan(_model_row_dot(a, x, -1, 7))
+
+
 def test_model_function_is_the_documented_order():
     rng = np.random.default_rng(5)
     a = rng.standard_normal(64).astype(np.float32)
@@ -32,7 +77,8 @@ def test_model_function_is_the_documented_order():
     assert np.isnan(_model_dot(a, x, model=2))             # unknown model
 
 
-@pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (16, 32, 1536), (16, 4, 128), (4, 12, 32)])
+@pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (16, 32, 1536), (16, 4, 128), (4, 12, 32),
+                                      (20, 10, 768), (20, 6, 128), (8, 25, 768), (10, 13, 640), (4, 7, 8192)])
 def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
     planes = np.random.default_rng(9).standard_normal((nb, r, dim)).astype(np.float32)
     model = _hostblas.blas_order_model(planes)
@@ -47,7 +93,7 @@ def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
             p = planes[b, t % r].astype(np.float64)
             x = (x - (x @ p) / (p @ p) * p).astype(np.float32)
         want = planes[b] @ x
-        got = np.array([_model_dot(planes[b, i], x) for i in range(r)], dtype=np.float32)
+        got = np.array([_model_row_dot(planes[b, i], x, i, r) for i in range(r)], dtype=np.float32)
         assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
     # the order matters on such data: a plain left-to-right f32 sum does not reproduce the library
     p = planes[0, 0].astype(np.float64)

@@ -316,6 +316,64 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     assert torch.equal(got, _hasher(42, 16, 16, 768, precision="f32").hash_device(x))
 
 
+@pytest.mark.parametrize("nb,r,dim,n,route", [
+    (20, 10, 768, 60_000, "split+replay"),      # the reference's docstring example (lshrs/core/main.py:146): 8 + 2 rows
+    (40, 5, 768, 50_000, "split+replay"),       # get_optimal_config(200, 0.5): 4 + 1 rows
+    (8, 25, 768, 50_000, "split+replay"),       # get_optimal_config(200, 0.9): 24 + 1 rows
+    (12, 23, 512, 40_000, "split+replay"),      # 20 + 3 rows: all three kernels of the library in one band
+    (16, 16, 8192, 12_000, "split+replay"),     # two blocks of the library
+    (16, 18, 4128, 9_000, "split+replay"),      # a block and a 32-element rest, 16 + 2 rows
+    (20, 6, 128, 30_000, "f32+replay"),         # lshrs/core/main.py:820's example: 4 + 2 rows
+    (10, 10, 768, 20_000, "split+replay"),      # get_optimal_config(100, 0.3): 160 key columns on the zero-padded image
+    (20, 5, 384, 20_000, "split+replay"),       # get_optimal_config(100, 0.5)
+    (28, 7, 512, 20_000, "split+replay"),       # 224 key columns
+    (10, 10, 256, 20_000, "f32+replay"),
+    (6, 11, 96, 20_000, "f32+replay"),          # 96 key columns, 8 + 3 rows
+    (4, 7, 4128, 4_000, "f32+replay"),
+])
+def test_bands_of_any_height_and_long_vectors_replay_the_hosts_own_kernels(torch_mod, nb, r, dim, n, route):
+    """The host BLAS takes a band's rows four at a time through its 8-lane fma kernel, the `rows_per_band % 4` rows left
+    over through unfused kernels of its own, and the vector in blocks of 4096 elements (lshrs_host.h,
+    `lshrs_tb_model_row_dot`): stage 2, the tie replay behind the f32 kernel and the small kernel follow it row kind by
+    row kind.  Batches salted with rows that cancel against hyperplanes of EVERY kind (true ties: only the order is left
+    of y) - same bytes as the reference-literal loop (lsh.py:200-211) and as the host engine."""
+    torch = torch_mod
+    from lshrs_amd import _hostblas
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(31, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(nb * r + dim))
+    kinds = _hostblas.blas_row_kinds(r)
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
+    # cancel every 40th row against three hyperplanes: the last rows of a band (the left-over kinds) and a first one
+    targets = [(b * r + j) for b in (0, nb // 2, nb - 1) for j in (r - 1, max(r - 2, 0), 0)]
+    special = np.arange(0, n, 40)
+    xs = x[special].cpu().numpy().astype(np.float64)
+    for i in range(special.size):
+        pl = stack[[targets[(i + t) % len(targets)] for t in range(3)]]
+        xs[i] -= (xs[i] @ np.linalg.pinv(pl)) @ pl
+    x[special] = torch.from_numpy(xs.astype(np.float32)).cuda()
+    got = h.hash_device(x)
+    st = dict(h.last_stats)
+    assert st["route"] == route and st.get("tie_break_engine") == "device-replay", st
+    assert st["tie_pairs"] > 2 * special.size, st
+    xh = x.cpu().numpy()
+    pick = np.unique(np.concatenate([special[:1500], np.arange(0, n, 7)[:1500]]))
+    want = hash_batch_literal_packed(h.projections, xh[pick])
+    assert np.array_equal(got.cpu().numpy()[pick], want), (kinds.tolist(), st)
+    hh = _hasher(31, nb, r, dim, tie_replay="off")
+    assert torch.equal(got, hh.hash_device(x))
+    if dim <= 4096:
+        # a handful of host vectors: the one-launch kernel, every projection the replayed value (the true ties among them)
+        few = xh[special[:48]]
+        assert np.array_equal(h.hash_batch_packed(few), hash_batch_literal_packed(h.projections, few))
+        assert h.last_stats.get("path") == "small-replay", h.last_stats
+        one = h.hash_vector(few[3])
+        assert one.as_tuple() == tuple(bytes(k) for k in hash_batch_literal_packed(h.projections, few[3:4])[0])
+
+
 def test_streaming_entry_point_equals_hash_device(torch_mod):
     """`hash_device_async`: the batch is enqueued at once, `result()` is the verified keys.  Same bytes as `hash_device`
     for several batches in flight, for sync and async calls mixed, for a batch whose stage-1 list overflows (verified

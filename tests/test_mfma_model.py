@@ -62,11 +62,14 @@ def _rows(rng, planes, dim):
     return np.concatenate(rows).astype(np.float32)
 
 
-@pytest.mark.parametrize("nb,r,dim,seed", [(16, 16, 768, 42), (4, 32, 1536, 7), (8, 16, 256, 3), (4, 16, 4096, 5)])
+@pytest.mark.parametrize("nb,r,dim,seed", [(16, 16, 768, 42), (4, 32, 1536, 7), (8, 16, 256, 3), (4, 16, 4096, 5),
+                                           (20, 10, 768, 11), (6, 13, 256, 3), (4, 7, 8192, 13)])
 def test_proven_window_contains_stage1s_distance_from_the_host(nb, r, dim, seed):
     """|y1 - y_host| <= ||x_hi|| coef_a + ||x_mid|| coef_b, with y1 from the accumulator model (what the kernel computes,
     bit for bit: the GPU suite checks that) and y_host = NumPy's `P_band @ x`, the reference's own call (lsh.py:200) - for
     the BLAS-order licence of THIS host when it has one (model 1), else for any summation order (model 0's host term).
+    Bands of 10, 13 and 7 rows: the rows the library's 8-lane kernel leaves over go through its unfused kernels, more
+    roundings each (`windows.host_roundings`); 8192-d: two blocks of the library.
     Also: the f32 chain's distance from the host inside ||x|| coef_tie, and how much of the window the worst row used."""
     from lshrs_amd import _hostblas
     from lshrs_amd.hasher import _bf16_rne, window_coefficients
@@ -79,7 +82,7 @@ def test_proven_window_contains_stage1s_distance_from_the_host(nb, r, dim, seed)
                   (rng.standard_normal((r, dim)) * np.exp(2 * rng.standard_normal((r, dim)))).astype(np.float32) for b in range(nb)]
     stack = np.concatenate(planes)
     model = int(_hostblas.blas_order_model(np.stack(planes)))
-    ca, cb, ct, info = window_coefficients(stack, model)
+    ca, cb, ct, info = window_coefficients(stack, model, r)
     x = _rows(rng, planes, dim)
     y1 = split_stage1_model(planes, x).astype(np.float64)
     yc = chain_project(planes, x).astype(np.float64)

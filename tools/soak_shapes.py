@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Soak of the proven windows ACROSS SHAPES: dimensions 32 .. 8192 (the split pass's whole range) and band layouts with one
+to three column blocks, padded bands, 128 key columns; per shape Gaussian rows, rows built against the window
+(tests/_adversary.py: residual-aligned and tent rows, for hyperplanes drawn at random), rows at extreme and mixed scales,
+rows dominated by one element, rows with empty k-tiles.  Every batch: split pass + proven window against the exact-f32
+kernel + proven tie window (same replay) on the whole batch, and against the reference-literal NumPy loop on a slice.
+    python tools/soak_shapes.py [rounds]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from lshrs_amd import LSHHasher
+from oracle.lshrs_oracle import hash_batch_literal_packed
+from tests._adversary import adversarial_row, tent_row
+
+SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), (8, 16, 384), (16, 4, 768), (4, 64, 512),
+          (12, 24, 768), (20, 13, 640), (64, 8, 768), (16, 16, 1024), (16, 32, 2048), (8, 32, 4096), (16, 16, 8192),
+          # bands the host BLAS does not take four rows at a time (its unfused kernels for the rest), vectors of several blocks
+          (20, 10, 768), (40, 5, 768), (8, 25, 768), (12, 23, 512), (16, 18, 4128), (20, 6, 128), (10, 10, 768), (20, 5, 384))
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    t0 = time.time()
+    rows = bad = batches = 0
+    worst = 0.0
+    for rnd in range(rounds):
+        for nb, r, dim in SHAPES:
+            rng = np.random.default_rng(7919 * rnd + 31 * dim + nb)
+            a = LSHHasher(nb, r, dim, seed=3 + rnd)
+            b = LSHHasher(nb, r, dim, seed=3 + rnd, precision="f32")
+            n = int(np.clip((24 << 20) // dim, 20_000, 200_000)) + int(rng.integers(0, 300))
+            g = torch.Generator("cuda").manual_seed(17 * rnd + dim + nb)
+            x0 = torch.randn(n, dim, device="cuda", generator=g)
+            planes = np.concatenate([np.asarray(p, dtype=np.float32) for p in a.projections])
+            built = []
+            for i in range(384):                       # rows against the window, each for a hyperplane of its own
+                p = planes[int(rng.integers(0, planes.shape[0]))]
+                make = adversarial_row if i % 3 else tent_row
+                built.append(make(p, target_units=float(rng.uniform(-40.0, 40.0)), seed=int(rng.integers(1 << 30))))
+            built = torch.from_numpy(np.stack(built)).cuda()
+            reps = (n + built.shape[0] - 1) // built.shape[0]
+            row_scale = torch.exp2(torch.randint(-30, 31, (n, 1), device="cuda", generator=g).float())
+            outlier = x0.clone()
+            outlier[torch.arange(n, device="cuda"), torch.randint(0, dim, (n,), device="cuda", generator=g)] *= 4096.0
+            holes = x0.clone()
+            for t in range(0, dim // 32, 2):
+                holes[:, 32 * t:32 * t + 32] = 0.0
+            data = {
+                "gaussian": x0,
+                "adversary": built.repeat(reps, 1)[:n] * torch.exp2(torch.randint(-3, 4, (n, 1), device="cuda", generator=g).float()),
+                "tiny_2^-30": x0 * 2.0 ** -30,
+                "huge_2^30": x0 * 2.0 ** 30,
+                "mixed_scales": x0 * row_scale,
+                "one_outlier": outlier,
+                "empty_k_tiles": holes,
+            }
+            for dname, x in data.items():
+                ka = a.hash_device(x)
+                sa = dict(a.last_stats)
+                kb = b.hash_device(x)
+                ok = torch.equal(ka, kb)
+                sl = slice(n // 3, n // 3 + 400)
+                ok_ref = np.array_equal(ka[sl].cpu().numpy(), hash_batch_literal_packed(a.projections, x[sl].cpu().numpy()))
+                used = sa.get("max_dev_units", 0.0) / a.window_info.get("window_units_worst_case_row", float("inf"))
+                worst = max(worst, used)
+                bad += (not ok) or (not ok_ref)
+                rows += n
+                batches += 1
+                print(f"round {rnd} {nb:2d}x{r:2d} dim {dim:5d} {dname:14s} n={n:6d} route={sa.get('route')} window={a.tau1_ulps:7.1f} "
+                      f"flagged={sa.get('flagged')} flips={sa.get('sign_flips')} max_dev={sa.get('max_dev_units', 0):7.1f} "
+                      f"({used:.3f} of worst-case window) {'ok' if ok and ok_ref else 'MISMATCH'}", flush=True)
+            a.close()
+            b.close()
+    print(f"shape soak: {batches} batches, {rows} rows, {bad} mismatches, largest measured deviation = {worst:.3f} of the "
+          f"worst-case-row window, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
