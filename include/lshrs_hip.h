@@ -141,8 +141,8 @@ int lshrs_sig_set_window(void* workspace, int32_t num_bands, int32_t rows_per_ba
  * Rows whose largest |x| is outside [2^-32, 2^32] are flagged wholesale.
  *   flag_list int64[flag_cap], flag_count int32[1] (zeroed by the caller): scratch, one entry per flagged
  *   projection; if *flag_count > flag_cap afterwards the pass is incomplete and must be repeated with a larger list.
- * Only for shapes with >= 256 padded columns whose key rows are whole 32-bit words (else LSHRS_E_TOOLARGE:
- * use lshrs_sig_hash_batch_f32).  Inputs that are not whole 32-deep k-tiles of 16-byte aligned rows (dim % 32,
+ * Only for shapes with >= 128 padded key columns (128 .. 224 run on an image zero-padded to 256; else LSHRS_E_TOOLARGE:
+ * use lshrs_sig_hash_batch_f32); keys in device memory, rows of any width.  Inputs that are not whole 32-deep k-tiles of 16-byte aligned rows (dim % 32,
  * ldx % 4, X % 16) are handed to lshrs_sig_hash_batch_f32 by the library itself (same keys). */
 int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
                                    const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
@@ -182,8 +182,8 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
  * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  counters: the int32[LSHRS_SIG_DEVICE_COUNTERS] block
  * whose element [0] was the f32 kernel's tie_count; [1] receives the items expanded.  host_counts (optional, pinned
  * host int32[LSHRS_SIG_COUNTERS]) receives the block, which is left zeroed; [0] > tie_cap or [1] > flag_cap: repeat
- * the pass with room.  Needs dim % 32 == 0, 16-byte aligned rows and key rows of whole 32-bit words (else
- * LSHRS_E_TOOLARGE: resolve on the host). */
+ * the pass with room.  Needs dim % 32 == 0 and 16-byte aligned rows (else LSHRS_E_TOOLARGE: resolve on the host); keys in
+ * device memory, rows of any width (bits are patched with 32-bit atomics on the aligned word around the byte). */
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
                                        const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
                                        uint8_t* keys, const int64_t* tie_list, int32_t tie_cap, int32_t* counters,

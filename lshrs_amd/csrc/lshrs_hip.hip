@@ -2104,9 +2104,11 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   if (tie_list != nullptr && (tie_count == nullptr || tie_cap < 0)) return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
-  // the second stage patches key bits with 32-bit atomics: rows must be whole words
+  // (the second stage patches key bits with 32-bit atomics on the ALIGNED word around the byte: a word that straddles two
+  //  rows, or the end of the buffer, shares its page with a byte that is ours, and the bits that are not ours go back as
+  //  they came - key rows of any width, keys at any address)
   const bool narrow = sig_has_narrow_split(g);
-  if ((!sig_has_split(g) && !narrow) || row_bytes % 4 != 0 || (reinterpret_cast<uintptr_t>(keys) & 3)) return LSHRS_E_TOOLARGE;
+  if (!sig_has_split(g) && !narrow) return LSHRS_E_TOOLARGE;
   const int64_t row_tiles = (n + 255) / 256;
   const int64_t wgs = (row_tiles + 7) / 8 * 8 * g.cb;
   if (n >= ((int64_t)1 << 42) || wgs > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
@@ -2236,9 +2238,8 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
     return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
-  // stage 2 stages whole 32-deep k-tiles of 16-byte aligned rows and patches key bits with 32-bit atomics
-  if (dim % 32 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || row_bytes % 4 != 0 ||
-      (reinterpret_cast<uintptr_t>(keys) & 3) != 0 || n >= ((int64_t)1 << 42))
+  // stage 2 stages whole 32-deep k-tiles of 16-byte aligned rows (key rows may have any width: split_pass's comment)
+  if (dim % 32 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || n >= ((int64_t)1 << 42))
     return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);

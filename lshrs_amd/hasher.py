@@ -473,7 +473,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
         ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 32 == 0, "
                                    ">= 256 key columns or 128 .. 224 with dim >= 384, hyperplane norms in range), 16-byte aligned rows"),
-        ("f32+replay",             "host BLAS order recognised, dim % 32 == 0, key rows of whole 32-bit words, aligned rows: small "
+        ("f32+replay",             "host BLAS order recognised, dim % 32 == 0, aligned rows: small "
                                    "batches and shapes the split pass does not take"),
         ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists: chunks "
                                    "overlapped by csrc/pipeline.hip, ties by the library's own sgemv"),
@@ -489,7 +489,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         if model and aligned:
             if short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
-            if self.dim % 32 == 0 and (self.num_bands * self.band_bytes) % 4 == 0:
+            if self.dim % 32 == 0:
                 return "f32+replay", model
         if (allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
                 and self._tie_engine() is not None):
@@ -808,8 +808,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         key_cols = 8 * self.num_bands * self.band_bytes
         # >= 256 key columns - or 128 .. 224 (the reference's default num_perm = 128 as 8 x 16, config 1's 16 x 4, its
         # docstring's 20 x 6): those run on a fragment image zero-padded to 256 columns - up to half the matrix work wasted,
-        # still 1.5x the f32 kernel; key rows of whole 32-bit words (stage 2 patches bits with 32-bit atomics)
-        if key_cols < 128 or (self.num_bands * self.band_bytes) % 4 != 0:
+        # still 1.5x the f32 kernel
+        if key_cols < 128:
             return False
         if self.dim > 8192:
             # the proven window widens the row norms stage 1 accumulates in f32 by 0.1 %: enough for the rounding of up to

@@ -213,7 +213,9 @@ def test_route_table():
         assert h._route(255, "host", **ok) == ("f32+replay", 1)                      # below replay_min_rows
         assert h._route(1_000_000, "host", aligned=True, short_stride=False, host_rows=False) == ("f32+replay", 1)
         assert LSHHasher(16, 4, 128, seed=1)._route(1_000_000, "host", **ok) == ("f32+replay", 1)   # 128 key columns, short rows
-        assert LSHHasher(5, 12, 64, seed=1)._route(5_000, "host", **ok) == ("plain", 0)             # 10 key bytes: not whole words
+        assert LSHHasher(5, 12, 64, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)        # 10 key bytes: any row width
+        assert LSHHasher(25, 8, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)     # 25 key bytes, 200 key columns
+        assert LSHHasher(20, 10, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 + 2 rows per band
         assert LSHHasher(16, 16, 100, seed=1)._route(5_000, "host", **ok) == ("plain", 0)           # dim % 32 != 0
     off = LSHHasher(16, 16, 768, seed=42, tie_replay="off")
     big = off._route(1_000_000, "host", **ok)

@@ -329,6 +329,11 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     (28, 7, 512, 20_000, "split+replay"),       # 224 key columns
     (10, 10, 256, 20_000, "f32+replay"),
     (6, 11, 96, 20_000, "f32+replay"),          # 96 key columns, 8 + 3 rows
+    (25, 8, 768, 30_001, "split+replay"),       # get_optimal_config(200, ...)-like: 25 key bytes per row - words straddle rows
+    (5, 20, 768, 20_003, "f32+replay"),         # get_optimal_config(100, 0.9): 15 key bytes, 120 key columns
+    (10, 20, 512, 20_001, "split+replay"),      # get_optimal_config(200, 0.3): 30 key bytes
+    (5, 11, 96, 20_001, "f32+replay"),          # 10 key bytes
+    (3, 5, 64, 1_001, "f32+replay"),            # 3 key bytes
     (4, 7, 4128, 4_000, "f32+replay"),
 ])
 def test_bands_of_any_height_and_long_vectors_replay_the_hosts_own_kernels(torch_mod, nb, r, dim, n, route):

@@ -20,7 +20,9 @@ from tests._adversary import adversarial_row, tent_row
 SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), (8, 16, 384), (16, 4, 768), (4, 64, 512),
           (12, 24, 768), (20, 13, 640), (64, 8, 768), (16, 16, 1024), (16, 32, 2048), (8, 32, 4096), (16, 16, 8192),
           # bands the host BLAS does not take four rows at a time (its unfused kernels for the rest), vectors of several blocks
-          (20, 10, 768), (40, 5, 768), (8, 25, 768), (12, 23, 512), (16, 18, 4128), (20, 6, 128), (10, 10, 768), (20, 5, 384))
+          (20, 10, 768), (40, 5, 768), (8, 25, 768), (12, 23, 512), (16, 18, 4128), (20, 6, 128), (10, 10, 768), (20, 5, 384),
+          # key rows that are not whole 32-bit words (stage 2's atomics straddle rows)
+          (25, 8, 768), (5, 20, 768), (10, 20, 512), (5, 11, 96), (3, 5, 64), (7, 9, 1024))
 
 
 def main():
