@@ -182,7 +182,8 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
  * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  counters: the int32[LSHRS_SIG_DEVICE_COUNTERS] block
  * whose element [0] was the f32 kernel's tie_count; [1] receives the items expanded.  host_counts (optional, pinned
  * host int32[LSHRS_SIG_COUNTERS]) receives the block, which is left zeroed; [0] > tie_cap or [1] > flag_cap: repeat
- * the pass with room.  Needs dim % 32 == 0 and 16-byte aligned rows (else LSHRS_E_TOOLARGE: resolve on the host); keys in
+ * the pass with room.  Needs dim % 4 == 0, dim >= 8 (8 m + 4 elements: up to 4096) and 16-byte aligned rows (else
+ * LSHRS_E_TOOLARGE: resolve on the host); only `dim` elements of a row are ever fetched; keys in
  * device memory, rows of any width (bits are patched with 32-bit atomics on the aligned word around the byte). */
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
                                        const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
@@ -203,8 +204,9 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
  *                projections inside the tie window (a statistic: they are decided like all others) and then [1] := epoch,
  *                after a system-scope fence - a caller that polls [1] for its epoch needs neither a copy nor a stream
  *                wait to read keys and flags it placed in pinned memory.  NULL: wait on the stream instead.
- * n <= LSHRS_SMALL_MAX_ROWS, dim % 32 == 0, dim <= 4096, 16-byte aligned rows (else LSHRS_E_TOOLARGE: use the batch
- * entry points). */
+ * n <= LSHRS_SMALL_MAX_ROWS, dim % 4 == 0, 8 <= dim <= 4096, 16-byte aligned rows, ldx >= 32 * ceil(dim / 32): the kernel
+ * fetches whole 32-element k-tiles of every row and uses `dim` elements of them - the caller pads its rows (else
+ * LSHRS_E_TOOLARGE: use the batch entry points). */
 #define LSHRS_SMALL_MAX_ROWS 256
 int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx,
                                     const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,

@@ -141,13 +141,14 @@ class _HostPaths:
         flags straight into pinned host memory and its last workgroup publishes this call's epoch there - the host
         polls that word: no copy back, no stream wait; above, one asynchronous copy back and one wait (the per-workgroup
         system-scope fences of the polled form cost more than they save there).  Returns None where the replay does not
-        apply (host tie-break engine, ``dim % 32``, ``dim > 4096``): the general path then does the work."""
+        apply (host tie-break engine, ``dim % 4``, ``dim > 4096``): the general path then does the work."""
         torch = _native.require_gpu()
         lib = _native.load()
         n = arr.shape[0]
         rb = self.num_bands * self.band_bytes
-        if self.tie_replay != "auto" or self.dim % 32 != 0 or self.dim > 4096:
+        if self.tie_replay != "auto" or self.dim % 4 != 0 or self.dim < 8 or self.dim > 4096:
             return None
+        ldx = (self.dim + 31) // 32 * 32          # (the kernel fetches whole k-tiles: rows padded with zeros, never used)
         model = self._replay_model()
         if not model:
             return None
@@ -157,9 +158,9 @@ class _HostPaths:
         if buf is None:
             tail = (cap * rb + cap + 15) // 16 * 16              # keys | flags | pad, then 4 int32: ties (device form), done[2]
             pin_out = torch.zeros(tail + 16, dtype=torch.uint8).pin_memory()
-            pin_x = torch.zeros((cap, self.dim), dtype=torch.float32).pin_memory()
+            pin_x = torch.zeros((cap, ldx), dtype=torch.float32).pin_memory()
             with torch.cuda.device(dev):
-                x_dev = torch.empty((cap, self.dim), dtype=torch.float32, device=dev)
+                x_dev = torch.zeros((cap, ldx), dtype=torch.float32, device=dev)
                 dev_out = torch.zeros(tail + 16, dtype=torch.uint8, device=dev)
                 counters = torch.zeros(64 * (1 + _native.SMALL_MAX_ROWS), dtype=torch.int32, device=dev)
                 torch.cuda.current_stream(dev).synchronize()
@@ -171,7 +172,7 @@ class _HostPaths:
         pin_out, host_out, words, pin_x, x_dev = buf["pin_out"], buf["host_out"], buf["words"], buf["pin_x"], buf["x_dev"]
         tail = buf["tail"]
         ws = self._workspace(dev)
-        buf["host_x"][:n] = arr
+        buf["host_x"][:n, :self.dim] = arr
         poll = n * rb <= self._small_poll_bytes
         ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
         with ctx:
@@ -186,7 +187,7 @@ class _HostPaths:
                 epoch = self._small_epoch = self._small_epoch % 0x7FFFFFF0 + 1
                 base = pin_out.data_ptr()
                 _native.check(
-                    lib.lshrs_sig_hash_small_replay_f32(x_ptr, n, self.dim, ws.data_ptr(), self.num_bands,
+                    lib.lshrs_sig_hash_small_replay_f32(x_ptr, n, ldx, ws.data_ptr(), self.num_bands,
                                                         self.rows_per_band, self.dim, base, base + cap * rb,
                                                         buf["counters"].data_ptr(), tau, model, base + tail + 4, epoch,
                                                         cur.cuda_stream), "lshrs_sig_hash_small_replay_f32")
@@ -203,7 +204,7 @@ class _HostPaths:
                 dev_out = buf["dev_out"]
                 base = dev_out.data_ptr()                        # (counter [0] lives in the block that comes back: it only grows)
                 _native.check(
-                    lib.lshrs_sig_hash_small_replay_f32(x_ptr, n, self.dim, ws.data_ptr(), self.num_bands,
+                    lib.lshrs_sig_hash_small_replay_f32(x_ptr, n, ldx, ws.data_ptr(), self.num_bands,
                                                         self.rows_per_band, self.dim, base, base + cap * rb, base + tail,
                                                         tau, model, None, 0, cur.cuda_stream),
                     "lshrs_sig_hash_small_replay_f32")

@@ -170,7 +170,7 @@ def blas_order_model(planes: np.ndarray) -> int:
         return _order_models[key]
     model = 0
     try:
-        if dim % 8 == 0 and os.path.exists(LIBRARY):
+        if dim % 4 == 0 and (dim % 8 == 0 or dim <= 4096) and os.path.exists(LIBRARY):
             lib = load()
             rng = np.random.default_rng(20240601)
             bands = sorted({0, nb // 2, nb - 1})

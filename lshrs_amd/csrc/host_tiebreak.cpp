@@ -247,8 +247,10 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
 //     through the 4x2 kernel ("kind 1": four chains over k = l (mod 4), reduced (v0+v1) + (v2+v3)), a single row -
 //     the only one left, or the third of three - through the 4x1 kernel ("kind 2": the eight chains and the tree of
 //     kind 0, unfused);
-//   * the vector is consumed in blocks of 4096 elements: every block's sum is reduced on its own and added to y.
-// n must be a multiple of 8.  Found by search (tools/blas_order/); the caller (lshrs_amd/_hostblas.py) compares it bit for
+//   * the vector is consumed in blocks of 4096 elements: every block's sum is reduced on its own and added to y;
+//   * a vector of 8 m + 4 elements (300-d, 100-d): the 8-lane kernels take the first four with their low lanes and then
+//     eight at a time from the fifth (modelled for n <= 4096).
+// n must be a multiple of 4.  Found by search (tools/blas_order/); the caller (lshrs_amd/_hostblas.py) compares it bit for
 // bit with `P_band @ x` of the running process, row kind by row kind, before the device replay may stand in for the host.
 static inline int tb_row_kind(int row, int rows) {
   const int r4 = rows & ~3;
@@ -257,8 +259,9 @@ static inline int tb_row_kind(int row, int rows) {
 }
 
 float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band) {
-  if (model != 1 || a == nullptr || x == nullptr || n <= 0 || n % 8 != 0 || row < 0 || row >= rows_per_band)
+  if (model != 1 || a == nullptr || x == nullptr || n <= 0 || n % 4 != 0 || row < 0 || row >= rows_per_band)
     return __builtin_nanf("");
+  if (n % 8 != 0 && n > 4096) return __builtin_nanf("");     // (a short last block behind full ones: not modelled)
   const int kind = tb_row_kind(row, rows_per_band);
   float y = 0.f;
   for (int64_t k0 = 0; k0 < n; k0 += 4096) {
@@ -275,12 +278,18 @@ float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t 
         }
       s = (v[0] + v[1]) + (v[2] + v[3]);
     } else {
+      // a block of 8 m + 4 elements: the 8-lane kernels take the FIRST four with their low lanes, then eight at a time
       float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const int64_t head = kn % 8;
+      for (int64_t j = 0; j < head; ++j) {
+        const volatile float prod = ab[j] * xb[j];                // (fma(a, x, 0) and 0 + fl(a x) are the same value)
+        p[j] = prod;
+      }
       if (kind == 0) {
-        for (int64_t k = 0; k < kn; k += 8)
+        for (int64_t k = head; k < kn; k += 8)
           for (int j = 0; j < 8; ++j) p[j] = __builtin_fmaf(ab[k + j], xb[k + j], p[j]);
       } else {
-        for (int64_t k = 0; k < kn; k += 8)
+        for (int64_t k = head; k < kn; k += 8)
           for (int j = 0; j < 8; ++j) {
             const volatile float prod = ab[k + j] * xb[k + j];
             p[j] = p[j] + prod;

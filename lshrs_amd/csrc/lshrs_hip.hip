@@ -614,7 +614,9 @@ __device__ __forceinline__ float blas_reduce(float pj, int kind, int lane) {
 }
 
 constexpr int kBlasBlockTiles = 128;     // the library consumes the vector in blocks of 4096 elements, each reduced on its own
-static inline bool blas_general(int rows_per_band, int ktiles) { return (rows_per_band & 3) != 0 || ktiles > kBlasBlockTiles; }
+static inline bool blas_general(int rows_per_band, int ktiles, int dim) {
+  return (rows_per_band & 3) != 0 || ktiles > kBlasBlockTiles || dim % kKTile != 0;
+}
 
 __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f32x4 (&x4)[2][4], float& acc, float& ss) {
 #pragma unroll
@@ -661,9 +663,12 @@ static_assert(LSHRS_SIG_COUNTERS + 3 * kFixGridG <= LSHRS_SIG_DEVICE_COUNTERS, "
 // The slabs are double-buffered across the whole list: while slab u is read, slab u + 1 - the next slab of the same
 // eight projections or the first slab of the wave's next eight - is landing (2 x kFixSlabG LDS-DMAs per slab, always
 // exactly that many, so the waits are counted: "all but the youngest 2 x kFixSlabG").
-// GENERAL (REPLAY only): bands whose rows are not a multiple of four and vectors longer than one block of the library -
-// the lanes look up their column's kernel kind, kind-1 lanes walk both halves of every 8-element step, and the partial
-// sums are reduced and added up at every block boundary.  The common shapes (16 x 16 x 768 ...) keep the plain loop.
+// GENERAL (REPLAY only): bands whose rows are not a multiple of four, vectors longer than one block of the library and
+// vectors that are not whole 32-deep k-tiles - the lanes look up their column's kernel kind, kind-1 lanes walk both halves
+// of every 8-element step, the partial sums are reduced and added up at every block boundary, chunks past the row's end
+// are fetched from its start and read as zero, and a vector of 8 m + 4 elements gives its first four to the low lanes
+// before the tiles begin AT the fifth (the library's order: lshrs_tb_model_row_dot).  The common shapes (16 x 16 x 768 ...)
+// keep the plain loop.
 template <bool REPLAY, bool GENERAL = false>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   __shared__ __attribute__((aligned(16))) f32x4 xs[2][kFixSlabG * 8 * kFixG];
@@ -673,12 +678,15 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   const int cnt = min(*a.flag_count, a.flag_cap);
   const int groups = (cnt + kFixG - 1) / kFixG;
   const size_t ldp = (size_t)a.ktiles * kKTile;
-  const int slabs = (a.ktiles + kFixSlabG - 1) / kFixSlabG;
+  const int head = GENERAL ? (a.dim & 4) : 0;                 // 8 m + 4 elements: the first four go ahead of the tiles
+  const int body = GENERAL ? a.dim - head : a.ktiles * kKTile; // elements the tiles cover (from element `head` on)
+  const int kt = GENERAL ? (body + kKTile - 1) / kKTile : a.ktiles;
+  const int slabs = (kt + kFixSlabG - 1) / kFixSlabG;
   // statistics are kept per lane and leave the wave once, at the end (one atomic per flagged projection on a single
   // address serialises the whole kernel as soon as the list is long)
   int n_ties = 0, n_flips = 0;
   float max_dev = 0.f;
-  struct Item { int64_t row; int col; bool live; const float* xg; const float* pg; int e; };
+  struct Item { int64_t row; int col; bool live; const float* xg; const float* pg; const float* xrow; int e; };
   auto fetch = [&](int grp) {                       // list entry g of group grp (a short last group re-does its first entry, unused)
     Item it;
     it.e = grp * kFixG + g;
@@ -687,8 +695,9 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     const int col_raw = (int)(item & ((1 << 21) - 1));
     it.live = it.e < cnt && col_raw < a.padcols;
     it.col = col_raw < a.padcols ? col_raw : 0;
-    it.xg = a.X + it.row * a.ldx + 16 * shh + 4 * sq;
-    it.pg = a.prow + (size_t)it.col * ldp + 16 * shh + 4 * sq;
+    it.xrow = a.X + it.row * a.ldx;
+    it.xg = it.xrow + head + 16 * shh + 4 * sq;
+    it.pg = a.prow + (size_t)it.col * ldp + head + 16 * shh + 4 * sq;
 #ifdef LSHRS_AB_FIX_SAME_P        // (A/B builds only: what a list sorted by column would make of the hyperplane stream - wrong keys by design)
     {
       const int c0 = (int)(a.flag_list[grp * kFixG < cnt ? grp * kFixG : 0] & ((1 << 21) - 1));
@@ -700,10 +709,11 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   auto issue = [&](const Item& it, int slab, int buf) {   // nothing lands in a VGPR; tiles past the row's end re-fetch its last
 #pragma unroll
     for (int i = 0; i < kFixSlabG; ++i) {
-      const int t = slab * kFixSlabG + i < a.ktiles ? slab * kFixSlabG + i : a.ktiles - 1;
+      const int t = slab * kFixSlabG + i < kt ? slab * kFixSlabG + i : kt - 1;
 #ifndef LSHRS_AB_FIX_NO_X        // (A/B builds only: which of the two streams bounds stage 2 - wrong keys by design)
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.xg + (size_t)t * kKTile), (LDS_AS void*)(xs[buf] + i * 64),
-                                       16, 0, 0);
+      const float* xsrc = it.xg + (size_t)t * kKTile;
+      if (GENERAL && t * kKTile + 16 * shh + 4 * sq >= body) xsrc = it.xrow;      // past the row's end: never read, never used
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)xsrc, (LDS_AS void*)(xs[buf] + i * 64), 16, 0, 0);
 #endif
 #ifndef LSHRS_AB_FIX_NO_P
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.pg + (size_t)t * kKTile), (LDS_AS void*)(ps[buf] + i * 64),
@@ -728,8 +738,18 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     float acc = 0.f, ss = 0.f, pj = 0.f, ytot = 0.f;
     bool blocks_done = false;
     const int kind = GENERAL ? blas_row_kind(col % a.band_cols, a.rows_per_band) : 0;
+    if (GENERAL && head != 0) {
+      // the library's 8-lane kernels take elements 0..3 with their low lanes (chains 0..3) before anything else; its 4-lane
+      // kernel (kind 1: chains in sub 0..3, mirrored in 4..7) simply starts there.  fl(p x): the first link of either chain.
+      const int hl = kind == 1 ? (sub & 3) : sub;
+      if (hl < 4) {
+        const float hx = cur.xrow[hl];
+        pj = a.prow[(size_t)col * ldp + hl] * hx;
+        if (sub < 4) ss = hx * hx;
+      }
+    }
     for (int sl = 0; sl < slabs; ++sl) {
-      const int tiles = a.ktiles - sl * kFixSlabG < kFixSlabG ? a.ktiles - sl * kFixSlabG : kFixSlabG;
+      const int tiles = kt - sl * kFixSlabG < kFixSlabG ? kt - sl * kFixSlabG : kFixSlabG;
       bool more = true;
       if (sl + 1 < slabs) issue(cur, sl + 1, buf ^ 1);
       else if (has_next) issue(nxt, 0, buf ^ 1);
@@ -759,15 +779,17 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
           }
         } else {
           for (int t = 0; t < tiles; ++t) {
+            const int kb0 = (sl * kFixSlabG + t) * kKTile;      // first element of this tile, counted from `head`
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
               const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
-              const float xv = xf[o];
+              const float xv = kb0 + 8 * m + sub < body ? xf[o] : 0.f;      // (past the row's end: zero, as the hyperplane is)
               ss = __builtin_fmaf(xv, xv, ss);
               if (kind == 1) {              // chain l = sub & 3 takes k = 8 m + l, then k = 8 m + 4 + l
                 const int o0 = ((t * 8 + 2 * m) * kFixG + g) * 4 + (sub & 3), o1 = o0 + kFixG * 4;
-                pj = mul_then_add(pj, pf[o0], xf[o0]);
-                pj = mul_then_add(pj, pf[o1], xf[o1]);
+                const int kl = kb0 + 8 * m + (sub & 3);
+                pj = mul_then_add(pj, pf[o0], kl < body ? xf[o0] : 0.f);
+                pj = mul_then_add(pj, pf[o1], kl + 4 < body ? xf[o1] : 0.f);
               } else if (kind == 2) {
                 pj = mul_then_add(pj, pf[o], xv);
               } else {
@@ -775,7 +797,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
               }
             }
             const int tile = sl * kFixSlabG + t + 1;      // (uniform: every lane of the wave is at the same k-tile)
-            if ((tile % kBlasBlockTiles) == 0 && tile < a.ktiles) {
+            if ((tile % kBlasBlockTiles) == 0 && tile < kt) {
               const float sblk = blas_reduce(pj, kind, lane);
               ytot = blocks_done ? ytot + sblk : sblk;
               blocks_done = true;
@@ -952,6 +974,7 @@ struct SmallArgs {
   float tau;
   int rows_per_band;      // (which of the library's kernels computes a column: blas_row_kind)
   int band_cols;
+  int dim;                // (GENERAL: rows that are not whole k-tiles - X is readable, not used, up to 32 * ktiles per row)
 };
 
 template <int KT, bool GENERAL>
@@ -963,30 +986,49 @@ __global__ __launch_bounds__(64) void sig_small_kernel(const SmallArgs a) {
   const int row = blockIdx.x / a.row_bytes, byte = blockIdx.x % a.row_bytes;
   const int col = 8 * byte + g;
   const size_t ldp = (size_t)a.ktiles * kKTile;
-  const float* pg = a.prow + (size_t)col * ldp + 4 * sub;
+  // GENERAL: a row of 8 m + 4 elements gives its first four to the low lanes before the tiles begin at the fifth, and the
+  // elements past its end read as zero (sig_fix8_kernel's comment); the x row sits in LDS from element 0 either way
+  const int head = GENERAL ? (a.dim & 4) : 0, hq = head >> 2;
+  const int body = GENERAL ? a.dim - head : a.ktiles * kKTile;
+  const int kt = GENERAL ? (body + kKTile - 1) / kKTile : a.ktiles;
+  const float* pg = a.prow + (size_t)col * ldp + head + 4 * sub;
   const float* xg = a.X + (int64_t)row * a.ldx;
   const int xchunks = a.ktiles * 8;
   for (int b = 0; b * 64 < xchunks; ++b) {          // lanes past the row's end re-fetch its last chunk (lands unused)
     const int c = b * 64 + lane < xchunks ? b * 64 + lane : xchunks - 1;
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xg + 4 * c), (LDS_AS void*)(xs + b * 64), 16, 0, 0);
   }
-  for (int t = 0; t < a.ktiles; ++t)
+  for (int t = 0; t < kt; ++t)
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(pg + (size_t)t * kKTile), (LDS_AS void*)(ps + t * 64), 16, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const float* xf = reinterpret_cast<const float*>(xs);
   const float* pf = reinterpret_cast<const float*>(ps);
   float pj = 0.f, ss = 0.f, am = 0.f;
   const int kind = GENERAL ? blas_row_kind(col % a.band_cols, a.rows_per_band) : 0;
-  for (int t = 0; t < a.ktiles; ++t) {
+  if (GENERAL && head != 0) {
+    const int hl = kind == 1 ? (sub & 3) : sub;
+    if (hl < 4) {
+      const float hx = xf[hl];
+      pj = a.prow[(size_t)col * ldp + hl] * hx;
+      if (sub < 4) {
+        ss = hx * hx;
+        am = __builtin_fabsf(hx);
+      }
+    }
+  }
+  for (int t = 0; t < kt; ++t) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {                   // k = 32 t + 8 m + sub: chunk 2 m + (sub >> 2), element sub & 3
+    for (int m = 0; m < 4; ++m) {                   // k = head + 32 t + 8 m + sub: chunk 2 m + (sub >> 2), element sub & 3
       const int o = t * 8 + 2 * m + (sub >> 2);
-      const float xv = xf[o * 4 + (sub & 3)];
+      const int ox = GENERAL ? (o + hq < xchunks ? o + hq : xchunks - 1) : o;
+      const float xv = (!GENERAL || t * kKTile + 8 * m + sub < body) ? xf[ox * 4 + (sub & 3)] : 0.f;
       const float pv = pf[(o * kFixG + g) * 4 + (sub & 3)];
       if (GENERAL && kind == 1) {                   // chain l = sub & 3: k = 8 m + l, then k = 8 m + 4 + l
         const int o0 = t * 8 + 2 * m, o1 = o0 + 1;
-        pj = mul_then_add(pj, pf[(o0 * kFixG + g) * 4 + (sub & 3)], xf[o0 * 4 + (sub & 3)]);
-        pj = mul_then_add(pj, pf[(o1 * kFixG + g) * 4 + (sub & 3)], xf[o1 * 4 + (sub & 3)]);
+        const int kl = t * kKTile + 8 * m + (sub & 3);
+        const int x0 = o0 + hq < xchunks ? o0 + hq : xchunks - 1, x1 = o1 + hq < xchunks ? o1 + hq : xchunks - 1;
+        pj = mul_then_add(pj, pf[(o0 * kFixG + g) * 4 + (sub & 3)], kl < body ? xf[x0 * 4 + (sub & 3)] : 0.f);
+        pj = mul_then_add(pj, pf[(o1 * kFixG + g) * 4 + (sub & 3)], kl + 4 < body ? xf[x1 * 4 + (sub & 3)] : 0.f);
       } else if (GENERAL && kind == 2) {
         pj = mul_then_add(pj, pv, xv);
       } else {
@@ -2195,7 +2237,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     f.flag_y = flag_y;
     f.partials = counters + LSHRS_SIG_COUNTERS;
     f.count_ties = 1;
-    if (blas_general(rows_per_band, g.ktiles))
+    if (blas_general(rows_per_band, g.ktiles, dim))
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     else
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
@@ -2238,8 +2280,9 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
     return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
-  // stage 2 stages whole 32-deep k-tiles of 16-byte aligned rows (key rows may have any width: split_pass's comment)
-  if (dim % 32 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || n >= ((int64_t)1 << 42))
+  // stage 2 stages 16-byte chunks of 16-byte aligned rows (key rows may have any width: split_pass's comment)
+  if (dim % 4 != 0 || dim < 8 || (dim % 8 != 0 && dim > 4096) || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 ||
+      n >= ((int64_t)1 << 42))
     return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
@@ -2275,7 +2318,7 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   {
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
-    if (blas_general(rows_per_band, g.ktiles)) hipLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, f);
+    if (blas_general(rows_per_band, g.ktiles, dim)) hipLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, f);
     else hipLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, f);
     hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
   }
@@ -2292,8 +2335,10 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx, cons
     return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
-  if (dim % 32 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || g.ktiles > 128 ||
-      n > LSHRS_SMALL_MAX_ROWS || n * row_bytes > 0x7fffffffLL)
+  // (rows that are not whole k-tiles: the kernel fetches 32 * ktiles floats of every row - the caller pads the rows - and
+  //  uses `dim` of them)
+  if (dim % 4 != 0 || dim < 8 || ldx < (int64_t)g.ktiles * kKTile || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 ||
+      g.ktiles > 128 || n > LSHRS_SMALL_MAX_ROWS || n * row_bytes > 0x7fffffffLL)
     return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
@@ -2313,8 +2358,9 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx, cons
   a.tau = tau;
   a.rows_per_band = rows_per_band;
   a.band_cols = 8 * g.bb;
+  a.dim = dim;
   const dim3 grid((unsigned)(n * row_bytes)), block(64);
-  if ((rows_per_band & 3) == 0) {
+  if (!blas_general(rows_per_band, g.ktiles, dim)) {
     if (g.ktiles <= 24) hipLaunchKernelGGL((sig_small_kernel<24, false>), grid, block, 0, s, a);
     else if (g.ktiles <= 48) hipLaunchKernelGGL((sig_small_kernel<48, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((sig_small_kernel<128, false>), grid, block, 0, s, a);      // 144 KiB of LDS: one workgroup per CU

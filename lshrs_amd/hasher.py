@@ -473,7 +473,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
         ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 32 == 0, "
                                    ">= 256 key columns or 128 .. 224 with dim >= 384, hyperplane norms in range), 16-byte aligned rows"),
-        ("f32+replay",             "host BLAS order recognised, dim % 32 == 0, aligned rows: small "
+        ("f32+replay",             "host BLAS order recognised, dim % 4 == 0, aligned rows: small "
                                    "batches and shapes the split pass does not take"),
         ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists: chunks "
                                    "overlapped by csrc/pipeline.hip, ties by the library's own sgemv"),
@@ -489,7 +489,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         if model and aligned:
             if short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
-            if self.dim % 32 == 0:
+            if self.dim % 4 == 0 and self.dim >= 8:      # (the model's own limits - 8 m + 4 elements only up to 4096 - are in `model`)
                 return "f32+replay", model
         if (allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
                 and self._tie_engine() is not None):

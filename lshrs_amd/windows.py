@@ -66,7 +66,7 @@ def host_roundings(dim: int, K: int, kinds: np.ndarray) -> np.ndarray:
     kk = k - 4096 * block
     blen = np.minimum(4096, dim - 4096 * block)                     # length of the block k sits in
     later = np.where(nblk > 1, nblk - np.maximum(block, 1), 0)      # additions of block sums this product is part of
-    fused = blen // 8 - kk // 8 + 3 + later
+    fused = (blen + 7) // 8 - kk // 8 + 3 + later              # (a block of 8 m + 4 elements: its first four go first, one step more)
     m = np.empty((len(kinds), K), dtype=np.float64)
     m[kinds == 0] = fused
     m[kinds == 2] = fused + 1
@@ -133,7 +133,7 @@ def window_coefficients(planes: np.ndarray, blas_model: int, rows_per_band: int 
     # (same two-sided charge: its final value y is what the tie test looks at, so |partial sum| <= min(prefix, |y| + suffix))
     pos = 32 * t + 2 * (k % 16) + (k % 32) // 16
     m_chain = np.where(pos < K // 2, K // 2 - pos, pos - K // 2 + 1).astype(np.float64)
-    if blas_model == 1 and dim % 8 == 0:
+    if blas_model == 1 and dim % 4 == 0:
         r = int(rows_per_band)
         if r > 0:
             if num % r:

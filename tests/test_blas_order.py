@@ -33,6 +33,10 @@ def _literal_row_dot(a, x, kind):
         ab, xb = a[k0:k0 + 4096], x[k0:k0 + 4096]
         lanes = 4 if kind == 1 else 8
         p = np.zeros(lanes, dtype=np.float32)
+        head = ab.shape[0] % lanes
+        for k in range(head):
+            p[k] = f(ab[k] * xb[k])
+        ab, xb = ab[head:], xb[head:]
         for k in range(ab.shape[0]):
             if kind == 0:           # (a double holds product + addend exactly unless their exponents are > 29 apart: not here)
                 p[k % lanes] = f(np.float64(ab[k]) * np.float64(xb[k]) + np.float64(p[k % lanes]))
@@ -54,7 +58,7 @@ def test_row_kinds_and_blocks_are_the_documented_order():
     assert _hostblas.blas_row_kinds(7).tolist() == [0, 0, 0, 0, 1, 1, 2]
     assert _hostblas.blas_row_kinds(3).tolist() == [1, 1, 2]
     rng = np.random.default_rng(6)
-    for dim in (64, 4096 + 64):
+    for dim in (64, 4096 + 64, 300, 12):                   # (300, 12: 8 m + 4 elements - the first four go first)
         a = rng.standard_normal(dim).astype(np.float32)
         x = rng.standard_normal(dim).astype(np.float32)
         for row, kind in enumerate(_hostblas.blas_row_kinds(7).tolist()):
@@ -73,12 +77,13 @@ def test_model_function_is_the_documented_order():
     want = np.float32(np.float32(q[0] + q[1]) + np.float32(q[2] + q[3]))
     # (* a double holds product + addend of two floats exactly unless their exponents are > 29 apart: not here)
     assert _model_dot(a, x).view(np.uint32) == want.view(np.uint32)
-    assert np.isnan(_model_dot(a[:60], x[:60]))            # n % 8 != 0
+    assert np.isnan(_model_dot(a[:62], x[:62]))            # n % 4 != 0
     assert np.isnan(_model_dot(a, x, model=2))             # unknown model
 
 
 @pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (16, 32, 1536), (16, 4, 128), (4, 12, 32),
-                                      (20, 10, 768), (20, 6, 128), (8, 25, 768), (10, 13, 640), (4, 7, 8192)])
+                                      (20, 10, 768), (20, 6, 128), (8, 25, 768), (10, 13, 640), (4, 7, 8192),
+                                      (16, 16, 300), (20, 10, 100), (8, 7, 200), (4, 6, 1004), (3, 7, 12)])
 def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
     planes = np.random.default_rng(9).standard_normal((nb, r, dim)).astype(np.float32)
     model = _hostblas.blas_order_model(planes)
@@ -107,9 +112,10 @@ def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
 
 
 def test_shapes_the_model_does_not_cover_are_refused():
-    planes = np.random.default_rng(1).standard_normal((8, 5, 100)).astype(np.float32)
-    assert _hostblas.blas_order_model(planes) == 0         # dim % 8 != 0: the library's tail handling is not modelled
-    h = LSHHasher(8, 5, 100, seed=3)
+    planes = np.random.default_rng(1).standard_normal((8, 5, 102)).astype(np.float32)
+    assert _hostblas.blas_order_model(planes) == 0         # dim % 4 != 0: the library's tail handling is not modelled
+    assert _hostblas.blas_order_model(np.random.default_rng(1).standard_normal((4, 8, 4100)).astype(np.float32)) == 0
+    h = LSHHasher(8, 5, 102, seed=3)
     assert h._replay_model() == 0
     h2 = LSHHasher(16, 16, 768, seed=3, tie_replay="off")
     assert h2.tie_replay == "off"

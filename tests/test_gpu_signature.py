@@ -334,6 +334,13 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     (10, 20, 512, 20_001, "split+replay"),      # get_optimal_config(200, 0.3): 30 key bytes
     (5, 11, 96, 20_001, "f32+replay"),          # 10 key bytes
     (3, 5, 64, 1_001, "f32+replay"),            # 3 key bytes
+    (16, 16, 300, 30_000, "f32+replay"),        # GloVe / word2vec: 8 m + 4 elements - the library takes the first four first
+    (20, 10, 100, 30_000, "f32+replay"),
+    (8, 7, 200, 20_000, "f32+replay"),          # not whole k-tiles
+    (16, 16, 1000, 20_000, "f32+replay"),
+    (4, 6, 1004, 9_000, "f32+replay"),
+    (6, 11, 36, 9_000, "f32+replay"),
+    (8, 12, 12, 5_000, "f32+replay"),
     (4, 7, 4128, 4_000, "f32+replay"),
 ])
 def test_bands_of_any_height_and_long_vectors_replay_the_hosts_own_kernels(torch_mod, nb, r, dim, n, route):
@@ -370,7 +377,7 @@ def test_bands_of_any_height_and_long_vectors_replay_the_hosts_own_kernels(torch
     assert np.array_equal(got.cpu().numpy()[pick], want), (kinds.tolist(), st)
     hh = _hasher(31, nb, r, dim, tie_replay="off")
     assert torch.equal(got, hh.hash_device(x))
-    if dim <= 4096:
+    if 8 <= dim <= 4096:
         # a handful of host vectors: the one-launch kernel, every projection the replayed value (the true ties among them)
         few = xh[special[:48]]
         assert np.array_equal(h.hash_batch_packed(few), hash_batch_literal_packed(h.projections, few))

@@ -22,7 +22,9 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # bands the host BLAS does not take four rows at a time (its unfused kernels for the rest), vectors of several blocks
           (20, 10, 768), (40, 5, 768), (8, 25, 768), (12, 23, 512), (16, 18, 4128), (20, 6, 128), (10, 10, 768), (20, 5, 384),
           # key rows that are not whole 32-bit words (stage 2's atomics straddle rows)
-          (25, 8, 768), (5, 20, 768), (10, 20, 512), (5, 11, 96), (3, 5, 64), (7, 9, 1024))
+          (25, 8, 768), (5, 20, 768), (10, 20, 512), (5, 11, 96), (3, 5, 64), (7, 9, 1024),
+          # rows that are not whole k-tiles; 8 m + 4 elements (the library takes the first four first)
+          (16, 16, 300), (20, 10, 100), (8, 7, 200), (16, 16, 1000), (4, 6, 1004), (6, 11, 36), (8, 12, 12))
 
 
 def main():
