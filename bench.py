@@ -30,6 +30,7 @@ Also in the line (N = 1 unless noted):
   measured_window_mode   the same step with round 2's default (a 64-unit window + guard): statistical, not proven;
   host_engine_mode       the same step with the device tie replay off (what an unrecognised host BLAS runs), with the proven
                          windows and (`host_engine_mode_measured_windows`) with round 2's measured ones;
+  other_shapes  bands of 10 / 5 / 6 rows, 25 key bytes per row, 300-d: route and rate of shapes that used to end at the host engine;
   c5            BASELINE config 5 (5M x 1536, num_perm 512) on one GPU with its own roofline and parity check;
   e2e_ingest    LSHRS.index() from host memory into an in-memory store, beside the reference-literal loop, and
                 query_many() of 10 000 queries against that index beside the reference-literal per-query flow;
@@ -448,6 +449,7 @@ def main() -> None:
                 "windows are a statistical statement instead of a proven one - a few thousand tied pairs per step for the "
                 "host instead of a few hundred thousand", tie_replay="off", tau1_ulps=64.0, tau_ulps=8.0)),
             ("roofline_f32_kernel", lambda: bench_f32(torch, x, keys, local_dev)),
+            ("other_shapes", lambda: bench_other_shapes(torch, np, local_dev, n)),
             ("small_n", lambda: bench_small_n(torch, np, hasher, x)),
             ("host_fed", lambda: bench_host_fed(torch, np, hasher, x, 500_000)),
             ("e2e_ingest", lambda: bench_e2e(torch, np, x, local_dev)),
@@ -643,6 +645,37 @@ def bench_variant(torch, x, keys, local_dev, steps, barrier, label, **kw):
     out["keys_identical_to_the_default_hashers"] = bool(
         torch.equal(hv.hash_device(x), LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_dev).hash_device(x)))
     hv.close()
+    return out
+
+
+def bench_other_shapes(torch, np, local_dev, n):
+    """Hashers the host BLAS does not take four rows at a time, or whose vectors are not whole k-tiles (the reference's own
+    docstring layouts, get_optimal_config's picks for num_perm 100 / 200, GloVe's 300-d): which route they take and at what
+    rate - the device replay follows the library's left-over-row kernels, its 4096-element blocks and its 8 m + 4 order, so
+    none of them ends at the host engine.  1 M rows each, settled, 10 timed steps; 2 000 rows against the oracle."""
+    from lshrs_amd import LSHHasher
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    out = {}
+    for nb, r, dim in ((20, 10, 768), (40, 5, 768), (25, 8, 768), (20, 6, 128), (16, 16, 300)):
+        h = LSHHasher(nb, r, dim, seed=42, device=local_dev)
+        x = torch.randn(n, dim, device=f"cuda:{local_dev}", generator=torch.Generator(device=f"cuda:{local_dev}").manual_seed(dim + nb))
+        keys = h.hash_device(x)
+        for _ in range(15):
+            h.hash_device(x, out=keys)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            h.hash_device(x, out=keys)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        st = dict(h.last_stats)
+        want = hash_batch_literal_packed(h.projections, x[:2000].cpu().numpy())
+        out[f"{nb}x{r}x{dim}"] = {"value": n / dt, "unit": "vectors/s", "ms_per_step": 1e3 * dt, "route": st.get("route"),
+                                  "tie_break_engine": st.get("tie_break_engine", "host"),
+                                  "bit_exact_vs_oracle_2000_rows": bool(np.array_equal(keys[:2000].cpu().numpy(), want))}
+        h.close()
+        del x, keys
     return out
 
 
