@@ -111,6 +111,32 @@ def test_proven_window_contains_stage1s_distance_from_the_host(nb, r, dim, seed)
         assert 300 < window_coefficients(stack, 1)[3]["window_units"] < 380      # 339: DESIGN.md §3's table
 
 
+@pytest.mark.parametrize("nb,r,dim", [(6, 10, 300), (5, 7, 100), (4, 16, 200), (3, 6, 1004)])
+def test_proven_tie_window_of_vectors_that_are_not_whole_k_tiles(nb, r, dim):
+    """The f32 kernel's chain against the host, `|y_chain - y_host| <= ||x|| coef_tie`, where the split pass does not go:
+    300-d / 100-d (8 m + 4 elements: the library's 8-lane kernels take the first four first - one chain step more) and rows
+    that end inside a k-tile; bands with left-over rows.  Rows cancelled against hyperplanes of every kind among them."""
+    from lshrs_amd import _hostblas
+    from lshrs_amd.windows import window_coefficients
+    from oracle.build import chain_project
+
+    rng = np.random.default_rng(dim + r)
+    planes = [rng.standard_normal((r, dim)).astype(np.float32) for _ in range(nb)]
+    stack = np.concatenate(planes)
+    model = int(_hostblas.blas_order_model(np.stack(planes)))
+    ca, cb, ct, info = window_coefficients(stack, model, r)
+    x = rng.standard_normal((300, dim))
+    for i in range(0, 300, 3):                                  # a third of the rows: nothing left of y but the order
+        p = stack[(7 * i) % len(stack)].astype(np.float64)
+        x[i] -= (x[i] @ p) / (p @ p) * p
+    x = x.astype(np.float32)
+    yc = chain_project(planes, x).astype(np.float64)
+    yh = np.concatenate([np.stack([p @ v for v in x]) for p in planes], axis=1).astype(np.float64)
+    nx = np.linalg.norm(x.astype(np.float64), axis=1)
+    used = np.abs(yc - yh) / (nx[:, None] * ct[None, :].astype(np.float64))
+    assert used.max() <= 1.0 and used.max() > 1e-4, float(used.max())
+
+
 def test_window_coefficients_of_degenerate_hyperplanes():
     from lshrs_amd.hasher import window_coefficients
 
