@@ -386,6 +386,39 @@ def test_bands_of_any_height_and_long_vectors_replay_the_hosts_own_kernels(torch
         assert one.as_tuple() == tuple(bytes(k) for k in hash_batch_literal_packed(h.projections, few[3:4])[0])
 
 
+@pytest.mark.parametrize("nb,r,dim,n", [(25, 8, 768, 4_099), (5, 11, 96, 3_001), (16, 16, 768, 5_000), (3, 5, 64, 777)])
+def test_keys_at_any_address_and_width_leave_their_neighbours_alone(torch_mod, nb, r, dim, n):
+    """Stage 2 patches key bits with 32-bit atomics on the ALIGNED word around the byte: with key rows that are not whole
+    words, or keys that start at an odd address, such a word reaches into the neighbouring row - or past the ends of the
+    keys.  The bytes in front of and behind the keys (a sentinel pattern in one allocation) must come back untouched, and
+    the keys must be the reference's - on a batch salted with true ties, so that stage 2 has bits to patch in the first
+    and the last row."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(77, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    rb = nb * h.band_bytes
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(n))
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
+    special = np.unique(np.concatenate([[0, n - 1], np.arange(0, n, 9)]))
+    xs = x[special].cpu().numpy().astype(np.float64)
+    for i in range(special.size):                       # ties in the first and the last key byte of the row, and in between
+        pl = stack[[0, stack.shape[0] - 1, (37 * i) % stack.shape[0]]]
+        xs[i] -= (xs[i] @ np.linalg.pinv(pl)) @ pl
+    x[special] = torch.from_numpy(xs.astype(np.float32)).cuda()
+    want = hash_batch_literal_packed(h.projections, x.cpu().numpy())
+    for front in (5, 64, 3):
+        big = torch.full((front + n * rb + 67,), 0xA5, dtype=torch.uint8, device="cuda")
+        out = big[front:front + n * rb].view(n, nb, h.band_bytes)
+        got = h.hash_device(x, out=out)
+        assert got.data_ptr() == out.data_ptr() and h.last_stats.get("tie_break_engine") == "device-replay"
+        assert h.last_stats["tie_pairs"] >= 2 * special.size
+        assert np.array_equal(out.cpu().numpy(), want)
+        assert bool((big[:front] == 0xA5).all()) and bool((big[front + n * rb:] == 0xA5).all())
+
+
 def test_streaming_entry_point_equals_hash_device(torch_mod):
     """`hash_device_async`: the batch is enqueued at once, `result()` is the verified keys.  Same bytes as `hash_device`
     for several batches in flight, for sync and async calls mixed, for a batch whose stage-1 list overflows (verified
