@@ -116,7 +116,47 @@ inline SigWindow sig_window(const float* base, const SigGeom& g) {
   w.wamax = p + 3 * wc; w.wbmax = w.wamax + cbp; w.wtmax = w.wbmax + cbp; w.wtmax_fine = w.wtmax + cbp;
   return w;
 }
-inline int64_t sig_workspace_floats(const SigGeom& g) { return sig_window_offset_floats(g) + sig_window_floats(g); }
+// COMPACT column blocks of the split pass.  The padded layout gives every band 8 * ceil(rows / 8) columns - the layout of the
+// keys - so a band of 10 rows wastes 6 of 16 columns and a band of 4 rows half of them, in matrix work as in fragments.
+// Where that costs whole 256-column blocks (20 x 10: 320 padded columns = two blocks, 200 real ones = one) stage 1 runs
+// on an image of its own: the key columns of whole bands side by side, `bpb` = 256 / rows bands per block (a band never
+// straddles two blocks), the block's tail zero.  Only stage 1 knows: its list entries carry padded column ids (table
+// `padcol`), its keys leave through a byte table (`bytetab`: source bit and mask of every key byte of the block), and it
+// reads copies of the norms and window coefficients in its own order.  At the end of the workspace:
+//   image_c [ncb * ktiles * 8192] | norms_c [ncb * 256] | norm_max_c [4..] | wa_c | wb_c [ncb * 256 each] | wamax_c | wbmax_c [4..]
+//   | padcol int32 [ncb * 256] | bytetab int32 [ncb * 256 * 2]
+struct SigCompact { bool on; int bpb; int ncb; };
+inline SigCompact sig_compact(const SigGeom& g, int num_bands, int rows) {
+  SigCompact c{false, 0, 0};
+  if (g.nt != 8 || rows > 128) return c;
+  c.bpb = 256 / rows;
+  c.ncb = (num_bands + c.bpb - 1) / c.bpb;
+  c.on = c.ncb < g.cb;
+  return c;
+}
+inline int64_t sig_pad4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+struct SigCompactWs { float *image, *norms, *norm_max, *wa, *wb, *wamax, *wbmax; int *padcol, *bytetab; };
+inline int64_t sig_compact_floats(const SigGeom& g, const SigCompact& c) {
+  if (!c.on) return 0;
+  return (int64_t)c.ncb * g.ktiles * 8192 + 3 * (int64_t)c.ncb * 256 + 3 * sig_pad4(c.ncb) + (int64_t)c.ncb * 256 * 3;
+}
+inline int64_t sig_workspace_floats(const SigGeom& g, int num_bands, int rows) {
+  return sig_window_offset_floats(g) + sig_window_floats(g) + sig_compact_floats(g, sig_compact(g, num_bands, rows));
+}
+inline SigCompactWs sig_compact_ws(float* base, const SigGeom& g, const SigCompact& c) {
+  SigCompactWs w;
+  float* p = base + sig_window_offset_floats(g) + sig_window_floats(g);
+  w.image = p; p += (int64_t)c.ncb * g.ktiles * 8192;
+  w.norms = p; p += (int64_t)c.ncb * 256;
+  w.norm_max = p; p += sig_pad4(c.ncb);
+  w.wa = p; p += (int64_t)c.ncb * 256;
+  w.wb = p; p += (int64_t)c.ncb * 256;
+  w.wamax = p; p += sig_pad4(c.ncb);
+  w.wbmax = p; p += sig_pad4(c.ncb);
+  w.padcol = reinterpret_cast<int*>(p); p += (int64_t)c.ncb * 256;
+  w.bytetab = reinterpret_cast<int*>(p);
+  return w;
+}
 constexpr int64_t kRoundRows = 65536;       // rows one full round of workgroups covers: 256 CUs x 2 x 128 (or 1 x 256)
 
 // Which geometry finishes a partial round (m < kRoundRows rows) sooner?  Cost model fitted to
@@ -216,6 +256,29 @@ __global__ void window_scatter_kernel(const float* __restrict__ ca, const float*
   wt[col] = live ? ct[j] : 0.f;
 }
 
+// Tables of the compact column blocks (sig_compact): per compact column its padded column id (-1: the zero tail of a
+// block), per key byte of a block the bit of the block's 256-bit sign string it starts at and the mask of its live bits.
+__global__ void compact_tables_kernel(int num_bands, int rows, int bb, int bpb, int ncb, int* __restrict__ padcol,
+                                      int* __restrict__ bytetab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncb * 256) return;
+  const int blk = i >> 8, cc = i & 255;
+  const int band = blk * bpb + cc / rows, bit = cc % rows;
+  padcol[i] = (cc < bpb * rows && band < num_bands) ? band * bb * 8 + bit : -1;
+  const int bl = cc / bb, q = cc % bb;                        // key byte cc of the block: byte q of its band bl
+  const bool live = bl < bpb && blk * bpb + bl < num_bands && 8 * q < rows;
+  const int nbits = live ? (rows - 8 * q < 8 ? rows - 8 * q : 8) : 0;
+  bytetab[2 * i] = live ? bl * rows + 8 * q : 0;
+  bytetab[2 * i + 1] = (1 << nbits) - 1;
+}
+
+// a per-padded-column array in the order of the compact blocks (0 in a block's tail)
+__global__ void compact_gather_kernel(const float* __restrict__ src, const int* __restrict__ padcol, int n,
+                                      float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = padcol[i] >= 0 ? src[padcol[i]] : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------
@@ -249,6 +312,14 @@ struct SigArgs {
   const float* wamax;
   const float* wbmax;
   float tau_b;
+  // ... compact column blocks (sig_compact): image, norms and coefficients above are in compact order; the list entries
+  // and the keys go through these tables
+  int compact;            // 0: the padded layout
+  const int* padcol;      // [ncb * 256]
+  const int* bytetab;     // [ncb * 256 * 2]
+  int bpb;                // bands per block
+  int band_bytes;
+  int num_bands;
   // project mode
   float* Y;
   int64_t ldy;
@@ -1201,7 +1272,7 @@ __global__ void scatter_keys_kernel(uint8_t* __restrict__ keys, int num_bands, i
 //   accumulator tile: column = lane & 15, row = 4 (lane >> 4) + register.
 // ------------------------------------------------------------------------------------------
 __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb,
-                                           int ktiles, int64_t chunks, u16x8* __restrict__ image) {
+                                           int ktiles, int64_t chunks, u16x8* __restrict__ image, int bpb = 0) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= chunks) return;
   const int lane = (int)(c & 63);
@@ -1211,8 +1282,13 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
   const int kt = (int)(t % ktiles);
   const int cb = (int)(t / ktiles);
   const int col = cb * 256 + ct * 16 + (lane & 15);
-  const int band = col / (bb * 8);
-  const int bit = col % (bb * 8);
+  int band = col / (bb * 8);
+  int bit = col % (bb * 8);
+  if (bpb > 0) {                                     // compact column blocks: bpb whole bands per block, no padding inside
+    const int cc = col & 255;
+    band = cc < bpb * rows ? cb * bpb + cc / rows : num_bands;
+    bit = cc % rows;
+  }
   const int k0 = kt * kKTile + 8 * (lane >> 4);
   u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
   if (band < num_bands && bit < rows) {
@@ -1239,6 +1315,9 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
 // SAME XCD at about the same time and the second one reads x from that XCD's L2 instead of HBM (config 5: 512 key
 // columns = two column blocks).
 constexpr int kS1ListCap = 8192;   // flagged projections a workgroup stages in LDS before its ONE global append
+// COMPACT: the column blocks hold the bands' key columns side by side (sig_compact) - list entries and keys leave through
+// the tables; a template parameter so that the padded layout's kernel is instruction for instruction what it was.
+template <bool COMPACT>
 __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   constexpr int RT = 2, W = 8;
   constexpr int kWaveRows = 16 * RT;
@@ -1536,6 +1615,11 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   float* coef_lds = lds + 3 * kS1ListCap;
   static_assert(3 * kS1ListCap + 512 <= kRingFloats, "coefficients behind the list stage");
   coef_lds[tid] = tid < 256 ? args.wa[cb * 256 + tid] : args.wb[cb * 256 + tid - 256];
+  // compact column blocks (sig_compact): the padded id of every column of this block, and room for the block's sign words
+  int* padcol_lds = reinterpret_cast<int*>(lds + 3 * kS1ListCap + 512);
+  uint32_t* cw_lds = reinterpret_cast<uint32_t*>(lds + 3 * kS1ListCap + 768);
+  static_assert(3 * kS1ListCap + 768 + 256 * 8 <= kRingFloats, "compact tables behind the coefficients");
+  if (COMPACT && tid < 256) padcol_lds[tid] = args.padcol[cb * 256 + tid];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     float s2 = ss[rt] + __shfl_xor(ss[rt], 16);
@@ -1616,8 +1700,9 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
             for (int q = 0; q < 8; ++q) {
               const int reg = q & 3, ct = 2 * w + (q >> 2);
               const int64_t grow = row0 + 16 * rt + 4 * ge + reg;
-              if (((hits >> q) & 1u) != 0u && grow < args.n) {
-                const int64_t entry = (grow << 21) | (int64_t)(cb * 256 + 16 * ct + r16e);
+              const int colid = COMPACT ? padcol_lds[16 * ct + r16e] : cb * 256 + 16 * ct + r16e;
+              if (((hits >> q) & 1u) != 0u && grow < args.n && (!COMPACT || colid >= 0)) {
+                const int64_t entry = (grow << 21) | (int64_t)colid;
                 // the stage-1 value travels with the entry: stage 2 measures |y1 - y_BLAS| on every flagged projection
                 // (rows flagged wholesale carry no usable y1: NaN, skipped by that statistic)
                 const float ykeep = wnd[reg] < __builtin_inff() ? ys[q] : __builtin_nanf("");
@@ -1647,7 +1732,11 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
       const int64_t grow = row0 + rlo + 4 * hl;
-      if (grow < args.n) {
+      if (COMPACT) {                  // the block's sign string of this row: to LDS, the key bytes are cut from it below
+        uint32_t* dstw = cw_lds + (wave * kWaveRows + rlo + 4 * hl) * 8 + wq;
+        dstw[0] = hl ? whi[0] : wlo[0];
+        dstw[1] = hl ? whi[1] : wlo[1];
+      } else if (grow < args.n) {
         uint8_t* dst = args.keys + grow * (int64_t)args.row_bytes + byte0;
         const uint32_t w0 = hl ? whi[0] : wlo[0], w1 = hl ? whi[1] : wlo[1];
         if (args.vec_store && byte0 + 8 <= args.row_bytes) {
@@ -1665,6 +1754,23 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 
   // ---- the workgroup's flagged projections: one global append ------------------------------------------------------
   __syncthreads();
+  if (COMPACT) {
+    // key byte o of this block = bits [src, src + 8) of the row's 256-bit sign string, masked to the band's live rows
+    const int bands_here = args.num_bands - cb * args.bpb < args.bpb ? args.num_bands - cb * args.bpb : args.bpb;
+    const int nby = bands_here * args.band_bytes;
+    const int byte_base = cb * args.bpb * args.band_bytes;
+    const int* tab = args.bytetab + cb * 512;
+    for (int idx = tid; idx < 256 * nby; idx += 64 * W) {
+      const int rl = idx / nby, o = idx - rl * nby;
+      const int64_t grow = blk_row0 + rl;
+      if (grow < args.n) {
+        const int src = tab[2 * o], w = src >> 5;
+        const uint32_t lo = cw_lds[rl * 8 + w], hi = cw_lds[rl * 8 + (w < 7 ? w + 1 : 7)];
+        const uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> (src & 31)) & (uint32_t)tab[2 * o + 1];
+        args.keys[grow * (int64_t)args.row_bytes + byte_base + o] = (uint8_t)v;
+      }
+    }
+  }
   const int staged = l_count[0] < kS1ListCap ? l_count[0] : kS1ListCap;
   if (staged > 0) {                                     // (workgroup-uniform)
     if (tid == 0) l_count[1] = atomicAdd(args.tie_count, staged);
@@ -1975,7 +2081,7 @@ static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
 int64_t lshrs_sig_workspace_bytes(int32_t num_bands, int32_t rows_per_band, int32_t dim) {
   if (!sig_shape_ok(num_bands, rows_per_band, dim)) return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
-  return sig_workspace_floats(g) * (int64_t)sizeof(float);
+  return sig_workspace_floats(g, num_bands, rows_per_band) * (int64_t)sizeof(float);
 }
 
 int32_t lshrs_sig_padded_columns(int32_t num_bands, int32_t rows_per_band) {
@@ -2037,6 +2143,20 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((wf + 255) / 256)), dim3(256), 0, s, image + sig_window_offset_floats(g),
                        wf, 1e30f);
   }
+  const SigCompact cp = sig_compact(g, num_bands, rows_per_band);
+  if (cp.on) {                                      // stage 1's own image, tables and copies (sig_compact)
+    const SigCompactWs cw = sig_compact_ws(image, g, cp);
+    const int cc = cp.ncb * 256;
+    const int64_t cchunks = (int64_t)cp.ncb * g.ktiles * 8192 / 4;
+    hipLaunchKernelGGL(compact_tables_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, num_bands, rows_per_band,
+                       g.bb, cp.bpb, cp.ncb, cw.padcol, cw.bytetab);
+    hipLaunchKernelGGL(pack_image_bf16_t16_kernel, dim3((unsigned)((cchunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                       rows_per_band, dim, g.bb, g.ktiles, cchunks, reinterpret_cast<u16x8*>(cw.image), cp.bpb);
+    hipLaunchKernelGGL(compact_gather_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, norms, cw.padcol, cc, cw.norms);
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3((unsigned)((cp.ncb + 63) / 64)), dim3(64), 0, s, cw.norms, 256, cp.ncb, cw.norm_max);
+    const int64_t wf = 2 * (int64_t)cc + 2 * sig_pad4(cp.ncb);          // wa_c .. wbmax_c are contiguous
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((wf + 255) / 256)), dim3(256), 0, s, cw.wa, wf, 1e30f);
+  }
   return -(int)hipGetLastError();
 }
 
@@ -2065,6 +2185,16 @@ int lshrs_sig_set_window(void* workspace, int32_t num_bands, int32_t rows_per_ba
   if (sig_has_narrow_split(g)) {            // the narrow image is ONE block of 256 columns
     hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, w.wa, 256, 1, const_cast<float*>(w.wamax) + kNarrowMaxSlot);
     hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, w.wb, 256, 1, const_cast<float*>(w.wbmax) + kNarrowMaxSlot);
+  }
+  const SigCompact cp = sig_compact(g, num_bands, rows_per_band);
+  if (cp.on) {                              // stage 1's copies in the order of its compact column blocks
+    const SigCompactWs cw = sig_compact_ws(base, g, cp);
+    const int cc = cp.ncb * 256;
+    const dim3 cg((unsigned)((cc + 255) / 256)), cbk(256), xg((unsigned)((cp.ncb + 63) / 64));
+    hipLaunchKernelGGL(compact_gather_kernel, cg, cbk, 0, s, w.wa, cw.padcol, cc, cw.wa);
+    hipLaunchKernelGGL(compact_gather_kernel, cg, cbk, 0, s, w.wb, cw.padcol, cc, cw.wb);
+    hipLaunchKernelGGL(pack_normmax_kernel, xg, mb, 0, s, cw.wa, 256, cp.ncb, cw.wamax);
+    hipLaunchKernelGGL(pack_normmax_kernel, xg, mb, 0, s, cw.wb, 256, cp.ncb, cw.wbmax);
   }
   return -(int)hipGetLastError();
 }
@@ -2180,6 +2310,20 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     a.norms = a.image + sig_narrow_image_floats(g);
     a.norm_max = a.norms + 256;
   }
+  const SigCompact cp = sig_compact(g, num_bands, rows_per_band);
+  const SigCompactWs cw = cp.on ? sig_compact_ws(const_cast<float*>(base), g, cp) : SigCompactWs{};
+  if (cp.on) {    // fewer column blocks with the bands' columns side by side (sig_compact)
+    a.ncb = cp.ncb;
+    a.image = cw.image;
+    a.norms = cw.norms;
+    a.norm_max = cw.norm_max;
+    a.compact = 1;
+    a.padcol = cw.padcol;
+    a.bytetab = cw.bytetab;
+    a.bpb = cp.bpb;
+    a.band_bytes = g.bb;
+    a.num_bands = num_bands;
+  }
   a.keys = keys;
   a.row_bytes = row_bytes;
   a.vec_store = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(keys) % 16) == 0);
@@ -2200,12 +2344,19 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     a.wb = w.wb;
     a.wamax = narrow ? w.wamax + kNarrowMaxSlot : w.wamax;
     a.wbmax = narrow ? w.wbmax + kNarrowMaxSlot : w.wbmax;
+    if (cp.on) {
+      a.wa = cw.wa;
+      a.wb = cw.wb;
+      a.wamax = cw.wamax;
+      a.wbmax = cw.wbmax;
+    }
   }
   a.row_flags = row_flags;
   a.clock_probe = o.clock_probe;
   {
     const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), 1, 1);
-    hipExtLaunchKernelGGL(sig16_kernel, grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
+    if (cp.on) hipExtLaunchKernelGGL(sig16_kernel<true>, grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
+    else hipExtLaunchKernelGGL(sig16_kernel<false>, grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
   }
   // stage 2: the flagged projections, one by one
   FixArgs f{};
@@ -2214,7 +2365,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.dim = dim;
   f.ktiles = g.ktiles;
   f.prow = base + sig_rowmajor_offset_floats(g);
-  f.norms = a.norms;
+  f.norms = cp.on ? base + sig_image_floats(g) : a.norms;       // (stage 2 works on padded column ids throughout)
   f.keys = keys;
   f.row_bytes = row_bytes;
   f.padcols = row_bytes * 8;
@@ -2226,7 +2377,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.tie_cap = tie_cap;
   f.tie_count = tie_count;
   f.tau = tau > 0.f ? tau : 1.0f;
-  f.tie_coef = tau > 0.f ? a.norms : sig_window(base, g).wt;      // (proven tie window: coefficient per column, factor 1)
+  f.tie_coef = tau > 0.f ? f.norms : sig_window(base, g).wt;      // (proven tie window: coefficient per column, factor 1)
   f.blas_model = blas_model;
   f.rows_per_band = rows_per_band;
   f.band_cols = 8 * g.bb;

@@ -95,6 +95,12 @@ def test_pure_host_entry_points(lib):
     # 160 padded columns (the reference's docstring example, 20 x 6): the f32 kernel's two column blocks of 128, five fine
     # tiles, and the same 256-column narrow image
     assert lib.lshrs_sig_workspace_bytes(20, 6, 128) == ((256 + 160 + 256 + 256) * 128 + 256 + 4 + 8 + 256 + 4 + 3 * 256 + 12 + 8) * 4
+    # 20 x 10 (the reference's docstring layout): 320 padded key columns = two column blocks everywhere - and, for stage 1 of the
+    # split pass, ONE compact block of the 200 real columns: its image (24 k-tiles x 8192 floats), 256 norms, two coefficient
+    # arrays, three maxima (x4), 256 padded column ids and 256 x 2 key-byte table entries
+    assert lib.lshrs_sig_workspace_bytes(20, 10, 768) == (
+        (512 * 768 + 512 + 4) + (320 * 768 + 12) + 512 * 768 + 512 * 768 + (3 * 512 + 12 + 12)
+        + (24 * 8192 + 3 * 256 + 3 * 4 + 3 * 256)) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (2 * 32 * 32 + 32 + 4 + 3 * 256 + 12 + 4) * 4
     assert lib.lshrs_sig_set_window(None, 16, 16, 768, None, None, None, None) == -10001
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0

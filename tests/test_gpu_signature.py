@@ -341,6 +341,12 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     (4, 6, 1004, 9_000, "f32+replay"),
     (6, 11, 36, 9_000, "f32+replay"),
     (8, 12, 12, 5_000, "f32+replay"),
+    # compact column blocks in stage 1 (fewer 256-column blocks with the bands' columns side by side than in the key layout)
+    (128, 4, 768, 20_000, "split+replay"),      # get_optimal_config(512, 0.3): 1024 padded columns, 512 real ones
+    (21, 12, 768, 20_000, "split+replay"),      # 336 padded / 252 real: one block, full to the last band
+    (60, 9, 384, 20_000, "split+replay"),       # 960 padded / 540 real: three blocks, the last one holds four bands
+    (33, 7, 640, 20_000, "split+replay"),       # 264 padded / 231 real
+    (100, 2, 512, 20_000, "split+replay"),      # 800 padded / 200 real
     (4, 7, 4128, 4_000, "f32+replay"),
 ])
 def test_bands_of_any_height_and_long_vectors_replay_the_hosts_own_kernels(torch_mod, nb, r, dim, n, route):
@@ -417,6 +423,29 @@ def test_keys_at_any_address_and_width_leave_their_neighbours_alone(torch_mod, n
         assert h.last_stats["tie_pairs"] >= 2 * special.size
         assert np.array_equal(out.cpu().numpy(), want)
         assert bool((big[:front] == 0xA5).all()) and bool((big[front + n * rb:] == 0xA5).all())
+
+
+def test_compact_column_blocks_with_measured_windows_and_the_host_engine(torch_mod):
+    """Stage 1's compact column blocks (20 x 10: one block of 200 columns instead of two of 320 padded ones) under the other
+    two callers of the split pass: a numeric (measured) window - the norms it multiplies are read in compact order - and the
+    host-engine route (`tie_replay="off"`: stage 2 evaluates the chain, ties go to the host).  Same keys as the default."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    n, dim = 150_000, 768
+    for nb, r in ((20, 10), (40, 5), (128, 4)):
+        x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(nb))
+        base = _hasher(9, nb, r, dim)
+        want = base.hash_device(x)
+        assert base.last_stats["route"] in ("split+replay", "plain", "host-engine pipelined")
+        m = _hasher(9, nb, r, dim, tau1_ulps=64.0, tau_ulps=8.0)
+        assert torch.equal(m.hash_device(x), want) and m.last_stats.get("window") in ("measured", None)
+        off = _hasher(9, nb, r, dim, tie_replay="off")
+        assert torch.equal(off.hash_device(x), want) and off.last_stats.get("tie_break_engine") != "device-replay"
+        raw = _hasher(9, nb, r, dim).hash_device(x, tie_break="none")          # the f32 kernel's own bits: a few ties apart
+        assert (raw != want).any(dim=2).any(dim=1).float().mean() < 0.01
+        sl = slice(70_000, 71_000)
+        assert np.array_equal(want[sl].cpu().numpy(), hash_batch_literal_packed(base.projections, x[sl].cpu().numpy()))
 
 
 def test_streaming_entry_point_equals_hash_device(torch_mod):

@@ -24,7 +24,9 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # key rows that are not whole 32-bit words (stage 2's atomics straddle rows)
           (25, 8, 768), (5, 20, 768), (10, 20, 512), (5, 11, 96), (3, 5, 64), (7, 9, 1024),
           # rows that are not whole k-tiles; 8 m + 4 elements (the library takes the first four first)
-          (16, 16, 300), (20, 10, 100), (8, 7, 200), (16, 16, 1000), (4, 6, 1004), (6, 11, 36), (8, 12, 12))
+          (16, 16, 300), (20, 10, 100), (8, 7, 200), (16, 16, 1000), (4, 6, 1004), (6, 11, 36), (8, 12, 12),
+          # compact column blocks in stage 1
+          (128, 4, 768), (21, 12, 768), (60, 9, 384), (33, 7, 640), (100, 2, 512), (50, 5, 1536))
 
 
 def main():
