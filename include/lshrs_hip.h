@@ -71,7 +71,12 @@ typedef struct lshrs_sig_opts {
  * ------------------------------------------------------------------------------------------ */
 
 /* Bytes of device workspace that lshrs_sig_pack_projections() fills for a hasher of this
- * shape (the hyperplanes re-laid-out in MFMA-fragment order + their row norms).
+ * shape: the hyperplanes re-laid-out in MFMA-fragment order (f32 and bf16 hi/mid images over the
+ * key layout's padded columns - every band 8 * ceil(rows_per_band / 8) of them -, a row-major
+ * copy for the exact decision), their norms, the window block of lshrs_sig_set_window and,
+ * where the padding costs the split pass whole 256-column blocks (bands of 10, 5, 4 ... rows),
+ * a second bf16 image with the bands' columns side by side plus the tables that take its list
+ * entries and key bytes back to the key layout.  The layout is the library's own business.
  * Returns <0 on bad arguments.  Needs 16-byte alignment. */
 int64_t lshrs_sig_workspace_bytes(int32_t num_bands, int32_t rows_per_band, int32_t dim);
 
