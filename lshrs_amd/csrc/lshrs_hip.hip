@@ -1317,7 +1317,9 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
 constexpr int kS1ListCap = 8192;   // flagged projections a workgroup stages in LDS before its ONE global append
 // COMPACT: the column blocks hold the bands' key columns side by side (sig_compact) - list entries and keys leave through
 // the tables; a template parameter so that the padded layout's kernel is instruction for instruction what it was.
-template <bool COMPACT>
+// PARTIAL: vectors that are not whole 32-element k-tiles (300-d, 100-d; dim % 4 == 0) - in the last k-tile the 16-byte
+// chunks past a row's end are fetched from the tile's first chunk instead (never past the end of X) and read as zero.
+template <bool COMPACT, bool PARTIAL = false>
 __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   constexpr int RT = 2, W = 8;
   constexpr int kWaveRows = 16 * RT;
@@ -1395,6 +1397,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   }
 
   struct Dma { const char* pg; const char* xg; float* pdst; float* xdst; int j0; };
+  const int last_valid_chunks = PARTIAL ? (args.dim - (ktiles - 1) * kKTile) / 4 : 8;   // 16-byte chunks of a row in the last k-tile
   auto plan = [&](int s) {          // what stage s issues: fragments of stage s+2, x pieces 4(s&1).. of tile (s>>1)+2
     Dma f;
     const int ns = s + 2, c = ns < lasts ? ns : lasts;
@@ -1407,12 +1410,25 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     return f;
   };
   auto issue = [&](const Dma& f, int d) {
-    if (d < kPP)
+    if constexpr (!PARTIAL) {
+      if (d < kPP)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + W * d * kFragFloats),
+                                         16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[kXPS + d - kPP] : xfo[d - kPP])),
+                                         (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, 0);
+    } else if (d < kPP) {
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + W * d * kFragFloats),
                                        16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[kXPS + d - kPP] : xfo[d - kPP])),
+    } else {
+      // branch-free (a branch here changes where hipcc joins the accumulator tiles around the inline-asm MFMAs): in the last
+      // k-tile a chunk past the row's end is fetched from the tile's first chunk instead; this lane's chunk of the line, as in xfo
+      const unsigned off = f.j0 ? xfo[kXPS + d - kPP] : xfo[d - kPP];
+      const int lim = f.xg == xblk + (size_t)(ktiles - 1) * (kKTile * 4) ? last_valid_chunks : 8;
+      const unsigned chunk = (unsigned)((lane & 7) ^ (lane >> 3) ^ ((f.j0 + d - kPP) & 1));
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (off - ((int)chunk >= lim ? 16u * chunk : 0u))),
                                        (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, 0);
+    }
   };
   f32x4 xr[RT][2];                           // raw f32 x of one k-tile: [row tile][chunk]
   auto read_x = [&](int t) {
@@ -1421,6 +1437,17 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int c = 0; c < 2; ++c) xr[rt][c] = *reinterpret_cast<const f32x4*>(xt + xrd[rt][c]);
+    if constexpr (PARTIAL) {                // chunks 2 g, 2 g + 1 of the last k-tile: past the row's end they read as zero (selects, no branch)
+      const int lim = t >= ktiles - 1 ? last_valid_chunks : 8;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bool gone = 2 * g + c >= lim;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xr[rt][c][e] = gone ? 0.f : xr[rt][c][e];
+        }
+    }
   };
   float r0 = 0.f, r1 = 0.f;
   auto split_step = [&](int q, Bf16Pairs (&hi)[RT], Bf16Pairs (&mid)[RT]) {   // slice q (0..kSlices-1) of one k-tile's split
@@ -2287,8 +2314,10 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Opts o = read_opts(opts);
   const float* base = static_cast<const float*>(workspace);
-  const bool aligned = (dim % 32 == 0) && (ldx % 4 == 0) && ldx < (1 << 20) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  if (!aligned) {  // the split pass is built for whole k-tiles of 16-byte aligned rows; anything else takes the f32 pass (same keys)
+  // (a partial last k-tile - dim % 32 != 0 - only with the replay: its stage 2 is the one that reads the chunks past a row's end as zero)
+  const bool aligned = (dim % 32 == 0 || (blas_model != 0 && dim % 4 == 0 && dim >= 32)) && (ldx % 4 == 0) && ldx < (1 << 20) &&
+                       ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (!aligned) {  // the split pass is built for 16-byte chunks of 16-byte aligned rows; anything else takes the f32 pass (same keys)
     if (blas_model != 0) return LSHRS_E_BADARG;   // (the f32 kernel reports ties, it does not resolve them)
     return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
                                     tie_count, tau, row_flags, opts, stream);
@@ -2355,8 +2384,14 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   a.clock_probe = o.clock_probe;
   {
     const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), 1, 1);
-    if (cp.on) hipExtLaunchKernelGGL(sig16_kernel<true>, grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
-    else hipExtLaunchKernelGGL(sig16_kernel<false>, grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
+    const bool partial = dim % kKTile != 0;
+    if (cp.on) {
+      if (partial) hipExtLaunchKernelGGL((sig16_kernel<true, true>), grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
+      else hipExtLaunchKernelGGL((sig16_kernel<true, false>), grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
+    } else {
+      if (partial) hipExtLaunchKernelGGL((sig16_kernel<false, true>), grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
+      else hipExtLaunchKernelGGL((sig16_kernel<false, false>), grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
+    }
   }
   // stage 2: the flagged projections, one by one
   FixArgs f{};
@@ -2413,7 +2448,7 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
                                           int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
                                           float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
                                           int32_t* host_counts, const lshrs_sig_opts* opts, void* stream) {
-  if (blas_model != 1 || dim % 8 != 0 || counters == nullptr) return LSHRS_E_BADARG;
+  if (blas_model != 1 || dim % 4 != 0 || dim < 32 || (dim % 8 != 0 && dim > 4096) || counters == nullptr) return LSHRS_E_BADARG;
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
                     flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, opts, stream);
 }

@@ -122,7 +122,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
       device      torch device index / ``torch.device`` (default: current device at call time)
       tie_break   "host" (default: bytes equal the reference on this host), or "none" (raw kernel bits)
       tie_threads host tie-break workers: None = auto (this process's share of the cores, at most 8), 1 = NumPy only
-      precision   "bf16x3" (default): batches whose shape allows it (dim % 32 == 0, >= 256 key columns - or 128 .. 224
+      precision   "bf16x3" (default): batches whose shape allows it (dim % 4 == 0, >= 256 key columns - or 128 .. 224
                   with dim >= 384 -, hyperplane norms in [2^-40, 2^40]) take the split-precision first pass - bf16 matrix cores,
                   then the exact decision for every projection inside the stage-1 window - everything else the f32
                   kernel; the keys are the same either way.  "f32": always the f32 kernel.
@@ -471,7 +471,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
     ROUTES = (
         # name                     taken when (first match wins)
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
-        ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 32 == 0, "
+        ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 4 == 0, "
                                    ">= 256 key columns or 128 .. 224 with dim >= 384, hyperplane norms in range), 16-byte aligned rows"),
         ("f32+replay",             "host BLAS order recognised, dim % 4 == 0, aligned rows: small "
                                    "batches and shapes the split pass does not take"),
@@ -790,7 +790,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         breaks the ties on the device - it has no host step to amortise, and beats "f32 kernel + host tie-break" from
         a few hundred rows up (85 against 300 us at 512 x 768, tools/replay_crossover.py), so only tiny batches (a
         query vector: the fine-geometry f32 kernel answers in 35 us) stay off it."""
-        if self.precision != "bf16x3" or self.dim % 32 != 0:
+        if self.precision != "bf16x3" or self.dim % 4 != 0 or self.dim < 32:
+            return False
+        if self.dim % 32 != 0 and not replay:      # (a partial last k-tile: only the replaying stage 2 masks the row's end)
             return False
         if replay:
             if n < self.replay_min_rows:

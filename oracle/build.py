@@ -151,6 +151,10 @@ def split_stage1_model(projections, vectors) -> np.ndarray:
     lib = load_mfma()
     x = _f32(vectors)
     p = _stack(projections)
+    if x.shape[1] % 32:                 # the kernel reads the chunks past a row's end as zero, the hyperplanes are zero-padded
+        pad = 32 - x.shape[1] % 32
+        x = np.ascontiguousarray(np.pad(x, ((0, 0), (0, pad))))
+        p = np.ascontiguousarray(np.pad(p, ((0, 0), (0, pad))))
     y = np.empty((x.shape[0], p.shape[0]), dtype=np.float32)
     lib.lshrs_split_stage1_model_batch(x.ctypes.data, x.shape[0], p.ctypes.data, p.shape[0], x.shape[1], y.ctypes.data)
     return y

@@ -222,7 +222,8 @@ def test_route_table():
         assert LSHHasher(5, 12, 64, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)        # 10 key bytes: any row width
         assert LSHHasher(25, 8, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)     # 25 key bytes, 200 key columns
         assert LSHHasher(20, 10, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 + 2 rows per band
-        assert LSHHasher(16, 16, 100, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)      # 8 m + 4 elements
+        assert LSHHasher(16, 16, 100, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 m + 4 elements, a partial k-tile
+        assert LSHHasher(8, 7, 100, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)        # ... with 64 key columns
         assert LSHHasher(16, 16, 102, seed=1)._route(5_000, "host", **ok) == ("plain", 0)           # dim % 4 != 0
     off = LSHHasher(16, 16, 768, seed=42, tie_replay="off")
     big = off._route(1_000_000, "host", **ok)

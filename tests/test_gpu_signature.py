@@ -334,10 +334,12 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     (10, 20, 512, 20_001, "split+replay"),      # get_optimal_config(200, 0.3): 30 key bytes
     (5, 11, 96, 20_001, "f32+replay"),          # 10 key bytes
     (3, 5, 64, 1_001, "f32+replay"),            # 3 key bytes
-    (16, 16, 300, 30_000, "f32+replay"),        # GloVe / word2vec: 8 m + 4 elements - the library takes the first four first
-    (20, 10, 100, 30_000, "f32+replay"),
+    (16, 16, 300, 30_000, "split+replay"),      # GloVe / word2vec: 8 m + 4 elements - the library takes the first four first;
+    (20, 10, 100, 30_000, "split+replay"),      #   stage 1 reads the chunks past a row's end as zero (sig16_kernel<.., PARTIAL>)
+    (32, 8, 44, 30_000, "split+replay"),        # two k-tiles, the second one three chunks long
     (8, 7, 200, 20_000, "f32+replay"),          # not whole k-tiles
-    (16, 16, 1000, 20_000, "f32+replay"),
+    (16, 16, 1000, 20_000, "split+replay"),
+    (16, 16, 36, 20_000, "split+replay"),
     (4, 6, 1004, 9_000, "f32+replay"),
     (6, 11, 36, 9_000, "f32+replay"),
     (8, 12, 12, 5_000, "f32+replay"),
@@ -701,7 +703,7 @@ def test_split_precision_pass_gives_the_f32_kernels_keys(torch_mod):
 
     for (seed, nb, r, dim, n) in ((42, 16, 16, 768, 200_000), (7, 16, 32, 1536, 70_000), (3, 32, 8, 96, 70_001),
                                  (11, 8, 16, 768, 90_000), (12, 16, 4, 384, 150_001),   # 128 key columns: zero-padded image
-                                 (3, 32, 8, 100, 70_001)):     # dim % 32 != 0: the f32 kernel takes over
+                                 (3, 32, 8, 100, 70_001)):     # dim % 32 != 0: without the replay the f32 kernel takes over
         h32 = _hasher(seed, nb, r, dim, precision="f32")
         hs = _hasher(seed, nb, r, dim, precision="bf16x3")
         hs.split_min_elems = 0                                # (the size threshold would keep the 96-d case on the f32 kernel)
@@ -1014,7 +1016,7 @@ def _stage1_values(torch, h, x):
     return y
 
 
-@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (7, 16, 32, 1536), (3, 16, 16, 256)])
+@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (7, 16, 32, 1536), (3, 16, 16, 256), (5, 16, 16, 300), (9, 32, 8, 100)])
 def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     """Stage 1 of the split pass, projection by projection, against oracle/mfma_model.c's accumulator: the bf16 split of
     x and p (round to nearest even, exact residual), per 32-deep k-tile the three instructions xh*ph, xh*pm, xm*ph in
