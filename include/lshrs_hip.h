@@ -165,7 +165,9 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
  * 4x2 / 4x1 kernels; the vector in blocks of 4096 elements - lshrs_tb_model_row_dot in lshrs_host.h states it).  The keys
  * are final when the stream has run: no tie list, no host step.  Only for callers that have checked the model against
  * their BLAS (lshrs_tb_model_row_dot vs `P_band @ x`, bit for bit; lshrs_amd/_hostblas.py does) and for inputs the split
- * pass takes itself (dim % 32 == 0, 16-byte aligned rows; else LSHRS_E_BADARG).
+ * pass takes itself (dim % 4 == 0, dim >= 32 - with 8 m + 4 elements: up to 4096 -, 16-byte aligned rows; else
+ * LSHRS_E_BADARG; of a row that is not whole 32-element k-tiles only its `dim` elements are ever used, and nothing past the
+ * end of X is fetched).
  *   counters     DEVICE int32[LSHRS_SIG_DEVICE_COUNTERS] (see above), zero on entry.
  *   flag_y       optional float[flag_cap]: the stage-1 value of every list entry; with it stage 2 measures how far
  *                stage 1 was from the host BLAS on every flagged projection of the batch (counter [2]).
