@@ -1016,7 +1016,8 @@ def _stage1_values(torch, h, x):
     return y
 
 
-@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (7, 16, 32, 1536), (3, 16, 16, 256), (5, 16, 16, 300), (9, 32, 8, 100)])
+@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (7, 16, 32, 1536), (3, 16, 16, 256), (5, 16, 16, 300), (9, 32, 8, 100),
+                                           (11, 20, 10, 768), (13, 40, 5, 100)])    # (every instantiation of sig16_kernel<COMPACT, PARTIAL>)
 def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     """Stage 1 of the split pass, projection by projection, against oracle/mfma_model.c's accumulator: the bf16 split of
     x and p (round to nearest even, exact residual), per 32-deep k-tile the three instructions xh*ph, xh*pm, xm*ph in
