@@ -30,7 +30,8 @@ Also in the line (N = 1 unless noted):
   measured_window_mode   the same step with round 2's default (a 64-unit window + guard): statistical, not proven;
   host_engine_mode       the same step with the device tie replay off (what an unrecognised host BLAS runs), with the proven
                          windows and (`host_engine_mode_measured_windows`) with round 2's measured ones;
-  other_shapes  bands of 10 / 5 / 6 rows, 25 key bytes per row, 300-d: route and rate of shapes that used to end at the host engine;
+  other_shapes  bands of 10 / 5 / 4 / 6 rows, 25 key bytes per row, 300-d: route and rate of shapes that used to end at the host engine
+                (or, 128 x 4, to pay for four column blocks where two hold its 512 real columns);
   c5            BASELINE config 5 (5M x 1536, num_perm 512) on one GPU with its own roofline and parity check;
   e2e_ingest    LSHRS.index() from host memory into an in-memory store, beside the reference-literal loop, and
                 query_many() of 10 000 queries against that index beside the reference-literal per-query flow;
@@ -657,7 +658,7 @@ def bench_other_shapes(torch, np, local_dev, n):
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
     out = {}
-    for nb, r, dim in ((20, 10, 768), (40, 5, 768), (25, 8, 768), (20, 6, 128), (16, 16, 300)):
+    for nb, r, dim in ((20, 10, 768), (40, 5, 768), (128, 4, 768), (25, 8, 768), (20, 6, 128), (16, 16, 300)):
         h = LSHHasher(nb, r, dim, seed=42, device=local_dev)
         x = torch.randn(n, dim, device=f"cuda:{local_dev}", generator=torch.Generator(device=f"cuda:{local_dev}").manual_seed(dim + nb))
         keys = h.hash_device(x)
