@@ -340,6 +340,7 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     (8, 7, 200, 20_000, "f32+replay"),          # not whole k-tiles
     (16, 16, 1000, 20_000, "split+replay"),
     (16, 16, 36, 20_000, "split+replay"),
+    (16, 16, 5000, 9_000, "split+replay"),      # a partial last k-tile behind a whole block of the library
     (4, 6, 1004, 9_000, "f32+replay"),
     (6, 11, 36, 9_000, "f32+replay"),
     (8, 12, 12, 5_000, "f32+replay"),

@@ -26,7 +26,9 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # rows that are not whole k-tiles; 8 m + 4 elements (the library takes the first four first)
           (16, 16, 300), (20, 10, 100), (8, 7, 200), (16, 16, 1000), (4, 6, 1004), (6, 11, 36), (8, 12, 12),
           # compact column blocks in stage 1
-          (128, 4, 768), (21, 12, 768), (60, 9, 384), (33, 7, 640), (100, 2, 512), (50, 5, 1536))
+          (128, 4, 768), (21, 12, 768), (60, 9, 384), (33, 7, 640), (100, 2, 512), (50, 5, 1536),
+          # partial k-tiles in stage 1 (with a second block of the library; with compact column blocks)
+          (16, 16, 5000), (40, 5, 100), (16, 16, 40))
 
 
 def main():
