@@ -190,6 +190,36 @@ def test_strided_and_unaligned_inputs(torch_mod):
         assert np.array_equal(got, chain_hash_packed(h.projections, v.cpu().numpy()))
 
 
+def test_views_of_wider_matrices_through_the_split_pass(torch_mod):
+    """Rows that are views - a column slice of a wider matrix (row stride > dim: what lies behind a row's end is somebody
+    else's data, NaN here), a row slice that does not start at the allocation - for a shape with a partial last k-tile
+    (300-d), one with whole k-tiles (768-d) and one on compact column blocks (20 x 10): the device replay route, the
+    reference's keys; a view that is not 16-byte aligned takes the f32 kernel and the host for its ties - same keys."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    for nb, r, dim in ((16, 16, 300), (16, 16, 768), (20, 10, 768), (20, 10, 100)):
+        h = _hasher(23, nb, r, dim)
+        if not h._replay_model():
+            pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+        n, wide = 20_000, dim + 212
+        big = torch.randn(n + 7, wide, device="cuda", generator=torch.Generator("cuda").manual_seed(dim))
+        big[:, dim + 8:] = float("nan")                       # poison behind every row's end
+        big[:, :8] = float("inf")                             # ... and in front of the view's columns
+        view = big[5:5 + n, 8:8 + dim]                        # 16-byte aligned: (5 * wide + 8) * 4 bytes
+        assert view.data_ptr() % 16 == 0 and view.stride(0) == wide
+        got = h.hash_device(view)
+        assert h.last_stats["route"] == "split+replay", h.last_stats
+        sl = np.r_[0:600, n - 600:n]
+        want = hash_batch_literal_packed(h.projections, view.cpu().numpy()[sl])
+        assert np.array_equal(got.cpu().numpy()[sl], want)
+        assert torch.equal(got, h.hash_device(view.contiguous()))
+        odd = big[5:5 + n, 9:9 + dim]                         # 4 bytes off: not the replay's input
+        got_odd = h.hash_device(odd)
+        assert h.last_stats["route"] in ("plain", "host-engine pipelined")
+        assert torch.equal(got_odd, h.hash_device(odd.contiguous()))
+
+
 def test_full_size_properties_1m_rows(torch_mod):
     """BASELINE config 2 size (1M x 768, 256 bits): size-independent properties."""
     torch = torch_mod
