@@ -220,6 +220,32 @@ def test_views_of_wider_matrices_through_the_split_pass(torch_mod):
         assert torch.equal(got_odd, h.hash_device(odd.contiguous()))
 
 
+@pytest.mark.parametrize("nb,r,dim", [(20, 10, 768), (16, 16, 300), (40, 5, 100), (128, 4, 768)])
+def test_ragged_batch_sizes_on_compact_blocks_and_partial_tiles(torch_mod, nb, r, dim):
+    """Batches that end inside a workgroup, inside a wave's 32 rows, one row past a round of workgroups - on the kernels
+    with the compact column blocks and / or the masked last k-tile: every row against the reference-literal loop."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(29, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    big = torch.randn(3_000, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(nb + dim))
+    big[17] = 0.0
+    big[300, 5] = float("nan")
+    want = hash_batch_literal_packed(h.projections, big.cpu().numpy())
+    for n in (1, 31, 255, 256, 257, 511, 513, 1_000, 2_999):
+        flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        got = h.hash_device(big[:n], row_flags=flags)
+        assert h.last_stats["route"] == ("split+replay" if n >= 256 else "f32+replay"), (n, h.last_stats)
+        assert np.array_equal(got.cpu().numpy(), want[:n]), n
+        assert int(flags.sum()) == (1 if n > 17 else 0) + (2 if n > 300 else 0)
+    x = torch.randn(65_536 + 1, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    got = h.hash_device(x)
+    sl = np.r_[0:300, 65_536 - 300:65_537]
+    assert np.array_equal(got.cpu().numpy()[sl], hash_batch_literal_packed(h.projections, x.cpu().numpy()[sl]))
+
+
 def test_full_size_properties_1m_rows(torch_mod):
     """BASELINE config 2 size (1M x 768, 256 bits): size-independent properties."""
     torch = torch_mod
