@@ -28,7 +28,10 @@ def run(rounds: int, seed: int = 2025, steps: int = 30, verbose: bool = True):
     rng = np.random.default_rng(seed)
     bad = checks = 0
     for rnd in range(rounds):
-        dim, nb, r = [(768, 16, 16), (128, 16, 4), (1536, 16, 32), (64, 8, 8), (256, 16, 16)][rnd % 5]
+        shapes = [(768, 16, 16), (128, 16, 4), (1536, 16, 32), (64, 8, 8), (256, 16, 16),
+                  # bands the host BLAS does not take four rows at a time, vectors that are not whole k-tiles, odd key widths
+                  (300, 20, 10), (100, 40, 5), (768, 25, 8), (96, 5, 20)]
+        dim, nb, r = shapes[rnd % len(shapes)]
         packed = bool(rnd % 2)
         centers = rng.standard_normal((40, dim)).astype(np.float32)
         def draw(m):
