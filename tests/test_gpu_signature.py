@@ -1152,15 +1152,17 @@ def test_adversarial_rows_and_the_proven_window(torch_mod):
         assert np.array_equal(h.hash_batch_packed(big)[-4096:], want)
 
 
-def test_streamed_host_input_equals_device_path(torch_mod):
+@pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (16, 16, 300), (20, 10, 768)])
+def test_streamed_host_input_equals_device_path(torch_mod, nb, r, dim):
     """hash_batch_packed on a large host array: chunks cross PCIe on a copy stream while the previous one is hashed and
     the one before that travels back (two pinned key buffers, source page-locked in place) - same bytes and flags as
-    hashing the whole batch on the device, with odd chunk sizes, a ragged tail, zero / NaN rows on chunk borders."""
+    hashing the whole batch on the device, with odd chunk sizes, a ragged tail, zero / NaN rows on chunk borders.
+    (300-d: the masked last k-tile; 20 x 10: compact column blocks.)"""
     torch = torch_mod
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
-    n, dim = 150_001, 768
-    h = _hasher(42, 16, 16, dim)
+    n = 150_001
+    h = _hasher(42, nb, r, dim)
     if not h._replay_model():
         pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
     x = np.random.default_rng(5).standard_normal((n, dim)).astype(np.float32)
