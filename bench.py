@@ -239,7 +239,12 @@ def self_launch(args) -> int:
 
 def main() -> None:
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    env_world = int(os.environ.get("WORLD_SIZE", "1") or "1")
+    if args.gpus > 1 and env_world != args.gpus:
+        # no launcher around this process (or an environment that exports WORLD_SIZE=1 on its own): become the launcher.
+        # Anything else - a launcher that started a different number of ranks - is an error, never a silent 1-GPU run.
+        if env_world != 1 or os.environ.get("LSHRS_BENCH_SELF_LAUNCHED"):
+            raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={env_world}")
         raise SystemExit(self_launch(args))
     # ONE JSON line on stdout, whatever the libraries underneath choose to print there (gloo announces its connections
     # on stdout): everything else this process writes to fd 1 goes to stderr, the line itself to the real stdout

@@ -109,9 +109,14 @@ class LSHRS:
 
     Keyword arguments are those of the reference constructor (lshrs/core/main.py:154-173).
     Extras: ``hasher`` (inject a ready hasher object; default builds ``LSHHasher``), ``device`` (GPU index for
-    the default hasher) and ``packed_ingest`` (hand whole key arrays to ``storage.batch_add_packed`` instead of
-    building one ``(band, key, id)`` tuple per operation; off by default so that ``batch_add`` sees exactly the
-    reference's operation lists).
+    the default hasher) and ``packed_ingest``: how ``index()`` hands a batch's buckets to the storage.
+    ``"auto"`` (default): batches of at least ``packed_auto_min_ops`` operations go as ONE bucket CSR grouped on the
+    device (``storage.batch_add_csr`` / ``batch_add_packed``; the reference's ``RedisStorage`` - anything with its
+    ``pipeline()`` + ``bucket_key()`` - is wrapped in ``RedisPackedWriter``: one ``SADD`` per bucket) where the storage
+    can take that, smaller batches and other storages get the reference's ``(band, key, id)`` tuples through
+    ``batch_add``; ``True``: the array path whenever the storage can take it; ``False``: always the reference's
+    operation lists, flush boundaries included (what tests/golden/g5_orchestration.json pins).  Same bucket contents
+    every way (lshrs/core/main.py:1113-1143, lshrs/storage/redis.py:348-416).
     """
 
     def __init__(
@@ -135,7 +140,7 @@ class LSHRS:
         seed: int = 42,
         hasher: Any = None,
         device: Any = None,
-        packed_ingest: bool = False,
+        packed_ingest: Union[bool, str] = "auto",
         devices: Optional[Sequence[int]] = None,
     ) -> None:
         if dim <= 0:
@@ -158,7 +163,11 @@ class LSHRS:
         self._dim = dim
         self._buffer_size = buffer_size
         self._vector_fetch_fn = vector_fetch_fn
-        self._packed_ingest = bool(packed_ingest)
+        if packed_ingest not in (True, False, "auto"):
+            raise ValueError("packed_ingest must be True, False or 'auto'")
+        self._packed_ingest = packed_ingest
+        self.packed_auto_min_ops = 8_192     # "auto": below this many (band, key, id) operations the tuples are cheaper
+        self._packed_writer = None
         self._hasher = hasher if hasher is not None else LSHHasher(
             num_bands=num_bands, rows_per_band=rows_per_band, dim=dim, seed=seed, device=device, devices=devices)
         self._storage = storage if storage is not None else default_storage(
@@ -221,7 +230,8 @@ class LSHRS:
                 "Number of vectors does not match number of indices "
                 f"(received {arr.shape[0]} vectors for {len(indices)} indices)")
 
-        packed = self._packed_ingest and (hasattr(self._storage, "batch_add_csr") or hasattr(self._storage, "batch_add_packed"))
+        sink = self._packed_sink(arr.shape[0] * self._config["num_bands"])
+        packed = sink is not None
         if packed:
             id_arr = np.asarray(indices)
             id_arr = id_arr.astype(np.int64) if id_arr.dtype.kind in "iuf" else np.array([int(i) for i in indices], dtype=np.int64)
@@ -249,15 +259,15 @@ class LSHRS:
             # array path: same buckets, same members, no per-operation Python objects.
             # Anything already buffered goes first so the storage sees operations in the original order.
             self.flush()
-            if hasattr(self._storage, "batch_add_csr"):
+            if hasattr(sink, "batch_add_csr"):
                 # the whole batch (the rows in front of a bad one) as ONE bucket CSR, grouped on the device
                 if stop:
-                    self._storage.batch_add_csr(_bucket_csr(id_arr[:stop], keys[:stop]))
+                    sink.batch_add_csr(_bucket_csr(id_arr[:stop], keys[:stop]))
             else:
                 per_call = max(1, -(-self._buffer_size // keys.shape[1]))  # vectors per storage call ~ buffer_size ops
                 for lo in range(0, stop, per_call):
                     hi = min(stop, lo + per_call)
-                    self._storage.batch_add_packed(id_arr[lo:hi], keys[lo:hi])
+                    sink.batch_add_packed(id_arr[lo:hi], keys[lo:hi])
             if error is not None:
                 raise error
             return
@@ -507,7 +517,7 @@ class LSHRS:
             similarity_threshold=cfg["similarity_threshold"], buffer_size=cfg["buffer_size"], vector_fetch_fn=None,
             redis_host=rc["host"], redis_port=rc["port"], redis_db=rc["db"], redis_password=rc["password"],
             redis_prefix=rc["prefix"], decode_responses=rc["decode_responses"], seed=cfg["seed"], hasher=hasher,
-            packed_ingest=bool(extra.get("packed_ingest", False)), storage=_DeferredStorage(rc))
+            packed_ingest=extra.get("packed_ingest", "auto"), storage=_DeferredStorage(rc))
         self.__dict__ = restored.__dict__
         self._hasher.projections = [np.asarray(m, dtype=np.float32) for m in state["projections"]]
 
@@ -564,7 +574,7 @@ class LSHRS:
             pair = np.sort((q << mbits) | m)
             first = np.r_[True, pair[1:] != pair[:-1]]
             starts = np.flatnonzero(first)
-            counts = np.minimum(np.diff(np.r_[starts, pair.shape[0]]), nb)     # (a band counts once: buckets are sets)
+            counts = np.diff(np.r_[starts, pair.shape[0]])     # (one pair per (query, band, member): the lookup's contract)
             uniq = pair[starts]
             uq, um = uniq >> mbits, uniq & ((1 << mbits) - 1)
             ranked = np.sort((uq << (mbits + cbits)) | ((nb - counts) << mbits) | um)
@@ -574,7 +584,7 @@ class LSHRS:
             q, m = q[order], m[order]
             first = np.r_[True, (q[1:] != q[:-1]) | (m[1:] != m[:-1])]
             starts = np.flatnonzero(first)
-            counts = np.minimum(np.diff(np.r_[starts, q.shape[0]]), nb)
+            counts = np.diff(np.r_[starts, q.shape[0]])
             uq, um = q[starts], m[starts]
             rank = np.lexsort((um, -counts, uq))                 # by query, then -collisions, then id
             uq, um = uq[rank], um[rank]
@@ -583,6 +593,26 @@ class LSHRS:
     def _ordered_candidates_many(self, keys: np.ndarray) -> List[List[int]]:
         um, bounds = self._ordered_candidates_arrays(keys)
         return _split_rows(um.tolist(), np.diff(bounds))
+
+    def _packed_sink(self, n_ops: int):
+        """The object ``index()`` hands a batch's buckets to as arrays, or None for the reference's operation tuples
+        (see ``packed_ingest`` in the class docstring)."""
+        mode = self._packed_ingest
+        if mode is False or (mode == "auto" and n_ops < self.packed_auto_min_ops):
+            return None
+        st = self._storage
+        if isinstance(st, _DeferredStorage):
+            st = st._resolve()                   # (index() is about to write to it anyway)
+        if hasattr(st, "batch_add_csr") or hasattr(st, "batch_add_packed"):
+            return st
+        if callable(getattr(st, "pipeline", None)) and callable(getattr(st, "bucket_key", None)):
+            # the reference's RedisStorage (lshrs/storage/redis.py:187,508): same SADDs, one command per bucket
+            if self._packed_writer is None or self._packed_writer.storage is not st:
+                from .packed_ops import RedisPackedWriter
+
+                self._packed_writer = RedisPackedWriter(st)
+            return self._packed_writer
+        return None
 
     def _enqueue_packed(self, index: int, band_keys: np.ndarray) -> None:
         ops = [(b, band_keys[b].tobytes(), index) for b in range(band_keys.shape[0])]

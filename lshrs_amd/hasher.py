@@ -385,9 +385,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             x = x.contiguous()
         mode = self.tie_break if tie_break is None else tie_break
         with self._lock:
-            return self._hash_device_locked(x, out, row_flags, mode, host_rows=None)
+            return self._hash_device_locked(x, out, row_flags, mode, host_rows=None, yield_lock=True)
 
-    def _hash_device_locked(self, x, out, row_flags, mode, host_rows, allow_pipeline: bool = True):
+    def _hash_device_locked(self, x, out, row_flags, mode, host_rows, allow_pipeline: bool = True, yield_lock: bool = False):
         torch = _native.require_gpu()
         lib = _native.load()
         dev = x.device
@@ -410,7 +410,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         tau = self._tau_arg()
         stats["route"] = route
         if route == "split+replay":
-            return self._hash_device_replay(x, out, row_flags, ws, tau, stats, model)
+            return self._hash_device_replay(x, out, row_flags, ws, tau, stats, model, yield_lock)
         if route == "f32+replay":
             return self._hash_device_f32_replay(x, out, row_flags, ws, tau, stats, model)
         if route == "host-engine pipelined":
@@ -427,7 +427,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                     if not self._flag_overflow(flag):
                         return out
                     stats["relaunches"] += 1
-            cap = min(max(4096, n // 16 + 4096), 2 ** 30)
+            cap = min(max(4096, n // 16 + 4096, int(1.3 * self._expected_tie_entries(n)) + 4096), 2 ** 30)
             while True:
                 tie_list = torch.empty((cap, 2), dtype=torch.int64, device=dev)
                 tie_count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -475,8 +475,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                                    ">= 256 key columns or 128 .. 224 with dim >= 384, hyperplane norms in range), 16-byte aligned rows"),
         ("f32+replay",             "host BLAS order recognised, dim % 4 == 0, aligned rows: small "
                                    "batches and shapes the split pass does not take"),
-        ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists: chunks "
-                                   "overlapped by csrc/pipeline.hip, ties by the library's own sgemv"),
+        ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists, a tie window "
+                                   "narrow enough for the per-chunk lists (measured windows): chunks overlapped by csrc/pipeline.hip, "
+                                   "ties by the library's own sgemv"),
         ("plain",                  "everything else: one pass, then the host engine or NumPy on the tied pairs"),
     )
 
@@ -492,9 +493,18 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             if self.dim % 4 == 0 and self.dim >= 8:      # (the model's own limits - 8 m + 4 elements only up to 4096 - are in `model`)
                 return "f32+replay", model
         if (allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
-                and self._tie_engine() is not None):
+                and self._expected_tie_entries(32) <= 0.75 and self._tie_engine() is not None):
+            # (the pipeline's per-chunk lists - and the pinned copies of the tied rows behind them - hold one entry per 32
+            #  rows; the PROVEN tie window without a replay, ~1 000 units at 768-d, ties a third of the rows: every chunk
+            #  would overflow and be hashed twice, so that case takes the plain path with a list sized for it)
             return "host-engine pipelined", 0
         return "plain", 0
+
+    def _expected_tie_entries(self, rows: int) -> float:
+        """Projections a batch of Gaussian-like rows puts inside the tie window in force: per unit of window width
+        (2^-24 ||x|| ||p||) a projection lands inside with probability 2 * 2^-24 * sqrt(dim / 2 pi) - 1.32e-6 at 768-d."""
+        per_unit = 2.0 * _U * (self.dim / (2.0 * np.pi)) ** 0.5
+        return rows * self.num_bands * self.rows_per_band * min(float(self.tau_ulps), 1.0e5) * per_unit
 
     # ------------------------------------------------------------------ ties broken on the device
     def _replay_model(self) -> int:
@@ -530,7 +540,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                 pinned = torch.zeros((4, nc), dtype=torch.int32).pin_memory()
                 scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
                            torch.zeros(_native.SIG_DEVICE_COUNTERS, dtype=torch.int32, device=dev),   # counters + stage-2 slots
-                           pinned, pinned.numpy(), [0],
+                           pinned, pinned.numpy(), [0, [3, 2, 1, 0]],             # launches so far, free pinned blocks
                            torch.empty((cap,), dtype=torch.float32, device=dev))   # stage-1 value of every list entry
                 if len(self._replay_scratch) >= 16 and not self._async_pending:
                     # a caller that keeps making new streams must not pile up lists: nothing is in flight, start over
@@ -539,7 +549,11 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
             flag_list, counts, pinned, host_counts, turn, flag_y = scratch
-            slot = turn[0] & 3
+            while not turn[1]:        # every pinned block belongs to an unverified launch: verify the oldest streamed one
+                if not self._async_pending:      # (cannot happen: a synchronous caller that takes the last block keeps the lock)
+                    raise _native.NativeLibraryError("no free counter block for a replay launch")
+                self._async_pending[0]._finish_locked()
+            slot = turn[1].pop()
             turn[0] += 1
             ev = None
             opts = None
@@ -569,22 +583,27 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             except BaseException:
                 cur.synchronize()
                 counts.zero_()              # a failed launch may have left counts behind: the next call starts from zero
+                turn[1].append(slot)
                 raise
             done = None
             if want_event:          # (the synchronous path waits for the stream instead)
                 done = torch.cuda.Event()
                 done.record(cur)
+        # (the ceiling the live check holds this launch to is the one of the coefficients it was launched with: `window_info`
+        #  follows whichever BLAS-order model `_ensure_window` set last, and an async handle may be finished after a switch)
         return (done if want_event else cur, host_counts, slot, int(flag_list.shape[0]), n, ev,
-                float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps))
+                float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps),
+                float(self.window_info.get("window_units_worst_case_row", float("inf"))), turn[0], turn)
 
     def _replay_finish(self, state, stats) -> bool:
         """Wait for a launch of `_replay_launch`; False when it must be repeated: its stage-1 list was too small (more
         room next time), or the stage-1 deviation measured on its flagged projections came within `margin_guard` of
         the window (the hasher switches to the deterministic bound and stays there)."""
-        done, host_counts, slot, cap, n, ev, window = state
+        done, host_counts, slot, cap, n, ev, window, worst = state[:8]
         done.synchronize()      # (the launch behind stage 2 has written the counters into the pinned block)
         ties, flagged, flips = int(host_counts[slot, 0]), int(host_counts[slot, 1]), int(host_counts[slot, 3])
         max_dev = float(host_counts[slot, 2:3].view(np.float32)[0])
+        state[9][1].append(slot)        # (the pinned block is free for the next launch)
         if flagged > cap:
             self._flag_cap_hint = int(flagged * 1.25) + 4096      # (rows flagged wholesale: NaN / Inf / extreme scales)
             stats["relaunches"] += 1
@@ -593,7 +612,6 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         if window == float("inf"):
             # proven window: what stage 2 measured on every flagged projection can only be INSIDE it - anything else is a
             # bug in the bound or in the arithmetic model it rests on, and must not pass silently
-            worst = float(self.window_info.get("window_units_worst_case_row", float("inf")))
             if max_dev > worst:
                 raise _native.NativeLibraryError(
                     f"stage 1 strayed {max_dev:.1f} units from the host's value, outside the proven window "
@@ -623,15 +641,31 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         stats["tie_break_engine"] = "device-replay"
         return True
 
-    def _hash_device_replay(self, x, out, row_flags, ws, tau, stats, model):
+    def _hash_device_replay(self, x, out, row_flags, ws, tau, stats, model, yield_lock: bool = False):
         """One launch of the split pass whose stage 2 also breaks the ties (``lshrs_sig_hash_batch_split_replay_f32``):
         the keys are the reference's when the stream has run.  The only host step is reading two counters back
         (stage-1 list overflow -> repeat with room; tied projections -> stats)."""
         while self._async_pending:      # (their pinned pairs are handed out in turn: verify them before taking more)
             self._async_pending[0]._finish_locked()
-        while not self._replay_finish(self._replay_launch(x, out, row_flags, ws, tau, model), stats):
+        while True:
+            state = self._replay_launch(x, out, row_flags, ws, tau, model)
+            if yield_lock and state[9][1]:      # (whoever takes the LAST pinned block keeps the lock until it is free again)
+                # (only for `hash_device` itself - the callers that drive shared staging buffers keep the lock.)  The
+                # hasher's lock covers what is SHARED - the hand-out of scratch, pinned counter blocks and turns, the window
+                # switch - not the wait for the device: another thread (another stream) may enqueue its batch meanwhile.
+                # Launches on one stream are ordered by the stream; every launch has a pinned counter block of its own.
+                self._lock.release()
+                try:
+                    state[0].synchronize()
+                finally:
+                    self._lock.acquire()
+            if self._replay_finish(state, stats):
+                break
             self._ensure_window(x.device, ws, model)      # (a guard that has just moved the hasher to the proven window)
-        if self.audit_every > 0 and stats.get("flagged", 0) > 0:
+        skey = (x.device.index, _native.require_gpu().cuda.current_stream(x.device).cuda_stream)
+        scratch = self._replay_scratch.get(skey)
+        undisturbed = scratch is not None and scratch[4][0] == state[8]     # nobody has launched over this list since
+        if self.audit_every > 0 and stats.get("flagged", 0) > 0 and undisturbed:
             self._audit_countdown -= 1
             if self._audit_countdown <= 0:
                 self._audit_countdown = self.audit_every

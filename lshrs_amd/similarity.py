@@ -132,13 +132,24 @@ def l2_normalize_device(x):
     return out, status
 
 
+def _upload(torch, a: np.ndarray):
+    """Host array -> device tensor.  The array is only read: a read-only view (``np.frombuffer``, a memory map, a
+    broadcast) is uploaded as it is, without the copy ``torch.from_numpy`` asks for in its warning."""
+    import warnings
+
+    a = np.ascontiguousarray(a)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return torch.from_numpy(a).cuda()
+
+
 def l2_norm(vector) -> np.ndarray:
     """Unit-length copy of ``vector`` (float32, flattened); zero vector -> ValueError (norm.py:48-61)."""
     torch = _native.require_gpu()
     vec = np.ascontiguousarray(np.asarray(vector, dtype=np.float32).reshape(-1))
     if vec.size == 0:
         raise ValueError("Cannot normalize zero vector")
-    out, status = l2_normalize_device(torch.from_numpy(vec).cuda().reshape(1, -1))
+    out, status = l2_normalize_device(_upload(torch, vec).reshape(1, -1))
     if int(status[0]) != 0:
         raise ValueError("Cannot normalize zero vector")
     return out.reshape(-1).cpu().numpy()
@@ -151,8 +162,8 @@ def cosine_similarity(query, candidates) -> np.ndarray:
     mat = _as_matrix(candidates)
     if mat.shape[1] != q.shape[0]:
         raise ValueError(f"shapes {mat.shape} and {q.shape} not aligned")
-    dev_c = torch.from_numpy(mat).cuda()
-    dev_q = torch.from_numpy(np.ascontiguousarray(q)).cuda().reshape(1, -1)
+    dev_c = _upload(torch, mat)
+    dev_q = _upload(torch, q).reshape(1, -1)
     scores, status, qstatus = cosine_scores_device(dev_c, dev_q, None, c=mat.shape[0])
     _raise_for_status(status, qstatus)
     return scores.reshape(-1).cpu().numpy()
@@ -169,8 +180,8 @@ def top_k_cosine(query, candidates, *, k: int) -> List[Tuple[int, float]]:
     if mat.shape[1] != q.shape[0]:
         raise ValueError(f"shapes {mat.shape} and {q.shape} not aligned")
     n = mat.shape[0]
-    dev_c = torch.from_numpy(mat).cuda()
-    dev_q = torch.from_numpy(np.ascontiguousarray(q)).cuda().reshape(1, -1)
+    dev_c = _upload(torch, mat)
+    dev_q = _upload(torch, q).reshape(1, -1)
     scores, status, qstatus = cosine_scores_device(dev_c, dev_q, None, c=n)
     _raise_for_status(status, qstatus)
     order, sorted_scores = topk_desc_device(scores, min(k, n))
@@ -195,7 +206,7 @@ def rerank_batch(queries, corpus, cand_idx, *, k: int, return_tensors: bool = Fa
     def dev(a, dtype):
         if isinstance(a, torch.Tensor):
             return a.cuda() if not a.is_cuda else a
-        return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).cuda()
+        return _upload(torch, np.asarray(a, dtype=dtype))
 
     d_q = dev(queries, np.float32)
     d_c = dev(corpus, np.float32)
@@ -221,7 +232,7 @@ def rerank_padded_arrays(queries, corpus, cand_idx):
     def dev(a, dtype):
         if isinstance(a, torch.Tensor):
             return a if a.is_cuda else a.cuda()
-        return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=dtype))).cuda()
+        return _upload(torch, np.asarray(a, dtype=dtype))
 
     d_q, d_c, d_i = dev(queries, np.float32), dev(corpus, np.float32), dev(cand_idx, np.int64)
     scores, status, qstatus = cosine_scores_device(d_c, d_q, d_i)

@@ -116,7 +116,13 @@ class InMemoryStorage:
                         qs.append(np.full(len(mem), qi, dtype=np.int64))
             return (np.concatenate(qs) if qs else np.empty(0, np.int64),
                     np.concatenate(ms) if ms else np.empty(0, np.int64))
-        sources = 1 if qs else 0
+        # Set semantics across sources: an id indexed through two calls sits in the same bucket twice - once per source - and
+        # must count once.  That needs a sort of every (query, band, member) pair, so it is only paid where it can happen:
+        # op-tuple buckets that were hit, a segment that may list a member twice, or segments whose id ranges overlap
+        # (sequential ingest - the normal state between compactions - gives disjoint ranges: no id is in two of them).
+        tuple_hits, seg_hits, dedupe = bool(qs), 0, False
+        spans = sorted(_id_span(seg) for seg in segments)
+        overlapping = any(a[1] >= b[0] for a, b in zip(spans[:-1], spans[1:]))
         codes = key_codes(keys).reshape(-1)
         qidx = np.repeat(np.arange(nq, dtype=np.int64), nb)
         bidx = np.tile(np.arange(nb, dtype=np.int64), nq)
@@ -136,11 +142,12 @@ class InMemoryStorage:
             ms.append(seg.members[pos])
             qs.append(np.repeat(q, lens))
             bs.append(np.repeat(b, lens))
-            sources += 1 if seg.distinct else 2         # (a segment that may list a member twice counts as two)
+            seg_hits += 1
+            dedupe = dedupe or not seg.distinct         # (a segment that may list a member twice in one bucket)
         if not qs:
             return np.empty(0, np.int64), np.empty(0, np.int64)
         q, m = np.concatenate(qs), np.concatenate(ms)
-        if sources > 1:
+        if dedupe or (tuple_hits and seg_hits) or (seg_hits > 1 and overlapping):
             # the same id may sit in the same bucket through two sources (indexed twice): once per (query, band)
             b = np.concatenate(bs)
             order = np.lexsort((m, b, q))
@@ -237,6 +244,15 @@ class InMemoryStorage:
     def unique_indices(self) -> Set[int]:
         with self._lock:
             return {i for b in self.batches for _, _, i in b}
+
+
+def _id_span(seg) -> Tuple[int, int]:
+    """(smallest, largest) member id of an array segment, remembered on the segment."""
+    span = getattr(seg, "_id_span", None)
+    if span is None:
+        span = (int(seg.members.min()), int(seg.members.max())) if seg.members.size else (0, -1)
+        seg._id_span = span
+    return span
 
 
 def default_storage(**redis_kwargs):

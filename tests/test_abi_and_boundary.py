@@ -225,7 +225,12 @@ def test_route_table():
         assert LSHHasher(16, 16, 100, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 m + 4 elements, a partial k-tile
         assert LSHHasher(8, 7, 100, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)        # ... with 64 key columns
         assert LSHHasher(16, 16, 102, seed=1)._route(5_000, "host", **ok) == ("plain", 0)           # dim % 4 != 0
-    off = LSHHasher(16, 16, 768, seed=42, tie_replay="off")
+    # the host engine: chunks overlapped by the native pipeline where the tie window is narrow enough for its per-chunk lists
+    # (measured windows); the PROVEN tie window without a replay ties a third of the rows - every chunk would overflow and be
+    # hashed twice - so it takes the plain path with a list sized for it
+    assert LSHHasher(16, 16, 768, seed=42, tie_replay="off")._route(1_000_000, "host", **ok) == ("plain", 0)
+    assert LSHHasher(16, 16, 768, seed=42, tie_replay="off")._expected_tie_entries(1_000_000) > 100_000
+    off = LSHHasher(16, 16, 768, seed=42, tie_replay="off", tau_ulps=8.0, tau1_ulps=64.0)
     big = off._route(1_000_000, "host", **ok)
     assert big == (("host-engine pipelined", 0) if off._tie_engine() is not None else ("plain", 0))
     assert off._route(1_000_000, "host", aligned=True, short_stride=True, host_rows=True) == ("plain", 0)

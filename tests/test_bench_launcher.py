@@ -29,10 +29,30 @@ def test_self_launch_two_ranks_one_json_line():
     assert json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "self_launched": True}
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_world_size_one_in_the_environment_still_launches_n_ranks():
+    """Some schedulers export WORLD_SIZE=1 on their own: `--gpus 2` must still start two ranks (not run one silently), and a
+    launcher that started another number of ranks is an error."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300,
+                         env=dict(_env(), WORLD_SIZE="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0]) == {"dry_run": True, "n_gpus": 2, "self_launched": True}
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120,
+                         env=dict(_env(), WORLD_SIZE="2", RANK="0"))
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and out.stdout.strip() == ""
+
+
 def test_launcher_form_still_works():
     """The driver's multi-GPU form: torch.distributed.run around the same script (ranks do not self-launch again)."""
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29713", BENCH, "--gpus", "2", "--dry-run"],
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2", "--dry-run"],
                          capture_output=True, text=True, timeout=300, env=_env())
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]

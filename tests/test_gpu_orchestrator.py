@@ -80,7 +80,7 @@ def test_config1_10k_x_128_through_hip(g5):
     from lshrs_amd import LSHRS, InMemoryStorage
 
     store = InMemoryStorage()
-    idx = LSHRS(dim=128, num_perm=64, storage=store, buffer_size=10_000)
+    idx = LSHRS(dim=128, num_perm=64, storage=store, buffer_size=10_000, packed_ingest=False)   # (the op lists g5 pins)
     x = np.random.default_rng(1).standard_normal((10_000, 128)).astype(np.float32)
     idx.index(list(range(10_000)), x)
     want = g5["c1"]

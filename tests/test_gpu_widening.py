@@ -130,8 +130,8 @@ def test_in_process_multi_device_ingestion(torch_mod):
 
     # through the orchestrator: the reference's operation order and flush boundaries (lshrs/core/main.py:1125-1143)
     m = 3_000
-    a = LSHRS(dim=dim, num_perm=256, storage=InMemoryStorage(), buffer_size=10_000)
-    b = LSHRS(dim=dim, num_perm=256, storage=InMemoryStorage(), buffer_size=10_000, devices=[0, 0])
+    a = LSHRS(dim=dim, num_perm=256, storage=InMemoryStorage(), buffer_size=10_000, packed_ingest=False)
+    b = LSHRS(dim=dim, num_perm=256, storage=InMemoryStorage(), buffer_size=10_000, devices=[0, 0], packed_ingest=False)
     b._hasher.multi_device_min_rows = 512
     ids = list(range(100, 100 + m))
     a.index(ids, x[:m])

@@ -82,7 +82,9 @@ def test_negative_id_mid_batch_error_timing(monkeypatch, g5):
 def test_config1_plumbing_10k_x_128(monkeypatch, g5):
     """BASELINE config 1: 10k x 128-d, num_perm=64 -> (16, 4), in-memory storage, CPU plumbing."""
     store = InMemoryStorage()
-    idx = make_cpu_lshrs(monkeypatch, dim=128, num_perm=64, storage=store, buffer_size=10_000)
+    # (packed_ingest=False: the reference's operation lists and flush boundaries are what g5 pins; the default, "auto",
+    #  hands a batch of this size over as ONE bucket CSR - same buckets, see test_packed_ops.py)
+    idx = make_cpu_lshrs(monkeypatch, dim=128, num_perm=64, storage=store, buffer_size=10_000, packed_ingest=False)
     x = np.random.default_rng(1).standard_normal((10_000, 128)).astype(np.float32)
     idx.index(list(range(10_000)), x)
     want = g5["c1"]

@@ -96,6 +96,64 @@ def test_redis_writer_sends_the_same_members_in_fewer_commands():
     assert writer.get_bucket(0, b"\x00") == {1, 2}          # everything else is delegated
 
 
+def test_default_ingest_mode_is_auto(monkeypatch):
+    """INTEGRATION option B unchanged (no `packed_ingest` argument) takes the array path where that is
+    safe - the storage can take a bucket CSR, or is the reference's RedisStorage (pipeline() + bucket_key(): wrapped in
+    RedisPackedWriter) - and the reference's operation tuples otherwise; small batches keep the tuples.  Same buckets."""
+    rng = np.random.default_rng(4)
+    data = rng.standard_normal((3000, 32)).astype(np.float32)
+    kw = dict(dim=32, num_bands=4, rows_per_band=4, num_perm=16)
+    tuples, auto = InMemoryStorage(), InMemoryStorage()
+    make_cpu_lshrs(monkeypatch, storage=tuples, packed_ingest=False, **kw).index(list(range(3000)), data)
+    idx = LSHRS(storage=auto, hasher=OracleBackedHasher(4, 4, 32, 42), **kw)        # no packed_ingest argument
+    assert idx._packed_ingest == "auto"
+    from lshrs_amd import core, packed_ops
+    monkeypatch.setattr(core, "_bucket_csr", lambda ids, keys: packed_ops._csr_host(
+        np.ascontiguousarray(np.asarray(ids, dtype=np.int64)), np.ascontiguousarray(keys, dtype=np.uint8)))
+    idx.index(list(range(3000)), data)                                              # 12 000 operations: one bucket CSR
+    assert [n for n, _ in auto.packed_batches] == [3000] and not auto.batches
+    assert auto.bucket_contents() == tuples.bucket_contents()
+    idx.index([5000, 5001], data[:2])                                               # 8 operations: the reference's tuples
+    assert [len(b) for b in auto.batches] == [8]
+    # the reference's RedisStorage interface: one SADD per bucket through its own pipeline
+    fake = FakeRedisStorage()
+    fake.batch_add = lambda ops: fake.commands.extend((fake.bucket_key(b, k), (i,)) for b, k, i in ops)
+    r = LSHRS(storage=fake, hasher=OracleBackedHasher(4, 4, 32, 42), **kw)
+    r.index(list(range(3000)), data)
+    sent = {(name, int(m)) for name, members in fake.commands for m in members}
+    assert sent == {(name, m) for name, ms in tuples.bucket_contents().items() for m in ms}
+    assert len(fake.commands) < 3000 * 4 // 2                                       # (buckets, not operations)
+    # a storage with neither interface (the reference's MockStorage): tuples, whatever the size
+    class Plain:
+        def __init__(self):
+            self.ops = []
+        def batch_add(self, ops):
+            self.ops.extend(ops)
+    plain = Plain()
+    LSHRS(storage=plain, hasher=OracleBackedHasher(4, 4, 32, 42), **kw).index(list(range(3000)), data)
+    assert len(plain.ops) == 12_000
+    with pytest.raises(ValueError):
+        LSHRS(storage=plain, packed_ingest="yes", **kw)
+
+
+def test_disjoint_segments_need_no_dedupe_and_overlapping_ones_get_it():
+    """sequential ingest leaves segments with disjoint id ranges - a lookup then concatenates their members
+    without sorting every (query, band, member) pair; ids indexed twice (overlapping ranges) still count once per band."""
+    from lshrs_amd.packed_ops import _csr_host
+
+    rng = np.random.default_rng(6)
+    keys = rng.integers(0, 3, size=(600, 4, 1), dtype=np.uint8)
+    store = InMemoryStorage()
+    store.batch_add_csr(_csr_host(np.arange(0, 300, dtype=np.int64), keys[:300]))
+    store.batch_add_csr(_csr_host(np.arange(300, 600, dtype=np.int64), keys[300:]))
+    q, m = store.get_buckets_many(keys[:5])
+    want = sorted((qi, b, i) for qi in range(5) for b in range(4) for i in range(600) if keys[i, b, 0] == keys[qi, b, 0])
+    assert sorted(zip(q.tolist(), m.tolist())) == sorted((qi, i) for qi, _, i in want)
+    store.batch_add_csr(_csr_host(np.arange(100, 200, dtype=np.int64), keys[100:200]))      # the same ids again
+    q2, m2 = store.get_buckets_many(keys[:5])
+    assert sorted(zip(q2.tolist(), m2.tolist())) == sorted(zip(q.tolist(), m.tolist()))
+
+
 @pytest.mark.gpu
 def test_hex_kernel_equals_bytes_hex():
     import torch

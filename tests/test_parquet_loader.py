@@ -113,6 +113,6 @@ def test_create_signatures_uses_the_fast_loader_and_is_faster(tmp_path, monkeypa
     same(fast, slow)
     assert (t1 - t0) < (t2 - t1), "array path should beat the per-value path"
     store = InMemoryStorage()
-    idx = make_cpu_lshrs(monkeypatch, dim=dim, num_perm=64, storage=store)
+    idx = make_cpu_lshrs(monkeypatch, dim=dim, num_perm=64, storage=store, packed_ingest=False)
     idx.create_signatures(format="parquet", source=path, batch_size=2000)
     assert store.total_operations == n * 16 and len(store.batches) == 3 * 4   # per loader batch: 3 flushes of 10 000 ops + the final 2 000

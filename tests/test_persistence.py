@@ -119,7 +119,7 @@ def test_pickle_carries_device_windows_and_ingest_mode_and_defers_the_storage():
     del state["lshrs_amd"]
     plain = LSHRS.__new__(LSHRS)
     plain.__setstate__(state)
-    assert plain._packed_ingest is False and plain._hasher.window_mode["tau1"] == "bound"       # (the default: the proven window)
+    assert plain._packed_ingest == "auto" and plain._hasher.window_mode["tau1"] == "bound"       # (the default: the proven window)
     # a storage proxy whose __init__ has not run (copy / pickle build instances that way) must not recurse
     import copy
 
