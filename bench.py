@@ -158,7 +158,7 @@ def in_kernel_clock(torch, hasher, x, keys):
     _native.check(lib.lshrs_sig_hash_batch_split_replay_f32(
         x.data_ptr(), n, x.stride(0), ws.data_ptr(), hasher.num_bands, hasher.rows_per_band, hasher.dim, keys.data_ptr(),
         counters.data_ptr(), hasher._tau_arg(), None, flag_list.data_ptr(), None, cap,
-        hasher._tau1_arg(), 1, None, ctypes.byref(opts), stream), "clock probe launch")
+        hasher._tau1_arg(), 1, None, None, ctypes.byref(opts), stream), "clock probe launch")
     torch.cuda.synchronize(x.device)
     st = stamps[:2 * ((n + 255) // 256)].view(-1, 2).cpu().numpy()
     st = st[st[:, 1] > 0]

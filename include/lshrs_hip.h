@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSHRS_ABI_VERSION 4
+#define LSHRS_ABI_VERSION 5
 
 #define LSHRS_E_BADARG   (-10001) /* NULL pointer / non-positive size / misaligned workspace */
 #define LSHRS_E_TOOLARGE (-10002) /* shape outside what the kernels support (see each call)  */
@@ -51,6 +51,26 @@ typedef struct lshrs_sig_opts {
   void* clock_probe;
 } lshrs_sig_opts;
 
+/* Audit of what stage 1 of the split pass does NOT send to the exact decision (optional, NULL = none).  The proven window
+ * rests on a bit-exact model of v_mfma_f32_16x16x32_bf16; stage 2 measures |y1 - y_hostBLAS| on every projection stage 1
+ * FLAGS - a wrong premise of the model would show there only by luck.  With this block every launch also leaves a
+ * pseudo-random sample of the projections stage 1 decided ON ITS OWN (one per sampled wave, chosen by a hash of the wave's
+ * position and `seed`: about `target` of them) in `list` / `vals`, and stage 2 replays the host BLAS's value for them like
+ * for the flagged ones - patching nothing, counting: counters [4] projections audited, [5] audited projections whose key
+ * bit is not the sign of the host's value, [6] float bits: max over them of |y1 - y_hostBLAS| / the window that projection
+ * was compared with.  [5] != 0 or [6] > 1 means a key bit the reference would not have produced: the caller raises.
+ *   list   DEVICE int64[slots], vals DEVICE float[2 * slots]: scratch, rewritten by every launch
+ *   slots  capacity of both (the library samples fewer waves if `target` would not fit)
+ *   seed   changes the sample from launch to launch (the caller passes a counter) */
+typedef struct lshrs_sig_audit {
+  uint32_t struct_bytes;   /* sizeof(lshrs_sig_audit) */
+  uint32_t seed;
+  int64_t* list;
+  float* vals;
+  int32_t slots;
+  int32_t target;
+} lshrs_sig_audit;
+
 /* Counters of the replay entry points.  The caller owns a DEVICE block int32[LSHRS_SIG_DEVICE_COUNTERS], zeroed once when
  * allocated; its first LSHRS_SIG_COUNTERS words are the counters below, the rest is where the workgroups of stage 2 leave
  * their statistics (one slot each: no atomics on shared words).  A launch behind stage 2 folds those in, stores the
@@ -60,7 +80,9 @@ typedef struct lshrs_sig_opts {
  *   [2] float bits: max over the flagged projections of |y_stage1 - y_hostBLAS| in units of 2^-24 ||x|| ||p|| - the
  *       stage-1 window's margin as measured on THIS batch (split replay only)
  *   [3] flagged projections whose key bit stage 2 had to change
- *   [4..7] reserved (0) */
+ *   [4] [5] [6] the audit (lshrs_sig_audit): audited projections, sign disagreements, float bits of the largest
+ *       |y1 - y_hostBLAS| / window among them
+ *   [7] reserved (0) */
 #define LSHRS_SIG_COUNTERS 8
 #define LSHRS_SIG_DEVICE_COUNTERS (LSHRS_SIG_COUNTERS + 3 * 4096)
 
@@ -171,6 +193,7 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
  *   counters     DEVICE int32[LSHRS_SIG_DEVICE_COUNTERS] (see above), zero on entry.
  *   flag_y       optional float[flag_cap]: the stage-1 value of every list entry; with it stage 2 measures how far
  *                stage 1 was from the host BLAS on every flagged projection of the batch (counter [2]).
+ *   audit        optional (see lshrs_sig_audit): a sample of the projections stage 1 did not flag, verified by stage 2.
  *   host_counts  optional: PINNED HOST int32[LSHRS_SIG_COUNTERS] the device can write (hipHostMalloc / torch
  *                pin_memory): a launch behind stage 2 stores the counters there and leaves the device block zeroed
  *                for the next call - the caller reads them after synchronising the stream ([1] > flag_cap: repeat
@@ -180,7 +203,7 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
                                           uint8_t* keys, int32_t* counters, float tau, uint8_t* row_flags,
                                           int64_t* flag_list, float* flag_y, int32_t flag_cap, float tau1,
                                           int32_t blas_model, int32_t* host_counts,
-                                          const lshrs_sig_opts* opts, void* stream);
+                                          const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream);
 
 /* The tie-break on the device for the f32 kernel: behind lshrs_sig_hash_batch_f32 (same X, keys, tie_list, tie_count,
  * tau, same stream) it decides every reported tie by the host BLAS's value - the tie entries are unpacked into

@@ -21,7 +21,7 @@ SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
 # (LSHRS_HIP_LIBRARY: load another build of the same ABI instead - A/B measurements of compiler flags, tools/ab_build.py)
 LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-ABI_VERSION = 4
+ABI_VERSION = 5
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
 SIG_DEVICE_COUNTERS = SIG_COUNTERS + 3 * 4096      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
@@ -91,9 +91,9 @@ def _declare(lib: ctypes.CDLL) -> None:
                                                    f32, vp, vp]
     lib.lshrs_sig_hash_batch_split_f32.restype = c.c_int
     # (X, n, ldx, workspace, bands, rows, dim, keys, counters, tau, row_flags, flag_list, flag_y, flag_cap, tau1,
-    #  blas_model, host_counts, opts, stream)
+    #  blas_model, host_counts, audit, opts, stream)
     lib.lshrs_sig_hash_batch_split_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, i32, f32,
-                                                          i32, vp, vp, vp]
+                                                          i32, vp, vp, vp, vp]
     lib.lshrs_sig_hash_batch_split_replay_f32.restype = c.c_int
     # (X, n, ldx, workspace, bands, rows, dim, keys, tie_list, tie_cap, counters, tau, flag_list, flag_cap, blas_model,
     #  host_counts, stream)
@@ -209,6 +209,19 @@ class SigOpts(ctypes.Structure):
             (self.ev_stage1_start, self.ev_stage1_stop, self.ev_stage2_start, self.ev_stage2_stop) = events
         if clock_probe is not None:
             self.clock_probe = clock_probe
+
+
+class SigAudit(ctypes.Structure):
+    """``lshrs_sig_audit`` of include/lshrs_hip.h: where a launch leaves its sample of the projections stage 1 decided on
+    its own, for stage 2 to verify against the replayed host-BLAS value."""
+
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("seed", ctypes.c_uint32), ("list", ctypes.c_void_p),
+                ("vals", ctypes.c_void_p), ("slots", ctypes.c_int32), ("target", ctypes.c_int32)]
+
+    def __init__(self, list_ptr: int, vals_ptr: int, slots: int, target: int, seed: int = 0):
+        super().__init__()
+        self.struct_bytes = ctypes.sizeof(SigAudit)
+        self.list, self.vals, self.slots, self.target, self.seed = list_ptr, vals_ptr, int(slots), int(target), int(seed) & 0xFFFFFFFF
 
 
 def check(code: int, what: str) -> None:

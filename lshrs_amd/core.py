@@ -495,7 +495,7 @@ class LSHRS:
             "packed_ingest": self._packed_ingest,
             "device": getattr(h, "_device", None) if isinstance(getattr(h, "_device", None), (int, str, type(None))) else str(h._device),
             "hasher_kwargs": {**{k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard",
-                                                            "tie_threads", "audit_every") if hasattr(h, k)},
+                                                            "tie_threads", "audit_every", "audit_unflagged") if hasattr(h, k)},
                               **({"devices": list(h._devices)} if getattr(h, "_devices", None) else {})},
             "windows": {"tau_ulps": "bound" if getattr(h, "window_mode", {}).get("tau") == "bound" else getattr(h, "tau_ulps", 8.0),
                         "tau1_ulps": "bound" if getattr(h, "window_mode", {}).get("tau1") == "bound" else getattr(h, "tau1_ulps", 64.0)},

@@ -250,7 +250,13 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
 //   * the vector is consumed in blocks of 4096 elements: every block's sum is reduced on its own and added to y;
 //   * a vector of 8 m + 4 elements (300-d, 100-d): the 8-lane kernels take the first four with their low lanes and then
 //     eight at a time from the fifth (modelled for n <= 4096).
-// n must be a multiple of 4.  Found by search (tools/blas_order/); the caller (lshrs_amd/_hostblas.py) compares it bit for
+//   * the n mod 4 elements behind the last whole group of four are added in plain C after all blocks (sgemv_t.c's "m3"
+//     branches as gcc contracts them): one left, y = fma(a0, x0, y); two, y = y + fma(a0, x0, fl(a1 x1)); three,
+//     y = y + fma(a2, x2, fma(a0, x0, fl(a1 x1))) - found by search on this library (tools/blas_order/), n >= 9: shorter
+//     vectors do not reach these kernels the same way and are refused.
+//     model 2 = the same with the tail as the library's Haswell / Zen build compiles it: y + fl(a0 x0), y + (fl(a0 x0) +
+//     fl(a1 x1)), y + ((fl(a0 x0) + fl(a1 x1)) + fl(a2 x2)) - nothing contracted.  (n % 4 == 0: models 1 and 2 coincide.)
+// rows_per_band = 1 is refused: NumPy then calls sdot, another kernel.  Found by search (tools/blas_order/); the caller (lshrs_amd/_hostblas.py) compares it bit for
 // bit with `P_band @ x` of the running process, row kind by row kind, before the device replay may stand in for the host.
 static inline int tb_row_kind(int row, int rows) {
   const int r4 = rows & ~3;
@@ -259,13 +265,15 @@ static inline int tb_row_kind(int row, int rows) {
 }
 
 float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band) {
-  if (model != 1 || a == nullptr || x == nullptr || n <= 0 || n % 4 != 0 || row < 0 || row >= rows_per_band)
+  if ((model != 1 && model != 2) || a == nullptr || x == nullptr || n <= 0 || row < 0 || row >= rows_per_band)
     return __builtin_nanf("");
-  if (n % 8 != 0 && n > 4096) return __builtin_nanf("");     // (a short last block behind full ones: not modelled)
+  if (n % 4 != 0 && (n < 9 || rows_per_band < 2)) return __builtin_nanf("");
+  const int64_t body = n & ~(int64_t)3;                       // whole groups of four: the kernels' share
+  if (body % 8 != 0 && body > 4096) return __builtin_nanf("");     // (a short last block behind full ones: not modelled)
   const int kind = tb_row_kind(row, rows_per_band);
   float y = 0.f;
-  for (int64_t k0 = 0; k0 < n; k0 += 4096) {
-    const int64_t kn = n - k0 < 4096 ? n - k0 : 4096;
+  for (int64_t k0 = 0; k0 < body; k0 += 4096) {
+    const int64_t kn = body - k0 < 4096 ? body - k0 : 4096;
     const float* ab = a + k0;
     const float* xb = x + k0;
     float s;
@@ -300,6 +308,30 @@ float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t 
       s = h0 + h1;
     }
     y = k0 == 0 ? s : y + s;
+  }
+  const float* at = a + body;
+  const float* xt = x + body;
+  if (model == 2) {                                           // the Haswell / Zen build of the same file: nothing contracted
+    for (int64_t j = 0, m3 = n - body; j < m3 && m3 > 0; ++j) {
+      if (m3 == 1) { const volatile float p0 = at[0] * xt[0]; y = y + p0; break; }
+      const volatile float p0 = at[0] * xt[0], p1 = at[1] * xt[1];
+      volatile float t = p0 + p1;
+      if (m3 == 3) { const volatile float p2 = at[2] * xt[2]; t = t + p2; }
+      y = y + t;
+      break;
+    }
+    return y;
+  }
+  switch (n - body) {                                         // the scalar tail (see above)
+    case 1: y = __builtin_fmaf(at[0], xt[0], y); break;
+    case 2: { const volatile float p1 = at[1] * xt[1]; const volatile float t = __builtin_fmaf(at[0], xt[0], p1); y = y + t; break; }
+    case 3: {
+      const volatile float p1 = at[1] * xt[1];
+      const volatile float t = __builtin_fmaf(at[2], xt[2], __builtin_fmaf(at[0], xt[0], p1));
+      y = y + t;
+      break;
+    }
+    default: break;
   }
   return y;
 }

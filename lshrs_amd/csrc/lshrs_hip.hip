@@ -140,8 +140,25 @@ inline int64_t sig_compact_floats(const SigGeom& g, const SigCompact& c) {
   if (!c.on) return 0;
   return (int64_t)c.ncb * g.ktiles * 8192 + 3 * (int64_t)c.ncb * 256 + 3 * sig_pad4(c.ncb) + (int64_t)c.ncb * 256 * 3;
 }
-inline int64_t sig_workspace_floats(const SigGeom& g, int num_bands, int rows) {
-  return sig_window_offset_floats(g) + sig_window_floats(g) + sig_compact_floats(g, sig_compact(g, num_bands, rows));
+// RESIDENT image of sig16r_kernel (short vectors, at most 256 key columns): ONE compact column block - every band's rows
+// side by side, `nct` 16-column tiles of it live - over `kt` (2 or 4) k-tiles, zero beyond dim; same tables and copies as a
+// compact block (SigCompactWs with ncb = 1, bpb = num_bands), behind the compact section.
+struct SigResident { bool on; int nct; int kt; };
+inline SigResident sig_resident(int num_bands, int rows, int dim) {
+  SigResident r{false, 0, 0};
+  const int64_t real = (int64_t)num_bands * rows;
+  if (real > 256 || dim > 128 || dim < 8 || dim % 4 != 0) return r;
+  r.on = true;
+  r.nct = (((int)real + 15) / 16 + 3) / 4 * 4;
+  r.kt = dim <= 64 ? 2 : 4;
+  return r;
+}
+inline int64_t sig_resident_floats(const SigResident& r) {
+  return r.on ? (int64_t)r.kt * 8192 + 3 * 256 + 3 * 4 + 256 * 3 : 0;
+}
+inline int64_t sig_workspace_floats(const SigGeom& g, int num_bands, int rows, int dim) {
+  return sig_window_offset_floats(g) + sig_window_floats(g) + sig_compact_floats(g, sig_compact(g, num_bands, rows)) +
+         sig_resident_floats(sig_resident(num_bands, rows, dim));
 }
 inline SigCompactWs sig_compact_ws(float* base, const SigGeom& g, const SigCompact& c) {
   SigCompactWs w;
@@ -154,6 +171,20 @@ inline SigCompactWs sig_compact_ws(float* base, const SigGeom& g, const SigCompa
   w.wamax = p; p += sig_pad4(c.ncb);
   w.wbmax = p; p += sig_pad4(c.ncb);
   w.padcol = reinterpret_cast<int*>(p); p += (int64_t)c.ncb * 256;
+  w.bytetab = reinterpret_cast<int*>(p);
+  return w;
+}
+inline SigCompactWs sig_resident_ws(float* base, const SigGeom& g, int num_bands, int rows, const SigResident& r) {
+  SigCompactWs w;
+  float* p = base + sig_window_offset_floats(g) + sig_window_floats(g) + sig_compact_floats(g, sig_compact(g, num_bands, rows));
+  w.image = p; p += (int64_t)r.kt * 8192;
+  w.norms = p; p += 256;
+  w.norm_max = p; p += 4;
+  w.wa = p; p += 256;
+  w.wb = p; p += 256;
+  w.wamax = p; p += 4;
+  w.wbmax = p; p += 4;
+  w.padcol = reinterpret_cast<int*>(p); p += 256;
   w.bytetab = reinterpret_cast<int*>(p);
   return w;
 }
@@ -325,7 +356,23 @@ struct SigArgs {
   int64_t ldy;
   // diagnostics: when set, wave 0 of every workgroup stores {shader-clock ticks, 100 MHz ticks} of its main loop
   unsigned long long* clock_probe;
+  // audit of what stage 1 does NOT flag (lshrs_sig_audit): one wave in `audit_div` (unit u = workgroup * 8 + wave for
+  // sig16_kernel, the 32-row tile for sig16r_kernel; sampled when u % audit_div == audit_phase) leaves ONE of its
+  // projections - chosen by a hash of (u, audit_seed) - in slot u / audit_div: the list entry, its stage-1 value and the
+  // window it was compared with; -1 where the choice fell on a flagged projection, a padding column or a row past the end.
+  // Every slot is written by every launch.
+  int64_t* audit_list;
+  float* audit_vals;
+  int audit_div;
+  int audit_phase;
+  unsigned audit_seed;
 };
+
+__device__ __forceinline__ unsigned audit_hash(unsigned u, unsigned seed) {
+  unsigned h = u * 0x9E3779B1u ^ (seed * 0x85EBCA6Bu + 0xC2B2AE35u);
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
 
 
 // ---- ring-buffered main loop of the f32 kernel ----------------------------------------------------
@@ -654,10 +701,17 @@ struct FixArgs {
   int band_cols;          //     and its padded width (8 * band_bytes)
   const float* flag_y;    // optional: stage-1 value of every list entry (sig16_kernel stores it beside the entry)
   int count_ties;         // sig_fix8_kernel<true>: report the projections inside the tie window in partials[0] (else 0)
-  int* partials;          // sig_fix8_kernel<true>: int32[3 * gridDim.x], per workgroup: projections inside the tie window,
-                          // flagged projections whose stage-1 sign differed from the host BLAS's, and (float bits) the max
-                          // over its flagged projections of |y1 - y_BLAS| in units of 2^-24 ||x|| ||p||
+  int* partials;          // sig_fix8_kernel<true>: int32[kFixParts * gridDim.x], per workgroup: projections inside the tie
+                          // window, flagged projections whose stage-1 sign differed from the host BLAS's, (float bits) the
+                          // max over its flagged projections of |y1 - y_BLAS| in units of 2^-24 ||x|| ||p||, and the audit:
+                          // projections audited, audited projections whose key bit is not the host's sign, (float bits)
+                          // max over them of |y1 - y_BLAS| / the window stage 1 compared that projection with
+  const int64_t* audit_list;   // the un-flagged projections stage 1 sampled (SigArgs::audit_list), audit_n slots, -1 = none:
+  const float* audit_vals;     // replayed like the flagged ones behind them, nothing patched - only compared
+  int audit_n;
+  int tail_model;         // sig_fixany_kernel: how the host compiles the dim % 4 elements behind the last group of four (1 / 2)
 };
+constexpr int kFixParts = 6;
 
 // The host BLAS's left-over rows (blas_row_kind != 0) multiply and add in TWO roundings: never contracted into an fma.
 __device__ __forceinline__ float mul_then_add(float acc, float a, float b) {
@@ -718,7 +772,7 @@ constexpr int kFixG = 8;
 constexpr int kFixSlabG = LSHRS_FIX_SLAB;       // k-tiles per slab; two slabs are resident (one being read, one landing): 2 x 2 x 6 x 8 chunks x 8
                                    // projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is four slabs)
 constexpr int kFixGridG = LSHRS_FIX_GRID;    // 256 CUs x 6 resident single-wave workgroups
-static_assert(LSHRS_SIG_COUNTERS + 3 * kFixGridG <= LSHRS_SIG_DEVICE_COUNTERS, "stage 2's per-workgroup slots must fit the counter block");
+static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridG <= LSHRS_SIG_DEVICE_COUNTERS, "stage 2's per-workgroup slots must fit the counter block");
 //
 // REPLAY: the tie-break on the device.  Every flagged projection gets the sign of the value the HOST BLAS computes for
 // it - the reference's `projection @ vector` (lshrs/hash/lsh.py:200) - and only that value is computed, by replaying
@@ -747,7 +801,8 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
   const int shh = sub >> 2, sq = sub & 3;           // this lane's chunk of every k-tile: k = 32 t + 16 shh + 4 sq + 0..3
   const int cnt = min(*a.flag_count, a.flag_cap);
-  const int groups = (cnt + kFixG - 1) / kFixG;
+  const int fgroups = (cnt + kFixG - 1) / kFixG;
+  const int groups = fgroups + (REPLAY && a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);   // audit groups behind the list's
   const size_t ldp = (size_t)a.ktiles * kKTile;
   const int head = GENERAL ? (a.dim & 4) : 0;                 // 8 m + 4 elements: the first four go ahead of the tiles
   const int body = GENERAL ? a.dim - head : a.ktiles * kKTile; // elements the tiles cover (from element `head` on)
@@ -755,16 +810,27 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   const int slabs = (kt + kFixSlabG - 1) / kFixSlabG;
   // statistics are kept per lane and leave the wave once, at the end (one atomic per flagged projection on a single
   // address serialises the whole kernel as soon as the list is long)
-  int n_ties = 0, n_flips = 0;
-  float max_dev = 0.f;
-  struct Item { int64_t row; int col; bool live; const float* xg; const float* pg; const float* xrow; int e; };
+  int n_ties = 0, n_flips = 0, n_aud = 0, n_abad = 0;
+  float max_dev = 0.f, max_ratio = 0.f;
+  struct Item { int64_t row; int col; bool live; const float* xg; const float* pg; const float* xrow; int e; bool audit; };
   auto fetch = [&](int grp) {                       // list entry g of group grp (a short last group re-does its first entry, unused)
     Item it;
-    it.e = grp * kFixG + g;
-    const int64_t item = a.flag_list[it.e < cnt ? it.e : grp * kFixG];
+    it.audit = grp >= fgroups;                      // (uniform per wave: a group is the list's or the audit's)
+    int64_t item;
+    bool inlist;
+    if (!it.audit) {
+      it.e = grp * kFixG + g;
+      inlist = it.e < cnt;
+      item = a.flag_list[inlist ? it.e : grp * kFixG];
+    } else {
+      it.e = (grp - fgroups) * kFixG + g;
+      item = it.e < a.audit_n ? a.audit_list[it.e] : -1;
+      inlist = item >= 0;
+      if (!inlist) item = 0;                         // (an empty slot: row 0, column 0 - fetched, never used)
+    }
     it.row = item >> 21;                            // relative to this launch's X / keys
     const int col_raw = (int)(item & ((1 << 21) - 1));
-    it.live = it.e < cnt && col_raw < a.padcols;
+    it.live = inlist && col_raw < a.padcols;
     it.col = col_raw < a.padcols ? col_raw : 0;
     it.xrow = a.X + it.row * a.ldx;
     it.xg = it.xrow + head + 16 * shh + 4 * sq;
@@ -854,17 +920,20 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
               const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
-              const float xv = kb0 + 8 * m + sub < body ? xf[o] : 0.f;      // (past the row's end: zero, as the hyperplane is)
+              // past the row's end BOTH factors read as zero: what the fetch brought there is the neighbouring hyperplane's
+              // (or the window block's) and may be anything - 0 * Inf would poison a column whose own value is finite
+              const bool in = kb0 + 8 * m + sub < body;
+              const float xv = in ? xf[o] : 0.f, pv = in ? pf[o] : 0.f;
               ss = __builtin_fmaf(xv, xv, ss);
               if (kind == 1) {              // chain l = sub & 3 takes k = 8 m + l, then k = 8 m + 4 + l
                 const int o0 = ((t * 8 + 2 * m) * kFixG + g) * 4 + (sub & 3), o1 = o0 + kFixG * 4;
                 const int kl = kb0 + 8 * m + (sub & 3);
-                pj = mul_then_add(pj, pf[o0], kl < body ? xf[o0] : 0.f);
-                pj = mul_then_add(pj, pf[o1], kl + 4 < body ? xf[o1] : 0.f);
+                pj = mul_then_add(pj, kl < body ? pf[o0] : 0.f, kl < body ? xf[o0] : 0.f);
+                pj = mul_then_add(pj, kl + 4 < body ? pf[o1] : 0.f, kl + 4 < body ? xf[o1] : 0.f);
               } else if (kind == 2) {
-                pj = mul_then_add(pj, pf[o], xv);
+                pj = mul_then_add(pj, pv, xv);
               } else {
-                pj = __builtin_fmaf(pf[o], xv, pj);
+                pj = __builtin_fmaf(pv, xv, pj);
               }
             }
             const int tile = sl * kFixSlabG + t + 1;      // (uniform: every lane of the wave is at the same k-tile)
@@ -902,7 +971,20 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       s2 += __shfl(s2, (lane + 8) & 63);
       ss = s2 + __shfl(s2, (lane + 16) & 63);
     }
-    if (sub == 0 && live) {
+    if (REPLAY && cur.audit) {
+      // a projection stage 1 decided on its own: its key bit must be the sign of the host's value, and its stage-1 value
+      // must lie within the window it was compared with.  Nothing is patched: a disagreement is for the caller to raise.
+      if (sub == 0 && live) {
+        const uint8_t kbyte = a.keys[row * (int64_t)a.row_bytes + (col >> 3)];
+        ++n_aud;
+        if ((yb > 0.f) != (((kbyte >> (col & 7)) & 1) != 0)) ++n_abad;
+        const float y1 = a.audit_vals[2 * e], thr = a.audit_vals[2 * e + 1];
+        if (thr > 0.f) {
+          const float ratio = __builtin_fabsf(y1 - yb) / thr;
+          if (ratio < __builtin_inff()) max_ratio = __builtin_fmaxf(max_ratio, ratio);
+        }
+      }
+    } else if (sub == 0 && live) {
     uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
     const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
     unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
@@ -946,14 +1028,20 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       n_ties += __shfl_xor(n_ties, off);
       n_flips += __shfl_xor(n_flips, off);
       max_dev = __builtin_fmaxf(max_dev, __shfl_xor(max_dev, off));
+      n_aud += __shfl_xor(n_aud, off);
+      n_abad += __shfl_xor(n_abad, off);
+      max_ratio = __builtin_fmaxf(max_ratio, __shfl_xor(max_ratio, off));
     }
     // One plain store per workgroup into its own slot; the launch behind this kernel folds the slots into the counters.
     // (Atomics on the three counters - 1 536 waves on one address each - were 28 of this kernel's 50 us at 22 k entries.)
     if (lane == 0) {
-      int* p = a.partials + 3 * blockIdx.x;
+      int* p = a.partials + kFixParts * blockIdx.x;
       p[0] = a.count_ties ? n_ties : 0;
       p[1] = n_flips;
       p[2] = __float_as_int(max_dev);
+      p[3] = n_aud;
+      p[4] = n_abad;
+      p[5] = __float_as_int(max_ratio);
     }
   }
 }
@@ -981,6 +1069,104 @@ __global__ void expand_ties_kernel(const int64_t* __restrict__ tie_list, const i
   }
 }
 
+// The tie replay for inputs the LDS-DMA form above does not take: vectors whose length is not a multiple of four (the
+// library's scalar tail, lshrs_tb_model_row_dot: blas_model 1 as its SkylakeX build contracts it, 2 as its Haswell / Zen
+// build leaves it), rows that are only 4-byte aligned.  Same lane roles - lane (sub, g) owns chain `sub` of list entry g of
+// the wave's eight - with plain 4-byte loads: the eight lanes of an entry read 32 consecutive bytes of its row and of its
+// hyperplane per step.  Only behind the f32 kernel (lshrs_sig_resolve_ties_replay_f32): a tie list is short, and the rate
+// of this kernel (a few ns per entry) does not matter next to the pass in front of it.
+__global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
+  const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
+  const int cnt = min(*a.flag_count, a.flag_cap);
+  const int groups = (cnt + kFixG - 1) / kFixG;
+  const size_t ldp = (size_t)a.ktiles * kKTile;
+  const int body = a.dim & ~3, m3 = a.dim & 3;
+  int n_ties = 0, n_flips = 0;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {     // (uniform per wave)
+    const int e = grp * kFixG + g;
+    const int64_t item = a.flag_list[e < cnt ? e : grp * kFixG];
+    const int64_t row = item >> 21;
+    const int col_raw = (int)(item & ((1 << 21) - 1));
+    const bool live = e < cnt && col_raw < a.padcols;
+    const int col = col_raw < a.padcols ? col_raw : 0;
+    const float* __restrict__ xr = a.X + row * a.ldx;
+    const float* __restrict__ pr = a.prow + (size_t)col * ldp;
+    const int kind = blas_row_kind(col % a.band_cols, a.rows_per_band);
+    float y = 0.f, ss = 0.f;
+    for (int k0 = 0; k0 < body; k0 += 4096) {                      // the library's blocks (uniform trip count)
+      const int kn = body - k0 < 4096 ? body - k0 : 4096;
+      float pj = 0.f;
+      if (kind == 1) {                                             // four unfused chains over k mod 4, mirrored in sub 4..7
+        for (int k = k0 + (sub & 3); k < k0 + kn; k += 4) {
+          const float xv = xr[k];
+          pj = mul_then_add(pj, pr[k], xv);
+          if (sub < 4) ss = __builtin_fmaf(xv, xv, ss);
+        }
+      } else {
+        const int head = kn & 4;                                   // a block of 8 m + 4 elements: its first four go first
+        if (head != 0 && sub < 4) {
+          const float xv = xr[k0 + sub];
+          pj = pr[k0 + sub] * xv;
+          ss = __builtin_fmaf(xv, xv, ss);
+        }
+        for (int k = k0 + head + sub; k < k0 + kn; k += 8) {
+          const float xv = xr[k];
+          pj = kind == 0 ? __builtin_fmaf(pr[k], xv, pj) : mul_then_add(pj, pr[k], xv);
+          ss = __builtin_fmaf(xv, xv, ss);
+        }
+      }
+      const float sblk = blas_reduce(pj, kind, lane);              // (every lane takes part in the shuffles)
+      y = k0 == 0 ? sblk : y + sblk;
+    }
+    if (m3 != 0) {                                                 // the scalar tail (lshrs_tb_model_row_dot)
+      const float a0 = pr[body], x0 = xr[body];
+      const float a1 = m3 > 1 ? pr[body + 1] : 0.f, x1 = m3 > 1 ? xr[body + 1] : 0.f;
+      const float a2 = m3 > 2 ? pr[body + 2] : 0.f, x2 = m3 > 2 ? xr[body + 2] : 0.f;
+      if (sub == 0) ss = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, __builtin_fmaf(x2, x2, ss)));
+      if (a.tail_model == 2) {                                     // nothing contracted
+        float t = mul_then_add(0.f, a0, x0);
+        if (m3 > 1) t = mul_then_add(t, a1, x1);
+        if (m3 > 2) t = mul_then_add(t, a2, x2);
+        y = mul_then_add(y, t, 1.0f);
+      } else if (m3 == 1) {
+        y = __builtin_fmaf(a0, x0, y);
+      } else {
+        float t = __builtin_fmaf(a0, x0, mul_then_add(0.f, a1, x1));
+        if (m3 > 2) t = __builtin_fmaf(a2, x2, t);
+        y = mul_then_add(y, t, 1.0f);
+      }
+    }
+    float s2 = ss + __shfl(ss, (lane + 32) & 63);
+    s2 += __shfl(s2, (lane + 8) & 63);
+    s2 += __shfl(s2, (lane + 16) & 63);
+    if (sub == 0 && live) {
+      uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
+      const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
+      unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
+      const unsigned int bitmask = 1u << (8 * (unsigned)(addr & 3) + (col & 7));
+      const bool want = y > 0.f;                                   // (0, -0 and NaN give 0: lsh.py:204)
+      const bool have = (*kb >> (col & 7)) & 1;
+      if (__builtin_fabsf(y) < a.tau * sqrtf(s2) * a.tie_coef[col]) ++n_ties;
+      if (want != have) {
+        ++n_flips;
+        if (want) atomicOr(w32, bitmask);
+        else atomicAnd(w32, ~bitmask);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    n_ties += __shfl_xor(n_ties, off);
+    n_flips += __shfl_xor(n_flips, off);
+  }
+  if (lane == 0) {
+    int* p = a.partials + kFixParts * blockIdx.x;
+    p[0] = a.count_ties ? n_ties : 0;
+    p[1] = n_flips;
+    p[2] = p[3] = p[4] = p[5] = 0;
+  }
+}
+
 // Behind stage 2 of a replay pass: folds the per-workgroup statistics (nparts slots of 3 ints behind the
 // LSHRS_SIG_COUNTERS counters: ties, sign flips, max deviation) into the counters, hands the counters to the host (pinned
 // memory) and leaves the whole block zeroed for the next call: one single-wave launch instead of a copy and a fill.
@@ -988,24 +1174,34 @@ __global__ void expand_ties_kernel(const int64_t* __restrict__ tie_list, const i
 __global__ void export_counts_kernel(int* counters, int* host_counts, int nparts) {
   const int lane = threadIdx.x;
   int* parts = counters + LSHRS_SIG_COUNTERS;
-  int ties = 0, flips = 0, dev = 0;
+  int ties = 0, flips = 0, dev = 0, aud = 0, abad = 0, ratio = 0;
   for (int i = lane; i < nparts; i += 64) {
-    ties += parts[3 * i];
-    flips += parts[3 * i + 1];
-    dev = max(dev, parts[3 * i + 2]);                // (non-negative floats order like their bits)
-    parts[3 * i] = parts[3 * i + 1] = parts[3 * i + 2] = 0;
+    int* q = parts + kFixParts * i;
+    ties += q[0];
+    flips += q[1];
+    dev = max(dev, q[2]);                            // (non-negative floats order like their bits)
+    aud += q[3];
+    abad += q[4];
+    ratio = max(ratio, q[5]);
+    q[0] = q[1] = q[2] = q[3] = q[4] = q[5] = 0;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     ties += __shfl_xor(ties, off);
     flips += __shfl_xor(flips, off);
     dev = max(dev, __shfl_xor(dev, off));
+    aud += __shfl_xor(aud, off);
+    abad += __shfl_xor(abad, off);
+    ratio = max(ratio, __shfl_xor(ratio, off));
   }
   if (lane < LSHRS_SIG_COUNTERS) {
     int v = counters[lane];
     if (lane == 0) v += ties;
     if (lane == 2) v = max(v, dev);
     if (lane == 3) v += flips;
+    if (lane == 4) v += aud;
+    if (lane == 5) v += abad;
+    if (lane == 6) v = max(v, ratio);
     if (host_counts != nullptr) {
       host_counts[lane] = v;
       counters[lane] = 0;
@@ -1092,14 +1288,16 @@ __global__ __launch_bounds__(64) void sig_small_kernel(const SmallArgs a) {
     for (int m = 0; m < 4; ++m) {                   // k = head + 32 t + 8 m + sub: chunk 2 m + (sub >> 2), element sub & 3
       const int o = t * 8 + 2 * m + (sub >> 2);
       const int ox = GENERAL ? (o + hq < xchunks ? o + hq : xchunks - 1) : o;
-      const float xv = (!GENERAL || t * kKTile + 8 * m + sub < body) ? xf[ox * 4 + (sub & 3)] : 0.f;
-      const float pv = pf[(o * kFixG + g) * 4 + (sub & 3)];
+      const bool in = !GENERAL || t * kKTile + 8 * m + sub < body;       // (past the row's end both factors read as zero)
+      const float xv = in ? xf[ox * 4 + (sub & 3)] : 0.f;
+      const float pv = in ? pf[(o * kFixG + g) * 4 + (sub & 3)] : 0.f;
       if (GENERAL && kind == 1) {                   // chain l = sub & 3: k = 8 m + l, then k = 8 m + 4 + l
         const int o0 = t * 8 + 2 * m, o1 = o0 + 1;
         const int kl = t * kKTile + 8 * m + (sub & 3);
         const int x0 = o0 + hq < xchunks ? o0 + hq : xchunks - 1, x1 = o1 + hq < xchunks ? o1 + hq : xchunks - 1;
-        pj = mul_then_add(pj, pf[(o0 * kFixG + g) * 4 + (sub & 3)], kl < body ? xf[x0 * 4 + (sub & 3)] : 0.f);
-        pj = mul_then_add(pj, pf[(o1 * kFixG + g) * 4 + (sub & 3)], kl + 4 < body ? xf[x1 * 4 + (sub & 3)] : 0.f);
+        pj = mul_then_add(pj, kl < body ? pf[(o0 * kFixG + g) * 4 + (sub & 3)] : 0.f, kl < body ? xf[x0 * 4 + (sub & 3)] : 0.f);
+        pj = mul_then_add(pj, kl + 4 < body ? pf[(o1 * kFixG + g) * 4 + (sub & 3)] : 0.f,
+                          kl + 4 < body ? xf[x1 * 4 + (sub & 3)] : 0.f);
       } else if (GENERAL && kind == 2) {
         pj = mul_then_add(pj, pv, xv);
       } else {
@@ -1344,7 +1542,23 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   const int bid = blockIdx.x;
   const int cb = (bid >> 3) % ncb;
   const int row_tile = ((bid >> 3) / ncb) * 8 + (bid & 7);
-  if ((int64_t)row_tile * 256 >= args.n) return;     // (whole workgroup: the grid is padded to a multiple of 8 row tiles)
+  // the audit sample of this wave (SigArgs::audit_list): slot au_slot (-1: not sampled), accumulator word au_rw = 8 rt + w,
+  // lane au_lane, slot au_q of that word's eight values
+  int au_slot = -1, au_rw = -1, au_lane = 0, au_q = 0;
+  if (args.audit_list != nullptr) {
+    const unsigned u = (unsigned)bid * 8u + (unsigned)wave;
+    if ((int)(u % (unsigned)args.audit_div) == args.audit_phase) {
+      const unsigned h = audit_hash(u, args.audit_seed);
+      au_slot = (int)(u / (unsigned)args.audit_div);
+      au_rw = (int)(h & 15u);
+      au_q = (int)((h >> 4) & 7u);
+      au_lane = (int)((h >> 7) & 63u);
+    }
+  }
+  if ((int64_t)row_tile * 256 >= args.n) {           // (whole workgroup: the grid is padded to a multiple of 8 row tiles)
+    if (au_slot >= 0 && lane == 0) args.audit_list[au_slot] = -1;
+    return;
+  }
   const int ktiles = args.ktiles;
   const int stages = 2 * ktiles, lasts = stages - 1;
   const char* img = reinterpret_cast<const char*>(args.image) + (size_t)cb * ktiles * 32768;
@@ -1711,11 +1925,12 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
           deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
           asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));
         }
-        if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0) {   // wave-uniform: the exact per-element test
+        const bool aud = au_rw == 8 * rt + w;                   // (wave-uniform: this word holds the wave's audit sample)
+        if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0 || aud) {   // wave-uniform: the exact per-element test
           // With the proven window this runs on a quarter of the words: first the eight comparisons, branch-free, into a
           // mask; only the lane that holds a flagged projection (one, seldom two of the wave) enters the append.
           unsigned hits = 0u;
-          float ys[8];
+          float ys[8], thrs[8];
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int ct = 2 * w + half;
@@ -1725,8 +1940,27 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
               float thr = wnd[reg] * pa + wnb[reg] * pb;
               thr = thr > 0.f ? thr : -1.f;                               // zero row / zero-padded column: y is exactly 0
               ys[4 * half + reg] = acc[rt][ct][reg];
+              thrs[4 * half + reg] = thr;
               hits |= (!(__builtin_fabsf(ys[4 * half + reg]) > thr) ? 1u : 0u) << (4 * half + reg);
             }
+          }
+          if (aud && lanee == au_lane) {
+            // the sample: value au_q of this lane - left for stage 2 with the window it has just been compared with, unless
+            // it is flagged anyway (then stage 2 decides it), sits in a padding column or past the last row
+            float yq = ys[0], tq = thrs[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) {
+              yq = au_q == q ? ys[q] : yq;
+              tq = au_q == q ? thrs[q] : tq;
+            }
+            const int64_t grow = row0 + 16 * rt + 4 * ge + (au_q & 3);
+            const int ct = 2 * w + (au_q >> 2);
+            const int colid = COMPACT ? padcol_lds[16 * ct + r16e] : cb * 256 + 16 * ct + r16e;
+            const bool keep = ((hits >> au_q) & 1u) == 0u && grow < args.n && colid >= 0 && colid < args.row_bytes * 8 &&
+                              tq < __builtin_inff();
+            args.audit_list[au_slot] = keep ? ((grow << 21) | (int64_t)colid) : (int64_t)-1;
+            args.audit_vals[2 * au_slot] = yq;
+            args.audit_vals[2 * au_slot + 1] = tq;
           }
           if (hits != 0u) {
 #pragma unroll
@@ -1821,6 +2055,333 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     const unsigned long long slot = (unsigned long long)gridDim.x + (unsigned long long)blockIdx.x;
     args.clock_probe[2 * slot] = __builtin_amdgcn_s_memtime() - t_shader;
     args.clock_probe[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - t_real;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 of the split pass for SHORT vectors and narrow hashers (dim <= 128, at most 256 key columns: BASELINE config
+// 1's 16 x 4 x 128, the reference's docstring layout 20 x 6 x 128, num_perm = 128 at 128-d): the whole bf16 hi / mid
+// fragment image stays RESIDENT in LDS (KT k-tiles x NCT 16-column tiles x 2 KiB: 64 KiB at 128 x 128) and every wave
+// walks 32-row tiles of x on its own - no ring, no barrier after the prologue, nothing staged per tile but x itself.
+// sig16_kernel spends a prologue and an epilogue per 256 rows around four k-tiles of such a shape, and the exact-f32 kernel is
+// bound by the f32 matrix rate there (1 M x 128 x 128 columns: 0.32 ms = 0.7 of that roof, 0.10 of the HBM roof).
+//   wave   = two 16-row tiles x NCT column tiles (accumulators: 8 NCT registers), one of eight in a persistent workgroup
+//            (one workgroup per CU, two waves per SIMD); tile i of the batch goes to wave i mod (8 x workgroups);
+//   x      straight from HBM to registers: lane (r, g) owns elements 32 t + 8 g .. + 7 of row r - the A operand of
+//            v_mfma_f32_16x16x32_bf16 as it comes; the registers of k-tile t are refilled with the NEXT tile's elements as
+//            soon as k-tile t has been split, so a whole tile of loads is in flight under the matrix work;
+//   order  per k-tile x_hi p_hi, x_hi p_mid, x_mid p_hi on every accumulator, k-tiles ascending: the accumulation
+//            lshrs_split_stage1_model states and the proven window (lshrs_sig_set_window) is derived for - same
+//            coefficients, same stage 2;
+//   keys   the column block is COMPACT (sig_compact's layout: the bands' rows side by side, no padding columns): the sign
+//            words of a tile go through the wave's own LDS patch and leave as key bytes through the byte table;
+//   list   flagged projections are staged per wave in LDS and leave with one global atomic per 64 .. 128 entries.
+// ------------------------------------------------------------------------------------------
+constexpr int kResWaves = 4;
+constexpr int kResListCap = 128;                       // flagged projections a wave stages before it appends them
+constexpr int kResWaveFloats = 32 + 32 + 256 + 3 * kResListCap + 4;   // windows a / b per row, sign words, list (entry, y1), counter
+template <int NCT, int KT>
+constexpr int res_lds_floats() { return KT * NCT * 512 + 512 + 256 + 512 + kResWaves * kResWaveFloats; }
+
+template <int NCT, int KT>
+__global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs args) {
+  constexpr int RT = 2, NW = NCT / 2;
+  constexpr int kImgFloats = KT * NCT * 512;
+  __shared__ __attribute__((aligned(16))) float lds[res_lds_floats<NCT, KT>()];
+  struct Bf16Pairs { bf16x2 p[4]; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  float* coef_lds = lds + kImgFloats;                                  // wa[256] | wb[256] of the (compact) block
+  int* padcol_lds = reinterpret_cast<int*>(lds + kImgFloats + 512);
+  int* tab_lds = reinterpret_cast<int*>(lds + kImgFloats + 768);       // byte table: (source bit, mask) per key byte
+  float* mine = lds + kImgFloats + 1280 + wave * kResWaveFloats;       // this wave's patch
+  float* wnd_lds = mine;
+  float* wnb_lds = mine + 32;
+  uint32_t* cw_lds = reinterpret_cast<uint32_t*>(mine + 64);           // [32 rows][8 words]
+  int64_t* l_list = reinterpret_cast<int64_t*>(mine + 320);
+  float* l_y = mine + 320 + 2 * kResListCap;
+  int* l_count = reinterpret_cast<int*>(mine + 320 + 3 * kResListCap);
+
+  // ---- prologue: the image (L2 -> LDS, [kt][ct < NCT][part][lane] x 16 B) and the block's tables --------------------
+  {
+    const f32x4* img = reinterpret_cast<const f32x4*>(args.image);     // global: [kt][16 ct][part][lane]
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int c = tid; c < KT * NCT * 128; c += 64 * kResWaves) {
+      const int l = c & 127, ct = (c >> 7) % NCT, kt = (c >> 7) / NCT;
+      dst[c] = img[(kt * 16 + ct) * 128 + l];
+    }
+    if (tid < 256) {
+      coef_lds[tid] = args.wa[tid];
+      coef_lds[256 + tid] = args.wb[tid];
+      padcol_lds[tid] = args.padcol[tid];
+      tab_lds[2 * tid] = args.bytetab[2 * tid];
+      tab_lds[2 * tid + 1] = args.bytetab[2 * tid + 1];
+    }
+    if (lane == 0) l_count[0] = 0;
+  }
+  __syncthreads();
+
+  const int64_t tiles = (args.n + 31) / 32;
+  const int64_t stride = (int64_t)gridDim.x * kResWaves;
+  const int dim = args.dim;
+  const float amax_cb = args.wamax[0], bmax_cb = args.wbmax[0];
+  const int nby = args.row_bytes;
+
+  // x of one 32-row tile: [row tile][k-tile][chunk of four]; elements past the row's end read as zero (dim % 4 == 0)
+  f32x4 xr[RT][KT][2];
+  auto load_x = [&](int64_t tile, int t) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      int64_t row = tile * 32 + 16 * rt + r16;
+      row = row < args.n ? row : args.n - 1;                           // clamp: loads stay in bounds, stores are masked
+      const float* xp = args.X + row * args.ldx + 32 * t + 8 * g;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        xr[rt][t][c] = 32 * t + 8 * g + 4 * c < dim ? *reinterpret_cast<const f32x4*>(xp + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;
+  if (tile < tiles) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) load_x(tile, t);
+  }
+
+  for (; tile < tiles; tile += stride) {
+    const int64_t row0 = tile * 32;
+    const int64_t next = tile + stride < tiles ? tile + stride : tile;  // (the last tile re-fetches itself: unused, in bounds)
+    f32x4 acc[RT][NCT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ss[RT] = {0.f, 0.f}, sm[RT] = {0.f, 0.f}, amax[RT] = {0.f, 0.f};
+
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      Bf16Pairs hi[RT], mid[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {                               // the split of sig16_kernel: hi = bf16(x), mid = bf16(x - hi)
+          const float v0 = xr[rt][t][pr >> 1][2 * (pr & 1)], v1 = xr[rt][t][pr >> 1][2 * (pr & 1) + 1];
+          const bf16x2 hp = bf16x2{(__bf16)v0, (__bf16)v1};
+          const float r0 = v0 - (float)hp[0], r1 = v1 - (float)hp[1];
+          const bf16x2 mp = bf16x2{(__bf16)r0, (__bf16)r1};
+          hi[rt].p[pr] = hp;
+          mid[rt].p[pr] = mp;
+          ss[rt] = __builtin_amdgcn_fdot2_f32_bf16(hp, hp, ss[rt], false);
+          sm[rt] = __builtin_amdgcn_fdot2_f32_bf16(mp, mp, sm[rt], false);
+          amax[rt] = __builtin_fmaxf(amax[rt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+        }
+      load_x(next, t);                                                 // this k-tile's registers are free: the next tile's elements
+      const f32x4* frag = reinterpret_cast<const f32x4*>(lds) + (size_t)t * NCT * 128 + lane;
+#pragma unroll
+      for (int cp = 0; cp < NCT / 2; ++cp) {                           // two column tiles at a time: four accumulators take turns
+        f32x4 ph[2], pm[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          ph[j] = frag[(2 * cp + j) * 128];
+          pm[j] = frag[(2 * cp + j) * 128 + 64];
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+              const bf16x8 av = __builtin_bit_cast(bf16x8, term == 2 ? mid[rt] : hi[rt]);
+              const bf16x8 bv = __builtin_bit_cast(bf16x8, term == 1 ? pm[j] : ph[j]);
+              acc[rt][2 * cp + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rt][2 * cp + j], 0, 0, 0);
+            }
+      }
+    }
+
+    // ---- row statistics -> the two factors of the stage-1 window per row (as sig16_kernel) ---------------------------
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float s2 = ss[rt] + __shfl_xor(ss[rt], 16);
+      s2 += __shfl_xor(s2, 32);
+      float m2 = sm[rt] + __shfl_xor(sm[rt], 16);
+      m2 += __shfl_xor(m2, 32);
+      float am = __builtin_fmaxf(amax[rt], __shfl_xor(amax[rt], 16));
+      am = __builtin_fmaxf(am, __shfl_xor(am, 32));
+      const int64_t myrow = row0 + 16 * rt + r16;
+      if (g == 0) {
+        float window = sqrtf(s2) * args.tau * 1.001f;
+        if (am != 0.f && !(am >= 0x1p-32f && am <= 0x1p32f)) window = __builtin_inff();
+        wnd_lds[16 * rt + r16] = window;
+        const float wb_ = sqrtf(m2) * args.tau_b * 1.001f;
+        wnb_lds[16 * rt + r16] = wb_ < __builtin_inff() ? wb_ : 0.f;
+        if (args.row_flags != nullptr && myrow < args.n) {
+          const bool has_nan = s2 != s2;
+          const bool zero = (am <= 1e-8f) && !has_nan;
+          args.row_flags[myrow] = (uint8_t)((zero ? 1 : 0) | (has_nan ? 2 : 0));
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // the audit sample of this tile (SigArgs::audit_list): one of its 32 x 16 NCT projections
+    int au_slot = -1, au_rw = -1, au_lane = 0, au_q = 0;
+    if (args.audit_list != nullptr && (int)(tile % args.audit_div) == args.audit_phase) {
+      const unsigned h = audit_hash((unsigned)tile, args.audit_seed);
+      au_slot = (int)(tile / args.audit_div);
+      au_rw = (int)(h & 1u) * 8 + (int)(((h >> 1) & 7u) % (unsigned)NW);
+      au_q = (int)((h >> 4) & 7u);
+      au_lane = (int)((h >> 7) & 63u);
+    }
+
+    // ---- sign bits, window test, list (the epilogue of sig16_kernel, one wave wide) ----------------------------------
+    {
+      uint32_t A[2] = {0u, 0u}, B[2] = {0u, 0u};
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * g);   // rows 16 rt + 4 g + 0..3
+        const f32x4 wnb = *reinterpret_cast<const f32x4*>(wnb_lds + 16 * rt + 4 * g);
+        float tsmax = __builtin_fmaxf(__builtin_fmaxf(wnd[0], wnd[1]), __builtin_fmaxf(wnd[2], wnd[3]));
+        if (!(wnd[0] < __builtin_inff()) || !(wnd[1] < __builtin_inff()) || !(wnd[2] < __builtin_inff()) ||
+            !(wnd[3] < __builtin_inff()))
+          tsmax = __builtin_inff();
+        tsmax = tsmax * amax_cb + __builtin_fmaxf(__builtin_fmaxf(wnb[0], wnb[1]), __builtin_fmaxf(wnb[2], wnb[3])) * bmax_cb;
+        tsmax = tsmax > 0.f ? tsmax : -1.f;               // all four rows zero: nothing to re-evaluate
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          float m = __builtin_inff();
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const float y0 = acc[rt][2 * w][reg], y1 = acc[rt][2 * w + 1][reg];
+            const int p0 = 8 * rt + reg * 2;              // pair (rt, reg, g'pair = 0); g'pair = 1 is p0 + 1
+            deposit_positive(A[w & 1], y0, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
+            deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
+            m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(y0), __builtin_fabsf(y1)));   // (NaN dropped, as v_min3)
+          }
+          const bool aud = au_rw == 8 * rt + w;
+          if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0 || aud) {   // wave-uniform: the exact per-element test
+            unsigned hits = 0u;
+            float ys[8], thrs[8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int ct = 2 * w + half;
+              const float pa = coef_lds[16 * ct + r16], pb = coef_lds[256 + 16 * ct + r16];
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                float thr = wnd[reg] * pa + wnb[reg] * pb;
+                thr = thr > 0.f ? thr : -1.f;                             // zero row / zero-padded column: y is exactly 0
+                ys[4 * half + reg] = acc[rt][ct][reg];
+                thrs[4 * half + reg] = thr;
+                hits |= (!(__builtin_fabsf(ys[4 * half + reg]) > thr) ? 1u : 0u) << (4 * half + reg);
+              }
+            }
+            if (aud && lane == au_lane) {
+              float yq = ys[0], tq = thrs[0];
+#pragma unroll
+              for (int q = 1; q < 8; ++q) {
+                yq = au_q == q ? ys[q] : yq;
+                tq = au_q == q ? thrs[q] : tq;
+              }
+              const int64_t grow = row0 + 16 * rt + 4 * g + (au_q & 3);
+              const int colid = padcol_lds[16 * (2 * w + (au_q >> 2)) + r16];
+              const bool keep = ((hits >> au_q) & 1u) == 0u && grow < args.n && colid >= 0 && tq < __builtin_inff();
+              args.audit_list[au_slot] = keep ? ((grow << 21) | (int64_t)colid) : (int64_t)-1;
+              args.audit_vals[2 * au_slot] = yq;
+              args.audit_vals[2 * au_slot + 1] = tq;
+            }
+            if (hits != 0u) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int reg = q & 3, ct = 2 * w + (q >> 2);
+                const int64_t grow = row0 + 16 * rt + 4 * g + reg;
+                const int colid = padcol_lds[16 * ct + r16];
+                if (((hits >> q) & 1u) != 0u && grow < args.n && colid >= 0) {
+                  const int64_t entry = (grow << 21) | (int64_t)colid;
+                  const float ykeep = wnd[reg] < __builtin_inff() ? ys[q] : __builtin_nanf("");
+                  const int pos = atomicAdd(l_count, 1);                  // LDS atomic on the wave's own counter
+                  if (pos < kResListCap) {
+                    l_list[pos] = entry;
+                    l_y[pos] = ykeep;
+                  } else {                                                // the wave's stage is full (rows flagged wholesale)
+                    const int slot = atomicAdd(args.tie_count, 1);
+                    if (slot < args.tie_cap) {
+                      args.tie_list[slot] = entry;
+                      if (args.flag_y != nullptr) args.flag_y[slot] = ykeep;
+                    }
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      // lane L: row pair p = L / 4 -> rows lo / lo + 4 of the tile, words 2 (L % 4), + 1 of the block's sign string
+      const int pr = lane >> 2, wq = 2 * (lane & 3);
+      const int rlo = 16 * (pr >> 3) + 8 * (pr & 1) + ((pr >> 1) & 3);
+      if (wq < NW) {
+        const uint32_t wlo[2] = {(A[0] & 0xFFFFu) | (B[0] << 16), (A[1] & 0xFFFFu) | (B[1] << 16)};
+        const uint32_t whi[2] = {(A[0] >> 16) | (B[0] & 0xFFFF0000u), (A[1] >> 16) | (B[1] & 0xFFFF0000u)};
+        cw_lds[rlo * 8 + wq] = wlo[0];
+        cw_lds[(rlo + 4) * 8 + wq] = whi[0];
+        if (wq + 1 < NW) {
+          cw_lds[rlo * 8 + wq + 1] = wlo[1];
+          cw_lds[(rlo + 4) * 8 + wq + 1] = whi[1];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- key bytes: byte o of a row = bits [src, src + 8) of its sign string, masked to the band's live rows ----------
+    if (args.vec_store) {                                 // whole 32-bit words of 4-byte aligned key rows
+      const int nw32 = nby >> 2;
+      for (int idx = lane; idx < 32 * nw32; idx += 64) {
+        const int rl = idx / nw32, o4 = idx - rl * nw32;
+        uint32_t out = 0u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int src = tab_lds[2 * (4 * o4 + b)], w = src >> 5;
+          const uint32_t lo = cw_lds[rl * 8 + w], hi_ = cw_lds[rl * 8 + (w < 7 ? w + 1 : 7)];
+          const uint32_t v = (uint32_t)((((uint64_t)hi_ << 32) | lo) >> (src & 31)) & (uint32_t)tab_lds[2 * (4 * o4 + b) + 1];
+          out |= (v & 0xFFu) << (8 * b);
+        }
+        if (row0 + rl < args.n) *reinterpret_cast<uint32_t*>(args.keys + (row0 + rl) * (int64_t)nby + 4 * o4) = out;
+      }
+    } else {
+      for (int idx = lane; idx < 32 * nby; idx += 64) {
+        const int rl = idx / nby, o = idx - rl * nby;
+        const int src = tab_lds[2 * o], w = src >> 5;
+        const uint32_t lo = cw_lds[rl * 8 + w], hi_ = cw_lds[rl * 8 + (w < 7 ? w + 1 : 7)];
+        const uint32_t v = (uint32_t)((((uint64_t)hi_ << 32) | lo) >> (src & 31)) & (uint32_t)tab_lds[2 * o + 1];
+        if (row0 + rl < args.n) args.keys[(row0 + rl) * (int64_t)nby + o] = (uint8_t)v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- the wave's staged list: out when it is half full or the wave is done --------------------------------------
+    {
+      const int staged_raw = l_count[0];
+      const int staged = staged_raw < kResListCap ? staged_raw : kResListCap;
+      if (staged >= kResListCap / 2 || (tile + stride >= tiles && staged > 0)) {       // (wave-uniform)
+        int base = 0;
+        if (lane == 0) base = atomicAdd(args.tie_count, staged);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int e = lane; e < staged; e += 64) {
+          const int slot = base + e;
+          if (slot < args.tie_cap) {
+            args.tie_list[slot] = l_list[e];
+            if (args.flag_y != nullptr) args.flag_y[slot] = l_y[e];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) l_count[0] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
   }
 }
 
@@ -2114,7 +2675,7 @@ static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
 int64_t lshrs_sig_workspace_bytes(int32_t num_bands, int32_t rows_per_band, int32_t dim) {
   if (!sig_shape_ok(num_bands, rows_per_band, dim)) return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
-  return sig_workspace_floats(g, num_bands, rows_per_band) * (int64_t)sizeof(float);
+  return sig_workspace_floats(g, num_bands, rows_per_band, dim) * (int64_t)sizeof(float);
 }
 
 int32_t lshrs_sig_padded_columns(int32_t num_bands, int32_t rows_per_band) {
@@ -2190,6 +2751,19 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     const int64_t wf = 2 * (int64_t)cc + 2 * sig_pad4(cp.ncb);          // wa_c .. wbmax_c are contiguous
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((wf + 255) / 256)), dim3(256), 0, s, cw.wa, wf, 1e30f);
   }
+  const SigResident rs = sig_resident(num_bands, rows_per_band, dim);
+  if (rs.on) {                                      // sig16r_kernel's image, tables and copies (sig_resident)
+    const SigCompactWs rw = sig_resident_ws(image, g, num_bands, rows_per_band, rs);
+    const int64_t rchunks = (int64_t)rs.kt * 8192 / 4;
+    hipLaunchKernelGGL(compact_tables_kernel, dim3(1), dim3(256), 0, s, num_bands, rows_per_band, g.bb, num_bands, 1, rw.padcol,
+                       rw.bytetab);
+    hipLaunchKernelGGL(pack_image_bf16_t16_kernel, dim3((unsigned)((rchunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
+                       rows_per_band, dim, g.bb, rs.kt, rchunks, reinterpret_cast<u16x8*>(rw.image), num_bands);
+    hipLaunchKernelGGL(compact_gather_kernel, dim3(1), dim3(256), 0, s, norms, rw.padcol, 256, rw.norms);
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, rw.norms, 256, 1, rw.norm_max);
+    const int64_t wf = 2 * 256 + 2 * 4;                                  // wa .. wbmax are contiguous
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((wf + 255) / 256)), dim3(256), 0, s, rw.wa, wf, 1e30f);
+  }
   return -(int)hipGetLastError();
 }
 
@@ -2228,6 +2802,14 @@ int lshrs_sig_set_window(void* workspace, int32_t num_bands, int32_t rows_per_ba
     hipLaunchKernelGGL(compact_gather_kernel, cg, cbk, 0, s, w.wb, cw.padcol, cc, cw.wb);
     hipLaunchKernelGGL(pack_normmax_kernel, xg, mb, 0, s, cw.wa, 256, cp.ncb, cw.wamax);
     hipLaunchKernelGGL(pack_normmax_kernel, xg, mb, 0, s, cw.wb, 256, cp.ncb, cw.wbmax);
+  }
+  const SigResident rs = sig_resident(num_bands, rows_per_band, dim);
+  if (rs.on) {
+    const SigCompactWs rw = sig_resident_ws(base, g, num_bands, rows_per_band, rs);
+    hipLaunchKernelGGL(compact_gather_kernel, dim3(1), dim3(256), 0, s, w.wa, rw.padcol, 256, rw.wa);
+    hipLaunchKernelGGL(compact_gather_kernel, dim3(1), dim3(256), 0, s, w.wb, rw.padcol, 256, rw.wb);
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), mb, 0, s, rw.wa, 256, 1, rw.wamax);
+    hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), mb, 0, s, rw.wb, 256, 1, rw.wbmax);
   }
   return -(int)hipGetLastError();
 }
@@ -2301,7 +2883,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
                       int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
                       int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, float* flag_y,
                       int32_t flag_cap, int32_t* flag_count, float tau1, int blas_model, int32_t* counters,
-                      int32_t* host_counts, const lshrs_sig_opts* opts, void* stream) {
+                      int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream) {
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
       flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
@@ -2313,7 +2895,10 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   //  rows, or the end of the buffer, shares its page with a byte that is ours, and the bits that are not ours go back as
   //  they came - key rows of any width, keys at any address)
   const bool narrow = sig_has_narrow_split(g);
-  if (!sig_has_split(g) && !narrow) return LSHRS_E_TOOLARGE;
+  // short vectors of narrow hashers: the resident-image kernel (whole rows in registers: any dim % 4 == 0 with the replay)
+  SigResident rs = sig_resident(num_bands, rows_per_band, dim);
+  if (rs.on && dim % kKTile != 0 && blas_model == 0) rs.on = false;   // (only the replaying stage 2 masks a row's end)
+  if (!sig_has_split(g) && !narrow && !rs.on) return LSHRS_E_TOOLARGE;
   const int64_t row_tiles = (n + 255) / 256;
   const int64_t wgs = (row_tiles + 7) / 8 * 8 * g.cb;
   if (n >= ((int64_t)1 << 42) || wgs > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
@@ -2321,8 +2906,8 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   const Opts o = read_opts(opts);
   const float* base = static_cast<const float*>(workspace);
   // (a partial last k-tile - dim % 32 != 0 - only with the replay: its stage 2 is the one that reads the chunks past a row's end as zero)
-  const bool aligned = (dim % 32 == 0 || (blas_model != 0 && dim % 4 == 0 && dim >= 32)) && (ldx % 4 == 0) && ldx < (1 << 20) &&
-                       ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const bool aligned = (dim % 32 == 0 || (blas_model != 0 && dim % 4 == 0 && (dim >= 32 || rs.on))) && (ldx % 4 == 0) &&
+                       ldx < (1 << 20) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   if (!aligned) {  // the split pass is built for 16-byte chunks of 16-byte aligned rows; anything else takes the f32 pass (same keys)
     if (blas_model != 0) return LSHRS_E_BADARG;   // (the f32 kernel reports ties, it does not resolve them)
     return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
@@ -2388,7 +2973,55 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   }
   a.row_flags = row_flags;
   a.clock_probe = o.clock_probe;
-  {
+  // the audit sample (lshrs_sig_audit): one unit in `div` - a wave of sig16_kernel, a 32-row tile of sig16r_kernel
+  int audit_n = 0;
+  if (audit != nullptr && audit->struct_bytes >= sizeof(lshrs_sig_audit) && audit->list != nullptr && audit->vals != nullptr &&
+      audit->slots > 0 && audit->target > 0 && blas_model != 0) {
+    const int64_t units = rs.on ? (n + 31) / 32 : (row_tiles + 7) / 8 * 8 * a.ncb * 8;
+    int64_t div = units / audit->target;
+    if (div < 1) div = 1;
+    if ((units + div - 1) / div > audit->slots) div = (units + audit->slots - 1) / audit->slots;
+    if (div <= 0x7fffffffLL) {
+      a.audit_list = audit->list;
+      a.audit_vals = audit->vals;
+      a.audit_div = (int)div;
+      a.audit_phase = (int)(audit->seed % (uint32_t)div);
+      a.audit_seed = audit->seed;
+      audit_n = (int)((units - 1 - a.audit_phase) / div + 1);           // units u < `units` with u % div == phase: every slot is written
+    }
+  }
+  if (rs.on) {
+    const SigCompactWs rw = sig_resident_ws(const_cast<float*>(base), g, num_bands, rows_per_band, rs);
+    a.ncb = 1;
+    a.image = rw.image;
+    a.norms = rw.norms;
+    a.norm_max = rw.norm_max;
+    a.compact = 1;
+    a.padcol = rw.padcol;
+    a.bytetab = rw.bytetab;
+    a.bpb = num_bands;
+    a.band_bytes = g.bb;
+    a.num_bands = num_bands;
+    a.vec_store = (row_bytes % 4 == 0) && ((reinterpret_cast<uintptr_t>(keys) % 4) == 0);
+    if (tau1 > 0.f) {
+      a.wa = a.wb = a.norms;
+      a.wamax = a.wbmax = a.norm_max;
+    } else {
+      a.wa = rw.wa;
+      a.wb = rw.wb;
+      a.wamax = rw.wamax;
+      a.wbmax = rw.wbmax;
+    }
+    const int64_t tiles = (n + 31) / 32;
+    const dim3 grid((unsigned)(tiles < 256 * kResWaves ? (tiles + kResWaves - 1) / kResWaves : 256), 1, 1), block(64 * kResWaves, 1, 1);
+#define LSHRS_RES(NCT_, KT_) hipExtLaunchKernelGGL((sig16r_kernel<NCT_, KT_>), grid, block, 0, s, o.ev[0], o.ev[1], 0, a)
+    if (rs.kt == 2) {
+      if (rs.nct == 4) LSHRS_RES(4, 2); else if (rs.nct == 8) LSHRS_RES(8, 2); else if (rs.nct == 12) LSHRS_RES(12, 2); else LSHRS_RES(16, 2);
+    } else {
+      if (rs.nct == 4) LSHRS_RES(4, 4); else if (rs.nct == 8) LSHRS_RES(8, 4); else if (rs.nct == 12) LSHRS_RES(12, 4); else LSHRS_RES(16, 4);
+    }
+#undef LSHRS_RES
+  } else {
     const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), 1, 1);
     const bool partial = dim % kKTile != 0;
     if (cp.on) {
@@ -2406,7 +3039,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.dim = dim;
   f.ktiles = g.ktiles;
   f.prow = base + sig_rowmajor_offset_floats(g);
-  f.norms = cp.on ? base + sig_image_floats(g) : a.norms;       // (stage 2 works on padded column ids throughout)
+  f.norms = (cp.on || rs.on) ? base + sig_image_floats(g) : a.norms;       // (stage 2 works on padded column ids throughout)
   f.keys = keys;
   f.row_bytes = row_bytes;
   f.padcols = row_bytes * 8;
@@ -2429,6 +3062,9 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     f.flag_y = flag_y;
     f.partials = counters + LSHRS_SIG_COUNTERS;
     f.count_ties = 1;
+    f.audit_list = audit_n > 0 ? a.audit_list : nullptr;
+    f.audit_vals = a.audit_vals;
+    f.audit_n = audit_n;
     if (blas_general(rows_per_band, g.ktiles, dim))
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     else
@@ -2446,17 +3082,20 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
                                    int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
                                    const lshrs_sig_opts* opts, void* stream) {
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap, tie_count, tau,
-                    row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, opts, stream);
+                    row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, nullptr, opts, stream);
 }
 
 int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
                                           int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
                                           int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
                                           float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
-                                          int32_t* host_counts, const lshrs_sig_opts* opts, void* stream) {
-  if (blas_model != 1 || dim % 4 != 0 || dim < 32 || (dim % 8 != 0 && dim > 4096) || counters == nullptr) return LSHRS_E_BADARG;
+                                          int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
+                                          void* stream) {
+  const bool resident = sig_resident(num_bands, rows_per_band, dim).on;
+  if (blas_model != 1 || dim % 4 != 0 || (dim < 32 && !resident) || (dim % 8 != 0 && dim > 4096) || counters == nullptr)
+    return LSHRS_E_BADARG;
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
-                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, opts, stream);
+                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, audit, opts, stream);
 }
 
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
@@ -2468,13 +3107,17 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || tie_list == nullptr || tie_count == nullptr ||
       flag_list == nullptr || flag_count == nullptr || tie_cap <= 0 || flag_cap <= 0 || n < 0 || ldx < dim ||
-      !sig_shape_ok(num_bands, rows_per_band, dim) || blas_model != 1)
+      !sig_shape_ok(num_bands, rows_per_band, dim) || (blas_model != 1 && blas_model != 2))
     return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
-  // stage 2 stages 16-byte chunks of 16-byte aligned rows (key rows may have any width: split_pass's comment)
-  if (dim % 4 != 0 || dim < 8 || (dim % 8 != 0 && dim > 4096) || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 ||
-      n >= ((int64_t)1 << 42))
+  // stage 2 stages 16-byte chunks of 16-byte aligned rows (key rows may have any width: split_pass's comment); anything
+  // else - dim % 4 elements of scalar tail (blas_model 1 / 2: how the host compiles it), rows that are only 4-byte aligned -
+  // goes through the plain-load form of the same replay (sig_fixany_kernel)
+  const bool fast = dim % 4 == 0 && dim >= 8 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  const int body = dim & ~3;
+  if ((body % 8 != 0 && body > 4096) || n >= ((int64_t)1 << 42) || (!fast && (dim < 9 || rows_per_band < 2)) ||
+      (fast && blas_model != 1))
     return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
@@ -2510,7 +3153,9 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   {
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
-    if (blas_general(rows_per_band, g.ktiles, dim)) hipLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, f);
+    f.tail_model = blas_model;
+    if (!fast) hipLaunchKernelGGL(sig_fixany_kernel, grid, block, 0, s, f);
+    else if (blas_general(rows_per_band, g.ktiles, dim)) hipLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, f);
     else hipLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, f);
     hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
   }

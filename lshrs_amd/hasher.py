@@ -138,6 +138,13 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                   at 768-d), a number for a measured one (round 2: 8).
       margin_guard  (numeric windows only) fraction of the window the measured deviation may reach before the batch is hashed
                   again with a wider one - up to the proven window (default 0.5; 0 disables the guard)
+      audit_unflagged  projections per launch of the split pass that stage 1 decided ON ITS OWN (did not flag) and that stage
+                  2 verifies anyway - a pseudo-random sample, different in every launch: the replayed host-BLAS sign against the
+                  key bit stage 1 stored, and |y_stage1 - y_hostBLAS| against the window that projection was compared with
+                  (default 4096: < 0.5 % of a 1M x 768 step; 0 = off).  ``last_stats["audited_unflagged"]``, ``["audit_sign_disagreements"]``,
+                  ``["audit_max_window_ratio"]``; a disagreement or a ratio above 1 means a key bit the reference would not have
+                  produced: with the proven window it raises (the window's premises - the instruction model - do not hold on
+                  this device), a measured window (``tau1_ulps=<number>``) is replaced by the proven one and the batch repeated
       audit_every every n-th synchronous ``hash_device`` batch (default 64, and the first) a handful of the projections
                   stage 2 decided are re-evaluated with ``P_band @ x`` on the host and compared with the key bits; a
                   disagreement revokes the device replay for this hasher (``audit_failures``) and the
@@ -152,7 +159,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                  tie_break: str = "host", tau_ulps=None, precision: str = "bf16x3",
                  tau1_ulps=None, tie_threads: Optional[int] = None,
                  tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64,
-                 devices: Optional[Sequence[int]] = None) -> None:
+                 audit_unflagged: int = 4096, devices: Optional[Sequence[int]] = None) -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -180,7 +187,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             device = self._devices[0]
         self._ctor_kwargs = dict(tie_break=tie_break, tau_ulps=tau_ulps, precision=precision, tau1_ulps=tau1_ulps,
                                  tie_threads=tie_threads, tie_replay=tie_replay, margin_guard=margin_guard,
-                                 audit_every=audit_every)
+                                 audit_every=audit_every, audit_unflagged=audit_unflagged)
         self._seed = seed
         self._children: Optional[list] = None
         self._pool = None
@@ -208,6 +215,13 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         # every audit_every-th synchronous batch (and the first): a few of the projections the device has decided are
         # re-evaluated with NumPy on the host and compared (0 = never)
         self.audit_every = int(audit_every)
+        # every launch of the split pass: this many of the projections stage 1 did NOT flag are replayed by stage 2 as well
+        # and compared with what stage 1 decided (include/lshrs_hip.h, lshrs_sig_audit); 0 = off
+        if int(audit_unflagged) < 0:
+            raise ValueError("audit_unflagged must be >= 0")
+        self.audit_unflagged = int(audit_unflagged)
+        self._audit_seed = 0
+        self.audit_totals = {"audited": 0, "sign_disagreements": 0, "max_window_ratio": 0.0}
         self._audit_countdown = 1
         self.audit_failures = 0
         self.margin_escalations = 0        # batches whose measured stage-1 deviation tripped the guard (then: bound window)
@@ -472,9 +486,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         # name                     taken when (first match wins)
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
         ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 4 == 0, "
-                                   ">= 256 key columns or 128 .. 224 with dim >= 384, hyperplane norms in range), 16-byte aligned rows"),
-        ("f32+replay",             "host BLAS order recognised, dim % 4 == 0, aligned rows: small "
-                                   "batches and shapes the split pass does not take"),
+                                   ">= 256 key columns or 128 .. 224 with dim >= 384 - or at most 256 key columns at dim <= 128: the "
+                                   "resident-image kernel -, hyperplane norms in range), 16-byte aligned rows"),
+        ("f32+replay",             "host BLAS order recognised: small batches and shapes the split pass does not take - any dim "
+                                   "(dim % 4 elements through the library's scalar tail), rows at any 4-byte address"),
         ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists, a tie window "
                                    "narrow enough for the per-chunk lists (measured windows): chunks overlapped by csrc/pipeline.hip, "
                                    "ties by the library's own sgemv"),
@@ -487,11 +502,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         if mode != "host":
             return "raw", 0
         model = self._replay_model() if self.tie_replay == "auto" else 0
-        if model and aligned:
-            if short_stride and self._split_applies(n, replay=True):
+        if model:       # (the model's own limits - 8 m + 4 elements only up to 4096, two rows per band or more - are in `model`)
+            if aligned and short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
-            if self.dim % 4 == 0 and self.dim >= 8:      # (the model's own limits - 8 m + 4 elements only up to 4096 - are in `model`)
-                return "f32+replay", model
+            return "f32+replay", model
         if (allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
                 and self._expected_tie_entries(32) <= 0.75 and self._tie_engine() is not None):
             # (the pipeline's per-chunk lists - and the pinned copies of the tied rows behind them - hold one entry per 32
@@ -541,14 +555,17 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                 scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
                            torch.zeros(_native.SIG_DEVICE_COUNTERS, dtype=torch.int32, device=dev),   # counters + stage-2 slots
                            pinned, pinned.numpy(), [0, [3, 2, 1, 0]],             # launches so far, free pinned blocks
-                           torch.empty((cap,), dtype=torch.float32, device=dev))   # stage-1 value of every list entry
+                           torch.empty((cap,), dtype=torch.float32, device=dev),   # stage-1 value of every list entry
+                           # the audit sample of a launch: entry, (stage-1 value, window) per slot
+                           torch.empty((2 * max(1, self.audit_unflagged),), dtype=torch.int64, device=dev),
+                           torch.empty((4 * max(1, self.audit_unflagged),), dtype=torch.float32, device=dev))
                 if len(self._replay_scratch) >= 16 and not self._async_pending:
                     # a caller that keeps making new streams must not pile up lists: nothing is in flight, start over
                     self._replay_scratch.clear()
                     self._replay_events.clear()
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
-            flag_list, counts, pinned, host_counts, turn, flag_y = scratch
+            flag_list, counts, pinned, host_counts, turn, flag_y, audit_list, audit_vals = scratch
             while not turn[1]:        # every pinned block belongs to an unverified launch: verify the oldest streamed one
                 if not self._async_pending:      # (cannot happen: a synchronous caller that takes the last block keeps the lock)
                     raise _native.NativeLibraryError("no free counter block for a replay launch")
@@ -571,14 +588,19 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                         ring.append((quad, _native.SigOpts(events=tuple(e.cuda_event for e in quad))))
                     self._replay_events[skey] = ring
                 ev, opts = ring[slot]
+            audit = None
+            if self.audit_unflagged > 0:
+                self._audit_seed = (self._audit_seed + 1) & 0x7FFFFFFF
+                audit = _native.SigAudit(audit_list.data_ptr(), audit_vals.data_ptr(), int(audit_list.shape[0]),
+                                         self.audit_unflagged, self._audit_seed * 2654435761)
             try:
                 _native.check(
                     lib.lshrs_sig_hash_batch_split_replay_f32(
                         x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
                         out.data_ptr(), counts.data_ptr(), tau, row_flags.data_ptr() if row_flags is not None else None,
                         flag_list.data_ptr(), flag_y.data_ptr(), int(flag_list.shape[0]), self._tau1_arg(),
-                        model, pinned[slot].data_ptr(), ctypes.byref(opts) if opts is not None else None,
-                        cur.cuda_stream),
+                        model, pinned[slot].data_ptr(), ctypes.byref(audit) if audit is not None else None,
+                        ctypes.byref(opts) if opts is not None else None, cur.cuda_stream),
                     "lshrs_sig_hash_batch_split_replay_f32")
             except BaseException:
                 cur.synchronize()
@@ -603,12 +625,40 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         done.synchronize()      # (the launch behind stage 2 has written the counters into the pinned block)
         ties, flagged, flips = int(host_counts[slot, 0]), int(host_counts[slot, 1]), int(host_counts[slot, 3])
         max_dev = float(host_counts[slot, 2:3].view(np.float32)[0])
+        audited, audit_bad = int(host_counts[slot, 4]), int(host_counts[slot, 5])
+        audit_ratio = float(host_counts[slot, 6:7].view(np.float32)[0])
         state[9][1].append(slot)        # (the pinned block is free for the next launch)
         if flagged > cap:
             self._flag_cap_hint = int(flagged * 1.25) + 4096      # (rows flagged wholesale: NaN / Inf / extreme scales)
             stats["relaunches"] += 1
             return False
         stats["max_dev_units"] = max(max_dev, stats.get("max_dev_units", 0.0))
+        # the audit of what stage 1 did NOT flag: whatever the window mode, a sign that is not the host's is a wrong key bit
+        stats["audited_unflagged"] = stats.get("audited_unflagged", 0) + audited
+        stats["audit_sign_disagreements"] = stats.get("audit_sign_disagreements", 0) + audit_bad
+        stats["audit_max_window_ratio"] = max(audit_ratio, stats.get("audit_max_window_ratio", 0.0))
+        tot = self.audit_totals
+        tot["audited"] += audited
+        tot["sign_disagreements"] += audit_bad
+        tot["max_window_ratio"] = max(tot["max_window_ratio"], audit_ratio)
+        if (audit_bad or audit_ratio > 1.0) and window != float("inf"):
+            # a MEASURED window refuted on this batch's own data (rows like tests/_adversary.py get past the margin guard,
+            # which only sees flagged projections): the proven window from here on, and this batch once more
+            if self.window_mode["tau1"] != "bound":
+                self.tau1_ulps, self.window_mode["tau1"] = bound_tau1_ulps(self.dim), "bound"
+                self._window_set.clear()
+            self.margin_escalations += 1
+            self.audit_escalations = getattr(self, "audit_escalations", 0) + 1
+            stats["relaunches"] += 1
+            stats["audit_escalations"] = self.audit_escalations
+            stats["margin_escalations"] = self.margin_escalations
+            return False
+        if audit_bad or audit_ratio > 1.0:
+            raise _native.NativeLibraryError(
+                f"audit of the projections stage 1 decided on its own: {audit_bad} of {audited} sampled key bits are not the "
+                f"sign of the host's value, largest |y_stage1 - y_host| / window = {audit_ratio:.3f} (> 1 means outside the "
+                f"window): the stage-1 window ({'proven' if window == float('inf') else f'{window:.0f} units, measured'}) "
+                "does not cover this data on this device - keys of this batch are not the reference's")
         if window == float("inf"):
             # proven window: what stage 2 measured on every flagged projection can only be INSIDE it - anything else is a
             # bug in the bound or in the arithmetic model it rests on, and must not pass silently
@@ -824,7 +874,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         breaks the ties on the device - it has no host step to amortise, and beats "f32 kernel + host tie-break" from
         a few hundred rows up (85 against 300 us at 512 x 768, tools/replay_crossover.py), so only tiny batches (a
         query vector: the fine-geometry f32 kernel answers in 35 us) stay off it."""
-        if self.precision != "bf16x3" or self.dim % 4 != 0 or self.dim < 32:
+        if self.precision != "bf16x3" or self.dim % 4 != 0 or (self.dim < 32 and not (replay and self._resident_shape())):
             return False
         if self.dim % 32 != 0 and not replay:      # (a partial last k-tile: only the replaying stage 2 masks the row's end)
             return False
@@ -840,18 +890,29 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         self._split_shape_ok = (self._projection_version, ok)
         return ok
 
+    def _resident_shape(self) -> bool:
+        """Short vectors of a narrow hasher - at most 256 key columns, dim <= 128 (BASELINE config 1's 16 x 4 x 128, the
+        reference's docstring layout 20 x 6 x 128): stage 1 of the split pass runs with the whole fragment image resident in
+        LDS (sig16r_kernel; the library's `sig_resident` decides the same way).  Accumulators of up to 8 column tiles over 4
+        k-tiles (or 16 over 2) fit a wave's registers."""
+        real = self.num_bands * self.rows_per_band
+        if real > 256 or self.dim > 128 or self.dim < 8 or self.dim % 4 != 0:
+            return False
+        return True
+
     def _split_shape_check(self) -> bool:
         key_cols = 8 * self.num_bands * self.band_bytes
+        resident = self._resident_shape()
         # >= 256 key columns - or 128 .. 224 (the reference's default num_perm = 128 as 8 x 16, config 1's 16 x 4, its
         # docstring's 20 x 6): those run on a fragment image zero-padded to 256 columns - up to half the matrix work wasted,
         # still 1.5x the f32 kernel
-        if key_cols < 128:
+        if key_cols < 128 and not resident:
             return False
         if self.dim > 8192:
             # the proven window widens the row norms stage 1 accumulates in f32 by 0.1 %: enough for the rounding of up to
             # ~8 k terms (4 k dot2 steps x 2^-23); longer rows keep the f32 kernel
             return False
-        if key_cols < 225 and self.dim < 384:
+        if key_cols < 225 and self.dim < 384 and not resident:
             # short vectors: the padded pass's 256-column epilogue outweighs its matrix rate (1M x 128, 16 x 4:
             # 0.36 ms against 0.32 ms for the f32 kernel; 1M x 768, 8 x 16: 1.18 against 1.71 ms)
             return False
@@ -963,6 +1024,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         self.__dict__.setdefault("split_min_elems", 16 << 20)
         self.__dict__.setdefault("margin_guard", 0.5)
         self.__dict__.setdefault("audit_every", 64)
+        self.__dict__.setdefault("audit_unflagged", 4096)
+        self.__dict__.setdefault("_audit_seed", 0)
+        self.__dict__.setdefault("audit_totals", {"audited": 0, "sign_disagreements": 0, "max_window_ratio": 0.0})
         self.__dict__.setdefault("_small_epoch", 0)
         self.__dict__.setdefault("_audit_countdown", 1)
         self.__dict__.setdefault("audit_failures", 0)

@@ -60,6 +60,8 @@ def host_roundings(dim: int, K: int, kinds: np.ndarray) -> np.ndarray:
     levels of the tree; the unfused kernels round the product itself once more (kind 2: same chains; kind 1: four chains of
     ``block/4`` steps and a two-level tree); every block after the first adds one rounding to everything before it and to
     itself.  (The chains' own sums are not small, so there is no two-sided charge here.)"""
+    tail = dim & 3                # (elements behind the last whole group of four: the library's scalar tail, below)
+    full_dim, dim = dim, dim & ~3
     k = np.arange(K)
     block = k // 4096
     nblk = (dim + 4095) // 4096
@@ -72,6 +74,11 @@ def host_roundings(dim: int, K: int, kinds: np.ndarray) -> np.ndarray:
     m[kinds == 2] = fused + 1
     m[kinds == 1] = blen // 4 - kk // 4 + 2 + 1 + later
     m[:, k >= dim] = 0.0
+    if tail:
+        # y = fma(a0, x0, y) / y + fma(a0, x0, fl(a1 x1)) / y + fma(a2, x2, fma(a0, x0, fl(a1 x1))): one more rounding for
+        # everything in front, at most four for a tail product
+        m[:, :dim] += 1.0
+        m[:, dim:full_dim] = 4.0
     return m
 
 
@@ -106,6 +113,8 @@ def window_coefficients(planes: np.ndarray, blas_model: int, rows_per_band: int 
     ``||x_mid|| = 0.4 * 2^-8 ||x||`` (Gaussian-like data) in units of 2^-24 ||x|| ||p||, averaged over the hyperplanes."""
     P = np.ascontiguousarray(planes, dtype=np.float32)
     num, dim = P.shape
+    if blas_model == 2:           # (model 2 compiles the dim % 4 tail without contraction: at most the same number of roundings)
+        blas_model = 1
     K = (dim + 31) // 32 * 32
     p32 = np.zeros((num, K), dtype=np.float32)
     p32[:, :dim] = P
@@ -133,7 +142,7 @@ def window_coefficients(planes: np.ndarray, blas_model: int, rows_per_band: int 
     # (same two-sided charge: its final value y is what the tie test looks at, so |partial sum| <= min(prefix, |y| + suffix))
     pos = 32 * t + 2 * (k % 16) + (k % 32) // 16
     m_chain = np.where(pos < K // 2, K // 2 - pos, pos - K // 2 + 1).astype(np.float64)
-    if blas_model == 1 and dim % 4 == 0:
+    if blas_model == 1:
         r = int(rows_per_band)
         if r > 0:
             if num % r:

@@ -38,7 +38,7 @@ def test_header_and_library_agree(lib):
     assert sorted(_native.EXPORTS) == names, "python binding list and header drifted apart"
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 4
+    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 5
     m = re.search(r"#define\s+LSHRS_ABI_VERSION\s+(\d+)", open(HEADER).read())
     assert int(m.group(1)) == lib.lshrs_abi_version()
 
@@ -91,10 +91,15 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_workspace_bytes(16, 32, 1536) == (4 * 512 * 1536 + 512 + 4 + 16 + 3 * 512 + 12 + 16) * 4
     # exactly 128 padded columns: + the 16x16x32 fragment image zero-padded to 256 columns (256 x dim bf16 hi/mid
     # = 256 x dim floats' worth), its 256 norms and their maximum (x4)
-    assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (3 * 128 * 128 + 128 + 4 + 4 + 256 * 128 + 256 + 4 + 3 * 256 + 12 + 4) * 4
+    # ... and (a short-vector hasher: at most 256 key columns, dim <= 128) the resident image of sig16r_kernel - 4 k-tiles of
+    # one compact 256-column block - with its norms, window copies, maxima (x4), padded column ids and key-byte table
+    res = 3 * 256 + 3 * 4 + 3 * 256
+    assert lib.lshrs_sig_workspace_bytes(16, 4, 128) == (3 * 128 * 128 + 128 + 4 + 4 + 256 * 128 + 256 + 4 + 3 * 256 + 12 + 4
+                                                         + 4 * 8192 + res) * 4
     # 160 padded columns (the reference's docstring example, 20 x 6): the f32 kernel's two column blocks of 128, five fine
     # tiles, and the same 256-column narrow image
-    assert lib.lshrs_sig_workspace_bytes(20, 6, 128) == ((256 + 160 + 256 + 256) * 128 + 256 + 4 + 8 + 256 + 4 + 3 * 256 + 12 + 8) * 4
+    assert lib.lshrs_sig_workspace_bytes(20, 6, 128) == ((256 + 160 + 256 + 256) * 128 + 256 + 4 + 8 + 256 + 4 + 3 * 256 + 12 + 8
+                                                         + 4 * 8192 + res) * 4
     # 20 x 10 (the reference's docstring layout): 320 padded key columns = two column blocks everywhere - and, for stage 1 of the
     # split pass, ONE compact block of the 200 real columns: its image (24 k-tiles x 8192 floats), 256 norms, two coefficient
     # arrays, three maxima (x4), 256 padded column ids and 256 x 2 key-byte table entries
@@ -102,6 +107,7 @@ def test_pure_host_entry_points(lib):
         (512 * 768 + 512 + 4) + (320 * 768 + 12) + 512 * 768 + 512 * 768 + (3 * 512 + 12 + 12)
         + (24 * 8192 + 3 * 256 + 3 * 4 + 3 * 256)) * 4
     assert lib.lshrs_sig_workspace_bytes(3, 5, 4) == (2 * 32 * 32 + 32 + 4 + 3 * 256 + 12 + 4) * 4
+    assert lib.lshrs_sig_workspace_bytes(3, 5, 8) - lib.lshrs_sig_workspace_bytes(3, 5, 4) == (2 * 8192 + res) * 4   # (2 k-tiles up to 64-d)
     assert lib.lshrs_sig_set_window(None, 16, 16, 768, None, None, None, None) == -10001
     assert lib.lshrs_sig_workspace_bytes(16, 16, 0) < 0
     # argument validation happens before anything touches a device
@@ -109,7 +115,7 @@ def test_pure_host_entry_points(lib):
     assert lib.lshrs_sig_hash_batch_split_f32(None, 5, 4, None, 1, 1, 4, None, None, 0, None, 0.0, None, None, 0, None,
                                               0.0, None, None) == -10001
     assert lib.lshrs_sig_hash_batch_split_replay_f32(None, 5, 32, None, 1, 1, 32, None, None, 0.0, None, None, None, 0, 0.0,
-                                                     1, None, None, None) == -10001
+                                                     1, None, None, None, None) == -10001
     # the measurement hooks travel in the call: the struct the binding passes is the header's
     text = open(HEADER).read()
     fields = re.search(r"typedef struct lshrs_sig_opts \{(.*?)\} lshrs_sig_opts;", text, flags=re.S).group(1)
@@ -117,6 +123,10 @@ def test_pure_host_entry_points(lib):
     from lshrs_amd import _native
     assert names == [f[0] for f in _native.SigOpts._fields_]
     assert ctypes.sizeof(_native.SigOpts) == 8 + 5 * ctypes.sizeof(ctypes.c_void_p)
+    fields = re.search(r"typedef struct lshrs_sig_audit \{(.*?)\} lshrs_sig_audit;", text, flags=re.S).group(1)
+    names = re.findall(r"(\w+);", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
+    assert names == [f[0] for f in _native.SigAudit._fields_]
+    assert ctypes.sizeof(_native.SigAudit) == 8 + 2 * ctypes.sizeof(ctypes.c_void_p) + 8
     assert int(re.search(r"#define\s+LSHRS_SIG_COUNTERS\s+(\d+)", text).group(1)) == _native.SIG_COUNTERS
     assert re.search(r"#define\s+LSHRS_SIG_DEVICE_COUNTERS\s+\(LSHRS_SIG_COUNTERS \+ 3 \* 4096\)", text)
     assert _native.SIG_DEVICE_COUNTERS == _native.SIG_COUNTERS + 3 * 4096
@@ -218,13 +228,24 @@ def test_route_table():
         assert h._route(256, "host", **ok) == ("split+replay", 1)
         assert h._route(255, "host", **ok) == ("f32+replay", 1)                      # below replay_min_rows
         assert h._route(1_000_000, "host", aligned=True, short_stride=False, host_rows=False) == ("f32+replay", 1)
-        assert LSHHasher(16, 4, 128, seed=1)._route(1_000_000, "host", **ok) == ("f32+replay", 1)   # 128 key columns, short rows
-        assert LSHHasher(5, 12, 64, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)        # 10 key bytes: any row width
+        assert LSHHasher(16, 4, 128, seed=1)._route(1_000_000, "host", **ok) == ("split+replay", 1)  # short rows: the resident-image kernel
+        assert LSHHasher(20, 6, 128, seed=1)._route(1_000_000, "host", **ok) == ("split+replay", 1)
+        assert LSHHasher(16, 4, 128, seed=1)._route(100, "host", **ok) == ("f32+replay", 1)
+        assert LSHHasher(16, 8, 256, seed=1)._route(1_000_000, "host", **ok) == ("f32+replay", 1)    # 128 key columns, 256-d
+        assert LSHHasher(5, 12, 64, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)      # 60 key columns at 64-d: resident
+        assert LSHHasher(5, 12, 256, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)       # 10 key bytes: any row width
         assert LSHHasher(25, 8, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)     # 25 key bytes, 200 key columns
         assert LSHHasher(20, 10, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 + 2 rows per band
         assert LSHHasher(16, 16, 100, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 m + 4 elements, a partial k-tile
-        assert LSHHasher(8, 7, 100, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)        # ... with 64 key columns
-        assert LSHHasher(16, 16, 102, seed=1)._route(5_000, "host", **ok) == ("plain", 0)           # dim % 4 != 0
+        assert LSHHasher(8, 7, 100, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)      # ... with 56 key columns: resident
+        assert LSHHasher(8, 7, 300, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)        # ... at 300-d
+        # shapes and views the reference accepts and that used to end at the host engine (~4 M vec/s)
+        tails = {LSHHasher(16, 16, 102, seed=1)._route(5_000, "host", **ok),                         # dim % 4 != 0: the library's
+                 LSHHasher(5, 8, 30, seed=1)._route(5_000, "host", **ok),                            # scalar tail (model 1 or 2:
+                 LSHHasher(9, 5, 30, seed=1)._route(5_000, "host", **ok)}                            # how this host compiles it)
+        assert tails <= {("f32+replay", 1), ("f32+replay", 2)} and len(tails) == 1
+        assert h._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False) == ("f32+replay", 1)   # a 4-byte offset view
+        assert LSHHasher(64, 1, 64, seed=1)._route(5_000, "host", **ok) == ("plain", 0)             # one row per band: NumPy calls sdot
     # the host engine: chunks overlapped by the native pipeline where the tie window is narrow enough for its per-chunk lists
     # (measured windows); the PROVEN tie window without a replay ties a third of the rows - every chunk would overflow and be
     # hashed twice - so it takes the plain path with a list sized for it
@@ -236,7 +257,7 @@ def test_route_table():
     assert off._route(1_000_000, "host", aligned=True, short_stride=True, host_rows=True) == ("plain", 0)
     assert off._route(100_000, "host", **ok) == ("plain", 0)
     assert off._route(1_000_000, "host", allow_pipeline=False, **ok) == ("plain", 0)
-    unaligned = h._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False)
+    unaligned = off._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False)
     assert unaligned[0] in ("host-engine pipelined", "plain") and unaligned[1] == 0
     with pytest.raises(TypeError):
         LSHHasher(16, 16, 768, pipeline="python")  # (the interpreter-driven route of rounds 1-2 is gone)

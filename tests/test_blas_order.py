@@ -77,8 +77,26 @@ def test_model_function_is_the_documented_order():
     want = np.float32(np.float32(q[0] + q[1]) + np.float32(q[2] + q[3]))
     # (* a double holds product + addend of two floats exactly unless their exponents are > 29 apart: not here)
     assert _model_dot(a, x).view(np.uint32) == want.view(np.uint32)
-    assert np.isnan(_model_dot(a[:62], x[:62]))            # n % 4 != 0
-    assert np.isnan(_model_dot(a, x, model=2))             # unknown model
+    assert np.isnan(_model_dot(a[:6], x[:6]))              # n % 4 != 0 below 9 elements: not modelled
+    # n % 4 elements behind the last group of four: the library's scalar tail, as its SkylakeX build contracts it (model 1)
+    # and as its Haswell / Zen build leaves it (model 2)
+    f = np.float32
+    fma = lambda u, v, w: f(np.float64(u) * np.float64(v) + np.float64(w))      # noqa: E731
+    for n in (61, 62, 63):
+        body = n & ~3
+        yb = _model_row_dot(a[:body], x[:body], 0, 4)
+        t, u = a[body:n], x[body:n]
+        if n - body == 1:
+            want1, want2 = fma(t[0], u[0], yb), f(yb + f(t[0] * u[0]))
+        elif n - body == 2:
+            want1, want2 = f(yb + fma(t[0], u[0], f(t[1] * u[1]))), f(yb + f(f(t[0] * u[0]) + f(t[1] * u[1])))
+        else:
+            want1 = f(yb + fma(t[2], u[2], fma(t[0], u[0], f(t[1] * u[1]))))
+            want2 = f(yb + f(f(f(t[0] * u[0]) + f(t[1] * u[1])) + f(t[2] * u[2])))
+        assert _model_row_dot(a[:n], x[:n], 0, 4, model=1).view(np.uint32) == want1.view(np.uint32), n
+        assert _model_row_dot(a[:n], x[:n], 0, 4, model=2).view(np.uint32) == want2.view(np.uint32), n
+    assert np.isnan(_model_row_dot(a[:61], x[:61], 0, 1))  # one row per band: NumPy calls sdot, another kernel
+    assert np.isnan(_model_dot(a, x, model=3))             # unknown model
 
 
 @pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (16, 32, 1536), (16, 4, 128), (4, 12, 32),
@@ -112,11 +130,22 @@ def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
 
 
 def test_shapes_the_model_does_not_cover_are_refused():
-    planes = np.random.default_rng(1).standard_normal((8, 5, 102)).astype(np.float32)
-    assert _hostblas.blas_order_model(planes) == 0         # dim % 4 != 0: the library's tail handling is not modelled
-    assert _hostblas.blas_order_model(np.random.default_rng(1).standard_normal((4, 8, 4100)).astype(np.float32)) == 0
-    h = LSHHasher(8, 5, 102, seed=3)
-    assert h._replay_model() == 0
+    rng = np.random.default_rng(1)
+    assert _hostblas.blas_order_model(rng.standard_normal((4, 8, 4100)).astype(np.float32)) == 0      # a short block behind full ones
+    assert _hostblas.blas_order_model(rng.standard_normal((8, 1, 64)).astype(np.float32)) == 0        # one row per band: sdot
+    assert _hostblas.blas_order_model(rng.standard_normal((4, 4, 7)).astype(np.float32)) == 0         # a tail below 9 elements
+    # dim % 4 != 0 is modelled now (the scalar tail, model 1 or 2 by how this host's library compiles it)
+    if _hostblas.blas_order_model(rng.standard_normal((2, 4, 64)).astype(np.float32)) == 1:
+        for shape in ((8, 5, 102), (5, 8, 30), (3, 7, 101), (2, 16, 4099), (16, 16, 103)):
+            planes = rng.standard_normal(shape).astype(np.float32)
+            model = _hostblas.blas_order_model(planes)
+            assert model in (1, 2), shape
+            for _ in range(5):                     # ... and the model IS this process's NumPy on fresh vectors
+                x = rng.standard_normal(shape[2]).astype(np.float32)
+                for b in (0, shape[0] - 1):
+                    got = np.array([_model_row_dot(planes[b, i], x, i, shape[1], model=model) for i in range(shape[1])])
+                    assert np.array_equal((planes[b] @ x).view(np.uint32), got.view(np.uint32)), shape
+        assert LSHHasher(8, 5, 102, seed=3)._replay_model() in (1, 2)
     h2 = LSHHasher(16, 16, 768, seed=3, tie_replay="off")
     assert h2.tie_replay == "off"
     with pytest.raises(ValueError):

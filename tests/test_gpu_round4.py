@@ -1,0 +1,363 @@
+"""GPU tests of round 4: the audit of what stage 1 does NOT flag, the resident-image kernel for short vectors, the tie
+replay for any vector length and row alignment, two threads on one hasher, the host-engine route with the default windows.
+Every call goes through the C ABI; the checker is the oracle's literal restatement of lshrs/hash/lsh.py:96-211."""
+
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _hasher(seed, nb, r, dim, **kw):
+    from lshrs_amd import LSHHasher
+
+    return LSHHasher(num_bands=nb, rows_per_band=r, dim=dim, seed=seed, **kw)
+
+
+def _salt_with_ties(h, x, every=40):
+    """Rows cancelled against three hyperplanes (the last rows of a band - the library's left-over kernels - and a first
+    one): true ties, where only the summation order is left of y."""
+    nb, r = h.num_bands, h.rows_per_band
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
+    targets = [(b * r + j) for b in (0, nb // 2, nb - 1) for j in (r - 1, max(r - 2, 0), 0)]
+    special = np.arange(0, x.shape[0], every)
+    xs = x[special].astype(np.float64)
+    for i in range(special.size):
+        pl = stack[[targets[(i + t) % len(targets)] for t in range(3)]]
+        xs[i] -= (xs[i] @ np.linalg.pinv(pl)) @ pl
+    x[special] = xs.astype(np.float32)
+    return special
+
+
+# ----------------------------------------------------------------------------- the audit
+def test_audit_of_unflagged_projections_passes_on_healthy_data_and_costs_little(torch_mod):
+    """Every launch of the split pass: ~4096 of the projections stage 1 decided ON ITS OWN are replayed by stage 2 as well;
+    their key bits must be the host's signs and their stage-1 values inside the window they were compared with."""
+    torch = torch_mod
+    h = _hasher(42, 16, 16, 768)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    x = torch.randn(300_000, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    keys = h.hash_device(x)
+    st = dict(h.last_stats)
+    assert 2_000 <= st["audited_unflagged"] <= 8_192, st
+    assert st["audit_sign_disagreements"] == 0 and 0.0 < st["audit_max_window_ratio"] < 0.5, st
+    # another launch audits another sample; the totals add up
+    h.hash_device(x)
+    assert h.audit_totals["audited"] >= st["audited_unflagged"] + 2_000 and h.audit_totals["sign_disagreements"] == 0
+    # the sample never changes a key, and switching it off changes nothing either
+    off = _hasher(42, 16, 16, 768, audit_unflagged=0)
+    assert torch.equal(off.hash_device(x), keys) and off.last_stats["audited_unflagged"] == 0
+    # small batches, compact column blocks, partial k-tiles, the resident-image kernel: every stage-1 kernel samples
+    for nb, r, dim, n in ((16, 16, 768, 300), (20, 10, 768, 5_000), (16, 16, 300, 5_000), (16, 4, 128, 50_000), (20, 6, 128, 999)):
+        hh = _hasher(3, nb, r, dim)
+        hh.hash_device(torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(n)))
+        s2 = hh.last_stats
+        assert s2["route"] == "split+replay" and s2["audited_unflagged"] > 0 and s2["audit_sign_disagreements"] == 0, (nb, r, dim, s2)
+        assert s2["audit_max_window_ratio"] < 0.7, (nb, r, dim, s2)
+    # cost: the same step with and without the sample, interleaved (the bound of the verdict is 0.5 % of the config-2 step)
+    big = torch.randn(1_000_000, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    out = torch.empty((1_000_000, 16, 2), dtype=torch.uint8, device="cuda")
+    for hh in (h, off):
+        for _ in range(15):
+            hh.hash_device(big, out=out)
+    times = {id(h): [], id(off): []}
+    for _ in range(6):
+        for hh in (h, off):
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                hh.hash_device(big, out=out)
+            b.record()
+            torch.cuda.synchronize()
+            times[id(hh)].append(a.elapsed_time(b) / 10)
+    with_audit, without = min(times[id(h)]), min(times[id(off)])
+    print(f"audit cost: {with_audit:.4f} ms per step with, {without:.4f} ms without ({100 * (with_audit / without - 1):.2f} %)")
+    assert with_audit < without * 1.02      # (box noise is ~1 %; profiles/r04_audit_cost.log holds the measured figure)
+
+
+def test_audit_fires_on_adversarial_rows_where_the_margin_guard_sees_nothing(torch_mod):
+    """tests/_adversary.py rows against a 64-unit MEASURED window: stage 1 leaves the targeted projections un-flagged with
+    the WRONG sign.  The margin guard (which only sees flagged projections) notices nothing - wrong keys, silently (asserted:
+    the hole is real).  The audit of un-flagged projections samples them, finds a key bit that is not the host's sign (or a
+    stage-1 value outside its window), the hasher moves to the proven window and repeats the batch: the reference's keys."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+    from tests._adversary import adversarial_row
+
+    nb, r, dim, n = 16, 16, 768, 2048
+    base = _hasher(42, nb, r, dim)
+    if not base._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    x = np.empty((n, dim), dtype=np.float32)
+    for i in range(n):                                       # every row targets one hyperplane: 1 of its 256 projections
+        x[i] = adversarial_row((1.0 if i % 2 else -1.0) * base.projections[(i // r) % nb][i % r], 20.0, seed=i)
+    want = hash_batch_literal_packed(base.projections, x)
+    xd = torch.from_numpy(x).cuda()
+    blind = _hasher(42, nb, r, dim, tau1_ulps=64.0, audit_unflagged=0)          # round 3's measured mode: guard on, no audit
+    got = blind.hash_device(xd).cpu().numpy()
+    assert (got != want).any(axis=(1, 2)).sum() > n // 2 and blind.margin_escalations == 0, "the adversarial rows no longer bite"
+    assert blind.window_mode["tau1"] == "measured"
+    # the same window with the audit: one sample per wave (8 per 256 rows x 256 columns) - a targeted projection is hit within
+    # a few launches (each sample: 1 in 256), the window is replaced, the batch repeated
+    h = _hasher(42, nb, r, dim, tau1_ulps=64.0, audit_unflagged=1_000_000)
+    launches = 0
+    while h.window_mode["tau1"] == "measured" and launches < 200:
+        out = h.hash_device(xd)
+        launches += 1
+    st = dict(h.last_stats)
+    assert h.window_mode["tau1"] == "bound" and st.get("audit_escalations", 0) >= 1, (launches, st)
+    assert np.array_equal(out.cpu().numpy(), want)           # (the batch that tripped the audit was repeated with the proven window)
+    assert np.array_equal(h.hash_device(xd).cpu().numpy(), want) and h.last_stats["window"] == "proven"
+    assert h.last_stats["audit_sign_disagreements"] == 0 and h.last_stats["audit_max_window_ratio"] <= 1.0
+    print(f"audit tripped after {launches} launch(es): {st}")
+
+
+# ----------------------------------------------------------------------------- short vectors
+@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 4, 128), (1, 20, 6, 128), (2, 8, 16, 128), (3, 16, 8, 64), (4, 3, 5, 64),
+                                           (5, 32, 8, 44), (6, 8, 12, 12), (7, 5, 11, 96), (8, 16, 16, 36), (9, 16, 16, 128),
+                                           (10, 25, 8, 100), (11, 128, 2, 128), (12, 2, 2, 8)])
+def test_resident_image_kernel_gives_the_reference_keys(torch_mod, seed, nb, r, dim):
+    """sig16r_kernel (stage 1 with the whole fragment image in LDS, rows straight into registers) on every instantiation:
+    ragged batch sizes, true ties against every kernel kind of the host library, zero / NaN / Inf / huge / tiny rows, key
+    rows of any width - the reference-literal loop's bytes and the exact-f32 kernel's, row flags included."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed, is_zero_vector_rows
+
+    h = _hasher(seed, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    f32 = _hasher(seed, nb, r, dim, precision="f32")
+    rng = np.random.default_rng(seed)
+    for n in (70_001, 33_000, 1_000, 257):
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        special = _salt_with_ties(h, x, every=37)
+        x[5] = 0.0
+        x[6, dim // 2] = np.nan
+        x[7, 0] = np.inf
+        x[8] *= np.float32(2.0 ** 40)
+        x[9] *= np.float32(2.0 ** -40)
+        x[10] = 1e-9
+        x[11:14] *= np.exp2(rng.integers(-14, 15, size=(3, dim))).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        got = h.hash_device(xd, row_flags=flags)
+        st = dict(h.last_stats)
+        assert st["route"] == "split+replay" and st["tie_break_engine"] == "device-replay", st
+        assert st["audit_sign_disagreements"] == 0, st
+        fl32 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        ref = f32.hash_device(xd, row_flags=fl32)
+        assert f32.last_stats["route"] == "f32+replay"
+        assert torch.equal(got, ref), (n, int((got != ref).any(dim=2).any(dim=1).sum()))
+        assert torch.equal(flags, fl32)
+        fl = flags.cpu().numpy()
+        assert np.array_equal(fl & 1, is_zero_vector_rows(x).astype(np.uint8)) and (fl[6] & 2)
+        pick = np.unique(np.concatenate([special[:600], np.arange(0, n, 11)[:1200], np.arange(20)]))
+        with np.errstate(all="ignore"):
+            want = hash_batch_literal_packed(h.projections, x[pick])
+        assert np.array_equal(got.cpu().numpy()[pick], want), (n, st)
+    # keys at an odd address and with neighbours that must stay untouched
+    n = 3_001
+    x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(seed))
+    bb = h.band_bytes
+    buf = torch.full((n * nb * bb + 7,), 0xA5, dtype=torch.uint8, device="cuda")
+    view = buf[3:3 + n * nb * bb].view(n, nb, bb)
+    h.hash_device(x, out=view)
+    assert torch.equal(view, f32.hash_device(x)) and bool((buf[:3] == 0xA5).all()) and bool((buf[3 + n * nb * bb:] == 0xA5).all())
+    # measured windows and the streamed host path take the same kernel
+    m = _hasher(seed, nb, r, dim, tau1_ulps=64.0, tau_ulps=8.0)
+    assert torch.equal(m.hash_device(x), view) and m.last_stats["window"] == "measured"
+    big = rng.standard_normal((40_000, dim)).astype(np.float32)
+    assert np.array_equal(h.hash_batch_packed(big), f32.hash_device(torch.from_numpy(big).cuda()).cpu().numpy())
+
+
+def test_short_vector_throughput(torch_mod):
+    """The two shapes the verdict names at 1 M rows: bit-exact on 2 000 rows and at least 3 G vectors/s through hash_device
+    (the bench line carries the measured rate; this is the floor below which something is broken)."""
+    torch = torch_mod
+    import time
+
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    for nb, r, dim in ((16, 4, 128), (20, 6, 128)):
+        h = _hasher(42, nb, r, dim)
+        if not h._replay_model():
+            pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+        n = 1_000_000
+        x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(dim + nb))
+        keys = h.hash_device(x)
+        for _ in range(10):
+            h.hash_device(x, out=keys)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            h.hash_device(x, out=keys)
+        torch.cuda.synchronize()
+        rate = 20 * n / (time.perf_counter() - t0)
+        print(f"{nb} x {r} x {dim}: {rate / 1e9:.2f} G vectors/s, {h.last_stats}")
+        assert np.array_equal(keys[:2000].cpu().numpy(), hash_batch_literal_packed(h.projections, x[:2000].cpu().numpy()))
+        assert rate > 3.0e9, rate
+
+
+# ----------------------------------------------------------------------------- any dim, any alignment
+@pytest.mark.parametrize("seed,nb,r,dim,n", [(1, 16, 16, 102, 20_000), (9, 5, 8, 30, 20_000), (3, 20, 10, 301, 12_000),
+                                             (4, 4, 13, 1001, 6_000), (5, 2, 16, 4099, 3_000), (6, 8, 7, 99, 20_000),
+                                             (7, 3, 2, 9, 5_000), (8, 16, 16, 767, 9_000), (10, 6, 6, 13, 4_000)])
+def test_vectors_of_any_length_keep_the_device_replay(torch_mod, seed, nb, r, dim, n):
+    """dim % 4 != 0: the exact-f32 kernel (plain loads) and, for its ties, the replay of the host library INCLUDING the
+    scalar tail it adds behind the last group of four (lshrs_tb_model_row_dot, model 1 or 2 by how this host's library
+    compiles it) - `f32+replay`, no host arithmetic.  True ties included; the reference-literal loop's bytes."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(seed, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    x = np.random.default_rng(seed).standard_normal((n, dim)).astype(np.float32)
+    special = _salt_with_ties(h, x)
+    got = h.hash_device(torch.from_numpy(x).cuda())
+    st = dict(h.last_stats)
+    assert st["route"] == "f32+replay" and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] > special.size, st
+    want = hash_batch_literal_packed(h.projections, x)
+    assert np.array_equal(got.cpu().numpy(), want), int((got.cpu().numpy() != want).any(axis=(1, 2)).sum())
+    off = _hasher(seed, nb, r, dim, tie_replay="off")
+    assert torch.equal(off.hash_device(torch.from_numpy(x).cuda()), got)
+    assert np.array_equal(h.hash_batch_packed(x[:50]), want[:50])                # a handful of host vectors
+    assert h.hash_vector(x[special[1]]).as_tuple() == tuple(bytes(k) for k in want[special[1]])
+
+
+@pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (20, 10, 300), (16, 4, 128), (8, 7, 99)])
+def test_rows_at_any_four_byte_address_keep_the_device_replay(torch_mod, nb, r, dim):
+    """A float32 view that starts 4, 8 or 12 bytes past a 16-byte boundary (a slice of a larger buffer, a column range of a
+    wider matrix): the f32 kernel's plain-load form and the plain-load replay - `f32+replay`, same bytes as the aligned copy."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(13, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    n = 30_000
+    x = np.random.default_rng(dim).standard_normal((n, dim)).astype(np.float32)
+    special = _salt_with_ties(h, x)
+    want = hash_batch_literal_packed(h.projections, x[:4_000])
+    aligned = h.hash_device(torch.from_numpy(x).cuda())
+    for off in (1, 2, 3):
+        buf = torch.zeros(n * dim + 8, dtype=torch.float32, device="cuda")
+        view = buf[off:off + n * dim].view(n, dim)
+        view.copy_(torch.from_numpy(x))
+        assert view.data_ptr() % 16 == 4 * off
+        got = h.hash_device(view)
+        st = dict(h.last_stats)
+        assert st["route"] == "f32+replay" and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] > special.size, st
+        assert torch.equal(got, aligned)
+        assert np.array_equal(got[:4_000].cpu().numpy(), want)
+    # a column range of a wider matrix whose row stride is not a multiple of four elements
+    wide = torch.zeros((n, dim + 3), dtype=torch.float32, device="cuda")
+    wide[:, 1:1 + dim] = torch.from_numpy(x).cuda()
+    got = h.hash_device(wide[:, 1:1 + dim])
+    assert h.last_stats["route"] == "f32+replay" and torch.equal(got, aligned)
+
+
+def test_replay_kernels_ignore_what_lies_behind_a_rows_end(torch_mod):
+    """at 300-d (8 m + 4 elements, ten k-tiles from the fifth element) the last chunk a replay lane fetches of
+    hyperplane j lies in hyperplane j + 1.  With a non-finite value there (user-assigned hyperplanes) 0 x Inf must not
+    poison column j: both factors past the row's end read as zero - stage 2 and the one-launch kernel."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    for dim in (300, 44, 172):
+        h = _hasher(2, 4, 8, dim)
+        if not h._replay_model():
+            pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+        planes = [np.array(p) for p in h.projections]
+        for b in range(4):
+            planes[b][3, 0] = np.inf if b % 2 else -np.inf          # the hyperplane behind column (b, 2)
+            planes[b][6, :4] = np.nan
+        h.projections = planes
+        rng = np.random.default_rng(dim)
+        x = rng.standard_normal((4_000, dim)).astype(np.float32)
+        for i in range(0, 4_000, 5):                                # ties against the columns IN FRONT of the poisoned ones
+            p = planes[i % 4][2 if i % 2 else 5].astype(np.float64)
+            v = x[i].astype(np.float64)
+            x[i] = (v - (v @ p) / (p @ p) * p).astype(np.float32)
+        with np.errstate(all="ignore"):
+            want = hash_batch_literal_packed(h.projections, x)
+        got = h.hash_device(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert h.last_stats["tie_break_engine"] == "device-replay" and h.last_stats["tie_pairs"] > 500, h.last_stats
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (dim, bad[:5])
+        with np.errstate(all="ignore"):
+            assert np.array_equal(h.hash_batch_packed(x[:100:5]), want[:100:5])          # sig_small_kernel<.., GENERAL>
+
+
+# ----------------------------------------------------------------------------- the lock
+def test_two_threads_on_one_hasher_overlap_their_waits(torch_mod):
+    """hash_device holds the hasher's lock for the hand-out of scratch and counters, not for the wait: two threads with a
+    stream each enqueue while the other waits.  Same keys as one thread; every launch verified (counters per launch)."""
+    torch = torch_mod
+    h = _hasher(42, 16, 16, 768)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    xs = [torch.randn(200_000 + 1_000 * i, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(50 + i)) for i in range(4)]
+    want = [h.hash_device(x) for x in xs]
+    errors, overlaps = [], []
+    inside = [0]
+    gate = threading.Lock()
+
+    def work(t):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for rep in range(12):
+                    i = (t + rep) % 4
+                    with gate:
+                        inside[0] += 1
+                        overlaps.append(inside[0])
+                    got = h.hash_device(xs[i])
+                    with gate:
+                        inside[0] -= 1
+                    if not torch.equal(got, want[i]):
+                        errors.append((t, rep, i))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    assert max(overlaps) >= 2
+    assert h.audit_totals["sign_disagreements"] == 0
+
+
+# ----------------------------------------------------------------------------- the host-engine route's lists
+def test_host_engine_route_with_default_windows_hashes_every_chunk_once(torch_mod):
+    """tie_replay="off" (what an unrecognised host BLAS runs) with the DEFAULT windows: a third of the rows hold a tied pair -
+    the pipeline's per-chunk lists (one entry per 32 rows) would overflow on every chunk and every chunk would be hashed
+    twice.  The route is `plain` with a list sized from the window in force: no relaunch, same keys."""
+    torch = torch_mod
+    h = _hasher(42, 16, 16, 768, tie_replay="off")
+    x = torch.randn(400_000, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(8))
+    got = h.hash_device(x)
+    st = dict(h.last_stats)
+    assert st["route"] == "plain" and st["relaunches"] == 0 and st["tie_pairs"] > 50_000, st
+    ref = _hasher(42, 16, 16, 768)
+    if ref._replay_model():
+        assert torch.equal(ref.hash_device(x), got)
+    m = _hasher(42, 16, 16, 768, tie_replay="off", tau_ulps=8.0, tau1_ulps=64.0)      # measured windows: the chunked pipeline
+    assert torch.equal(m.hash_device(x), got)
+    assert m.last_stats["route"] in ("host-engine pipelined", "plain") and m.last_stats["relaunches"] <= 1, m.last_stats

@@ -33,7 +33,7 @@ for n in (1_000_000, 1_048_576, 1_250_000):
         cnt.zero_(); stamps.zero_()
         _native.check(lib.lshrs_sig_hash_batch_split_replay_f32(
             x.data_ptr(), n, x.stride(0), ws.data_ptr(), 16, 16, 768, keys.data_ptr(), cnt.data_ptr(), float(h.tau_ulps * _U),
-            None, fl.data_ptr(), None, cap, float(h.tau1_ulps * _U), 1, None, ctypes.byref(opts), cur.cuda_stream), "probe")
+            None, fl.data_ptr(), None, cap, float(h.tau1_ulps * _U), 1, None, None, ctypes.byref(opts), cur.cuda_stream), "probe")
         torch.cuda.synchronize()
         k_ms = ev[0].elapsed_time(ev[1])
         st = stamps.cpu().numpy()
