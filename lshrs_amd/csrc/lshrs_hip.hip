@@ -2065,8 +2065,9 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 // walks 32-row tiles of x on its own - no ring, no barrier after the prologue, nothing staged per tile but x itself.
 // sig16_kernel spends a prologue and an epilogue per 256 rows around four k-tiles of such a shape, and the exact-f32 kernel is
 // bound by the f32 matrix rate there (1 M x 128 x 128 columns: 0.32 ms = 0.7 of that roof, 0.10 of the HBM roof).
-//   wave   = two 16-row tiles x NCT column tiles (accumulators: 8 NCT registers), one of eight in a persistent workgroup
-//            (one workgroup per CU, two waves per SIMD); tile i of the batch goes to wave i mod (8 x workgroups);
+//   wave   = RT (two, or one where the registers ask for it: res_rt) 16-row tiles x NCT column tiles, one of eight in a
+//            persistent workgroup (one workgroup per CU, two waves per SIMD within 256 registers each: the second wave is
+//            what hides a wave's LDS round trips); tile i of the batch goes to wave i mod (8 x workgroups);
 //   x      straight from HBM to registers: lane (r, g) owns elements 32 t + 8 g .. + 7 of row r - the A operand of
 //            v_mfma_f32_16x16x32_bf16 as it comes; the registers of k-tile t are refilled with the NEXT tile's elements as
 //            soon as k-tile t has been split, so a whole tile of loads is in flight under the matrix work;
@@ -2077,16 +2078,21 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 //            words of a tile go through the wave's own LDS patch and leave as key bytes through the byte table;
 //   list   flagged projections are staged per wave in LDS and leave with one global atomic per 64 .. 128 entries.
 // ------------------------------------------------------------------------------------------
-constexpr int kResWaves = 4;
-constexpr int kResListCap = 128;                       // flagged projections a wave stages before it appends them
-constexpr int kResWaveFloats = 32 + 32 + 256 + 3 * kResListCap + 4;   // windows a / b per row, sign words, list (entry, y1), counter
+// waves per workgroup (one workgroup per CU): two per SIMD (<= 256 registers each), three where one row tile over <= 32
+// (column tile, k-tile) pairs fits 168 registers - the other waves are what hides a wave's LDS and memory round trips
+constexpr int res_waves(int nct, int kt) { return (nct * kt > 16 && nct * kt <= 32) ? 12 : 8; }
+constexpr int kResListCap = 64;                        // flagged projections a wave stages before it appends them
+// row tiles per wave: two where the accumulators (8 NCT RT registers) and the rows in flight (8 KT RT) leave room, else one
+constexpr int res_rt(int nct, int kt) { return nct * kt <= 16 ? 2 : 1; }
+constexpr int res_wave_floats(int rt) { return 32 * rt + 144 * rt + 3 * kResListCap + 4; }   // windows a / b, sign words (9 per row), list (entry, y1), counter: a multiple of 16 B
 template <int NCT, int KT>
-constexpr int res_lds_floats() { return KT * NCT * 512 + 512 + 256 + 512 + kResWaves * kResWaveFloats; }
+constexpr int res_lds_floats() { return KT * NCT * 512 + 512 + 256 + 512 + res_waves(NCT, KT) * res_wave_floats(res_rt(NCT, KT)); }
 
 template <int NCT, int KT>
-__global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs args) {
-  constexpr int RT = 2, NW = NCT / 2;
+__global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(const SigArgs args) {
+  constexpr int RT = res_rt(NCT, KT), NW = NCT / 2, kRows = 16 * RT, kResWaves = res_waves(NCT, KT);
   constexpr int kImgFloats = KT * NCT * 512;
+  constexpr int kResWaveFloats = res_wave_floats(RT);
   __shared__ __attribute__((aligned(16))) float lds[res_lds_floats<NCT, KT>()];
   struct Bf16Pairs { bf16x2 p[4]; };
 
@@ -2099,11 +2105,11 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
   int* tab_lds = reinterpret_cast<int*>(lds + kImgFloats + 768);       // byte table: (source bit, mask) per key byte
   float* mine = lds + kImgFloats + 1280 + wave * kResWaveFloats;       // this wave's patch
   float* wnd_lds = mine;
-  float* wnb_lds = mine + 32;
-  uint32_t* cw_lds = reinterpret_cast<uint32_t*>(mine + 64);           // [32 rows][8 words]
-  int64_t* l_list = reinterpret_cast<int64_t*>(mine + 320);
-  float* l_y = mine + 320 + 2 * kResListCap;
-  int* l_count = reinterpret_cast<int*>(mine + 320 + 3 * kResListCap);
+  float* wnb_lds = mine + kRows;
+  uint32_t* cw_lds = reinterpret_cast<uint32_t*>(mine + 2 * kRows);    // [rows of the tile][8 words + one that is only ever read]
+  int64_t* l_list = reinterpret_cast<int64_t*>(mine + 11 * kRows);
+  float* l_y = mine + 11 * kRows + 2 * kResListCap;
+  int* l_count = reinterpret_cast<int*>(mine + 11 * kRows + 3 * kResListCap);
 
   // ---- prologue: the image (L2 -> LDS, [kt][ct < NCT][part][lane] x 16 B) and the block's tables --------------------
   {
@@ -2117,30 +2123,35 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
       coef_lds[tid] = args.wa[tid];
       coef_lds[256 + tid] = args.wb[tid];
       padcol_lds[tid] = args.padcol[tid];
-      tab_lds[2 * tid] = args.bytetab[2 * tid];
-      tab_lds[2 * tid + 1] = args.bytetab[2 * tid + 1];
+      tab_lds[tid] = args.bytetab[2 * tid] | (args.bytetab[2 * tid + 1] << 16);      // source bit | mask of the live bits
     }
     if (lane == 0) l_count[0] = 0;
   }
   __syncthreads();
 
-  const int64_t tiles = (args.n + 31) / 32;
+  const int64_t tiles = (args.n + kRows - 1) / kRows;
   const int64_t stride = (int64_t)gridDim.x * kResWaves;
   const int dim = args.dim;
   const float amax_cb = args.wamax[0], bmax_cb = args.wbmax[0];
   const int nby = args.row_bytes;
 
-  // x of one 32-row tile: [row tile][k-tile][chunk of four]; elements past the row's end read as zero (dim % 4 == 0)
+  // x of one 32-row tile: [row tile][k-tile][chunk of four].  Every load is unconditional (a predicated load is a branch, and
+  // a wait for everything in flight behind it): a chunk past the row's end (dim % 4 == 0) is fetched from the row's last
+  // chunk instead and zeroed when its k-tile is split.
   f32x4 xr[RT][KT][2];
+  int koff[KT][2];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) koff[t][c] = 32 * t + 8 * g + 4 * c < dim ? 32 * t + 8 * g + 4 * c : dim - 4;
   auto load_x = [&](int64_t tile, int t) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      int64_t row = tile * 32 + 16 * rt + r16;
+      int64_t row = tile * kRows + 16 * rt + r16;
       row = row < args.n ? row : args.n - 1;                           // clamp: loads stay in bounds, stores are masked
-      const float* xp = args.X + row * args.ldx + 32 * t + 8 * g;
+      const float* xp = args.X + row * args.ldx;
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-        xr[rt][t][c] = 32 * t + 8 * g + 4 * c < dim ? *reinterpret_cast<const f32x4*>(xp + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 2; ++c) xr[rt][t][c] = *reinterpret_cast<const f32x4*>(xp + koff[t][c]);
     }
   };
   int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;
@@ -2150,18 +2161,28 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
   }
 
   for (; tile < tiles; tile += stride) {
-    const int64_t row0 = tile * 32;
+    const int64_t row0 = tile * kRows;
     const int64_t next = tile + stride < tiles ? tile + stride : tile;  // (the last tile re-fetches itself: unused, in bounds)
     f32x4 acc[RT][NCT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float ss[RT] = {0.f, 0.f}, sm[RT] = {0.f, 0.f}, amax[RT] = {0.f, 0.f};
+    float ss[RT] = {}, sm[RT] = {}, amax[RT] = {};
 
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       Bf16Pairs hi[RT], mid[RT];
+      if (32 * (t + 1) > dim) {                                        // (uniform) a k-tile that reaches past the row's end
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const bool gone = 32 * t + 8 * g + 4 * c >= dim;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[rt][t][c][e] = gone ? 0.f : xr[rt][t][c][e];
+          }
+      }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -2174,7 +2195,7 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
           mid[rt].p[pr] = mp;
           ss[rt] = __builtin_amdgcn_fdot2_f32_bf16(hp, hp, ss[rt], false);
           sm[rt] = __builtin_amdgcn_fdot2_f32_bf16(mp, mp, sm[rt], false);
-          amax[rt] = __builtin_fmaxf(amax[rt], __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+          asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax[rt]) : "v"(v0), "v"(v1));
         }
       load_x(next, t);                                                 // this k-tile's registers are free: the next tile's elements
       const f32x4* frag = reinterpret_cast<const f32x4*>(lds) + (size_t)t * NCT * 128 + lane;
@@ -2210,10 +2231,11 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
       am = __builtin_fmaxf(am, __shfl_xor(am, 32));
       const int64_t myrow = row0 + 16 * rt + r16;
       if (g == 0) {
-        float window = sqrtf(s2) * args.tau * 1.001f;
+        // (v_sqrt_f32 as it is - 1 ulp - instead of the library's corrected root: the 0.1 % below covers far more)
+        float window = __builtin_amdgcn_sqrtf(s2) * args.tau * 1.001f;
         if (am != 0.f && !(am >= 0x1p-32f && am <= 0x1p32f)) window = __builtin_inff();
         wnd_lds[16 * rt + r16] = window;
-        const float wb_ = sqrtf(m2) * args.tau_b * 1.001f;
+        const float wb_ = __builtin_amdgcn_sqrtf(m2) * args.tau_b * 1.001f;
         wnb_lds[16 * rt + r16] = wb_ < __builtin_inff() ? wb_ : 0.f;
         if (args.row_flags != nullptr && myrow < args.n) {
           const bool has_nan = s2 != s2;
@@ -2230,7 +2252,7 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
     if (args.audit_list != nullptr && (int)(tile % args.audit_div) == args.audit_phase) {
       const unsigned h = audit_hash((unsigned)tile, args.audit_seed);
       au_slot = (int)(tile / args.audit_div);
-      au_rw = (int)(h & 1u) * 8 + (int)(((h >> 1) & 7u) % (unsigned)NW);
+      au_rw = (int)((h & 1u) % (unsigned)RT) * 8 + (int)(((h >> 1) & 7u) % (unsigned)NW);
       au_q = (int)((h >> 4) & 7u);
       au_lane = (int)((h >> 7) & 63u);
     }
@@ -2257,7 +2279,7 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
             const int p0 = 8 * rt + reg * 2;              // pair (rt, reg, g'pair = 0); g'pair = 1 is p0 + 1
             deposit_positive(A[w & 1], y0, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
             deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
-            m = __builtin_fminf(m, __builtin_fminf(__builtin_fabsf(y0), __builtin_fabsf(y1)));   // (NaN dropped, as v_min3)
+            asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));        // (NaN dropped)
           }
           const bool aud = au_rw == 8 * rt + w;
           if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0 || aud) {   // wave-uniform: the exact per-element test
@@ -2319,14 +2341,14 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
       // lane L: row pair p = L / 4 -> rows lo / lo + 4 of the tile, words 2 (L % 4), + 1 of the block's sign string
       const int pr = lane >> 2, wq = 2 * (lane & 3);
       const int rlo = 16 * (pr >> 3) + 8 * (pr & 1) + ((pr >> 1) & 3);
-      if (wq < NW) {
+      if (wq < NW && pr < 8 * RT) {
         const uint32_t wlo[2] = {(A[0] & 0xFFFFu) | (B[0] << 16), (A[1] & 0xFFFFu) | (B[1] << 16)};
         const uint32_t whi[2] = {(A[0] >> 16) | (B[0] & 0xFFFF0000u), (A[1] >> 16) | (B[1] & 0xFFFF0000u)};
-        cw_lds[rlo * 8 + wq] = wlo[0];
-        cw_lds[(rlo + 4) * 8 + wq] = whi[0];
+        cw_lds[rlo * 9 + wq] = wlo[0];
+        cw_lds[(rlo + 4) * 9 + wq] = whi[0];
         if (wq + 1 < NW) {
-          cw_lds[rlo * 8 + wq + 1] = wlo[1];
-          cw_lds[(rlo + 4) * 8 + wq + 1] = whi[1];
+          cw_lds[rlo * 9 + wq + 1] = wlo[1];
+          cw_lds[(rlo + 4) * 9 + wq + 1] = whi[1];
         }
       }
     }
@@ -2334,26 +2356,28 @@ __global__ __launch_bounds__(64 * kResWaves) void sig16r_kernel(const SigArgs ar
     __builtin_amdgcn_wave_barrier();
 
     // ---- key bytes: byte o of a row = bits [src, src + 8) of its sign string, masked to the band's live rows ----------
+    constexpr int kLPR = 64 / kRows;                      // lanes per row of the tile
     if (args.vec_store) {                                 // whole 32-bit words of 4-byte aligned key rows
-      const int nw32 = nby >> 2;
-      for (int idx = lane; idx < 32 * nw32; idx += 64) {
-        const int rl = idx / nw32, o4 = idx - rl * nw32;
+      const int nw32 = nby >> 2, rl = lane / kLPR;
+      for (int o4 = lane % kLPR; o4 < nw32; o4 += kLPR) {
         uint32_t out = 0u;
+        const u32x4 rec = *reinterpret_cast<const u32x4*>(tab_lds + 4 * o4);       // the four bytes' table entries
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int src = tab_lds[2 * (4 * o4 + b)], w = src >> 5;
-          const uint32_t lo = cw_lds[rl * 8 + w], hi_ = cw_lds[rl * 8 + (w < 7 ? w + 1 : 7)];
-          const uint32_t v = (uint32_t)((((uint64_t)hi_ << 32) | lo) >> (src & 31)) & (uint32_t)tab_lds[2 * (4 * o4 + b) + 1];
-          out |= (v & 0xFFu) << (8 * b);
+          const int src = (int)(rec[b] & 0xFFFFu), w = src >> 5;
+          const uint32_t lo = cw_lds[rl * 9 + w], hi_ = cw_lds[rl * 9 + w + 1];    // (a ninth word per row: never live, always readable)
+          const uint32_t v = __builtin_amdgcn_alignbit(hi_, lo, (uint32_t)(src & 31)) & (rec[b] >> 16);
+          out |= v << (8 * b);
         }
         if (row0 + rl < args.n) *reinterpret_cast<uint32_t*>(args.keys + (row0 + rl) * (int64_t)nby + 4 * o4) = out;
       }
     } else {
-      for (int idx = lane; idx < 32 * nby; idx += 64) {
-        const int rl = idx / nby, o = idx - rl * nby;
-        const int src = tab_lds[2 * o], w = src >> 5;
-        const uint32_t lo = cw_lds[rl * 8 + w], hi_ = cw_lds[rl * 8 + (w < 7 ? w + 1 : 7)];
-        const uint32_t v = (uint32_t)((((uint64_t)hi_ << 32) | lo) >> (src & 31)) & (uint32_t)tab_lds[2 * o + 1];
+      const int rl = lane / kLPR;
+      for (int o = lane % kLPR; o < nby; o += kLPR) {
+        const uint32_t rec = (uint32_t)tab_lds[o];
+        const int src = (int)(rec & 0xFFFFu), w = src >> 5;
+        const uint32_t lo = cw_lds[rl * 9 + w], hi_ = cw_lds[rl * 9 + w + 1];
+        const uint32_t v = __builtin_amdgcn_alignbit(hi_, lo, (uint32_t)(src & 31)) & (rec >> 16);
         if (row0 + rl < args.n) args.keys[(row0 + rl) * (int64_t)nby + o] = (uint8_t)v;
       }
     }
@@ -2977,7 +3001,8 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   int audit_n = 0;
   if (audit != nullptr && audit->struct_bytes >= sizeof(lshrs_sig_audit) && audit->list != nullptr && audit->vals != nullptr &&
       audit->slots > 0 && audit->target > 0 && blas_model != 0) {
-    const int64_t units = rs.on ? (n + 31) / 32 : (row_tiles + 7) / 8 * 8 * a.ncb * 8;
+    const int res_rows = 16 * res_rt(rs.nct, rs.kt);
+    const int64_t units = rs.on ? (n + res_rows - 1) / res_rows : (row_tiles + 7) / 8 * 8 * a.ncb * 8;
     int64_t div = units / audit->target;
     if (div < 1) div = 1;
     if ((units + div - 1) / div > audit->slots) div = (units + audit->slots - 1) / audit->slots;
@@ -3012,8 +3037,10 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
       a.wamax = rw.wamax;
       a.wbmax = rw.wbmax;
     }
-    const int64_t tiles = (n + 31) / 32;
-    const dim3 grid((unsigned)(tiles < 256 * kResWaves ? (tiles + kResWaves - 1) / kResWaves : 256), 1, 1), block(64 * kResWaves, 1, 1);
+    const int res_rows = 16 * res_rt(rs.nct, rs.kt);
+    const int64_t tiles = (n + res_rows - 1) / res_rows;
+    const int rwaves = res_waves(rs.nct, rs.kt);
+    const dim3 grid((unsigned)(tiles < 256 * rwaves ? (tiles + rwaves - 1) / rwaves : 256), 1, 1), block(64 * rwaves, 1, 1);
 #define LSHRS_RES(NCT_, KT_) hipExtLaunchKernelGGL((sig16r_kernel<NCT_, KT_>), grid, block, 0, s, o.ev[0], o.ev[1], 0, a)
     if (rs.kt == 2) {
       if (rs.nct == 4) LSHRS_RES(4, 2); else if (rs.nct == 8) LSHRS_RES(8, 2); else if (rs.nct == 12) LSHRS_RES(12, 2); else LSHRS_RES(16, 2);

@@ -558,14 +558,14 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                            torch.empty((cap,), dtype=torch.float32, device=dev),   # stage-1 value of every list entry
                            # the audit sample of a launch: entry, (stage-1 value, window) per slot
                            torch.empty((2 * max(1, self.audit_unflagged),), dtype=torch.int64, device=dev),
-                           torch.empty((4 * max(1, self.audit_unflagged),), dtype=torch.float32, device=dev))
+                           torch.empty((4 * max(1, self.audit_unflagged),), dtype=torch.float32, device=dev), [None])
                 if len(self._replay_scratch) >= 16 and not self._async_pending:
                     # a caller that keeps making new streams must not pile up lists: nothing is in flight, start over
                     self._replay_scratch.clear()
                     self._replay_events.clear()
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
-            flag_list, counts, pinned, host_counts, turn, flag_y, audit_list, audit_vals = scratch
+            flag_list, counts, pinned, host_counts, turn, flag_y, audit_list, audit_vals, audit_box = scratch
             while not turn[1]:        # every pinned block belongs to an unverified launch: verify the oldest streamed one
                 if not self._async_pending:      # (cannot happen: a synchronous caller that takes the last block keeps the lock)
                     raise _native.NativeLibraryError("no free counter block for a replay launch")
@@ -591,8 +591,12 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             audit = None
             if self.audit_unflagged > 0:
                 self._audit_seed = (self._audit_seed + 1) & 0x7FFFFFFF
-                audit = _native.SigAudit(audit_list.data_ptr(), audit_vals.data_ptr(), int(audit_list.shape[0]),
-                                         self.audit_unflagged, self._audit_seed * 2654435761)
+                audit = audit_box[0]                 # (the struct of this scratch: the library reads it during the call only)
+                if audit is None:
+                    audit = audit_box[0] = _native.SigAudit(audit_list.data_ptr(), audit_vals.data_ptr(),
+                                                            int(audit_list.shape[0]), self.audit_unflagged, 0)
+                audit.target = self.audit_unflagged
+                audit.seed = (self._audit_seed * 2654435761) & 0xFFFFFFFF
             try:
                 _native.check(
                     lib.lshrs_sig_hash_batch_split_replay_f32(
@@ -712,9 +716,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             if self._replay_finish(state, stats):
                 break
             self._ensure_window(x.device, ws, model)      # (a guard that has just moved the hasher to the proven window)
-        skey = (x.device.index, _native.require_gpu().cuda.current_stream(x.device).cuda_stream)
-        scratch = self._replay_scratch.get(skey)
-        undisturbed = scratch is not None and scratch[4][0] == state[8]     # nobody has launched over this list since
+        undisturbed = state[9][0] == state[8]         # nobody has launched over this launch's list since
         if self.audit_every > 0 and stats.get("flagged", 0) > 0 and undisturbed:
             self._audit_countdown -= 1
             if self._audit_countdown <= 0:
