@@ -243,6 +243,11 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx,
                                     uint8_t* keys, uint8_t* row_flags, int32_t* counters, float tau,
                                     int32_t blas_model, int32_t* host_done, int32_t epoch, void* stream);
 
+/* Block the calling thread until everything enqueued on `stream` has run (hipStreamSynchronize): what a synchronous
+ * caller - LSHHasher.hash_batch returning its keys, lshrs/hash/lsh.py:136-169 - does behind the replay entry points before
+ * it reads the counters they left in pinned memory.  A convenience for bindings that hold a raw stream handle only. */
+int lshrs_stream_synchronize(void* stream);
+
 /* Diagnostic twin of lshrs_sig_hash_batch_f32: writes the raw projections instead of their sign bits.
  *   Y (n, ldy) f32 with ldy >= padded columns rounded up to the kernel's column tile
  *   (lshrs_sig_padded_columns()); column b*8*B + i holds dot(P[b*rows+i], X[row]).

@@ -103,6 +103,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     # (X, n, ldx, workspace, bands, rows, dim, keys, row_flags, counters, tau, blas_model, host_done, epoch, stream)
     lib.lshrs_sig_hash_small_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, vp, f32, i32, vp, i32, vp]
     lib.lshrs_sig_hash_small_replay_f32.restype = c.c_int
+    lib.lshrs_stream_synchronize.argtypes = [vp]
+    lib.lshrs_stream_synchronize.restype = c.c_int
     lib.lshrs_sig_project_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, i64, vp]
     lib.lshrs_sig_project_f32.restype = c.c_int
     lib.lshrs_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, vp, vp]
@@ -144,6 +146,7 @@ EXPORTS = (
     "lshrs_sig_hash_batch_split_replay_f32",
     "lshrs_sig_resolve_ties_replay_f32",
     "lshrs_sig_hash_small_replay_f32",
+    "lshrs_stream_synchronize",
     "lshrs_sig_project_f32",
     "lshrs_gather_rows_f32",
     "lshrs_gather_tied_rows_f32",

@@ -3236,6 +3236,8 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx, cons
   return -(int)hipGetLastError();
 }
 
+int lshrs_stream_synchronize(void* stream) { return -(int)hipStreamSynchronize(static_cast<hipStream_t>(stream)); }
+
 int lshrs_sig_project_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
                           int32_t rows_per_band, int32_t dim, float* Y, int64_t ldy, void* stream) {
   if (n == 0) return 0;

@@ -76,6 +76,21 @@ class _ProjectionList(list):
         return (list, (list(self),))
 
 
+class _RawStreamWait:
+    """What a synchronous launch waits on: the stream it was enqueued on, by its raw handle (`lshrs_stream_synchronize`)."""
+
+    __slots__ = ("_lib", "_raw")
+
+    def __init__(self, lib, raw) -> None:
+        self._lib, self._raw = lib, raw
+
+    def synchronize(self) -> None:
+        _native.check(self._lib.lshrs_stream_synchronize(self._raw), "lshrs_stream_synchronize")
+
+    def query(self) -> bool:
+        return False
+
+
 class _PendingKeys:
     """Handle of :meth:`LSHHasher.hash_device_async`."""
 
@@ -505,7 +520,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         if model:       # (the model's own limits - 8 m + 4 elements only up to 4096, two rows per band or more - are in `model`)
             if aligned and short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
-            return "f32+replay", model
+            if self.dim >= 9 or self.dim == 8:        # (the replay kernels: 8 elements and up; shorter vectors: the host)
+                return "f32+replay", model
         if (allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
                 and self._expected_tie_entries(32) <= 0.75 and self._tie_engine() is not None):
             # (the pipeline's per-chunk lists - and the pinned copies of the tied rows behind them - hold one entry per 32
@@ -543,13 +559,16 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         timing = self.kernel_events is not None
         ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
         with ctx:
-            cur = torch.cuda.current_stream(dev)
+            # (the raw handle of the device's current stream: building a torch Stream object per launch costs more than the
+            #  arithmetic around it; the object is made where something needs it - events, the error path)
+            raw = torch._C._cuda_getCurrentRawStream(dev.index)
+            cur = None
             cap = max(int(self._flag_cap_hint), n // 4 + 4096)
             if self.tau1_ulps > 256.0:      # a wide (e.g. "bound") window flags ~1.3e-6 of the projections per unit
                 cap = max(cap, int(n * self.num_bands * self.rows_per_band * min(self.tau1_ulps, 4096.0) * 2.0e-6) + 4096)
-            skey = (dev.index, cur.cuda_stream)
+            skey = (dev.index, raw)
             scratch = self._replay_scratch.get(skey)
-            if scratch is None or scratch[0].shape[0] < cap:
+            if scratch is None or scratch[9][3] < cap:
                 nc = _native.SIG_COUNTERS
                 pinned = torch.zeros((4, nc), dtype=torch.int32).pin_memory()
                 scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
@@ -559,13 +578,16 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                            # the audit sample of a launch: entry, (stage-1 value, window) per slot
                            torch.empty((2 * max(1, self.audit_unflagged),), dtype=torch.int64, device=dev),
                            torch.empty((4 * max(1, self.audit_unflagged),), dtype=torch.float32, device=dev), [None])
+                # ... and what every launch passes of it: list / counter / value pointers, the list's capacity, the four pinned blocks
+                scratch += ((scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[5].data_ptr(), int(scratch[0].shape[0]),
+                             tuple(pinned.data_ptr() + 4 * nc * i for i in range(4))),)
                 if len(self._replay_scratch) >= 16 and not self._async_pending:
                     # a caller that keeps making new streams must not pile up lists: nothing is in flight, start over
                     self._replay_scratch.clear()
                     self._replay_events.clear()
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
-            flag_list, counts, pinned, host_counts, turn, flag_y, audit_list, audit_vals, audit_box = scratch
+            flag_list, counts, pinned, host_counts, turn, flag_y, audit_list, audit_vals, audit_box, ptrs = scratch
             while not turn[1]:        # every pinned block belongs to an unverified launch: verify the oldest streamed one
                 if not self._async_pending:      # (cannot happen: a synchronous caller that takes the last block keeps the lock)
                     raise _native.NativeLibraryError("no free counter block for a replay launch")
@@ -580,6 +602,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                 # the measured); they travel in the call's own lshrs_sig_opts
                 ring = self._replay_events.get(skey)
                 if ring is None:
+                    cur = torch.cuda.current_stream(dev)
                     ring = []
                     for _ in range(4):
                         quad = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -601,23 +624,25 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                 _native.check(
                     lib.lshrs_sig_hash_batch_split_replay_f32(
                         x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
-                        out.data_ptr(), counts.data_ptr(), tau, row_flags.data_ptr() if row_flags is not None else None,
-                        flag_list.data_ptr(), flag_y.data_ptr(), int(flag_list.shape[0]), self._tau1_arg(),
-                        model, pinned[slot].data_ptr(), ctypes.byref(audit) if audit is not None else None,
-                        ctypes.byref(opts) if opts is not None else None, cur.cuda_stream),
+                        out.data_ptr(), ptrs[1], tau, row_flags.data_ptr() if row_flags is not None else None,
+                        ptrs[0], ptrs[2], ptrs[3], self._tau1_arg(),
+                        model, ptrs[4][slot], ctypes.byref(audit) if audit is not None else None,
+                        ctypes.byref(opts) if opts is not None else None, raw),
                     "lshrs_sig_hash_batch_split_replay_f32")
             except BaseException:
-                cur.synchronize()
+                torch.cuda.current_stream(dev).synchronize()
                 counts.zero_()              # a failed launch may have left counts behind: the next call starts from zero
                 turn[1].append(slot)
                 raise
             done = None
             if want_event:          # (the synchronous path waits for the stream instead)
                 done = torch.cuda.Event()
-                done.record(cur)
+                done.record(torch.cuda.current_stream(dev))
+            else:
+                done = _RawStreamWait(lib, raw)
         # (the ceiling the live check holds this launch to is the one of the coefficients it was launched with: `window_info`
         #  follows whichever BLAS-order model `_ensure_window` set last, and an async handle may be finished after a switch)
-        return (done if want_event else cur, host_counts, slot, int(flag_list.shape[0]), n, ev,
+        return (done, host_counts, slot, ptrs[3], n, ev,
                 float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps),
                 float(self.window_info.get("window_units_worst_case_row", float("inf"))), turn[0], turn)
 
@@ -627,10 +652,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         the window (the hasher switches to the deterministic bound and stays there)."""
         done, host_counts, slot, cap, n, ev, window, worst = state[:8]
         done.synchronize()      # (the launch behind stage 2 has written the counters into the pinned block)
-        ties, flagged, flips = int(host_counts[slot, 0]), int(host_counts[slot, 1]), int(host_counts[slot, 3])
-        max_dev = float(host_counts[slot, 2:3].view(np.float32)[0])
-        audited, audit_bad = int(host_counts[slot, 4]), int(host_counts[slot, 5])
-        audit_ratio = float(host_counts[slot, 6:7].view(np.float32)[0])
+        row = host_counts[slot]
+        ties, flagged, _, flips, audited, audit_bad, _, _ = row.tolist()
+        as_float = row.view(np.float32)
+        max_dev, audit_ratio = float(as_float[2]), float(as_float[6])
         state[9][1].append(slot)        # (the pinned block is free for the next launch)
         if flagged > cap:
             self._flag_cap_hint = int(flagged * 1.25) + 4096      # (rows flagged wholesale: NaN / Inf / extreme scales)

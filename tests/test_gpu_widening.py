@@ -128,6 +128,30 @@ def test_in_process_multi_device_ingestion(torch_mod):
     assert np.array_equal(two.hash_batch_packed(x), one.hash_batch_packed(x))
     two.close()
 
+    # four entries: a ragged batch - slices of whole 256-row tiles, the last one short -, fewer rows than
+    # entries x the minimum (stays on devices[0]), and a worker that raises: the error reaches the caller, the hasher stays usable
+    four = LSHHasher(16, 16, dim, seed=42, devices=[0, 0, 0, 0])
+    four.multi_device_min_rows = 1_000
+    ragged = x[:4 * 1_000 + 777]
+    k4 = four.hash_batch_packed(ragged)
+    assert four.last_stats.get("devices") == [0, 0, 0, 0] and len(four.last_stats["per_device"]) == 4
+    assert [st["n"] for st in four.last_stats["per_device"]] == [1280, 1280, 1280, 937]
+    ref4 = LSHHasher(16, 16, dim, seed=42)
+    assert np.array_equal(k4, ref4.hash_batch_packed(ragged))
+    four.hash_batch_packed(x[:3_999])
+    assert "devices" not in four.last_stats                            # 3 999 < 4 x 1 000: one device
+    boom = four._children[2].hash_batch_packed
+
+    def failing(*a, **kw):
+        raise RuntimeError("worker 2 fell over")
+
+    four._children[2].hash_batch_packed = failing
+    with pytest.raises(RuntimeError, match="worker 2 fell over"):
+        four.hash_batch_packed(ragged)
+    four._children[2].hash_batch_packed = boom
+    assert np.array_equal(four.hash_batch_packed(ragged), k4)          # (nothing is left half-done: the lock is free, the pool alive)
+    four.close()
+
     # through the orchestrator: the reference's operation order and flush boundaries (lshrs/core/main.py:1125-1143)
     m = 3_000
     a = LSHRS(dim=dim, num_perm=256, storage=InMemoryStorage(), buffer_size=10_000, packed_ingest=False)
