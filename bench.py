@@ -806,9 +806,12 @@ def bench_small_n(torch, np, hasher, x):
             ts.append(time.perf_counter() - t0)
         return 1e6 * pct(ts, 0.5)
 
-    idx = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(), hasher=hasher)
+    idx = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(), hasher=hasher, packed_ingest=False)   # op-tuple buckets (as round 3 measured)
     idx.index(list(range(1000)), xs[:1000])
+    arr = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(), hasher=hasher)                        # the default: array-fed buckets
+    arr.index(list(range(1000)), xs[:1000])
     out = {"unit": "us (p50 of 200 calls)",
+           "get_top_k_gpu_array_buckets": p50(lambda i: arr.get_top_k(xs[i], topk=10)),
            "hash_vector_gpu": p50(lambda i: hasher.hash_vector(xs[i])),
            "hash_vector_cpu_reference_literal": p50(lambda i: hash_vector_literal(hasher.projections, xs[i], DIM)),
            "ingest_gpu": p50(lambda i: idx.ingest(10_000 + i, xs[1000 + i])),
