@@ -141,16 +141,16 @@ inline int64_t sig_compact_floats(const SigGeom& g, const SigCompact& c) {
   return (int64_t)c.ncb * g.ktiles * 8192 + 3 * (int64_t)c.ncb * 256 + 3 * sig_pad4(c.ncb) + (int64_t)c.ncb * 256 * 3;
 }
 // RESIDENT image of sig16r_kernel (short vectors, at most 256 key columns): ONE compact column block - every band's rows
-// side by side, `nct` 16-column tiles of it live - over `kt` (2 or 4) k-tiles, zero beyond dim; same tables and copies as a
+// side by side, `nct` 16-column tiles of it live - over `kt` (2, 4 or 8) k-tiles, zero beyond dim; same tables and copies as a
 // compact block (SigCompactWs with ncb = 1, bpb = num_bands), behind the compact section.
 struct SigResident { bool on; int nct; int kt; };
 inline SigResident sig_resident(int num_bands, int rows, int dim) {
   SigResident r{false, 0, 0};
   const int64_t real = (int64_t)num_bands * rows;
-  if (real > 256 || dim > 128 || dim < 8 || dim % 4 != 0) return r;
-  r.on = true;
+  if (real > 256 || dim > 256 || dim < 8 || dim % 4 != 0) return r;
   r.nct = (((int)real + 15) / 16 + 3) / 4 * 4;
-  r.kt = dim <= 64 ? 2 : 4;
+  r.kt = dim <= 64 ? 2 : (dim <= 128 ? 4 : 8);
+  r.on = r.nct * r.kt <= 64;                        // (the image - nct x kt x 2 KiB - and a wave's rows in flight must fit)
   return r;
 }
 inline int64_t sig_resident_floats(const SigResident& r) {
@@ -2059,7 +2059,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Stage 1 of the split pass for SHORT vectors and narrow hashers (dim <= 128, at most 256 key columns: BASELINE config
+// Stage 1 of the split pass for SHORT vectors and narrow hashers (dim <= 256 and nct x kt <= 64, at most 256 key columns: BASELINE config
 // 1's 16 x 4 x 128, the reference's docstring layout 20 x 6 x 128, num_perm = 128 at 128-d): the whole bf16 hi / mid
 // fragment image stays RESIDENT in LDS (KT k-tiles x NCT 16-column tiles x 2 KiB: 64 KiB at 128 x 128) and every wave
 // walks 32-row tiles of x on its own - no ring, no barrier after the prologue, nothing staged per tile but x itself.
@@ -2080,7 +2080,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 // ------------------------------------------------------------------------------------------
 // waves per workgroup (one workgroup per CU): two per SIMD (<= 256 registers each), three where one row tile over <= 32
 // (column tile, k-tile) pairs fits 168 registers - the other waves are what hides a wave's LDS and memory round trips
-constexpr int res_waves(int nct, int kt) { return (nct * kt > 16 && nct * kt <= 32) ? 12 : 8; }
+constexpr int res_waves(int nct, int kt) { return (nct * kt > 16 && nct * kt <= 32 && kt <= 4) ? 12 : 8; }
 constexpr int kResListCap = 64;                        // flagged projections a wave stages before it appends them
 // row tiles per wave: two where the accumulators (8 NCT RT registers) and the rows in flight (8 KT RT) leave room, else one
 constexpr int res_rt(int nct, int kt) { return nct * kt <= 16 ? 2 : 1; }
@@ -3044,8 +3044,10 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
 #define LSHRS_RES(NCT_, KT_) hipExtLaunchKernelGGL((sig16r_kernel<NCT_, KT_>), grid, block, 0, s, o.ev[0], o.ev[1], 0, a)
     if (rs.kt == 2) {
       if (rs.nct == 4) LSHRS_RES(4, 2); else if (rs.nct == 8) LSHRS_RES(8, 2); else if (rs.nct == 12) LSHRS_RES(12, 2); else LSHRS_RES(16, 2);
-    } else {
+    } else if (rs.kt == 4) {
       if (rs.nct == 4) LSHRS_RES(4, 4); else if (rs.nct == 8) LSHRS_RES(8, 4); else if (rs.nct == 12) LSHRS_RES(12, 4); else LSHRS_RES(16, 4);
+    } else {
+      if (rs.nct == 4) LSHRS_RES(4, 8); else LSHRS_RES(8, 8);
     }
 #undef LSHRS_RES
   } else {

@@ -918,14 +918,16 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         return ok
 
     def _resident_shape(self) -> bool:
-        """Short vectors of a narrow hasher - at most 256 key columns, dim <= 128 (BASELINE config 1's 16 x 4 x 128, the
-        reference's docstring layout 20 x 6 x 128): stage 1 of the split pass runs with the whole fragment image resident in
-        LDS (sig16r_kernel; the library's `sig_resident` decides the same way).  Accumulators of up to 8 column tiles over 4
-        k-tiles (or 16 over 2) fit a wave's registers."""
+        """Short vectors of a narrow hasher - at most 256 key columns, dim <= 256, (16-column tiles) x (32-element k-tiles)
+        <= 64: BASELINE config 1's 16 x 4 x 128, the reference's docstring layout 20 x 6 x 128, num_perm = 128 at 256-d -: stage
+        1 of the split pass runs with the whole fragment image resident in LDS (sig16r_kernel; the library's `sig_resident`
+        decides the same way)."""
         real = self.num_bands * self.rows_per_band
-        if real > 256 or self.dim > 128 or self.dim < 8 or self.dim % 4 != 0:
+        if real > 256 or self.dim > 256 or self.dim < 8 or self.dim % 4 != 0:
             return False
-        return True
+        nct = ((real + 15) // 16 + 3) // 4 * 4
+        kt = 2 if self.dim <= 64 else (4 if self.dim <= 128 else 8)
+        return nct * kt <= 64
 
     def _split_shape_check(self) -> bool:
         key_cols = 8 * self.num_bands * self.band_bytes

@@ -231,9 +231,11 @@ def test_route_table():
         assert LSHHasher(16, 4, 128, seed=1)._route(1_000_000, "host", **ok) == ("split+replay", 1)  # short rows: the resident-image kernel
         assert LSHHasher(20, 6, 128, seed=1)._route(1_000_000, "host", **ok) == ("split+replay", 1)
         assert LSHHasher(16, 4, 128, seed=1)._route(100, "host", **ok) == ("f32+replay", 1)
-        assert LSHHasher(16, 8, 256, seed=1)._route(1_000_000, "host", **ok) == ("f32+replay", 1)    # 128 key columns, 256-d
+        assert LSHHasher(16, 8, 256, seed=1)._route(1_000_000, "host", **ok) == ("split+replay", 1)  # 128 key columns, 256-d: resident too
+        assert LSHHasher(16, 8, 288, seed=1)._route(1_000_000, "host", **ok) == ("f32+replay", 1)    # ... 288-d: the f32 kernel
+        assert LSHHasher(12, 16, 256, seed=1)._route(1_000_000, "host", **ok) == ("f32+replay", 1)   # 192 key columns x 8 k-tiles: too large an image
         assert LSHHasher(5, 12, 64, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)      # 60 key columns at 64-d: resident
-        assert LSHHasher(5, 12, 256, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)       # 10 key bytes: any row width
+        assert LSHHasher(5, 12, 320, seed=1)._route(5_000, "host", **ok) == ("f32+replay", 1)       # 10 key bytes: any row width
         assert LSHHasher(25, 8, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)     # 25 key bytes, 200 key columns
         assert LSHHasher(20, 10, 768, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 + 2 rows per band
         assert LSHHasher(16, 16, 100, seed=1)._route(5_000, "host", **ok) == ("split+replay", 1)    # 8 m + 4 elements, a partial k-tile

@@ -129,7 +129,8 @@ def test_audit_fires_on_adversarial_rows_where_the_margin_guard_sees_nothing(tor
 # ----------------------------------------------------------------------------- short vectors
 @pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 4, 128), (1, 20, 6, 128), (2, 8, 16, 128), (3, 16, 8, 64), (4, 3, 5, 64),
                                            (5, 32, 8, 44), (6, 8, 12, 12), (7, 5, 11, 96), (8, 16, 16, 36), (9, 16, 16, 128),
-                                           (10, 25, 8, 100), (11, 128, 2, 128), (12, 2, 2, 8)])
+                                           (10, 25, 8, 100), (11, 128, 2, 128), (12, 2, 2, 8), (13, 16, 8, 256), (14, 5, 12, 200),
+                                           (15, 8, 16, 132)])
 def test_resident_image_kernel_gives_the_reference_keys(torch_mod, seed, nb, r, dim):
     """sig16r_kernel (stage 1 with the whole fragment image in LDS, rows straight into registers) on every instantiation:
     ragged batch sizes, true ties against every kernel kind of the host library, zero / NaN / Inf / huge / tiny rows, key

@@ -383,20 +383,22 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     (10, 10, 768, 20_000, "split+replay"),      # get_optimal_config(100, 0.3): 160 key columns on the zero-padded image
     (20, 5, 384, 20_000, "split+replay"),       # get_optimal_config(100, 0.5)
     (28, 7, 512, 20_000, "split+replay"),       # 224 key columns
-    (10, 10, 256, 20_000, "f32+replay"),
+    (10, 10, 256, 20_000, "split+replay"),      # 100 key columns at 256-d: the resident-image kernel over eight k-tiles
+    (10, 10, 288, 20_000, "f32+replay"),
     (6, 11, 96, 20_000, "split+replay"),        # 66 key columns at 96-d, 8 + 3 rows: the resident-image kernel
-    (6, 11, 160, 20_000, "f32+replay"),         # ... at 160-d: 96 padded key columns, the f32 kernel
+    (6, 11, 288, 20_000, "f32+replay"),         # ... at 288-d: 96 padded key columns, the f32 kernel
     (25, 8, 768, 30_001, "split+replay"),       # get_optimal_config(200, ...)-like: 25 key bytes per row - words straddle rows
     (5, 20, 768, 20_003, "f32+replay"),         # get_optimal_config(100, 0.9): 15 key bytes, 120 key columns
     (10, 20, 512, 20_001, "split+replay"),      # get_optimal_config(200, 0.3): 30 key bytes
     (5, 11, 96, 20_001, "split+replay"),        # 10 key bytes
-    (5, 11, 192, 20_001, "f32+replay"),
+    (5, 11, 320, 20_001, "f32+replay"),
     (3, 5, 64, 1_001, "split+replay"),          # 3 key bytes
-    (3, 5, 200, 1_001, "f32+replay"),
+    (3, 5, 300, 1_001, "f32+replay"),
     (16, 16, 300, 30_000, "split+replay"),      # GloVe / word2vec: 8 m + 4 elements - the library takes the first four first;
     (20, 10, 100, 30_000, "split+replay"),      #   stage 1 reads the chunks past a row's end as zero (sig16_kernel<.., PARTIAL>)
     (32, 8, 44, 30_000, "split+replay"),        # two k-tiles, the second one three chunks long
-    (8, 7, 200, 20_000, "f32+replay"),          # not whole k-tiles
+    (8, 7, 200, 20_000, "split+replay"),        # not whole k-tiles (resident image, eight k-tiles, the seventh partial)
+    (8, 7, 260, 20_000, "f32+replay"),
     (16, 16, 1000, 20_000, "split+replay"),
     (16, 16, 36, 20_000, "split+replay"),
     (16, 16, 5000, 9_000, "split+replay"),      # a partial last k-tile behind a whole block of the library
@@ -1081,7 +1083,8 @@ def _stage1_values(torch, h, x):
 @pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (7, 16, 32, 1536), (3, 16, 16, 256), (5, 16, 16, 300), (9, 32, 8, 100),
                                            (11, 20, 10, 768), (13, 40, 5, 100),     # (every instantiation of sig16_kernel<COMPACT, PARTIAL>)
                                            (42, 16, 4, 128), (3, 20, 6, 128), (5, 24, 8, 96), (6, 16, 16, 128),   # sig16r_kernel<4 .. 16, 4>
-                                           (7, 5, 12, 64), (8, 16, 8, 36), (9, 12, 16, 44), (10, 32, 8, 12)])     # sig16r_kernel<4 .. 16, 2>
+                                           (7, 5, 12, 64), (8, 16, 8, 36), (9, 12, 16, 44), (10, 32, 8, 12),      # sig16r_kernel<4 .. 16, 2>
+                                           (12, 16, 8, 256), (14, 3, 20, 160)])                                  # sig16r_kernel<8 / 4, 8>
 def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     """Stage 1 of the split pass, projection by projection, against oracle/mfma_model.c's accumulator: the bf16 split of
     x and p (round to nearest even, exact residual), per 32-deep k-tile the three instructions xh*ph, xh*pm, xm*ph in
