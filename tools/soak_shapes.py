@@ -28,13 +28,18 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # compact column blocks in stage 1
           (128, 4, 768), (21, 12, 768), (60, 9, 384), (33, 7, 640), (100, 2, 512), (50, 5, 1536),
           # partial k-tiles in stage 1 (with a second block of the library; with compact column blocks)
-          (16, 16, 5000), (40, 5, 100), (16, 16, 40))
+          (16, 16, 5000), (40, 5, 100), (16, 16, 40),
+          # round 4: short vectors on the resident-image kernel (every instantiation family: 2 / 4 / 8 k-tiles, 4 .. 16 column tiles)
+          (16, 4, 128), (8, 16, 128), (16, 8, 64), (16, 8, 256), (5, 12, 200), (128, 2, 128), (24, 8, 96), (16, 16, 128), (2, 2, 12),
+          # round 4: vector lengths that are not a multiple of four (the host library's scalar tail: blas model 1 / 2)
+          (16, 16, 102), (5, 8, 30), (20, 10, 301), (4, 13, 1001), (8, 7, 99), (2, 16, 4099), (16, 16, 767), (3, 2, 9), (16, 4, 129))
 
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     t0 = time.time()
-    rows = bad = batches = 0
+    rows = bad = batches = audit_bad = audited = 0
+    routes = {}
     worst = 0.0
     for rnd in range(rounds):
         for nb, r, dim in SHAPES:
@@ -58,8 +63,12 @@ def main():
             holes = x0.clone()
             for t in range(0, dim // 32, 2):
                 holes[:, 32 * t:32 * t + 32] = 0.0
+            shifted = torch.zeros(n * dim + 8, device="cuda")          # the same rows 4 bytes past a 16-byte boundary
+            off_view = shifted[1:1 + n * dim].view(n, dim)
+            off_view.copy_(x0)
             data = {
                 "gaussian": x0,
+                "offset_view": off_view,
                 "adversary": built.repeat(reps, 1)[:n] * torch.exp2(torch.randint(-3, 4, (n, 1), device="cuda", generator=g).float()),
                 "tiny_2^-30": x0 * 2.0 ** -30,
                 "huge_2^30": x0 * 2.0 ** 30,
@@ -72,7 +81,10 @@ def main():
                 sa = dict(a.last_stats)
                 kb = b.hash_device(x)
                 ok = torch.equal(ka, kb)
-                sl = slice(n // 3, n // 3 + 400)
+                sl = slice(n // 3, n // 3 + (400 if dim % 4 == 0 and dname != "offset_view" else 2000))
+                routes[sa.get("route")] = routes.get(sa.get("route"), 0) + 1
+                audit_bad += int(sa.get("audit_sign_disagreements", 0))
+                audited += int(sa.get("audited_unflagged", 0))
                 ok_ref = np.array_equal(ka[sl].cpu().numpy(), hash_batch_literal_packed(a.projections, x[sl].cpu().numpy()))
                 used = sa.get("max_dev_units", 0.0) / a.window_info.get("window_units_worst_case_row", float("inf"))
                 worst = max(worst, used)
@@ -85,8 +97,9 @@ def main():
             a.close()
             b.close()
     print(f"shape soak: {batches} batches, {rows} rows, {bad} mismatches, largest measured deviation = {worst:.3f} of the "
-          f"worst-case-row window, {time.time() - t0:.0f} s")
-    sys.exit(1 if bad else 0)
+          f"worst-case-row window, routes {routes}, {audited} un-flagged projections audited ({audit_bad} sign disagreements), "
+          f"{time.time() - t0:.0f} s")
+    sys.exit(1 if bad or audit_bad or routes.get("plain") else 0)
 
 
 if __name__ == "__main__":
