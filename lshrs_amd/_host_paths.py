@@ -146,7 +146,7 @@ class _HostPaths:
         lib = _native.load()
         n = arr.shape[0]
         rb = self.num_bands * self.band_bytes
-        if self.tie_replay != "auto" or self.dim % 4 != 0 or self.dim < 8 or self.dim > 4096:
+        if self.tie_replay != "auto" or self.dim % 4 != 0 or self.dim < 8 or self.dim > 4096 or self.rows_per_band == 1:
             return None
         ldx = (self.dim + 31) // 32 * 32          # (the kernel fetches whole k-tiles: rows padded with zeros, never used)
         model = self._replay_model()

@@ -172,7 +172,7 @@ def blas_order_model(planes: np.ndarray) -> int:
     try:
         body = dim & ~3               # (dim % 4 elements behind it: the library's scalar tail, modelled from 9 elements up)
         if ((dim % 4 == 0 or (dim >= 9 and r >= 2)) and (body % 8 == 0 or body <= 4096) and r >= 1
-                and os.path.exists(LIBRARY)):
+                and (r >= 2 or dim % 32 == 0) and os.path.exists(LIBRARY)):
             lib = load()
             rng = np.random.default_rng(20240601)
             bands = sorted({0, nb // 2, nb - 1})
@@ -196,7 +196,8 @@ def blas_order_model(planes: np.ndarray) -> int:
                     trials.append((plane, x32, plane @ x32))    # the reference's call (lshrs/hash/lsh.py:200)
             # model 2 differs from 1 only in the dim % 4 elements of the scalar tail (the library's Haswell / Zen build
             # contracts nothing there): tried second, and only where there is a tail
-            for candidate in ((1,) if dim % 4 == 0 else (1, 2)):
+            # ... and in how a band of ONE row is summed (NumPy calls sdot there: model 1 needs whole 64-element steps, 2 whole 32s)
+            for candidate in ((1,) if dim % 4 == 0 and r >= 2 else (1, 2)):
                 if all(np.array_equal(want.view(np.uint32), np.array(
                         [lib.lshrs_tb_model_row_dot(plane[i].ctypes.data, x32.ctypes.data, dim, candidate, i, r)
                          for i in range(r)], dtype=np.float32).view(np.uint32)) for plane, x32, want in trials):

@@ -256,7 +256,7 @@ void* lshrs_tb_create(const char* blas_path, const char* sgemv_symbol, const cha
 //     vectors do not reach these kernels the same way and are refused.
 //     model 2 = the same with the tail as the library's Haswell / Zen build compiles it: y + fl(a0 x0), y + (fl(a0 x0) +
 //     fl(a1 x1)), y + ((fl(a0 x0) + fl(a1 x1)) + fl(a2 x2)) - nothing contracted.  (n % 4 == 0: models 1 and 2 coincide.)
-// rows_per_band = 1 is refused: NumPy then calls sdot, another kernel.  Found by search (tools/blas_order/); the caller (lshrs_amd/_hostblas.py) compares it bit for
+// rows_per_band = 1 is another kernel (sdot: tb_model_sdot below).  Found by search (tools/blas_order/); the caller (lshrs_amd/_hostblas.py) compares it bit for
 // bit with `P_band @ x` of the running process, row kind by row kind, before the device replay may stand in for the host.
 static inline int tb_row_kind(int row, int rows) {
   const int r4 = rows & ~3;
@@ -264,9 +264,41 @@ static inline int tb_row_kind(int row, int rows) {
   return ((rows & 3) == 1 || row - r4 == 2) ? 2 : 1;
 }
 
+// A band of ONE row: NumPy's matmul sends (1, n) @ (n,) to sdot, not to sgemv.  The two builds of the library sum it
+// differently (tools/blas_order/tail_search.py), modelled for lengths without a tail:
+//   model 1 (SkylakeX build, n % 64 == 0): 64 fma chains over k mod 64 = four 16-lane accumulators; each folded to eight
+//     lanes (l + (l + 8)), the four added in turn ((t0 + t1) + t2) + t3, lanes i + (i + 4), then (w0 + w1) + (w2 + w3);
+//   model 2 (Haswell / Zen build, n % 32 == 0): 32 fma chains over k mod 32 = eight 4-lane accumulators, added pairwise
+//     ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) per lane, then (l0 + l1) + (l2 + l3).
+static float tb_model_sdot(const float* a, const float* x, int64_t n, int32_t model) {
+  if (model == 1) {
+    if (n % 64 != 0) return __builtin_nanf("");
+    float acc[64] = {0};
+    for (int64_t k = 0; k < n; ++k) acc[k & 63] = __builtin_fmaf(a[k], x[k], acc[k & 63]);
+    float v[8];
+    for (int l = 0; l < 8; ++l) {
+      float t[4];
+      for (int u = 0; u < 4; ++u) t[u] = acc[16 * u + l] + acc[16 * u + l + 8];
+      v[l] = ((t[0] + t[1]) + t[2]) + t[3];
+    }
+    const float w0 = v[0] + v[4], w1 = v[1] + v[5], w2 = v[2] + v[6], w3 = v[3] + v[7];
+    return (w0 + w1) + (w2 + w3);
+  }
+  if (n % 32 != 0) return __builtin_nanf("");
+  float acc[32] = {0};
+  for (int64_t k = 0; k < n; ++k) acc[k & 31] = __builtin_fmaf(a[k], x[k], acc[k & 31]);
+  float v[4];
+  for (int l = 0; l < 4; ++l) {
+    const float s0 = acc[l] + acc[4 + l], s1 = acc[8 + l] + acc[12 + l], s2 = acc[16 + l] + acc[20 + l], s3 = acc[24 + l] + acc[28 + l];
+    v[l] = (s0 + s1) + (s2 + s3);
+  }
+  return (v[0] + v[1]) + (v[2] + v[3]);
+}
+
 float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band) {
   if ((model != 1 && model != 2) || a == nullptr || x == nullptr || n <= 0 || row < 0 || row >= rows_per_band)
     return __builtin_nanf("");
+  if (rows_per_band == 1) return tb_model_sdot(a, x, n, model);
   if (n % 4 != 0 && (n < 9 || rows_per_band < 2)) return __builtin_nanf("");
   const int64_t body = n & ~(int64_t)3;                       // whole groups of four: the kernels' share
   if (body % 8 != 0 && body > 4096) return __builtin_nanf("");     // (a short last block behind full ones: not modelled)

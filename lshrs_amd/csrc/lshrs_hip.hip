@@ -1093,6 +1093,36 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
     const float* __restrict__ pr = a.prow + (size_t)col * ldp;
     const int kind = blas_row_kind(col % a.band_cols, a.rows_per_band);
     float y = 0.f, ss = 0.f;
+    if (a.rows_per_band == 1) {
+      // A band of ONE row: NumPy calls sdot (lshrs_host.h, tb_model_sdot).  Lane `sub` owns the chains c = sub + 8 j.
+      if (a.tail_model == 1) {          // SkylakeX build: 64 chains, accumulators folded in halves, added in turn
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < a.dim; k0 += 64)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xv = xr[k0 + 8 * j + sub];
+            acc[j] = __builtin_fmaf(pr[k0 + 8 * j + sub], xv, acc[j]);
+            ss = __builtin_fmaf(xv, xv, ss);
+          }
+        const float v = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + (acc[4] + acc[5])) + (acc[6] + acc[7]);
+        y = blas_reduce(v, 0, lane);    // lanes i + (i + 4), then (w0 + w1) + (w2 + w3)
+      } else {                          // Haswell / Zen build: 32 chains, accumulators pairwise, lanes pairwise
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < a.dim; k0 += 32)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xv = xr[k0 + 8 * j + sub];
+            acc[j] = __builtin_fmaf(pr[k0 + 8 * j + sub], xv, acc[j]);
+            ss = __builtin_fmaf(xv, xv, ss);
+          }
+        float sj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sj[j] = acc[j] + __shfl(acc[j], (lane + 32) & 63);   // a(2j) + a(2j+1): lanes l and l + 4
+        const float v = (sj[0] + sj[1]) + (sj[2] + sj[3]);
+        const float h = v + __shfl(v, (lane + 8) & 63);
+        y = h + __shfl(h, (lane + 16) & 63);
+      }
+    } else
     for (int k0 = 0; k0 < body; k0 += 4096) {                      // the library's blocks (uniform trip count)
       const int kn = body - k0 < 4096 ? body - k0 : 4096;
       float pj = 0.f;
@@ -1118,7 +1148,7 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
       const float sblk = blas_reduce(pj, kind, lane);              // (every lane takes part in the shuffles)
       y = k0 == 0 ? sblk : y + sblk;
     }
-    if (m3 != 0) {                                                 // the scalar tail (lshrs_tb_model_row_dot)
+    if (m3 != 0 && a.rows_per_band != 1) {                         // the scalar tail (lshrs_tb_model_row_dot)
       const float a0 = pr[body], x0 = xr[body];
       const float a1 = m3 > 1 ? pr[body + 1] : 0.f, x1 = m3 > 1 ? xr[body + 1] : 0.f;
       const float a2 = m3 > 2 ? pr[body + 2] : 0.f, x2 = m3 > 2 ? xr[body + 2] : 0.f;
@@ -3143,9 +3173,11 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   // stage 2 stages 16-byte chunks of 16-byte aligned rows (key rows may have any width: split_pass's comment); anything
   // else - dim % 4 elements of scalar tail (blas_model 1 / 2: how the host compiles it), rows that are only 4-byte aligned -
   // goes through the plain-load form of the same replay (sig_fixany_kernel)
-  const bool fast = dim % 4 == 0 && dim >= 8 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  const bool fast = dim % 4 == 0 && dim >= 8 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && rows_per_band >= 2;
   const int body = dim & ~3;
-  if ((body % 8 != 0 && body > 4096) || n >= ((int64_t)1 << 42) || (!fast && (dim < 9 || rows_per_band < 2)) ||
+  // (a band of ONE row is sdot on the host: modelled for whole 64-element steps - model 1 - or whole 32s - model 2)
+  const bool one_row_ok = rows_per_band == 1 && (blas_model == 1 ? dim % 64 == 0 : dim % 32 == 0);
+  if ((body % 8 != 0 && body > 4096) || n >= ((int64_t)1 << 42) || (!fast && dim < 9) || (rows_per_band < 2 && !one_row_ok) ||
       (fast && blas_model != 1))
     return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -903,6 +903,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         query vector: the fine-geometry f32 kernel answers in 35 us) stay off it."""
         if self.precision != "bf16x3" or self.dim % 4 != 0 or (self.dim < 32 and not (replay and self._resident_shape())):
             return False
+        if self.rows_per_band == 1:       # (the host sums a one-row band with sdot: only the plain-load replay follows that)
+            return False
         if self.dim % 32 != 0 and not replay:      # (a partial last k-tile: only the replaying stage 2 masks the row's end)
             return False
         if replay:

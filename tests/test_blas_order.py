@@ -132,7 +132,17 @@ def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
 def test_shapes_the_model_does_not_cover_are_refused():
     rng = np.random.default_rng(1)
     assert _hostblas.blas_order_model(rng.standard_normal((4, 8, 4100)).astype(np.float32)) == 0      # a short block behind full ones
-    assert _hostblas.blas_order_model(rng.standard_normal((8, 1, 64)).astype(np.float32)) == 0        # one row per band: sdot
+    assert _hostblas.blas_order_model(rng.standard_normal((8, 1, 100)).astype(np.float32)) == 0       # one row per band (sdot) with a tail
+    if _hostblas.blas_order_model(rng.standard_normal((2, 4, 64)).astype(np.float32)) == 1:
+        # one row per band, whole 64-element steps: NumPy's sdot, modelled for both builds of the library (1 / 2)
+        for dim in (64, 128, 768):
+            planes = rng.standard_normal((6, 1, dim)).astype(np.float32)
+            model = _hostblas.blas_order_model(planes)
+            assert model in (1, 2), dim
+            for _ in range(8):
+                x = rng.standard_normal(dim).astype(np.float32)
+                got = _model_row_dot(planes[3, 0], x, 0, 1, model=model)
+                assert (planes[3] @ x)[0].view(np.uint32) == got.view(np.uint32), dim
     assert _hostblas.blas_order_model(rng.standard_normal((4, 4, 7)).astype(np.float32)) == 0         # a tail below 9 elements
     # dim % 4 != 0 is modelled now (the scalar tail, model 1 or 2 by how this host's library compiles it)
     if _hostblas.blas_order_model(rng.standard_normal((2, 4, 64)).astype(np.float32)) == 1:

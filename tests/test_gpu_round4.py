@@ -240,6 +240,36 @@ def test_vectors_of_any_length_keep_the_device_replay(torch_mod, seed, nb, r, di
     assert h.hash_vector(x[special[1]]).as_tuple() == tuple(bytes(k) for k in want[special[1]])
 
 
+@pytest.mark.parametrize("nb,dim,n", [(64, 64, 20_000), (16, 128, 20_000), (8, 768, 12_000), (128, 256, 5_000)])
+def test_bands_of_one_row_replay_the_hosts_sdot(torch_mod, nb, dim, n):
+    """`rows_per_band = 1` (a pair `get_optimal_config`'s search can return): NumPy's matmul sends `(1, dim) @ (dim,)` to sdot,
+    whose order both builds of the library are modelled for where the length is whole 64 / 32-element steps - the f32 kernel
+    + the plain-load replay of that order, true ties included; the reference-literal loop's bytes."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(17, nb, 1, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's sdot order is not one the replay knows on this box")
+    x = np.random.default_rng(dim).standard_normal((n, dim)).astype(np.float32)
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
+    special = np.arange(0, n, 25)
+    for i in special:                                      # true ties against three hyperplanes each
+        pl = stack[[(i + t) % nb for t in (0, 7, 11)]]
+        v = x[i].astype(np.float64)
+        x[i] = (v - (v @ np.linalg.pinv(pl)) @ pl).astype(np.float32)
+    got = h.hash_device(torch.from_numpy(x).cuda())
+    st = dict(h.last_stats)
+    assert st["route"] == "f32+replay" and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] > special.size, st
+    want = hash_batch_literal_packed(h.projections, x)
+    assert np.array_equal(got.cpu().numpy(), want), int((got.cpu().numpy() != want).any(axis=(1, 2)).sum())
+    assert torch.equal(_hasher(17, nb, 1, dim, tie_replay="off").hash_device(torch.from_numpy(x).cuda()), got)
+    assert np.array_equal(h.hash_batch_packed(x[:60]), want[:60])
+    assert h.hash_vector(x[special[2]]).as_tuple() == tuple(bytes(k) for k in want[special[2]])
+    big = np.concatenate([x] * 4)                          # a host batch large enough for the streamed path: same route
+    assert np.array_equal(h.hash_batch_packed(big)[-n:], want)
+
+
 @pytest.mark.parametrize("nb,r,dim", [(16, 16, 768), (20, 10, 300), (16, 4, 128), (8, 7, 99)])
 def test_rows_at_any_four_byte_address_keep_the_device_replay(torch_mod, nb, r, dim):
     """A float32 view that starts 4, 8 or 12 bytes past a 16-byte boundary (a slice of a larger buffer, a column range of a

@@ -32,7 +32,9 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # round 4: short vectors on the resident-image kernel (every instantiation family: 2 / 4 / 8 k-tiles, 4 .. 16 column tiles)
           (16, 4, 128), (8, 16, 128), (16, 8, 64), (16, 8, 256), (5, 12, 200), (128, 2, 128), (24, 8, 96), (16, 16, 128), (2, 2, 12),
           # round 4: vector lengths that are not a multiple of four (the host library's scalar tail: blas model 1 / 2)
-          (16, 16, 102), (5, 8, 30), (20, 10, 301), (4, 13, 1001), (8, 7, 99), (2, 16, 4099), (16, 16, 767), (3, 2, 9), (16, 4, 129))
+          (16, 16, 102), (5, 8, 30), (20, 10, 301), (4, 13, 1001), (8, 7, 99), (2, 16, 4099), (16, 16, 767), (3, 2, 9), (16, 4, 129),
+          # round 4: one row per band (the host's sdot)
+          (64, 1, 64), (16, 1, 128), (32, 1, 768))
 
 
 def main():
