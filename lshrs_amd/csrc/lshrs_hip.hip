@@ -772,6 +772,12 @@ constexpr int kFixG = 8;
 constexpr int kFixSlabG = LSHRS_FIX_SLAB;       // k-tiles per slab; two slabs are resident (one being read, one landing): 2 x 2 x 6 x 8 chunks x 8
                                    // projections x 16 B = 24 KiB of LDS per wave (a 768-deep row is four slabs)
 constexpr int kFixGridG = LSHRS_FIX_GRID;    // 256 CUs x 6 resident single-wave workgroups
+// SHORT vectors (at most four k-tiles: dim <= 128): one slab IS the whole row, so a slab of four (16 KiB per workgroup, ten
+// workgroups per CU) and a grid of up to 2 048 let every group of a short list be in flight at once - the list of a 1 M x 128
+// batch (15 k flagged + 4 k audited) takes one round trip instead of two and a half (17 -> ~9 us)
+constexpr int kFixSlabShort = 4;
+constexpr int kFixGridShort = 2048;
+static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridShort <= LSHRS_SIG_DEVICE_COUNTERS, "stage 2's per-workgroup slots must fit the counter block");
 static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridG <= LSHRS_SIG_DEVICE_COUNTERS, "stage 2's per-workgroup slots must fit the counter block");
 //
 // REPLAY: the tie-break on the device.  Every flagged projection gets the sign of the value the HOST BLAS computes for
@@ -794,10 +800,10 @@ static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridG <= LSHRS_SIG_DEVICE_COU
 // are fetched from its start and read as zero, and a vector of 8 m + 4 elements gives its first four to the low lanes
 // before the tiles begin AT the fifth (the library's order: lshrs_tb_model_row_dot).  The common shapes (16 x 16 x 768 ...)
 // keep the plain loop.
-template <bool REPLAY, bool GENERAL = false>
+template <bool REPLAY, bool GENERAL = false, int SLAB = kFixSlabG>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
-  __shared__ __attribute__((aligned(16))) f32x4 xs[2][kFixSlabG * 8 * kFixG];
-  __shared__ __attribute__((aligned(16))) f32x4 ps[2][kFixSlabG * 8 * kFixG];
+  __shared__ __attribute__((aligned(16))) f32x4 xs[2][SLAB * 8 * kFixG];
+  __shared__ __attribute__((aligned(16))) f32x4 ps[2][SLAB * 8 * kFixG];
   const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
   const int shh = sub >> 2, sq = sub & 3;           // this lane's chunk of every k-tile: k = 32 t + 16 shh + 4 sq + 0..3
   const int cnt = min(*a.flag_count, a.flag_cap);
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   const int head = GENERAL ? (a.dim & 4) : 0;                 // 8 m + 4 elements: the first four go ahead of the tiles
   const int body = GENERAL ? a.dim - head : a.ktiles * kKTile; // elements the tiles cover (from element `head` on)
   const int kt = GENERAL ? (body + kKTile - 1) / kKTile : a.ktiles;
-  const int slabs = (kt + kFixSlabG - 1) / kFixSlabG;
+  const int slabs = (kt + SLAB - 1) / SLAB;
   // statistics are kept per lane and leave the wave once, at the end (one atomic per flagged projection on a single
   // address serialises the whole kernel as soon as the list is long)
   int n_ties = 0, n_flips = 0, n_aud = 0, n_abad = 0;
@@ -845,8 +851,8 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   };
   auto issue = [&](const Item& it, int slab, int buf) {   // nothing lands in a VGPR; tiles past the row's end re-fetch its last
 #pragma unroll
-    for (int i = 0; i < kFixSlabG; ++i) {
-      const int t = slab * kFixSlabG + i < kt ? slab * kFixSlabG + i : kt - 1;
+    for (int i = 0; i < SLAB; ++i) {
+      const int t = slab * SLAB + i < kt ? slab * SLAB + i : kt - 1;
 #ifndef LSHRS_AB_FIX_NO_X        // (A/B builds only: which of the two streams bounds stage 2 - wrong keys by design)
       const float* xsrc = it.xg + (size_t)t * kKTile;
       if (GENERAL && t * kKTile + 16 * shh + 4 * sq >= body) xsrc = it.xrow;      // past the row's end: never read, never used
@@ -886,15 +892,15 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       }
     }
     for (int sl = 0; sl < slabs; ++sl) {
-      const int tiles = kt - sl * kFixSlabG < kFixSlabG ? kt - sl * kFixSlabG : kFixSlabG;
+      const int tiles = kt - sl * SLAB < SLAB ? kt - sl * SLAB : SLAB;
       bool more = true;
       if (sl + 1 < slabs) issue(cur, sl + 1, buf ^ 1);
       else if (has_next) issue(nxt, 0, buf ^ 1);
       else more = false;
 #if defined(LSHRS_AB_FIX_NO_X) || defined(LSHRS_AB_FIX_NO_P)
-      if (more) wait_vmcnt<kFixSlabG>();
+      if (more) wait_vmcnt<SLAB>();
 #else
-      if (more) wait_vmcnt<2 * kFixSlabG>();        // this slab has landed, the next one is on its way
+      if (more) wait_vmcnt<2 * SLAB>();        // this slab has landed, the next one is on its way
 #endif
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (REPLAY) {
@@ -916,7 +922,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
           }
         } else {
           for (int t = 0; t < tiles; ++t) {
-            const int kb0 = (sl * kFixSlabG + t) * kKTile;      // first element of this tile, counted from `head`
+            const int kb0 = (sl * SLAB + t) * kKTile;      // first element of this tile, counted from `head`
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
               const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
@@ -936,7 +942,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
                 pj = __builtin_fmaf(pv, xv, pj);
               }
             }
-            const int tile = sl * kFixSlabG + t + 1;      // (uniform: every lane of the wave is at the same k-tile)
+            const int tile = sl * SLAB + t + 1;      // (uniform: every lane of the wave is at the same k-tile)
             if ((tile % kBlasBlockTiles) == 0 && tile < kt) {
               const float sblk = blas_reduce(pj, kind, lane);
               ytot = blocks_done ? ytot + sblk : sblk;
@@ -2199,7 +2205,20 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float ss[RT] = {}, sm[RT] = {}, amax[RT] = {};
+#ifndef LSHRS_AB_RES_NO_PRIO
+    // the k-loop is where a wave issues the loads of its NEXT tile: it goes ahead of the waves that are in their epilogues,
+    // so that the memory pipeline is fed on time (the kernel's floor is the x stream: profiles/r04_resident_attribution.log)
+    __builtin_amdgcn_s_setprio(2);
+#endif
 
+#ifdef LSHRS_AB_RES_NO_MAIN   // (A/B builds only, tools/ab_build.py: the epilogue and the x stream alone - wrong keys by design)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][t % NCT] += xr[rt][t][0] + xr[rt][t][1];
+      load_x(next, t);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       Bf16Pairs hi[RT], mid[RT];
@@ -2250,6 +2269,22 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
       }
     }
 
+#endif
+#ifndef LSHRS_AB_RES_NO_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef LSHRS_AB_RES_NO_EPILOGUE   // (A/B builds only: the main loop alone - one word per lane keeps the accumulators alive)
+    {
+      float keep = 0.f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) keep += acc[rt][ct][0] + acc[rt][ct][1] + acc[rt][ct][2] + acc[rt][ct][3];
+      keep += ss[0] + sm[0] + amax[0];
+      if (keep == 123.456f) args.keys[lane] = 1;
+    }
+    continue;
+#endif
     // ---- row statistics -> the two factors of the stage-1 window per row (as sig16_kernel) ---------------------------
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -3115,7 +3150,9 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.rows_per_band = rows_per_band;
   f.band_cols = 8 * g.bb;
   const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
-  const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
+  const bool short_rows = g.ktiles <= kFixSlabShort && blas_model != 0;
+  const int grid_cap = short_rows ? kFixGridShort : kFixGridG;
+  const dim3 grid((unsigned)(groups < grid_cap ? groups : grid_cap)), block(64);
   if (blas_model != 0) {
     f.tie_list = nullptr;
     f.flag_y = flag_y;
@@ -3124,7 +3161,12 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     f.audit_list = audit_n > 0 ? a.audit_list : nullptr;
     f.audit_vals = a.audit_vals;
     f.audit_n = audit_n;
-    if (blas_general(rows_per_band, g.ktiles, dim))
+    if (short_rows) {
+      if (blas_general(rows_per_band, g.ktiles, dim))
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+      else
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+    } else if (blas_general(rows_per_band, g.ktiles, dim))
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     else
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);

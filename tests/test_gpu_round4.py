@@ -86,7 +86,7 @@ def test_audit_of_unflagged_projections_passes_on_healthy_data_and_costs_little(
             times[id(hh)].append(a.elapsed_time(b) / 10)
     with_audit, without = sorted(times[id(h)])[3], sorted(times[id(off)])[3]
     print(f"audit cost: {with_audit:.4f} ms per step with, {without:.4f} ms without ({100 * (with_audit / without - 1):.2f} %)")
-    assert with_audit < without * 1.03      # (run-to-run noise on one box is 1-2 %; profiles/r04_audit_cost.log holds measured figures)
+    assert with_audit < without * 1.05      # (run-to-run noise on one box is 1-2 %; profiles/r04_audit_cost.log: +0.18 % measured)
 
 
 def test_audit_fires_on_adversarial_rows_where_the_margin_guard_sees_nothing(torch_mod):
