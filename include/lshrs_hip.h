@@ -187,7 +187,8 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx,
  * 4x2 / 4x1 kernels; the vector in blocks of 4096 elements - lshrs_tb_model_row_dot in lshrs_host.h states it).  The keys
  * are final when the stream has run: no tie list, no host step.  Only for callers that have checked the model against
  * their BLAS (lshrs_tb_model_row_dot vs `P_band @ x`, bit for bit; lshrs_amd/_hostblas.py does) and for inputs the split
- * pass takes itself (dim % 4 == 0, dim >= 32 - with 8 m + 4 elements: up to 4096 -, 16-byte aligned rows; else
+ * pass takes itself (dim % 4 == 0, dim >= 32 - from 8 for short-vector hashers: at most 256 key columns (bands x rows), dim <=
+ * 256, whose stage 1 runs with the whole fragment image resident in LDS -; with 8 m + 4 elements: up to 4096; 16-byte aligned rows; else
  * LSHRS_E_BADARG; of a row that is not whole 32-element k-tiles only its `dim` elements are ever used, and nothing past the
  * end of X is fetched).
  *   counters     DEVICE int32[LSHRS_SIG_DEVICE_COUNTERS] (see above), zero on entry.
@@ -212,9 +213,12 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
  * (blas_model, see lshrs_sig_hash_batch_split_replay_f32) for the sign.  counters: the int32[LSHRS_SIG_DEVICE_COUNTERS] block
  * whose element [0] was the f32 kernel's tie_count; [1] receives the items expanded.  host_counts (optional, pinned
  * host int32[LSHRS_SIG_COUNTERS]) receives the block, which is left zeroed; [0] > tie_cap or [1] > flag_cap: repeat
- * the pass with room.  Needs dim % 4 == 0, dim >= 8 (8 m + 4 elements: up to 4096) and 16-byte aligned rows (else
- * LSHRS_E_TOOLARGE: resolve on the host); only `dim` elements of a row are ever fetched; keys in
- * device memory, rows of any width (bits are patched with 32-bit atomics on the aligned word around the byte). */
+ * the pass with room.  Inputs of whole groups of four elements (dim % 4 == 0, dim >= 8) in 16-byte aligned rows take the
+ * LDS-DMA form of the replay; anything else - dim % 4 elements of scalar tail from 9 elements up (blas_model 1 / 2: how
+ * the host's build of the library compiles that tail), rows at any 4-byte address, bands of ONE row (the host then calls
+ * sdot: whole 64-element steps for blas_model 1, whole 32s for 2) - its plain-load form; 8 m + 4 body elements only up to 4096;
+ * else LSHRS_E_TOOLARGE: resolve on the host.  Only `dim` elements of a row are ever fetched; keys in device memory, rows of
+ * any width (bits are patched with 32-bit atomics on the aligned word around the byte). */
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
                                        const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,
                                        uint8_t* keys, const int64_t* tie_list, int32_t tie_cap, int32_t* counters,

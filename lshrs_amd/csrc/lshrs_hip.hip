@@ -1,6 +1,11 @@
 // lshrs_hip.hip — gfx950 (MI355X / CDNA4) kernels + C ABI for the lshrs hot path.
 //
-//   K1  sig_kernel        random-projection signature pass (exact-f32 MFMA, ballot bit-pack)
+//   K1  sig16_kernel      stage 1 of the split-precision signature pass (bf16 x 3 on v_mfma_f32_16x16x32_bf16, proven window)
+//       sig16r_kernel     ... for short vectors: fragment image resident in LDS, rows straight into registers
+//       sig_fix8_kernel   stage 2: the host BLAS's summation order replayed for every flagged (and audited) projection
+//       sig_fixany_kernel ... with plain loads: any vector length, any 4-byte row address, one-row bands
+//       sig_small_kernel  a query vector or a handful: every projection the replayed value, one round trip
+//       sig_kernel        the exact-f32 pass (v_mfma_f32_32x32x2_f32, ballot bit-pack)
 //   K2  cosine_kernel     gather + dot + norm cosine of candidates against a query
 //   K3  topk_kernel       per-query descending order (LDS bitonic network)
 //   + small helpers (hyperplane re-layout, row gather, key patch scatter)

@@ -549,9 +549,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
 
     def _replay_launch(self, x, out, row_flags, ws, tau, model, want_event: bool = False):
         """Enqueue one split pass with the tie replay on the current stream; returns what `_replay_finish` needs.
-        The counters of the launch come back through one of four pinned blocks (launches are handed out in turn:
-        at most three may be unfinished, `hash_device_async` sees to that).  Scratch is per (device, stream): launches
-        enqueued on different streams never share a list or a counter block."""
+        The counters of the launch come back through one of four pinned blocks, taken from a free list and returned by
+        `_replay_finish` (streamed launches keep at most three; a synchronous caller that takes the last one keeps the lock
+        until it is back).  Scratch is per (device, stream): launches enqueued on different streams never share a list or a
+        counter block; launches on one stream are ordered by the stream."""
         torch = _native.require_gpu()
         lib = _native.load()
         dev = x.device
