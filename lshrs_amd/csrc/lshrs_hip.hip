@@ -158,6 +158,15 @@ inline SigResident sig_resident(int num_bands, int rows, int dim) {
   r.on = r.nct * r.kt <= 64;                        // (the image - nct x kt x 2 KiB - and a wave's rows in flight must fit)
   return r;
 }
+// The compact column that sits at fragment position (column tile ct, row m of the tile) of the resident image.  sig16r_kernel
+// computes P X^T: lane (r16, g) ends with columns m = 4 g + e of every column tile for ONE row and shifts their signs into a
+// word value by value (ct ascending, e ascending: the first lands highest) - so that word IS 32 (a last group of four column
+// tiles: 16) consecutive bits of the row's sign string: group k of eight column tiles = columns 128 k + bits g .. of the string.
+__host__ __device__ inline int res_colmap(int nct, int ct, int m) {
+  const int g = m >> 2, e = m & 3, k = ct >> 3;
+  const int bits = 4 * (nct - 8 * k < 8 ? nct - 8 * k : 8);
+  return 128 * k + bits * g + (bits - 1) - (4 * (ct & 7) + e);
+}
 inline int64_t sig_resident_floats(const SigResident& r) {
   return r.on ? (int64_t)r.kt * 8192 + 3 * 256 + 3 * 4 + 256 * 3 : 0;
 }
@@ -294,13 +303,18 @@ __global__ void window_scatter_kernel(const float* __restrict__ ca, const float*
 
 // Tables of the compact column blocks (sig_compact): per compact column its padded column id (-1: the zero tail of a
 // block), per key byte of a block the bit of the block's 256-bit sign string it starts at and the mask of its live bits.
+// (res_nct > 0: the resident image's order - position i holds compact column res_colmap(res_nct, i / 16, i % 16).)
 __global__ void compact_tables_kernel(int num_bands, int rows, int bb, int bpb, int ncb, int* __restrict__ padcol,
-                                      int* __restrict__ bytetab) {
+                                      int* __restrict__ bytetab, int res_nct = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ncb * 256) return;
-  const int blk = i >> 8, cc = i & 255;
-  const int band = blk * bpb + cc / rows, bit = cc % rows;
-  padcol[i] = (cc < bpb * rows && band < num_bands) ? band * bb * 8 + bit : -1;
+  const int blk = i >> 8;
+  int cc = i & 255;
+  {
+    const int pc = res_nct > 0 ? ((cc >> 4) < res_nct ? res_colmap(res_nct, cc >> 4, cc & 15) : 256) : cc;
+    const int band = blk * bpb + pc / rows, bit = pc % rows;
+    padcol[i] = (pc < bpb * rows && band < num_bands) ? band * bb * 8 + bit : -1;
+  }
   const int bl = cc / bb, q = cc % bb;                        // key byte cc of the block: byte q of its band bl
   const bool live = bl < bpb && blk * bpb + bl < num_bands && 8 * q < rows;
   const int nbits = live ? (rows - 8 * q < 8 ? rows - 8 * q : 8) : 0;
@@ -1511,7 +1525,7 @@ __global__ void scatter_keys_kernel(uint8_t* __restrict__ keys, int num_bands, i
 //   accumulator tile: column = lane & 15, row = 4 (lane >> 4) + register.
 // ------------------------------------------------------------------------------------------
 __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_bands, int rows, int dim, int bb,
-                                           int ktiles, int64_t chunks, u16x8* __restrict__ image, int bpb = 0) {
+                                           int ktiles, int64_t chunks, u16x8* __restrict__ image, int bpb = 0, int res_nct = 0) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= chunks) return;
   const int lane = (int)(c & 63);
@@ -1524,7 +1538,8 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
   int band = col / (bb * 8);
   int bit = col % (bb * 8);
   if (bpb > 0) {                                     // compact column blocks: bpb whole bands per block, no padding inside
-    const int cc = col & 255;
+    int cc = col & 255;
+    if (res_nct > 0) cc = ct < res_nct ? res_colmap(res_nct, ct, lane & 15) : 256;     // the resident image's column order
     band = cc < bpb * rows ? cb * bpb + cc / rows : num_bands;
     bit = cc % rows;
   }
@@ -1553,6 +1568,9 @@ __global__ void pack_image_bf16_t16_kernel(const float* __restrict__ P, int num_
 // ids apart: workgroups are dealt round-robin over the 8 XCDs, so the `cb` passes over the same 256 rows run on the
 // SAME XCD at about the same time and the second one reads x from that XCD's L2 instead of HBM (config 5: 512 key
 // columns = two column blocks).
+#ifndef LSHRS_X_AUX
+#define LSHRS_X_AUX 0              // cache policy of stage 1's x loads (A/B builds: 2 = nt)
+#endif
 constexpr int kS1ListCap = 8192;   // flagged projections a workgroup stages in LDS before its ONE global append
 // COMPACT: the column blocks hold the bands' key columns side by side (sig_compact) - list entries and keys leave through
 // the tables; a template parameter so that the padded layout's kernel is instruction for instruction what it was.
@@ -1671,7 +1689,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
                                          16, 0, 0);
       else
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[kXPS + d - kPP] : xfo[d - kPP])),
-                                         (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, 0);
+                                         (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, LSHRS_X_AUX);
     } else if (d < kPP) {
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + W * d * kFragFloats),
                                        16, 0, 0);
@@ -1682,7 +1700,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
       const int lim = f.xg == xblk + (size_t)(ktiles - 1) * (kKTile * 4) ? last_valid_chunks : 8;
       const unsigned chunk = (unsigned)((lane & 7) ^ (lane >> 3) ^ ((f.j0 + d - kPP) & 1));
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (off - ((int)chunk >= lim ? 16u * chunk : 0u))),
-                                       (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, 0);
+                                       (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, LSHRS_X_AUX);
     }
   };
   f32x4 xr[RT][2];                           // raw f32 x of one k-tile: [row tile][chunk]
@@ -2131,7 +2149,7 @@ constexpr int res_lds_floats() { return KT * NCT * 512 + 512 + 256 + 512 + res_w
 
 template <int NCT, int KT>
 __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(const SigArgs args) {
-  constexpr int RT = res_rt(NCT, KT), NW = NCT / 2, kRows = 16 * RT, kResWaves = res_waves(NCT, KT);
+  constexpr int RT = res_rt(NCT, KT), NW = NCT / 2, kRows = 16 * RT, kResWaves = res_waves(NCT, KT), kResGroups = (NCT + 7) / 8;
   constexpr int kImgFloats = KT * NCT * 512;
   constexpr int kResWaveFloats = res_wave_floats(RT);
   __shared__ __attribute__((aligned(16))) float lds[res_lds_floats<NCT, KT>()];
@@ -2145,8 +2163,6 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
   int* padcol_lds = reinterpret_cast<int*>(lds + kImgFloats + 512);
   int* tab_lds = reinterpret_cast<int*>(lds + kImgFloats + 768);       // byte table: (source bit, mask) per key byte
   float* mine = lds + kImgFloats + 1280 + wave * kResWaveFloats;       // this wave's patch
-  float* wnd_lds = mine;
-  float* wnb_lds = mine + kRows;
   uint32_t* cw_lds = reinterpret_cast<uint32_t*>(mine + 2 * kRows);    // [rows of the tile][8 words + one that is only ever read]
   int64_t* l_list = reinterpret_cast<int64_t*>(mine + 11 * kRows);
   float* l_y = mine + 11 * kRows + 2 * kResListCap;
@@ -2269,7 +2285,7 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
             for (int rt = 0; rt < RT; ++rt) {
               const bf16x8 av = __builtin_bit_cast(bf16x8, term == 2 ? mid[rt] : hi[rt]);
               const bf16x8 bv = __builtin_bit_cast(bf16x8, term == 1 ? pm[j] : ph[j]);
-              acc[rt][2 * cp + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rt][2 * cp + j], 0, 0, 0);
+              acc[rt][2 * cp + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, acc[rt][2 * cp + j], 0, 0, 0);   // D = P X^T: (column, row)
             }
       }
     }
@@ -2290,7 +2306,11 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
     }
     continue;
 #endif
-    // ---- row statistics -> the two factors of the stage-1 window per row (as sig16_kernel) ---------------------------
+    // ---- row statistics -> the two factors of the stage-1 window (as sig16_kernel).  The accumulators are TRANSPOSED
+    // (D = P X^T: lane (r16, g) holds columns 4 g .. + 3 of every column tile for row r16), so a lane needs the factors of
+    // ONE row - its own - and has them in registers after the reduction: no trip through LDS.
+    float wnd[RT], wnb[RT], tsmax[RT];
+    bool zrow[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       float s2 = ss[rt] + __shfl_xor(ss[rt], 16);
@@ -2300,24 +2320,24 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
       float am = __builtin_fmaxf(amax[rt], __shfl_xor(amax[rt], 16));
       am = __builtin_fmaxf(am, __shfl_xor(am, 32));
       const int64_t myrow = row0 + 16 * rt + r16;
-      if (g == 0) {
-        // (v_sqrt_f32 as it is - 1 ulp - instead of the library's corrected root: the 0.1 % below covers far more)
-        float window = __builtin_amdgcn_sqrtf(s2) * args.tau * 1.001f;
-        if (am != 0.f && !(am >= 0x1p-32f && am <= 0x1p32f)) window = __builtin_inff();
-        wnd_lds[16 * rt + r16] = window;
-        const float wb_ = __builtin_amdgcn_sqrtf(m2) * args.tau_b * 1.001f;
-        wnb_lds[16 * rt + r16] = wb_ < __builtin_inff() ? wb_ : 0.f;
-        if (args.row_flags != nullptr && myrow < args.n) {
-          const bool has_nan = s2 != s2;
-          const bool zero = (am <= 1e-8f) && !has_nan;
-          args.row_flags[myrow] = (uint8_t)((zero ? 1 : 0) | (has_nan ? 2 : 0));
-        }
+      // (v_sqrt_f32 as it is - 1 ulp - instead of the library's corrected root: the 0.1 % below covers far more)
+      float window = __builtin_amdgcn_sqrtf(s2) * args.tau * 1.001f;
+      if (am != 0.f && !(am >= 0x1p-32f && am <= 0x1p32f)) window = __builtin_inff();
+      float wb_ = __builtin_amdgcn_sqrtf(m2) * args.tau_b * 1.001f;
+      wb_ = wb_ < __builtin_inff() ? wb_ : 0.f;
+      if (g == 0 && args.row_flags != nullptr && myrow < args.n) {
+        const bool has_nan = s2 != s2;
+        const bool zero = (am <= 1e-8f) && !has_nan;
+        args.row_flags[myrow] = (uint8_t)((zero ? 1 : 0) | (has_nan ? 2 : 0));
       }
+      wnd[rt] = window;
+      wnb[rt] = wb_;
+      float ts = window < __builtin_inff() ? window * amax_cb + wb_ * bmax_cb : __builtin_inff();
+      tsmax[rt] = ts > 0.f ? ts : -1.f;                  // a zero row: nothing to re-evaluate
+      zrow[rt] = am == 0.f;                              // every projection of the row is +0: all bits 0 (a NaN row is flagged wholesale)
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 
-    // the audit sample of this tile (SigArgs::audit_list): one of its 32 x 16 NCT projections
+    // the audit sample of this tile (SigArgs::audit_list): one of its 16 RT x 16 NCT projections
     int au_slot = -1, au_rw = -1, au_lane = 0, au_q = 0;
     if (args.audit_list != nullptr && (int)(tile % args.audit_div) == args.audit_phase) {
       const unsigned h = audit_hash((unsigned)tile, args.audit_seed);
@@ -2327,47 +2347,50 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
       au_lane = (int)((h >> 7) & 63u);
     }
 
-    // ---- sign bits, window test, list (the epilogue of sig16_kernel, one wave wide) ----------------------------------
+    // ---- sign bits, window test, list ------------------------------------------------------------------------------
+    // A lane's 4 NCT values of a row are 4 NCT consecutive bits of the row's sign string (res_colmap: the image is packed in
+    // that order): ONE v_alignbit per value shifts the accumulator's sign into the lane's word - the string holds y < 0, the
+    // key wants y > 0: the word is inverted on its way out (exact zeros are flagged, or the whole row is zero).
     {
-      uint32_t A[2] = {0u, 0u}, B[2] = {0u, 0u};
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const f32x4 wnd = *reinterpret_cast<const f32x4*>(wnd_lds + 16 * rt + 4 * g);   // rows 16 rt + 4 g + 0..3
-        const f32x4 wnb = *reinterpret_cast<const f32x4*>(wnb_lds + 16 * rt + 4 * g);
-        float tsmax = __builtin_fmaxf(__builtin_fmaxf(wnd[0], wnd[1]), __builtin_fmaxf(wnd[2], wnd[3]));
-        if (!(wnd[0] < __builtin_inff()) || !(wnd[1] < __builtin_inff()) || !(wnd[2] < __builtin_inff()) ||
-            !(wnd[3] < __builtin_inff()))
-          tsmax = __builtin_inff();
-        tsmax = tsmax * amax_cb + __builtin_fmaxf(__builtin_fmaxf(wnb[0], wnb[1]), __builtin_fmaxf(wnb[2], wnb[3])) * bmax_cb;
-        tsmax = tsmax > 0.f ? tsmax : -1.f;               // all four rows zero: nothing to re-evaluate
+        uint32_t word[kResGroups] = {};
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           float m = __builtin_inff();
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const float y0 = acc[rt][2 * w][reg], y1 = acc[rt][2 * w + 1][reg];
-            const int p0 = 8 * rt + reg * 2;              // pair (rt, reg, g'pair = 0); g'pair = 1 is p0 + 1
-            deposit_positive(A[w & 1], y0, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
-            deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
+          for (int reg = 0; reg < 4; reg += 2) {
+            const float y0 = acc[rt][2 * w][reg], y1 = acc[rt][2 * w][reg + 1];
+            word[w >> 2] = __builtin_amdgcn_alignbit(word[w >> 2], __float_as_uint(y0), 31u);
+            word[w >> 2] = __builtin_amdgcn_alignbit(word[w >> 2], __float_as_uint(y1), 31u);
             asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));        // (NaN dropped)
           }
+#pragma unroll
+          for (int reg = 0; reg < 4; reg += 2) {
+            const float y0 = acc[rt][2 * w + 1][reg], y1 = acc[rt][2 * w + 1][reg + 1];
+            word[w >> 2] = __builtin_amdgcn_alignbit(word[w >> 2], __float_as_uint(y0), 31u);
+            word[w >> 2] = __builtin_amdgcn_alignbit(word[w >> 2], __float_as_uint(y1), 31u);
+            asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));
+          }
           const bool aud = au_rw == 8 * rt + w;
-          if (__builtin_amdgcn_ballot_w64(!(m > tsmax)) != 0 || aud) {   // wave-uniform: the exact per-element test
+          if (__builtin_amdgcn_ballot_w64(!(m > tsmax[rt])) != 0 || aud) {   // wave-uniform: the exact per-element test
             unsigned hits = 0u;
             float ys[8], thrs[8];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
               const int ct = 2 * w + half;
-              const float pa = coef_lds[16 * ct + r16], pb = coef_lds[256 + 16 * ct + r16];
+              const f32x4 pa = *reinterpret_cast<const f32x4*>(coef_lds + 16 * ct + 4 * g);
+              const f32x4 pb = *reinterpret_cast<const f32x4*>(coef_lds + 256 + 16 * ct + 4 * g);
 #pragma unroll
               for (int reg = 0; reg < 4; ++reg) {
-                float thr = wnd[reg] * pa + wnb[reg] * pb;
+                float thr = wnd[rt] * pa[reg] + wnb[rt] * pb[reg];
                 thr = thr > 0.f ? thr : -1.f;                             // zero row / zero-padded column: y is exactly 0
                 ys[4 * half + reg] = acc[rt][ct][reg];
                 thrs[4 * half + reg] = thr;
                 hits |= (!(__builtin_fabsf(ys[4 * half + reg]) > thr) ? 1u : 0u) << (4 * half + reg);
               }
             }
+            const int64_t grow = row0 + 16 * rt + r16;
             if (aud && lane == au_lane) {
               float yq = ys[0], tq = thrs[0];
 #pragma unroll
@@ -2375,8 +2398,7 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
                 yq = au_q == q ? ys[q] : yq;
                 tq = au_q == q ? thrs[q] : tq;
               }
-              const int64_t grow = row0 + 16 * rt + 4 * g + (au_q & 3);
-              const int colid = padcol_lds[16 * (2 * w + (au_q >> 2)) + r16];
+              const int colid = padcol_lds[16 * (2 * w + (au_q >> 2)) + 4 * g + (au_q & 3)];
               const bool keep = ((hits >> au_q) & 1u) == 0u && grow < args.n && colid >= 0 && tq < __builtin_inff();
               args.audit_list[au_slot] = keep ? ((grow << 21) | (int64_t)colid) : (int64_t)-1;
               args.audit_vals[2 * au_slot] = yq;
@@ -2386,11 +2408,10 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
                 const int reg = q & 3, ct = 2 * w + (q >> 2);
-                const int64_t grow = row0 + 16 * rt + 4 * g + reg;
-                const int colid = padcol_lds[16 * ct + r16];
+                const int colid = padcol_lds[16 * ct + 4 * g + reg];
                 if (((hits >> q) & 1u) != 0u && grow < args.n && colid >= 0) {
                   const int64_t entry = (grow << 21) | (int64_t)colid;
-                  const float ykeep = wnd[reg] < __builtin_inff() ? ys[q] : __builtin_nanf("");
+                  const float ykeep = wnd[rt] < __builtin_inff() ? ys[q] : __builtin_nanf("");
                   const int pos = atomicAdd(l_count, 1);                  // LDS atomic on the wave's own counter
                   if (pos < kResListCap) {
                     l_list[pos] = entry;
@@ -2407,18 +2428,14 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
             }
           }
         }
-      }
-      // lane L: row pair p = L / 4 -> rows lo / lo + 4 of the tile, words 2 (L % 4), + 1 of the block's sign string
-      const int pr = lane >> 2, wq = 2 * (lane & 3);
-      const int rlo = 16 * (pr >> 3) + 8 * (pr & 1) + ((pr >> 1) & 3);
-      if (wq < NW && pr < 8 * RT) {
-        const uint32_t wlo[2] = {(A[0] & 0xFFFFu) | (B[0] << 16), (A[1] & 0xFFFFu) | (B[1] << 16)};
-        const uint32_t whi[2] = {(A[0] >> 16) | (B[0] & 0xFFFF0000u), (A[1] >> 16) | (B[1] & 0xFFFF0000u)};
-        cw_lds[rlo * 9 + wq] = wlo[0];
-        cw_lds[(rlo + 4) * 9 + wq] = whi[0];
-        if (wq + 1 < NW) {
-          cw_lds[rlo * 9 + wq + 1] = wlo[1];
-          cw_lds[(rlo + 4) * 9 + wq + 1] = whi[1];
+        // the lane's bits of row 16 rt + r16: group k of eight column tiles = words 4 k + g of the row's string (32 bits a
+        // lane), a last group of four = half-words
+        const int rl = 16 * rt + r16;
+#pragma unroll
+        for (int k = 0; k < kResGroups; ++k) {
+          const uint32_t v = zrow[rt] ? 0u : ~word[k];
+          if (NCT - 8 * k >= 8) cw_lds[rl * 9 + 4 * k + g] = v;
+          else reinterpret_cast<uint16_t*>(cw_lds)[(rl * 9 + 4 * k) * 2 + g] = (uint16_t)v;
         }
       }
     }
@@ -2850,9 +2867,9 @@ int lshrs_sig_pack_projections(const float* P, int32_t num_bands, int32_t rows_p
     const SigCompactWs rw = sig_resident_ws(image, g, num_bands, rows_per_band, rs);
     const int64_t rchunks = (int64_t)rs.kt * 8192 / 4;
     hipLaunchKernelGGL(compact_tables_kernel, dim3(1), dim3(256), 0, s, num_bands, rows_per_band, g.bb, num_bands, 1, rw.padcol,
-                       rw.bytetab);
+                       rw.bytetab, rs.nct);
     hipLaunchKernelGGL(pack_image_bf16_t16_kernel, dim3((unsigned)((rchunks + 255) / 256)), dim3(256), 0, s, P, num_bands,
-                       rows_per_band, dim, g.bb, rs.kt, rchunks, reinterpret_cast<u16x8*>(rw.image), num_bands);
+                       rows_per_band, dim, g.bb, rs.kt, rchunks, reinterpret_cast<u16x8*>(rw.image), num_bands, rs.nct);
     hipLaunchKernelGGL(compact_gather_kernel, dim3(1), dim3(256), 0, s, norms, rw.padcol, 256, rw.norms);
     hipLaunchKernelGGL(pack_normmax_kernel, dim3(1), dim3(64), 0, s, rw.norms, 256, 1, rw.norm_max);
     const int64_t wf = 2 * 256 + 2 * 4;                                  // wa .. wbmax are contiguous

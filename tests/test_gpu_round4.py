@@ -179,7 +179,9 @@ def test_resident_image_kernel_gives_the_reference_keys(torch_mod, seed, nb, r, 
     h.hash_device(x, out=view)
     assert torch.equal(view, f32.hash_device(x)) and bool((buf[:3] == 0xA5).all()) and bool((buf[3 + n * nb * bb:] == 0xA5).all())
     # measured windows and the streamed host path take the same kernel
-    m = _hasher(seed, nb, r, dim, tau1_ulps=64.0, tau_ulps=8.0)
+    # (a window a short vector honours: the products the split drops do not average out over 12 elements - 1 % of such
+    # projections are further than 64 units from the host's value, and the audit of unflagged projections sees it)
+    m = _hasher(seed, nb, r, dim, tau1_ulps=64.0 if dim >= 256 else 512.0, tau_ulps=8.0)
     assert torch.equal(m.hash_device(x), view) and m.last_stats["window"] == "measured"
     big = rng.standard_normal((40_000, dim)).astype(np.float32)
     assert np.array_equal(h.hash_batch_packed(big), f32.hash_device(torch.from_numpy(big).cuda()).cpu().numpy())
