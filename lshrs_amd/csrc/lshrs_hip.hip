@@ -1224,13 +1224,15 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
 
 // Behind stage 2 of a replay pass: folds the per-workgroup statistics (nparts slots of 3 ints behind the
 // LSHRS_SIG_COUNTERS counters: ties, sign flips, max deviation) into the counters, hands the counters to the host (pinned
-// memory) and leaves the whole block zeroed for the next call: one single-wave launch instead of a copy and a fill.
+// memory) and leaves the whole block zeroed for the next call: one small launch instead of a copy and a fill.
 // Without host_counts the folded counters stay in the device block (the caller copies it).
-__global__ void export_counts_kernel(int* counters, int* host_counts, int nparts) {
-  const int lane = threadIdx.x;
+constexpr int kExportThreads = 1024;      // one part or two per thread: the fold is one memory round trip deep, not nparts / 64
+__global__ __launch_bounds__(kExportThreads) void export_counts_kernel(int* counters, int* host_counts, int nparts) {
+  __shared__ int fold[kExportThreads / 64][kFixParts];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* parts = counters + LSHRS_SIG_COUNTERS;
   int ties = 0, flips = 0, dev = 0, aud = 0, abad = 0, ratio = 0;
-  for (int i = lane; i < nparts; i += 64) {
+  for (int i = tid; i < nparts; i += kExportThreads) {
     int* q = parts + kFixParts * i;
     ties += q[0];
     flips += q[1];
@@ -1249,19 +1251,33 @@ __global__ void export_counts_kernel(int* counters, int* host_counts, int nparts
     abad += __shfl_xor(abad, off);
     ratio = max(ratio, __shfl_xor(ratio, off));
   }
-  if (lane < LSHRS_SIG_COUNTERS) {
-    int v = counters[lane];
-    if (lane == 0) v += ties;
-    if (lane == 2) v = max(v, dev);
-    if (lane == 3) v += flips;
-    if (lane == 4) v += aud;
-    if (lane == 5) v += abad;
-    if (lane == 6) v = max(v, ratio);
+  if (lane == 0) {
+    fold[wave][0] = ties; fold[wave][1] = flips; fold[wave][2] = dev;
+    fold[wave][3] = aud; fold[wave][4] = abad; fold[wave][5] = ratio;
+  }
+  __syncthreads();
+  if (tid < LSHRS_SIG_COUNTERS) {
+    ties = flips = dev = aud = abad = ratio = 0;
+    for (int w = 0; w < kExportThreads / 64; ++w) {
+      ties += fold[w][0];
+      flips += fold[w][1];
+      dev = max(dev, fold[w][2]);
+      aud += fold[w][3];
+      abad += fold[w][4];
+      ratio = max(ratio, fold[w][5]);
+    }
+    int v = counters[tid];
+    if (tid == 0) v += ties;
+    if (tid == 2) v = max(v, dev);
+    if (tid == 3) v += flips;
+    if (tid == 4) v += aud;
+    if (tid == 5) v += abad;
+    if (tid == 6) v = max(v, ratio);
     if (host_counts != nullptr) {
-      host_counts[lane] = v;
-      counters[lane] = 0;
+      host_counts[tid] = v;
+      counters[tid] = 0;
     } else {
-      counters[lane] = v;
+      counters[tid] = v;
     }
   }
 }
@@ -3192,7 +3208,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     else
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
-    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)grid.x);
   } else {
     hipExtLaunchKernelGGL((sig_fix8_kernel<false, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
   }
@@ -3282,7 +3298,7 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
     if (!fast) hipLaunchKernelGGL(sig_fixany_kernel, grid, block, 0, s, f);
     else if (blas_general(rows_per_band, g.ktiles, dim)) hipLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, f);
     else hipLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, f);
-    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(64), 0, s, counters, host_counts, (int)grid.x);
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)grid.x);
   }
   return -(int)hipGetLastError();
 }
