@@ -2155,10 +2155,13 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 // ------------------------------------------------------------------------------------------
 // waves per workgroup (one workgroup per CU): two per SIMD (<= 256 registers each), three where one row tile over <= 32
 // (column tile, k-tile) pairs fits 168 registers - the other waves are what hides a wave's LDS and memory round trips
-constexpr int res_waves(int nct, int kt) { return (nct * kt > 16 && nct * kt <= 32 && kt <= 4) ? 12 : 8; }
-constexpr int kResListCap = 64;                        // flagged projections a wave stages before it appends them
+#ifndef LSHRS_RES_RT2_MAX
+#define LSHRS_RES_RT2_MAX 16       // (A/B builds: two row tiles per wave up to this many (column tile, k-tile) pairs)
+#endif
 // row tiles per wave: two where the accumulators (8 NCT RT registers) and the rows in flight (8 KT RT) leave room, else one
-constexpr int res_rt(int nct, int kt) { return nct * kt <= 16 ? 2 : 1; }
+constexpr int res_rt(int nct, int kt) { return (nct * kt <= 16 || (nct * kt <= LSHRS_RES_RT2_MAX && kt <= 4)) ? 2 : 1; }
+constexpr int res_waves(int nct, int kt) { return (res_rt(nct, kt) == 1 && nct * kt <= 32 && kt <= 4) ? 12 : 8; }
+constexpr int kResListCap = 64;                        // flagged projections a wave stages before it appends them
 constexpr int res_wave_floats(int rt) { return 32 * rt + 144 * rt + 3 * kResListCap + 4; }   // windows a / b, sign words (9 per row), list (entry, y1), counter: a multiple of 16 B
 template <int NCT, int KT>
 constexpr int res_lds_floats() { return KT * NCT * 512 + 512 + 256 + 512 + res_waves(NCT, KT) * res_wave_floats(res_rt(NCT, KT)); }
@@ -2222,6 +2225,9 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
     for (int rt = 0; rt < RT; ++rt) {
       int64_t row = tile * kRows + 16 * rt + r16;
       row = row < args.n ? row : args.n - 1;                           // clamp: loads stay in bounds, stores are masked
+#ifdef LSHRS_AB_RES_L2ROWS        // (A/B builds only: every tile reads the batch's first rows - from L2: the kernel without the HBM stream; wrong keys by design)
+      row &= (LSHRS_AB_RES_L2ROWS - 1);
+#endif
       const float* xp = args.X + row * args.ldx;
 #pragma unroll
       for (int c = 0; c < 2; ++c) xr[rt][t][c] = *reinterpret_cast<const f32x4*>(xp + koff[t][c]);
@@ -2233,7 +2239,14 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
     for (int t = 0; t < KT; ++t) load_x(tile, t);
   }
 
+#ifdef LSHRS_AB_RES_PROBE        // (A/B builds only, tools/res_phase_probe.py: shader cycles a wave spends in its k-loops and in its epilogues)
+  unsigned long long pr_main = 0, pr_epi = 0, pr_tiles = 0;
+  const unsigned long long pr_t00 = __builtin_amdgcn_s_memtime(), pr_r00 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (; tile < tiles; tile += stride) {
+#ifdef LSHRS_AB_RES_PROBE
+    const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int64_t row0 = tile * kRows;
     const int64_t next = tile + stride < tiles ? tile + stride : tile;  // (the last tile re-fetches itself: unused, in bounds)
     f32x4 acc[RT][NCT];
@@ -2309,6 +2322,10 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
 #endif
 #ifndef LSHRS_AB_RES_NO_PRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef LSHRS_AB_RES_PROBE
+    asm volatile("" ::: "memory");
+    const unsigned long long pr_t1 = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef LSHRS_AB_RES_NO_EPILOGUE   // (A/B builds only: the main loop alone - one word per lane keeps the accumulators alive)
     {
@@ -2472,7 +2489,11 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
           const uint32_t v = __builtin_amdgcn_alignbit(hi_, lo, (uint32_t)(src & 31)) & (rec[b] >> 16);
           out |= v << (8 * b);
         }
+#ifdef LSHRS_AB_RES_NO_KEYSTORE     // (A/B builds only: what the key stores cost the waves' load waits - one word per launch keeps the work alive)
+        if (out == 0x12345678u && row0 + rl < args.n) *reinterpret_cast<uint32_t*>(args.keys + (row0 + rl) * (int64_t)nby + 4 * o4) = out;
+#else
         if (row0 + rl < args.n) *reinterpret_cast<uint32_t*>(args.keys + (row0 + rl) * (int64_t)nby + 4 * o4) = out;
+#endif
       }
     } else {
       const int rl = lane / kLPR;
@@ -2509,7 +2530,23 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
         __builtin_amdgcn_wave_barrier();
       }
     }
+#ifdef LSHRS_AB_RES_PROBE
+    {
+      asm volatile("" ::: "memory");
+      const unsigned long long pr_t2 = __builtin_amdgcn_s_memtime();
+      pr_main += pr_t1 - pr_t0;
+      pr_epi += pr_t2 - pr_t1;
+      pr_tiles += 1;
+    }
+#endif
   }
+#ifdef LSHRS_AB_RES_PROBE
+  if (args.clock_probe != nullptr && lane == 0) {
+    unsigned long long* q = args.clock_probe + 6 * ((size_t)blockIdx.x * kResWaves + wave);
+    q[0] = pr_main; q[1] = pr_epi; q[2] = pr_tiles;
+    q[3] = __builtin_amdgcn_s_memtime() - pr_t00; q[4] = __builtin_amdgcn_s_memrealtime() - pr_r00; q[5] = 1;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import torch
 from lshrs_amd import LSHHasher
 
 n = 1_000_000
-for nb, r, dim in ((16, 4, 128), (20, 6, 128), (16, 8, 256)):
+for nb, r, dim in ((16, 4, 128), (20, 6, 128), (8, 16, 128), (16, 16, 64), (24, 8, 64), (16, 8, 256)):
     x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(dim + nb))
     h = LSHHasher(nb, r, dim, seed=42, tau1_ulps=64.0, tau_ulps=8.0, margin_guard=0.0, audit_every=0, audit_unflagged=0)
     keys = h.hash_device(x)
