@@ -2190,11 +2190,19 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
   // ---- prologue: the image (L2 -> LDS, [kt][ct < NCT][part][lane] x 16 B) and the block's tables --------------------
   {
     const f32x4* img = reinterpret_cast<const f32x4*>(args.image);     // global: [kt][16 ct][part][lane]
+#ifdef LSHRS_AB_RES_COPY_PROLOGUE
     f32x4* dst = reinterpret_cast<f32x4*>(lds);
     for (int c = tid; c < KT * NCT * 128; c += 64 * kResWaves) {
       const int l = c & 127, ct = (c >> 7) % NCT, kt = (c >> 7) / NCT;
       dst[c] = img[(kt * 16 + ct) * 128 + l];
     }
+#else
+    // LDS-DMA, every piece of the image in flight at once (a copy through registers is a chain of round trips: -5 us a launch)
+    for (int c0 = wave * 64; c0 < KT * NCT * 128; c0 += 64 * kResWaves) {          // (uniform: 64 chunks of 16 B per wave and step)
+      const int c = c0 + lane, l = c & 127, ct = (c >> 7) % NCT, kt = (c >> 7) / NCT;
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(img + (kt * 16 + ct) * 128 + l), (LDS_AS void*)(lds + 4 * c0), 16, 0, 0);
+    }
+#endif
     if (tid < 256) {
       coef_lds[tid] = args.wa[tid];
       coef_lds[256 + tid] = args.wb[tid];
@@ -2202,6 +2210,9 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
       tab_lds[tid] = args.bytetab[2 * tid] | (args.bytetab[2 * tid + 1] << 16);      // source bit | mask of the live bits
     }
     if (lane == 0) l_count[0] = 0;
+#ifndef LSHRS_AB_RES_COPY_PROLOGUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   }
   __syncthreads();
 

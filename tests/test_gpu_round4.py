@@ -213,6 +213,17 @@ def test_short_vector_throughput(torch_mod):
         print(f"{nb} x {r} x {dim}: {rate / 1e9:.2f} G vectors/s, {h.last_stats}")
         assert np.array_equal(keys[:2000].cpu().numpy(), hash_batch_literal_packed(h.projections, x[:2000].cpu().numpy()))
         assert rate > 3.0e9, rate
+        # ... and EVERY row against the exact-f32 route (another kernel, the same replay): a launch of this size is where the
+        # workgroups' tile queues and the stealing between them are at work - a tile lost or done twice shows here
+        f32 = _hasher(42, nb, r, dim, precision="f32")
+        ref = f32.hash_device(x)
+        assert f32.last_stats["route"] == "f32+replay"
+        for _ in range(3):
+            keys.fill_(0xA5)
+            h.hash_device(x, out=keys)
+            assert torch.equal(keys, ref), int((keys != ref).any(dim=2).any(dim=1).sum())
+        odd = x[: 777_777]
+        assert torch.equal(h.hash_device(odd), ref[: 777_777])
 
 
 # ----------------------------------------------------------------------------- any dim, any alignment

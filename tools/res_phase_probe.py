@@ -41,8 +41,17 @@ for nb, r, dim in ((16, 4, 128), (20, 6, 128), (8, 16, 128), (16, 8, 256)):
         st = stamps.cpu().numpy().reshape(-1, 6)
         st = st[st[:, 5] == 1].astype(np.float64)
         tiles = st[:, 2].sum()
+        if rep == 6:        # how the waves' lifetimes spread: between workgroups (CUs) and inside one
+            full = stamps.cpu().numpy().reshape(-1, 6).astype(np.float64)
+            wpw = int(round(st.shape[0] / 256))
+            life_w = (full[:256 * wpw, 4] / 100.0).reshape(256, wpw)
+            tiles_w = full[:256 * wpw, 2].reshape(256, wpw)
+            xcd = np.arange(256) % 8
+            print(f"   workgroup means: min {life_w.mean(1).min():.1f} max {life_w.mean(1).max():.1f} us; spread inside a workgroup (max - min): "
+                  f"mean {np.ptp(life_w, axis=1).mean():.1f} us; per XCD mean life: " + " ".join(f"{life_w[xcd == k].mean():.1f}" for k in range(8))
+                  + f"; tiles per wave {tiles_w.min():.0f}-{tiles_w.max():.0f}", flush=True)
         res.append((1e3 * ev[0].elapsed_time(ev[1]), st.shape[0], st[:, 0].sum() / tiles, st[:, 1].sum() / tiles,
-                    (st[:, 3] / st[:, 2]).mean(), (st[:, 3] / st[:, 4]).mean() * 0.1, (st[:, 4] / 100.0).mean()))
-    k_us, waves, main, epi, per_tile, ghz, life = np.median(np.array(res), axis=0)
-    print(f"{nb} x {r} x {dim}: kernel {k_us:.1f} us, {int(waves)} waves (life {life:.1f} us) at {ghz:.2f} GHz; per tile and wave: "
+                    (st[:, 3] / st[:, 2]).mean(), (st[:, 3] / st[:, 4]).mean() * 0.1, (st[:, 4] / 100.0).mean(), (st[:, 4] / 100.0).max(), (st[:, 4] / 100.0).min()))
+    k_us, waves, main, epi, per_tile, ghz, life, lmax, lmin = np.median(np.array(res), axis=0)
+    print(f"{nb} x {r} x {dim}: kernel {k_us:.1f} us, {int(waves)} waves (life {lmin:.1f} / {life:.1f} / {lmax:.1f} us min / mean / max) at {ghz:.2f} GHz; per tile and wave: "
           f"k-loop {main:.0f} cycles, epilogue {epi:.0f}, whole period {per_tile:.0f}", flush=True)
