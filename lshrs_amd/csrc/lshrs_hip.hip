@@ -3191,7 +3191,10 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     const int res_rows = 16 * res_rt(rs.nct, rs.kt);
     const int64_t tiles = (n + res_rows - 1) / res_rows;
     const int rwaves = res_waves(rs.nct, rs.kt);
-    const dim3 grid((unsigned)(tiles < 256 * rwaves ? (tiles + rwaves - 1) / rwaves : 256), 1, 1), block(64 * rwaves, 1, 1);
+#ifndef LSHRS_RES_GRID
+#define LSHRS_RES_GRID 256        // workgroups of a full launch: one per CU (A/B builds: more, shorter ones - the hardware hands them to the CUs that finish first)
+#endif
+    const dim3 grid((unsigned)(tiles < (int64_t)LSHRS_RES_GRID * rwaves ? (tiles + rwaves - 1) / rwaves : LSHRS_RES_GRID), 1, 1), block(64 * rwaves, 1, 1);
 #define LSHRS_RES(NCT_, KT_) hipExtLaunchKernelGGL((sig16r_kernel<NCT_, KT_>), grid, block, 0, s, o.ev[0], o.ev[1], 0, a)
     if (rs.kt == 2) {
       if (rs.nct == 4) LSHRS_RES(4, 2); else if (rs.nct == 8) LSHRS_RES(8, 2); else if (rs.nct == 12) LSHRS_RES(12, 2); else LSHRS_RES(16, 2);
