@@ -405,3 +405,29 @@ def test_host_engine_route_with_default_windows_hashes_every_chunk_once(torch_mo
     m = _hasher(42, 16, 16, 768, tie_replay="off", tau_ulps=8.0, tau1_ulps=64.0)      # measured windows: the chunked pipeline
     assert torch.equal(m.hash_device(x), got)
     assert m.last_stats["route"] in ("host-engine pipelined", "plain") and m.last_stats["relaunches"] <= 1, m.last_stats
+
+
+# ----------------------------------------------------------------------------- the host-engine route, device-resident rows
+@pytest.mark.parametrize("nb,r,dim,n", [(16, 16, 768, 60_000), (20, 6, 100, 40_000), (5, 20, 64, 40_000), (4, 32, 256, 40_000),
+                                        (3, 40, 128, 40_000), (9, 5, 30, 40_000)])
+def test_plain_route_cuts_pairs_on_the_device_and_streams_rows_through_pinned_blocks(torch_mod, nb, r, dim, n):
+    """`tie_replay="off"` (what a host with an unknown BLAS runs) on device-resident rows: the (row, band) pairs and the unique
+    rows are cut on the device - by 32-column word where a word lies inside one band, bit by bit otherwise (8, 16, 24, 40 key
+    columns per band) -, the rows cross PCIe in chunks through two pinned blocks while the engine works on the chunk before.
+    The reference-literal loop's bytes, with ties actually resolved on the host, over several chunks."""
+    torch = torch_mod
+    from lshrs_amd import _hostblas
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    if _hostblas.engine() is None:
+        pytest.skip("host tie-break engine unavailable on this box")
+    h = _hasher(11, nb, r, dim, tie_replay="off")
+    h._expected_tie_entries = lambda rows: 0.05 * rows * nb          # (the plain route, with room: not the chunked pipeline)
+    h._PLAIN_CHUNK_BYTES = 4 * dim * 1500                             # 1 500 rows per pinned block: many chunks, both blocks reused
+    rng = np.random.default_rng(nb + dim)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    x[::97] *= np.float32(1e-3)
+    got = h.hash_device(torch.from_numpy(x).cuda()).cpu().numpy()
+    st = dict(h.last_stats)
+    assert st["route"] == "plain" and st["tie_pairs"] > 0 and st.get("tie_break_engine") is None, st
+    assert np.array_equal(got, hash_batch_literal_packed(h.projections, x)), st
