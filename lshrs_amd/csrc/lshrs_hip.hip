@@ -2143,14 +2143,16 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 //   wave   = RT (two, or one where the registers ask for it: res_rt) 16-row tiles x NCT column tiles, one of eight in a
 //            persistent workgroup (one workgroup per CU, two waves per SIMD within 256 registers each: the second wave is
 //            what hides a wave's LDS round trips); tile i of the batch goes to wave i mod (8 x workgroups);
-//   x      straight from HBM to registers: lane (r, g) owns elements 32 t + 8 g .. + 7 of row r - the A operand of
-//            v_mfma_f32_16x16x32_bf16 as it comes; the registers of k-tile t are refilled with the NEXT tile's elements as
-//            soon as k-tile t has been split, so a whole tile of loads is in flight under the matrix work;
+//   x      straight from HBM to registers: lane (r, g) owns elements 32 t + 8 g .. + 7 of row r - an operand of
+//            v_mfma_f32_16x16x32_bf16 as it comes (the B operand: the accumulators are P X^T, lane (r, g) ends with columns
+//            4 g .. + 3 of every column tile for ITS row r); the registers of k-tile t are refilled with the NEXT tile's
+//            elements as soon as k-tile t has been split, so a whole tile of loads is in flight under the matrix work;
 //   order  per k-tile x_hi p_hi, x_hi p_mid, x_mid p_hi on every accumulator, k-tiles ascending: the accumulation
 //            lshrs_split_stage1_model states and the proven window (lshrs_sig_set_window) is derived for - same
 //            coefficients, same stage 2;
-//   keys   the column block is COMPACT (sig_compact's layout: the bands' rows side by side, no padding columns): the sign
-//            words of a tile go through the wave's own LDS patch and leave as key bytes through the byte table;
+//   keys   the column block is COMPACT (sig_compact's layout: the bands' rows side by side, no padding columns) and packed in
+//            the order that makes a lane's values consecutive bits of its row's sign string (res_colmap): one v_alignbit per
+//            value; the strings go through the wave's own LDS patch and leave as key bytes through the byte table;
 //   list   flagged projections are staged per wave in LDS and leave with one global atomic per 64 .. 128 entries.
 // ------------------------------------------------------------------------------------------
 // waves per workgroup (one workgroup per CU): two per SIMD (<= 256 registers each), three where one row tile over <= 32
