@@ -1075,6 +1075,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         for child in getattr(self, "_children", None) or ():
             child.close()
         self._children = None
+        self._pinned_cache = {}          # (the staging blocks of the host-fed and plain routes: pinned memory goes back with them)
         pipes, self._pipes = getattr(self, "_pipes", {}), {}
         if pipes:
             try:
