@@ -475,8 +475,11 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                 # chunks through two pinned blocks while the engine works on the chunk before
                 self._plain_resolve_device(torch, lib, dev, x, out, tie_list[:cnt], stats, stream)
             elif cnt:
-                entries = tie_list[:cnt].cpu().numpy()
-                rows, bands = self._tie_pairs(entries)
+                if cnt > 8192:                   # (long lists: the pairs are cut on the device - the same pairs in the same order)
+                    rows_d, bands_d = self._tie_pairs_device(torch, tie_list[:cnt])
+                    rows, bands = rows_d.cpu().numpy(), bands_d.to(torch.int32).cpu().numpy()
+                else:
+                    rows, bands = self._tie_pairs(tie_list[:cnt].cpu().numpy())
                 stats["tie_pairs"] = int(rows.shape[0])
                 urows, inverse = np.unique(rows, return_inverse=True)
                 if host_rows is not None:

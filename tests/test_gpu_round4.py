@@ -431,3 +431,21 @@ def test_plain_route_cuts_pairs_on_the_device_and_streams_rows_through_pinned_bl
     st = dict(h.last_stats)
     assert st["route"] == "plain" and st["tie_pairs"] > 0 and st.get("tie_break_engine") is None, st
     assert np.array_equal(got, hash_batch_literal_packed(h.projections, x)), st
+
+
+@pytest.mark.parametrize("nb,r", [(16, 16), (20, 6), (5, 20), (4, 32), (3, 40), (7, 64)])
+def test_tie_pairs_cut_on_the_device_are_the_hosts(torch_mod, nb, r):
+    """`_tie_pairs_device` (torch ops on the kernel's tie entries) against `_tie_pairs` (NumPy): the same unique (row, band)
+    pairs in the same (band, row) order, for key rows whose 32-column words lie inside one band and for those that do not."""
+    torch = torch_mod
+    h = _hasher(1, nb, r, 32)
+    rng = np.random.default_rng(nb * 100 + r)
+    words_per_row = (nb * 8 * h.band_bytes + 31) // 32 + 1            # (one word past the last band: must be dropped)
+    m = 50_000
+    entries = np.empty((m, 2), dtype=np.int64)
+    entries[:, 0] = rng.integers(0, 3_000, size=m) * 65536 + rng.integers(0, words_per_row, size=m)
+    entries[:, 1] = rng.integers(1, 2 ** 32, size=m)
+    rows, bands = h._tie_pairs(entries)
+    rows_d, bands_d = h._tie_pairs_device(torch, torch.from_numpy(entries).cuda())
+    assert np.array_equal(rows, rows_d.cpu().numpy()) and np.array_equal(bands, bands_d.cpu().numpy().astype(np.int32))
+    assert rows.shape[0] > 0 and int(bands.max()) < nb
