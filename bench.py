@@ -525,7 +525,7 @@ def main() -> None:
                 torch, x, keys, local_dev, max(3, args.steps // 4), barrier,
                 "tie_replay='off': what a host whose BLAS order the replay does not know (MKL, BLIS, another thread "
                 "slicing) runs - stage 2 evaluates the f32 chain, the ties inside the proven tie window go to the host "
-                "engine (the library's own sgemv on several cores), chunks overlapped by csrc/pipeline.hip",
+                "engine (the library's own sgemv on several cores): pairs cut on the device, tied rows through two pinned blocks under the engine's work",
                 tie_replay="off")),
             ("host_engine_mode_measured_windows", lambda: bench_variant(
                 torch, x, keys, local_dev, args.steps, barrier,
