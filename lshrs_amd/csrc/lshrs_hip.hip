@@ -2162,7 +2162,10 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 #endif
 // row tiles per wave: two where the accumulators (8 NCT RT registers) and the rows in flight (8 KT RT) leave room, else one
 constexpr int res_rt(int nct, int kt) { return (nct * kt <= 16 || (nct * kt <= LSHRS_RES_RT2_MAX && kt <= 4)) ? 2 : 1; }
-constexpr int res_waves(int nct, int kt) { return (res_rt(nct, kt) == 1 && nct * kt <= 32 && kt <= 4) ? 12 : 8; }
+#ifndef LSHRS_RES_WAVES_32
+#define LSHRS_RES_WAVES_32 12      // (A/B builds: waves per workgroup where 16 < NCT KT <= 32 - 16 = four per SIMD within 128 registers)
+#endif
+constexpr int res_waves(int nct, int kt) { return (res_rt(nct, kt) == 1 && nct * kt <= 32 && kt <= 4) ? LSHRS_RES_WAVES_32 : 8; }
 constexpr int kResListCap = 64;                        // flagged projections a wave stages before it appends them
 constexpr int res_wave_floats(int rt) { return 32 * rt + 144 * rt + 3 * kResListCap + 4; }   // windows a / b, sign words (9 per row), list (entry, y1), counter: a multiple of 16 B
 template <int NCT, int KT>
