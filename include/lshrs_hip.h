@@ -26,13 +26,23 @@
 extern "C" {
 #endif
 
-#define LSHRS_ABI_VERSION 5
+#define LSHRS_ABI_VERSION 6
 
 #define LSHRS_E_BADARG   (-10001) /* NULL pointer / non-positive size / misaligned workspace */
 #define LSHRS_E_TOOLARGE (-10002) /* shape outside what the kernels support (see each call)  */
 
 /* ABI version of the loaded library (== LSHRS_ABI_VERSION of the header it was built from). */
 int lshrs_abi_version(void);
+
+/* What this build of the library was compiled with (ABI 6).  The source carries A/B switches for measurements
+ * (-DLSHRS_AB_*: tools/ab_build.py); several of them drop work the keys need - a library built with one of those computes
+ * WRONG KEYS BY DESIGN and must never be mistaken for the product: bit LSHRS_BUILD_WRONG_KEYS says so, and
+ * lshrs_amd/_native.py refuses to load such a build unless LSHRS_ALLOW_AB=1 is set.  LSHRS_BUILD_TUNED: switches and
+ * constants that change speed only (the keys stay the reference's).  Bits 8 and up name the individual switches
+ * (csrc/lshrs_hip.hip, lshrs_build_flags).  The product build returns 0. */
+#define LSHRS_BUILD_WRONG_KEYS 0x1u
+#define LSHRS_BUILD_TUNED      0x2u
+uint32_t lshrs_build_flags(void);
 
 /* Optional per-call measurement hooks of the signature entry points (NULL = none).  Nothing here changes a result.
  *   ev_stage*   hipEvent_t handles (created by the caller, timing enabled) that ride ON the dispatch packets of the
@@ -205,6 +215,43 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
                                           int64_t* flag_list, float* flag_y, int32_t flag_cap, float tau1,
                                           int32_t blas_model, int32_t* host_counts,
                                           const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream);
+
+/* lshrs_sig_hash_batch_split_replay_f32 as a short pipeline inside ONE call (ABI 6): the batch is cut into `nchunks` row
+ * chunks; stage 1 of the chunks runs back to back on `stream`, stage 2 (and the export of the counters) of every chunk but
+ * the last on a side stream of the caller's, BESIDE the next chunk's stage 1 - what is left serial is the last chunk's
+ * stage 2.  Same keys as the one-launch form (chunks are row ranges; rows do not interact).  `stream` waits for every side
+ * stream before the call's work counts as done: synchronising `stream` is enough, as for every other call.
+ *   rows[c]        rows of chunk c, in order; their sum is n.  Whole rounds of workgroups (multiples of 65 536 rows) make a
+ *                  chunk's stage 1 end evenly; the last chunk takes the ragged end.
+ *   flag_cap[c]    list entries chunk c may use: the chunks' regions lie back to back in flag_list / flag_y (the caller
+ *                  sizes both for the sum)
+ *   side_stream[c] hipStream_t for stage 2 of chunk c < nchunks - 1 (distinct from `stream`; may repeat: stage 2 of two
+ *                  chunks on one side stream run in order)
+ *   ev_fork[c], ev_join[c]   hipEvent_t of the caller's (no timing needed), one pair per forked chunk
+ *   ev_timing      optional hipEvent_t[4 * nchunks]: per chunk what lshrs_sig_opts' four events are per call (then `opts`
+ *                  must be given; its own four are ignored)
+ *   counters       DEVICE int32[nchunks * LSHRS_SIG_DEVICE_COUNTERS], zero on entry, left zeroed (one block per chunk)
+ *   host_counts    PINNED HOST int32[nchunks * LSHRS_SIG_COUNTERS]: the counters of chunk c in block c - the caller adds /
+ *                  maxes them; [1] of block c > flag_cap[c]: that chunk is incomplete, repeat the pass with room
+ *   audit          its slots and target are shared out over the chunks by rows */
+#define LSHRS_SIG_MAX_CHUNKS 8
+typedef struct lshrs_sig_chunk_plan {
+  uint32_t struct_bytes;   /* sizeof(lshrs_sig_chunk_plan) */
+  int32_t nchunks;         /* 1 .. LSHRS_SIG_MAX_CHUNKS */
+  int64_t rows[LSHRS_SIG_MAX_CHUNKS];
+  int32_t flag_cap[LSHRS_SIG_MAX_CHUNKS];
+  void* side_stream[LSHRS_SIG_MAX_CHUNKS];
+  void* ev_fork[LSHRS_SIG_MAX_CHUNKS];
+  void* ev_join[LSHRS_SIG_MAX_CHUNKS];
+  void** ev_timing;
+} lshrs_sig_chunk_plan;
+int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int64_t ldx,
+                                                  const void* workspace, int32_t num_bands, int32_t rows_per_band,
+                                                  int32_t dim, uint8_t* keys, int32_t* counters, float tau,
+                                                  uint8_t* row_flags, int64_t* flag_list, float* flag_y, float tau1,
+                                                  int32_t blas_model, int32_t* host_counts,
+                                                  const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
+                                                  const lshrs_sig_chunk_plan* plan, void* stream);
 
 /* The tie-break on the device for the f32 kernel: behind lshrs_sig_hash_batch_f32 (same X, keys, tie_list, tie_count,
  * tau, same stream) it decides every reported tie by the host BLAS's value - the tie entries are unpacked into

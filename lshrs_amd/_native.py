@@ -21,10 +21,14 @@ SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
 # (LSHRS_HIP_LIBRARY: load another build of the same ABI instead - A/B measurements of compiler flags, tools/ab_build.py)
 LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-ABI_VERSION = 5
+ABI_VERSION = 6
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
 SIG_DEVICE_COUNTERS = SIG_COUNTERS + 3 * 4096      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
+SIG_MAX_CHUNKS = 8        # LSHRS_SIG_MAX_CHUNKS
+
+BUILD_WRONG_KEYS = 0x1   # LSHRS_BUILD_WRONG_KEYS
+BUILD_TUNED = 0x2        # LSHRS_BUILD_TUNED
 
 E_BADARG = -10001
 E_TOOLARGE = -10002
@@ -74,6 +78,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     vp, i32, i64, f32 = c.c_void_p, c.c_int32, c.c_int64, c.c_float
     lib.lshrs_abi_version.argtypes = []
     lib.lshrs_abi_version.restype = c.c_int
+    lib.lshrs_build_flags.argtypes = []
+    lib.lshrs_build_flags.restype = c.c_uint32
     lib.lshrs_sig_workspace_bytes.argtypes = [i32, i32, i32]
     lib.lshrs_sig_workspace_bytes.restype = i64
     lib.lshrs_sig_padded_columns.argtypes = [i32, i32]
@@ -95,6 +101,11 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_sig_hash_batch_split_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, i32, f32,
                                                           i32, vp, vp, vp, vp]
     lib.lshrs_sig_hash_batch_split_replay_f32.restype = c.c_int
+    # (X, n, ldx, workspace, bands, rows, dim, keys, counters, tau, row_flags, flag_list, flag_y, tau1, blas_model,
+    #  host_counts, audit, opts, plan, stream)
+    lib.lshrs_sig_hash_batch_split_replay_chunked_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp,
+                                                                  f32, i32, vp, vp, vp, vp, vp]
+    lib.lshrs_sig_hash_batch_split_replay_chunked_f32.restype = c.c_int
     # (X, n, ldx, workspace, bands, rows, dim, keys, tie_list, tie_cap, counters, tau, flag_list, flag_cap, blas_model,
     #  host_counts, stream)
     lib.lshrs_sig_resolve_ties_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, i32, i32, vp,
@@ -137,6 +148,7 @@ def _declare(lib: ctypes.CDLL) -> None:
 
 EXPORTS = (
     "lshrs_abi_version",
+    "lshrs_build_flags",
     "lshrs_sig_workspace_bytes",
     "lshrs_sig_padded_columns",
     "lshrs_sig_pack_projections",
@@ -144,6 +156,7 @@ EXPORTS = (
     "lshrs_sig_hash_batch_f32",
     "lshrs_sig_hash_batch_split_f32",
     "lshrs_sig_hash_batch_split_replay_f32",
+    "lshrs_sig_hash_batch_split_replay_chunked_f32",
     "lshrs_sig_resolve_ties_replay_f32",
     "lshrs_sig_hash_small_replay_f32",
     "lshrs_stream_synchronize",
@@ -193,6 +206,13 @@ def load() -> ctypes.CDLL:
         got = lib.lshrs_abi_version()
         if got != ABI_VERSION:
             raise NativeLibraryError(f"{LIBRARY} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+        flags = int(lib.lshrs_build_flags())
+        if flags & BUILD_WRONG_KEYS and os.environ.get("LSHRS_ALLOW_AB") != "1":
+            # an A/B build that drops work the keys need (tools/ab_build.py -DLSHRS_AB_...): indistinguishable from the
+            # product by ABI number, so it says what it is and is refused here
+            raise NativeLibraryError(
+                f"{LIBRARY} is a measurement build whose keys are wrong by design (lshrs_build_flags() = {flags:#x}); "
+                "set LSHRS_ALLOW_AB=1 to load it for an A/B run, or unset LSHRS_HIP_LIBRARY")
         _lib = lib
         return lib
 
@@ -225,6 +245,20 @@ class SigAudit(ctypes.Structure):
         super().__init__()
         self.struct_bytes = ctypes.sizeof(SigAudit)
         self.list, self.vals, self.slots, self.target, self.seed = list_ptr, vals_ptr, int(slots), int(target), int(seed) & 0xFFFFFFFF
+
+
+class SigChunkPlan(ctypes.Structure):
+    """``lshrs_sig_chunk_plan`` of include/lshrs_hip.h: row chunks of one pass, the side streams their stage 2 runs on and the
+    events that fork / join them."""
+
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("nchunks", ctypes.c_int32),
+                ("rows", ctypes.c_int64 * SIG_MAX_CHUNKS), ("flag_cap", ctypes.c_int32 * SIG_MAX_CHUNKS),
+                ("side_stream", ctypes.c_void_p * SIG_MAX_CHUNKS), ("ev_fork", ctypes.c_void_p * SIG_MAX_CHUNKS),
+                ("ev_join", ctypes.c_void_p * SIG_MAX_CHUNKS), ("ev_timing", ctypes.POINTER(ctypes.c_void_p))]
+
+    def __init__(self):
+        super().__init__()
+        self.struct_bytes = ctypes.sizeof(SigChunkPlan)
 
 
 def check(code: int, what: str) -> None:

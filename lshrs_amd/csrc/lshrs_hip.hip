@@ -2846,6 +2846,55 @@ extern "C" {
 
 int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
 
+// Which measurement switches this build was compiled with (include/lshrs_hip.h, LSHRS_BUILD_*): the product build returns 0.
+uint32_t lshrs_build_flags(void) {
+  uint32_t f = 0;
+#ifdef LSHRS_AB_FIX_SAME_P
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 8);
+#endif
+#ifdef LSHRS_AB_FIX_NO_X
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 9);
+#endif
+#ifdef LSHRS_AB_FIX_NO_P
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 10);
+#endif
+#ifdef LSHRS_AB_NO_XMID_NORM
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 11);
+#endif
+#ifdef LSHRS_AB_RES_L2ROWS
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 12);
+#endif
+#ifdef LSHRS_AB_RES_NO_MAIN
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 13);
+#endif
+#ifdef LSHRS_AB_RES_NO_EPILOGUE
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 14);
+#endif
+#ifdef LSHRS_AB_RES_NO_KEYSTORE
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 15);
+#endif
+#ifdef LSHRS_AB_NO_STATIC_PRIO
+  f |= LSHRS_BUILD_TUNED | (1u << 16);
+#endif
+#ifdef LSHRS_AB_RES_COPY_PROLOGUE
+  f |= LSHRS_BUILD_TUNED | (1u << 17);
+#endif
+#ifdef LSHRS_AB_RES_NO_PRIO
+  f |= LSHRS_BUILD_TUNED | (1u << 18);
+#endif
+#ifdef LSHRS_AB_RES_PROBE
+  f |= LSHRS_BUILD_TUNED | (1u << 19);
+#endif
+#ifdef LSHRS_T16_BUILTIN
+  f |= LSHRS_BUILD_TUNED | (1u << 20);
+#endif
+#if LSHRS_X_AUX != 0 || LSHRS_FIX_SLAB != 6 || LSHRS_FIX_GRID != 1536 || LSHRS_RES_RT2_MAX != 16 || LSHRS_RES_WAVES_32 != 12 || \
+    (defined(LSHRS_RES_GRID) && LSHRS_RES_GRID != 256)
+  f |= LSHRS_BUILD_TUNED | (1u << 21);
+#endif
+  return f;
+}
+
 static bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
   if (num_bands <= 0 || rows <= 0 || dim <= 0) return false;
   const int64_t padcols = (int64_t)num_bands * ((rows + 7) / 8) * 8;
@@ -3056,6 +3105,14 @@ int lshrs_sig_hash_batch_f32(const float* X, int64_t n, int64_t ldx, const void*
   return 0;
 }
 
+// A chunk of lshrs_sig_hash_batch_split_replay_chunked_f32 whose stage 2 runs BESIDE the next chunk's stage 1: stage 2 and the
+// export are enqueued on `side` behind `ev_fork` (recorded on the pass's own stream behind stage 1), `ev_join` is recorded
+// behind them; the caller makes its stream wait for ev_join before it returns.
+struct SplitFork {
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
+};
+
 // blas_model 0: ties are reported in tie_list (the caller resolves them on the host); > 0: stage 2 resolves them itself
 // by replaying that summation order of the host BLAS (sig_fix8_kernel<true>), tie_list is not used.
 // counters (replay only): the LSHRS_SIG_DEVICE_COUNTERS block; flag_y: the stage-1 value of every list entry (may be NULL).
@@ -3063,7 +3120,8 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
                       int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
                       int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, float* flag_y,
                       int32_t flag_cap, int32_t* flag_count, float tau1, int blas_model, int32_t* counters,
-                      int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream) {
+                      int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream,
+                      const SplitFork* fork = nullptr) {
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
       flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
@@ -3220,7 +3278,13 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
       else hipExtLaunchKernelGGL((sig16_kernel<false, false>), grid, dim3(512, 1, 1), 0, s, o.ev[0], o.ev[1], 0, a);
     }
   }
-  // stage 2: the flagged projections, one by one
+  // stage 2: the flagged projections, one by one (a forked chunk: on the side stream, behind stage 1's event)
+  if (fork != nullptr) {
+    hipError_t e = hipEventRecord(fork->ev_fork, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(fork->side, fork->ev_fork, 0);
+    if (e != hipSuccess) return -(int)e;
+    s = fork->side;
+  }
   FixArgs f{};
   f.X = X;
   f.ldx = ldx;
@@ -3268,6 +3332,10 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   } else {
     hipExtLaunchKernelGGL((sig_fix8_kernel<false, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
   }
+  if (fork != nullptr) {
+    const hipError_t e = hipEventRecord(fork->ev_join, s);
+    if (e != hipSuccess) return -(int)e;
+  }
   return -(int)hipGetLastError();
 }
 
@@ -3280,17 +3348,112 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
                     row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, nullptr, opts, stream);
 }
 
+static int lshrs_sig_hash_batch_split_replay_f32_impl(const float* X, int64_t n, int64_t ldx, const void* workspace,
+                                                      int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
+                                                      int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                                      float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
+                                                      int32_t* host_counts, const lshrs_sig_audit* audit,
+                                                      const lshrs_sig_opts* opts, void* stream, const SplitFork* fork) {
+  const bool resident = sig_resident(num_bands, rows_per_band, dim).on;
+  if (blas_model != 1 || dim % 4 != 0 || (dim < 32 && !resident) || (dim % 8 != 0 && dim > 4096) || counters == nullptr)
+    return LSHRS_E_BADARG;
+  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
+                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, audit, opts, stream, fork);
+}
+
 int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
                                           int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
                                           int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
                                           float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
                                           int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
                                           void* stream) {
-  const bool resident = sig_resident(num_bands, rows_per_band, dim).on;
-  if (blas_model != 1 || dim % 4 != 0 || (dim < 32 && !resident) || (dim % 8 != 0 && dim > 4096) || counters == nullptr)
+  return lshrs_sig_hash_batch_split_replay_f32_impl(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, counters, tau,
+                                                    row_flags, flag_list, flag_y, flag_cap, tau1, blas_model, host_counts, audit,
+                                                    opts, stream, nullptr);
+}
+
+int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
+                                                  int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
+                                                  int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                                  float* flag_y, float tau1, int32_t blas_model, int32_t* host_counts,
+                                                  const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
+                                                  const lshrs_sig_chunk_plan* plan, void* stream) {
+  if (plan == nullptr || plan->struct_bytes < sizeof(lshrs_sig_chunk_plan) || plan->nchunks < 1 ||
+      plan->nchunks > LSHRS_SIG_MAX_CHUNKS || counters == nullptr || host_counts == nullptr)
     return LSHRS_E_BADARG;
-  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
-                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, audit, opts, stream);
+  const int nc = plan->nchunks;
+  int64_t total = 0;
+  for (int c = 0; c < nc; ++c) {
+    if (plan->rows[c] <= 0 || plan->flag_cap[c] <= 0) return LSHRS_E_BADARG;
+    if (c + 1 < nc && (plan->side_stream[c] == nullptr || plan->ev_fork[c] == nullptr || plan->ev_join[c] == nullptr ||
+                       plan->side_stream[c] == stream))
+      return LSHRS_E_BADARG;
+    total += plan->rows[c];
+  }
+  if (total != n) return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  const int64_t row_bytes = (int64_t)num_bands * g.bb;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int64_t lo = 0, list_off = 0;
+  int32_t slot_off = 0;
+  const bool audit_on = audit != nullptr && audit->struct_bytes >= sizeof(lshrs_sig_audit) && audit->list != nullptr &&
+                        audit->vals != nullptr && audit->slots > 0 && audit->target > 0;
+  for (int c = 0; c < nc; ++c) {
+    const int64_t rows = plan->rows[c];
+    // the audit sample and its slots: every chunk its share by rows (the last one what is left)
+    lshrs_sig_audit au{};
+    if (audit_on) {
+      au = *audit;
+      const int32_t slots = c + 1 < nc ? (int32_t)((int64_t)audit->slots * rows / n) : audit->slots - slot_off;
+      int32_t target = (int32_t)((int64_t)audit->target * rows / n);
+      if (target < 1) target = 1;
+      au.list = audit->list + slot_off;
+      au.vals = audit->vals + 2 * (int64_t)slot_off;
+      au.slots = slots;
+      au.target = target < slots ? target : slots;
+      au.seed = audit->seed + 0x9E3779B9u * (uint32_t)c;
+      slot_off += slots;
+    }
+    // the measurement hooks: one quadruple of events per chunk, handed over back to back behind the struct's own
+    lshrs_sig_opts op{};
+    const lshrs_sig_opts* opp = nullptr;
+    if (opts != nullptr && opts->struct_bytes >= sizeof(lshrs_sig_opts)) {
+      op = *opts;
+      if (plan->ev_timing != nullptr) {
+        op.ev_stage1_start = plan->ev_timing[4 * c + 0];
+        op.ev_stage1_stop = plan->ev_timing[4 * c + 1];
+        op.ev_stage2_start = plan->ev_timing[4 * c + 2];
+        op.ev_stage2_stop = plan->ev_timing[4 * c + 3];
+      }
+      if (c != 0) op.clock_probe = nullptr;
+      opp = &op;
+    }
+    SplitFork fk{};
+    const bool forked = c + 1 < nc;
+    if (forked) {
+      fk.side = static_cast<hipStream_t>(plan->side_stream[c]);
+      fk.ev_fork = static_cast<hipEvent_t>(plan->ev_fork[c]);
+      fk.ev_join = static_cast<hipEvent_t>(plan->ev_join[c]);
+    }
+    int32_t* cnt = counters + (int64_t)c * LSHRS_SIG_DEVICE_COUNTERS;
+    const int rc = lshrs_sig_hash_batch_split_replay_f32_impl(
+        X + lo * ldx, rows, ldx, workspace, num_bands, rows_per_band, dim, keys + lo * row_bytes, cnt, tau,
+        row_flags != nullptr ? row_flags + lo : nullptr, flag_list + list_off, flag_y != nullptr ? flag_y + list_off : nullptr,
+        plan->flag_cap[c], tau1, blas_model, host_counts + (int64_t)c * LSHRS_SIG_COUNTERS, audit_on ? &au : nullptr, opp, stream,
+        forked ? &fk : nullptr);
+    if (rc != 0) {
+      // (chunks already enqueued run to their end: the caller's stream must still see them finish before buffers go away)
+      for (int d = 0; d < c && d + 1 < nc; ++d) (void)hipStreamWaitEvent(s, static_cast<hipEvent_t>(plan->ev_join[d]), 0);
+      return rc;
+    }
+    lo += rows;
+    list_off += plan->flag_cap[c];
+  }
+  for (int c = 0; c + 1 < nc; ++c) {
+    const hipError_t e = hipStreamWaitEvent(s, static_cast<hipEvent_t>(plan->ev_join[c]), 0);
+    if (e != hipSuccess) return -(int)e;
+  }
+  return 0;
 }
 
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
