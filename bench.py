@@ -35,6 +35,8 @@ Also in the line (N = 1 unless noted):
   measured_window_mode   the same step with round 2's default (a 64-unit window + guard): statistical, not proven;
   host_engine_mode       the same step with the device tie replay off (what an unrecognised host BLAS runs), with the proven
                          windows and (`host_engine_mode_measured_windows`) with round 2's measured ones;
+  pinned_model_mode      the same step with `reference_blas="openblas-skylakex"` and the host's BLAS made unrecognisable: what such
+                         a host gets INSTEAD of host_engine_mode when it names the build its keys shall be those of;
   other_shapes  bands of 10 / 5 / 4 / 6 rows, 25 key bytes per row, 300-d: route and rate of shapes that used to end at the host engine
                 (or, 128 x 4, to pay for four column blocks where two hold its 512 real columns);
   c5            BASELINE config 5 (5M x 1536, num_perm 512) on one GPU with its own roofline and parity check;
@@ -527,6 +529,7 @@ def main() -> None:
                 "slicing) runs - stage 2 evaluates the f32 chain, the ties inside the proven tie window go to the host "
                 "engine (the library's own sgemv on several cores): pairs cut on the device, tied rows through two pinned blocks under the engine's work",
                 tie_replay="off")),
+            ("pinned_model_mode", lambda: bench_pinned(torch, x, keys, local_dev, args.steps, barrier)),
             ("host_engine_mode_measured_windows", lambda: bench_variant(
                 torch, x, keys, local_dev, args.steps, barrier,
                 "tie_replay='off' with round 2's measured windows (tau1_ulps=64, tau_ulps=8): what that route costs when the "
@@ -730,6 +733,33 @@ def bench_variant(torch, x, keys, local_dev, steps, barrier, label, **kw):
         torch.equal(hv.hash_device(x), LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_dev).hash_device(x)))
     hv.close()
     return out
+
+
+def bench_pinned(torch, x, keys, local_dev, steps, barrier):
+    """The same step with the keys pinned to a NAMED build of OpenBLAS (`reference_blas="openblas-skylakex"`) while the check
+    that recognises the host's own BLAS is made to answer "not recognised" - what a host on MKL / BLIS / aarch64 gets: the
+    device route instead of `host_engine_mode`."""
+    from lshrs_amd import _hostblas
+
+    real = _hostblas.blas_order_model
+    host_model = int(real(np_planes(x.device.index)))
+    _hostblas.blas_order_model = lambda planes: 0
+    try:
+        out = bench_variant(torch, x, keys, local_dev, steps, barrier,
+                            "reference_blas='openblas-skylakex' on a host whose own BLAS the licence check does not recognise "
+                            "(forced: blas_order_model -> 0): the named build's order is replayed on the device, no host engine",
+                            reference_blas="openblas-skylakex")
+    finally:
+        _hostblas.blas_order_model = real
+    out["host_blas_model_really"] = host_model      # (1: this host IS that build for this shape - then the keys are the default hasher's)
+    return out
+
+
+def np_planes(_dev):
+    import numpy as np
+    from lshrs_amd import LSHHasher
+
+    return LSHHasher(BANDS, ROWS, DIM, seed=42)._stacked().reshape(BANDS, ROWS, DIM).astype(np.float32)
 
 
 def bench_other_shapes(torch, np, local_dev, n):

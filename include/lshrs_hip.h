@@ -263,7 +263,8 @@ int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int
  * the pass with room.  Inputs of whole groups of four elements (dim % 4 == 0, dim >= 8) in 16-byte aligned rows take the
  * LDS-DMA form of the replay; anything else - dim % 4 elements of scalar tail from 9 elements up (blas_model 1 / 2: how
  * the host's build of the library compiles that tail), rows at any 4-byte address, bands of ONE row (the host then calls
- * sdot: whole 64-element steps for blas_model 1, whole 32s for 2) - its plain-load form; 8 m + 4 body elements only up to 4096;
+ * sdot: every length, ABI 6 - the build's SIMD kernel over the whole 32-element steps, blas_model 1 / 2, the f32 products of
+ * the elements behind them summed in a double) - its plain-load form; 8 m + 4 body elements only up to 4096;
  * else LSHRS_E_TOOLARGE: resolve on the host.  Only `dim` elements of a row are ever fetched; keys in device memory, rows of
  * any width (bits are patched with 32-bit atomics on the aligned word around the byte). */
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,

@@ -156,6 +156,34 @@ def blas_row_kinds(rows_per_band: int) -> np.ndarray:
     return np.where(j < r4, 0, np.where(((r & 3) == 1) | (j - r4 == 2), 2, 1)).astype(np.int32)
 
 
+# Named builds of the BLAS the reference's `projection @ vector` (lshrs/hash/lsh.py:200) may run on: `LSHHasher(reference_blas=...)`
+# pins the keys to one of them whatever BLAS this host's NumPy has.  Value = the model id of `lshrs_tb_model_row_dot` that build
+# follows where the two differ (the dim % 4 elements of sgemv_t's scalar tail, the SIMD kernel of sdot).
+NAMED_BUILDS = {
+    "openblas-skylakex": 1,     # OpenBLAS 0.3.2x DYNAMIC_ARCH on Intel Skylake-X / Cascade Lake / Ice Lake / Sapphire Rapids
+    "openblas-haswell": 2,      # ... on Haswell / Broadwell and every AMD Zen (EPYC, Ryzen): the "Haswell" / "Zen" core types
+    "openblas-zen": 2,
+}
+
+
+def named_model(build: str, rows_per_band: int, dim: int) -> int:
+    """The summation-order model `lshrs_tb_model_row_dot` takes for hyperplane bands of this shape when the keys are pinned to
+    a NAMED build of OpenBLAS (0: that build's order is not modelled for this shape).  The coverage is what
+    `blas_order_model` licenses on a host that really runs that build - tests/test_reference_blas.py checks the two against
+    each other under ``OPENBLAS_CORETYPE`` - minus the shapes no device route takes (fewer than 9 elements with bands of two rows
+    or more: the small-matrix paths of the two builds differ there and are not modelled)."""
+    b = NAMED_BUILDS.get(build, 0)
+    r, dim = int(rows_per_band), int(dim)
+    if not b or r < 1 or dim < 1:
+        return 0
+    if r == 1:                       # sdot: every length, the build's own SIMD kernel
+        return b
+    body = dim & ~3
+    if dim < 9 or (body % 8 != 0 and body > 4096):
+        return 0
+    return 1 if dim % 4 == 0 else b  # (whole groups of four: both builds sum alike)
+
+
 def blas_order_model(planes: np.ndarray) -> int:
     """Which summation-order model of ``lshrs_tb_model_row_dot`` (0 = none) reproduces, bit for bit, what this process's
     NumPy returns for ``P_band @ x`` at this ``(rows_per_band, dim)`` - the licence for the GPU's tie replay
@@ -171,8 +199,9 @@ def blas_order_model(planes: np.ndarray) -> int:
     model = 0
     try:
         body = dim & ~3               # (dim % 4 elements behind it: the library's scalar tail, modelled from 9 elements up)
-        if ((dim % 4 == 0 or (dim >= 9 and r >= 2)) and (body % 8 == 0 or body <= 4096) and r >= 1
-                and (r >= 2 or dim % 32 == 0) and os.path.exists(LIBRARY)):
+        # (a band of ONE row is sdot on the host: modelled for every length, round 5)
+        if ((r == 1 or ((dim % 4 == 0 or dim >= 9) and (body % 8 == 0 or body <= 4096))) and r >= 1
+                and os.path.exists(LIBRARY)):
             lib = load()
             rng = np.random.default_rng(20240601)
             bands = sorted({0, nb // 2, nb - 1})
@@ -196,7 +225,8 @@ def blas_order_model(planes: np.ndarray) -> int:
                     trials.append((plane, x32, plane @ x32))    # the reference's call (lshrs/hash/lsh.py:200)
             # model 2 differs from 1 only in the dim % 4 elements of the scalar tail (the library's Haswell / Zen build
             # contracts nothing there): tried second, and only where there is a tail
-            # ... and in how a band of ONE row is summed (NumPy calls sdot there: model 1 needs whole 64-element steps, 2 whole 32s)
+            # ... and in how a band of ONE row is summed (NumPy calls sdot there: the SIMD kernel of the build, then the
+            # elements behind the last whole 32 in a double - lshrs_tb_model_row_dot)
             for candidate in ((1,) if dim % 4 == 0 and r >= 2 else (1, 2)):
                 if all(np.array_equal(want.view(np.uint32), np.array(
                         [lib.lshrs_tb_model_row_dot(plane[i].ctypes.data, x32.ctypes.data, dim, candidate, i, r)

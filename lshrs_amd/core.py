@@ -117,6 +117,9 @@ class LSHRS:
     ``batch_add``; ``True``: the array path whenever the storage can take it; ``False``: always the reference's
     operation lists, flush boundaries included (what tests/golden/g5_orchestration.json pins).  Same bucket contents
     every way (lshrs/core/main.py:1113-1143, lshrs/storage/redis.py:348-416).
+    ``reference_blas``: which BLAS build the band keys are the reference's keys on (``LSHHasher``; "host" = this process's
+    NumPy).  A named build is stored by ``save_to_disk`` (key ``lshrs_amd`` of metadata.json, which the reference's loader
+    does not read) and by pickle, so an index and everything that queries it hash alike on any machine.
     """
 
     def __init__(
@@ -142,6 +145,7 @@ class LSHRS:
         device: Any = None,
         packed_ingest: Union[bool, str] = "auto",
         devices: Optional[Sequence[int]] = None,
+        reference_blas: str = "host",
     ) -> None:
         if dim <= 0:
             raise ValueError("Vector dimensionality must be greater than zero")
@@ -169,7 +173,8 @@ class LSHRS:
         self.packed_auto_min_ops = 8_192     # "auto": below this many (band, key, id) operations the tuples are cheaper
         self._packed_writer = None
         self._hasher = hasher if hasher is not None else LSHHasher(
-            num_bands=num_bands, rows_per_band=rows_per_band, dim=dim, seed=seed, device=device, devices=devices)
+            num_bands=num_bands, rows_per_band=rows_per_band, dim=dim, seed=seed, device=device, devices=devices,
+            reference_blas=reference_blas)
         self._storage = storage if storage is not None else default_storage(
             host=redis_host, port=redis_port, db=redis_db, password=redis_password,
             decode_responses=decode_responses, prefix=redis_prefix, max_connections=redis_max_connections)
@@ -455,7 +460,11 @@ class LSHRS:
         if "password" in redis_cfg:
             redis_cfg["password"] = "<REDACTED>"
         with open(out / "metadata.json", "w") as fh:
-            json.dump({"version": _FORMAT_VERSION, "config": self._config, "redis_config": redis_cfg}, fh, indent=2)
+            meta = {"version": _FORMAT_VERSION, "config": self._config, "redis_config": redis_cfg}
+            blas = getattr(self._hasher, "reference_blas", "host")
+            if blas != "host":        # (a key of our own: the reference's load_from_disk reads the three above only)
+                meta["lshrs_amd"] = {"reference_blas": blas}
+            json.dump(meta, fh, indent=2)
         np.savez_compressed(out / "projections.npz", *self._hasher.projections)
 
     @classmethod
@@ -477,7 +486,8 @@ class LSHRS:
             similarity_threshold=cfg["similarity_threshold"], buffer_size=cfg["buffer_size"],
             vector_fetch_fn=vector_fetch_fn, storage=storage, redis_host=redis_cfg["host"], redis_port=redis_cfg["port"],
             redis_db=redis_cfg["db"], redis_password=redis_cfg["password"], redis_prefix=redis_cfg["prefix"],
-            decode_responses=redis_cfg["decode_responses"], seed=cfg["seed"])
+            decode_responses=redis_cfg["decode_responses"], seed=cfg["seed"],
+            reference_blas=meta.get("lshrs_amd", {}).get("reference_blas", "host"))
         with np.load(src / "projections.npz") as data:
             inst._hasher.projections = [data[f"arr_{i}"].astype(np.float32) for i in range(len(data.files))]
         return inst
@@ -495,7 +505,8 @@ class LSHRS:
             "packed_ingest": self._packed_ingest,
             "device": getattr(h, "_device", None) if isinstance(getattr(h, "_device", None), (int, str, type(None))) else str(h._device),
             "hasher_kwargs": {**{k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard",
-                                                            "tie_threads", "audit_every", "audit_unflagged") if hasattr(h, k)},
+                                                            "tie_threads", "audit_every", "audit_unflagged",
+                                                            "reference_blas") if hasattr(h, k)},
                               **({"devices": list(h._devices)} if getattr(h, "_devices", None) else {})},
             "windows": {"tau_ulps": "bound" if getattr(h, "window_mode", {}).get("tau") == "bound" else getattr(h, "tau_ulps", 8.0),
                         "tau1_ulps": "bound" if getattr(h, "window_mode", {}).get("tau1") == "bound" else getattr(h, "tau1_ulps", 64.0)},

@@ -264,35 +264,49 @@ static inline int tb_row_kind(int row, int rows) {
   return ((rows & 3) == 1 || row - r4 == 2) ? 2 : 1;
 }
 
-// A band of ONE row: NumPy's matmul sends (1, n) @ (n,) to sdot, not to sgemv.  The two builds of the library sum it
-// differently (tools/blas_order/tail_search.py), modelled for lengths without a tail:
-//   model 1 (SkylakeX build, n % 64 == 0): 64 fma chains over k mod 64 = four 16-lane accumulators; each folded to eight
-//     lanes (l + (l + 8)), the four added in turn ((t0 + t1) + t2) + t3, lanes i + (i + 4), then (w0 + w1) + (w2 + w3);
-//   model 2 (Haswell / Zen build, n % 32 == 0): 32 fma chains over k mod 32 = eight 4-lane accumulators, added pairwise
-//     ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) per lane, then (l0 + l1) + (l2 + l3).
+// A band of ONE row: NumPy's matmul sends (1, n) @ (n,) to sdot, not to sgemv.  OpenBLAS's x86-64 sdot hands the first
+// n1 = n & -32 elements to a SIMD kernel with an f32 result, sums the f32 PRODUCTS of the n - n1 elements behind them one by one
+// in a DOUBLE, adds the kernel's result to that double and rounds once to f32 (found in round 5 by masking probes, FPRev style,
+// tools/blas_order/fprev.py; checked bit for bit for every n from 1 to 139 and beyond under OPENBLAS_CORETYPE=SkylakeX / Haswell).
+// The two builds of the library differ in the kernel:
+//   model 1 (SkylakeX build): whole 64-element steps on four 16-lane fma accumulators, each folded to eight lanes
+//     (l + (l + 8)); a last 32-element step (n1 % 64 == 32) goes straight onto the four folded accumulators, eight lanes
+//     each; the four added in turn ((t0 + t1) + t2) + t3, lanes i + (i + 4), then (w0 + w1) + (w2 + w3);
+//   model 2 (Haswell / Zen build): 32-element steps on four 8-lane fma accumulators, each folded to four lanes
+//     (l + (l + 4)), added pairwise (q0 + q1) + (q2 + q3), then (l0 + l1) + (l2 + l3).
 static float tb_model_sdot(const float* a, const float* x, int64_t n, int32_t model) {
-  if (model == 1) {
-    if (n % 64 != 0) return __builtin_nanf("");
+  const int64_t n1 = n & ~(int64_t)31;
+  float kernel = 0.f;
+  if (n1 > 0 && model == 1) {
+    const int64_t n64 = n1 & ~(int64_t)63;
     float acc[64] = {0};
-    for (int64_t k = 0; k < n; ++k) acc[k & 63] = __builtin_fmaf(a[k], x[k], acc[k & 63]);
+    for (int64_t k = 0; k < n64; ++k) acc[k & 63] = __builtin_fmaf(a[k], x[k], acc[k & 63]);
+    float t[4][8];
+    for (int u = 0; u < 4; ++u)
+      for (int l = 0; l < 8; ++l) t[u][l] = n64 > 0 ? acc[16 * u + l] + acc[16 * u + l + 8] : 0.f;
+    if (n64 < n1)
+      for (int u = 0; u < 4; ++u)
+        for (int l = 0; l < 8; ++l) t[u][l] = __builtin_fmaf(a[n64 + 8 * u + l], x[n64 + 8 * u + l], t[u][l]);
     float v[8];
-    for (int l = 0; l < 8; ++l) {
-      float t[4];
-      for (int u = 0; u < 4; ++u) t[u] = acc[16 * u + l] + acc[16 * u + l + 8];
-      v[l] = ((t[0] + t[1]) + t[2]) + t[3];
-    }
+    for (int l = 0; l < 8; ++l) v[l] = ((t[0][l] + t[1][l]) + t[2][l]) + t[3][l];
     const float w0 = v[0] + v[4], w1 = v[1] + v[5], w2 = v[2] + v[6], w3 = v[3] + v[7];
-    return (w0 + w1) + (w2 + w3);
+    kernel = (w0 + w1) + (w2 + w3);
+  } else if (n1 > 0) {
+    float acc[32] = {0};
+    for (int64_t k = 0; k < n1; ++k) acc[k & 31] = __builtin_fmaf(a[k], x[k], acc[k & 31]);
+    float v[4];
+    for (int l = 0; l < 4; ++l) {
+      const float s0 = acc[l] + acc[4 + l], s1 = acc[8 + l] + acc[12 + l], s2 = acc[16 + l] + acc[20 + l], s3 = acc[24 + l] + acc[28 + l];
+      v[l] = (s0 + s1) + (s2 + s3);
+    }
+    kernel = (v[0] + v[1]) + (v[2] + v[3]);
   }
-  if (n % 32 != 0) return __builtin_nanf("");
-  float acc[32] = {0};
-  for (int64_t k = 0; k < n; ++k) acc[k & 31] = __builtin_fmaf(a[k], x[k], acc[k & 31]);
-  float v[4];
-  for (int l = 0; l < 4; ++l) {
-    const float s0 = acc[l] + acc[4 + l], s1 = acc[8 + l] + acc[12 + l], s2 = acc[16 + l] + acc[20 + l], s3 = acc[24 + l] + acc[28 + l];
-    v[l] = (s0 + s1) + (s2 + s3);
+  double tail = 0.0;
+  for (int64_t k = n1; k < n; ++k) {
+    volatile float prod = a[k] * x[k];      // (an f32 product, rounded on its own: nothing here may be contracted)
+    tail += (double)prod;
   }
-  return (v[0] + v[1]) + (v[2] + v[3]);
+  return (float)(tail + (double)kernel);
 }
 
 float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band) {

@@ -1119,21 +1119,37 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
     const int kind = blas_row_kind(col % a.band_cols, a.rows_per_band);
     float y = 0.f, ss = 0.f;
     if (a.rows_per_band == 1) {
-      // A band of ONE row: NumPy calls sdot (lshrs_host.h, tb_model_sdot).  Lane `sub` owns the chains c = sub + 8 j.
-      if (a.tail_model == 1) {          // SkylakeX build: 64 chains, accumulators folded in halves, added in turn
+      // A band of ONE row: NumPy calls sdot (lshrs_host.h, tb_model_sdot): the first n1 = dim & -32 elements through the
+      // build's SIMD kernel (f32 result), the f32 products of the elements behind them summed one by one in a double, the
+      // kernel's result added to that double, one rounding to f32.  Lane `sub` owns the chains c = sub + 8 j.
+      const int n1 = a.dim & ~31;
+      float kernel = 0.f;
+      if (a.tail_model == 1) {          // SkylakeX build: 64-element steps on 64 chains, folded in halves; a last 32-element
+        const int n64 = n1 & ~63;       // step onto the folded accumulators; those added in turn
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < a.dim; k0 += 64)
+        for (int k0 = 0; k0 < n64; k0 += 64)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float xv = xr[k0 + 8 * j + sub];
             acc[j] = __builtin_fmaf(pr[k0 + 8 * j + sub], xv, acc[j]);
             ss = __builtin_fmaf(xv, xv, ss);
           }
-        const float v = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + (acc[4] + acc[5])) + (acc[6] + acc[7]);
-        y = blas_reduce(v, 0, lane);    // lanes i + (i + 4), then (w0 + w1) + (w2 + w3)
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = n64 > 0 ? acc[2 * u] + acc[2 * u + 1] : 0.f;
+        if (n64 < n1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float xv = xr[n64 + 8 * u + sub];
+            t[u] = __builtin_fmaf(pr[n64 + 8 * u + sub], xv, t[u]);
+            ss = __builtin_fmaf(xv, xv, ss);
+          }
+        }
+        const float v = ((t[0] + t[1]) + t[2]) + t[3];
+        kernel = blas_reduce(v, 0, lane);    // lanes i + (i + 4), then (w0 + w1) + (w2 + w3)
       } else {                          // Haswell / Zen build: 32 chains, accumulators pairwise, lanes pairwise
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < a.dim; k0 += 32)
+        for (int k0 = 0; k0 < n1; k0 += 32)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float xv = xr[k0 + 8 * j + sub];
@@ -1145,8 +1161,16 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
         for (int j = 0; j < 4; ++j) sj[j] = acc[j] + __shfl(acc[j], (lane + 32) & 63);   // a(2j) + a(2j+1): lanes l and l + 4
         const float v = (sj[0] + sj[1]) + (sj[2] + sj[3]);
         const float h = v + __shfl(v, (lane + 8) & 63);
-        y = h + __shfl(h, (lane + 16) & 63);
+        kernel = h + __shfl(h, (lane + 16) & 63);
       }
+      if (n1 == 0) kernel = 0.f;
+      double tail = 0.0;                // (every lane of the entry computes the same tail: at most 31 elements)
+      for (int k = n1; k < a.dim; ++k) {
+        const float xv = xr[k];
+        tail += (double)mul_then_add(0.f, pr[k], xv);       // the f32 product, rounded on its own
+        if (sub == 0) ss = __builtin_fmaf(xv, xv, ss);
+      }
+      y = (float)(tail + (double)kernel);
     } else
     for (int k0 = 0; k0 < body; k0 += 4096) {                      // the library's blocks (uniform trip count)
       const int kn = body - k0 < 4096 ? body - k0 : 4096;
@@ -3474,11 +3498,10 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   // goes through the plain-load form of the same replay (sig_fixany_kernel)
   const bool fast = dim % 4 == 0 && dim >= 8 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && rows_per_band >= 2;
   const int body = dim & ~3;
-  // (a band of ONE row is sdot on the host: modelled for whole 64-element steps - model 1 - or whole 32s - model 2)
-  const bool one_row_ok = rows_per_band == 1 && (blas_model == 1 ? dim % 64 == 0 : dim % 32 == 0);
-  if ((body % 8 != 0 && body > 4096) || n >= ((int64_t)1 << 42) || (!fast && dim < 9) || (rows_per_band < 2 && !one_row_ok) ||
-      (fast && blas_model != 1))
-    return LSHRS_E_TOOLARGE;
+  // (a band of ONE row is sdot on the host: modelled for every length, both builds - the plain-load form follows it)
+  const bool one_row = rows_per_band == 1;
+  if (!one_row && ((body % 8 != 0 && body > 4096) || (!fast && dim < 9))) return LSHRS_E_TOOLARGE;
+  if (n >= ((int64_t)1 << 42) || (fast && blas_model != 1)) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
   {

@@ -166,6 +166,15 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                   batch is hashed again with the host engine.  0 = never
       tie_replay  "auto" (default): batches that take the split pass break their ties on the device (stage 2 replays
                   the host BLAS's summation order, recognised and verified at first use); "off": host engine only
+      reference_blas  which BLAS the keys are the reference's keys ON.  The reference's bits are whatever `projection @ vector`
+                  (lsh.py:200) returns on the machine that runs it - its BLAS's summation order decides the projections that
+                  are ties.  "host" (default): this process's NumPy, recognised and verified at first use (a host whose
+                  BLAS is not recognised hashes through the host engine: same keys, 20 M instead of 800 M vectors/s).
+                  "openblas-skylakex" / "openblas-haswell" (= "openblas-zen"): the order of that build of OpenBLAS 0.3.2x
+                  (what NumPy's wheels ship) replayed on the device WHATEVER BLAS this host has - an index and its
+                  queries hash alike on every machine that names the same build, and no host loses the device path.
+                  The choice travels with `LSHRS.save_to_disk` / pickle.  Shapes the named build is not modelled for
+                  (bands of two rows or more over fewer than 9 elements; 8 m + 4 elements beyond 4096) raise `ValueError`.
       devices     in-process multi-device ingestion: host batches of >= 32 768 rows per device are cut into one row slice
                   per entry, hashed concurrently (one thread + hasher per entry), keys returned in row order
     """
@@ -174,7 +183,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                  tie_break: str = "host", tau_ulps=None, precision: str = "bf16x3",
                  tau1_ulps=None, tie_threads: Optional[int] = None,
                  tie_replay: str = "auto", margin_guard: float = 0.5, audit_every: int = 64,
-                 audit_unflagged: int = 4096, devices: Optional[Sequence[int]] = None) -> None:
+                 audit_unflagged: int = 4096, devices: Optional[Sequence[int]] = None,
+                 reference_blas: str = "host") -> None:
         # messages: lshrs/hash/lsh.py:78-83
         if num_bands <= 0:
             raise ValueError("num_bands must be > 0")
@@ -190,6 +200,16 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         self.rows_per_band = int(rows_per_band)
         self.dim = int(dim)
         self.tie_break = tie_break
+        if reference_blas != "host":
+            if reference_blas not in _hostblas.NAMED_BUILDS:
+                raise ValueError("reference_blas must be 'host' or one of " + ", ".join(sorted(_hostblas.NAMED_BUILDS)))
+            if tie_replay != "auto":
+                raise ValueError("a named reference_blas is replayed on the device: tie_replay must be 'auto'")
+            if not _hostblas.named_model(reference_blas, self.rows_per_band, self.dim):
+                raise ValueError(f"reference_blas={reference_blas!r} is not modelled for rows_per_band={self.rows_per_band}, "
+                                 f"dim={self.dim}; use reference_blas='host'")
+        self.reference_blas = reference_blas
+        self._host_agrees: Optional[tuple] = None
         # In-process multi-device ingestion: host batches handed to `hash_batch_packed` are cut into one
         # contiguous row slice per entry of `devices`, each slice hashed by a worker thread through a hasher of its own
         # (own device, streams, scratch; the same hyperplanes), the keys land in one array in the original row order.  No
@@ -202,7 +222,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
             device = self._devices[0]
         self._ctor_kwargs = dict(tie_break=tie_break, tau_ulps=tau_ulps, precision=precision, tau1_ulps=tau1_ulps,
                                  tie_threads=tie_threads, tie_replay=tie_replay, margin_guard=margin_guard,
-                                 audit_every=audit_every, audit_unflagged=audit_unflagged)
+                                 audit_every=audit_every, audit_unflagged=audit_unflagged, reference_blas=reference_blas)
         self._seed = seed
         self._children: Optional[list] = None
         self._pool = None
@@ -610,14 +630,18 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         if model:       # (the model's own limits - 8 m + 4 elements only up to 4096, two rows per band or more - are in `model`)
             if aligned and short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
-            if self.dim >= 9 or self.dim == 8:        # (the replay kernels: 8 elements and up; shorter vectors: the host)
+            # (the replay kernels: 9 elements and up at any 4-byte address, 8 in 16-byte aligned rows - shorter vectors: the host;
+            #  a band of ONE row is sdot on the host, replayed at every length)
+            if self.rows_per_band == 1 or self.dim >= 9 or (self.dim == 8 and aligned):
                 return "f32+replay", model
-        if (allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
+        if (self.reference_blas == "host" and allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
                 and self._expected_tie_entries(32) <= 0.75 and self._tie_engine() is not None):
             # (the pipeline's per-chunk lists - and the pinned copies of the tied rows behind them - hold one entry per 32
             #  rows; the PROVEN tie window without a replay, ~1 000 units at 768-d, ties a third of the rows: every chunk
             #  would overflow and be hashed twice, so that case takes the plain path with a list sized for it)
             return "host-engine pipelined", 0
+        if self.reference_blas != "host":      # (cannot happen for shapes the constructor accepted: the named order has no host engine)
+            raise _native.NativeLibraryError(f"no device route replays reference_blas={self.reference_blas!r} for this batch")
         return "plain", 0
 
     def _expected_tie_entries(self, rows: int) -> float:
@@ -628,13 +652,30 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
 
     # ------------------------------------------------------------------ ties broken on the device
     def _replay_model(self) -> int:
-        """Summation-order model of the host BLAS for this hasher's shape (0: not recognised -> host engine)."""
+        """Summation-order model stage 2 replays for this hasher's shape: the host BLAS's, recognised and verified (0: not
+        recognised -> host engine) - or, with a named `reference_blas`, that build's, whatever the host has."""
+        if self.reference_blas != "host":
+            return _hostblas.named_model(self.reference_blas, self.rows_per_band, self.dim)
         cached = self._replay_model_cache
         sig = _hostblas.blas_signature()      # (library, thread count, pid): one C call - the licence is per signature
         if cached is None or cached[0] != self._projection_version or cached[2] != sig:
             planes = self._stacked().reshape(self.num_bands, self.rows_per_band, self.dim)
             cached = (self._projection_version, int(_hostblas.blas_order_model(planes)), sig)
             self._replay_model_cache = cached
+        return cached[1]
+
+    def _host_blas_agrees(self) -> bool:
+        """Is what this process's NumPy computes the order the keys are pinned to?  (Always, for reference_blas="host"; for a
+        named build: where the host's own BLAS is recognised as the same model.)  The live audit against `P_band @ x` only
+        means something where it is."""
+        if self.reference_blas == "host":
+            return True
+        sig = _hostblas.blas_signature()
+        cached = self._host_agrees
+        if cached is None or cached[0] != self._projection_version or cached[2] != sig:
+            planes = self._stacked().reshape(self.num_bands, self.rows_per_band, self.dim)
+            cached = (self._projection_version, int(_hostblas.blas_order_model(planes)) == self._replay_model(), sig)
+            self._host_agrees = cached
         return cached[1]
 
     def _replay_launch(self, x, out, row_flags, ws, tau, model, want_event: bool = False):
@@ -952,7 +993,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                 break
             self._ensure_window(x.device, ws, model)      # (a guard that has just moved the hasher to the proven window)
         undisturbed = state[9][0] == state[8]         # nobody has launched over this launch's list since
-        if self.audit_every > 0 and stats.get("flagged", 0) > 0 and undisturbed:
+        if self.reference_blas != "host":
+            stats["reference_blas"] = self.reference_blas
+        if self.audit_every > 0 and stats.get("flagged", 0) > 0 and undisturbed and self._host_blas_agrees():
             self._audit_countdown -= 1
             if self._audit_countdown <= 0:
                 self._audit_countdown = self.audit_every
@@ -1244,6 +1287,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         state["_async_pending"] = []
         state["_replay_events"] = {}
         state["_replay_model_cache"] = None
+        state["_host_agrees"] = None
         state["_host_planes_cache"] = None
         state["kernel_events"] = None
         state["_projections"] = list(self._projections)
@@ -1262,6 +1306,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         self.__dict__.setdefault("_replay_events", {})
         self.__dict__.setdefault("_replay_model_cache", None)
         self.__dict__.setdefault("tie_replay", "auto")
+        self.__dict__.setdefault("reference_blas", "host")
+        self.__dict__.setdefault("_host_agrees", None)
         self.__dict__.setdefault("replay_min_rows", 256)
         self.__dict__.setdefault("pipeline_pair_head", True)
         self.__dict__.setdefault("_host_planes_cache", None)

@@ -82,6 +82,23 @@ def host_roundings(dim: int, K: int, kinds: np.ndarray) -> np.ndarray:
     return m
 
 
+def host_roundings_sdot(dim: int, K: int) -> np.ndarray:
+    """`host_roundings` for a band of ONE row - the host then calls sdot, whose order is not sgemv's (`tb_model_sdot`, csrc/
+    host_tiebreak.cpp): a ``(K,)`` array, 0 beyond ``dim``.  SkylakeX build (model 1): a product of 64-element step s of S is
+    rounded by its own fma and every later step's, by the fold to eight lanes, by the last 32-element step if there is one, by the
+    three additions of the four accumulators, the lane halves, two levels of pairs and the final rounding of (double tail +
+    kernel): ``S - s + 9``; a product of the 32-element step 8; Haswell / Zen build (model 2): 32-element steps, ``S' - s + 6``.
+    An element behind the last whole 32: its own product's rounding, the final one, and one for the double sums.  Both builds
+    share one window (`window_coefficients` folds model 2 into 1): the elementwise maximum."""
+    k = np.arange(K)
+    n1, n64 = dim & ~31, dim & ~63
+    m1 = np.where(k < n64, n64 // 64 - k // 64 + 9, np.where(k < n1, 8, 3))
+    m2 = np.where(k < n1, n1 // 32 - k // 32 + 6, 3)
+    m = np.maximum(m1, m2).astype(np.float64)
+    m[k >= dim] = 0.0
+    return m
+
+
 def window_coefficients(planes: np.ndarray, blas_model: int, rows_per_band: int = 0
                         ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, dict]:
     """The PROVEN windows of the signature pass, as per-hyperplane coefficients (float64 arithmetic, rounded up to float32):
@@ -151,7 +168,7 @@ def window_coefficients(planes: np.ndarray, blas_model: int, rows_per_band: int 
             kinds = np.where(j < r4, 0, np.where(((r & 3) == 1) | (j - r4 == 2), 2, 1))
         else:
             kinds = np.zeros(num, dtype=np.int64)
-        m_host = host_roundings(dim, K, kinds)
+        m_host = host_roundings(dim, K, kinds) if r != 1 else np.broadcast_to(host_roundings_sdot(dim, K), (num, K))
     else:
         m_host = np.where(k < dim, dim + 1, 0).astype(np.float64)
     # what stage 1's value is measured against is what finally DECIDES a projection it does not flag: the replayed BLAS

@@ -250,7 +250,14 @@ def test_route_table():
         one = LSHHasher(64, 1, 64, seed=1)._route(5_000, "host", **ok)                              # one row per band: NumPy calls sdot -
         assert one in (("f32+replay", 1), ("f32+replay", 2))                                        # modelled for whole 64 / 32-element steps
         assert LSHHasher(64, 1, 64, seed=1)._route(1_000_000, "host", **ok) == one                  # (never the split pass)
-        assert LSHHasher(8, 1, 100, seed=1)._route(5_000, "host", **ok) == ("plain", 0)             # ... 100 elements: not modelled
+        assert LSHHasher(8, 1, 100, seed=1)._route(5_000, "host", **ok) == one                      # ... at every length (round 5:
+        assert LSHHasher(8, 1, 5, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"             #  the elements behind the last whole 32
+        assert LSHHasher(8, 1, 1, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"             #  are summed in a double)
+        # 8 elements in rows that are only 4-byte aligned - the replay kernels do not take them: the host route
+        assert LSHHasher(4, 4, 8, seed=1)._route(5_000, "host", aligned=False, short_stride=True, host_rows=False)[0] in ("plain", "f32+replay")
+        if LSHHasher(4, 4, 8, seed=1)._replay_model():
+            assert LSHHasher(4, 4, 8, seed=1)._route(5_000, "host", aligned=False, short_stride=True, host_rows=False) == ("plain", 0)
+            assert LSHHasher(4, 4, 8, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"
     # the host engine: chunks overlapped by the native pipeline where the tie window is narrow enough for its per-chunk lists
     # (measured windows); the PROVEN tie window without a replay ties a third of the rows - every chunk would overflow and be
     # hashed twice - so it takes the plain path with a list sized for it

@@ -95,7 +95,15 @@ def test_model_function_is_the_documented_order():
             want2 = f(yb + f(f(f(t[0] * u[0]) + f(t[1] * u[1])) + f(t[2] * u[2])))
         assert _model_row_dot(a[:n], x[:n], 0, 4, model=1).view(np.uint32) == want1.view(np.uint32), n
         assert _model_row_dot(a[:n], x[:n], 0, 4, model=2).view(np.uint32) == want2.view(np.uint32), n
-    assert np.isnan(_model_row_dot(a[:61], x[:61], 0, 1))  # one row per band: NumPy calls sdot, another kernel
+    # one row per band: NumPy calls sdot - f32 kernel over the whole 32s, the rest summed in a double (any length, both builds)
+    for n in (61, 31, 5):
+        for model, head in ((1, None), (2, None)):
+            n1 = n & ~31
+            kern = np.float32(0) if n1 == 0 else _model_row_dot(a[:n1], x[:n1], 0, 1, model=model)
+            tail = 0.0
+            for k in range(n1, n):
+                tail += float(f(a[k] * x[k]))
+            assert _model_row_dot(a[:n], x[:n], 0, 1, model=model).view(np.uint32) == f(tail + float(kern)).view(np.uint32), (n, model)
     assert np.isnan(_model_dot(a, x, model=3))             # unknown model
 
 
@@ -132,10 +140,10 @@ def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
 def test_shapes_the_model_does_not_cover_are_refused():
     rng = np.random.default_rng(1)
     assert _hostblas.blas_order_model(rng.standard_normal((4, 8, 4100)).astype(np.float32)) == 0      # a short block behind full ones
-    assert _hostblas.blas_order_model(rng.standard_normal((8, 1, 100)).astype(np.float32)) == 0       # one row per band (sdot) with a tail
     if _hostblas.blas_order_model(rng.standard_normal((2, 4, 64)).astype(np.float32)) == 1:
-        # one row per band, whole 64-element steps: NumPy's sdot, modelled for both builds of the library (1 / 2)
-        for dim in (64, 128, 768):
+        # one row per band: NumPy's sdot, modelled for both builds of the library (1 / 2) at EVERY length (round 5: whole
+        # 32-element steps through the build's SIMD kernel, the elements behind them summed in a double)
+        for dim in (64, 128, 768, 100, 33, 31, 7, 1, 1000, 4100):
             planes = rng.standard_normal((6, 1, dim)).astype(np.float32)
             model = _hostblas.blas_order_model(planes)
             assert model in (1, 2), dim

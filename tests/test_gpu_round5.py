@@ -112,3 +112,110 @@ def test_chunked_pass_guards_still_fire(torch_mod):
     want = hash_batch_literal_packed(base.projections, adv)
     assert np.array_equal(out[300_000:300_000 + k].cpu().numpy(), want)
     assert torch.equal(out, base.hash_device(x))
+
+
+# ----------------------------------------------------------------------------- one row per band at any length
+@pytest.mark.parametrize("nb,dim,n", [(64, 100, 6_000), (16, 33, 5_000), (40, 31, 5_000), (24, 7, 4_000), (8, 2, 3_000),
+                                      (128, 770, 3_000), (200, 96, 4_000), (32, 1000, 3_000)])
+def test_bands_of_one_row_at_lengths_with_a_tail(torch_mod, nb, dim, n):
+    """`rows_per_band = 1`: the host calls sdot - the build's SIMD kernel over the whole 32-element steps, the f32 products of the
+    elements behind them summed in a DOUBLE, one rounding (round 5, `tb_model_sdot`).  The plain-load replay follows that at
+    every length: route `f32+replay`, true ties included, the reference-literal loop's bytes."""
+    torch = torch_mod
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    h = _hasher(19, nb, 1, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's sdot order is not one the replay knows on this box")
+    x = np.random.default_rng(dim).standard_normal((n, dim)).astype(np.float32)
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
+    special = np.arange(0, n, 20)
+    k = min(3, max(1, dim - 1))
+    for i in special:                                      # true ties against up to three hyperplanes each
+        pl = stack[[(i + t) % nb for t in (0, 7, 11)][:k]]
+        v = x[i].astype(np.float64)
+        x[i] = (v - (v @ np.linalg.pinv(pl)) @ pl).astype(np.float32)
+    got = h.hash_device(torch.from_numpy(x).cuda())
+    st = dict(h.last_stats)
+    assert st["route"] == "f32+replay" and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] >= special.size // 2, st
+    want = hash_batch_literal_packed(h.projections, x)
+    assert np.array_equal(got.cpu().numpy(), want), int((got.cpu().numpy() != want).any(axis=(1, 2)).sum())
+    assert np.array_equal(h.hash_batch_packed(x[:60]), want[:60])
+    assert h.hash_vector(x[special[2]]).as_tuple() == tuple(bytes(kk) for kk in want[special[2]])
+
+
+# ----------------------------------------------------------------------------- VERDICT r4 item 3: keys pinned to a named BLAS build
+def test_named_reference_blas_keeps_the_device_route_whatever_the_host_blas(torch_mod, monkeypatch):
+    """`reference_blas="openblas-skylakex"` with the licence check answering "not recognised": route `split+replay`, no host
+    engine; for dim % 4 == 0 both named builds give the same keys, and where this host IS an OpenBLAS of that kind, the
+    reference-literal loop's bytes."""
+    import time
+
+    from lshrs_amd import _hostblas
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    torch = torch_mod
+    base = _hasher(42, 16, 16, 768)
+    host_model = base._replay_model()                      # (the real answer of this host, before the patch)
+    monkeypatch.setattr(_hostblas, "blas_order_model", lambda planes: 0)
+    n = 400_000
+    x = torch.randn(n, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(21))
+    lost = _hasher(42, 16, 16, 768)
+    assert lost._replay_model() == 0 and lost._route(n, "host", aligned=True, short_stride=True, host_rows=False)[0] != "split+replay"
+    sk = _hasher(42, 16, 16, 768, reference_blas="openblas-skylakex")
+    hw = _hasher(42, 16, 16, 768, reference_blas="openblas-haswell")
+    ks = sk.hash_device(x)
+    st = dict(sk.last_stats)
+    assert st["route"] == "split+replay" and st["tie_break_engine"] == "device-replay" and st["reference_blas"] == "openblas-skylakex"
+    assert st["audit_sign_disagreements"] == 0 and "audited" not in st        # (no live audit against a NumPy that is another BLAS)
+    assert torch.equal(hw.hash_device(x), ks)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        sk.hash_device(x)
+    torch.cuda.synchronize()
+    print(f"pinned model: {n * 20 / (time.perf_counter() - t0) / 1e6:.0f} M vec/s on 400 000 x 768 (bench.py pinned_model_mode has the 1 M figure)")
+    if host_model == 1:
+        rows = np.r_[0:1500, n - 1500:n]
+        assert np.array_equal(ks[rows].cpu().numpy(), hash_batch_literal_packed(base.projections, x[rows].cpu().numpy()))
+        monkeypatch.undo()
+        assert torch.equal(_hasher(42, 16, 16, 768).hash_device(x), ks)
+
+
+@pytest.mark.parametrize("nb,r,dim", [(16, 16, 102), (8, 5, 99), (64, 1, 100), (16, 1, 768)])
+def test_named_builds_differ_exactly_where_their_libraries_do(torch_mod, nb, r, dim):
+    """dim % 4 != 0 (the scalar tail) and one-row bands (sdot): the two named builds sum differently - on rows cancelled against a
+    hyperplane the keys of each are the signs of ITS model (`lshrs_tb_model_row_dot`), and the one that is this host's gives the
+    reference-literal loop's bytes."""
+    from lshrs_amd import _hostblas
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    torch = torch_mod
+    n = 4_000
+    lib = _hostblas.load()
+    x = np.random.default_rng(dim).standard_normal((n, dim)).astype(np.float32)
+    base = _hasher(23, nb, r, dim)
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in base.projections])
+    targets = []
+    for i in range(0, n, 10):                              # a true tie against one hyperplane per salted row
+        j = (7 * i) % (nb * r)
+        v = x[i].astype(np.float64)
+        x[i] = (v - (v @ stack[j]) / (stack[j] @ stack[j]) * stack[j]).astype(np.float32)
+        targets.append((i, j))
+    xd = torch.from_numpy(x).cuda()
+    keys = {}
+    for build in ("openblas-skylakex", "openblas-haswell"):
+        h = _hasher(23, nb, r, dim, reference_blas=build)
+        keys[build] = h.hash_device(xd).cpu().numpy()
+        assert h.last_stats["route"] == "f32+replay", h.last_stats
+        model = h._replay_model()
+        for i, j in targets:                               # the tied projection's key bit is the sign of THAT build's value
+            b, bit = j // r, j % r
+            p32 = np.ascontiguousarray(base.projections[b][bit], dtype=np.float32)
+            y = lib.lshrs_tb_model_row_dot(p32.ctypes.data, x[i].ctypes.data, dim, model, bit, r)
+            assert ((keys[build][i, b, bit >> 3] >> (bit & 7)) & 1) == int(y > 0), (build, i, j, y)
+    host_model = base._replay_model()
+    if host_model in (1, 2):
+        mine = "openblas-skylakex" if host_model == 1 else "openblas-haswell"
+        assert np.array_equal(keys[mine], hash_batch_literal_packed(base.projections, x))
+    differ = int((keys["openblas-skylakex"] != keys["openblas-haswell"]).any(axis=(1, 2)).sum())
+    print(f"{nb} x {r} x {dim}: rows whose keys differ between the two builds: {differ} of {len(targets)} salted")
