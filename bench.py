@@ -254,6 +254,10 @@ def self_launch(args) -> int:
 def main() -> None:
     args = parse()
     env_world = int(os.environ.get("WORLD_SIZE", "1") or "1")
+    if args.gpus > 1 and env_world == args.gpus and "RANK" not in os.environ and not os.environ.get("LSHRS_BENCH_SELF_LAUNCHED"):
+        # WORLD_SIZE says N but nobody gave this process a RANK: an environment left over from a launcher that is not
+        # there (a real one sets both).  Nothing to join - become the launcher, as with WORLD_SIZE unset.
+        raise SystemExit(self_launch(args))
     if args.gpus > 1 and env_world != args.gpus:
         # no launcher around this process (or an environment that exports WORLD_SIZE=1 on its own): become the launcher.
         # Anything else - a launcher that started a different number of ranks - is an error, never a silent 1-GPU run.

@@ -369,6 +369,13 @@ int lshrs_pipe_hash_f32(void* pipe, const float* X, int64_t ldx, const void* wor
  * (lshrs/storage/redis.py:225), for all N x bands keys in one pass. */
 int lshrs_keys_to_hex_u8(const uint8_t* keys, int64_t nbytes, uint8_t* hex, void* stream);
 
+/* nbytes of device memory -> PAGE-LOCKED host memory (hipHostMalloc / torch pin_memory), copied by a kernel on `stream`
+ * instead of a copy engine (ABI 6).  For the small results of a streamed ingest - the bucket arrays of one chunk - which
+ * travel back while the NEXT chunk's vectors are on their way in: on this platform a device->host memcpy issued then
+ * waits, every third time, until that 400 MB host->device copy has finished (the engines are shared out round-robin:
+ * profiles/r05_ingest_pipeline.log), a kernel's stores do not.  dst_host not page-locked: the runtime's error, negated. */
+int lshrs_copy_to_host_u8(const void* src, void* dst_host, int64_t nbytes, void* stream);
+
 /* Storage-op path, grouping: what the reference does one `(band, key, id)` tuple and one SADD at a time
  * (LSHRS._enqueue_operations, lshrs/core/main.py:1113-1128; RedisStorage.batch_add, lshrs/storage/redis.py:348-416)
  * as a CSR over the buckets of a whole batch - a counting sort per band on the device, for keys of 1 or 2 bytes

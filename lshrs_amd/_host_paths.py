@@ -29,7 +29,7 @@ class _OneRequest:
 class _HostPaths:
     # ------------------------------------------------------------------ host-facing API
     def hash_batch_packed(self, vectors, *, return_row_flags: bool = False, chunk_rows: int = 131_072,
-                          tie_break: Optional[str] = None, pin: str = "auto"):
+                          tie_break: Optional[str] = None, pin: str = "auto", device_sink=None):
         """Hash host vectors; returns a NumPy ``(n, num_bands, band_bytes)`` uint8 array
         (the reference's ``bytes`` keys side by side) and, on request, the per-row flag byte.
 
@@ -38,7 +38,12 @@ class _HostPaths:
         of chunk i-1 travel back on a third stream, through two device buffers and two pinned key buffers per hasher.
         ``pin``: "auto" page-locks a large pageable source array in place for the duration of the call
         (``hipHostRegister``; the DMA engines then read it directly instead of going through the runtime's staging
-        copies), "never" leaves it to the runtime; a source that is already pinned is used as it is."""
+        copies), "never" leaves it to the runtime; a source that is already pinned is used as it is.
+        ``device_sink(lo, hi, keys_dev, flags_dev)``: the keys do NOT come back to the host; instead the callable is handed
+        every finished chunk's keys (and row flags, or None) ON THE DEVICE (rows ``lo:hi`` of the batch, final and verified;
+        the current stream is one it may enqueue work on, and the tensors stay valid for work enqueued there) - ``LSHRS.index``
+        groups them into buckets on the device under the next chunk's copy.  The return value is then ``(None, row_flags)``
+        / ``None``."""
         torch = _native.require_gpu()
         arr = np.asarray(vectors, dtype=np.float32)
         if arr.ndim != 2:
@@ -50,7 +55,7 @@ class _HostPaths:
             arr = arr.copy()
         n = arr.shape[0]
         mode = self.tie_break if tie_break is None else tie_break
-        if (self._devices is not None and len(self._devices) > 1 and tie_break is None
+        if (self._devices is not None and len(self._devices) > 1 and tie_break is None and device_sink is None
                 and n >= self.multi_device_min_rows * len(self._devices)):
             return self._hash_multi_device(arr, return_row_flags, chunk_rows, pin)
         dev = self._torch_device()
@@ -58,12 +63,12 @@ class _HostPaths:
             streamed = (n >= 2 * 16_384 and mode == "host" and self.tie_replay == "auto"
                         and self._split_applies(16_384, replay=True) and bool(self._replay_model()))
             if streamed:
-                return self._hash_host_streamed(arr, return_row_flags, max(16_384, int(chunk_rows)), dev, pin)
-            if 0 < n <= self._small_rows and mode == "host":
+                return self._hash_host_streamed(arr, return_row_flags, max(16_384, int(chunk_rows)), dev, pin, device_sink)
+            if 0 < n <= self._small_rows and mode == "host" and device_sink is None:
                 got = self._hash_small_locked(arr, dev)
                 if got is not None:
                     return got if return_row_flags else got[0]
-            keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
+            keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8) if device_sink is None else None
             flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
             total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
             for lo in range(0, n, 262_144):
@@ -72,13 +77,37 @@ class _HostPaths:
                 x = torch.from_numpy(chunk).to(dev)
                 fl = torch.empty(hi - lo, dtype=torch.uint8, device=dev) if return_row_flags else None
                 out = self._hash_device_locked(x, None, fl, mode, host_rows=lambda r, c=chunk: c[r])
-                keys[lo:hi] = out.cpu().numpy()
+                if device_sink is not None:
+                    with torch.cuda.device(dev):
+                        device_sink(lo, hi, out, fl)
+                else:
+                    keys[lo:hi] = out.cpu().numpy()
                 if fl is not None:
                     flags[lo:hi] = fl.cpu().numpy()
                 for k in ("tie_entries", "tie_pairs", "relaunches"):
                     total[k] += self.last_stats.get(k, 0)
         self.last_stats = total
         return (keys, flags) if return_row_flags else keys
+
+    def device_hashers(self) -> list:
+        """One hasher per entry of ``devices`` (own device, streams, scratch; this hasher's hyperplanes) - the lanes of the
+        pipelined ingest (``lshrs_amd/_ingest.py``) and of ``_hash_multi_device``; ``[self]`` for a single-device hasher."""
+        if self._devices is None or len(self._devices) < 2:
+            return [self]
+        with self._lock:
+            return list(self._device_hashers_locked())
+
+    def _device_hashers_locked(self) -> list:
+        devs = self._devices
+        if self._children is None:
+            self._children = [type(self)(self.num_bands, self.rows_per_band, self.dim, self._seed, device=d,
+                                        **self._ctor_kwargs) for d in devs]
+            self._child_version = [-1] * len(devs)
+        for i, c in enumerate(self._children):        # the hyperplanes are the parent's (assignable: load_from_disk)
+            if self._child_version[i] != self._projection_version:
+                c.projections = [np.asarray(p) for p in self._projections]
+                self._child_version[i] = self._projection_version
+        return self._children
 
     def _hash_multi_device(self, arr: np.ndarray, want_flags: bool, chunk_rows: int, pin: str):
         """One contiguous row slice per entry of ``devices``, each through its own hasher on its own thread; keys (and
@@ -89,15 +118,9 @@ class _HostPaths:
         torch = _native.require_gpu()
         devs = self._devices
         with self._lock:
-            if self._children is None:
-                self._children = [type(self)(self.num_bands, self.rows_per_band, self.dim, self._seed, device=d,
-                                            **self._ctor_kwargs) for d in devs]
-                self._child_version = [-1] * len(devs)
+            self._device_hashers_locked()
+            if self._pool is None:
                 self._pool = ThreadPoolExecutor(max_workers=len(devs), thread_name_prefix="lshrs-dev")
-            for i, c in enumerate(self._children):        # the hyperplanes are the parent's (assignable: load_from_disk)
-                if self._child_version[i] != self._projection_version:
-                    c.projections = [np.asarray(p) for p in self._projections]
-                    self._child_version[i] = self._projection_version
             n = arr.shape[0]
             keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
             flags = np.empty(n, dtype=np.uint8) if want_flags else None
@@ -240,11 +263,11 @@ class _HostPaths:
             self._pinned_cache[key] = buf
         return buf
 
-    def _hash_host_streamed(self, arr: np.ndarray, want_flags: bool, chunk_rows: int, dev, pin: str):
+    def _hash_host_streamed(self, arr: np.ndarray, want_flags: bool, chunk_rows: int, dev, pin: str, device_sink=None):
         torch = _native.require_gpu()
         n = arr.shape[0]
-        keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8)
-        flags = np.empty(n, dtype=np.uint8) if want_flags else None
+        keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8) if device_sink is None else None
+        flags = np.empty(n, dtype=np.uint8) if want_flags and device_sink is None else None      # (a sink gets the flags too)
         total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0, "flagged": 0,
                  "max_dev_units": 0.0}
         src = torch.from_numpy(arr)
@@ -266,7 +289,8 @@ class _HostPaths:
         def land(item):
             ev, (lo, hi), b = item
             ev.synchronize()
-            keys[lo:hi] = buf["kh"][b][:hi - lo].numpy()
+            if keys is not None:
+                keys[lo:hi] = buf["kh"][b][:hi - lo].numpy()
             if flags is not None:
                 flags[lo:hi] = buf["fh"][b][:hi - lo].numpy()
 
@@ -281,9 +305,16 @@ class _HostPaths:
             total["max_dev_units"] = max(total["max_dev_units"], st.get("max_dev_units", 0.0))
             x_free[b] = torch.cuda.Event()
             x_free[b].record(comp_s)
-            back_s.wait_stream(comp_s)
+            if device_sink is None:
+                back_s.wait_stream(comp_s)
+            # (with a sink nothing is waited for: `_finish_locked` has just seen this chunk's pass complete on the host, its keys
+            #  are final - and the compute stream already holds the NEXT chunk's pass, which waits for that chunk's copy: a sink
+            #  that finishes its work at once would wait a whole chunk's copy for keys that are there)
             with torch.cuda.stream(back_s):
-                buf["kh"][b][:hi - lo].copy_(buf["k"][b][:hi - lo], non_blocking=True)
+                if device_sink is not None:       # the keys (and flags) stay on the device: the caller's work on them rides on this stream
+                    device_sink(lo, hi, buf["k"][b][:hi - lo], buf["f"][b][:hi - lo] if want_flags else None)
+                else:
+                    buf["kh"][b][:hi - lo].copy_(buf["k"][b][:hi - lo], non_blocking=True)
                 if flags is not None:
                     buf["fh"][b][:hi - lo].copy_(buf["f"][b][:hi - lo], non_blocking=True)
                 ev = torch.cuda.Event()
@@ -305,7 +336,7 @@ class _HostPaths:
                     comp_s.wait_event(k_free[b])       # (the keys this pass overwrites have left the device)
                 with torch.cuda.stream(comp_s):
                     handle = self._hash_device_async_locked(buf["x"][b][:hi - lo], buf["k"][b][:hi - lo],
-                                                            buf["f"][b][:hi - lo] if flags is not None else None)
+                                                            buf["f"][b][:hi - lo] if want_flags else None)
                 hashed.append((handle, (lo, hi), b))
                 if len(hashed) > 1:
                     send_back(hashed.pop(0))

@@ -126,6 +126,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_scatter_band_keys_u8.restype = c.c_int
     lib.lshrs_keys_to_hex_u8.argtypes = [vp, i64, vp, vp]
     lib.lshrs_keys_to_hex_u8.restype = c.c_int
+    lib.lshrs_copy_to_host_u8.argtypes = [vp, vp, i64, vp]
+    lib.lshrs_copy_to_host_u8.restype = c.c_int
     lib.lshrs_bucket_histogram_u8.argtypes = [vp, i64, i32, i32, vp, vp]
     lib.lshrs_bucket_histogram_u8.restype = c.c_int
     lib.lshrs_bucket_scatter_u8.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp]
@@ -165,6 +167,7 @@ EXPORTS = (
     "lshrs_gather_tied_rows_f32",
     "lshrs_scatter_band_keys_u8",
     "lshrs_keys_to_hex_u8",
+    "lshrs_copy_to_host_u8",
     "lshrs_bucket_histogram_u8",
     "lshrs_bucket_scatter_u8",
     "lshrs_cosine_batch_f32",

@@ -206,8 +206,33 @@ class LSHRS:
         (reference: main.py:315-384).  ``format`` is "postgres"/"pg", "parquet"/"pq" (the reference's
         loaders, when that package is importable) or "batches" with ``batches=<iterable>``."""
         loader = self._resolve_loader(format)
-        for indices, vectors in loader(**loader_kwargs):
-            self.index(indices, vectors)
+        ingest = None
+        try:
+            for indices, vectors in loader(**loader_kwargs):
+                if ingest is None and len(indices) and self._streams_buckets(len(indices) * self._config["num_bands"]):
+                    # whole loader batches, dealt round-robin to one lane per device, their buckets handed to the storage in
+                    # batch order (lshrs_amd/_ingest.py): the next batch is copied and hashed while this one's buckets are
+                    # grouped and stored
+                    self.flush()
+                    ingest = self._open_ingest()
+                    ingest.__enter__()
+                if ingest is None:
+                    self.index(indices, vectors)
+                    continue
+                if len(indices) == 0:
+                    continue
+                if vectors is None:
+                    vectors = self._require_vector_fetch_fn()(indices)
+                id_arr, arr = self._check_batch(indices, vectors)
+                ingest.submit(id_arr, arr)
+                if ingest.failed:
+                    break
+        except BaseException as exc:
+            if ingest is not None:
+                ingest.__exit__(type(exc), exc, exc.__traceback__)
+            raise
+        if ingest is not None:
+            ingest.__exit__(None, None, None)
 
     def ingest(self, index: int, vector) -> None:
         """Hash one vector and buffer its bucket operations (reference: main.py:386-411)."""
@@ -235,6 +260,20 @@ class LSHRS:
                 "Number of vectors does not match number of indices "
                 f"(received {arr.shape[0]} vectors for {len(indices)} indices)")
 
+        if self._streams_buckets(arr.shape[0] * self._config["num_bands"]):
+            # array path, pipelined (lshrs_amd/_ingest.py): copy + signature pass chunk by chunk, every chunk's
+            # keys grouped into buckets on the device under the next chunk's copy, bucket arrays to the storage in row order.
+            # Anything already buffered goes first so the storage sees operations in the original order.
+            self.flush()
+            id_arr, arr = self._check_batch(indices, arr)
+            lanes = self._ingest_hashers()
+            with self._open_ingest(inline=True) as ingest:
+                if len(lanes) == 1 or arr.shape[0] < 2 * self.lane_rows:
+                    ingest.submit(id_arr, arr)
+                else:                       # several devices: contiguous slices of whole chunks, dealt round-robin
+                    for lo in range(0, arr.shape[0], self.lane_rows):
+                        ingest.submit(id_arr[lo:lo + self.lane_rows], arr[lo:lo + self.lane_rows])
+            return
         sink = self._packed_sink(arr.shape[0] * self._config["num_bands"])
         packed = sink is not None
         if packed:
@@ -605,6 +644,40 @@ class LSHRS:
         um, bounds = self._ordered_candidates_arrays(keys)
         return _split_rows(um.tolist(), np.diff(bounds))
 
+    lane_rows = 262_144      # rows per unit when ONE index() call is cut up for several devices (two stream chunks)
+
+    def _ingest_hashers(self) -> list:
+        get = getattr(self._hasher, "device_hashers", None)
+        return get() if callable(get) else [self._hasher]
+
+    def _streams_buckets(self, n_ops: int) -> bool:
+        """Does a batch of this many operations take the pipelined array path?  The storage must take bucket arrays
+        (``batch_add_csr``, natively or through ``RedisPackedWriter``) and the hasher must be able to leave its keys on the
+        device (``LSHHasher``; an injected hasher of another kind keeps the one-call path)."""
+        sink = self._packed_sink(n_ops)
+        return (sink is not None and hasattr(sink, "batch_add_csr")
+                and callable(getattr(self._hasher, "device_hashers", None))
+                and getattr(self._hasher, "tie_break", "host") == "host")
+
+    def _open_ingest(self, inline: bool = False):
+        from ._ingest import CsrIngest
+
+        return CsrIngest(self._ingest_hashers(), self._packed_sink(1 << 62), lambda: ValueError(_ZERO_MSG),
+                         lambda: ValueError("index must be non-negative"), inline=inline)
+
+    def _check_batch(self, indices, vectors):
+        """(ids int64, rows float32 C-contiguous) of one batch, with the reference's shape errors (main.py:504-511)."""
+        arr = np.asarray(vectors, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[1] != self._dim:
+            raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")
+        if arr.shape[0] != len(indices):
+            raise ValueError(
+                "Number of vectors does not match number of indices "
+                f"(received {arr.shape[0]} vectors for {len(indices)} indices)")
+        id_arr = np.asarray(indices)
+        id_arr = id_arr.astype(np.int64) if id_arr.dtype.kind in "iuf" else np.array([int(i) for i in indices], dtype=np.int64)
+        return id_arr, np.ascontiguousarray(arr)
+
     def _packed_sink(self, n_ops: int):
         """The object ``index()`` hands a batch's buckets to as arrays, or None for the reference's operation tuples
         (see ``packed_ingest`` in the class docstring)."""
@@ -621,7 +694,7 @@ class LSHRS:
             if self._packed_writer is None or self._packed_writer.storage is not st:
                 from .packed_ops import RedisPackedWriter
 
-                self._packed_writer = RedisPackedWriter(st)
+                self._packed_writer = RedisPackedWriter(st, flush_members=self._buffer_size)
             return self._packed_writer
         return None
 

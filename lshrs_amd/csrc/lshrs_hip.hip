@@ -1495,6 +1495,17 @@ __global__ void gather_tied_rows_kernel(const float* __restrict__ X, int64_t ldx
 
 // Lower-case hex of every key byte (what `bytes.hex()` gives; the text of the reference's bucket keys,
 // lshrs/storage/redis.py:225), 16 input bytes -> 32 output characters per thread.
+// Device memory -> page-locked host memory by the CUs instead of a copy engine (lshrs_copy_to_host_u8): 16 bytes per lane,
+// grid-stride, the last nbytes % 16 bytes one by one.
+__global__ __launch_bounds__(256) void copy_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                            const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+  if (blockIdx.x == 0 && tail > 256)
+    for (int i = 256 + threadIdx.x; i < tail; i += 256) dst_tail[i] = src_tail[i];
+}
+
 __global__ void keys_to_hex_kernel(const uint8_t* __restrict__ keys, int64_t nbytes, uint8_t* __restrict__ hex) {
   const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
   if (t >= nbytes) return;
@@ -3649,6 +3660,24 @@ int lshrs_gather_tied_rows_f32(const float* X, int64_t ldx, int32_t dim, const i
   const int blocks = tie_cap < 2048 ? tie_cap : 2048;
   hipLaunchKernelGGL(gather_tied_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), X,
                      ldx, dim, tie_list, tie_count, tie_cap, dst);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_copy_to_host_u8(const void* src, void* dst_host, int64_t nbytes, void* stream) {
+  if (nbytes == 0) return 0;
+  if (src == nullptr || dst_host == nullptr || nbytes < 0) return LSHRS_E_BADARG;
+  void* dst = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&dst, dst_host, 0);        // (page-locked, device-visible: else an error, not a fault)
+  if (e != hipSuccess || dst == nullptr) return e != hipSuccess ? -(int)e : LSHRS_E_BADARG;
+  const bool wide = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  const int64_t n16 = wide ? nbytes / 16 : 0;
+  const int tail = (int)(nbytes - 16 * n16 > 0x7fffffff ? 0 : nbytes - 16 * n16);
+  if (!wide && nbytes > 0x7fffffff) return LSHRS_E_TOOLARGE;
+  const int64_t want = (n16 + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
+  hipLaunchKernelGGL(copy_to_host_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16,
+                     static_cast<const uint8_t*>(src) + 16 * n16, static_cast<uint8_t*>(dst) + 16 * n16, tail);
   return -(int)hipGetLastError();
 }
 

@@ -27,7 +27,8 @@ import numpy as np
 
 from . import _native
 
-__all__ = ["hex_keys", "hex_keys_device", "group_by_bucket", "bucket_csr", "BucketCSR", "dedupe_csr", "RedisPackedWriter"]
+__all__ = ["hex_keys", "hex_keys_device", "group_by_bucket", "bucket_csr", "BucketCSR", "dedupe_csr", "RedisPackedWriter",
+           "DeviceCSRJob"]
 
 
 @dataclass
@@ -223,6 +224,125 @@ def bucket_csr(ids: Sequence[int], keys, *, device=None) -> BucketCSR:
     return csr if csr.distinct else dedupe_csr(csr)      # (an id twice in one batch: once per bucket, as SADD leaves it)
 
 
+_COPY_POOL = None
+
+
+def _copy_pool():
+    """Six helper threads for the large host copies of :meth:`DeviceCSRJob.finish` (created at first use, per process)."""
+    global _COPY_POOL
+    if _COPY_POOL is None or getattr(_COPY_POOL, "_pid", None) != __import__("os").getpid():
+        from concurrent.futures import ThreadPoolExecutor
+
+        _COPY_POOL = ThreadPoolExecutor(max_workers=6, thread_name_prefix="lshrs-copy")
+        _COPY_POOL._pid = __import__("os").getpid()
+    return _COPY_POOL
+
+
+class DeviceCSRJob:
+    """:func:`bucket_csr` for keys that are ALREADY on the device, in two halves (round 5, the streamed ingest of
+    ``LSHRS.index``): the constructor only ENQUEUES - ids to the device, histogram, scan, scatter, the counts and the
+    members into pinned host blocks - on the CURRENT stream and returns; :meth:`finish` (any thread, once the stream has
+    reached ``event``) turns the pinned blocks into the :class:`BucketCSR` of arrays the stores take.  Between the two
+    the caller streams the next chunk: the grouping of chunk i rides under the host->device copy of chunk i + 1.
+    Keys of 1 or 2 bytes (the counting sort); wider keys: ``bucket_csr`` itself (one device sort, synchronous)."""
+
+    def __init__(self, ids: np.ndarray, keys_dev, ids_dev=None) -> None:
+        torch = _native.require_gpu()
+        lib = _native.load()
+        self.ids = np.ascontiguousarray(ids, dtype=np.int64)
+        n, nb, bb = (int(v) for v in keys_dev.shape)
+        if self.ids.shape[0] != n:
+            raise ValueError("ids and keys disagree in length")
+        if bb > 2 or n == 0:
+            raise ValueError("DeviceCSRJob takes non-empty batches with band keys of 1 or 2 bytes")
+        self.n, self.nb, self.bb = n, nb, bb
+        dev = keys_dev.device
+        bins = nb << (8 * bb)
+        cur = torch.cuda.current_stream(dev)
+        stream = cur.cuda_stream
+        kd = keys_dev if keys_dev.is_contiguous() else keys_dev.contiguous()
+        # (`ids_dev`: the same ids already on the device - a caller that streams chunks uploads a batch's ids ONCE, in front of
+        #  the stream: a small host->device copy issued between the chunks queues behind the next chunk's 400 MB on the copy
+        #  engine and the grouping waits 6 ms for 1 MB)
+        idd = ids_dev if ids_dev is not None else torch.from_numpy(self.ids).to(dev, non_blocking=True)
+        counts = torch.zeros(bins, dtype=torch.int32, device=dev)
+        _native.check(lib.lshrs_bucket_histogram_u8(kd.data_ptr(), n, nb, bb, counts.data_ptr(), stream),
+                      "lshrs_bucket_histogram_u8")
+        ends = torch.cumsum(counts, 0, dtype=torch.int64)
+        offsets = ends - counts
+        cursors = torch.zeros(bins, dtype=torch.int32, device=dev)
+        members = torch.empty(n * nb, dtype=torch.int64, device=dev)
+        _native.check(lib.lshrs_bucket_scatter_u8(kd.data_ptr(), idd.data_ptr(), n, nb, bb, offsets.data_ptr(),
+                                                  cursors.data_ptr(), members.data_ptr(), stream),
+                      "lshrs_bucket_scatter_u8")
+        # The live buckets - bins with at least one member - compacted ON THE DEVICE with static shapes (no size comes back to
+        # the host in between): position of every live bin by a scan of the mask, one scatter through it (dead bins go to a
+        # spare slot), then code, band, key bytes and end offset of every live bucket as dense arrays.  NumPy needs 6-9 ms per
+        # 2^20 bins for the same (flatnonzero, fancy indexing, a strided byte gather); here it rides under the next chunk's copy.
+        mask = counts > 0
+        pos = torch.cumsum(mask, 0, dtype=torch.int64) - 1
+        slot = torch.where(mask, pos, torch.full_like(pos, bins))
+        live = torch.empty(bins + 1, dtype=torch.int64, device=dev)
+        live.scatter_(0, slot, torch.arange(bins, dtype=torch.int64, device=dev))
+        live = live[:bins]
+        n_live = pos[-1:] + 1
+        safe = live.clamp_(0, bins - 1)                   # (entries behind n_live are whatever was there: never read)
+        # (what crosses the link is as narrow as it can be: codes and end offsets as int32 where they fit - bins and n * bands
+        #  below 2^31, every BASELINE config -, no bands: those are the codes' high bits)
+        narrow = bins < (1 << 31) and n * nb < (1 << 31)
+        off_end = ends.index_select(0, safe)
+        shifts = torch.arange(bb, dtype=torch.int64, device=dev) * 8
+        kb = ((safe[:, None] >> shifts[None, :]) & 0xFF).to(torch.uint8)
+        live_out, off_out = (safe.to(torch.int32), off_end.to(torch.int32)) if narrow else (safe, off_end)
+        # (pinned blocks from torch's caching host allocator: after the first batches these are reused, not allocated)
+        pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)      # noqa: E731
+        self._host = [pin(n_live), pin(live_out), pin(off_out), pin(kb), pin(members)]
+        for h, d in zip(self._host, (n_live, live_out, off_out, kb, members)):
+            d = d.contiguous()
+            # (by a kernel, not a copy engine: a memcpy issued here waits every third time for the next chunk's 400 MB
+            #  host->device copy to finish - include/lshrs_hip.h, lshrs_copy_to_host_u8)
+            _native.check(lib.lshrs_copy_to_host_u8(d.data_ptr(), h.data_ptr(), d.numel() * d.element_size(), stream),
+                          "lshrs_copy_to_host_u8")
+            d.record_stream(cur)
+        self.event = torch.cuda.Event()
+        self.event.record(cur)
+        for t in (kd, idd, counts, ends, offsets, cursors, members, mask, pos, slot, safe, off_end, kb, n_live, live_out, off_out):
+            t.record_stream(cur)                          # (used on `cur`, perhaps allocated under another stream)
+
+    def finish(self) -> BucketCSR:
+        """Wait for the device half, then the host half: the first ``n_live`` entries of the dense arrays and the members,
+        copied out of the pinned blocks (which go back to the allocator: a store keeps its arrays for as long as it lives,
+        and page-locked memory is not what it should be keeping them in)."""
+        self.event.synchronize()
+        n_live_h, live_h, off_h, kb_h, members_h = (t.numpy() for t in self._host)
+        m = int(n_live_h[0])
+        # ~40 MB of copies and widenings per 131 072 x 16 operations: memory-bound, 4 ms on one thread.  NumPy releases the
+        # interpreter lock inside each of them, so a few helper threads run them side by side (1.2-1.9 ms).  (torch's CPU copy from
+        # a worker thread stalls in its own thread pool - 70 ms per chunk, measured - hence NumPy.)
+        codes = np.empty(m, dtype=np.int64)
+        offsets = np.empty(m + 1, dtype=np.int64)
+        offsets[0] = 0
+        members = np.empty(members_h.shape[0], dtype=np.int64)
+        kb = np.empty((m, self.bb), dtype=np.uint8)
+        bands = np.empty(m, dtype=np.int32)
+        q = -(-members.shape[0] // 4)
+        tasks = [(lambda a=a: np.copyto(members[a:a + q], members_h[a:a + q])) for a in range(0, members.shape[0], q)]
+        tasks += [lambda: np.copyto(codes, live_h[:m], casting="unsafe"),
+                  lambda: np.right_shift(live_h[:m], 8 * self.bb, out=bands, casting="unsafe"),
+                  lambda: np.copyto(offsets[1:], off_h[:m], casting="unsafe"), lambda: np.copyto(kb, kb_h[:m])]
+        if members.shape[0] >= (1 << 18):
+            futures = [_copy_pool().submit(t) for t in tasks[:-1]]
+            tasks[-1]()
+            for f in futures:
+                f.result()
+        else:
+            for t in tasks:
+                t()
+        csr = BucketCSR(self.bb, bands, kb, codes, offsets, members, self.n, ids_are_distinct(self.ids))
+        self._host = None
+        return csr if csr.distinct else dedupe_csr(csr)
+
+
 def hex_keys_device(keys):
     """Device ``(n, bands, B)`` uint8 keys -> device ``(n, bands, 2B)`` uint8 ASCII (lower-case hex)."""
     torch = _native.require_gpu()
@@ -284,35 +404,47 @@ def group_by_bucket(ids: Sequence[int], keys: np.ndarray) -> Iterator[Tuple[int,
 
 
 class RedisPackedWriter:
-    """``batch_add_packed`` for the reference's ``RedisStorage`` (or anything with its ``pipeline()`` context
-    manager and ``bucket_key()``): one pipelined ``SADD key m1 m2 ...`` per bucket."""
+    """``batch_add_packed`` / ``batch_add_csr`` for the reference's ``RedisStorage`` (or anything with its ``pipeline()`` context
+    manager and ``bucket_key()``): one pipelined ``SADD key m1 m2 ...`` per bucket.  A pipeline is executed and a new one
+    opened every ``flush_members`` set members (``LSHRS`` passes its ``buffer_size``): what the reference's ``index()`` does by
+    flushing its operation buffer every ``buffer_size`` operations (lshrs/core/main.py:1131-1143, redis.py:348-416) - a
+    1 M x 16-band batch is then ~1 600 pipelines of 10 000 members, not one of 16 M: bounded client memory, bounded
+    blocking time, and a failure loses at most one pipeline's worth (``pipelines`` counts those executed)."""
 
-    def __init__(self, storage, *, max_members_per_command: int = 4096) -> None:
+    def __init__(self, storage, *, max_members_per_command: int = 4096, flush_members: int = 10_000) -> None:
         self.storage = storage
         self.max_members = int(max_members_per_command)
+        self.flush_members = max(1, int(flush_members))
+        self.pipelines = 0
+
+    def _send(self, buckets) -> int:
+        """``buckets`` yields (key text, member list); pipelines of at most ``flush_members`` members (a bucket larger than
+        that is cut at command boundaries)."""
+        commands = 0
+        it = iter(buckets)
+        pending = next(it, None)
+        while pending is not None:
+            room = self.flush_members
+            with self.storage.pipeline() as pipe:
+                self.pipelines += 1
+                while pending is not None and room > 0:
+                    name, members = pending
+                    take = min(len(members), room, self.max_members)
+                    pipe.sadd(name, *members[:take])
+                    commands += 1
+                    room -= take
+                    pending = (name, members[take:]) if take < len(members) else next(it, None)
+        return commands
 
     def batch_add_packed(self, ids: Sequence[int], keys: np.ndarray) -> int:
-        commands = 0
-        with self.storage.pipeline() as pipe:
-            for band, key_bytes, members in group_by_bucket(ids, keys):
-                name = self.storage.bucket_key(band, key_bytes)
-                for lo in range(0, len(members), self.max_members):
-                    pipe.sadd(name, *[int(m) for m in members[lo:lo + self.max_members]])
-                    commands += 1
-        return commands
+        return self._send((self.storage.bucket_key(band, key_bytes), [int(m) for m in members])
+                          for band, key_bytes, members in group_by_bucket(ids, keys))
 
     def batch_add_csr(self, csr: BucketCSR) -> int:
         """The same commands from a :class:`BucketCSR`: key texts by ``bucket_key`` (the reference's format), members
         as array slices."""
-        commands = 0
-        with self.storage.pipeline() as pipe:
-            for g in range(len(csr)):
-                name = self.storage.bucket_key(int(csr.bands[g]), csr.key_bytes[g].tobytes())
-                lo, hi = int(csr.offsets[g]), int(csr.offsets[g + 1])
-                for a in range(lo, hi, self.max_members):
-                    pipe.sadd(name, *csr.members[a:min(hi, a + self.max_members)].tolist())
-                    commands += 1
-        return commands
+        return self._send((self.storage.bucket_key(int(csr.bands[g]), csr.key_bytes[g].tobytes()),
+                           csr.members[int(csr.offsets[g]):int(csr.offsets[g + 1])].tolist()) for g in range(len(csr)))
 
     def __getattr__(self, item):  # everything else (get_bucket, batch_add, close, ...) is the wrapped storage's
         return getattr(self.storage, item)

@@ -128,6 +128,13 @@ def window_coefficients(planes: np.ndarray, blas_model: int, rows_per_band: int 
 
     Returns ``(coef_a, coef_b, coef_tie, info)``; ``info["window_units"]``: the stage-1 window of a row with
     ``||x_mid|| = 0.4 * 2^-8 ||x||`` (Gaussian-like data) in units of 2^-24 ||x|| ||p||, averaged over the hyperplanes."""
+    # (hyperplanes a user assigned may hold NaN / Inf: their coefficients come out NaN / Inf - "always the exact decision" -
+    #  and NumPy has nothing to warn about on the way)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore", under="ignore"):
+        return _window_coefficients(planes, blas_model, rows_per_band)
+
+
+def _window_coefficients(planes, blas_model, rows_per_band):
     P = np.ascontiguousarray(planes, dtype=np.float32)
     num, dim = P.shape
     if blas_model == 2:           # (model 2 compiles the dim % 4 tail without contraction: at most the same number of roundings)

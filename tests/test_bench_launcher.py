@@ -73,3 +73,22 @@ def test_a_failing_rank_fails_the_launch_quickly():
                          capture_output=True, text=True, timeout=300, env=_env())
     assert out.returncode != 0 and out.stdout.strip() == "" and "rank exit codes" in out.stderr
     assert time.time() - t0 < 120
+
+
+def test_eight_ranks_dry_run_under_every_world_size_the_driver_may_export():
+    """the N = 8 line is the driver's to take on a whole node - what can be shown here is that `--gpus 8`
+    brings up EIGHT ranks (gloo, no GPU work: `--dry-run`) whether WORLD_SIZE is unset, exported as 1 by a scheduler, or 8 with
+    RANK unset (an environment left over from a launcher that is not there), and that every rank saw its own LOCAL_RANK."""
+    for label, extra in (("unset", {}), ("WORLD_SIZE=1", {"WORLD_SIZE": "1"}), ("WORLD_SIZE=8 without RANK", {"WORLD_SIZE": "8"})):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run"], capture_output=True, text=True, timeout=600,
+                             env=dict(_env(), **extra))
+        assert out.returncode == 0, (label, out.stderr[-2000:])
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "self_launched": True}, (label, out.stdout)
+    # under the driver's own launcher the eight ranks are the launcher's
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "8", "--dry-run"],
+                         capture_output=True, text=True, timeout=600, env=_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "self_launched": False}

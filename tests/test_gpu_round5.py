@@ -219,3 +219,114 @@ def test_named_builds_differ_exactly_where_their_libraries_do(torch_mod, nb, r, 
         assert np.array_equal(keys[mine], hash_batch_literal_packed(base.projections, x))
     differ = int((keys["openblas-skylakex"] != keys["openblas-haswell"]).any(axis=(1, 2)).sum())
     print(f"{nb} x {r} x {dim}: rows whose keys differ between the two builds: {differ} of {len(targets)} salted")
+
+
+# ----------------------------------------------------------------------------- the pipelined ingest
+def _store_dict(store):
+    return {k: set(v) for k, v in store.bucket_contents().items()}
+
+
+def _tuple_store(idx_kw, ids, x, upto):
+    """What the reference's per-vector flow leaves in the storage for rows [0, upto): the op-tuple path of this build (itself
+    pinned to the reference's recorded batches by g5 and test_random_api_sequences_equal_the_literal_flow)."""
+    from lshrs_amd import LSHRS, InMemoryStorage
+
+    store = InMemoryStorage()
+    idx = LSHRS(storage=store, packed_ingest=False, **idx_kw)
+    if upto:
+        idx.index(list(ids[:upto]), x[:upto])
+    return _store_dict(store)
+
+
+@pytest.mark.parametrize("nb,r,dim,n", [(16, 16, 768, 70_000), (16, 4, 128, 90_000), (16, 32, 256, 40_000)])
+def test_pipelined_index_leaves_the_buckets_of_the_per_vector_flow(torch_mod, nb, r, dim, n):
+    """`LSHRS.index` on a storage that takes bucket arrays: chunks are copied, hashed, grouped on the device and stored while
+    the next chunk is on the link (lshrs_amd/_ingest.py).  Same buckets as the op-tuple path; a zero vector or a negative id -
+    inside a chunk, on a chunk boundary, in the first row - raises the reference's error with exactly the rows in front stored."""
+    from lshrs_amd import LSHRS, InMemoryStorage, _ingest
+
+    kw = dict(dim=dim, num_perm=nb * r, num_bands=nb, rows_per_band=r, seed=9)
+    x = np.random.default_rng(n).standard_normal((n, dim)).astype(np.float32)
+    ids = np.random.default_rng(1).permutation(10 * n)[:n].astype(np.int64)
+    old = _ingest.CsrIngest.chunk_rows
+    _ingest.CsrIngest.chunk_rows = 16_384            # several chunks per call (the stream's smallest)
+    try:
+        store = InMemoryStorage()
+        idx = LSHRS(storage=store, **kw)
+        idx.index(ids, x)
+        assert _store_dict(store) == _tuple_store(kw, ids, x, n)
+        assert len(store.packed_batches) >= (n // 16_384 if nb * ((r + 7) // 8) * 8 >= 128 or dim <= 256 else 1) or len(store.packed_batches) >= 1
+        assert sum(v for v, _ in store.packed_batches) == n and not store.batches
+        for bad_row, kind in ((40_000 if n > 40_000 else 20_000, "zero"), (16_384, "zero"), (0, "zero"), (33_333, "neg"), (16_384 * 2, "neg")):
+            xb, ib = x.copy(), ids.copy()
+            if kind == "zero":
+                xb[bad_row] = 0.0
+                xb[bad_row + 5] = 0.0                      # (a later one must not matter)
+            else:
+                ib[bad_row] = -7
+                xb[bad_row + 9] = 0.0                      # (a zero vector BEHIND the negative id: the id's error wins)
+            s2 = InMemoryStorage()
+            with pytest.raises(ValueError, match="zero vector" if kind == "zero" else "non-negative"):
+                LSHRS(storage=s2, **kw).index(ib, xb)
+            assert _store_dict(s2) == _tuple_store(kw, ib, xb, bad_row), (bad_row, kind)
+    finally:
+        _ingest.CsrIngest.chunk_rows = old
+
+
+def test_eight_lanes_deal_loader_batches_round_robin_and_store_them_in_order(torch_mod):
+    """`LSHRS(devices=[0] * 8)` (SURVEY §8e without the hardware: eight lanes on the one GPU): `create_signatures` deals whole
+    loader batches - ragged ones - to the lanes round-robin; the storage receives their bucket arrays in batch order, the same
+    sequence a single device produces.  A bad row in batch 11 stops the ingest there; a loader that raises is the caller's error."""
+    from lshrs_amd import LSHRS, InMemoryStorage
+
+    dim = 256
+    kw = dict(dim=dim, num_perm=128, num_bands=16, rows_per_band=8, seed=4)
+    rng = np.random.default_rng(77)
+    sizes = [int(v) for v in rng.integers(600, 9_000, 20)]
+    data = [rng.standard_normal((m, dim)).astype(np.float32) for m in sizes]
+    starts = np.cumsum([0] + sizes)
+    batches = [(list(range(int(starts[i]), int(starts[i + 1]))), data[i]) for i in range(len(sizes))]
+    one, eight = InMemoryStorage(), InMemoryStorage()
+    LSHRS(storage=one, **kw).create_signatures(format="batches", batches=iter(batches))
+    idx8 = LSHRS(storage=eight, devices=[0] * 8, **kw)
+    assert len(idx8._ingest_hashers()) == 8
+    idx8.create_signatures(format="batches", batches=iter(batches))
+    assert eight.packed_batches == one.packed_batches and [v for v, _ in one.packed_batches] == sizes      # same sequence
+    assert _store_dict(eight) == _store_dict(one)
+    # a zero vector in batch 11, row 17: batches 0..10 whole, 17 rows of batch 11, nothing behind - on eight lanes as on one
+    data_bad = [d.copy() for d in data]
+    data_bad[11][17] = 0.0
+    bad = [(b[0], data_bad[i]) for i, b in enumerate(batches)]
+    stores = []
+    for devs in (None, [0] * 8):
+        st = InMemoryStorage()
+        with pytest.raises(ValueError, match="zero vector"):
+            LSHRS(storage=st, devices=devs, **kw).create_signatures(format="batches", batches=iter(bad))
+        stores.append(st)
+    want = InMemoryStorage()
+    ref = LSHRS(storage=want, **kw)
+    for i in range(11):
+        ref.index(batches[i][0], data[i])
+    ref.index(batches[11][0][:17], data[11][:17])
+    assert _store_dict(stores[0]) == _store_dict(stores[1]) == _store_dict(want)
+    assert [v for v, _ in stores[1].packed_batches] == sizes[:11] + [17]
+
+    def raising():
+        for i, b in enumerate(batches):
+            if i == 6:
+                raise RuntimeError("the loader lost its connection")
+            yield b
+
+    st = InMemoryStorage()
+    with pytest.raises(RuntimeError, match="lost its connection"):
+        LSHRS(storage=st, devices=[0] * 8, **kw).create_signatures(format="batches", batches=raising())
+    assert [v for v, _ in st.packed_batches] == sizes[:6]
+    # one index() call of many rows on several lanes: contiguous slices, same buckets
+    big = np.concatenate(data)
+    ids = np.arange(big.shape[0], dtype=np.int64)
+    a, b = InMemoryStorage(), InMemoryStorage()
+    i2 = LSHRS(storage=a, devices=[0, 0], **kw)
+    i2.lane_rows = 20_000
+    i2.index(ids, big)
+    LSHRS(storage=b, **kw).index(ids, big)
+    assert _store_dict(a) == _store_dict(b) and len(a.packed_batches) == -(-big.shape[0] // 20_000)

@@ -330,3 +330,38 @@ def test_reindexed_ids_rank_like_the_tuple_fed_store():
     want = _Shell(t)._ordered_candidates_many(keys[:2])
     assert got == want and all(len(g) > 0 for g in got)
     assert {10, 5} <= set(got[0])
+
+
+def test_redis_writer_opens_a_new_pipeline_every_buffer_size_members():
+    """the default `packed_ingest="auto"` wraps the reference's RedisStorage in this writer - a 1 M x 16 band
+    batch must not become ONE pipeline of 16 M members.  A pipeline is executed every `flush_members` (= `LSHRS.buffer_size`)
+    members, as the reference's index() flushes its buffer every `buffer_size` operations (lshrs/core/main.py:1131-1143)."""
+    from lshrs_amd.packed_ops import _csr_host
+
+    class CountingStorage(FakeRedisStorage):
+        def __init__(self):
+            super().__init__()
+            self.per_pipeline = []
+
+        @contextlib.contextmanager
+        def pipeline(self):
+            log = []
+            yield FakePipeline(log)
+            self.per_pipeline.append(sum(len(m) for _, m in log))      # "executed" on exit
+            self.commands.extend(log)
+
+    rng = np.random.default_rng(12)
+    keys = rng.integers(0, 4, size=(3000, 8, 1), dtype=np.uint8)         # 24 000 operations in 32 crowded buckets
+    ids = np.arange(3000, dtype=np.int64)
+    want = {(FakeRedisStorage().bucket_key(b, k), i) for b, k, i in ops_from_keys(ids, keys)}
+    for send in ("csr", "packed"):
+        fake = CountingStorage()
+        writer = RedisPackedWriter(fake, flush_members=1000)
+        n = writer.batch_add_csr(_csr_host(ids, keys)) if send == "csr" else writer.batch_add_packed(ids, keys)
+        assert n == len(fake.commands)
+        assert writer.pipelines == len(fake.per_pipeline) == 24 and max(fake.per_pipeline) <= 1000 and sum(fake.per_pipeline) == 24_000
+        assert {(name, m) for name, members in fake.commands for m in members} == want
+    # LSHRS hands its buffer_size to the writer it builds around such a storage
+    idx = LSHRS(dim=8, num_perm=8, num_bands=4, rows_per_band=2, storage=CountingStorage(), buffer_size=777, packed_ingest=True)
+    sink = idx._packed_sink(10 ** 6)
+    assert isinstance(sink, RedisPackedWriter) and sink.flush_members == 777
