@@ -51,6 +51,7 @@ uint32_t lshrs_build_flags(void);
  *   clock_probe device u64[2 * 2 * workgroups]: the first wide-geometry launch of the call stores per workgroup the
  *               {shader-clock, 100 MHz} tick counts of its main loop (first half) and of the whole workgroup (second
  *               half; split pass only): in-kernel clock = ratio x 100 MHz (MI355X_MICROARCH.md, DVFS item 6). */
+struct lshrs_sig_sort;
 typedef struct lshrs_sig_opts {
   uint32_t struct_bytes;   /* sizeof(lshrs_sig_opts): lets the struct grow without breaking old callers */
   uint32_t reserved;       /* 0 */
@@ -59,7 +60,24 @@ typedef struct lshrs_sig_opts {
   void* ev_stage2_start;
   void* ev_stage2_stop;
   void* clock_probe;
+  const struct lshrs_sig_sort* sort;   /* ABI 6: scratch for the column-sorted stage 2 (below), or NULL */
 } lshrs_sig_opts;
+
+/* Scratch that lets stage 2 of lshrs_sig_hash_batch_split_replay_f32 work through the flagged projections COLUMN BY COLUMN
+ * (ABI 6; optional - the keys are the same with or without it, this is speed): the stage-1 list is counting-sorted by
+ * padded column on the device (three small launches), and every group of eight entries stage 2 takes then shares one
+ * hyperplane, fetched once into LDS instead of eight times from L2 - the row gather of x is the only stream left.  Pays
+ * where the list is long and the rows are (config 5: 2.35 M entries of 1536 elements); the library uses it when given, for
+ * hashers of at most 1024 padded key columns whose rows are longer than four k-tiles.
+ *   list  DEVICE int64[cap], y DEVICE float[cap]   cap >= flag_cap + 8 * padded columns (runs are padded to groups of eight)
+ *   hist  DEVICE int32[256 * padded columns + 1]   per-workgroup column histograms; the last word: entries incl. padding */
+typedef struct lshrs_sig_sort {
+  uint32_t struct_bytes;   /* sizeof(lshrs_sig_sort) */
+  int32_t cap;
+  int64_t* list;
+  float* y;
+  int32_t* hist;
+} lshrs_sig_sort;
 
 /* Audit of what stage 1 of the split pass does NOT send to the exact decision (optional, NULL = none).  The proven window
  * rests on a bit-exact model of v_mfma_f32_16x16x32_bf16; stage 2 measures |y1 - y_hostBLAS| on every projection stage 1

@@ -226,15 +226,33 @@ class SigOpts(ctypes.Structure):
     _fields_ = [("struct_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
                 ("ev_stage1_start", ctypes.c_void_p), ("ev_stage1_stop", ctypes.c_void_p),
                 ("ev_stage2_start", ctypes.c_void_p), ("ev_stage2_stop", ctypes.c_void_p),
-                ("clock_probe", ctypes.c_void_p)]
+                ("clock_probe", ctypes.c_void_p), ("sort", ctypes.c_void_p)]
 
-    def __init__(self, events=None, clock_probe=None):
+    def __init__(self, events=None, clock_probe=None, sort=None):
         super().__init__()
         self.struct_bytes = ctypes.sizeof(SigOpts)
         if events is not None:
             (self.ev_stage1_start, self.ev_stage1_stop, self.ev_stage2_start, self.ev_stage2_stop) = events
         if clock_probe is not None:
             self.clock_probe = clock_probe
+        self.set_sort(sort)
+
+    def set_sort(self, sort) -> None:
+        """Attach (or detach) the scratch of the column-sorted stage 2; the SigSort object must outlive the call it is passed to."""
+        self._sort_ref = sort
+        self.sort = ctypes.addressof(sort) if sort is not None else None
+
+
+class SigSort(ctypes.Structure):
+    """``lshrs_sig_sort`` of include/lshrs_hip.h: scratch for the column-sorted stage 2."""
+
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("cap", ctypes.c_int32), ("list", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("hist", ctypes.c_void_p)]
+
+    def __init__(self, list_ptr: int, y_ptr: int, hist_ptr: int, cap: int):
+        super().__init__()
+        self.struct_bytes = ctypes.sizeof(SigSort)
+        self.list, self.y, self.hist, self.cap = list_ptr, y_ptr, hist_ptr, int(cap)
 
 
 class SigAudit(ctypes.Structure):

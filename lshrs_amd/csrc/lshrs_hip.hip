@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <math.h>
 
 #include "lshrs_hip.h"
@@ -729,6 +730,11 @@ struct FixArgs {
   const float* audit_vals;     // replayed like the flagged ones behind them, nothing patched - only compared
   int audit_n;
   int tail_model;         // sig_fixany_kernel: how the host compiles the dim % 4 elements behind the last group of four (1 / 2)
+  // the list sorted by padded column (lshrs_sig_sort, SAMEP instantiations): every group of eight entries has ONE column, runs
+  // padded to whole groups with -1; sorted_y: the entries' stage-1 values in that order; sorted_count: entries incl. padding
+  const int64_t* sorted_list;
+  const float* sorted_y;
+  const int* sorted_count;
 };
 constexpr int kFixParts = 6;
 
@@ -819,15 +825,22 @@ static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridG <= LSHRS_SIG_DEVICE_COU
 // are fetched from its start and read as zero, and a vector of 8 m + 4 elements gives its first four to the low lanes
 // before the tiles begin AT the fifth (the library's order: lshrs_tb_model_row_dot).  The common shapes (16 x 16 x 768 ...)
 // keep the plain loop.
-template <bool REPLAY, bool GENERAL = false, int SLAB = kFixSlabG>
+// SAMEP (REPLAY only; round 5): the list comes SORTED BY COLUMN (fix_sort_* below), every group of eight entries shares one
+// hyperplane - its row is fetched ONCE per slab (one LDS-DMA of SLAB x 128 bytes by 8 SLAB lanes) and read by all eight entries
+// from the same LDS words, instead of eight times from L2: the x rows are then the only stream (72.6 against 98.7 us per 115 k
+// entries at 768-d, profiles/r03_stage2_streams.log).  The audit sample is not sorted: it keeps the plain instantiation.
+template <bool REPLAY, bool GENERAL = false, int SLAB = kFixSlabG, bool SAMEP = false>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
+  static_assert(!SAMEP || (REPLAY && SLAB * 8 <= 64), "the shared hyperplane slab is one LDS-DMA of the wave");
   __shared__ __attribute__((aligned(16))) f32x4 xs[2][SLAB * 8 * kFixG];
-  __shared__ __attribute__((aligned(16))) f32x4 ps[2][SLAB * 8 * kFixG];
+  __shared__ __attribute__((aligned(16))) f32x4 ps[2][SAMEP ? 64 : SLAB * 8 * kFixG];
   const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
   const int shh = sub >> 2, sq = sub & 3;           // this lane's chunk of every k-tile: k = 32 t + 16 shh + 4 sq + 0..3
-  const int cnt = min(*a.flag_count, a.flag_cap);
+  const int64_t* __restrict__ list = SAMEP ? a.sorted_list : a.flag_list;
+  const float* __restrict__ ylist = SAMEP ? a.sorted_y : a.flag_y;
+  const int cnt = SAMEP ? *a.sorted_count : min(*a.flag_count, a.flag_cap);
   const int fgroups = (cnt + kFixG - 1) / kFixG;
-  const int groups = fgroups + (REPLAY && a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);   // audit groups behind the list's
+  const int groups = fgroups + (!SAMEP && REPLAY && a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);   // audit groups behind the list's
   const size_t ldp = (size_t)a.ktiles * kKTile;
   const int head = GENERAL ? (a.dim & 4) : 0;                 // 8 m + 4 elements: the first four go ahead of the tiles
   const int body = GENERAL ? a.dim - head : a.ktiles * kKTile; // elements the tiles cover (from element `head` on)
@@ -846,7 +859,11 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     if (!it.audit) {
       it.e = grp * kFixG + g;
       inlist = it.e < cnt;
-      item = a.flag_list[inlist ? it.e : grp * kFixG];
+      item = list[inlist ? it.e : grp * kFixG];
+      if (SAMEP && item < 0) {                       // padding behind a column's run: the group's first entry, fetched, never used
+        inlist = false;
+        item = list[grp * kFixG];
+      }
     } else {
       it.e = (grp - fgroups) * kFixG + g;
       item = it.e < a.audit_n ? a.audit_list[it.e] : -1;
@@ -878,9 +895,16 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)xsrc, (LDS_AS void*)(xs[buf] + i * 64), 16, 0, 0);
 #endif
 #ifndef LSHRS_AB_FIX_NO_P
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.pg + (size_t)t * kKTile), (LDS_AS void*)(ps[buf] + i * 64),
-                                       16, 0, 0);
+      if (!SAMEP)
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(it.pg + (size_t)t * kKTile), (LDS_AS void*)(ps[buf] + i * 64),
+                                         16, 0, 0);
 #endif
+    }
+    if (SAMEP) {      // the group's ONE hyperplane: lane L brings chunk L & 7 of the slab's tile L >> 3 (lanes past the slab: its last)
+      const int ti = (lane >> 3) < SLAB ? (lane >> 3) : SLAB - 1;
+      const int t = slab * SLAB + ti < kt ? slab * SLAB + ti : kt - 1;
+      const float* psrc = a.prow + (size_t)it.col * ldp + head + (size_t)t * kKTile + 4 * (lane & 7);
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)psrc, (LDS_AS void*)ps[buf], 16, 0, 0);
     }
   };
   int grp = blockIdx.x;                             // uniform per wave
@@ -919,7 +943,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
 #if defined(LSHRS_AB_FIX_NO_X) || defined(LSHRS_AB_FIX_NO_P)
       if (more) wait_vmcnt<SLAB>();
 #else
-      if (more) wait_vmcnt<2 * SLAB>();        // this slab has landed, the next one is on its way
+      if (more) wait_vmcnt<SAMEP ? SLAB + 1 : 2 * SLAB>();        // this slab has landed, the next one is on its way
 #endif
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (REPLAY) {
@@ -934,8 +958,9 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
               const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
+              const int op = SAMEP ? (t * 8 + 2 * m + (sub >> 2)) * 4 + (sub & 3) : o;     // (shared slab: no entry index)
               const float xv = xf[o];
-              pj = __builtin_fmaf(pf[o], xv, pj);
+              pj = __builtin_fmaf(pf[op], xv, pj);
               ss = __builtin_fmaf(xv, xv, ss);
             }
           }
@@ -945,16 +970,18 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
               const int o = ((t * 8 + 2 * m + (sub >> 2)) * kFixG + g) * 4 + (sub & 3);
+              const int op = SAMEP ? (t * 8 + 2 * m + (sub >> 2)) * 4 + (sub & 3) : o;
               // past the row's end BOTH factors read as zero: what the fetch brought there is the neighbouring hyperplane's
               // (or the window block's) and may be anything - 0 * Inf would poison a column whose own value is finite
               const bool in = kb0 + 8 * m + sub < body;
-              const float xv = in ? xf[o] : 0.f, pv = in ? pf[o] : 0.f;
+              const float xv = in ? xf[o] : 0.f, pv = in ? pf[op] : 0.f;
               ss = __builtin_fmaf(xv, xv, ss);
               if (kind == 1) {              // chain l = sub & 3 takes k = 8 m + l, then k = 8 m + 4 + l
                 const int o0 = ((t * 8 + 2 * m) * kFixG + g) * 4 + (sub & 3), o1 = o0 + kFixG * 4;
+                const int p0 = SAMEP ? (t * 8 + 2 * m) * 4 + (sub & 3) : o0, p1 = SAMEP ? p0 + 4 : o1;
                 const int kl = kb0 + 8 * m + (sub & 3);
-                pj = mul_then_add(pj, kl < body ? pf[o0] : 0.f, kl < body ? xf[o0] : 0.f);
-                pj = mul_then_add(pj, kl + 4 < body ? pf[o1] : 0.f, kl + 4 < body ? xf[o1] : 0.f);
+                pj = mul_then_add(pj, kl < body ? pf[p0] : 0.f, kl < body ? xf[o0] : 0.f);
+                pj = mul_then_add(pj, kl + 4 < body ? pf[p1] : 0.f, kl + 4 < body ? xf[o1] : 0.f);
               } else if (kind == 2) {
                 pj = mul_then_add(pj, pv, xv);
               } else {
@@ -1021,9 +1048,9 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       const float scale = sqrtf(ss) * a.norms[col];                        // ||x|| ||p||
       if (__builtin_fabsf(yb) < a.tau * sqrtf(ss) * a.tie_coef[col]) ++n_ties;   // statistics: projections inside the tie window
       if (want != have) ++n_flips;
-      if (a.flag_y != nullptr && scale > 0.f) {
+      if (ylist != nullptr && scale > 0.f) {
         // the live margin of stage 1: how far its value was from the host BLAS's, in the units its window is given in
-        const float dev = __builtin_fabsf(a.flag_y[e] - yb) / (scale * 0x1p-24f);
+        const float dev = __builtin_fabsf(ylist[e] - yb) / (scale * 0x1p-24f);
         if (dev < __builtin_inff()) max_dev = __builtin_fmaxf(max_dev, dev);   // (NaN - a row flagged wholesale - drops out)
       }
     }
@@ -1068,6 +1095,77 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       p[4] = n_abad;
       p[5] = __float_as_int(max_ratio);
     }
+  }
+}
+
+// ---- The stage-1 list sorted by padded column (round 5), for sig_fix8_kernel<.., SAMEP>: a counting sort in three launches.
+// kSortWgs workgroups take one contiguous slice of the list each; (1) per-workgroup histogram of the columns in LDS, stored
+// column-major; (2) one workgroup: every column's total rounded up to whole groups of eight, scanned over the columns, then
+// over the workgroups inside a column - the slot where each workgroup's entries of each column start - and -1 into the
+// padding behind every column's run; (3) the slices once more: every entry to its column's next slot (LDS cursors).
+constexpr int kSortWgs = 256, kSortThreads = 256, kSortMaxCols = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void fix_sort_hist_kernel(const int64_t* __restrict__ list, const int* __restrict__ count,
+                                                                     int cap, int padcols, int* __restrict__ wg_hist) {
+  __shared__ int hist[kSortMaxCols];
+  for (int c = threadIdx.x; c < padcols; c += kSortThreads) hist[c] = 0;
+  __syncthreads();
+  const int cnt = min(*count, cap);
+  const int per = (cnt + kSortWgs - 1) / kSortWgs;
+  const int lo = blockIdx.x * per, hi = min(cnt, lo + per);
+  for (int e = lo + threadIdx.x; e < hi; e += kSortThreads) {
+    const int col = (int)(list[e] & ((1 << 21) - 1));
+    if (col < padcols) atomicAdd(&hist[col], 1);      // (a column out of range - an entry stage 2 skips - is dropped here)
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < padcols; c += kSortThreads) wg_hist[(size_t)c * kSortWgs + blockIdx.x] = hist[c];
+}
+
+__global__ __launch_bounds__(kSortMaxCols) void fix_sort_scan_kernel(int* __restrict__ wg_hist, int padcols, int64_t* __restrict__ sorted,
+                                                                      int* __restrict__ sorted_count) {
+  __shared__ int tot[kSortMaxCols];
+  const int c = threadIdx.x;
+  int mine = 0;
+  if (c < padcols)
+    for (int w = 0; w < kSortWgs; ++w) mine += wg_hist[(size_t)c * kSortWgs + w];
+  const int padded = (mine + kFixG - 1) / kFixG * kFixG;
+  tot[c] = c < padcols ? padded : 0;
+  __syncthreads();
+  for (int off = 1; off < kSortMaxCols; off <<= 1) {      // inclusive scan over the columns
+    const int v = c >= off ? tot[c - off] : 0;
+    __syncthreads();
+    tot[c] += v;
+    __syncthreads();
+  }
+  if (c < padcols) {
+    int at = tot[c] - padded;                             // where this column's run starts
+    for (int w = 0; w < kSortWgs; ++w) {
+      const int n = wg_hist[(size_t)c * kSortWgs + w];
+      wg_hist[(size_t)c * kSortWgs + w] = at;
+      at += n;
+    }
+    for (int e = at; e < tot[c]; ++e) sorted[e] = -1;     // at most seven
+  }
+  if (c == kSortMaxCols - 1) *sorted_count = tot[c];
+}
+
+__global__ __launch_bounds__(kSortThreads) void fix_sort_scatter_kernel(const int64_t* __restrict__ list, const float* __restrict__ y,
+                                                                        const int* __restrict__ count, int cap, int padcols,
+                                                                        const int* __restrict__ wg_hist, int64_t* __restrict__ sorted,
+                                                                        float* __restrict__ sorted_y) {
+  __shared__ int cursor[kSortMaxCols];
+  for (int c = threadIdx.x; c < padcols; c += kSortThreads) cursor[c] = wg_hist[(size_t)c * kSortWgs + blockIdx.x];
+  __syncthreads();
+  const int cnt = min(*count, cap);
+  const int per = (cnt + kSortWgs - 1) / kSortWgs;
+  const int lo = blockIdx.x * per, hi = min(cnt, lo + per);
+  for (int e = lo + threadIdx.x; e < hi; e += kSortThreads) {
+    const int64_t item = list[e];
+    const int col = (int)(item & ((1 << 21) - 1));
+    if (col >= padcols) continue;
+    const int at = atomicAdd(&cursor[col], 1);
+    sorted[at] = item;
+    if (y != nullptr) sorted_y[at] = y[e];
   }
 }
 
@@ -2863,15 +2961,19 @@ namespace {
 struct Opts {            // the caller's lshrs_sig_opts, or all-null
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* clock_probe = nullptr;
+  const lshrs_sig_sort* sort = nullptr;
 };
 inline Opts read_opts(const lshrs_sig_opts* o) {
   Opts r;
-  if (o != nullptr && o->struct_bytes >= sizeof(lshrs_sig_opts)) {
+  if (o != nullptr && o->struct_bytes >= offsetof(lshrs_sig_opts, sort)) {       // (a caller built against the struct without `sort`)
     r.ev[0] = static_cast<hipEvent_t>(o->ev_stage1_start);
     r.ev[1] = static_cast<hipEvent_t>(o->ev_stage1_stop);
     r.ev[2] = static_cast<hipEvent_t>(o->ev_stage2_start);
     r.ev[3] = static_cast<hipEvent_t>(o->ev_stage2_stop);
     r.clock_probe = static_cast<unsigned long long*>(o->clock_probe);
+    if (o->struct_bytes >= sizeof(lshrs_sig_opts) && o->sort != nullptr && o->sort->struct_bytes >= sizeof(lshrs_sig_sort) &&
+        o->sort->list != nullptr && o->sort->y != nullptr && o->sort->hist != nullptr)
+      r.sort = o->sort;
   }
   return r;
 }
@@ -3354,16 +3456,59 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     f.audit_list = audit_n > 0 ? a.audit_list : nullptr;
     f.audit_vals = a.audit_vals;
     f.audit_n = audit_n;
+    int nparts = (int)grid.x;
+    const bool sorted = o.sort != nullptr && !short_rows && f.padcols <= kSortMaxCols &&
+                        (int64_t)o.sort->cap >= (int64_t)flag_cap + (int64_t)kFixG * f.padcols;
     if (short_rows) {
       if (blas_general(rows_per_band, g.ktiles, dim))
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
       else
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+    } else if (sorted) {
+      // the list by column first (three launches), then stage 2 with ONE hyperplane per group of eight; the audit sample -
+      // unsorted, a few thousand entries - through the plain instantiation behind it, its statistics in the slots behind
+      int* hist = o.sort->hist;
+      int* sorted_count = hist + (size_t)kSortWgs * f.padcols;
+      hipExtLaunchKernelGGL(fix_sort_hist_kernel, dim3(kSortWgs), dim3(kSortThreads), 0, s, o.ev[2], nullptr, 0, flag_list, flag_count,
+                            flag_cap, f.padcols, hist);
+      hipLaunchKernelGGL(fix_sort_scan_kernel, dim3(1), dim3(kSortMaxCols), 0, s, hist, f.padcols, o.sort->list, sorted_count);
+      hipLaunchKernelGGL(fix_sort_scatter_kernel, dim3(kSortWgs), dim3(kSortThreads), 0, s, flag_list, flag_y, flag_count, flag_cap,
+                         f.padcols, hist, o.sort->list, o.sort->y);
+      FixArgs fs = f;
+      fs.sorted_list = o.sort->list;
+      fs.sorted_y = flag_y != nullptr ? o.sort->y : nullptr;
+      fs.sorted_count = sorted_count;
+      fs.audit_list = nullptr;
+      fs.audit_n = 0;
+      const bool has_audit = f.audit_list != nullptr && f.audit_n > 0;
+      const int64_t sgroups = ((int64_t)flag_cap + kFixG - 1) / kFixG + f.padcols;
+      constexpr int kSortedGrid = (LSHRS_SIG_DEVICE_COUNTERS - LSHRS_SIG_COUNTERS) / kFixParts - 512 < kFixGridG
+                                      ? ((LSHRS_SIG_DEVICE_COUNTERS - LSHRS_SIG_COUNTERS) / kFixParts - 512) / 8 * 8 : kFixGridG;
+      const dim3 sgrid((unsigned)(sgroups < kSortedGrid ? sgroups : kSortedGrid));     // (512 statistics slots stay for the audit launch)
+      hipEvent_t stop = has_audit ? nullptr : o.ev[3];
+      if (blas_general(rows_per_band, g.ktiles, dim))
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabG, true>), sgrid, block, 0, s, nullptr, stop, 0, fs);
+      else
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kFixSlabG, true>), sgrid, block, 0, s, nullptr, stop, 0, fs);
+      nparts = (int)sgrid.x;
+      if (has_audit) {
+        FixArgs fa = f;
+        fa.flag_cap = 0;                    // (no list entries: only the audit groups)
+        fa.count_ties = 0;
+        fa.partials = f.partials + (size_t)kFixParts * sgrid.x;
+        const int agroups = (f.audit_n + kFixG - 1) / kFixG;
+        const dim3 agrid((unsigned)(agroups < 512 ? agroups : 512));
+        if (blas_general(rows_per_band, g.ktiles, dim))
+          hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), agrid, block, 0, s, nullptr, o.ev[3], 0, fa);
+        else
+          hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), agrid, block, 0, s, nullptr, o.ev[3], 0, fa);
+        nparts += (int)agrid.x;
+      }
     } else if (blas_general(rows_per_band, g.ktiles, dim))
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     else
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
-    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)grid.x);
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, nparts);
   } else {
     hipExtLaunchKernelGGL((sig_fix8_kernel<false, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
   }

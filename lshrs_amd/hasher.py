@@ -306,8 +306,14 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         # away - the work is conserved, the stage-1 launches end one chunk boundary later each: 1 M x 768 -1 .. -4 %,
         # 5 M x 1536 -1 .. -2 % on every plan tried.
         self.chunking = "off"
+        # Stage 2 column by column (ABI 6, lshrs_sig_sort): the stage-1 list is counting-sorted by key column on the device and
+        # every eight entries stage 2 takes share one hyperplane, fetched once - the row gather is the only stream left.  "auto":
+        # where the three extra launches pay - long rows and long lists (dim >= 1024; config 5: stage 2 3.36 -> 2.6 ms);
+        # True / False: always / never (measurements).  Same keys either way.
+        self.stage2_sorted = "auto"
         self.chunk_min_rounds = 6
         self._chunk_res: Dict[tuple, dict] = {}
+        self._sort_res: Dict[tuple, tuple] = {}
         self._pipes: Dict[tuple, int] = {}
         self._plan_cache: Dict[tuple, tuple] = {}
         self._replay_scratch: Dict[object, tuple] = {}
@@ -723,6 +729,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                     self._replay_scratch.clear()
                     self._replay_events.clear()
                     self._chunk_res.clear()
+                    self._sort_res.clear()
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
             flag_list, counts, pinned, host_counts, turn, flag_y, audit_list, audit_vals, audit_box, ptrs = scratch
@@ -767,6 +774,15 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
                         cres["timing"][slot] = (tev, ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)), arr)
                     ev, plan.ev_timing = cres["timing"][slot][:2]
                     opts = cres["opts"]
+            want_sort = (self.stage2_sorted is True or (self.stage2_sorted == "auto" and self.dim >= 1024)) and plan is None
+            if want_sort:
+                sort = self._sort_scratch(torch, dev, skey, cap)
+                if opts is None:
+                    opts = sort[1]
+                else:
+                    opts.set_sort(sort[0])
+            elif opts is not None and opts.sort:
+                opts.set_sort(None)
             audit = None
             if self.audit_unflagged > 0:
                 self._audit_seed = (self._audit_seed + 1) & 0x7FFFFFFF
@@ -819,6 +835,22 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         return (done, host_counts, slot, cap_of, n, ev,
                 float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps),
                 float(self.window_info.get("window_units_worst_case_row", float("inf"))), turn[0], turn)
+
+    def _sort_scratch(self, torch, dev, skey, cap: int):
+        """(SigSort, a SigOpts that carries it) for launches on this (device, stream): the sorted list and its stage-1 values -
+        room for every run padded to eight -, the per-workgroup histograms."""
+        lib = _native.load()
+        padcols = int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band))
+        need = int(cap) + 8 * padcols
+        got = self._sort_res.get(skey)
+        if got is None or got[2] < need:
+            lst = torch.empty(need, dtype=torch.int64, device=dev)
+            y = torch.empty(need, dtype=torch.float32, device=dev)
+            hist = torch.zeros(256 * padcols + 1, dtype=torch.int32, device=dev)
+            sort = _native.SigSort(lst.data_ptr(), y.data_ptr(), hist.data_ptr(), need)
+            got = (sort, _native.SigOpts(sort=sort), need, (lst, y, hist))
+            self._sort_res[skey] = got
+        return got
 
     _ROUND_WORKGROUPS = 256            # one 256-row stage-1 workgroup per CU
 
@@ -1284,6 +1316,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         state["_plan_cache"] = {}
         state["_replay_scratch"] = {}
         state["_chunk_res"] = {}
+        state["_sort_res"] = {}
         state["_async_pending"] = []
         state["_replay_events"] = {}
         state["_replay_model_cache"] = None
@@ -1300,6 +1333,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute):
         self.__dict__.setdefault("_plan_cache", {})
         self.__dict__.setdefault("_replay_scratch", {})
         self.__dict__.setdefault("_chunk_res", {})
+        self.__dict__.setdefault("_sort_res", {})
+        self.__dict__.setdefault("stage2_sorted", "auto")
         self.__dict__.setdefault("chunking", "off")
         self.__dict__.setdefault("chunk_min_rounds", 6)
         self.__dict__.setdefault("_async_pending", [])

@@ -330,3 +330,49 @@ def test_eight_lanes_deal_loader_batches_round_robin_and_store_them_in_order(tor
     i2.index(ids, big)
     LSHRS(storage=b, **kw).index(ids, big)
     assert _store_dict(a) == _store_dict(b) and len(a.packed_batches) == -(-big.shape[0] // 20_000)
+
+
+# ----------------------------------------------------------------------------- stage 2 column by column
+@pytest.mark.parametrize("nb,r,dim,n,seed", [(16, 32, 1536, 120_000, 7), (16, 16, 768, 90_000, 42), (20, 10, 768, 60_000, 3),
+                                              (16, 16, 300, 50_000, 5), (25, 8, 1000, 40_000, 6), (8, 25, 4100 - 4, 9_000, 8),
+                                              (8, 7, 200, 30_000, 9)])
+def test_stage2_on_a_column_sorted_list_decides_the_same_bits(torch_mod, nb, r, dim, n, seed):
+    """ABI 6, `lshrs_sig_sort`: the stage-1 list counting-sorted by key column, stage 2 with ONE hyperplane per group of eight
+    (fetched once into LDS).  Same keys as the plain stage 2 - bands of any height, partial k-tiles, 8 m + 4 elements, blocks of
+    4096 -, same statistics, the audit sample still verified; and the reference-literal loop's bytes on rows with true ties."""
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    torch = torch_mod
+    h = _hasher(seed, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    x = np.random.default_rng(dim + nb).standard_normal((n, dim)).astype(np.float32)
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
+    special = np.arange(0, n, 50)
+    for i in special:                                      # true ties against three hyperplanes (first, middle, last rows of bands)
+        pl = stack[[(i * 7 + t) % (nb * r) for t in (0, r // 2, r - 1)]]
+        v = x[i].astype(np.float64)
+        x[i] = (v - (v @ np.linalg.pinv(pl)) @ pl).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    h.stage2_sorted = False
+    ref = h.hash_device(xd).clone()
+    plain = dict(h.last_stats)
+    assert plain["route"] == "split+replay"
+    h.stage2_sorted = True
+    for _ in range(2):                                     # (the second launch reuses the scratch)
+        got = h.hash_device(xd)
+        st = dict(h.last_stats)
+        assert torch.equal(got, ref)
+        assert (st["flagged"], st["sign_flips"], st["tie_pairs"]) == (plain["flagged"], plain["sign_flips"], plain["tie_pairs"]), (st, plain)
+        assert abs(st["max_dev_units"] - plain["max_dev_units"]) <= 1e-3 * max(1.0, plain["max_dev_units"])
+        assert st["audited_unflagged"] > 0 and st["audit_sign_disagreements"] == 0 and st["relaunches"] == 0
+    rows = np.r_[special[:200], n - 300:n]
+    assert np.array_equal(ref[rows].cpu().numpy(), hash_batch_literal_packed(h.projections, x[rows]))
+    # a list that outgrows its capacity is noticed with the sorted stage 2 as without (rows flagged wholesale), and repeated
+    xd[1000:1400] *= 2.0 ** 40
+    h._flag_cap_hint = 0
+    got = h.hash_device(xd)
+    assert h.last_stats["flagged"] >= 400 * nb * r
+    h.stage2_sorted = False
+    assert torch.equal(got, h.hash_device(xd))
+    assert _hasher(seed, nb, r, dim).stage2_sorted == "auto"
