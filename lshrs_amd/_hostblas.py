@@ -179,6 +179,8 @@ def named_model(build: str, rows_per_band: int, dim: int) -> int:
     if r == 1:                       # sdot: every length, the build's own SIMD kernel
         return b
     body = dim & ~3
+    if dim == 8 and b == 2:          # (eight elements: the Haswell / Zen build runs its 8-lane kernels; the SkylakeX build another path)
+        return 1
     if dim < 9 or (body % 8 != 0 and body > 4096):
         return 0
     return 1 if dim % 4 == 0 else b  # (whole groups of four: both builds sum alike)
