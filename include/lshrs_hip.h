@@ -39,7 +39,7 @@ int lshrs_abi_version(void);
  * WRONG KEYS BY DESIGN and must never be mistaken for the product: bit LSHRS_BUILD_WRONG_KEYS says so, and
  * lshrs_amd/_native.py refuses to load such a build unless LSHRS_ALLOW_AB=1 is set.  LSHRS_BUILD_TUNED: switches and
  * constants that change speed only (the keys stay the reference's).  Bits 8 and up name the individual switches
- * (csrc/lshrs_hip.hip, lshrs_build_flags).  The product build returns 0. */
+ * (csrc/sig16.hip, sig16r.hip, sig_replay.hip: lshrs_flags_*).  The product build returns 0. */
 #define LSHRS_BUILD_WRONG_KEYS 0x1u
 #define LSHRS_BUILD_TUNED      0x2u
 uint32_t lshrs_build_flags(void);

@@ -4,7 +4,7 @@ Drop-in names (same surface as the reference package ``lshrs``):
 
     LSHRS / lshrs, LSHHasher, HashSignatures, top_k_cosine, cosine_similarity, l2_norm
 
-The arithmetic lives in ``csrc/lshrs_hip.hip`` (gfx950 only) behind the C ABI of
+The arithmetic lives in ``csrc/*.hip`` (gfx950 only; one translation unit per kernel family) behind the C ABI of
 ``include/lshrs_hip.h``; this package is the Python boundary around it.  There is
 no CPU compute path: without the built extension and a visible MI355X every
 compute call raises ``lshrs_amd._native.NativeLibraryError``.

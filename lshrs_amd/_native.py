@@ -16,8 +16,10 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-SOURCE = os.path.join(CSRC, "lshrs_hip.hip")
-SOURCES = (SOURCE, os.path.join(CSRC, "pipeline.hip"))
+# one translation unit per kernel family (what they share: csrc/lshrs_common.h); pipeline.hip: the native driver of the host-engine route
+UNITS = ("sig_setup", "sig_f32", "sig16", "sig16r", "sig_replay", "sig_small", "sig_split", "storage", "rerank", "pipeline")
+SOURCES = tuple(os.path.join(CSRC, u + ".hip") for u in UNITS)
+SOURCE = SOURCES[0]
 # (LSHRS_HIP_LIBRARY: load another build of the same ABI instead - A/B measurements of compiler flags, tools/ab_build.py)
 LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
@@ -48,22 +50,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     _hostblas.build(force=force, verbose=verbose)
     with _lock:
-        header = os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h"))
+        header = max(os.path.getmtime(os.path.join(INCLUDE, "lshrs_hip.h")), os.path.getmtime(os.path.join(CSRC, "lshrs_common.h")))
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         objdir = os.path.join(CSRC, "_obj")
         os.makedirs(objdir, exist_ok=True)
-        objects, relink = [], force or not os.path.exists(LIBRARY)
+        objects, stale, relink = [], [], force or not os.path.exists(LIBRARY)
         for src in SOURCES:
             obj = os.path.join(objdir, os.path.basename(src) + ".o")
             objects.append(obj)
             if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), header):
-                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-c", src,
-                       "-o", obj + ".tmp"]
-                if verbose:
-                    print(" ".join(cmd))
-                subprocess.run(cmd, check=True)
-                os.replace(obj + ".tmp", obj)
-                relink = True
+                stale.append((src, obj))
+
+        def compile_one(job):
+            src, obj = job
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility-inlines-hidden", "-I" + INCLUDE,
+                   "-I" + CSRC, "-c", src, "-o", obj + ".tmp"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            os.replace(obj + ".tmp", obj)
+
+        if stale:       # (the units are independent: a few at a time - the two stage-1 kernels take ~7 s each, the rest 1-2 s)
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=min(4, len(stale))) as pool:
+                list(pool.map(compile_one, stale))
+            relink = True
         if relink or os.path.getmtime(LIBRARY) < max(os.path.getmtime(o) for o in objects):
             cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objects, "-o", LIBRARY + ".tmp"]
             if verbose:

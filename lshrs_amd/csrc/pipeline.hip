@@ -2,7 +2,7 @@
 // (C ABI: lshrs_pipe_* in include/lshrs_hip.h; design: DESIGN.md "Host pipeline").
 //
 // Per chunk c of n:
-//   caller's stream : signature pass (split-precision or f32 kernel; lshrs_hip.hip)
+//   caller's stream : signature pass (split-precision or f32 kernel; sig_split.hip, sig_f32.hip)
 //   side stream     : c < n-2: export_ties_kernel gathers the tie entries, their X rows and both counters into a
 //                     device image, and a speculative prefix of it (the count is not known on the host yet) is copied
 //                     to pinned host memory; c >= n-2: the same kernel, on the caller's stream, writes the pinned

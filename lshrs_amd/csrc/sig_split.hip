@@ -1,0 +1,336 @@
+// sig_split.hip - part of liblshrs_hip.so, the gfx950 (MI355X / CDNA4) implementation of the lshrs hot path.
+// The split-precision signature pass as the C ABI offers it: stage 1 (sig16.hip / sig16r.hip) + stage 2 (sig_replay.hip) on
+// one stream, with the tie replay, as a chunked pipeline; the library's version and build flags.
+// One translation unit per kernel family (round 5): what is shared lives in lshrs_common.h, measurement switches (-DLSHRS_AB_*,
+// tools/ab_build.py) are local to the unit whose kernel they alter and reported through lshrs_build_flags().
+// ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md.
+#include "lshrs_common.h"
+
+using namespace lshrs;
+
+extern "C" {
+
+int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
+
+// Which measurement switches this build was compiled with (include/lshrs_hip.h, LSHRS_BUILD_*): every translation unit
+// reports its own; the product build returns 0.
+uint32_t lshrs_build_flags(void) { return lshrs_flags_sig16() | lshrs_flags_sig16r() | lshrs_flags_replay(); }
+
+int lshrs_stream_synchronize(void* stream) { return -(int)hipStreamSynchronize(static_cast<hipStream_t>(stream)); }
+
+// blas_model 0: ties are reported in tie_list (the caller resolves them on the host); > 0: stage 2 resolves them itself
+// by replaying that summation order of the host BLAS (sig_fix8_kernel<true>), tie_list is not used.
+// counters (replay only): the LSHRS_SIG_DEVICE_COUNTERS block; flag_y: the stage-1 value of every list entry (may be NULL).
+static int split_pass(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                      int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
+                      int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, float* flag_y,
+                      int32_t flag_cap, int32_t* flag_count, float tau1, int blas_model, int32_t* counters,
+                      int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream,
+                      const SplitFork* fork = nullptr) {
+  if (n == 0) return 0;
+  if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
+      flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
+    return LSHRS_E_BADARG;
+  if (tie_list != nullptr && (tie_count == nullptr || tie_cap < 0)) return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  const int row_bytes = num_bands * g.bb;
+  // (the second stage patches key bits with 32-bit atomics on the ALIGNED word around the byte: a word that straddles two
+  //  rows, or the end of the buffer, shares its page with a byte that is ours, and the bits that are not ours go back as
+  //  they came - key rows of any width, keys at any address)
+  const bool narrow = sig_has_narrow_split(g);
+  // short vectors of narrow hashers: the resident-image kernel (whole rows in registers: any dim % 4 == 0 with the replay)
+  SigResident rs = sig_resident(num_bands, rows_per_band, dim);
+  if (rs.on && dim % kKTile != 0 && blas_model == 0) rs.on = false;   // (only the replaying stage 2 masks a row's end)
+  if (!sig_has_split(g) && !narrow && !rs.on) return LSHRS_E_TOOLARGE;
+  const int64_t row_tiles = (n + 255) / 256;
+  const int64_t wgs = (row_tiles + 7) / 8 * 8 * g.cb;
+  if (n >= ((int64_t)1 << 42) || wgs > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Opts o = read_opts(opts);
+  const float* base = static_cast<const float*>(workspace);
+  // (a partial last k-tile - dim % 32 != 0 - only with the replay: its stage 2 is the one that reads the chunks past a row's end as zero)
+  const bool aligned = (dim % 32 == 0 || (blas_model != 0 && dim % 4 == 0 && (dim >= 32 || rs.on))) && (ldx % 4 == 0) &&
+                       ldx < (1 << 20) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  if (!aligned) {  // the split pass is built for 16-byte chunks of 16-byte aligned rows; anything else takes the f32 pass (same keys)
+    if (blas_model != 0) return LSHRS_E_BADARG;   // (the f32 kernel reports ties, it does not resolve them)
+    return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
+                                    tie_count, tau, row_flags, opts, stream);
+  }
+  // stage 1: bf16 x 3 projections -> keys + list of the projections inside the stage-1 window (+ their values)
+  SigArgs a{};
+  a.X = X;
+  a.n = n;
+  a.ldx = ldx;
+  a.dim = dim;
+  a.ktiles = g.ktiles;
+  a.ncb = g.cb;
+  a.image = base + sig_t16_offset_floats(g);
+  a.norms = base + sig_image_floats(g);
+  a.norm_max = a.norms + sig_norm_floats(g);
+  if (narrow) {   // the zero-padded 256-column image and its norms
+    a.ncb = 1;
+    a.image = base + sig_narrow_offset_floats(g);
+    a.norms = a.image + sig_narrow_image_floats(g);
+    a.norm_max = a.norms + 256;
+  }
+  const SigCompact cp = sig_compact(g, num_bands, rows_per_band);
+  const SigCompactWs cw = cp.on ? sig_compact_ws(const_cast<float*>(base), g, cp) : SigCompactWs{};
+  if (cp.on) {    // fewer column blocks with the bands' columns side by side (sig_compact)
+    a.ncb = cp.ncb;
+    a.image = cw.image;
+    a.norms = cw.norms;
+    a.norm_max = cw.norm_max;
+    a.compact = 1;
+    a.padcol = cw.padcol;
+    a.bytetab = cw.bytetab;
+    a.bpb = cp.bpb;
+    a.band_bytes = g.bb;
+    a.num_bands = num_bands;
+  }
+  a.keys = keys;
+  a.row_bytes = row_bytes;
+  a.vec_store = (row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(keys) % 16) == 0);
+  a.row_base = 0;
+  a.tie_list = flag_list;
+  a.flag_y = flag_y;
+  a.tie_cap = flag_cap;
+  a.tie_count = flag_count;
+  if (tau1 > 0.f) {                 // a window of tau1 units of ||x|| ||p||, the caller's responsibility
+    a.tau = tau1;
+    a.tau_b = 0.f;
+    a.wa = a.wb = a.norms;
+    a.wamax = a.wbmax = a.norm_max;
+  } else {                          // LSHRS_WINDOW_PROVEN: ||x_hi|| wa + ||x_mid|| wb (lshrs_sig_set_window)
+    const SigWindow w = sig_window(base, g);
+    a.tau = a.tau_b = 1.0f;
+    a.wa = w.wa;
+    a.wb = w.wb;
+    a.wamax = narrow ? w.wamax + kNarrowMaxSlot : w.wamax;
+    a.wbmax = narrow ? w.wbmax + kNarrowMaxSlot : w.wbmax;
+    if (cp.on) {
+      a.wa = cw.wa;
+      a.wb = cw.wb;
+      a.wamax = cw.wamax;
+      a.wbmax = cw.wbmax;
+    }
+  }
+  a.row_flags = row_flags;
+  a.clock_probe = o.clock_probe;
+  // the audit sample (lshrs_sig_audit): one unit in `div` - a wave of sig16_kernel, a 32-row tile of sig16r_kernel
+  int audit_n = 0;
+  if (audit != nullptr && audit->struct_bytes >= sizeof(lshrs_sig_audit) && audit->list != nullptr && audit->vals != nullptr &&
+      audit->slots > 0 && audit->target > 0 && blas_model != 0) {
+    const int res_rows = 16 * res_rt(rs.nct, rs.kt);
+    const int64_t units = rs.on ? (n + res_rows - 1) / res_rows : (row_tiles + 7) / 8 * 8 * a.ncb * 8;
+    int64_t div = units / audit->target;
+    if (div < 1) div = 1;
+    if ((units + div - 1) / div > audit->slots) div = (units + audit->slots - 1) / audit->slots;
+    if (div <= 0x7fffffffLL) {
+      a.audit_list = audit->list;
+      a.audit_vals = audit->vals;
+      a.audit_div = (int)div;
+      a.audit_phase = (int)(audit->seed % (uint32_t)div);
+      a.audit_seed = audit->seed;
+      audit_n = (int)((units - 1 - a.audit_phase) / div + 1);           // units u < `units` with u % div == phase: every slot is written
+    }
+  }
+  if (rs.on) {
+    const SigCompactWs rw = sig_resident_ws(const_cast<float*>(base), g, num_bands, rows_per_band, rs);
+    a.ncb = 1;
+    a.image = rw.image;
+    a.norms = rw.norms;
+    a.norm_max = rw.norm_max;
+    a.compact = 1;
+    a.padcol = rw.padcol;
+    a.bytetab = rw.bytetab;
+    a.bpb = num_bands;
+    a.band_bytes = g.bb;
+    a.num_bands = num_bands;
+    a.vec_store = (row_bytes % 4 == 0) && ((reinterpret_cast<uintptr_t>(keys) % 4) == 0);
+    if (tau1 > 0.f) {
+      a.wa = a.wb = a.norms;
+      a.wamax = a.wbmax = a.norm_max;
+    } else {
+      a.wa = rw.wa;
+      a.wb = rw.wb;
+      a.wamax = rw.wamax;
+      a.wbmax = rw.wbmax;
+    }
+    const int res_rows = 16 * res_rt(rs.nct, rs.kt);
+    const int64_t tiles = (n + res_rows - 1) / res_rows;
+    const int rwaves = res_waves(rs.nct, rs.kt);
+#ifndef LSHRS_RES_GRID
+#define LSHRS_RES_GRID 256        // workgroups of a full launch: one per CU (A/B builds: more, shorter ones - the hardware hands them to the CUs that finish first)
+#endif
+    const unsigned grid = (unsigned)(tiles < (int64_t)LSHRS_RES_GRID * rwaves ? (tiles + rwaves - 1) / rwaves : LSHRS_RES_GRID);
+    const int rc = lshrs_launch_sig16r(a, rs.nct, rs.kt, grid, 64u * (unsigned)rwaves, s, o.ev[0], o.ev[1]);
+    if (rc != 0) return rc;
+  } else {
+    const int rc = lshrs_launch_sig16(a, (unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), cp.on, dim % kKTile != 0, s, o.ev[0], o.ev[1]);
+    if (rc != 0) return rc;
+  }
+  // stage 2: the flagged projections, one by one (a forked chunk: on the side stream, behind stage 1's event)
+  if (fork != nullptr) {
+    hipError_t e = hipEventRecord(fork->ev_fork, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(fork->side, fork->ev_fork, 0);
+    if (e != hipSuccess) return -(int)e;
+    s = fork->side;
+  }
+  FixArgs f{};
+  f.X = X;
+  f.ldx = ldx;
+  f.dim = dim;
+  f.ktiles = g.ktiles;
+  f.prow = base + sig_rowmajor_offset_floats(g);
+  f.norms = (cp.on || rs.on) ? base + sig_image_floats(g) : a.norms;       // (stage 2 works on padded column ids throughout)
+  f.keys = keys;
+  f.row_bytes = row_bytes;
+  f.padcols = row_bytes * 8;
+  f.flag_list = flag_list;
+  f.flag_count = flag_count;
+  f.flag_cap = flag_cap;
+  f.row_base = 0;
+  f.tie_list = tie_list;
+  f.tie_cap = tie_cap;
+  f.tie_count = tie_count;
+  f.tau = tau > 0.f ? tau : 1.0f;
+  f.tie_coef = tau > 0.f ? f.norms : sig_window(base, g).wt;      // (proven tie window: coefficient per column, factor 1)
+  f.blas_model = blas_model;
+  f.rows_per_band = rows_per_band;
+  f.band_cols = 8 * g.bb;
+  if (blas_model != 0) {
+    f.tie_list = nullptr;
+    f.flag_y = flag_y;
+    f.partials = counters + LSHRS_SIG_COUNTERS;
+    f.count_ties = 1;
+    f.audit_list = audit_n > 0 ? a.audit_list : nullptr;
+    f.audit_vals = a.audit_vals;
+    f.audit_n = audit_n;
+  }
+  const int rc2 = lshrs_replay_stage2(f, counters, host_counts, o, s);
+  if (rc2 != 0) return rc2;
+  if (fork != nullptr) {
+    const hipError_t e = hipEventRecord(fork->ev_join, s);
+    if (e != hipSuccess) return -(int)e;
+  }
+  return -(int)hipGetLastError();
+}
+
+int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
+                                   int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list,
+                                   int32_t tie_cap, int32_t* tie_count, float tau, uint8_t* row_flags,
+                                   int64_t* flag_list, int32_t flag_cap, int32_t* flag_count, float tau1,
+                                   const lshrs_sig_opts* opts, void* stream) {
+  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap, tie_count, tau,
+                    row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, nullptr, opts, stream);
+}
+
+static int lshrs_sig_hash_batch_split_replay_f32_impl(const float* X, int64_t n, int64_t ldx, const void* workspace,
+                                                      int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
+                                                      int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                                      float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
+                                                      int32_t* host_counts, const lshrs_sig_audit* audit,
+                                                      const lshrs_sig_opts* opts, void* stream, const SplitFork* fork) {
+  const bool resident = sig_resident(num_bands, rows_per_band, dim).on;
+  if (blas_model != 1 || dim % 4 != 0 || (dim < 32 && !resident) || (dim % 8 != 0 && dim > 4096) || counters == nullptr)
+    return LSHRS_E_BADARG;
+  return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
+                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, audit, opts, stream, fork);
+}
+
+int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
+                                          int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
+                                          int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                          float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
+                                          int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
+                                          void* stream) {
+  return lshrs_sig_hash_batch_split_replay_f32_impl(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, counters, tau,
+                                                    row_flags, flag_list, flag_y, flag_cap, tau1, blas_model, host_counts, audit,
+                                                    opts, stream, nullptr);
+}
+
+int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
+                                                  int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
+                                                  int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                                  float* flag_y, float tau1, int32_t blas_model, int32_t* host_counts,
+                                                  const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
+                                                  const lshrs_sig_chunk_plan* plan, void* stream) {
+  if (plan == nullptr || plan->struct_bytes < sizeof(lshrs_sig_chunk_plan) || plan->nchunks < 1 ||
+      plan->nchunks > LSHRS_SIG_MAX_CHUNKS || counters == nullptr || host_counts == nullptr)
+    return LSHRS_E_BADARG;
+  const int nc = plan->nchunks;
+  int64_t total = 0;
+  for (int c = 0; c < nc; ++c) {
+    if (plan->rows[c] <= 0 || plan->flag_cap[c] <= 0) return LSHRS_E_BADARG;
+    if (c + 1 < nc && (plan->side_stream[c] == nullptr || plan->ev_fork[c] == nullptr || plan->ev_join[c] == nullptr ||
+                       plan->side_stream[c] == stream))
+      return LSHRS_E_BADARG;
+    total += plan->rows[c];
+  }
+  if (total != n) return LSHRS_E_BADARG;
+  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
+  const int64_t row_bytes = (int64_t)num_bands * g.bb;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int64_t lo = 0, list_off = 0;
+  int32_t slot_off = 0;
+  const bool audit_on = audit != nullptr && audit->struct_bytes >= sizeof(lshrs_sig_audit) && audit->list != nullptr &&
+                        audit->vals != nullptr && audit->slots > 0 && audit->target > 0;
+  for (int c = 0; c < nc; ++c) {
+    const int64_t rows = plan->rows[c];
+    // the audit sample and its slots: every chunk its share by rows (the last one what is left)
+    lshrs_sig_audit au{};
+    if (audit_on) {
+      au = *audit;
+      const int32_t slots = c + 1 < nc ? (int32_t)((int64_t)audit->slots * rows / n) : audit->slots - slot_off;
+      int32_t target = (int32_t)((int64_t)audit->target * rows / n);
+      if (target < 1) target = 1;
+      au.list = audit->list + slot_off;
+      au.vals = audit->vals + 2 * (int64_t)slot_off;
+      au.slots = slots;
+      au.target = target < slots ? target : slots;
+      au.seed = audit->seed + 0x9E3779B9u * (uint32_t)c;
+      slot_off += slots;
+    }
+    // the measurement hooks: one quadruple of events per chunk, handed over back to back behind the struct's own
+    lshrs_sig_opts op{};
+    const lshrs_sig_opts* opp = nullptr;
+    if (opts != nullptr && opts->struct_bytes >= sizeof(lshrs_sig_opts)) {
+      op = *opts;
+      if (plan->ev_timing != nullptr) {
+        op.ev_stage1_start = plan->ev_timing[4 * c + 0];
+        op.ev_stage1_stop = plan->ev_timing[4 * c + 1];
+        op.ev_stage2_start = plan->ev_timing[4 * c + 2];
+        op.ev_stage2_stop = plan->ev_timing[4 * c + 3];
+      }
+      if (c != 0) op.clock_probe = nullptr;
+      opp = &op;
+    }
+    SplitFork fk{};
+    const bool forked = c + 1 < nc;
+    if (forked) {
+      fk.side = static_cast<hipStream_t>(plan->side_stream[c]);
+      fk.ev_fork = static_cast<hipEvent_t>(plan->ev_fork[c]);
+      fk.ev_join = static_cast<hipEvent_t>(plan->ev_join[c]);
+    }
+    int32_t* cnt = counters + (int64_t)c * LSHRS_SIG_DEVICE_COUNTERS;
+    const int rc = lshrs_sig_hash_batch_split_replay_f32_impl(
+        X + lo * ldx, rows, ldx, workspace, num_bands, rows_per_band, dim, keys + lo * row_bytes, cnt, tau,
+        row_flags != nullptr ? row_flags + lo : nullptr, flag_list + list_off, flag_y != nullptr ? flag_y + list_off : nullptr,
+        plan->flag_cap[c], tau1, blas_model, host_counts + (int64_t)c * LSHRS_SIG_COUNTERS, audit_on ? &au : nullptr, opp, stream,
+        forked ? &fk : nullptr);
+    if (rc != 0) {
+      // (chunks already enqueued run to their end: the caller's stream must still see them finish before buffers go away)
+      for (int d = 0; d < c && d + 1 < nc; ++d) (void)hipStreamWaitEvent(s, static_cast<hipEvent_t>(plan->ev_join[d]), 0);
+      return rc;
+    }
+    lo += rows;
+    list_off += plan->flag_cap[c];
+  }
+  for (int c = 0; c + 1 < nc; ++c) {
+    const hipError_t e = hipStreamWaitEvent(s, static_cast<hipEvent_t>(plan->ev_join[c]), 0);
+    if (e != hipSuccess) return -(int)e;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,7 +1,7 @@
 """``LSHHasher`` — the signature pass of lshrs on MI355X.
 
 Same constructor, attributes, methods and error messages as the reference class
-(lshrs/hash/lsh.py:51-247); the arithmetic runs in ``csrc/lshrs_hip.hip`` through
+(lshrs/hash/lsh.py:51-247); the arithmetic runs in ``csrc/sig16.hip`` / ``sig16r.hip`` / ``sig_replay.hip`` / ``sig_f32.hip`` / ``sig_small.hip`` through
 the C ABI of ``include/lshrs_hip.h``.  There is no CPU hashing path in here.
 
 Bit-exactness.  The reference's bits are ``sign(sgemv_f32(P_band, x))`` as rounded by the *host's* BLAS.

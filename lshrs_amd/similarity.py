@@ -3,7 +3,7 @@ batched ``rerank_batch``.
 
 Function names, argument meaning, return types and error behaviour follow
 lshrs/utils/similarity.py:26-183 and lshrs/utils/norm.py:4-61; the arithmetic runs in
-``cosine_kernel`` / ``topk_kernel`` of ``csrc/lshrs_hip.hip`` (C ABI:
+``cosine_kernel`` / ``topk_kernel`` of ``csrc/rerank.hip`` (C ABI:
 ``lshrs_cosine_batch_f32`` / ``lshrs_topk_desc_f32``).  No CPU compute path.
 
 Numerics: the kernel evaluates ``dot(c, q) / (||c|| * ||q||)`` in float32 with a fixed

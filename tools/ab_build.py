@@ -9,9 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out, flags = sys.argv[1], sys.argv[2:]
 csrc = os.path.join(ROOT, "lshrs_amd", "csrc")
 objs = []
-for src in ("lshrs_hip.hip", "pipeline.hip"):
+sys.path.insert(0, ROOT)
+from lshrs_amd._native import UNITS          # noqa: E402  (the library's translation units)
+
+for src in [u + ".hip" for u in UNITS]:
     obj = out + "." + src + ".o"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                     *flags, "-c", os.path.join(csrc, src), "-o", obj], check=True)
     objs.append(obj)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", out], check=True)

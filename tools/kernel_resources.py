@@ -7,11 +7,15 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "lshrs_amd", "csrc", "lshrs_hip.hip")
-out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                      "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", "/dev/null",
-                      "-Rpass-analysis=kernel-resource-usage"] + [a for a in sys.argv[1:] if a.startswith("-D")],
-                     capture_output=True, text=True).stderr
+sys.path.insert(0, ROOT)
+from lshrs_amd._native import CSRC, SOURCES      # noqa: E402  (one translation unit per kernel family)
+
+out = ""
+for src in SOURCES:
+    out += subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", src, "-o", "/dev/null",
+                           "-Rpass-analysis=kernel-resource-usage"] + [a for a in sys.argv[1:] if a.startswith("-D")],
+                          capture_output=True, text=True).stderr
 want = [a for a in sys.argv[1:] if not a.startswith("-D")] or ["sig16", "sig_fix", "sig_small", "sig_kernel<8, true"]
 cur, rows = None, {}
 for ln in out.splitlines():
