@@ -70,7 +70,7 @@ CONFIG4_TOTAL_ROWS = 10_000_000
 
 def pmc_traffic(kernel: str, field: str, units: float):
     """HBM bytes per launch measured by the PMC passes committed under profiles/ (None if absent)."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)[kernel][field] * units, name
@@ -951,10 +951,16 @@ def bench_c5(torch, np, local_dev, check):
     steps = 10
     elapsed, events, _ = timed_steps(torch, h, x, keys, steps, False, lambda: torch.cuda.synchronize(dev))
     k1 = sum(e[0] for e in events) / len(events)
+    k2 = [e[3] for e in events if e[3] is not None]
     out = {"workload": "BASELINE config 5: 5M x 1536-d f32, num_perm=512 (16 x 32), HBM-resident (30.7 GB), bit-exact keys",
            "value": n * steps / elapsed, "unit": "vectors/s", "ms_per_step": 1e3 * elapsed / steps,
            "stats_last_step": dict(h.last_stats),
            "roofline": stage1_roofline(k1, n, dim, num_perm, "sig16_kernel, two column blocks per row tile paired on one XCD")}
+    if k2:      # stage 2 column by column (round 5): sort launches + sig_fix8_kernel<.., SAMEP> + the audit sample, first start .. last end
+        out["stage2_ms_mean"] = sum(k2) / len(k2)
+        out["stage2_is"] = "list counting-sorted by key column, one hyperplane per group of eight (lshrs_sig_sort); was 3.36 ms unsorted"
+        flagged = int(h.last_stats.get("flagged", 0))
+        out["stage2_gather_TBps"] = flagged * 4.0 * dim / (out["stage2_ms_mean"] * 1e-3) / 1e12 if flagged else None
     if check:
         from oracle.parallel import SharedVectors, hash_shared_literal_packed
 
