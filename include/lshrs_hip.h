@@ -112,7 +112,7 @@ typedef struct lshrs_sig_audit {
  *       |y1 - y_hostBLAS| / window among them
  *   [7] reserved (0) */
 #define LSHRS_SIG_COUNTERS 8
-#define LSHRS_SIG_DEVICE_COUNTERS (LSHRS_SIG_COUNTERS + 3 * 4096)
+#define LSHRS_SIG_DEVICE_COUNTERS (LSHRS_SIG_COUNTERS + 6 * 4096)
 
 /* ------------------------------------------------------------------------------------------
  * Signature pass — replaces LSHHasher.hash_vector / hash_batch / _project_and_pack

@@ -25,7 +25,7 @@ LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hi
 INCLUDE = os.path.join(REPO_ROOT, "include")
 ABI_VERSION = 6
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
-SIG_DEVICE_COUNTERS = SIG_COUNTERS + 3 * 4096      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
+SIG_DEVICE_COUNTERS = SIG_COUNTERS + 6 * 4096      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
 SIG_MAX_CHUNKS = 8        # LSHRS_SIG_MAX_CHUNKS
 

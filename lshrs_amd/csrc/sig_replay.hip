@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
 
 // ---- The stage-1 list sorted by padded column (round 5), for sig_fix8_kernel<.., SAMEP>: a counting sort in three launches.
 // kSortWgs workgroups take one contiguous slice of the list each; (1) per-workgroup histogram of the columns in LDS, stored
-// column-major; (2) one workgroup: every column's total rounded up to whole groups of eight, scanned over the columns, then
+// workgroup-major (every access of the three kernels coalesced over the columns); (2) one workgroup: every column's total rounded up to whole groups of eight, scanned over the columns, then
 // over the workgroups inside a column - the slot where each workgroup's entries of each column start - and -1 into the
 // padding behind every column's run; (3) the slices once more: every entry to its column's next slot (LDS cursors).
 constexpr int kSortWgs = 256, kSortThreads = 256;      // (kSortMaxCols: lshrs_common.h)
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kSortThreads) void fix_sort_hist_kernel(const int64
     if (col < padcols) atomicAdd(&hist[col], 1);      // (a column out of range - an entry stage 2 skips - is dropped here)
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < padcols; c += kSortThreads) wg_hist[(size_t)c * kSortWgs + blockIdx.x] = hist[c];
+  for (int c = threadIdx.x; c < padcols; c += kSortThreads) wg_hist[(size_t)blockIdx.x * padcols + c] = hist[c];
 }
 
 __global__ __launch_bounds__(kSortMaxCols) void fix_sort_scan_kernel(int* __restrict__ wg_hist, int padcols, int64_t* __restrict__ sorted,
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kSortMaxCols) void fix_sort_scan_kernel(int* __rest
   const int c = threadIdx.x;
   int mine = 0;
   if (c < padcols)
-    for (int w = 0; w < kSortWgs; ++w) mine += wg_hist[(size_t)c * kSortWgs + w];
+    for (int w = 0; w < kSortWgs; ++w) mine += wg_hist[(size_t)w * padcols + c];
   const int padded = (mine + kFixG - 1) / kFixG * kFixG;
   tot[c] = c < padcols ? padded : 0;
   __syncthreads();
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(kSortMaxCols) void fix_sort_scan_kernel(int* __rest
   if (c < padcols) {
     int at = tot[c] - padded;                             // where this column's run starts
     for (int w = 0; w < kSortWgs; ++w) {
-      const int n = wg_hist[(size_t)c * kSortWgs + w];
-      wg_hist[(size_t)c * kSortWgs + w] = at;
+      const int n = wg_hist[(size_t)w * padcols + c];
+      wg_hist[(size_t)w * padcols + c] = at;
       at += n;
     }
     for (int e = at; e < tot[c]; ++e) sorted[e] = -1;     // at most seven
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kSortThreads) void fix_sort_scatter_kernel(const in
                                                                         const int* __restrict__ wg_hist, int64_t* __restrict__ sorted,
                                                                         float* __restrict__ sorted_y) {
   __shared__ int cursor[kSortMaxCols];
-  for (int c = threadIdx.x; c < padcols; c += kSortThreads) cursor[c] = wg_hist[(size_t)c * kSortWgs + blockIdx.x];
+  for (int c = threadIdx.x; c < padcols; c += kSortThreads) cursor[c] = wg_hist[(size_t)blockIdx.x * padcols + c];
   __syncthreads();
   const int cnt = min(*count, cap);
   const int per = (cnt + kSortWgs - 1) / kSortWgs;
@@ -685,8 +685,11 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
       fs.audit_n = 0;
       const bool has_audit = f.audit_list != nullptr && f.audit_n > 0;
       const int64_t sgroups = ((int64_t)flag_cap + kFixG - 1) / kFixG + f.padcols;
-      constexpr int kSortedGrid = (LSHRS_SIG_DEVICE_COUNTERS - LSHRS_SIG_COUNTERS) / kFixParts - 512 < kFixGridG
-                                      ? ((LSHRS_SIG_DEVICE_COUNTERS - LSHRS_SIG_COUNTERS) / kFixParts - 512) / 8 * 8 : kFixGridG;
+#ifndef LSHRS_SORTED_GRID
+#define LSHRS_SORTED_GRID 2048      // eight single-wave workgroups per CU (14 KB of LDS each); 1528: +4 %, 2304 / 2560: the same, 2816: +33 % (A/B builds, config 5)
+#endif
+      constexpr int kSlots = (LSHRS_SIG_DEVICE_COUNTERS - LSHRS_SIG_COUNTERS) / kFixParts - 512;
+      constexpr int kSortedGrid = LSHRS_SORTED_GRID < kSlots ? LSHRS_SORTED_GRID : kSlots / 8 * 8;
       const dim3 sgrid((unsigned)(sgroups < kSortedGrid ? sgroups : kSortedGrid));     // (512 statistics slots stay for the audit launch)
       hipEvent_t stop = has_audit ? nullptr : o.ev[3];
       if (blas_general(rows_per_band, f.ktiles, dim))

@@ -132,8 +132,8 @@ def test_pure_host_entry_points(lib):
     assert names == [f[0] for f in _native.SigAudit._fields_]
     assert ctypes.sizeof(_native.SigAudit) == 8 + 2 * ctypes.sizeof(ctypes.c_void_p) + 8
     assert int(re.search(r"#define\s+LSHRS_SIG_COUNTERS\s+(\d+)", text).group(1)) == _native.SIG_COUNTERS
-    assert re.search(r"#define\s+LSHRS_SIG_DEVICE_COUNTERS\s+\(LSHRS_SIG_COUNTERS \+ 3 \* 4096\)", text)
-    assert _native.SIG_DEVICE_COUNTERS == _native.SIG_COUNTERS + 3 * 4096
+    assert re.search(r"#define\s+LSHRS_SIG_DEVICE_COUNTERS\s+\(LSHRS_SIG_COUNTERS \+ 6 \* 4096\)", text)
+    assert _native.SIG_DEVICE_COUNTERS == _native.SIG_COUNTERS + 6 * 4096
     assert lib.lshrs_topk_desc_f32(None, 1, 5, 3, None, None, None, None) == -10001
     assert lib.lshrs_topk_workspace_bytes(10, 1000) == 0
     assert lib.lshrs_topk_workspace_bytes(3, 40_000) == 3 * 65536 * 8
