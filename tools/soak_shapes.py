@@ -34,17 +34,24 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # round 4: vector lengths that are not a multiple of four (the host library's scalar tail: blas model 1 / 2)
           (16, 16, 102), (5, 8, 30), (20, 10, 301), (4, 13, 1001), (8, 7, 99), (2, 16, 4099), (16, 16, 767), (3, 2, 9), (16, 4, 129),
           # round 4: one row per band (the host's sdot)
-          (64, 1, 64), (16, 1, 128), (32, 1, 768))
+          (64, 1, 64), (16, 1, 128), (32, 1, 768),
+          # round 5: one row per band at lengths WITH a tail behind the last whole 32 (summed in a double), down to two elements
+          (64, 1, 100), (16, 1, 33), (40, 1, 31), (24, 1, 7), (8, 1, 2), (128, 1, 770), (200, 1, 96), (32, 1, 1000), (16, 1, 4100),
+          # round 5: long rows - stage 2 column by column (the list sorted by key column; dim >= 1024), incl. bands of any height,
+          # partial k-tiles, several blocks of the library
+          (16, 32, 1536), (25, 8, 1024), (20, 10, 1100), (8, 25, 4096), (12, 7, 2052), (40, 5, 1280))
 
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    only_new = len(sys.argv) > 2 and sys.argv[2] == "new"          # (the shapes round 5 added)
+    shapes = SHAPES[SHAPES.index((64, 1, 100)):] if only_new else SHAPES
     t0 = time.time()
     rows = bad = batches = audit_bad = audited = 0
     routes = {}
     worst = 0.0
     for rnd in range(rounds):
-        for nb, r, dim in SHAPES:
+        for nb, r, dim in shapes:
             rng = np.random.default_rng(7919 * rnd + 31 * dim + nb)
             a = LSHHasher(nb, r, dim, seed=3 + rnd)
             b = LSHHasher(nb, r, dim, seed=3 + rnd, precision="f32")
@@ -78,11 +85,18 @@ def main():
                 "one_outlier": outlier,
                 "empty_k_tiles": holes,
             }
+            named = None
+            model = a._replay_model()
+            if model in (1, 2):          # the keys pinned to the build this host runs: must be the default hasher's
+                from lshrs_amd import _hostblas
+                build = "openblas-skylakex" if model == 1 else "openblas-haswell"
+                if _hostblas.named_model(build, r, dim) == model or (dim % 4 == 0 and r > 1 and _hostblas.named_model(build, r, dim)):
+                    named = LSHHasher(nb, r, dim, seed=3 + rnd, reference_blas=build)
             for dname, x in data.items():
                 ka = a.hash_device(x)
                 sa = dict(a.last_stats)
                 kb = b.hash_device(x)
-                ok = torch.equal(ka, kb)
+                ok = torch.equal(ka, kb) and (named is None or torch.equal(named.hash_device(x), ka))
                 sl = slice(n // 3, n // 3 + (400 if dim % 4 == 0 and dname != "offset_view" else 2000))
                 routes[sa.get("route")] = routes.get(sa.get("route"), 0) + 1
                 audit_bad += int(sa.get("audit_sign_disagreements", 0))
@@ -98,6 +112,8 @@ def main():
                       f"({used:.3f} of worst-case window) {'ok' if ok and ok_ref else 'MISMATCH'}", flush=True)
             a.close()
             b.close()
+            if named is not None:
+                named.close()
     print(f"shape soak: {batches} batches, {rows} rows, {bad} mismatches, largest measured deviation = {worst:.3f} of the "
           f"worst-case-row window, routes {routes}, {audited} un-flagged projections audited ({audit_bad} sign disagreements), "
           f"{time.time() - t0:.0f} s")
