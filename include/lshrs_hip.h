@@ -64,19 +64,26 @@ typedef struct lshrs_sig_opts {
 } lshrs_sig_opts;
 
 /* Scratch that lets stage 2 of lshrs_sig_hash_batch_split_replay_f32 work through the flagged projections COLUMN BY COLUMN
- * (ABI 6; optional - the keys are the same with or without it, this is speed): the stage-1 list is counting-sorted by
- * padded column on the device (three small launches), and every group of eight entries stage 2 takes then shares one
- * hyperplane, fetched once into LDS instead of eight times from L2 - the row gather of x is the only stream left.  Pays
- * where the list is long and the rows are (config 5: 2.35 M entries of 1536 elements); the library uses it when given, for
- * hashers of at most 1024 padded key columns whose rows are longer than four k-tiles.
- *   list  DEVICE int64[cap], y DEVICE float[cap]   cap >= flag_cap + 8 * padded columns (runs are padded to groups of eight)
- *   hist  DEVICE int32[256 * padded columns + 1]   per-workgroup column histograms; the last word: entries incl. padding */
+ * (ABI 6; optional - the keys are the same with or without it, this is speed): every group of eight entries stage 2 takes
+ * then shares one hyperplane, fetched once into LDS instead of eight times from L2 - the row gather of x is the only
+ * stream left.  For hashers of at most 1024 padded key columns whose rows are longer than four k-tiles.  Two ways there:
+ *   mode 1, BUCKETS (what lshrs_amd uses): stage 1 itself appends every flagged projection - and its audit sample, bit 62 of
+ *     the entry - to the SEGMENT of its padded key column: list / y / thr are [columns][cap / columns], hist holds the
+ *     entries wanted per column, TWO sets of 1024 counters used alternately (`parity`: the set this call counts in - zero on
+ *     entry; the call clears the other one for the next, so the caller can still read this call's).  A column that wanted
+ *     more than its segment holds: counter [7] of the call's counters != 0 - repeat with room.  No launch between the stages.
+ *   mode 0, SORT: the stage-1 list is counting-sorted by padded column on the device (three small launches), runs padded to
+ *     groups of eight; list DEVICE int64[cap], y DEVICE float[cap], cap >= flag_cap + 8 * padded columns; hist DEVICE
+ *     int32[256 * padded columns + 1].  (Pays for config 5's 2.35 M entries of 1536 elements, not at 768-d.) */
 typedef struct lshrs_sig_sort {
   uint32_t struct_bytes;   /* sizeof(lshrs_sig_sort) */
-  int32_t cap;
+  int32_t cap;             /* entries list / y (/ thr) hold */
   int64_t* list;
   float* y;
-  int32_t* hist;
+  int32_t* hist;           /* mode 0: int32[256 * columns + 1]; mode 1: int32[2 * 1024] */
+  float* thr;              /* mode 1: DEVICE float[cap] - the window each audit entry was compared with */
+  int32_t mode;
+  int32_t parity;
 } lshrs_sig_sort;
 
 /* Audit of what stage 1 of the split pass does NOT send to the exact decision (optional, NULL = none).  The proven window

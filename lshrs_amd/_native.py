@@ -28,6 +28,7 @@ SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
 SIG_DEVICE_COUNTERS = SIG_COUNTERS + 6 * 4096      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
 SIG_MAX_CHUNKS = 8        # LSHRS_SIG_MAX_CHUNKS
+SORT_MAX_COLS = 1024      # kSortMaxCols of csrc/lshrs_common.h: padded key columns the column-wise stage 2 takes
 
 BUILD_WRONG_KEYS = 0x1   # LSHRS_BUILD_WRONG_KEYS
 BUILD_TUNED = 0x2        # LSHRS_BUILD_TUNED
@@ -259,12 +260,13 @@ class SigSort(ctypes.Structure):
     """``lshrs_sig_sort`` of include/lshrs_hip.h: scratch for the column-sorted stage 2."""
 
     _fields_ = [("struct_bytes", ctypes.c_uint32), ("cap", ctypes.c_int32), ("list", ctypes.c_void_p), ("y", ctypes.c_void_p),
-                ("hist", ctypes.c_void_p)]
+                ("hist", ctypes.c_void_p), ("thr", ctypes.c_void_p), ("mode", ctypes.c_int32), ("parity", ctypes.c_int32)]
 
-    def __init__(self, list_ptr: int, y_ptr: int, hist_ptr: int, cap: int):
+    def __init__(self, list_ptr: int, y_ptr: int, hist_ptr: int, cap: int, thr_ptr=None, mode: int = 0):
         super().__init__()
         self.struct_bytes = ctypes.sizeof(SigSort)
         self.list, self.y, self.hist, self.cap = list_ptr, y_ptr, hist_ptr, int(cap)
+        self.thr, self.mode, self.parity = thr_ptr, int(mode), 0
 
 
 class SigAudit(ctypes.Structure):

@@ -161,9 +161,13 @@ class _ReplayPaths:
                         cres["timing"][slot] = (tev, ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)), arr)
                     ev, plan.ev_timing = cres["timing"][slot][:2]
                     opts = cres["opts"]
-            want_sort = (self.stage2_sorted is True or (self.stage2_sorted == "auto" and self.dim >= 1024)) and plan is None
-            if want_sort:
-                sort = self._sort_scratch(torch, dev, skey, cap)
+            smode = self._stage2_mode() if plan is None else None
+            sort = None
+            if smode is not None:
+                sort = self._sort_scratch(torch, dev, skey, cap, smode)
+                if smode == 1:
+                    sort[0].parity = sort[4][0] & 1          # the set of column counters this launch counts in (the other: cleared by it)
+                    sort[4][0] += 1
                 if opts is None:
                     opts = sort[1]
                 else:
@@ -205,6 +209,8 @@ class _ReplayPaths:
                 counts.zero_()              # a failed launch may have left counts behind: the next call starts from zero
                 if cres is not None:
                     cres["counts"].zero_()
+                if sort is not None:
+                    sort[3][2].zero_()
                 turn[1].append(slot)
                 raise
             done = None
@@ -223,19 +229,45 @@ class _ReplayPaths:
                 float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps),
                 float(self.window_info.get("window_units_worst_case_row", float("inf"))), turn[0], turn)
 
-    def _sort_scratch(self, torch, dev, skey, cap: int):
-        """(SigSort, a SigOpts that carries it) for launches on this (device, stream): the sorted list and its stage-1 values -
-        room for every run padded to eight -, the per-workgroup histograms."""
-        lib = _native.load()
-        padcols = int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band))
-        need = int(cap) + 8 * padcols
+    def _stage2_mode(self):
+        """Which column-wise stage 2 a launch of the split pass asks for: 1 = buckets (stage 1 appends by key column), 0 = the list
+        sorted on the device, None = the plain stage 2 (what the resident-image kernel's short rows always take)."""
+        want = self.stage2_sorted
+        if want is False or self.dim <= 128:
+            return None
+        padcols = self.num_bands * self.band_bytes * 8
+        if padcols > _native.SORT_MAX_COLS:
+            return None
+        if want == "sort" or want is True:
+            return 0
+        if self._resident_shape():    # (the resident-image kernel keeps one list: its stage 2 is the plain one)
+            return None
+        return 1                      # "auto", "buckets"
+
+    def _sort_scratch(self, torch, dev, skey, cap: int, mode: int):
+        """(SigSort, a SigOpts that carries it, capacity, tensors, launch counter) for launches on this (device, stream).  Buckets:
+        a segment per padded key column - 1.5 x its share of the list + 64 entries -, the entries' stage-1 values and the audit
+        entries' windows beside them, two sets of 1024 column counters.  Sort: the sorted list and its values - room for every
+        run padded to eight -, the per-workgroup histograms."""
+        padcols = self.num_bands * self.band_bytes * 8
+        if mode == 1:
+            per = max(int(1.5 * cap / padcols) + 64, int(self._bucket_cap_hint))
+            need = per * padcols
+        else:
+            need = int(cap) + 8 * padcols
         got = self._sort_res.get(skey)
-        if got is None or got[2] < need:
+        if got is None or got[2] < need or got[0].mode != mode:
             lst = torch.empty(need, dtype=torch.int64, device=dev)
             y = torch.empty(need, dtype=torch.float32, device=dev)
-            hist = torch.zeros(256 * padcols + 1, dtype=torch.int32, device=dev)
-            sort = _native.SigSort(lst.data_ptr(), y.data_ptr(), hist.data_ptr(), need)
-            got = (sort, _native.SigOpts(sort=sort), need, (lst, y, hist))
+            if mode == 1:
+                hist = torch.zeros(2 * _native.SORT_MAX_COLS, dtype=torch.int32, device=dev)
+                thr = torch.empty(need, dtype=torch.float32, device=dev)
+                sort = _native.SigSort(lst.data_ptr(), y.data_ptr(), hist.data_ptr(), need, thr.data_ptr(), 1)
+            else:
+                hist = torch.zeros(256 * padcols + 1, dtype=torch.int32, device=dev)
+                thr = None
+                sort = _native.SigSort(lst.data_ptr(), y.data_ptr(), hist.data_ptr(), need)
+            got = (sort, _native.SigOpts(sort=sort), need, (lst, y, hist, thr), [0])
             self._sort_res[skey] = got
         return got
 
@@ -304,10 +336,15 @@ class _ReplayPaths:
         finally:
             state[9][1].append(slot)        # (the pinned block is free for the next launch - also when the wait raised)
         if len(caps) == 1:
-            ties, flagged, _, flips, audited, audit_bad, _, _ = host_counts[0].tolist()
+            ties, flagged, _, flips, audited, audit_bad, _, col_over = host_counts[0].tolist()
             as_float = host_counts[0].view(np.float32)
             max_dev, audit_ratio = float(as_float[2]), float(as_float[6])
             over = flagged > caps[0]
+            if col_over:        # buckets: one key column wanted more than its segment holds (rows aligned with a hyperplane): double them
+                over = True
+                per = max(64, int(self._bucket_cap_hint), int(1.5 * caps[0] / max(1, self.num_bands * self.band_bytes * 8)) + 64)
+                self._bucket_cap_hint = 2 * per
+                flagged = max(flagged, caps[0])
         else:       # one block per chunk: sums and maxima; a chunk that outgrew ITS share of the list makes the pass incomplete
             rows = host_counts.tolist()
             as_float = host_counts.view(np.float32)
@@ -444,6 +481,19 @@ class _ReplayPaths:
             return True
         # list entries, their rows of x and of the keys: gathered on the device, ONE copy to the host
         items_d = scratch[0][:k]
+        sort = self._sort_res.get((dev.index, torch.cuda.current_stream(dev).cuda_stream))
+        if sort is not None and sort[0].mode == 1 and self._stage2_mode() == 1:
+            # buckets: the flagged projections sit in their key columns' segments - the first entry of up to `sample` columns
+            # that have one (the counters of the pass that has just run are the set it was not told to clear)
+            lst, _, hist, _ = sort[3]
+            padcols = self.num_bands * self.band_bytes * 8
+            per = int(sort[0].cap) // padcols
+            used = ((sort[4][0] - 1) & 1) * _native.SORT_MAX_COLS
+            cols = torch.nonzero(hist[used:used + padcols] > 0)[:sample, 0]
+            if cols.numel() == 0:
+                return True
+            items_d = lst[cols * per] & ~(1 << 62)            # (an audit entry is a projection like any other here)
+            k = int(items_d.shape[0])
         rows_d = (items_d >> 21).clamp_(0, int(x.shape[0]) - 1)
         nx, nk = k * self.dim * 4, k * self.num_bands * self.band_bytes
         packed = torch.cat([items_d.view(torch.uint8), x.index_select(0, rows_d).reshape(-1).view(torch.uint8),

@@ -264,7 +264,15 @@ struct SigArgs {
   int audit_div;
   int audit_phase;
   unsigned audit_seed;
+  // BUCKETS (lshrs_sig_sort mode 1; sig16_kernel only): col_cap > 0 - flagged projections do not go to one list but to the
+  // segment of their padded key column: entry `col_count[col]++` of tie_list / flag_y [col * col_cap ..) (tie_count still takes
+  // the total), and the audit sample goes there too, marked by bit 62 of the entry, its window in flag_thr: stage 2 then finds
+  // every group of eight entries under ONE hyperplane without a sort in between
+  int* col_count;
+  int col_cap;
+  float* flag_thr;
 };
+constexpr int64_t kAuditBit = (int64_t)1 << 62;
 
 __device__ __forceinline__ unsigned audit_hash(unsigned u, unsigned seed) {
   unsigned h = u * 0x9E3779B1u ^ (seed * 0x85EBCA6Bu + 0xC2B2AE35u);
@@ -348,6 +356,13 @@ struct FixArgs {
   const int64_t* sorted_list;
   const float* sorted_y;
   const int* sorted_count;
+  // ... or in BUCKETS (SigArgs::col_cap): sorted_list / sorted_y are the segments, col_count the entries stage 1 wanted per
+  // column (more than col_cap: the column overflowed - reported through *overflow, the pass is repeated with room),
+  // flag_thr the window of the audit entries (bit 62 of an entry)
+  const int* col_count;
+  int col_cap;
+  const float* flag_thr;
+  int* overflow;
 };
 constexpr int kFixParts = 6;
 

@@ -461,9 +461,21 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
             const int colid = COMPACT ? padcol_lds[16 * ct + r16e] : cb * 256 + 16 * ct + r16e;
             const bool keep = ((hits >> au_q) & 1u) == 0u && grow < args.n && colid >= 0 && colid < args.row_bytes * 8 &&
                               tq < __builtin_inff();
+            if (args.col_cap > 0) {           // buckets: the sample rides in its column's segment, marked
+              if (keep) {
+                const int slot = atomicAdd(args.col_count + colid, 1);
+                if (slot < args.col_cap) {
+                  const size_t at = (size_t)colid * args.col_cap + slot;
+                  args.tie_list[at] = ((grow << 21) | (int64_t)colid) | kAuditBit;
+                  args.flag_y[at] = yq;
+                  args.flag_thr[at] = tq;
+                }
+              }
+            } else {
             args.audit_list[au_slot] = keep ? ((grow << 21) | (int64_t)colid) : (int64_t)-1;
             args.audit_vals[2 * au_slot] = yq;
             args.audit_vals[2 * au_slot + 1] = tq;
+            }
           }
           if (hits != 0u) {
 #pragma unroll
@@ -471,7 +483,10 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
               const int reg = q & 3, ct = 2 * w + (q >> 2);
               const int64_t grow = row0 + 16 * rt + 4 * ge + reg;
               const int colid = COMPACT ? padcol_lds[16 * ct + r16e] : cb * 256 + 16 * ct + r16e;
-              if (((hits >> q) & 1u) != 0u && grow < args.n && (!COMPACT || colid >= 0)) {
+              // (a NaN / Inf row also "flags" the zero-padded columns behind the last key column: the plain list carries
+              //  them to stage 2, which skips them; a bucket launch has no segment for them)
+              if (((hits >> q) & 1u) != 0u && grow < args.n && (!COMPACT || colid >= 0) &&
+                  (args.col_cap == 0 || colid < args.row_bytes * 8)) {
                 const int64_t entry = (grow << 21) | (int64_t)colid;
                 // the stage-1 value travels with the entry: stage 2 measures |y1 - y_BLAS| on every flagged projection
                 // (rows flagged wholesale carry no usable y1: NaN, skipped by that statistic)
@@ -480,6 +495,13 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
                 if (pos < kS1ListCap) {
                   l_list[pos] = entry;
                   l_y[pos] = ykeep;
+                } else if (args.col_cap > 0) {                            // LDS stage full, buckets: straight to the column's segment
+                  atomicAdd(args.tie_count, 1);
+                  const int slot = atomicAdd(args.col_count + colid, 1);
+                  if (slot < args.col_cap) {
+                    args.tie_list[(size_t)colid * args.col_cap + slot] = entry;
+                    args.flag_y[(size_t)colid * args.col_cap + slot] = ykeep;
+                  }
                 } else {                                                  // LDS stage full (rows flagged wholesale): straight out
                   const int slot = atomicAdd(args.tie_count, 1);
                   if (slot < args.tie_cap) {
@@ -542,7 +564,18 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     }
   }
   const int staged = l_count[0] < kS1ListCap ? l_count[0] : kS1ListCap;
-  if (staged > 0) {                                     // (workgroup-uniform)
+  if (staged > 0 && args.col_cap > 0) {                 // buckets: every staged entry to its column's segment (one atomic on
+    if (tid == 0) atomicAdd(args.tie_count, staged);    // one of <= 1024 addresses each: ~30 per workgroup at 768-d, ~60 at 1536-d)
+    for (int e = tid; e < staged; e += 64 * W) {
+      const int64_t entry = l_list[e];
+      const int col = (int)(entry & ((1 << 21) - 1));
+      const int slot = atomicAdd(args.col_count + col, 1);
+      if (slot < args.col_cap) {
+        args.tie_list[(size_t)col * args.col_cap + slot] = entry;
+        args.flag_y[(size_t)col * args.col_cap + slot] = l_y[e];
+      }
+    }
+  } else if (staged > 0) {                              // (workgroup-uniform)
     if (tid == 0) l_count[1] = atomicAdd(args.tie_count, staged);
     __syncthreads();
     const int base = l_count[1];

@@ -60,7 +60,39 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   const int shh = sub >> 2, sq = sub & 3;           // this lane's chunk of every k-tile: k = 32 t + 16 shh + 4 sq + 0..3
   const int64_t* __restrict__ list = SAMEP ? a.sorted_list : a.flag_list;
   const float* __restrict__ ylist = SAMEP ? a.sorted_y : a.flag_y;
-  const int cnt = SAMEP ? *a.sorted_count : min(*a.flag_count, a.flag_cap);
+  // BUCKETS (SAMEP with a.col_cap > 0): stage 1 left every entry in its column's segment; the groups of eight are numbered
+  // through the columns - gstart[c] = groups in front of column c, by a scan every workgroup does for itself (<= 1024 counts)
+  __shared__ int gstart[SAMEP ? kSortMaxCols + 1 : 1];
+  const bool buckets = SAMEP && a.col_cap > 0;
+  if (SAMEP && buckets) {
+    constexpr int kPer = kSortMaxCols / 64;
+    int mine[kPer], sum = 0;
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int c = lane * kPer + i;
+      const int want = c < a.padcols ? a.col_count[c] : 0;
+      over = over || want > a.col_cap;
+      mine[i] = ((want < a.col_cap ? want : a.col_cap) + kFixG - 1) / kFixG;
+      sum += mine[i];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    int at = incl - sum;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      gstart[lane * kPer + i] = at;
+      at += mine[i];
+    }
+    if (lane == 63) gstart[kSortMaxCols] = at;
+    if (blockIdx.x == 0 && __any(over) && lane == 0) *a.overflow = 1;
+    __syncthreads();
+  }
+  const int cnt = !SAMEP ? min(*a.flag_count, a.flag_cap) : (buckets ? gstart[kSortMaxCols] * kFixG : *a.sorted_count);
   const int fgroups = (cnt + kFixG - 1) / kFixG;
   const int groups = fgroups + (!SAMEP && REPLAY && a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);   // audit groups behind the list's
   const size_t ldp = (size_t)a.ktiles * kKTile;
@@ -78,7 +110,20 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     it.audit = grp >= fgroups;                      // (uniform per wave: a group is the list's or the audit's)
     int64_t item;
     bool inlist;
-    if (!it.audit) {
+    if (SAMEP && buckets) {
+      int lo = 0, hi = a.padcols - 1;                // the column this group belongs to: the last c with gstart[c] <= grp
+      while (lo < hi) {                              // (uniform per wave: ten LDS reads of one address each)
+        const int mid = (lo + hi + 1) >> 1;
+        if (gstart[mid] <= grp) lo = mid; else hi = mid - 1;
+      }
+      const int off = (grp - gstart[lo]) * kFixG + g;
+      const int have = min(a.col_count[lo], a.col_cap);
+      inlist = off < have;
+      it.e = lo * a.col_cap + (inlist ? off : 0);    // (a short last group re-does the column's first entry, unused)
+      item = list[it.e];
+      it.audit = (item & kAuditBit) != 0;            // the sample of un-flagged projections rides in the segments, marked
+      item &= ~kAuditBit;
+    } else if (!it.audit) {
       it.e = grp * kFixG + g;
       inlist = it.e < cnt;
       item = list[inlist ? it.e : grp * kFixG];
@@ -252,7 +297,8 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
         const uint8_t kbyte = a.keys[row * (int64_t)a.row_bytes + (col >> 3)];
         ++n_aud;
         if ((yb > 0.f) != (((kbyte >> (col & 7)) & 1) != 0)) ++n_abad;
-        const float y1 = a.audit_vals[2 * e], thr = a.audit_vals[2 * e + 1];
+        const float y1 = (SAMEP && buckets) ? ylist[e] : a.audit_vals[2 * e];
+        const float thr = (SAMEP && buckets) ? a.flag_thr[e] : a.audit_vals[2 * e + 1];
         if (thr > 0.f) {
           const float ratio = __builtin_fabsf(y1 - yb) / thr;
           if (ratio < __builtin_inff()) max_ratio = __builtin_fmaxf(max_ratio, ratio);
@@ -572,9 +618,11 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
 // memory) and leaves the whole block zeroed for the next call: one small launch instead of a copy and a fill.
 // Without host_counts the folded counters stay in the device block (the caller copies it).
 constexpr int kExportThreads = 1024;      // one part or two per thread: the fold is one memory round trip deep, not nparts / 64
-__global__ __launch_bounds__(kExportThreads) void export_counts_kernel(int* counters, int* host_counts, int nparts) {
+__global__ __launch_bounds__(kExportThreads) void export_counts_kernel(int* counters, int* host_counts, int nparts, int* zero = nullptr,
+                                                                      int nzero = 0) {
   __shared__ int fold[kExportThreads / 64][kFixParts];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < nzero; i += kExportThreads) zero[i] = 0;      // (buckets: the column counters of the NEXT launch)
   int* parts = counters + LSHRS_SIG_COUNTERS;
   int ties = 0, flips = 0, dev = 0, aud = 0, abad = 0, ratio = 0;
   for (int i = tid; i < nparts; i += kExportThreads) {
@@ -667,6 +715,24 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
       else
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+    } else if (f.col_cap > 0) {
+      // BUCKETS: stage 1 left every flagged (and sampled) projection in its column's segment - stage 2 with ONE hyperplane per
+      // group of eight at once, no sort, no launch of its own for the audit sample; the launch behind it also clears the
+      // column counters the next pass will use (the two sets alternate: this pass's stay readable for the live audit)
+      constexpr int kBucketGrid = 2048;
+      const int64_t bgroups = (int64_t)f.padcols * ((f.col_cap + kFixG - 1) / kFixG);
+      const dim3 bgrid((unsigned)(bgroups < kBucketGrid ? bgroups : kBucketGrid));
+      FixArgs fb = f;
+      fb.audit_list = nullptr;
+      fb.audit_n = 0;
+      fb.overflow = counters + 7;
+      if (blas_general(rows_per_band, f.ktiles, dim))
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabG, true>), bgrid, block, 0, s, o.ev[2], o.ev[3], 0, fb);
+      else
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kFixSlabG, true>), bgrid, block, 0, s, o.ev[2], o.ev[3], 0, fb);
+      hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)bgrid.x,
+                         o.sort->hist + (size_t)(1 - (o.sort->parity & 1)) * kSortMaxCols, kSortMaxCols);
+      return -(int)hipGetLastError();
     } else if (sorted) {
       // the list by column first (three launches), then stage 2 with ONE hyperplane per group of eight; the audit sample -
       // unsorted, a few thousand entries - through the plain instantiation behind it, its statistics in the slots behind

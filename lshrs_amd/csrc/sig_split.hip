@@ -134,6 +134,18 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
       audit_n = (int)((units - 1 - a.audit_phase) / div + 1);           // units u < `units` with u % div == phase: every slot is written
     }
   }
+  // BUCKETS (lshrs_sig_sort mode 1): sig16_kernel appends flagged and sampled projections by key column (sig_replay.hip takes
+  // them from there): long rows, at most 1024 padded key columns, the replaying stage 2, the caller's scratch given
+  const int padcols_all = row_bytes * 8;
+  const bool buckets = !rs.on && blas_model != 0 && o.sort != nullptr && o.sort->mode == 1 && o.sort->thr != nullptr &&
+                       padcols_all <= kSortMaxCols && g.ktiles > kFixSlabShort && o.sort->cap / padcols_all >= 64;
+  if (buckets) {
+    a.tie_list = o.sort->list;
+    a.flag_y = o.sort->y;
+    a.flag_thr = o.sort->thr;
+    a.col_count = o.sort->hist + (size_t)(o.sort->parity & 1) * kSortMaxCols;
+    a.col_cap = o.sort->cap / padcols_all;
+  }
   if (rs.on) {
     const SigCompactWs rw = sig_resident_ws(const_cast<float*>(base), g, num_bands, rows_per_band, rs);
     a.ncb = 1;
@@ -198,6 +210,13 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   f.blas_model = blas_model;
   f.rows_per_band = rows_per_band;
   f.band_cols = 8 * g.bb;
+  if (buckets) {
+    f.sorted_list = o.sort->list;
+    f.sorted_y = o.sort->y;
+    f.flag_thr = o.sort->thr;
+    f.col_count = a.col_count;
+    f.col_cap = a.col_cap;
+  }
   if (blas_model != 0) {
     f.tie_list = nullptr;
     f.flag_y = flag_y;

@@ -254,14 +254,17 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         # away - the work is conserved, the stage-1 launches end one chunk boundary later each: 1 M x 768 -1 .. -4 %,
         # 5 M x 1536 -1 .. -2 % on every plan tried.
         self.chunking = "off"
-        # Stage 2 column by column (ABI 6, lshrs_sig_sort): the stage-1 list is counting-sorted by key column on the device and
-        # every eight entries stage 2 takes share one hyperplane, fetched once - the row gather is the only stream left.  "auto":
-        # where the three extra launches pay - long rows and long lists (dim >= 1024; config 5: stage 2 3.36 -> 2.6 ms);
-        # True / False: always / never (measurements).  Same keys either way.
+        # Stage 2 column by column (ABI 6, lshrs_sig_sort): every eight entries stage 2 takes share one hyperplane, fetched once -
+        # the row gather of x is the only stream left.  "auto" = "buckets" for every hasher the split pass's main kernel serves
+        # (up to 1024 padded key columns, rows longer than four k-tiles): stage 1 itself appends flagged and sampled projections
+        # to the segment of their key column, no launch between the stages (config 2: stage 2 0.107 -> 0.08 ms; config 5: 3.36 ->
+        # 2.5 ms).  "sort": the stage-1 list counting-sorted on the device instead (three launches: pays at dim >= 1024 only);
+        # False: the plain stage 2.  Same keys every way.
         self.stage2_sorted = "auto"
         self.chunk_min_rounds = 6
         self._chunk_res: Dict[tuple, dict] = {}
         self._sort_res: Dict[tuple, tuple] = {}
+        self._bucket_cap_hint = 0
         self._pipes: Dict[tuple, int] = {}
         self._plan_cache: Dict[tuple, tuple] = {}
         self._replay_scratch: Dict[object, tuple] = {}
@@ -787,6 +790,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self.__dict__.setdefault("_chunk_res", {})
         self.__dict__.setdefault("_sort_res", {})
         self.__dict__.setdefault("stage2_sorted", "auto")
+        self.__dict__.setdefault("_bucket_cap_hint", 0)
         self.__dict__.setdefault("chunking", "off")
         self.__dict__.setdefault("chunk_min_rounds", 6)
         self.__dict__.setdefault("_async_pending", [])

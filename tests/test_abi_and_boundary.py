@@ -126,7 +126,7 @@ def test_pure_host_entry_points(lib):
     fields = re.search(r"typedef struct lshrs_sig_sort \{(.*?)\} lshrs_sig_sort;", text, flags=re.S).group(1)
     names = re.findall(r"(\w+);", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
     assert names == [f[0] for f in _native.SigSort._fields_]
-    assert ctypes.sizeof(_native.SigSort) == 8 + 3 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_native.SigSort) == 8 + 4 * ctypes.sizeof(ctypes.c_void_p) + 8
     fields = re.search(r"typedef struct lshrs_sig_audit \{(.*?)\} lshrs_sig_audit;", text, flags=re.S).group(1)
     names = re.findall(r"(\w+);", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
     assert names == [f[0] for f in _native.SigAudit._fields_]

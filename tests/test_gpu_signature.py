@@ -1069,6 +1069,7 @@ def _stage1_values(torch, h, x):
     """y1 of EVERY projection of a small batch: a window so wide that stage 1 flags everything; the list and the values
     stage 1 stored beside it are read back from the hasher's scratch.  -> (n, padded columns) float32."""
     n = int(x.shape[0])
+    h.stage2_sorted = False         # (the one plain list of the launch: a bucket launch keeps a segment per key column instead)
     h.hash_device(x)
     scratch = h._replay_scratch[(x.device.index, torch.cuda.current_stream(x.device).cuda_stream)]
     cnt = int(h.last_stats["flagged"])

@@ -15,6 +15,7 @@ for nb, r, dim, n, seed in ((16, 32, 1536, 300_000, 7), (16, 16, 768, 450_000, 4
     x = torch.randn(n, dim, device=dev, generator=torch.Generator(dev).manual_seed(11))
     raw = torch._C._cuda_getCurrentRawStream(0)
     h.chunking = "off"
+    h.stage2_sorted = False      # (the plain list is what is looked at here)
     h.hash_device(x)
     st = dict(h.last_stats)
     lst = h._replay_scratch[(0, raw)][0]

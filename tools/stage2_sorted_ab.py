@@ -22,7 +22,7 @@ for name, n, dim, nb, r, seed, steps in (("c5", 5_000_000, 1536, 16, 32, 7, 10),
     h.stage2_sorted = False
     ref = h.hash_device(x).clone()
     out = torch.empty_like(ref)
-    for mode in (False, True, False, True):
+    for mode in (False, "sort", "buckets", False, "sort", "buckets"):
         h.stage2_sorted = mode
         for _ in range(steps // 3 + 2):
             h.hash_device(x, out=out)
@@ -40,7 +40,7 @@ for name, n, dim, nb, r, seed, steps in (("c5", 5_000_000, 1536, 16, 32, 7, 10),
         s1 = sum(e[0] for e in ev) / len(ev)
         s2 = sum(e[3] for e in ev) / len(ev)
         st = h.last_stats
-        print(f"{name} sorted={str(mode):5s} {per * 1e3:8.4f} ms/step {n / per / 1e6:7.1f} M vec/s  keys ok {ok}  stage1 {s1:.4f}  stage2 {s2:.4f}  "
+        print(f"{name} stage2={str(mode):8s} {per * 1e3:8.4f} ms/step {n / per / 1e6:7.1f} M vec/s  keys ok {ok}  stage1 {s1:.4f}  stage2 {s2:.4f}  "
               f"flagged {st.get('flagged')} flips {st.get('sign_flips')} max_dev {st.get('max_dev_units'):.1f} audited {st.get('audited_unflagged')}", flush=True)
     del x, ref, out
     torch.cuda.empty_cache()
