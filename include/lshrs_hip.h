@@ -72,6 +72,9 @@ typedef struct lshrs_sig_opts {
  *     entries wanted per column, TWO sets of 1024 counters used alternately (`parity`: the set this call counts in - zero on
  *     entry; the call clears the other one for the next, so the caller can still read this call's).  A column that wanted
  *     more than its segment holds: counter [7] of the call's counters != 0 - repeat with room.  No launch between the stages.
+ *     Padded columns are the key columns here (8 x key bytes per row): the zero-padded columns of a stage-1 column block
+ *     have no segment - a NaN / Inf row's entries for them are dropped in stage 1 ([1] then counts fewer than without
+ *     the scratch).  The chunked pass ignores `sort`: its chunks overlap and cannot share one scratch.
  *   mode 0, SORT: the stage-1 list is counting-sorted by padded column on the device (three small launches), runs padded to
  *     groups of eight; list DEVICE int64[cap], y DEVICE float[cap], cap >= flag_cap + 8 * padded columns; hist DEVICE
  *     int32[256 * padded columns + 1].  (Pays for config 5's 2.35 M entries of 1536 elements, not at 768-d.) */

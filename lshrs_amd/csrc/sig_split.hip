@@ -322,6 +322,7 @@ int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int
         op.ev_stage2_stop = plan->ev_timing[4 * c + 3];
       }
       if (c != 0) op.clock_probe = nullptr;
+      if (nc > 1) op.sort = nullptr;       // (ONE column scratch: chunks of a pass overlap, they cannot share it)
       opp = &op;
     }
     SplitFork fk{};
