@@ -257,8 +257,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         # Stage 2 column by column (ABI 6, lshrs_sig_sort): every eight entries stage 2 takes share one hyperplane, fetched once -
         # the row gather of x is the only stream left.  "auto" = "buckets" for every hasher the split pass's main kernel serves
         # (up to 1024 padded key columns, rows longer than four k-tiles): stage 1 itself appends flagged and sampled projections
-        # to the segment of their key column, no launch between the stages (config 2: stage 2 0.107 -> 0.08 ms; config 5: 3.36 ->
-        # 2.5 ms).  "sort": the stage-1 list counting-sorted on the device instead (three launches: pays at dim >= 1024 only);
+        # to the segment of their key column, no launch between the stages (config 2: stage 2 0.107 -> 0.084 ms; config 5: 3.36 ->
+        # 2.37 ms).  "sort": the stage-1 list counting-sorted on the device instead (three launches: pays at dim >= 1024 only);
         # False: the plain stage 2.  Same keys every way.
         self.stage2_sorted = "auto"
         self.chunk_min_rounds = 6
