@@ -146,7 +146,7 @@ struct SigResident { bool on; int nct; int kt; };
 inline SigResident sig_resident(int num_bands, int rows, int dim) {
   SigResident r{false, 0, 0};
   const int64_t real = (int64_t)num_bands * rows;
-  if (real > 256 || dim > 256 || dim < 8 || dim % 4 != 0) return r;
+  if (real > 256 || dim > 256 || dim < 8) return r;         // (any dim: the row's last dim % 4 elements are shifted into place)
   r.nct = (((int)real + 15) / 16 + 3) / 4 * 4;
   r.kt = dim <= 64 ? 2 : (dim <= 128 ? 4 : 8);
   r.on = r.nct * r.kt <= 64;                        // (the image - nct x kt x 2 KiB - and a wave's rows in flight must fit)
@@ -351,6 +351,7 @@ struct FixArgs {
   const float* audit_vals;     // replayed like the flagged ones behind them, nothing patched - only compared
   int audit_n;
   int tail_model;         // sig_fixany_kernel: how the host compiles the dim % 4 elements behind the last group of four (1 / 2)
+  int plain_loads;        // stage 2 behind the split pass through sig_fixany_kernel (rows of any length at any 4-byte address)
   // the list sorted by padded column (lshrs_sig_sort, SAMEP instantiations): every group of eight entries has ONE column, runs
   // padded to whole groups with -1; sorted_y: the entries' stage-1 values in that order; sorted_count: entries incl. padding
   const int64_t* sorted_list;

@@ -90,14 +90,18 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
   const int nby = args.row_bytes;
 
   // x of one 32-row tile: [row tile][k-tile][chunk of four].  Every load is unconditional (a predicated load is a branch, and
-  // a wait for everything in flight behind it): a chunk past the row's end (dim % 4 == 0) is fetched from the row's last
-  // chunk instead and zeroed when its k-tile is split.
+  // a wait for everything in flight behind it): a chunk past the row's end is fetched from the row's last four elements
+  // instead and zeroed when its k-tile is split.  Rows of any length at any 4-byte address (round 5: 16 x 16 x 102, offset
+  // views): the chunk that holds the row's last dim % 4 elements is ALSO fetched from the last four elements - never a byte
+  // past the row - and shifted into place when its k-tile is split; the loads are 16 bytes wide at 4-byte alignment.
+  struct __attribute__((packed, aligned(4))) Chunk { f32x4 v; };
   f32x4 xr[RT][KT][2];
   int koff[KT][2];
+  const int rem = dim & 3;
 #pragma unroll
   for (int t = 0; t < KT; ++t)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) koff[t][c] = 32 * t + 8 * g + 4 * c < dim ? 32 * t + 8 * g + 4 * c : dim - 4;
+    for (int c = 0; c < 2; ++c) koff[t][c] = 32 * t + 8 * g + 4 * c + 4 <= dim ? 32 * t + 8 * g + 4 * c : dim - 4;
   auto load_x = [&](int64_t tile, int t) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
 #endif
       const float* xp = args.X + row * args.ldx;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) xr[rt][t][c] = *reinterpret_cast<const f32x4*>(xp + koff[t][c]);
+      for (int c = 0; c < 2; ++c) xr[rt][t][c] = reinterpret_cast<const Chunk*>(xp + koff[t][c])->v;
     }
   };
   int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;
@@ -155,7 +159,16 @@ __global__ __launch_bounds__(64 * res_waves(NCT, KT), 1) void sig16r_kernel(cons
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
-            const bool gone = 32 * t + 8 * g + 4 * c >= dim;
+            const int k0 = 32 * t + 8 * g + 4 * c;
+            const bool gone = k0 >= dim;
+            if (rem != 0) {                                            // (uniform) the chunk with the row's last 1 .. 3 elements
+              const bool part = !gone && k0 + 4 > dim;                 // holds x[dim - 4 .. dim - 1]: element e is x[k0 + e]
+              const f32x4 v = xr[rt][t][c];                            // = v[e + 4 - rem] for e < rem, nothing behind it
+              const float w0 = rem == 1 ? v[3] : (rem == 2 ? v[2] : v[1]);
+              const float w1 = rem == 1 ? 0.f : (rem == 2 ? v[3] : v[2]);
+              const float w2 = rem == 3 ? v[3] : 0.f;
+              xr[rt][t][c] = part ? f32x4{w0, w1, w2, 0.f} : v;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) xr[rt][t][c][e] = gone ? 0.f : xr[rt][t][c][e];
           }

@@ -568,8 +568,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         # name                     taken when (first match wins)
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
         ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 4 == 0, "
-                                   ">= 256 key columns or 128 .. 224 with dim >= 384 - or at most 256 key columns at dim <= 128: the "
-                                   "resident-image kernel -, hyperplane norms in range), 16-byte aligned rows"),
+                                   ">= 256 key columns or 128 .. 224 with dim >= 384, 16-byte aligned rows - or at most 256 key columns "
+                                   "at dim <= 128 .. 256: the resident-image kernel, rows of any length >= 9 at any 4-byte address -, "
+                                   "hyperplane norms in range)"),
         ("f32+replay",             "host BLAS order recognised: small batches and shapes the split pass does not take - any dim "
                                    "(dim % 4 elements through the library's scalar tail), rows at any 4-byte address"),
         ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists, a tie window "
@@ -585,7 +586,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             return "raw", 0
         model = self._replay_model() if self.tie_replay == "auto" else 0
         if model:       # (the model's own limits - 8 m + 4 elements only up to 4096, two rows per band or more - are in `model`)
-            if aligned and short_stride and self._split_applies(n, replay=True):
+            # (the resident-image kernel reads rows at any 4-byte address - an offset view, 102 elements a row)
+            if (aligned or self._resident_shape()) and short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
             # (the replay kernels: 9 elements and up at any 4-byte address, 8 in 16-byte aligned rows - shorter vectors: the host;
             #  a band of ONE row is sdot on the host, replayed at every length)
@@ -641,8 +643,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         breaks the ties on the device - it has no host step to amortise, and beats "f32 kernel + host tie-break" from
         a few hundred rows up (85 against 300 us at 512 x 768, tools/replay_crossover.py), so only tiny batches (a
         query vector: the fine-geometry f32 kernel answers in 35 us) stay off it."""
-        if self.precision != "bf16x3" or self.dim % 4 != 0 or (self.dim < 32 and not (replay and self._resident_shape())):
+        if self.precision != "bf16x3" or (self.dim < 32 and not (replay and self._resident_shape())):
             return False
+        if self.dim % 4 != 0 and not (replay and self._resident_shape() and self.dim >= 9):
+            return False              # (a scalar tail: the resident-image kernel shifts it into place, the plain-load replay follows it)
         if self.rows_per_band == 1:       # (the host sums a one-row band with sdot: only the plain-load replay follows that)
             return False
         if self.dim % 32 != 0 and not replay:      # (a partial last k-tile: only the replaying stage 2 masks the row's end)
@@ -665,7 +669,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         1 of the split pass runs with the whole fragment image resident in LDS (sig16r_kernel; the library's `sig_resident`
         decides the same way)."""
         real = self.num_bands * self.rows_per_band
-        if real > 256 or self.dim > 256 or self.dim < 8 or self.dim % 4 != 0:
+        if real > 256 or self.dim > 256 or self.dim < 8:
             return False
         nct = ((real + 15) // 16 + 3) // 4 * 4
         kt = 2 if self.dim <= 64 else (4 if self.dim <= 128 else 8)

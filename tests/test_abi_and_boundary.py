@@ -248,8 +248,11 @@ def test_route_table():
         # shapes and views the reference accepts and that used to end at the host engine (~4 M vec/s)
         tails = {LSHHasher(16, 16, 102, seed=1)._route(5_000, "host", **ok),                         # dim % 4 != 0: the library's
                  LSHHasher(5, 8, 30, seed=1)._route(5_000, "host", **ok),                            # scalar tail (model 1 or 2:
-                 LSHHasher(9, 5, 30, seed=1)._route(5_000, "host", **ok)}                            # how this host compiles it)
-        assert tails <= {("f32+replay", 1), ("f32+replay", 2)} and len(tails) == 1
+                 LSHHasher(9, 5, 30, seed=1)._route(5_000, "host", **ok)}                            # how this host compiles it) -
+        assert tails <= {("split+replay", 1), ("split+replay", 2)} and len(tails) == 1              # round 5: resident-image shapes take them
+        tails = {LSHHasher(16, 16, 302, seed=1)._route(5_000, "host", **ok), LSHHasher(32, 16, 102, seed=1)._route(5_000, "host", **ok)}
+        assert tails <= {("f32+replay", 1), ("f32+replay", 2)} and len(tails) == 1                  # ... longer or wider ones: the f32 kernel
+        assert LSHHasher(16, 4, 128, seed=1)._route(5_000, "host", aligned=False, short_stride=True, host_rows=False) == ("split+replay", 1)
         assert h._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False) == ("f32+replay", 1)   # a 4-byte offset view
         one = LSHHasher(64, 1, 64, seed=1)._route(5_000, "host", **ok)                              # one row per band: NumPy calls sdot -
         assert one in (("f32+replay", 1), ("f32+replay", 2))                                        # modelled for whole 64 / 32-element steps

@@ -206,7 +206,7 @@ def test_named_builds_differ_exactly_where_their_libraries_do(torch_mod, nb, r, 
     for build in ("openblas-skylakex", "openblas-haswell"):
         h = _hasher(23, nb, r, dim, reference_blas=build)
         keys[build] = h.hash_device(xd).cpu().numpy()
-        assert h.last_stats["route"] == "f32+replay", h.last_stats
+        assert h.last_stats["route"] == ("split+replay" if h._resident_shape() and r >= 2 else "f32+replay"), h.last_stats
         model = h._replay_model()
         for i, j in targets:                               # the tied projection's key bit is the sign of THAT build's value
             b, bit = j // r, j % r
@@ -428,3 +428,70 @@ def test_buckets_have_no_segment_for_the_padding_columns(torch_mod, nb, r, dim, 
         assert torch.equal(got, ref)
         assert st["audited_unflagged"] > 0 and st["audit_sign_disagreements"] == 0 and st["audit_max_window_ratio"] <= 1.0, st
         assert st["flagged"] == plain["flagged"] - pad, (st, plain, pad)
+
+
+# ----------------------------------------------------------------------------- rows with a scalar tail through the split pass
+@pytest.mark.parametrize("nb,r,dim,n,seed", [(16, 16, 102, 60_001, 1), (20, 6, 127, 50_000, 2), (32, 8, 9, 40_000, 3),
+                                              (8, 7, 201, 30_000, 4), (16, 4, 33, 70_000, 5), (12, 16, 61, 20_003, 6)])
+def test_rows_with_a_scalar_tail_take_the_resident_split_pass(torch_mod, nb, r, dim, n, seed):
+    """dim % 4 != 0 at resident-image shapes (16 x 16 x 102 of `other_shapes`): stage 1 fetches the row's last dim % 4 elements
+    with its last four and shifts them into place, stage 2 is the plain-load replay (scalar tail as the host's build compiles
+    it) with the margin statistics and the audit sample.  Keys == the exact-f32 route's on every row, == the literal loop's on
+    rows with true ties; a NaN row, a zero row, the batch's last row, and rows that are a view into a wider matrix."""
+    from oracle.lshrs_oracle import hash_batch_literal_packed
+
+    torch = torch_mod
+    h = _hasher(seed, nb, r, dim)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    assert h._resident_shape()
+    x = np.random.default_rng(dim + nb).standard_normal((n, dim)).astype(np.float32)
+    stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
+    special = np.arange(0, n, 40)
+    for i in special:                                      # true ties against up to three hyperplanes
+        pl = stack[sorted({(i * 7 + t) % (nb * r) for t in (0, r // 2, r - 1)})][: max(1, min(3, dim - 2))]
+        v = x[i].astype(np.float64)
+        x[i] = (v - (v @ np.linalg.pinv(pl)) @ pl).astype(np.float32)
+    x[7] = 0.0
+    x[9, dim - 1] = float("nan")                           # in the tail
+    x[n - 1, dim - 2:] = 3.0
+    xd = torch.from_numpy(x).cuda()
+    flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    got = h.hash_device(xd, row_flags=flags)
+    st = dict(h.last_stats)
+    assert st["route"] == "split+replay" and st["relaunches"] == 0, st
+    assert st["audited_unflagged"] > 0 and st["audit_sign_disagreements"] == 0 and st["audit_max_window_ratio"] <= 1.0, st
+    assert 0.0 < st["max_dev_units"] < st["tau1_ulps"], st
+    assert flags[7].item() == 1 and flags[9].item() == 2 and int(flags.sum()) == 3
+    h32 = _hasher(seed, nb, r, dim, precision="f32")
+    ref = h32.hash_device(xd)
+    assert h32.last_stats["route"] == "f32+replay"
+    assert torch.equal(got, ref), f"{int((got != ref).any(dim=2).any(dim=1).sum())} rows differ"
+    rows = np.unique(np.concatenate([special, [7, 9, n - 1], np.arange(n - 300, n)]))
+    with np.errstate(invalid="ignore"):
+        lit = hash_batch_literal_packed(h.projections, x[rows])
+    assert np.array_equal(got.cpu().numpy()[rows], lit)
+    # a view into a wider matrix: rows at 4-byte addresses, the stride no multiple of four
+    wide = torch.zeros(4096, dim + 7, device="cuda")
+    wide[:, 3:3 + dim] = xd[:4096]
+    wide[:, :3] = float("nan")                             # what lies beside a row must never be read into it
+    wide[:, 3 + dim:] = float("inf")
+    view = wide[:, 3:3 + dim]
+    got_v = h.hash_device(view)
+    assert h.last_stats["route"] == "split+replay"
+    assert torch.equal(got_v, got[:4096])
+
+
+def test_aligned_resident_shapes_take_views_at_any_address(torch_mod):
+    """dim % 4 == 0 at a resident-image shape, but the rows are a view at a 4-byte address (round 4 sent those to the f32 kernel)."""
+    torch = torch_mod
+    h = _hasher(3, 16, 4, 128)
+    if not h._replay_model():
+        pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    n = 50_000
+    wide = torch.randn(n, 131, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    view = wide[:, 1:129]
+    got = h.hash_device(view)
+    assert h.last_stats["route"] == "split+replay"
+    ref = h.hash_device(view.contiguous())
+    assert h.last_stats["route"] == "split+replay" and torch.equal(got, ref)
