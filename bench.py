@@ -770,7 +770,7 @@ def bench_other_shapes(torch, np, local_dev, n):
     """Hashers the host BLAS does not take four rows at a time, or whose vectors are not whole k-tiles (the reference's own
     docstring layouts, get_optimal_config's picks for num_perm 100 / 200, GloVe's 300-d), short vectors (BASELINE config 1's
     16 x 4 x 128 and 20 x 6 x 128: the resident-image kernel) and a vector length that is not a multiple of four (102: the
-    library's scalar tail): which route they take and at what rate - the device replay follows the library's left-over-row
+    library's scalar tail - through the resident-image split pass since round 5): which route they take and at what rate - the device replay follows the library's left-over-row
     kernels, its 4096-element blocks, its 8 m + 4 order and its tail, so none of them ends at the host engine.  1 M rows
     each, settled, 10 timed steps; 2 000 rows against the oracle."""
     from lshrs_amd import LSHHasher
