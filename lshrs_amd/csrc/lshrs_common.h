@@ -350,8 +350,7 @@ struct FixArgs {
   const int64_t* audit_list;   // the un-flagged projections stage 1 sampled (SigArgs::audit_list), audit_n slots, -1 = none:
   const float* audit_vals;     // replayed like the flagged ones behind them, nothing patched - only compared
   int audit_n;
-  int tail_model;         // sig_fixany_kernel: how the host compiles the dim % 4 elements behind the last group of four (1 / 2)
-  int plain_loads;        // stage 2 behind the split pass through sig_fixany_kernel (rows of any length at any 4-byte address)
+  int tail_model;         // how the host compiles the dim % 4 elements behind the last group of four (1 / 2): sig_fixany_kernel, sig_fix8_kernel<., GENERAL>
   // the list sorted by padded column (lshrs_sig_sort, SAMEP instantiations): every group of eight entries has ONE column, runs
   // padded to whole groups with -1; sorted_y: the entries' stage-1 values in that order; sorted_count: entries incl. padding
   const int64_t* sorted_list;

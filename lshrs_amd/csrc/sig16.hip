@@ -18,8 +18,10 @@ namespace {
 constexpr int kS1ListCap = 8192;   // flagged projections a workgroup stages in LDS before its ONE global append
 // COMPACT: the column blocks hold the bands' key columns side by side (sig_compact) - list entries and keys leave through
 // the tables; a template parameter so that the padded layout's kernel is instruction for instruction what it was.
-// PARTIAL: vectors that are not whole 32-element k-tiles (300-d, 100-d; dim % 4 == 0) - in the last k-tile the 16-byte
-// chunks past a row's end are fetched from the tile's first chunk instead (never past the end of X) and read as zero.
+// PARTIAL: vectors that are not whole 32-element k-tiles (300-d, 100-d; round 5: any length, 301-d, 767-d) - in the last k-tile
+// the 16-byte chunks that reach past a row's end are fetched from the row's last four elements instead (never a byte past the
+// row): the chunk that holds the row's last dim % 4 elements is shifted into place when it is read back, the ones behind it
+// read as zero.  Rows may start at any 4-byte address (the LDS-DMA takes it: tools/probes/lds_dma_align_probe.hip).
 template <bool COMPACT, bool PARTIAL = false>
 __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   constexpr int RT = 2, W = 8;
@@ -114,7 +116,9 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   }
 
   struct Dma { const char* pg; const char* xg; float* pdst; float* xdst; int j0; };
-  const int last_valid_chunks = PARTIAL ? (args.dim - (ktiles - 1) * kKTile) / 4 : 8;   // 16-byte chunks of a row in the last k-tile
+  const int last_valid_chunks = PARTIAL ? (args.dim - (ktiles - 1) * kKTile) / 4 : 8;   // WHOLE 16-byte chunks of a row in the last k-tile
+  const int rem = PARTIAL ? (args.dim & 3) : 0;                                          // elements of the chunk behind them
+  const int tail_off = PARTIAL ? (args.dim - 4 - (ktiles - 1) * kKTile) * 4 : 0;         // the row's last four elements, from the last k-tile's start (bytes)
   auto plan = [&](int s) {          // what stage s issues: fragments of stage s+2, x pieces 4(s&1).. of tile (s>>1)+2
     Dma f;
     const int ns = s + 2, c = ns < lasts ? ns : lasts;
@@ -139,11 +143,13 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
                                        16, 0, 0);
     } else {
       // branch-free (a branch here changes where hipcc joins the accumulator tiles around the inline-asm MFMAs): in the last
-      // k-tile a chunk past the row's end is fetched from the tile's first chunk instead; this lane's chunk of the line, as in xfo
+      // k-tile a chunk that is not wholly inside the row is fetched from the row's last four elements instead; this lane's
+      // chunk of the line, as in xfo
       const unsigned off = f.j0 ? xfo[kXPS + d - kPP] : xfo[d - kPP];
       const int lim = f.xg == xblk + (size_t)(ktiles - 1) * (kKTile * 4) ? last_valid_chunks : 8;
-      const unsigned chunk = (unsigned)((lane & 7) ^ (lane >> 3) ^ ((f.j0 + d - kPP) & 1));
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (off - ((int)chunk >= lim ? 16u * chunk : 0u))),
+      const int chunk = (int)((lane & 7) ^ (lane >> 3) ^ ((f.j0 + d - kPP) & 1));
+      const int o2 = chunk >= lim ? (int)off - 16 * chunk + tail_off : (int)off;      // (off < 2^30: 256 rows of < 2^20 elements)
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + o2),
                                        (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, LSHRS_X_AUX);
     }
   };
@@ -160,7 +166,14 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          const bool gone = 2 * g + c >= lim;
+          // the chunk with the row's last dim % 4 elements holds x[dim - 4 .. dim - 1]: element e is v[e + 4 - rem] for e < rem
+          const bool part = rem != 0 && 2 * g + c == lim;
+          const bool gone = 2 * g + c >= lim && !part;
+          const f32x4 v = xr[rt][c];
+          const float w0 = rem == 1 ? v[3] : (rem == 2 ? v[2] : v[1]);
+          const float w1 = rem == 1 ? 0.f : (rem == 2 ? v[3] : v[2]);
+          const float w2 = rem == 3 ? v[3] : 0.f;
+          xr[rt][c] = part ? f32x4{w0, w1, w2, 0.f} : v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) xr[rt][c][e] = gone ? 0.f : xr[rt][c][e];
         }

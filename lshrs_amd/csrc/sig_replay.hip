@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   const int groups = fgroups + (!SAMEP && REPLAY && a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);   // audit groups behind the list's
   const size_t ldp = (size_t)a.ktiles * kKTile;
   const int head = GENERAL ? (a.dim & 4) : 0;                 // 8 m + 4 elements: the first four go ahead of the tiles
-  const int body = GENERAL ? a.dim - head : a.ktiles * kKTile; // elements the tiles cover (from element `head` on)
+  const int m3 = GENERAL ? (a.dim & 3) : 0;                   // the library's scalar tail behind the last group of four (round 5)
+  const int body = GENERAL ? a.dim - m3 - head : a.ktiles * kKTile; // elements the tiles cover (from element `head` on)
   const int kt = GENERAL ? (body + kKTile - 1) / kKTile : a.ktiles;
   const int slabs = (kt + SLAB - 1) / SLAB;
   // statistics are kept per lane and leave the wave once, at the end (one atomic per flagged projection on a single
@@ -286,6 +287,30 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       // sub 0..3: p_sub + p_(sub+4); sub 0: q0 + q1, sub 2: q2 + q3; sub 0: (q0 + q1) + (q2 + q3)
       yb = blas_reduce(pj, kind, lane);
       if (GENERAL && blocks_done) yb = ytot + yb;
+      if (GENERAL && m3 != 0) {
+        // dim % 4 elements of scalar tail, added in plain C behind all blocks (lshrs_tb_model_row_dot; sig_fixany_kernel has the
+        // same lines): tail_model 1 as OpenBLAS's SkylakeX build contracts it, 2 as its Haswell / Zen build leaves it.  Every
+        // lane of the entry computes it (three elements at most, plain loads).
+        const int tb = head + body;
+        const float* pt = a.prow + (size_t)col * ldp + tb;
+        const float* xt = cur.xrow + tb;
+        const float a0 = pt[0], x0 = xt[0];
+        const float a1 = m3 > 1 ? pt[1] : 0.f, x1 = m3 > 1 ? xt[1] : 0.f;
+        const float a2 = m3 > 2 ? pt[2] : 0.f, x2 = m3 > 2 ? xt[2] : 0.f;
+        if (sub == 0) ss = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, __builtin_fmaf(x2, x2, ss)));
+        if (a.tail_model == 2) {                                   // nothing contracted
+          float tl = mul_then_add(0.f, a0, x0);
+          if (m3 > 1) tl = mul_then_add(tl, a1, x1);
+          if (m3 > 2) tl = mul_then_add(tl, a2, x2);
+          yb = mul_then_add(yb, tl, 1.0f);
+        } else if (m3 == 1) {
+          yb = __builtin_fmaf(a0, x0, yb);
+        } else {
+          float tl = __builtin_fmaf(a0, x0, mul_then_add(0.f, a1, x1));
+          if (m3 > 2) tl = __builtin_fmaf(a2, x2, tl);
+          yb = mul_then_add(yb, tl, 1.0f);
+        }
+      }
       float s2 = ss + __shfl(ss, (lane + 32) & 63);
       s2 += __shfl(s2, (lane + 8) & 63);
       ss = s2 + __shfl(s2, (lane + 16) & 63);
@@ -470,28 +495,16 @@ __global__ void expand_ties_kernel(const int64_t* __restrict__ tie_list, const i
 __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
   const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
   const int cnt = min(*a.flag_count, a.flag_cap);
-  const int fgroups = (cnt + kFixG - 1) / kFixG;
-  const int groups = fgroups + (a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);    // audit groups behind the list's
+  const int groups = (cnt + kFixG - 1) / kFixG;
   const size_t ldp = (size_t)a.ktiles * kKTile;
   const int body = a.dim & ~3, m3 = a.dim & 3;
-  int n_ties = 0, n_flips = 0, n_aud = 0, n_abad = 0;
-  float max_dev = 0.f, max_ratio = 0.f;
+  int n_ties = 0, n_flips = 0;
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {     // (uniform per wave)
-    const bool audit = grp >= fgroups;                             // (behind the split pass's resident stage 1: sig_fix8_kernel's audit)
-    const int e = (audit ? grp - fgroups : grp) * kFixG + g;
-    int64_t item;
-    bool inlist;
-    if (!audit) {
-      inlist = e < cnt;
-      item = a.flag_list[inlist ? e : grp * kFixG];
-    } else {
-      item = e < a.audit_n ? a.audit_list[e] : -1;
-      inlist = item >= 0;
-      if (!inlist) item = 0;
-    }
+    const int e = grp * kFixG + g;
+    const int64_t item = a.flag_list[e < cnt ? e : grp * kFixG];
     const int64_t row = item >> 21;
     const int col_raw = (int)(item & ((1 << 21) - 1));
-    const bool live = inlist && col_raw < a.padcols;
+    const bool live = e < cnt && col_raw < a.padcols;
     const int col = col_raw < a.padcols ? col_raw : 0;
     const float* __restrict__ xr = a.X + row * a.ldx;
     const float* __restrict__ pr = a.prow + (size_t)col * ldp;
@@ -597,16 +610,7 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
     float s2 = ss + __shfl(ss, (lane + 32) & 63);
     s2 += __shfl(s2, (lane + 8) & 63);
     s2 += __shfl(s2, (lane + 16) & 63);
-    if (sub == 0 && live && audit) {                               // nothing patched: compared (sig_fix8_kernel's audit branch)
-      const uint8_t kbyte = a.keys[row * (int64_t)a.row_bytes + (col >> 3)];
-      ++n_aud;
-      if ((y > 0.f) != (((kbyte >> (col & 7)) & 1) != 0)) ++n_abad;
-      const float thr = a.audit_vals[2 * e + 1];
-      if (thr > 0.f) {
-        const float ratio = __builtin_fabsf(a.audit_vals[2 * e] - y) / thr;
-        if (ratio < __builtin_inff()) max_ratio = __builtin_fmaxf(max_ratio, ratio);
-      }
-    } else if (sub == 0 && live) {
+    if (sub == 0 && live) {
       uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
       const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
       unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
@@ -614,11 +618,6 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
       const bool want = y > 0.f;                                   // (0, -0 and NaN give 0: lsh.py:204)
       const bool have = (*kb >> (col & 7)) & 1;
       if (__builtin_fabsf(y) < a.tau * sqrtf(s2) * a.tie_coef[col]) ++n_ties;
-      const float scale = sqrtf(s2) * a.norms[col];
-      if (a.flag_y != nullptr && scale > 0.f) {                    // the live margin of stage 1 (as sig_fix8_kernel measures it)
-        const float dev = __builtin_fabsf(a.flag_y[e] - y) / (scale * 0x1p-24f);
-        if (dev < __builtin_inff()) max_dev = __builtin_fmaxf(max_dev, dev);
-      }
       if (want != have) {
         ++n_flips;
         if (want) atomicOr(w32, bitmask);
@@ -630,19 +629,12 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
   for (int off = 1; off < 8; off <<= 1) {
     n_ties += __shfl_xor(n_ties, off);
     n_flips += __shfl_xor(n_flips, off);
-    n_aud += __shfl_xor(n_aud, off);
-    n_abad += __shfl_xor(n_abad, off);
-    max_dev = __builtin_fmaxf(max_dev, __shfl_xor(max_dev, off));
-    max_ratio = __builtin_fmaxf(max_ratio, __shfl_xor(max_ratio, off));
   }
   if (lane == 0) {
     int* p = a.partials + kFixParts * blockIdx.x;
     p[0] = a.count_ties ? n_ties : 0;
     p[1] = n_flips;
-    p[2] = __float_as_int(max_dev);
-    p[3] = n_aud;
-    p[4] = n_abad;
-    p[5] = __float_as_int(max_ratio);
+    p[2] = p[3] = p[4] = p[5] = 0;
   }
 }
 
@@ -741,13 +733,9 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
   const dim3 grid((unsigned)(groups < grid_cap ? groups : grid_cap)), block(64);
   if (blas_model != 0) {
     int nparts = (int)grid.x;
-    const bool sorted = o.sort != nullptr && !short_rows && f.padcols <= kSortMaxCols &&
+    const bool sorted = o.sort != nullptr && o.sort->mode == 0 && !short_rows && f.padcols <= kSortMaxCols &&
                         (int64_t)o.sort->cap >= (int64_t)flag_cap + (int64_t)kFixG * f.padcols;
-    if (f.plain_loads) {
-      // rows the LDS-DMA forms do not take (dim % 4 elements of scalar tail, rows at any 4-byte address: the resident stage 1
-      // reads those, sig16r.hip): the plain-load replay, with the list's margin statistics and the audit sample
-      hipExtLaunchKernelGGL(sig_fixany_kernel, grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
-    } else if (short_rows) {
+    if (short_rows) {
       if (blas_general(rows_per_band, f.ktiles, dim))
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
       else

@@ -49,12 +49,13 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   const Opts o = read_opts(opts);
   const float* base = static_cast<const float*>(workspace);
   // (a partial last k-tile - dim % 32 != 0 - only with the replay: its stage 2 is the one that reads the chunks past a row's end as zero)
-  // (the resident-image kernel reads rows of any length at any 4-byte address; their stage 2 is the plain-load replay)
-  const bool ragged = rs.on && blas_model != 0 && ldx < (1 << 20) &&
-                      (dim % 4 != 0 || ldx % 4 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0);
-  if (dim % 4 != 0 && !ragged) rs.on = false;
-  const bool aligned = ragged || ((dim % 32 == 0 || (blas_model != 0 && dim % 4 == 0 && (dim >= 32 || rs.on))) && (ldx % 4 == 0) &&
-                                  ldx < (1 << 20) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0));
+  // With the replaying stage 2 rows of any length (from 9 elements) at any 4-byte address: both stage-1 kernels fetch the row's
+  // last dim % 4 elements with its last four and shift them into place; stage 2 adds the library's scalar tail behind its tiles
+  // (sig_fix8_kernel<., GENERAL>); the LDS-DMA takes 4-byte aligned addresses.  (Without the replay - blas_model 0 - as
+  // before: 16-byte chunks of 16-byte aligned rows.)
+  const bool aligned = ldx < (1 << 20) &&
+                       (blas_model != 0 ? (dim % 4 == 0 || dim >= 9) && (dim >= 32 || rs.on)
+                                        : dim % 32 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0);
   if (!aligned) {  // the split pass is built for 16-byte chunks of 16-byte aligned rows; anything else takes the f32 pass (same keys)
     if (blas_model != 0) return LSHRS_E_BADARG;   // (the f32 kernel reports ties, it does not resolve them)
     return lshrs_sig_hash_batch_f32(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, tie_list, tie_cap,
@@ -223,7 +224,6 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   }
   if (blas_model != 0) {
     f.tail_model = blas_model;
-    f.plain_loads = ragged ? 1 : 0;
     f.tie_list = nullptr;
     f.flag_y = flag_y;
     f.partials = counters + LSHRS_SIG_COUNTERS;
@@ -259,9 +259,10 @@ static int lshrs_sig_hash_batch_split_replay_f32_impl(const float* X, int64_t n,
   const bool resident = sig_resident(num_bands, rows_per_band, dim).on;
   // dim % 4 elements of scalar tail: modelled from 9 elements up, model 1 / 2 = how the build compiles them (sig_fixany_kernel);
   // whole groups of four: both builds sum alike, model 1
-  const bool tail_ok = dim % 4 != 0 && resident && dim >= 9 && rows_per_band >= 2 && (blas_model == 1 || blas_model == 2);
+  const bool tail_ok = dim % 4 != 0 && dim >= 9 && rows_per_band >= 2 && (blas_model == 1 || blas_model == 2);
   if (!tail_ok && (blas_model != 1 || dim % 4 != 0)) return LSHRS_E_BADARG;
-  if ((dim < 32 && !resident) || (dim % 8 != 0 && dim > 4096) || counters == nullptr) return LSHRS_E_BADARG;
+  const int body = dim & ~3;
+  if ((dim < 32 && !resident) || (body % 8 != 0 && body > 4096) || counters == nullptr) return LSHRS_E_BADARG;
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
                     flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, audit, opts, stream, fork);
 }

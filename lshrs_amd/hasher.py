@@ -567,10 +567,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
     ROUTES = (
         # name                     taken when (first match wins)
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
-        ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (dim % 4 == 0, "
-                                   ">= 256 key columns or 128 .. 224 with dim >= 384, 16-byte aligned rows - or at most 256 key columns "
-                                   "at dim <= 128 .. 256: the resident-image kernel, rows of any length >= 9 at any 4-byte address -, "
-                                   "hyperplane norms in range)"),
+        ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (>= 256 key columns "
+                                   "or 128 .. 224 with dim >= 384 - or at most 256 key columns at dim <= 128 .. 256: the resident-image "
+                                   "kernel -, hyperplane norms in range); rows of any length >= 9 (8 m + 4 elements up to 4096) at any "
+                                   "4-byte address"),
         ("f32+replay",             "host BLAS order recognised: small batches and shapes the split pass does not take - any dim "
                                    "(dim % 4 elements through the library's scalar tail), rows at any 4-byte address"),
         ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists, a tie window "
@@ -586,8 +586,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             return "raw", 0
         model = self._replay_model() if self.tie_replay == "auto" else 0
         if model:       # (the model's own limits - 8 m + 4 elements only up to 4096, two rows per band or more - are in `model`)
-            # (the resident-image kernel reads rows at any 4-byte address - an offset view, 102 elements a row)
-            if (aligned or self._resident_shape()) and short_stride and self._split_applies(n, replay=True):
+            # (round 5: rows at any 4-byte address - an offset view, 102 or 767 elements a row - through both stage-1 kernels)
+            if short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
             # (the replay kernels: 9 elements and up at any 4-byte address, 8 in 16-byte aligned rows - shorter vectors: the host;
             #  a band of ONE row is sdot on the host, replayed at every length)
@@ -645,8 +645,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         query vector: the fine-geometry f32 kernel answers in 35 us) stay off it."""
         if self.precision != "bf16x3" or (self.dim < 32 and not (replay and self._resident_shape())):
             return False
-        if self.dim % 4 != 0 and not (replay and self._resident_shape() and self.dim >= 9):
-            return False              # (a scalar tail: the resident-image kernel shifts it into place, the plain-load replay follows it)
+        if self.dim % 4 != 0 and not (replay and self.dim >= 9):
+            return False              # (a scalar tail: stage 1 shifts it into place, the plain-load replay follows it - from 9 elements)
         if self.rows_per_band == 1:       # (the host sums a one-row band with sdot: only the plain-load replay follows that)
             return False
         if self.dim % 32 != 0 and not replay:      # (a partial last k-tile: only the replaying stage 2 masks the row's end)

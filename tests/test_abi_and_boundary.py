@@ -251,9 +251,11 @@ def test_route_table():
                  LSHHasher(9, 5, 30, seed=1)._route(5_000, "host", **ok)}                            # how this host compiles it) -
         assert tails <= {("split+replay", 1), ("split+replay", 2)} and len(tails) == 1              # round 5: resident-image shapes take them
         tails = {LSHHasher(16, 16, 302, seed=1)._route(5_000, "host", **ok), LSHHasher(32, 16, 102, seed=1)._route(5_000, "host", **ok)}
-        assert tails <= {("f32+replay", 1), ("f32+replay", 2)} and len(tails) == 1                  # ... longer or wider ones: the f32 kernel
+        assert tails <= {("split+replay", 1), ("split+replay", 2)} and len(tails) == 1              # ... and longer or wider ones (sig16_kernel)
+        tails = {LSHHasher(4, 13, 1001, seed=1)._route(5_000, "host", **ok), LSHHasher(16, 8, 289, seed=1)._route(5_000, "host", **ok)}
+        assert tails <= {("f32+replay", 1), ("f32+replay", 2)} and len(tails) == 1                  # shapes the split pass does not take at all
         assert LSHHasher(16, 4, 128, seed=1)._route(5_000, "host", aligned=False, short_stride=True, host_rows=False) == ("split+replay", 1)
-        assert h._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False) == ("f32+replay", 1)   # a 4-byte offset view
+        assert h._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False) == ("split+replay", 1)  # a 4-byte offset view (round 5)
         one = LSHHasher(64, 1, 64, seed=1)._route(5_000, "host", **ok)                              # one row per band: NumPy calls sdot -
         assert one in (("f32+replay", 1), ("f32+replay", 2))                                        # modelled for whole 64 / 32-element steps
         assert LSHHasher(64, 1, 64, seed=1)._route(1_000_000, "host", **ok) == one                  # (never the split pass)

@@ -276,8 +276,8 @@ def test_vectors_of_any_length_keep_the_device_replay(torch_mod, seed, nb, r, di
     special = _salt_with_ties(h, x)
     got = h.hash_device(torch.from_numpy(x).cuda())
     st = dict(h.last_stats)
-    # (round 5: the resident-image shapes among them - at most 256 key columns, up to 256 elements - take the split pass)
-    route = "split+replay" if h._resident_shape() and r >= 2 else "f32+replay"
+    # (round 5: the shapes among them that the split pass takes at dim % 4 == 0 take it with a scalar tail too)
+    route = "split+replay" if h._split_applies(n, replay=True) else "f32+replay"
     assert st["route"] == route and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] > special.size, st
     want = hash_batch_literal_packed(h.projections, x)
     assert np.array_equal(got.cpu().numpy(), want), int((got.cpu().numpy() != want).any(axis=(1, 2)).sum())
@@ -341,7 +341,7 @@ def test_rows_at_any_four_byte_address_keep_the_device_replay(torch_mod, nb, r, 
         assert view.data_ptr() % 16 == 4 * off
         got = h.hash_device(view)
         st = dict(h.last_stats)
-        route = "split+replay" if h._resident_shape() and r >= 2 else "f32+replay"      # (round 5: the resident-image kernel reads rows at any 4-byte address)
+        route = "split+replay" if h._split_applies(n, replay=True) else "f32+replay"     # (round 5: stage 1 reads rows at any 4-byte address)
         assert st["route"] == route and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] > special.size, st
         assert torch.equal(got, aligned)
         assert np.array_equal(got[:4_000].cpu().numpy(), want)

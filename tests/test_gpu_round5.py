@@ -206,7 +206,7 @@ def test_named_builds_differ_exactly_where_their_libraries_do(torch_mod, nb, r, 
     for build in ("openblas-skylakex", "openblas-haswell"):
         h = _hasher(23, nb, r, dim, reference_blas=build)
         keys[build] = h.hash_device(xd).cpu().numpy()
-        assert h.last_stats["route"] == ("split+replay" if h._resident_shape() and r >= 2 else "f32+replay"), h.last_stats
+        assert h.last_stats["route"] == ("split+replay" if h._split_applies(n, replay=True) else "f32+replay"), h.last_stats
         model = h._replay_model()
         for i, j in targets:                               # the tied projection's key bit is the sign of THAT build's value
             b, bit = j // r, j % r
@@ -335,7 +335,7 @@ def test_eight_lanes_deal_loader_batches_round_robin_and_store_them_in_order(tor
 # ----------------------------------------------------------------------------- stage 2 column by column
 @pytest.mark.parametrize("nb,r,dim,n,seed", [(16, 32, 1536, 120_000, 7), (16, 16, 768, 90_000, 42), (20, 10, 768, 60_000, 3),
                                               (16, 16, 300, 50_000, 5), (25, 8, 1000, 40_000, 6), (8, 25, 4100 - 4, 9_000, 8),
-                                              (8, 7, 200, 30_000, 9)])
+                                              (8, 7, 200, 30_000, 9), (16, 16, 767, 30_000, 10), (20, 10, 333, 20_000, 11)])   # (+ a scalar tail)
 def test_stage2_on_a_column_sorted_list_decides_the_same_bits(torch_mod, nb, r, dim, n, seed):
     """ABI 6, `lshrs_sig_sort`: the stage-1 list counting-sorted by key column, stage 2 with ONE hyperplane per group of eight
     (fetched once into LDS).  Same keys as the plain stage 2 - bands of any height, partial k-tiles, 8 m + 4 elements, blocks of
@@ -432,24 +432,27 @@ def test_buckets_have_no_segment_for_the_padding_columns(torch_mod, nb, r, dim, 
 
 # ----------------------------------------------------------------------------- rows with a scalar tail through the split pass
 @pytest.mark.parametrize("nb,r,dim,n,seed", [(16, 16, 102, 60_001, 1), (20, 6, 127, 50_000, 2), (32, 8, 9, 40_000, 3),
-                                              (8, 7, 201, 30_000, 4), (16, 4, 33, 70_000, 5), (12, 16, 61, 20_003, 6)])
-def test_rows_with_a_scalar_tail_take_the_resident_split_pass(torch_mod, nb, r, dim, n, seed):
-    """dim % 4 != 0 at resident-image shapes (16 x 16 x 102 of `other_shapes`): stage 1 fetches the row's last dim % 4 elements
-    with its last four and shifts them into place, stage 2 is the plain-load replay (scalar tail as the host's build compiles
-    it) with the margin statistics and the audit sample.  Keys == the exact-f32 route's on every row, == the literal loop's on
-    rows with true ties; a NaN row, a zero row, the batch's last row, and rows that are a view into a wider matrix."""
+                                              (8, 7, 201, 30_000, 4), (16, 4, 33, 70_000, 5), (12, 16, 61, 20_003, 6),
+                                              # ... and through sig16_kernel<., PARTIAL>: one element into the last k-tile, three
+                                              # short of a whole one, compact column blocks, the zero-padded 256-column image
+                                              (16, 16, 301, 30_001, 7), (16, 16, 769, 20_000, 8), (16, 16, 767, 20_000, 9),
+                                              (20, 10, 333, 20_000, 10), (8, 16, 771, 20_000, 11), (16, 32, 1025, 12_000, 12)])
+def test_rows_with_a_scalar_tail_take_the_split_pass(torch_mod, nb, r, dim, n, seed):
+    """dim % 4 != 0 (16 x 16 x 102 of `other_shapes`): stage 1 fetches the row's last dim % 4 elements with its last four and
+    shifts them into place (both kernels), stage 2 is the plain-load replay (scalar tail as the host's build compiles it) with
+    the margin statistics and the audit sample.  Keys == the exact-f32 route's on every row, == the literal loop's on rows with
+    true ties; a NaN row, a zero row, the batch's last row, and rows that are a view into a wider matrix."""
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
     torch = torch_mod
     h = _hasher(seed, nb, r, dim)
     if not h._replay_model():
         pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
-    assert h._resident_shape()
     x = np.random.default_rng(dim + nb).standard_normal((n, dim)).astype(np.float32)
     stack = np.concatenate([np.asarray(p, dtype=np.float64) for p in h.projections])
     special = np.arange(0, n, 40)
     for i in special:                                      # true ties against up to three hyperplanes
-        pl = stack[sorted({(i * 7 + t) % (nb * r) for t in (0, r // 2, r - 1)})][: max(1, min(3, dim - 2))]
+        pl = stack[sorted({(i // 40 * 7 + t) % (nb * r) for t in (0, r // 2, r - 1)})][: max(1, min(3, dim - 2))]   # (spread over the columns)
         v = x[i].astype(np.float64)
         x[i] = (v - (v @ np.linalg.pinv(pl)) @ pl).astype(np.float32)
     x[7] = 0.0

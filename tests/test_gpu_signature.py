@@ -216,7 +216,7 @@ def test_views_of_wider_matrices_through_the_split_pass(torch_mod):
         assert torch.equal(got, h.hash_device(view.contiguous()))
         odd = big[5:5 + n, 9:9 + dim]                         # 4 bytes off: the f32 kernel's and the replay's plain-load forms -
         got_odd = h.hash_device(odd)                          # or (round 5) the resident-image kernel, which reads rows at any 4-byte address
-        assert h.last_stats["route"] == ("split+replay" if h._resident_shape() else "f32+replay")
+        assert h.last_stats["route"] == "split+replay"        # (round 4: f32+replay)
         assert h.last_stats["tie_break_engine"] == "device-replay"
         assert torch.equal(got_odd, h.hash_device(odd.contiguous()))
 
@@ -1088,7 +1088,8 @@ def _stage1_values(torch, h, x):
                                            (7, 5, 12, 64), (8, 16, 8, 36), (9, 12, 16, 44), (10, 32, 8, 12),      # sig16r_kernel<4 .. 16, 2>
                                            (12, 16, 8, 256), (14, 3, 20, 160),                                   # sig16r_kernel<8 / 4, 8>
                                            (15, 16, 16, 102), (16, 20, 6, 127), (17, 32, 8, 9), (18, 8, 7, 201),  # rows with a scalar tail (round 5):
-                                           (19, 16, 4, 33), (20, 12, 16, 61)])                                   # the last dim % 4 elements shifted into place
+                                           (19, 16, 4, 33), (20, 12, 16, 61),                                    # the last dim % 4 elements shifted into place
+                                           (21, 16, 16, 301), (22, 20, 10, 333), (23, 16, 16, 767), (24, 8, 16, 771)])  # ... in sig16_kernel<., PARTIAL>
 def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     """Stage 1 of the split pass, projection by projection, against oracle/mfma_model.c's accumulator: the bf16 split of
     x and p (round to nearest even, exact residual), per 32-deep k-tile the three instructions xh*ph, xh*pm, xm*ph in

@@ -17,7 +17,7 @@ from oracle.lshrs_oracle import hash_batch_literal_packed
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-shapes = ((16, 4, 128), (20, 6, 128), (8, 16, 128), (16, 8, 256), (16, 16, 256), (16, 16, 300), (16, 16, 128), (16, 16, 102), (20, 6, 127))
+shapes = ((16, 4, 128), (20, 6, 128), (8, 16, 128), (16, 8, 256), (16, 16, 256), (16, 16, 300), (16, 16, 128), (16, 16, 102), (20, 6, 127), (16, 16, 301), (16, 16, 767), (16, 16, 768))
 for nb, r, dim in shapes:
     h = LSHHasher(nb, r, dim, seed=42)
     x = torch.randn(n, dim, device="cuda", generator=torch.Generator("cuda").manual_seed(dim + nb))
