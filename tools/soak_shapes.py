@@ -39,7 +39,9 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           (64, 1, 100), (16, 1, 33), (40, 1, 31), (24, 1, 7), (8, 1, 2), (128, 1, 770), (200, 1, 96), (32, 1, 1000), (16, 1, 4100),
           # round 5: long rows - stage 2 column by column (the list sorted by key column; dim >= 1024), incl. bands of any height,
           # partial k-tiles, several blocks of the library
-          (16, 32, 1536), (25, 8, 1024), (20, 10, 1100), (8, 25, 4096), (12, 7, 2052), (40, 5, 1280))
+          (16, 32, 1536), (25, 8, 1024), (20, 10, 1100), (8, 25, 4096), (12, 7, 2052), (40, 5, 1280),
+          # round 5: a scalar tail through the split pass (both stage-1 kernels, the bucket stage 2, the zero-padded 256-column image)
+          (16, 32, 1537), (25, 8, 1023), (8, 16, 771), (20, 6, 127), (16, 16, 33), (12, 13, 2050))
 
 
 def main():
