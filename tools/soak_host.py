@@ -8,7 +8,7 @@ import numpy as np, torch
 from lshrs_amd import LSHHasher, LSHRS, InMemoryStorage
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(77)
-shapes = [(16, 16, 768), (16, 4, 128), (8, 16, 768), (16, 32, 1536), (4, 12, 32)]
+shapes = [(16, 16, 768), (16, 4, 128), (8, 16, 768), (16, 32, 1536), (4, 12, 32), (16, 16, 102), (16, 16, 767)]
 bad = 0; rows = 0; t0 = time.time()
 hashers = {}
 for it in range(iters):
@@ -28,7 +28,8 @@ for it in range(iters):
     if n <= 3000 and not np.isnan(x).any():
         pass
     m = min(n, 3000)
-    xs = np.nan_to_num(x[:m]) + (np.abs(x[:m]).sum(1, keepdims=True) == 0)      # no zero / NaN rows for index()
+    xs = np.nan_to_num(x[:m])
+    xs = xs + (np.abs(xs).sum(1, keepdims=True) == 0)      # no zero / NaN rows for index() (the NaN may sit in the zero row)
     a, b = InMemoryStorage(), InMemoryStorage()
     ids = rng.permutation(10**6)[:m].astype(np.int64)
     LSHRS(dim=dim, num_bands=nb, rows_per_band=r, num_perm=nb * r, storage=a, hasher=h, packed_ingest=True).index(ids, xs)
