@@ -181,7 +181,7 @@ def test_named_reference_blas_keeps_the_device_route_whatever_the_host_blas(torc
         assert torch.equal(_hasher(42, 16, 16, 768).hash_device(x), ks)
 
 
-@pytest.mark.parametrize("nb,r,dim", [(16, 16, 102), (8, 5, 99), (64, 1, 100), (16, 1, 768)])
+@pytest.mark.parametrize("nb,r,dim", [(16, 16, 102), (8, 5, 99), (64, 1, 100), (16, 1, 768), (16, 16, 301), (20, 10, 767)])
 def test_named_builds_differ_exactly_where_their_libraries_do(torch_mod, nb, r, dim):
     """dim % 4 != 0 (the scalar tail) and one-row bands (sdot): the two named builds sum differently - on rows cancelled against a
     hyperplane the keys of each are the signs of ITS model (`lshrs_tb_model_row_dot`), and the one that is this host's gives the

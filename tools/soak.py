@@ -12,7 +12,7 @@ from tests._adversary import adversarial_row, tent_row
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # another seed: other batches, other planted rows
 rng = np.random.default_rng(2024 + seed)
-shapes = [(16, 16, 768), (16, 32, 1536), (16, 16, 128), (32, 8, 96), (16, 16, 100), (16, 16, 768), (16, 16, 102), (8, 16, 768)]
+shapes = [(16, 16, 768), (16, 32, 1536), (16, 16, 128), (32, 8, 96), (16, 16, 100), (16, 16, 768), (16, 16, 102), (8, 16, 768), (16, 16, 767), (20, 10, 301)]
 hashers = {}
 t0 = time.time(); rows = 0; bad = 0; planted = 0; worst_used = 0.0
 for it in range(iters):
