@@ -715,6 +715,9 @@ uint32_t lshrs_flags_replay(void) {
 #if LSHRS_FIX_SLAB != 6 || LSHRS_FIX_GRID != 1536
   f |= LSHRS_BUILD_TUNED | (1u << 21);
 #endif
+#if defined(LSHRS_BUCKET_GRID) || defined(LSHRS_BUCKET_SLAB)
+  f |= LSHRS_BUILD_TUNED | (1u << 22);
+#endif
   return f;
 }
 
@@ -744,7 +747,14 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
       // BUCKETS: stage 1 left every flagged (and sampled) projection in its column's segment - stage 2 with ONE hyperplane per
       // group of eight at once, no sort, no launch of its own for the audit sample; the launch behind it also clears the
       // column counters the next pass will use (the two sets alternate: this pass's stay readable for the live audit)
-      constexpr int kBucketGrid = 2048;
+#ifndef LSHRS_BUCKET_GRID
+#define LSHRS_BUCKET_GRID 2048      // eight single-wave workgroups per CU.  A/B builds (profiles/r05_bucket_grid_ab.log), stage 2 at config 2 / config 5 in ms:
+                                    // 2048 x 6 tiles 0.088 / 2.47; 1536: 0.102 / 2.79; 2560: 0.115 / 3.32; 2816: 0.105 / 3.20; slabs of 4: 0.094 / 2.75; of 8: 0.121 / 3.70
+#endif
+#ifndef LSHRS_BUCKET_SLAB
+#define LSHRS_BUCKET_SLAB LSHRS_FIX_SLAB
+#endif
+      constexpr int kBucketGrid = LSHRS_BUCKET_GRID, kBucketSlab = LSHRS_BUCKET_SLAB;
       const int64_t bgroups = (int64_t)f.padcols * ((f.col_cap + kFixG - 1) / kFixG);
       const dim3 bgrid((unsigned)(bgroups < kBucketGrid ? bgroups : kBucketGrid));
       FixArgs fb = f;
@@ -752,9 +762,9 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
       fb.audit_n = 0;
       fb.overflow = counters + 7;
       if (blas_general(rows_per_band, f.ktiles, dim))
-        hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabG, true>), bgrid, block, 0, s, o.ev[2], o.ev[3], 0, fb);
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kBucketSlab, true>), bgrid, block, 0, s, o.ev[2], o.ev[3], 0, fb);
       else
-        hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kFixSlabG, true>), bgrid, block, 0, s, o.ev[2], o.ev[3], 0, fb);
+        hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kBucketSlab, true>), bgrid, block, 0, s, o.ev[2], o.ev[3], 0, fb);
       hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)bgrid.x,
                          o.sort->hist + (size_t)(1 - (o.sort->parity & 1)) * kSortMaxCols, kSortMaxCols);
       return -(int)hipGetLastError();
