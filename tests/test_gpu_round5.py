@@ -483,6 +483,8 @@ def test_rows_with_a_scalar_tail_take_the_split_pass(torch_mod, nb, r, dim, n, s
     got_v = h.hash_device(view)
     assert h.last_stats["route"] == "split+replay"
     assert torch.equal(got_v, got[:4096])
+    pend = [h.hash_device_async(view), h.hash_device_async(xd)]       # the asynchronous form takes the same rows
+    assert torch.equal(pend[0].result(), got_v) and torch.equal(pend[1].result(), got)
 
 
 def test_aligned_resident_shapes_take_views_at_any_address(torch_mod):
