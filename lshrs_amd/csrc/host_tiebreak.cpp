@@ -313,7 +313,10 @@ float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t 
   if ((model != 1 && model != 2) || a == nullptr || x == nullptr || n <= 0 || row < 0 || row >= rows_per_band)
     return __builtin_nanf("");
   if (rows_per_band == 1) return tb_model_sdot(a, x, n, model);
-  if (n % 4 != 0 && (n < 9 || rows_per_band < 2)) return __builtin_nanf("");
+  // fewer than 9 elements: the SkylakeX build takes small-matrix paths of its own there (seven different trees, not modelled);
+  // the Haswell / Zen build (model 2) runs the same kernels as for longer rows - verified for every length from 1 and every row
+  // kind against NumPy on that build (tests/test_reference_blas.py)
+  if (n % 4 != 0 && (rows_per_band < 2 || (n < 9 && model != 2))) return __builtin_nanf("");
   const int64_t body = n & ~(int64_t)3;                       // whole groups of four: the kernels' share
   if (body % 8 != 0 && body > 4096) return __builtin_nanf("");     // (a short last block behind full ones: not modelled)
   const int kind = tb_row_kind(row, rows_per_band);

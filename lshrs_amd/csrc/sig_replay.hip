@@ -844,7 +844,8 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   const int body = dim & ~3;
   // (a band of ONE row is sdot on the host: modelled for every length, both builds - the plain-load form follows it)
   const bool one_row = rows_per_band == 1;
-  if (!one_row && ((body % 8 != 0 && body > 4096) || (!fast && dim < 9))) return LSHRS_E_TOOLARGE;
+  // (fewer than 9 elements with a scalar tail: only the Haswell / Zen build's order - model 2 - is modelled there)
+  if (!one_row && ((body % 8 != 0 && body > 4096) || (dim < 9 && dim % 4 != 0 && blas_model != 2))) return LSHRS_E_TOOLARGE;
   if (n >= ((int64_t)1 << 42) || (fast && blas_model != 1)) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);

@@ -589,10 +589,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             # (round 5: rows at any 4-byte address - an offset view, 102 or 767 elements a row - through both stage-1 kernels)
             if short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
-            # (the replay kernels: 9 elements and up at any 4-byte address, 8 in 16-byte aligned rows - shorter vectors: the host;
-            #  a band of ONE row is sdot on the host, replayed at every length)
-            if self.rows_per_band == 1 or self.dim >= 9 or (self.dim == 8 and aligned):
-                return "f32+replay", model
+            # (the replay kernels follow whatever `model` licenses: every length at any 4-byte address - fewer than 9 elements only
+            #  where the host's / the named build is the Haswell / Zen one, whose order is modelled down to one element)
+            return "f32+replay", model
         if (self.reference_blas == "host" and allow_pipeline and not host_rows and n >= max(131_072, self.pipeline_chunk_rows // 2)
                 and self._expected_tie_entries(32) <= 0.75 and self._tie_engine() is not None):
             # (the pipeline's per-chunk lists - and the pinned copies of the tied rows behind them - hold one entry per 32

@@ -20,6 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # and sdot (one row per band) at lengths with and without whole 32 / 64-element steps and a tail behind them
 SHAPES = [(16, 768), (32, 1536), (4, 128), (5, 100), (6, 101), (7, 102), (3, 103), (13, 640), (10, 300), (7, 12), (4, 9), (2, 10),
           (2, 8), (5, 8),
+          # fewer than 9 elements (round 5): the Haswell / Zen build runs its usual kernels there - modelled down to ONE element, every
+          # row kind; the SkylakeX build takes small-matrix paths of its own - claimed by nobody
+          (2, 2), (3, 3), (4, 5), (5, 6), (6, 7), (7, 1), (16, 4), (13, 3), (9, 7), (2, 5),
           (16, 4100 - 4), (4, 8192), (1, 768), (1, 64), (1, 100), (1, 96), (1, 33), (1, 31), (1, 7), (1, 1), (1, 1000), (1, 4100)]
 
 _PROBE = r"""
@@ -69,6 +72,9 @@ def test_named_model_is_numpy_on_that_build_bit_for_bit(build, coretype):
         if dim == 8 and r > 1 and build == "openblas-skylakex":
             assert model == 0 and licensed == 0, (r, dim)     # eight elements: that build takes another path, claimed by nobody
             continue
+        if dim < 9 and r > 1 and build == "openblas-skylakex":
+            assert model == 0, (r, dim)                       # (the licence check may still recognise an order where the paths coincide)
+            continue
         assert model in (1, 2), (r, dim)                      # every other shape of the list is one the named builds are modelled for
         assert bad == 0, (build, r, dim, model, bad)
         assert licensed in (1, 2), (build, r, dim)
@@ -84,7 +90,8 @@ def test_named_model_coverage_and_constructor_contract():
     assert nm("openblas-skylakex", 16, 768) == 1 and nm("openblas-haswell", 16, 768) == 1
     assert nm("openblas-skylakex", 16, 102) == 1 and nm("openblas-haswell", 16, 102) == 2 and nm("openblas-zen", 16, 102) == 2
     assert nm("openblas-skylakex", 1, 5) == 1 and nm("openblas-haswell", 1, 5) == 2
-    assert nm("openblas-skylakex", 2, 8) == 0 and nm("openblas-haswell", 4, 4) == 0       # small-matrix paths: not modelled
+    assert nm("openblas-skylakex", 2, 8) == 0 and nm("openblas-skylakex", 4, 4) == 0 and nm("openblas-skylakex", 3, 5) == 0   # small-matrix paths
+    assert nm("openblas-haswell", 4, 4) == 1 and nm("openblas-haswell", 3, 5) == 2 and nm("openblas-zen", 7, 1) == 2         # (round 5)
     assert nm("openblas-haswell", 2, 8) == 1 and nm("openblas-zen", 16, 8) == 1             # (eight elements: the 8-lane kernels)
     assert nm("openblas-skylakex", 4, 4100) == 0                                           # 8 m + 4 behind a full block
     assert nm("mkl", 16, 768) == 0 and nm("host", 16, 768) == 0
