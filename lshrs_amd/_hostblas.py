@@ -181,8 +181,6 @@ def named_model(build: str, rows_per_band: int, dim: int) -> int:
     body = dim & ~3
     if dim < 9 and b != 2:           # (fewer than 9 elements: the SkylakeX build takes small-matrix paths of its own - seven trees, not
         return 0                     #  modelled; the Haswell / Zen build runs the kernels it runs for longer rows, at every length from 1)
-    if body % 8 != 0 and body > 4096:
-        return 0
     return 1 if dim % 4 == 0 else b  # (whole groups of four: both builds sum alike)
 
 
@@ -203,7 +201,7 @@ def blas_order_model(planes: np.ndarray) -> int:
         body = dim & ~3               # (dim % 4 elements behind it: the library's scalar tail - from 9 elements up on its SkylakeX
         # build, at every length on its Haswell / Zen build; what the candidates below do not reproduce is not licensed)
         # (a band of ONE row is sdot on the host: modelled for every length, round 5)
-        if (r == 1 or body % 8 == 0 or body <= 4096) and r >= 1 and os.path.exists(LIBRARY):
+        if r >= 1 and os.path.exists(LIBRARY):
             lib = load()
             rng = np.random.default_rng(20240601)
             bands = sorted({0, nb // 2, nb - 1})

@@ -845,8 +845,11 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   // (a band of ONE row is sdot on the host: modelled for every length, both builds - the plain-load form follows it)
   const bool one_row = rows_per_band == 1;
   // (fewer than 9 elements with a scalar tail: only the Haswell / Zen build's order - model 2 - is modelled there)
-  if (!one_row && ((body % 8 != 0 && body > 4096) || (dim < 9 && dim % 4 != 0 && blas_model != 2))) return LSHRS_E_TOOLARGE;
-  if (n >= ((int64_t)1 << 42) || (fast && blas_model != 1)) return LSHRS_E_TOOLARGE;
+  // (8 m + 4 elements beyond 4096 - a short last block behind full ones - only through the plain-load form, which takes every
+  //  block's first four first; the LDS-DMA form takes the ROW's first four first: right up to 4096 elements)
+  if (!one_row && dim < 9 && dim % 4 != 0 && blas_model != 2) return LSHRS_E_TOOLARGE;
+  const bool short_last_block = body % 8 != 0 && body > 4096;
+  if (n >= ((int64_t)1 << 42) || (fast && !short_last_block && blas_model != 1)) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float* base = static_cast<const float*>(workspace);
   {
@@ -882,7 +885,7 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
     const int64_t groups = ((int64_t)flag_cap + kFixG - 1) / kFixG;
     const dim3 grid((unsigned)(groups < kFixGridG ? groups : kFixGridG)), block(64);
     f.tail_model = blas_model;
-    if (!fast) hipLaunchKernelGGL(sig_fixany_kernel, grid, block, 0, s, f);
+    if (!fast || short_last_block) hipLaunchKernelGGL(sig_fixany_kernel, grid, block, 0, s, f);
     else if (blas_general(rows_per_band, g.ktiles, dim)) hipLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, f);
     else hipLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, f);
     hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)grid.x);

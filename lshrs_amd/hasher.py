@@ -122,7 +122,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
                   (what NumPy's wheels ship) replayed on the device WHATEVER BLAS this host has - an index and its
                   queries hash alike on every machine that names the same build, and no host loses the device path.
                   The choice travels with `LSHRS.save_to_disk` / pickle.  Shapes the named build is not modelled for
-                  (bands of two rows or more over fewer than 9 elements; 8 m + 4 elements beyond 4096) raise `ValueError`.
+                  (bands of two rows or more over fewer than 9 elements on the SkylakeX build) raise `ValueError`.
       devices     in-process multi-device ingestion: host batches of >= 32 768 rows per device are cut into one row slice
                   per entry, hashed concurrently (one thread + hasher per entry), keys returned in row order
     """
@@ -569,7 +569,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         ("raw",                    "tie_break='none': the kernel's own bits, no tie-break"),
         ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (>= 256 key columns "
                                    "or 128 .. 224 with dim >= 384 - or at most 256 key columns at dim <= 128 .. 256: the resident-image "
-                                   "kernel -, hyperplane norms in range); rows of any length >= 9 (8 m + 4 elements up to 4096) at any "
+                                   "kernel -, hyperplane norms in range); rows of any length >= 9 (8 m + 4 elements: up to 4096) at any "
                                    "4-byte address"),
         ("f32+replay",             "host BLAS order recognised: small batches and shapes the split pass does not take - any dim "
                                    "(dim % 4 elements through the library's scalar tail), rows at any 4-byte address"),
@@ -585,7 +585,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         if mode != "host":
             return "raw", 0
         model = self._replay_model() if self.tie_replay == "auto" else 0
-        if model:       # (the model's own limits - 8 m + 4 elements only up to 4096, two rows per band or more - are in `model`)
+        if model:       # (the model's own limits - fewer than 9 elements only on the Haswell / Zen build - are in `model`)
             # (round 5: rows at any 4-byte address - an offset view, 102 or 767 elements a row - through both stage-1 kernels)
             if short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
@@ -647,6 +647,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         if self.dim % 4 != 0 and not (replay and self.dim >= 9):
             return False              # (a scalar tail: stage 1 shifts it into place, the plain-load replay follows it - from 9 elements)
         if self.rows_per_band == 1:       # (the host sums a one-row band with sdot: only the plain-load replay follows that)
+            return False
+        body = self.dim & ~3
+        if body % 8 != 0 and body > 4096:  # (8 m + 4 elements beyond 4096: the library's short last block - the plain-load replay)
             return False
         if self.dim % 32 != 0 and not replay:      # (a partial last k-tile: only the replaying stage 2 masks the row's end)
             return False

@@ -139,7 +139,16 @@ def test_recognised_model_reproduces_numpy_bit_for_bit(nb, r, dim):
 
 def test_shapes_the_model_does_not_cover_are_refused():
     rng = np.random.default_rng(1)
-    assert _hostblas.blas_order_model(rng.standard_normal((4, 8, 4100)).astype(np.float32)) == 0      # a short block behind full ones
+    recognised = _hostblas.blas_order_model(rng.standard_normal((2, 4, 64)).astype(np.float32)) == 1
+    # a short block behind full ones (8 m + 4 elements beyond 4096): modelled since round 5 - every block takes ITS first four first
+    for shape in ((4, 8, 4100), (3, 5, 4108), (2, 6, 8196)):
+        planes = rng.standard_normal(shape).astype(np.float32)
+        model = _hostblas.blas_order_model(planes)
+        assert model == (1 if recognised else 0), shape
+        for _ in range(6 if model else 0):
+            x = rng.standard_normal(shape[2]).astype(np.float32)
+            got = np.array([_model_row_dot(planes[1, i], x, i, shape[1], model=model) for i in range(shape[1])], dtype=np.float32)
+            assert np.array_equal((planes[1] @ x).view(np.uint32), got.view(np.uint32)), shape
     if _hostblas.blas_order_model(rng.standard_normal((2, 4, 64)).astype(np.float32)) == 1:
         # one row per band: NumPy's sdot, modelled for both builds of the library (1 / 2) at EVERY length (round 5: whole
         # 32-element steps through the build's SIMD kernel, the elements behind them summed in a double)
@@ -151,7 +160,16 @@ def test_shapes_the_model_does_not_cover_are_refused():
                 x = rng.standard_normal(dim).astype(np.float32)
                 got = _model_row_dot(planes[3, 0], x, 0, 1, model=model)
                 assert (planes[3] @ x)[0].view(np.uint32) == got.view(np.uint32), dim
-    assert _hostblas.blas_order_model(rng.standard_normal((4, 4, 7)).astype(np.float32)) == 0         # a tail below 9 elements
+    # a tail below 9 elements: the library's SkylakeX build takes small-matrix paths there (refused); its Haswell / Zen build runs
+    # its usual kernels (model 2, round 5) - whichever this host has, a licensed model reproduces NumPy
+    for shape in ((4, 4, 7), (3, 5, 3), (2, 9, 5), (5, 2, 6)):
+        planes = rng.standard_normal(shape).astype(np.float32)
+        model = _hostblas.blas_order_model(planes)
+        assert model in (0, 2), shape
+        for _ in range(8 if model else 0):
+            x = rng.standard_normal(shape[2]).astype(np.float32)
+            got = np.array([_model_row_dot(planes[0, i], x, i, shape[1], model=model) for i in range(shape[1])], dtype=np.float32)
+            assert np.array_equal((planes[0] @ x).view(np.uint32), got.view(np.uint32)), shape
     # dim % 4 != 0 is modelled now (the scalar tail, model 1 or 2 by how this host's library compiles it)
     if _hostblas.blas_order_model(rng.standard_normal((2, 4, 64)).astype(np.float32)) == 1:
         for shape in ((8, 5, 102), (5, 8, 30), (3, 7, 101), (2, 16, 4099), (16, 16, 103)):

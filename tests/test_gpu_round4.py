@@ -261,7 +261,8 @@ def test_perf_short_vector_throughput(torch_mod):
 @gpu
 @pytest.mark.parametrize("seed,nb,r,dim,n", [(1, 16, 16, 102, 20_000), (9, 5, 8, 30, 20_000), (3, 20, 10, 301, 12_000),
                                              (4, 4, 13, 1001, 6_000), (5, 2, 16, 4099, 3_000), (6, 8, 7, 99, 20_000),
-                                             (7, 3, 2, 9, 5_000), (8, 16, 16, 767, 9_000), (10, 6, 6, 13, 4_000)])
+                                             (7, 3, 2, 9, 5_000), (8, 16, 16, 767, 9_000), (10, 6, 6, 13, 4_000),
+                                             (11, 4, 6, 4100, 3_000), (12, 16, 16, 8199, 2_000), (13, 16, 16, 4108, 3_000)])   # 8 m + 4 beyond 4096 (round 5)
 def test_vectors_of_any_length_keep_the_device_replay(torch_mod, seed, nb, r, dim, n):
     """dim % 4 != 0: the exact-f32 kernel (plain loads) and, for its ties, the replay of the host library INCLUDING the
     scalar tail it adds behind the last group of four (lshrs_tb_model_row_dot, model 1 or 2 by how this host's library

@@ -23,7 +23,9 @@ SHAPES = [(16, 768), (32, 1536), (4, 128), (5, 100), (6, 101), (7, 102), (3, 103
           # fewer than 9 elements (round 5): the Haswell / Zen build runs its usual kernels there - modelled down to ONE element, every
           # row kind; the SkylakeX build takes small-matrix paths of its own - claimed by nobody
           (2, 2), (3, 3), (4, 5), (5, 6), (6, 7), (7, 1), (16, 4), (13, 3), (9, 7), (2, 5),
-          (16, 4100 - 4), (4, 8192), (1, 768), (1, 64), (1, 100), (1, 96), (1, 33), (1, 31), (1, 7), (1, 1), (1, 1000), (1, 4100)]
+          (16, 4100 - 4), (4, 8192),
+          # 8 m + 4 elements beyond 4096 (round 5): the short last block takes ITS first four first; with a scalar tail behind it
+          (4, 4100), (5, 4108), (3, 8196), (6, 4101), (7, 8199), (2, 5004), (1, 768), (1, 64), (1, 100), (1, 96), (1, 33), (1, 31), (1, 7), (1, 1), (1, 1000), (1, 4100)]
 
 _PROBE = r"""
 import json, sys
@@ -93,7 +95,7 @@ def test_named_model_coverage_and_constructor_contract():
     assert nm("openblas-skylakex", 2, 8) == 0 and nm("openblas-skylakex", 4, 4) == 0 and nm("openblas-skylakex", 3, 5) == 0   # small-matrix paths
     assert nm("openblas-haswell", 4, 4) == 1 and nm("openblas-haswell", 3, 5) == 2 and nm("openblas-zen", 7, 1) == 2         # (round 5)
     assert nm("openblas-haswell", 2, 8) == 1 and nm("openblas-zen", 16, 8) == 1             # (eight elements: the 8-lane kernels)
-    assert nm("openblas-skylakex", 4, 4100) == 0                                           # 8 m + 4 behind a full block
+    assert nm("openblas-skylakex", 4, 4100) == 1 and nm("openblas-haswell", 6, 4101) == 2  # 8 m + 4 behind a full block (round 5)
     assert nm("mkl", 16, 768) == 0 and nm("host", 16, 768) == 0
     with pytest.raises(ValueError, match="reference_blas must be"):
         LSHHasher(16, 16, 768, reference_blas="mkl")

@@ -41,7 +41,9 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # partial k-tiles, several blocks of the library
           (16, 32, 1536), (25, 8, 1024), (20, 10, 1100), (8, 25, 4096), (12, 7, 2052), (40, 5, 1280),
           # round 5: a scalar tail through the split pass (both stage-1 kernels, the bucket stage 2, the zero-padded 256-column image)
-          (16, 32, 1537), (25, 8, 1023), (8, 16, 771), (20, 6, 127), (16, 16, 33), (12, 13, 2050))
+          (16, 32, 1537), (25, 8, 1023), (8, 16, 771), (20, 6, 127), (16, 16, 33), (12, 13, 2050),
+          # round 5: 8 m + 4 elements beyond 4096 (the library's short last block)
+          (8, 6, 4100), (4, 16, 8196), (16, 16, 4109))
 
 
 def main():
