@@ -289,11 +289,12 @@ int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int
  * whose element [0] was the f32 kernel's tie_count; [1] receives the items expanded.  host_counts (optional, pinned
  * host int32[LSHRS_SIG_COUNTERS]) receives the block, which is left zeroed; [0] > tie_cap or [1] > flag_cap: repeat
  * the pass with room.  Inputs of whole groups of four elements (dim % 4 == 0, dim >= 8) in 16-byte aligned rows take the
- * LDS-DMA form of the replay; anything else - dim % 4 elements of scalar tail from 9 elements up (blas_model 1 / 2: how
- * the host's build of the library compiles that tail), rows at any 4-byte address, bands of ONE row (the host then calls
- * sdot: every length, ABI 6 - the build's SIMD kernel over the whole 32-element steps, blas_model 1 / 2, the f32 products of
- * the elements behind them summed in a double) - its plain-load form; 8 m + 4 body elements only up to 4096;
- * else LSHRS_E_TOOLARGE: resolve on the host.  Only `dim` elements of a row are ever fetched; keys in device memory, rows of
+ * LDS-DMA form of the replay; anything else - dim % 4 elements of scalar tail (blas_model 1: as the library's SkylakeX build
+ * compiles that tail, from 9 elements up; 2: as its Haswell / Zen build does, every length from 1), rows at any 4-byte address,
+ * 8 m + 4 elements beyond 4096 (the library's short last block), bands of ONE row (the host then calls sdot: every length,
+ * ABI 6 - the build's SIMD kernel over the whole 32-element steps, blas_model 1 / 2, the f32 products of the elements behind
+ * them summed in a double), and blas_model 3: the SkylakeX build's small-matrix kernels, bands of two rows and more over at
+ * most 8 elements (lshrs_host.h) - its plain-load form; else LSHRS_E_TOOLARGE / LSHRS_E_BADARG: resolve on the host.  Only `dim` elements of a row are ever fetched; keys in device memory, rows of
  * any width (bits are patched with 32-bit atomics on the aligned word around the byte). */
 int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx,
                                        const void* workspace, int32_t num_bands, int32_t rows_per_band, int32_t dim,

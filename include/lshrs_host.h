@@ -45,8 +45,11 @@ void lshrs_tb_destroy(void* engine);
  * ((p0+p4) + (p1+p5)) + ((p2+p6) + (p3+p7))); of the rows_per_band % 4 rows left over, a pair through the 4x2 kernel (four
  * chains over k = l (mod 4), multiply and add in two roundings, reduced (v0+v1) + (v2+v3)) and a single one through the 4x1
  * kernel (the eight chains, unfused); the vector consumed in blocks of 4096, each block's sum added to y; of 8 m + 4
- * elements the 8-lane kernels take the first four with their low lanes, then eight at a time.  n % 4 == 0 (n % 8 == 4:
- * n <= 4096).  NaN on bad arguments.  Used to check, bit for bit against NumPy in the running process, that the replay may stand in for
+ * elements the 8-lane kernels take the first four with their low lanes (every block of 4096 its own first four), then eight at
+ * a time; n % 4 elements of scalar tail behind all blocks (model 1: as the SkylakeX build contracts it, from 9 elements; model 2:
+ * as the Haswell / Zen build leaves it, every length from 1).  A band of ONE row: sdot (both builds' SIMD kernels, the elements
+ * behind the last whole 32 in a double).  model 3 = the SkylakeX build's small-matrix kernels: bands of two rows and more over
+ * at most 8 elements (rows in blocks of 16 / 8 / 4 / 2 / 1, each with its own tree per length).  NaN on bad arguments.  Used to check, bit for bit against NumPy in the running process, that the replay may stand in for
  * the engine below.  lshrs_tb_model_dot: row 0 of a four-row band. */
 float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band);
 float lshrs_tb_model_dot(const float* a, const float* x, int64_t n, int32_t model);

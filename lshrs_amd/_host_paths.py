@@ -61,7 +61,7 @@ class _HostPaths:
         dev = self._torch_device()
         with self._lock:
             streamed = (n >= 2 * 16_384 and mode == "host" and self.tie_replay == "auto"
-                        and self._split_applies(16_384, replay=True) and bool(self._replay_model()))
+                        and self._split_applies(16_384, replay=True) and self._replay_model() in (1, 2))
             if streamed:
                 return self._hash_host_streamed(arr, return_row_flags, max(16_384, int(chunk_rows)), dev, pin, device_sink)
             if 0 < n <= self._small_rows and mode == "host" and device_sink is None:
@@ -173,7 +173,7 @@ class _HostPaths:
             return None
         ldx = (self.dim + 31) // 32 * 32          # (the kernel fetches whole k-tiles: rows padded with zeros, never used)
         model = self._replay_model()
-        if not model:
+        if not model or model == 3:      # (model 3: the SkylakeX build's small-matrix kernels - the general path's plain-load replay)
             return None
         key = ("small", dev.index)
         buf = self._pinned_cache.get(key)

@@ -179,8 +179,8 @@ def named_model(build: str, rows_per_band: int, dim: int) -> int:
     if r == 1:                       # sdot: every length, the build's own SIMD kernel
         return b
     body = dim & ~3
-    if dim < 9 and b != 2:           # (fewer than 9 elements: the SkylakeX build takes small-matrix paths of its own - seven trees, not
-        return 0                     #  modelled; the Haswell / Zen build runs the kernels it runs for longer rows, at every length from 1)
+    if dim < 9 and b != 2:           # (fewer than 9 elements: the SkylakeX build's small-matrix kernels - model 3; the Haswell / Zen
+        return 3                     #  build runs the kernels it runs for longer rows, at every length from 1)
     return 1 if dim % 4 == 0 else b  # (whole groups of four: both builds sum alike)
 
 
@@ -227,7 +227,8 @@ def blas_order_model(planes: np.ndarray) -> int:
             # contracts nothing there): tried second, and only where there is a tail
             # ... and in how a band of ONE row is summed (NumPy calls sdot there: the SIMD kernel of the build, then the
             # elements behind the last whole 32 in a double - lshrs_tb_model_row_dot)
-            for candidate in ((1,) if dim % 4 == 0 and r >= 2 else (1, 2)):
+            # ... model 3: the SkylakeX build's small-matrix kernels (bands of two rows and more over at most eight elements)
+            for candidate in ((1, 2, 3) if dim < 9 and r >= 2 else ((1,) if dim % 4 == 0 and r >= 2 else (1, 2))):
                 if all(np.array_equal(want.view(np.uint32), np.array(
                         [lib.lshrs_tb_model_row_dot(plane[i].ctypes.data, x32.ctypes.data, dim, candidate, i, r)
                          for i in range(r)], dtype=np.float32).view(np.uint32)) for plane, x32, want in trials):

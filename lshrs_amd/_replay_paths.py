@@ -543,7 +543,7 @@ class _ReplayPaths:
         if (n > 0 and self.tie_break == "host" and self.tie_replay == "auto" and self._split_applies(n, replay=True)
                 and x.stride(0) < (1 << 20)):          # (round 5: rows at any 4-byte address)
             model = self._replay_model()
-        if not model:
+        if not model or model == 3:          # (model 3: at most eight elements on the SkylakeX build - the plain-load replay, synchronous)
             return _PendingKeys(self, x, self._hash_device_locked(x, out, row_flags, self.tie_break, host_rows=None),
                                 row_flags, None)
         bb = self.band_bytes

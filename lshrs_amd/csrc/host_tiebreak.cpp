@@ -309,9 +309,65 @@ static float tb_model_sdot(const float* a, const float* x, int64_t n, int32_t mo
   return (float)(tail + (double)kernel);
 }
 
+// model 3: OpenBLAS's SkylakeX build on a contiguous band of two rows and more over at most EIGHT elements - its small-matrix
+// kernels (sgemv_t_microk_skylakex: lda == m <= 8).  The band's rows go in blocks of 16 / 8, then one of four, a pair, a single
+// row - each with arithmetic of its own per length.  Found with tools/blas_order/small_matrix_search.py (summation tree by
+// masking probes, then every placement of fused multiply-adds on it against NumPy bit for bit; profiles/r05_blas_sdot_order.log
+// part 5), checked for bands of 2 .. 64 rows in tests/test_reference_blas.py.  p(k) = fl(a_k x_k); f(k, s) = fma(a_k, x_k, s).
+static float tb_model_small_skx(const float* a, const float* x, int n, int row, int rows) {
+  auto p = [&](int k) { const volatile float v = a[k] * x[k]; return (float)v; };
+  auto f = [&](int k, float s) { return __builtin_fmaf(a[k], x[k], s); };
+  auto add = [](float u, float v) { const volatile float s = u + v; return (float)s; };
+  const int b16 = rows / 16 * 16, b8 = rows / 8 * 8;
+  int rem = rows - b8;
+  int type;                                   // 16, 8, 4, 2, 1: the block this row sits in
+  if (row < b16) type = 16;
+  else if (row < b8) type = 8;
+  else if (rem >= 4 && row < b8 + 4) type = 4;
+  else {
+    const int base = b8 + (rem >= 4 ? 4 : 0);
+    rem -= rem >= 4 ? 4 : 0;
+    type = (rem >= 2 && row < base + 2) ? 2 : 1;
+  }
+  auto seq = [&]() {                          // plain left-to-right adds of rounded products
+    float s = p(0);
+    for (int k = 1; k < n; ++k) s = add(s, p(k));
+    return s;
+  };
+  auto chain = [&]() {                        // fma chain in element order, started by the rounded first product
+    float s = p(0);
+    for (int k = 1; k < n; ++k) s = f(k, s);
+    return s;
+  };
+  switch (n) {
+    case 1: return p(0);
+    case 2: return type == 16 ? f(1, p(0)) : add(p(0), p(1));
+    case 3:
+      if (type >= 8) return f(2, f(1, p(0)));
+      if (type == 2) return add(add(p(0), p(1)), p(2));
+      return f(2, f(0, p(1)));                                              // blocks of four and the single row
+    case 4: return type == 1 ? seq() : add(add(p(0), p(1)), add(p(2), p(3)));
+    case 5: return type >= 4 ? chain() : seq();
+    case 6:
+      if (type >= 8) return chain();
+      if (type == 4) return add(add(p(0), f(1, p(2))), add(p(3), f(4, p(5))));
+      return seq();
+    case 7:
+      if (type >= 8) return chain();
+      if (type == 4) return add(add(f(0, p(1)), f(4, p(5))), add(f(2, p(3)), p(6)));
+      return seq();
+    default:                                                                // 8
+      if (type >= 4) return add(add(add(p(0), p(1)), add(p(2), p(3))), add(add(p(4), p(5)), add(p(6), p(7))));
+      if (type == 2) return add(add(add(p(0), p(1)), add(p(4), p(5))), add(add(p(2), p(3)), add(p(6), p(7))));
+      return add(add(add(add(p(0), p(4)), add(p(1), p(5))), add(p(2), p(6))), add(p(3), p(7)));
+  }
+}
+
 float lshrs_tb_model_row_dot(const float* a, const float* x, int64_t n, int32_t model, int32_t row, int32_t rows_per_band) {
-  if ((model != 1 && model != 2) || a == nullptr || x == nullptr || n <= 0 || row < 0 || row >= rows_per_band)
+  if ((model != 1 && model != 2 && model != 3) || a == nullptr || x == nullptr || n <= 0 || row < 0 || row >= rows_per_band)
     return __builtin_nanf("");
+  if (model == 3)
+    return (n <= 8 && rows_per_band >= 2) ? tb_model_small_skx(a, x, (int)n, row, rows_per_band) : __builtin_nanf("");
   if (rows_per_band == 1) return tb_model_sdot(a, x, n, model);
   // fewer than 9 elements: the SkylakeX build takes small-matrix paths of its own there (seven different trees, not modelled);
   // the Haswell / Zen build (model 2) runs the same kernels as for longer rows - verified for every length from 1 and every row

@@ -492,6 +492,65 @@ __global__ void expand_ties_kernel(const int64_t* __restrict__ tie_list, const i
 // the wave's eight - with plain 4-byte loads: the eight lanes of an entry read 32 consecutive bytes of its row and of its
 // hyperplane per step.  Only behind the f32 kernel (lshrs_sig_resolve_ties_replay_f32): a tie list is short, and the rate
 // of this kernel (a few ns per entry) does not matter next to the pass in front of it.
+// blas model 3 (lshrs_host.h, tb_model_small_skx): OpenBLAS's SkylakeX build on bands of two rows and more over at most eight
+// elements - rows in blocks of 16 / 8 / 4 / 2 / 1, each with its own arithmetic per length.  One lane computes the whole value.
+__device__ __forceinline__ float mul_rounded(float a, float b) {      // (never contracted into an fma with the addition behind it:
+#pragma clang fp contract(off)                                          //  hipcc's __fmul_rn is a plain product, which it would be)
+  return a * b;
+}
+__device__ __forceinline__ float add_rounded(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float small_skx_dot(const float* __restrict__ a, const float* __restrict__ x, int n, int row, int rows) {
+  auto p = [&](int k) { return mul_rounded(a[k], x[k]); };
+  auto f = [&](int k, float s) { return __builtin_fmaf(a[k], x[k], s); };
+  const int b16 = rows / 16 * 16, b8 = rows / 8 * 8;
+  int rem = rows - b8, type;
+  if (row < b16) type = 16;
+  else if (row < b8) type = 8;
+  else if (rem >= 4 && row < b8 + 4) type = 4;
+  else {
+    const int base = b8 + (rem >= 4 ? 4 : 0);
+    rem -= rem >= 4 ? 4 : 0;
+    type = (rem >= 2 && row < base + 2) ? 2 : 1;
+  }
+  auto seq = [&]() {
+    float s = p(0);
+    for (int k = 1; k < n; ++k) s = add_rounded(s, p(k));
+    return s;
+  };
+  auto chain = [&]() {
+    float s = p(0);
+    for (int k = 1; k < n; ++k) s = f(k, s);
+    return s;
+  };
+  switch (n) {
+    case 1: return p(0);
+    case 2: return type == 16 ? f(1, p(0)) : add_rounded(p(0), p(1));
+    case 3:
+      if (type >= 8) return f(2, f(1, p(0)));
+      if (type == 2) return add_rounded(add_rounded(p(0), p(1)), p(2));
+      return f(2, f(0, p(1)));
+    case 4: return type == 1 ? seq() : add_rounded(add_rounded(p(0), p(1)), add_rounded(p(2), p(3)));
+    case 5: return type >= 4 ? chain() : seq();
+    case 6:
+      if (type >= 8) return chain();
+      if (type == 4) return add_rounded(add_rounded(p(0), f(1, p(2))), add_rounded(p(3), f(4, p(5))));
+      return seq();
+    case 7:
+      if (type >= 8) return chain();
+      if (type == 4) return add_rounded(add_rounded(f(0, p(1)), f(4, p(5))), add_rounded(f(2, p(3)), p(6)));
+      return seq();
+    default:
+      if (type >= 4)
+        return add_rounded(add_rounded(add_rounded(p(0), p(1)), add_rounded(p(2), p(3))), add_rounded(add_rounded(p(4), p(5)), add_rounded(p(6), p(7))));
+      if (type == 2)
+        return add_rounded(add_rounded(add_rounded(p(0), p(1)), add_rounded(p(4), p(5))), add_rounded(add_rounded(p(2), p(3)), add_rounded(p(6), p(7))));
+      return add_rounded(add_rounded(add_rounded(add_rounded(p(0), p(4)), add_rounded(p(1), p(5))), add_rounded(p(2), p(6))), add_rounded(p(3), p(7)));
+  }
+}
+
 __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
   const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
   const int cnt = min(*a.flag_count, a.flag_cap);
@@ -510,7 +569,13 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
     const float* __restrict__ pr = a.prow + (size_t)col * ldp;
     const int kind = blas_row_kind(col % a.band_cols, a.rows_per_band);
     float y = 0.f, ss = 0.f;
-    if (a.rows_per_band == 1) {
+    if (a.tail_model == 3) {
+      // the SkylakeX build's small-matrix kernels (at most eight elements, bands of two rows and more): every lane of the entry
+      const int j = col % a.band_cols;
+      y = j < a.rows_per_band ? small_skx_dot(pr, xr, a.dim, j, a.rows_per_band) : 0.f;
+      if (sub == 0)
+        for (int k = 0; k < a.dim; ++k) ss = __builtin_fmaf(xr[k], xr[k], ss);
+    } else if (a.rows_per_band == 1) {
       // A band of ONE row: NumPy calls sdot (lshrs_host.h, tb_model_sdot): the first n1 = dim & -32 elements through the
       // build's SIMD kernel (f32 result), the f32 products of the elements behind them summed one by one in a double, the
       // kernel's result added to that double, one rounding to f32.  Lane `sub` owns the chains c = sub + 8 j.
@@ -589,7 +654,7 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
       const float sblk = blas_reduce(pj, kind, lane);              // (every lane takes part in the shuffles)
       y = k0 == 0 ? sblk : y + sblk;
     }
-    if (m3 != 0 && a.rows_per_band != 1) {                         // the scalar tail (lshrs_tb_model_row_dot)
+    if (m3 != 0 && a.rows_per_band != 1 && a.tail_model != 3) {    // the scalar tail (lshrs_tb_model_row_dot)
       const float a0 = pr[body], x0 = xr[body];
       const float a1 = m3 > 1 ? pr[body + 1] : 0.f, x1 = m3 > 1 ? xr[body + 1] : 0.f;
       const float a2 = m3 > 2 ? pr[body + 2] : 0.f, x2 = m3 > 2 ? xr[body + 2] : 0.f;
@@ -833,21 +898,23 @@ int lshrs_sig_resolve_ties_replay_f32(const float* X, int64_t n, int64_t ldx, co
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || tie_list == nullptr || tie_count == nullptr ||
       flag_list == nullptr || flag_count == nullptr || tie_cap <= 0 || flag_cap <= 0 || n < 0 || ldx < dim ||
-      !sig_shape_ok(num_bands, rows_per_band, dim) || (blas_model != 1 && blas_model != 2))
+      !sig_shape_ok(num_bands, rows_per_band, dim) || (blas_model != 1 && blas_model != 2 && blas_model != 3) ||
+      (blas_model == 3 && (dim > 8 || rows_per_band < 2)))     // (model 3: the SkylakeX build's small-matrix kernels only)
     return LSHRS_E_BADARG;
   const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
   const int row_bytes = num_bands * g.bb;
   // stage 2 stages 16-byte chunks of 16-byte aligned rows (key rows may have any width: split_pass's comment); anything
   // else - dim % 4 elements of scalar tail (blas_model 1 / 2: how the host compiles it), rows that are only 4-byte aligned -
   // goes through the plain-load form of the same replay (sig_fixany_kernel)
-  const bool fast = dim % 4 == 0 && dim >= 8 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && rows_per_band >= 2;
+  const bool fast = dim % 4 == 0 && dim >= 8 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && rows_per_band >= 2 &&
+                    blas_model != 3;
   const int body = dim & ~3;
   // (a band of ONE row is sdot on the host: modelled for every length, both builds - the plain-load form follows it)
   const bool one_row = rows_per_band == 1;
   // (fewer than 9 elements with a scalar tail: only the Haswell / Zen build's order - model 2 - is modelled there)
   // (8 m + 4 elements beyond 4096 - a short last block behind full ones - only through the plain-load form, which takes every
   //  block's first four first; the LDS-DMA form takes the ROW's first four first: right up to 4096 elements)
-  if (!one_row && dim < 9 && dim % 4 != 0 && blas_model != 2) return LSHRS_E_TOOLARGE;
+  if (!one_row && dim < 9 && dim % 4 != 0 && blas_model == 1) return LSHRS_E_TOOLARGE;
   const bool short_last_block = body % 8 != 0 && body > 4096;
   if (n >= ((int64_t)1 << 42) || (fast && !short_last_block && blas_model != 1)) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -587,7 +587,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         model = self._replay_model() if self.tie_replay == "auto" else 0
         if model:       # (the model's own limits - fewer than 9 elements only on the Haswell / Zen build - are in `model`)
             # (round 5: rows at any 4-byte address - an offset view, 102 or 767 elements a row - through both stage-1 kernels)
-            if short_stride and self._split_applies(n, replay=True):
+            # (model 3 - the SkylakeX build's small-matrix kernels, at most eight elements - is replayed by the plain-load form only)
+            if model != 3 and short_stride and self._split_applies(n, replay=True):
                 return "split+replay", model
             # (the replay kernels follow whatever `model` licenses: every length at any 4-byte address - fewer than 9 elements only
             #  where the host's / the named build is the Haswell / Zen one, whose order is modelled down to one element)

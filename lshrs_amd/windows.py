@@ -139,6 +139,9 @@ def _window_coefficients(planes, blas_model, rows_per_band):
     num, dim = P.shape
     if blas_model == 2:           # (model 2 compiles the dim % 4 tail without contraction: at most the same number of roundings)
         blas_model = 1
+    small_skx = blas_model == 3   # (the SkylakeX build's small-matrix kernels, at most eight elements: every product passes at most
+    if small_skx:                 #  dim roundings - its own or its fma's, then at most dim - 1 additions)
+        blas_model = 1
     K = (dim + 31) // 32 * 32
     p32 = np.zeros((num, K), dtype=np.float32)
     p32[:, :dim] = P
@@ -176,6 +179,8 @@ def _window_coefficients(planes, blas_model, rows_per_band):
         else:
             kinds = np.zeros(num, dtype=np.int64)
         m_host = host_roundings(dim, K, kinds) if r != 1 else np.broadcast_to(host_roundings_sdot(dim, K), (num, K))
+        if small_skx:
+            m_host = np.broadcast_to(np.where(k < dim, float(dim), 0.0), (num, K))
     else:
         m_host = np.where(k < dim, dim + 1, 0).astype(np.float64)
     # what stage 1's value is measured against is what finally DECIDES a projection it does not flag: the replayed BLAS

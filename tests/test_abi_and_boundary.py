@@ -262,11 +262,17 @@ def test_route_table():
         assert LSHHasher(8, 1, 100, seed=1)._route(5_000, "host", **ok) == one                      # ... at every length (round 5:
         assert LSHHasher(8, 1, 5, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"             #  the elements behind the last whole 32
         assert LSHHasher(8, 1, 1, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"             #  are summed in a double)
-        # 8 elements in rows that are only 4-byte aligned - the replay kernels do not take them: the host route
-        assert LSHHasher(4, 4, 8, seed=1)._route(5_000, "host", aligned=False, short_stride=True, host_rows=False)[0] in ("plain", "f32+replay")
-        if LSHHasher(4, 4, 8, seed=1)._replay_model():
-            assert LSHHasher(4, 4, 8, seed=1)._route(5_000, "host", aligned=False, short_stride=True, host_rows=False) == ("plain", 0)
-            assert LSHHasher(4, 4, 8, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"
+        # 8 elements in rows that are only 4-byte aligned kept the host route; round 5: the plain-load replay takes every
+        # length - and fewer than 9 elements on EITHER build of the library (model 2 / 3): no `plain` for any shape with dim >= 1
+        small = LSHHasher(4, 4, 8, seed=1)
+        assert small._replay_model() in (1, 3)
+        assert small._route(5_000, "host", aligned=False, short_stride=True, host_rows=False)[0] in ("split+replay", "f32+replay")
+        assert small._route(5_000, "host", **ok)[0] in ("split+replay", "f32+replay")
+        for nb, r, dim in ((4, 4, 7), (3, 5, 3), (8, 2, 2), (5, 9, 5), (6, 16, 4), (2, 7, 6), (9, 3, 1)):
+            h2 = LSHHasher(nb, r, dim, seed=1)
+            assert h2._replay_model() in (1, 2, 3) and h2._route(5_000, "host", **ok) == ("f32+replay", h2._replay_model()), (nb, r, dim)
+            if h2._replay_model() == 3:            # (the SkylakeX build's small-matrix kernels: never the split pass)
+                assert LSHHasher(16, 4, 8, seed=1)._route(50_000, "host", **ok) == ("f32+replay", 3)
     # the host engine: chunks overlapped by the native pipeline where the tie window is narrow enough for its per-chunk lists
     # (measured windows); the PROVEN tie window without a replay ties a third of the rows - every chunk would overflow and be
     # hashed twice - so it takes the plain path with a list sized for it

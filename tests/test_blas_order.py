@@ -165,7 +165,7 @@ def test_shapes_the_model_does_not_cover_are_refused():
     for shape in ((4, 4, 7), (3, 5, 3), (2, 9, 5), (5, 2, 6)):
         planes = rng.standard_normal(shape).astype(np.float32)
         model = _hostblas.blas_order_model(planes)
-        assert model in (0, 2), shape
+        assert model in ((2, 3) if recognised else (0,)), shape      # (round 5: both builds are modelled below 9 elements)
         for _ in range(8 if model else 0):
             x = rng.standard_normal(shape[2]).astype(np.float32)
             got = np.array([_model_row_dot(planes[0, i], x, i, shape[1], model=model) for i in range(shape[1])], dtype=np.float32)

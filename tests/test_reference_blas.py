@@ -23,6 +23,7 @@ SHAPES = [(16, 768), (32, 1536), (4, 128), (5, 100), (6, 101), (7, 102), (3, 103
           # fewer than 9 elements (round 5): the Haswell / Zen build runs its usual kernels there - modelled down to ONE element, every
           # row kind; the SkylakeX build takes small-matrix paths of its own - claimed by nobody
           (2, 2), (3, 3), (4, 5), (5, 6), (6, 7), (7, 1), (16, 4), (13, 3), (9, 7), (2, 5),
+          (16, 2), (17, 3), (24, 6), (33, 7), (20, 8), (9, 5), (64, 7), (31, 4), (15, 8), (6, 3), (7, 6),
           (16, 4100 - 4), (4, 8192),
           # 8 m + 4 elements beyond 4096 (round 5): the short last block takes ITS first four first; with a scalar tail behind it
           (4, 4100), (5, 4108), (3, 8196), (6, 4101), (7, 8199), (2, 5004), (1, 768), (1, 64), (1, 100), (1, 96), (1, 33), (1, 31), (1, 7), (1, 1), (1, 1000), (1, 4100)]
@@ -71,15 +72,12 @@ def test_named_model_is_numpy_on_that_build_bit_for_bit(build, coretype):
     rows = json.loads(res.stdout.strip().splitlines()[-1])
     assert len(rows) == len(SHAPES)
     for r, dim, model, licensed, bad in rows:
-        if dim == 8 and r > 1 and build == "openblas-skylakex":
-            assert model == 0 and licensed == 0, (r, dim)     # eight elements: that build takes another path, claimed by nobody
-            continue
         if dim < 9 and r > 1 and build == "openblas-skylakex":
-            assert model == 0, (r, dim)                       # (the licence check may still recognise an order where the paths coincide)
-            continue
-        assert model in (1, 2), (r, dim)                      # every other shape of the list is one the named builds are modelled for
+            assert model == 3, (r, dim)                       # that build's small-matrix kernels (round 5: found and modelled)
+        else:
+            assert model in (1, 2), (r, dim)                  # every shape of the list is one the named builds are modelled for
         assert bad == 0, (build, r, dim, model, bad)
-        assert licensed in (1, 2), (build, r, dim)
+        assert licensed in (1, 2, 3), (build, r, dim)
     # the two builds are told apart where they differ: the scalar tail and sdot's kernel
     by = {(r, dim): model for r, dim, model, _, _ in rows}
     want = _hostblas.NAMED_BUILDS[build]
@@ -92,15 +90,14 @@ def test_named_model_coverage_and_constructor_contract():
     assert nm("openblas-skylakex", 16, 768) == 1 and nm("openblas-haswell", 16, 768) == 1
     assert nm("openblas-skylakex", 16, 102) == 1 and nm("openblas-haswell", 16, 102) == 2 and nm("openblas-zen", 16, 102) == 2
     assert nm("openblas-skylakex", 1, 5) == 1 and nm("openblas-haswell", 1, 5) == 2
-    assert nm("openblas-skylakex", 2, 8) == 0 and nm("openblas-skylakex", 4, 4) == 0 and nm("openblas-skylakex", 3, 5) == 0   # small-matrix paths
+    assert nm("openblas-skylakex", 2, 8) == 3 and nm("openblas-skylakex", 4, 4) == 3 and nm("openblas-skylakex", 3, 5) == 3   # small-matrix kernels
     assert nm("openblas-haswell", 4, 4) == 1 and nm("openblas-haswell", 3, 5) == 2 and nm("openblas-zen", 7, 1) == 2         # (round 5)
     assert nm("openblas-haswell", 2, 8) == 1 and nm("openblas-zen", 16, 8) == 1             # (eight elements: the 8-lane kernels)
     assert nm("openblas-skylakex", 4, 4100) == 1 and nm("openblas-haswell", 6, 4101) == 2  # 8 m + 4 behind a full block (round 5)
     assert nm("mkl", 16, 768) == 0 and nm("host", 16, 768) == 0
     with pytest.raises(ValueError, match="reference_blas must be"):
         LSHHasher(16, 16, 768, reference_blas="mkl")
-    with pytest.raises(ValueError, match="not modelled"):
-        LSHHasher(4, 2, 8, reference_blas="openblas-skylakex")
+    assert LSHHasher(4, 2, 8, reference_blas="openblas-skylakex")._replay_model() == 3      # (round 4: refused)
     with pytest.raises(ValueError, match="tie_replay"):
         LSHHasher(16, 16, 768, reference_blas="openblas-haswell", tie_replay="off")
     h = LSHHasher(16, 16, 768, seed=42, reference_blas="openblas-haswell")

@@ -43,7 +43,9 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # round 5: a scalar tail through the split pass (both stage-1 kernels, the bucket stage 2, the zero-padded 256-column image)
           (16, 32, 1537), (25, 8, 1023), (8, 16, 771), (20, 6, 127), (16, 16, 33), (12, 13, 2050),
           # round 5: 8 m + 4 elements beyond 4096 (the library's short last block)
-          (8, 6, 4100), (4, 16, 8196), (16, 16, 4109))
+          (8, 6, 4100), (4, 16, 8196), (16, 16, 4109),
+          # round 5: fewer than 9 elements with bands of two rows and more (model 2 on the Haswell / Zen build, 3 on the SkylakeX build)
+          (8, 4, 2), (5, 3, 7), (6, 2, 8), (4, 13, 8), (16, 16, 4), (3, 9, 5), (7, 6, 3), (2, 33, 6))
 
 
 def main():
