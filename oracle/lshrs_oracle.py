@@ -108,11 +108,12 @@ def hash_batch_literal_packed(projections: Sequence[np.ndarray], vectors) -> np.
     nb = len(projections)
     bb = band_bytes(projections[0].shape[0])
     out = np.empty((arr.shape[0], nb, bb), dtype=np.uint8)
-    for i in range(arr.shape[0]):
-        v = arr[i]
-        for b in range(nb):
-            y = projections[b] @ v
-            out[i, b] = np.packbits((y > 0).astype(np.uint8), bitorder="little")
+    with np.errstate(invalid="ignore", over="ignore"):     # (NaN / Inf rows: the reference computes on, NumPy only warns)
+        for i in range(arr.shape[0]):
+            v = arr[i]
+            for b in range(nb):
+                y = projections[b] @ v
+                out[i, b] = np.packbits((y > 0).astype(np.uint8), bitorder="little")
     return out
 
 
