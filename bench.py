@@ -777,9 +777,10 @@ def bench_other_shapes(torch, np, local_dev, n):
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
     out = {}
-    # (round 5: 64 x 1 x 100 - one row per band at a length with a tail: the host calls sdot, replayed at every length now)
+    # (round 5: 64 x 1 x 100 - one row per band at a length with a tail: the host calls sdot, replayed at every length now;
+    #  16 x 16 x 767 - a scalar tail through sig16_kernel; 16 x 4 x 6 - fewer than 9 elements: the library's small-matrix paths)
     for nb, r, dim in ((20, 10, 768), (40, 5, 768), (128, 4, 768), (25, 8, 768), (16, 4, 128), (20, 6, 128), (16, 16, 300),
-                       (16, 16, 102), (64, 1, 100)):
+                       (16, 16, 102), (64, 1, 100), (16, 16, 767), (16, 4, 6)):
         h = LSHHasher(nb, r, dim, seed=42, device=local_dev)
         x = torch.randn(n, dim, device=f"cuda:{local_dev}", generator=torch.Generator(device=f"cuda:{local_dev}").manual_seed(dim + nb))
         keys = h.hash_device(x)
