@@ -31,7 +31,8 @@ def run(rounds: int, seed: int = 2025, steps: int = 30, verbose: bool = True):
         shapes = [(768, 16, 16), (128, 16, 4), (1536, 16, 32), (64, 8, 8), (256, 16, 16),
                   # bands the host BLAS does not take four rows at a time, vectors that are not whole k-tiles, odd key widths
                   (300, 20, 10), (100, 40, 5), (768, 25, 8), (96, 5, 20),
-                  (102, 16, 16), (767, 16, 16), (301, 20, 10)]      # (round 5: a scalar tail through the split pass)
+                  (102, 16, 16), (767, 16, 16), (301, 20, 10),      # (round 5: a scalar tail through the split pass)
+                  (6, 16, 4), (8, 8, 5), (3, 12, 2), (4100, 4, 6)]  # (fewer than 9 elements; 8 m + 4 elements beyond 4096)
         dim, nb, r = shapes[rnd % len(shapes)]
         packed = bool(rnd % 2)
         centers = rng.standard_normal((40, dim)).astype(np.float32)
