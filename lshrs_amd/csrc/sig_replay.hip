@@ -25,6 +25,27 @@ __device__ __forceinline__ void fix_chain_tile(const f32x4 (&p4)[2][4], const f3
 // SIMD x 6 k issue cycles, i.e. the kernel is bound by redundant VALU issue (measured 33 us per chunk).  Here lane
 // (sub, g) = (lane >> 3, lane & 7) works for projection g of the wave's group: the eight 16-byte chunks (sub) of a
 
+// The library's scalar tail: the dim % 4 elements behind the last group of four are added in plain C behind all blocks
+// (lshrs_tb_model_row_dot) - tail_model 1 as OpenBLAS's SkylakeX build contracts that C, 2 as its Haswell / Zen build leaves it.
+// pt / xt: the first tail element of the hyperplane / the row; returns y with the tail, adds the tail's x^2 to *ss where asked.
+__device__ __forceinline__ float blas_scalar_tail(float y, const float* __restrict__ pt, const float* __restrict__ xt, int m3,
+                                                  int tail_model, bool count_ss, float* ss) {
+  const float a0 = pt[0], x0 = xt[0];
+  const float a1 = m3 > 1 ? pt[1] : 0.f, x1 = m3 > 1 ? xt[1] : 0.f;
+  const float a2 = m3 > 2 ? pt[2] : 0.f, x2 = m3 > 2 ? xt[2] : 0.f;
+  if (count_ss) *ss = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, __builtin_fmaf(x2, x2, *ss)));
+  if (tail_model == 2) {                                     // nothing contracted
+    float t = mul_then_add(0.f, a0, x0);
+    if (m3 > 1) t = mul_then_add(t, a1, x1);
+    if (m3 > 2) t = mul_then_add(t, a2, x2);
+    return mul_then_add(y, t, 1.0f);
+  }
+  if (m3 == 1) return __builtin_fmaf(a0, x0, y);
+  float t = __builtin_fmaf(a0, x0, mul_then_add(0.f, a1, x1));
+  if (m3 > 2) t = __builtin_fmaf(a2, x2, t);
+  return mul_then_add(y, t, 1.0f);
+}
+
 static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridG <= LSHRS_SIG_DEVICE_COUNTERS, "stage 2's per-workgroup slots must fit the counter block");
 //
 // REPLAY: the tie-break on the device.  Every flagged projection gets the sign of the value the HOST BLAS computes for
@@ -287,30 +308,8 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       // sub 0..3: p_sub + p_(sub+4); sub 0: q0 + q1, sub 2: q2 + q3; sub 0: (q0 + q1) + (q2 + q3)
       yb = blas_reduce(pj, kind, lane);
       if (GENERAL && blocks_done) yb = ytot + yb;
-      if (GENERAL && m3 != 0) {
-        // dim % 4 elements of scalar tail, added in plain C behind all blocks (lshrs_tb_model_row_dot; sig_fixany_kernel has the
-        // same lines): tail_model 1 as OpenBLAS's SkylakeX build contracts it, 2 as its Haswell / Zen build leaves it.  Every
-        // lane of the entry computes it (three elements at most, plain loads).
-        const int tb = head + body;
-        const float* pt = a.prow + (size_t)col * ldp + tb;
-        const float* xt = cur.xrow + tb;
-        const float a0 = pt[0], x0 = xt[0];
-        const float a1 = m3 > 1 ? pt[1] : 0.f, x1 = m3 > 1 ? xt[1] : 0.f;
-        const float a2 = m3 > 2 ? pt[2] : 0.f, x2 = m3 > 2 ? xt[2] : 0.f;
-        if (sub == 0) ss = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, __builtin_fmaf(x2, x2, ss)));
-        if (a.tail_model == 2) {                                   // nothing contracted
-          float tl = mul_then_add(0.f, a0, x0);
-          if (m3 > 1) tl = mul_then_add(tl, a1, x1);
-          if (m3 > 2) tl = mul_then_add(tl, a2, x2);
-          yb = mul_then_add(yb, tl, 1.0f);
-        } else if (m3 == 1) {
-          yb = __builtin_fmaf(a0, x0, yb);
-        } else {
-          float tl = __builtin_fmaf(a0, x0, mul_then_add(0.f, a1, x1));
-          if (m3 > 2) tl = __builtin_fmaf(a2, x2, tl);
-          yb = mul_then_add(yb, tl, 1.0f);
-        }
-      }
+      if (GENERAL && m3 != 0)       // dim % 4 elements of scalar tail behind all blocks: every lane of the entry, plain loads
+        yb = blas_scalar_tail(yb, a.prow + (size_t)col * ldp + head + body, cur.xrow + head + body, m3, a.tail_model, sub == 0, &ss);
       float s2 = ss + __shfl(ss, (lane + 32) & 63);
       s2 += __shfl(s2, (lane + 8) & 63);
       ss = s2 + __shfl(s2, (lane + 16) & 63);
@@ -654,24 +653,8 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
       const float sblk = blas_reduce(pj, kind, lane);              // (every lane takes part in the shuffles)
       y = k0 == 0 ? sblk : y + sblk;
     }
-    if (m3 != 0 && a.rows_per_band != 1 && a.tail_model != 3) {    // the scalar tail (lshrs_tb_model_row_dot)
-      const float a0 = pr[body], x0 = xr[body];
-      const float a1 = m3 > 1 ? pr[body + 1] : 0.f, x1 = m3 > 1 ? xr[body + 1] : 0.f;
-      const float a2 = m3 > 2 ? pr[body + 2] : 0.f, x2 = m3 > 2 ? xr[body + 2] : 0.f;
-      if (sub == 0) ss = __builtin_fmaf(x0, x0, __builtin_fmaf(x1, x1, __builtin_fmaf(x2, x2, ss)));
-      if (a.tail_model == 2) {                                     // nothing contracted
-        float t = mul_then_add(0.f, a0, x0);
-        if (m3 > 1) t = mul_then_add(t, a1, x1);
-        if (m3 > 2) t = mul_then_add(t, a2, x2);
-        y = mul_then_add(y, t, 1.0f);
-      } else if (m3 == 1) {
-        y = __builtin_fmaf(a0, x0, y);
-      } else {
-        float t = __builtin_fmaf(a0, x0, mul_then_add(0.f, a1, x1));
-        if (m3 > 2) t = __builtin_fmaf(a2, x2, t);
-        y = mul_then_add(y, t, 1.0f);
-      }
-    }
+    if (m3 != 0 && a.rows_per_band != 1 && a.tail_model != 3)      // the scalar tail (lshrs_tb_model_row_dot)
+      y = blas_scalar_tail(y, pr + body, xr + body, m3, a.tail_model, sub == 0, &ss);
     float s2 = ss + __shfl(ss, (lane + 32) & 63);
     s2 += __shfl(s2, (lane + 8) & 63);
     s2 += __shfl(s2, (lane + 16) & 63);
