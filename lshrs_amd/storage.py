@@ -126,6 +126,11 @@ class InMemoryStorage:
         codes = key_codes(keys).reshape(-1)
         qidx = np.repeat(np.arange(nq, dtype=np.int64), nb)
         bidx = np.tile(np.arange(nb, dtype=np.int64), nq)
+        if len(segments) > 0 and codes.shape[0] > 4096:
+            # the needles in ascending order: a binary search per needle then walks memory it has just touched (160 000 lookups in
+            # a million-code segment: 19 -> 4 ms); every segment reuses the one ordering
+            by_code = np.argsort(codes, kind="stable")
+            codes, qidx, bidx = codes[by_code], qidx[by_code], bidx[by_code]
         for seg in segments:
             g = np.searchsorted(seg.codes, codes)
             g[g >= len(seg)] = 0
