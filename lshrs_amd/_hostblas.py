@@ -158,20 +158,53 @@ def blas_row_kinds(rows_per_band: int) -> np.ndarray:
 
 # Named builds of the BLAS the reference's `projection @ vector` (lshrs/hash/lsh.py:200) may run on: `LSHHasher(reference_blas=...)`
 # pins the keys to one of them whatever BLAS this host's NumPy has.  Value = the model id of `lshrs_tb_model_row_dot` that build
-# follows where the two differ (the dim % 4 elements of sgemv_t's scalar tail, the SIMD kernel of sdot).
+# follows where the two differ (the dim % 4 elements of sgemv_t's scalar tail, the SIMD kernel of sdot, fewer than 9 elements).
+# Which CPUs run which (OpenBLAS 0.3.2x DYNAMIC_ARCH, what NumPy's wheels ship - `host_build_name()` answers for THIS process):
+#   "openblas-skylakex"  every CPU with AVX-512: the SkylakeX / Cooperlake / SapphireRapids core types - Intel Skylake-X, Cascade
+#                        Lake, Ice Lake, Sapphire Rapids and later servers, AND AMD Zen 4 / Zen 5 (EPYC 9004 / 9005, Ryzen 7000+:
+#                        the GPU box's EPYC 9575F is licensed as this build);
+#   "openblas-haswell"   AVX2 without AVX-512: the Haswell / Zen core types - Intel Haswell .. client parts, AMD Zen 1 - 3
+#                        (EPYC 7001 - 7003, Ryzen 1000 - 5000).
+# (Round 5 had an alias "openblas-zen" for the second: wrong for the Zen generations this package targets, hence gone - an index
+#  that recorded it is read as "openblas-haswell", which is what it computed.)
 NAMED_BUILDS = {
-    "openblas-skylakex": 1,     # OpenBLAS 0.3.2x DYNAMIC_ARCH on Intel Skylake-X / Cascade Lake / Ice Lake / Sapphire Rapids
-    "openblas-haswell": 2,      # ... on Haswell / Broadwell and every AMD Zen (EPYC, Ryzen): the "Haswell" / "Zen" core types
-    "openblas-zen": 2,
+    "openblas-skylakex": 1,
+    "openblas-haswell": 2,
 }
+LEGACY_BUILD_NAMES = {"openblas-zen": "openblas-haswell"}
+_MODEL_NAMES = {1: "openblas-skylakex", 2: "openblas-haswell"}
+_build_names: Dict[tuple, Optional[str]] = {}
+
+
+def host_build_name() -> Optional[str]:
+    """Which NAMED build this process's NumPy computes like, right now - "openblas-skylakex", "openblas-haswell" - or None
+    (a BLAS whose order is not recognised, or the host library has not been built).  Decided where the two builds differ: a
+    band of seven rows over 102 elements (sgemv_t's scalar tail) and a one-row band over 100 (sdot), each licensed bit for bit
+    against `P_band @ x` by `blas_order_model`; both must name the same build.  Cached per (library, thread count, process)."""
+    sig = blas_signature()
+    if sig not in _build_names:
+        rng = np.random.default_rng(20241005)
+        tail = blas_order_model(rng.standard_normal((1, 7, 102)).astype(np.float32))
+        sdot = blas_order_model(rng.standard_normal((1, 1, 100)).astype(np.float32))
+        _build_names[sig] = _MODEL_NAMES.get(tail) if tail == sdot else None
+    return _build_names[sig]
+
+
+def builds_differ(rows_per_band: int, dim: int) -> bool:
+    """Do the named builds sum a band of this shape differently (so that keys of tied projections can differ between an
+    index built on one and a query hashed on the other)?  True for a scalar tail (dim % 4 != 0), one-row bands (sdot) and
+    fewer than 9 elements; False for whole groups of four elements in bands of two rows or more - every BASELINE config."""
+    return named_model("openblas-skylakex", rows_per_band, dim) != named_model("openblas-haswell", rows_per_band, dim)
 
 
 def named_model(build: str, rows_per_band: int, dim: int) -> int:
     """The summation-order model `lshrs_tb_model_row_dot` takes for hyperplane bands of this shape when the keys are pinned to
-    a NAMED build of OpenBLAS (0: that build's order is not modelled for this shape).  The coverage is what
-    `blas_order_model` licenses on a host that really runs that build - tests/test_reference_blas.py checks the two against
-    each other under ``OPENBLAS_CORETYPE`` - minus the shapes no device route takes (fewer than 9 elements with bands of two rows
-    or more: the small-matrix paths of the two builds differ there and are not modelled)."""
+    a NAMED build of OpenBLAS (0: not a named build).  Every shape is modelled on both builds: one-row bands (sdot) at every
+    length; bands of two rows or more over whole groups of four elements sum alike on both (model 1); a scalar tail
+    (dim % 4 != 0, from 9 elements) follows the build; fewer than 9 elements: the SkylakeX build's small-matrix kernels are
+    model 3, the Haswell build runs its usual kernels down to one element.  The coverage is what `blas_order_model` licenses on
+    a host that really runs that build - tests/test_reference_blas.py checks the two against each other under
+    ``OPENBLAS_CORETYPE``."""
     b = NAMED_BUILDS.get(build, 0)
     r, dim = int(rows_per_band), int(dim)
     if not b or r < 1 or dim < 1:

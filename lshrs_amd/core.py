@@ -26,12 +26,14 @@ import gc
 import json
 import logging
 import math
+import warnings
 from pathlib import Path
 from threading import Lock
 from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
+from . import _hostblas
 from .bandrows import get_optimal_config
 from .hasher import LSHHasher
 from .packed_ops import bucket_csr as _bucket_csr
@@ -48,6 +50,30 @@ __all__ = ["LSHRS", "lshrs"]
 
 _FORMAT_VERSION = "0.1.1a4"  # on-disk format version string the reference writes (main.py:882)
 _ZERO_MSG = "Cannot index zero vector - norm undefined. Check embeddings for corruption."
+
+
+class ReferenceBlasMismatch(UserWarning):
+    """An index hashed with ``reference_blas="host"`` is being loaded on a host whose BLAS sums differently at its shape."""
+
+
+def _check_recorded_blas(reference_blas: str, recorded: Optional[str], rows_per_band: int, dim: int, strict: bool) -> None:
+    """The reference's keys are ``sign(P_band @ v)`` AS THE HOST'S ``sgemv`` ROUNDS IT (lshrs/hash/lsh.py:200): an index
+    built with ``reference_blas="host"`` on one OpenBLAS build and queried from the other hashes tied projections differently
+    wherever the two builds sum differently - a scalar tail (``dim % 4 != 0``), one-row bands, fewer than 9 elements
+    (``_hostblas.builds_differ``).  ``recorded`` is the build ``save_to_disk`` / pickle wrote down.  Says so (a
+    :class:`ReferenceBlasMismatch` warning naming both builds; ``strict``: ``ValueError``); silent where the builds agree."""
+    if reference_blas != "host" or not recorded or not _hostblas.builds_differ(rows_per_band, dim):
+        return
+    here = _hostblas.host_build_name()
+    if here == recorded:
+        return
+    msg = (f"this index was hashed with reference_blas='host' on a {recorded!r} host; this host's NumPy runs "
+           f"{here!r}" + ("" if here else " (a BLAS whose summation order is not recognised)") +
+           f", which sums bands of {rows_per_band} rows over {dim} elements differently: keys of near-tie projections may "
+           f"differ from the stored ones.  Load with reference_blas={recorded!r} to hash as the index was built.")
+    if strict:
+        raise ValueError(msg)
+    warnings.warn(msg, ReferenceBlasMismatch, stacklevel=3)
 
 
 class _DeferredStorage:
@@ -500,17 +526,22 @@ class LSHRS:
             redis_cfg["password"] = "<REDACTED>"
         with open(out / "metadata.json", "w") as fh:
             meta = {"version": _FORMAT_VERSION, "config": self._config, "redis_config": redis_cfg}
-            blas = getattr(self._hasher, "reference_blas", "host")
-            if blas != "host":        # (a key of our own: the reference's load_from_disk reads the three above only)
-                meta["lshrs_amd"] = {"reference_blas": blas}
+            # (a key of our own: the reference's load_from_disk reads the three above only.)  Which BLAS the keys are the
+            # reference's keys ON: the named build, or - for "host" - the build this host's NumPy was recognised as, so that a
+            # loader on the other kind of host can tell (`_check_recorded_blas`)
+            meta["lshrs_amd"] = self._blas_record()
             json.dump(meta, fh, indent=2)
         np.savez_compressed(out / "projections.npz", *self._hasher.projections)
 
     @classmethod
     def load_from_disk(cls, path, *, redis_config: Optional[Dict[str, Any]] = None,
-                       vector_fetch_fn: Optional[VectorFetchFn] = None, storage: Any = None) -> "LSHRS":
+                       vector_fetch_fn: Optional[VectorFetchFn] = None, storage: Any = None,
+                       reference_blas: Optional[str] = None, strict_blas: Optional[bool] = None) -> "LSHRS":
         """Rebuild from :meth:`save_to_disk` output (reference: main.py:898-983).  The stored hyperplanes
-        replace the freshly drawn ones — assigning ``_hasher.projections`` re-uploads the device image."""
+        replace the freshly drawn ones — assigning ``_hasher.projections`` re-uploads the device image.
+        ``reference_blas``: override the stored choice (e.g. the build a ``"host"`` index was recorded on);
+        ``strict_blas``: raise instead of warning when a ``"host"`` index is loaded on a host whose BLAS sums its shape
+        differently (default: the class attribute ``LSHRS.strict_blas``)."""
         src = Path(path)
         if not src.exists():
             raise FileNotFoundError(f"Directory not found: {src}")
@@ -520,13 +551,17 @@ class LSHRS:
         redis_cfg = meta["redis_config"].copy()
         if redis_config:
             redis_cfg.update(redis_config)
+        extra = meta.get("lshrs_amd", {})
+        blas = extra.get("reference_blas", "host") if reference_blas is None else reference_blas
+        blas = _hostblas.LEGACY_BUILD_NAMES.get(blas, blas)
+        _check_recorded_blas(blas, extra.get("host_blas"), cfg["rows_per_band"], cfg["dim"],
+                             cls.strict_blas if strict_blas is None else strict_blas)
         inst = cls(
             dim=cfg["dim"], num_perm=cfg["num_perm"], num_bands=cfg["num_bands"], rows_per_band=cfg["rows_per_band"],
             similarity_threshold=cfg["similarity_threshold"], buffer_size=cfg["buffer_size"],
             vector_fetch_fn=vector_fetch_fn, storage=storage, redis_host=redis_cfg["host"], redis_port=redis_cfg["port"],
             redis_db=redis_cfg["db"], redis_password=redis_cfg["password"], redis_prefix=redis_cfg["prefix"],
-            decode_responses=redis_cfg["decode_responses"], seed=cfg["seed"],
-            reference_blas=meta.get("lshrs_amd", {}).get("reference_blas", "host"))
+            decode_responses=redis_cfg["decode_responses"], seed=cfg["seed"], reference_blas=blas)
         with np.load(src / "projections.npz") as data:
             inst._hasher.projections = [data[f"arr_{i}"].astype(np.float32) for i in range(len(data.files))]
         return inst
@@ -541,6 +576,7 @@ class LSHRS:
         # back on the same device with the same windows and ingest mode
         h = self._hasher
         state["lshrs_amd"] = {
+            "host_blas": self._blas_record().get("host_blas"),
             "packed_ingest": self._packed_ingest,
             "device": getattr(h, "_device", None) if isinstance(getattr(h, "_device", None), (int, str, type(None))) else str(h._device),
             "hasher_kwargs": {**{k: getattr(h, k) for k in ("tie_break", "precision", "tie_replay", "margin_guard",
@@ -559,6 +595,10 @@ class LSHRS:
         if extra:
             hk = dict(extra.get("hasher_kwargs", {}))
             hk.pop("pipeline", None)               # (an option of earlier rounds: the interpreter-driven chunking is gone)
+            if "reference_blas" in hk:
+                hk["reference_blas"] = _hostblas.LEGACY_BUILD_NAMES.get(hk["reference_blas"], hk["reference_blas"])
+            _check_recorded_blas(hk.get("reference_blas", "host"), extra.get("host_blas"), cfg["rows_per_band"], cfg["dim"],
+                                 type(self).strict_blas)
             hk.update(extra.get("windows", {}))
             hasher = LSHHasher(num_bands=cfg["num_bands"], rows_per_band=cfg["rows_per_band"], dim=cfg["dim"],
                                seed=cfg["seed"], device=extra.get("device"), **hk)
@@ -572,6 +612,19 @@ class LSHRS:
         self._hasher.projections = [np.asarray(m, dtype=np.float32) for m in state["projections"]]
 
     # ------------------------------------------------------------------ helpers
+    strict_blas = False      # True: loading / unpickling a "host" index on a host of the other BLAS build raises (else: warns)
+
+    def _blas_record(self) -> Dict[str, Any]:
+        """What persistence writes about the BLAS the keys are the reference's keys on (`_check_recorded_blas` reads it)."""
+        blas = getattr(self._hasher, "reference_blas", "host")
+        rec: Dict[str, Any] = {"reference_blas": blas}
+        if blas == "host":
+            try:
+                rec["host_blas"] = _hostblas.host_build_name()
+            except Exception:           # pragma: no cover - a NumPy without OpenBLAS, the host library not built
+                rec["host_blas"] = None
+        return rec
+
     def _check_dim(self, vector) -> np.ndarray:
         """float32, flattened, right length (reference: main.py:1075-1080; the near-zero test of
         :1083 is evaluated by the kernel's row flag, see ``_ZERO_MSG`` call sites)."""

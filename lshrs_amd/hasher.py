@@ -118,11 +118,13 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
                   (lsh.py:200) returns on the machine that runs it - its BLAS's summation order decides the projections that
                   are ties.  "host" (default): this process's NumPy, recognised and verified at first use (a host whose
                   BLAS is not recognised hashes through the host engine: same keys, 20 M instead of 800 M vectors/s).
-                  "openblas-skylakex" / "openblas-haswell" (= "openblas-zen"): the order of that build of OpenBLAS 0.3.2x
-                  (what NumPy's wheels ship) replayed on the device WHATEVER BLAS this host has - an index and its
-                  queries hash alike on every machine that names the same build, and no host loses the device path.
-                  The choice travels with `LSHRS.save_to_disk` / pickle.  Shapes the named build is not modelled for
-                  (bands of two rows or more over fewer than 9 elements on the SkylakeX build) raise `ValueError`.
+                  "openblas-skylakex" / "openblas-haswell": the order of that build of OpenBLAS 0.3.2x (what NumPy's
+                  wheels ship) replayed on the device WHATEVER BLAS this host has - an index and its queries hash alike on
+                  every machine that names the same build, and no host loses the device path.  SkylakeX = every CPU with
+                  AVX-512 (Intel servers since Skylake-X, AMD Zen 4 / Zen 5 - EPYC 9004 / 9005); Haswell = AVX2 only (Intel
+                  Haswell .., AMD Zen 1 - 3); `LSHHasher.host_blas_name()` says which one THIS process's NumPy runs.
+                  The choice travels with `LSHRS.save_to_disk` / pickle.  Every shape is modelled on both builds (bands of
+                  two rows or more over fewer than 9 elements: the SkylakeX build's small-matrix kernels, model 3).
       devices     in-process multi-device ingestion: host batches of >= 32 768 rows per device are cut into one row slice
                   per entry, hashed concurrently (one thread + hasher per entry), keys returned in row order
     """
@@ -149,6 +151,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self.dim = int(dim)
         self.tie_break = tie_break
         if reference_blas != "host":
+            if reference_blas in _hostblas.LEGACY_BUILD_NAMES:
+                raise ValueError(f"reference_blas={reference_blas!r} named the AVX2 (Zen 1 - 3) kernels only and is gone: say "
+                                 f"{_hostblas.LEGACY_BUILD_NAMES[reference_blas]!r} for those, 'openblas-skylakex' for Zen 4 / "
+                                 "Zen 5 (AVX-512); LSHHasher.host_blas_name() tells which one this host runs")
             if reference_blas not in _hostblas.NAMED_BUILDS:
                 raise ValueError("reference_blas must be 'host' or one of " + ", ".join(sorted(_hostblas.NAMED_BUILDS)))
             if tie_replay != "auto":
@@ -623,6 +629,14 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             self._replay_model_cache = cached
         return cached[1]
 
+    @staticmethod
+    def host_blas_name() -> Optional[str]:
+        """Which named build (``reference_blas=`` value) this process's NumPy computes like - "openblas-skylakex" (AVX-512:
+        Intel servers, AMD Zen 4 / 5) or "openblas-haswell" (AVX2: Haswell .., Zen 1 - 3) -, or None when its BLAS is not
+        recognised.  What `LSHRS.save_to_disk` / pickle record beside ``reference_blas="host"``, so that loading the index on
+        a host of the other kind can say so (``_hostblas.host_build_name``)."""
+        return _hostblas.host_build_name()
+
     def _host_blas_agrees(self) -> bool:
         """Is what this process's NumPy computes the order the keys are pinned to?  (Always, for reference_blas="host"; for a
         named build: where the host's own BLAS is recognised as the same model.)  The live audit against `P_band @ x` only
@@ -805,6 +819,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self.__dict__.setdefault("_replay_model_cache", None)
         self.__dict__.setdefault("tie_replay", "auto")
         self.__dict__.setdefault("reference_blas", "host")
+        self.reference_blas = _hostblas.LEGACY_BUILD_NAMES.get(self.reference_blas, self.reference_blas)
         self.__dict__.setdefault("_host_agrees", None)
         self.__dict__.setdefault("replay_min_rows", 256)
         self.__dict__.setdefault("pipeline_pair_head", True)

@@ -40,6 +40,9 @@ def test_save_writes_the_reference_format(tmp_path, golden_dir):
     assert sorted(os.listdir(out)) == ["metadata.json", "projections.npz"]
     mine = json.load(open(out / "metadata.json"))
     ref = json.load(open(os.path.join(golden_dir, "g7_saved_index", "metadata.json")))
+    # (round 6: one key of our own beside the reference's three - which BLAS build the host's NumPy ran; the reference's loader
+    #  reads "config" / "redis_config" only, lshrs/core/main.py:941-947)
+    assert mine.pop("lshrs_amd") == {"reference_blas": "host", "host_blas": LSHHasher.host_blas_name()}
     assert mine == ref                                  # incl. version string and "<REDACTED>" password
     assert "hunter2" not in open(out / "metadata.json").read()
     with np.load(out / "projections.npz") as a, np.load(os.path.join(golden_dir, "g7_saved_index", "projections.npz")) as b:

@@ -59,7 +59,7 @@ print(json.dumps(out))
 
 
 @pytest.mark.parametrize("build,coretype", [("openblas-skylakex", "SkylakeX"), ("openblas-haswell", "Haswell"),
-                                            ("openblas-zen", "Zen")])
+                                            ("openblas-haswell", "Zen"), ("openblas-skylakex", "Cooperlake")])
 def test_named_model_is_numpy_on_that_build_bit_for_bit(build, coretype):
     """NumPy's bundled OpenBLAS forced onto the named build's kernels: wherever `named_model` claims a shape, the model
     reproduces `P_band @ x` bit for bit on every row of the band (random and cancelling vectors), and the licence check
@@ -88,15 +88,18 @@ def test_named_model_is_numpy_on_that_build_bit_for_bit(build, coretype):
 def test_named_model_coverage_and_constructor_contract():
     nm = _hostblas.named_model
     assert nm("openblas-skylakex", 16, 768) == 1 and nm("openblas-haswell", 16, 768) == 1
-    assert nm("openblas-skylakex", 16, 102) == 1 and nm("openblas-haswell", 16, 102) == 2 and nm("openblas-zen", 16, 102) == 2
+    assert nm("openblas-skylakex", 16, 102) == 1 and nm("openblas-haswell", 16, 102) == 2 and nm("openblas-zen", 16, 102) == 0
     assert nm("openblas-skylakex", 1, 5) == 1 and nm("openblas-haswell", 1, 5) == 2
     assert nm("openblas-skylakex", 2, 8) == 3 and nm("openblas-skylakex", 4, 4) == 3 and nm("openblas-skylakex", 3, 5) == 3   # small-matrix kernels
-    assert nm("openblas-haswell", 4, 4) == 1 and nm("openblas-haswell", 3, 5) == 2 and nm("openblas-zen", 7, 1) == 2         # (round 5)
-    assert nm("openblas-haswell", 2, 8) == 1 and nm("openblas-zen", 16, 8) == 1             # (eight elements: the 8-lane kernels)
+    assert nm("openblas-haswell", 4, 4) == 1 and nm("openblas-haswell", 3, 5) == 2 and nm("openblas-haswell", 7, 1) == 2         # (round 5)
+    assert nm("openblas-haswell", 2, 8) == 1 and nm("openblas-haswell", 16, 8) == 1             # (eight elements: the 8-lane kernels)
     assert nm("openblas-skylakex", 4, 4100) == 1 and nm("openblas-haswell", 6, 4101) == 2  # 8 m + 4 behind a full block (round 5)
     assert nm("mkl", 16, 768) == 0 and nm("host", 16, 768) == 0
     with pytest.raises(ValueError, match="reference_blas must be"):
         LSHHasher(16, 16, 768, reference_blas="mkl")
+    with pytest.raises(ValueError, match="openblas-haswell.*Zen 4"):          # (round 6: the alias named the wrong kernels for Zen 4 / 5)
+        LSHHasher(16, 16, 768, reference_blas="openblas-zen")
+    assert LSHHasher(4, 4, 6, reference_blas="openblas-skylakex")._replay_model() == 3     # (model 3 covers dim <= 8, r >= 2)
     assert LSHHasher(4, 2, 8, reference_blas="openblas-skylakex")._replay_model() == 3      # (round 4: refused)
     with pytest.raises(ValueError, match="tie_replay"):
         LSHHasher(16, 16, 768, reference_blas="openblas-haswell", tie_replay="off")
@@ -128,16 +131,21 @@ def test_the_choice_travels_with_the_index(tmp_path):
     idx.save_to_disk(tmp_path / "idx")
     meta = json.load(open(tmp_path / "idx" / "metadata.json"))
     assert meta["lshrs_amd"] == {"reference_blas": "openblas-haswell"} and set(meta) == {"version", "config", "redis_config", "lshrs_amd"}
+    meta["lshrs_amd"]["reference_blas"] = "openblas-zen"          # an index saved by round 5 under the alias: read as what it computed
+    json.dump(meta, open(tmp_path / "idx" / "metadata.json", "w"))
+    assert LSHRS.load_from_disk(tmp_path / "idx", storage=InMemoryStorage())._hasher.reference_blas == "openblas-haswell"
     back = LSHRS.load_from_disk(tmp_path / "idx", storage=InMemoryStorage())
     assert back._hasher.reference_blas == "openblas-haswell"
     assert all(np.array_equal(a, b) for a, b in zip(back._hasher.projections, idx._hasher.projections))
     again = pickle.loads(pickle.dumps(idx))
     assert again._hasher.reference_blas == "openblas-haswell"
     assert pickle.loads(pickle.dumps(idx._hasher)).reference_blas == "openblas-haswell"
-    # the default writes nothing of its own: the file is the reference's, byte for byte as before
+    # the default records which build the host's NumPy ran (round 6) under a key of our own; the reference's three keys are as before
     plain = LSHRS(dim=64, num_perm=32, storage=InMemoryStorage())
     plain.save_to_disk(tmp_path / "plain")
-    assert set(json.load(open(tmp_path / "plain" / "metadata.json"))) == {"version", "config", "redis_config"}
+    pmeta = json.load(open(tmp_path / "plain" / "metadata.json"))
+    assert set(pmeta) == {"version", "config", "redis_config", "lshrs_amd"}
+    assert pmeta["lshrs_amd"] == {"reference_blas": "host", "host_blas": LSHHasher.host_blas_name()}
     assert LSHRS.load_from_disk(tmp_path / "plain", storage=InMemoryStorage())._hasher.reference_blas == "host"
     old = LSHHasher(4, 4, 32).__getstate__()
     old.pop("reference_blas")
@@ -179,3 +187,66 @@ def test_sdot_roundings_bound_the_hosts_value_for_mass_in_the_last_elements():
     planes = rng.standard_normal((8, dim)).astype(np.float32)
     ca1, _, ct1, _ = window_coefficients(planes, 1, 1)
     assert np.isfinite(ca1).all() and (ca1 > 0).all() and (ct1 > 0).all()
+
+
+_SAVE = r"""
+import sys
+sys.path.insert(0, %(root)r)
+from lshrs_amd import LSHRS, InMemoryStorage, LSHHasher
+import pickle
+print("BUILD", LSHHasher.host_blas_name())
+for dim in (102, 768):
+    idx = LSHRS(dim=dim, num_perm=256, num_bands=16, rows_per_band=16, storage=InMemoryStorage())
+    idx.save_to_disk(sys.argv[1] + "/idx%%d" %% dim)
+    pickle.dump(idx, open(sys.argv[1] + "/idx%%d.pkl" %% dim, "wb"))
+"""
+
+_LOAD = r"""
+import json, pickle, sys, warnings
+sys.path.insert(0, %(root)r)
+from lshrs_amd import LSHRS, InMemoryStorage, LSHHasher
+out = {"build": LSHHasher.host_blas_name()}
+for dim in (102, 768):
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        idx = LSHRS.load_from_disk(sys.argv[1] + "/idx%%d" %% dim, storage=InMemoryStorage())
+        out["disk%%d" %% dim] = [str(x.message) for x in w if x.category.__name__ == "ReferenceBlasMismatch"]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        pickle.load(open(sys.argv[1] + "/idx%%d.pkl" %% dim, "rb"))
+        out["pickle%%d" %% dim] = [str(x.message) for x in w if x.category.__name__ == "ReferenceBlasMismatch"]
+try:
+    LSHRS.load_from_disk(sys.argv[1] + "/idx102", storage=InMemoryStorage(), strict_blas=True)
+    out["strict"] = "loaded"
+except ValueError as exc:
+    out["strict"] = str(exc)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    pinned = LSHRS.load_from_disk(sys.argv[1] + "/idx102", storage=InMemoryStorage(), reference_blas="openblas-skylakex")
+    out["pinned"] = [pinned._hasher.reference_blas, len(w)]
+print(json.dumps(out))
+"""
+
+
+def test_host_blas_name_and_the_warning_when_a_host_index_moves_to_the_other_build(tmp_path):
+    """`reference_blas="host"` on an AVX-512 host (OpenBLAS's SkylakeX-class kernels - Zen 4 / 5 included) and on
+    an AVX2 host are different keys at shapes where the two builds sum differently.  `save_to_disk` / pickle record which build the
+    host ran; loading on the other one warns (naming both) at 16 x 16 x 102 (a scalar tail) and is silent at 16 x 16 x 768."""
+    if _hostblas.numpy_blas() is None:
+        pytest.skip("this NumPy is not built on OpenBLAS")
+    run = lambda script, core: subprocess.run([sys.executable, "-c", script % {"root": ROOT}, str(tmp_path)],   # noqa: E731
+                                               env=dict(os.environ, OPENBLAS_CORETYPE=core, PYTHONPATH=ROOT),
+                                               capture_output=True, text=True, check=True).stdout
+    assert "BUILD openblas-skylakex" in run(_SAVE, "SkylakeX")
+    assert json.load(open(tmp_path / "idx102" / "metadata.json"))["lshrs_amd"] == {"reference_blas": "host", "host_blas": "openblas-skylakex"}
+    same = json.loads(run(_LOAD, "SkylakeX").strip().splitlines()[-1])
+    assert same["build"] == "openblas-skylakex" and same["disk102"] == same["pickle102"] == same["disk768"] == [] and same["strict"] == "loaded"
+    other = json.loads(run(_LOAD, "Haswell").strip().splitlines()[-1])
+    assert other["build"] == "openblas-haswell"
+    for key in ("disk102", "pickle102"):
+        assert len(other[key]) == 1 and "openblas-skylakex" in other[key][0] and "openblas-haswell" in other[key][0], other
+    assert other["disk768"] == other["pickle768"] == []                        # (whole groups of four, bands of 16 rows: both builds sum alike)
+    assert "openblas-skylakex" in other["strict"] and "openblas-haswell" in other["strict"]
+    assert other["pinned"] == ["openblas-skylakex", 0]                         # (naming the recorded build: hashed as built, nothing to warn about)
+    assert _hostblas.builds_differ(16, 102) and _hostblas.builds_differ(1, 768) and _hostblas.builds_differ(4, 6)
+    assert not _hostblas.builds_differ(16, 768) and not _hostblas.builds_differ(32, 1536) and not _hostblas.builds_differ(4, 128)
