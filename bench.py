@@ -105,7 +105,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline step (+ parity): no sustained / bound / c5 / e2e / small-n / f32 lines")
     ap.add_argument("--tau1", default=None, help="stage-1 window of the timed hasher (number or 'bound')")
-    ap.add_argument("--only", choices=("c5", "rerank"), default=None,
+    ap.add_argument("--only", choices=("c5", "rerank", "e2e", "query"), default=None,
                     help="run just that block (BASELINE config 5 / config 3) and print it as the JSON line: the command the "
                          "per-kernel rocprofv3 --stats summaries under profiles/ are taken with (tools/profile_round.sh)")
     ap.add_argument("--dry-run", action="store_true",
@@ -288,6 +288,9 @@ def main() -> None:
         torch.cuda.set_device(0)
         if args.only == "c5":
             block = bench_c5(torch, np, 0, not args.no_check)
+        elif args.only in ("e2e", "query"):
+            xr = torch.randn(1_000_000, DIM, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1000))
+            block = bench_e2e(torch, np, xr, 0) if args.only == "e2e" else bench_query_many(torch, np, xr, xr.cpu().numpy(), 0)
         else:
             xr = torch.randn(1_000_000, DIM, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1000))
             block = bench_rerank(torch, torch.device("cuda", 0), xr, np, not args.no_cpu_baseline)
@@ -897,8 +900,8 @@ def bench_e2e(torch, np, x, local_dev):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         out[label] = m / best
-        if packed:
-            out["query_many"] = bench_query_many(torch, np, idx, x[:rows], host)
+        del idx
+    out["query_many"] = bench_query_many(torch, np, x, host, local_dev)
     m = 20_000
     t0 = time.perf_counter()
     index_literal(InMemoryStorage(), ids[:m].tolist(), host[:m], LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(),
@@ -909,29 +912,99 @@ def bench_e2e(torch, np, x, local_dev):
     return out
 
 
-def bench_query_many(torch, np, idx, corpus, host):
-    """10 000 queries (noisy copies of stored rows, as config 3's) through the public batched API against
-    the index bench_e2e just built - one signature launch, array collision counting, one rerank launch on the
-    device-resident corpus - beside the reference's per-query flow restated literally (oracle) on a sample."""
+def bench_query_many(torch, np, x, host_rows, local_dev):
+    """SURVEY §8f-2 / BASELINE config 3 THROUGH THE PUBLIC API: the resident 1 M x 768 corpus indexed under id = row, then
+    10 000 queries (noisy copies of stored rows, as config 3's) in one `LSHRS.query_many`: signature pass, bucket lookup,
+    collision counting and candidate order on the device (csrc/query.hip), the cosine rerank on the resident corpus, the
+    top-p / top-k cut, one copy back.  Array form and list form, the host-counted path of round 5 beside them, the
+    reference's per-query flow restated literally (oracle) on a sample - and what fraction of cosine_kernel's own rate the
+    candidates reach when they come through the API."""
+    from lshrs_amd import LSHRS, InMemoryStorage
     from oracle.lshrs_oracle import query_literal
 
-    rows = int(corpus.shape[0])
+    rows = int(x.shape[0])
+    host = host_rows if host_rows.shape[0] == rows else x.cpu().numpy()
+    idx = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(), device=local_dev, packed_ingest=True,
+                vector_fetch_fn=lambda ids: host[np.asarray(ids)])
+    t0 = time.perf_counter()
+    idx.index(np.arange(rows, dtype=np.int64), host)
+    out = {"queries": 10_000, "stored_ids": rows, "unit": "queries/s", "index_seconds": time.perf_counter() - t0}
+    idx.set_corpus(x)
     rng = np.random.default_rng(7)
     nq = 10_000
     pick = rng.choice(rows, nq, replace=False)
     q = host[pick] + 0.1 * rng.standard_normal((nq, DIM)).astype(np.float32)
-    # bench_e2e stored every vector under ids + 1e7 and ids + 2e7 (and the first 100 000 under ids): id % 1e7 = its row
-    out = {"queries": nq, "stored_ids": 2 * rows + 100_000, "unit": "queries/s"}
-    idx.query_many(q[:200], top_k=10)
+
+    def best_of(fn, reps=5):
+        best, res = None, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, res
+
     t0 = time.perf_counter()
-    got = idx.query_many(q, top_k=10)
-    out["top_k_10"] = nq / (time.perf_counter() - t0)
-    out["source_row_among_first_three"] = float(np.mean([bool(g) and pick[i] in [v % 10_000_000 for v in g[:3]] for i, g in enumerate(got)]))
+    idx.query_many(q[:200], top_k=10)                       # first call: the store's bucket arrays go to the device, once
+    out["first_call_ms_incl_index_upload"] = (time.perf_counter() - t0) * 1e3
+    out["index_mirror_MB"] = idx._dev_buckets.upload_bytes / 1e6
+    idx.query_many(q[:200], top_k=None, top_p=0.5)
+    t, got = best_of(lambda: idx.query_many(q, top_k=10))
+    out["top_k_10"] = nq / t
+    t, arr10 = best_of(lambda: idx.query_many(q, top_k=10, return_arrays=True))
+    out["top_k_10_arrays"] = nq / t
+    out["source_row_first"] = float(np.mean([bool(g) and g[0] == pick[i] for i, g in enumerate(got)]))
+    t, arrs = best_of(lambda: idx.query_many(q, top_k=None, top_p=0.5, return_arrays=True))
+    out["top_p_0.5_arrays"] = nq / t
+    stats = dict(idx.last_query_stats)
+    t_all, full = best_of(lambda: idx.query_many(q, top_k=None, top_p=1.0, return_arrays=True))
+    cands = int(full[2][-1])
+    out["top_p_1.0_arrays"] = nq / t_all
+    t, lists = best_of(lambda: idx.query_many(q, top_k=None, top_p=0.5), reps=2)
+    out["top_p_0.5_lists"] = nq / t
+    t, _ = best_of(lambda: idx.query_many(q, top_k=10, top_p=0.5, return_arrays=True))
+    out["top_p_0.5_top_k_10_arrays"] = nq / t
+    out["results_top_p_0.5"] = int(arrs[2][-1])
+    out["candidates_reranked"] = cands
+    out["pairs_counted"] = int(stats.get("pairs", 0))
+    out["bucket_segments"] = int(stats.get("segments", 0))
+    # candidates through the API against what the rerank kernel does alone (config 3's leg of this run) and against the HBM roof
+    out["candidates_per_s_through_api"] = cands / t_all
+    out["fraction_of_hbm_roof"] = cands / t_all * (4 * DIM + 12) / 8.0e12
+    # the device part alone: the same call timed with HIP events around it (upload of the queries to download of the answers)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    idx.query_many(q, top_k=None, top_p=0.5, return_arrays=True)
+    ev1.record()
+    ev1.synchronize()
+    out["top_p_0.5_arrays_device_span_ms"] = ev0.elapsed_time(ev1)
+    # round 5's path: NumPy counting between the two launches
+    t, hosted = best_of(lambda: idx.query_many(q, top_k=10, engine="host"), reps=2)
+    out["top_k_10_host_counted"] = nq / t
+    t, hosted_p = best_of(lambda: idx.query_many(q, top_k=None, top_p=0.5, return_arrays=True, engine="host"), reps=2)
+    out["top_p_0.5_arrays_host_counted"] = nq / t
+    out["device_equals_host_counted"] = bool(hosted == got and np.array_equal(hosted_p[0], arrs[0]) and np.array_equal(hosted_p[2], arrs[2])
+                                             and float(np.abs(hosted_p[1] - arrs[1]).max()) <= 1e-6)
+    out["arrays_equal_lists"] = bool([arr10[0][arr10[2][i]:arr10[2][i + 1]].tolist() for i in range(nq)] == got
+                                     and [i for r in lists for i, _ in r] == arrs[0].tolist())
     lit = 40
     t0 = time.perf_counter()
     want = [query_literal(idx._storage, idx._hasher.projections, DIM, v, top_k=10) for v in q[:lit]]
     out["top_k_10_cpu_reference_literal"] = lit / (time.perf_counter() - t0)
     out["equal_to_reference_literal_on_sample"] = bool(want == got[:lit])
+    lit = 12
+    t0 = time.perf_counter()
+    want_p = [query_literal(idx._storage, idx._hasher.projections, DIM, v, top_k=None, top_p=0.5,
+                            fetch=lambda ids: host[np.asarray(ids)]) for v in q[:lit]]
+    out["top_p_0.5_cpu_reference_literal"] = lit / (time.perf_counter() - t0)
+    worst, same_ids = 0.0, True
+    for i, w in enumerate(want_p):
+        g = lists[i]
+        same_ids = same_ids and len(g) == len(w)
+        for (gi, gs), (wi, wsc) in zip(g, w):
+            worst = max(worst, abs(gs - wsc))
+            same_ids = same_ids and (gi == wi or abs(gs - wsc) <= 2e-5)
+    out["top_p_0.5_vs_reference_literal"] = {"queries": lit, "max_abs_score_diff": worst, "tolerance": 1e-5, "ids_equal_up_to_near_ties": bool(same_ids)}
     return out
 
 
@@ -1021,7 +1094,7 @@ def bench_rerank(torch, dev, corpus, np, with_cpu: bool):
         "metric": "cosine-rerank candidates/sec (1M x 768 corpus, 10k queries x 1k candidates, k=1000)",
         "value": q * c / (total_ms * 1e-3), "unit": "candidates/s", "ms_per_pass": total_ms,
         "roofline": {
-            "kernel": "cosine_kernel<true>", "bound": "hbm", "achieved": bytes_per_launch / (cos_ms * 1e-3) / 1e9,
+            "kernel": "cosine_kernel<true, false>", "bound": "hbm", "achieved": bytes_per_launch / (cos_ms * 1e-3) / 1e9,
             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_per_launch / (cos_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "traffic": traffic, "kernel_ms": cos_ms, "kernel_ms_min": min(cos_all), "kernel_ms_max": max(cos_all),
             "kernel_ms_is": f"mean of {reps} consecutive passes (HIP events)",

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LSHRS_ABI_VERSION 6
+#define LSHRS_ABI_VERSION 7
 
 #define LSHRS_E_BADARG   (-10001) /* NULL pointer / non-positive size / misaligned workspace */
 #define LSHRS_E_TOOLARGE (-10002) /* shape outside what the kernels support (see each call)  */
@@ -453,6 +453,76 @@ int lshrs_l2_normalize_f32(const float* X, int64_t n, int64_t ldx, int32_t dim, 
 int64_t lshrs_topk_workspace_bytes(int32_t q, int32_t c);
 int lshrs_topk_desc_f32(const float* scores, int32_t q, int32_t c, int32_t k,
                         int32_t* order, float* sorted, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Candidate path of a batch of queries (ABI 7) - what sits between the two hot kernels in
+ * LSHRS.query (lshrs/core/main.py:524-658): for every query the members of the bucket each band key selects
+ * (_candidate_counts, :1088-1111: one get_bucket per band, a dict of collision counts), the candidates ordered by
+ * (-collisions, id) (:614), the cosine of every candidate (:646, top_k_cosine with k = all of them), and the cut to
+ * max(1, ceil(n * top_p)) and top_k (:650-657) - for thousands of queries at once, nothing leaving the device in between.
+ * Integer work, bit-exact: ids, counts and order are the reference's; scores are lshrs_cosine_batch_f32's.
+ * ------------------------------------------------------------------------------------------ */
+
+/* One array segment of the bucket index as the device sees it (lshrs_amd.packed_ops.BucketCSR, uploaded once and kept):
+ * buckets sorted by code = band << (8 * band_bytes) | little-endian key; bucket g holds members[offsets[g] .. offsets[g+1]).
+ * All three DEVICE pointers.  A store holds one segment per ingested batch (until it folds them). */
+typedef struct lshrs_bucket_segment {
+  const int64_t* codes;     /* int64[n_codes], ascending */
+  const int64_t* offsets;   /* int64[n_codes + 1] */
+  const int64_t* members;   /* int64[offsets[n_codes]]: vector ids, >= 0 */
+  int64_t n_codes;
+} lshrs_bucket_segment;
+
+/* Longest pair list (members of all its buckets, with multiplicity) - and longest candidate list - ONE query may have for the
+ * LDS-resident networks below: 16 384 64-bit items = 128 KB of the 160 KB of a CU.  Longer: LSHRS_E_TOOLARGE (the caller
+ * counts on the host). */
+#define LSHRS_QUERY_MAX_PAIRS 16384
+
+/* Bucket lookup.  keys (q, num_bands, band_bytes) u8 DEVICE (the signature pass's output; band_bytes <= 6); segments DEVICE
+ * lshrs_bucket_segment[nseg] (nseg may be 0: an empty index).  Slot (query, band, segment) = (qi * num_bands + b) * nseg + g:
+ *   slot_start int64, slot_len int32   the bucket's members are segment g's members[start .. start + len)
+ *   slot_off   int32                   where they go in the query's pair list (exclusive running sum over the query's slots)
+ *   pair_count int32[q]                length of that list (saturated at INT32_MAX) */
+int lshrs_query_lookup_u8(const uint8_t* keys, int32_t q, int32_t num_bands, int32_t band_bytes,
+                          const lshrs_bucket_segment* segments, int32_t nseg, int64_t* slot_start, int32_t* slot_len,
+                          int32_t* slot_off, int32_t* pair_count, void* stream);
+
+/* offsets int64[q + 1] = exclusive running sum of v[i], totals int64[2] (optional) = {sum, max} of v; one workgroup.
+ *   keep_out == NULL: v = counts.
+ *   keep_out != NULL: v[i] = keep_out[i] = how many of counts[i] ranked candidates LSHRS.query returns
+ *     (lshrs/core/main.py:619-625, :650-657): 0 for no candidates; top_p < 0 (None): min(n, top_k) (top_k < 0: n);
+ *     else min(max(1, ceil((double)n * top_p)), top_k).  top_p <= 1. */
+int lshrs_query_scan_i32(const int32_t* counts, int32_t q, int32_t top_k, double top_p, int32_t* keep_out,
+                         int64_t* offsets, int64_t* totals, void* stream);
+
+/* Collision counts and candidate order, one workgroup per query, in LDS.  pair_off int64[q + 1]: the scan of pair_count;
+ * max_pairs >= every list (<= LSHRS_QUERY_MAX_PAIRS).  Query qi's candidates - distinct ids over its buckets - are written
+ * to cand_ids[pair_off[qi] .. + ucount[qi]) ordered by (-collisions, id), cand_hits (optional) the collisions of each: an id
+ * found twice in ONE band's bucket (two segments) counts once there (buckets are sets).  Needs every id < 2^(63 - bits(num_bands)).
+ * _index: members read from the segments through lshrs_query_lookup_u8's slots; _pairs: (member, band) pairs handed in flat
+ * (query qi's at pair_off[qi]) - for stores that only answer get_bucket (lshrs/storage/redis.py:282). */
+int lshrs_query_collide_index_i64(const lshrs_bucket_segment* segments, int32_t nseg, int32_t num_bands,
+                                  const int64_t* slot_start, const int32_t* slot_len, const int32_t* slot_off,
+                                  const int64_t* pair_off, int32_t q, int32_t max_pairs, int64_t* cand_ids,
+                                  int32_t* cand_hits, int32_t* ucount, void* stream);
+int lshrs_query_collide_pairs_i64(const int64_t* members, const int32_t* bands, const int64_t* pair_off, int32_t q,
+                                  int32_t max_pairs, int32_t num_bands, int64_t* cand_ids, int32_t* cand_hits,
+                                  int32_t* ucount, void* stream);
+
+/* lshrs_cosine_batch_f32 over ragged candidate lists: query qi's candidates are corpus rows cand_rows[row_off[qi] .. +
+ * row_cnt[qi]), their scores land at the same flat positions.  total = entries the lists span (sizes the launch only).
+ * err int32[1] (optional, zeroed by the caller): OR of 1 = a candidate of zero norm, 2 = a row outside [0, m), 4 = a query of
+ * zero norm that has candidates (scores NaN there; the reference raises "Cannot normalize zero vector", norm.py:56-57). */
+int lshrs_cosine_ragged_f32(const float* corpus, int64_t m, int64_t ldc, int32_t dim, const float* queries, int32_t q,
+                            const int64_t* cand_rows, const int64_t* row_off, const int32_t* row_cnt, int64_t total,
+                            float* scores, int32_t* err, void* stream);
+
+/* Per query the first keep[qi] candidates in descending score (ties: ascending position in the list; NaN last - the order of
+ * lshrs_topk_desc_f32) into the compact arrays out_ids / out_scores at out_off[qi]; lists and scores at pair_off[qi], ucount[qi]
+ * long (<= max_candidates <= LSHRS_QUERY_MAX_PAIRS).  scores == NULL: the order the lists already have (out_scores unused). */
+int lshrs_query_rank_f32(const int64_t* cand_ids, const float* scores, const int64_t* pair_off, const int32_t* ucount,
+                         const int32_t* keep, const int64_t* out_off, int32_t q, int32_t max_candidates,
+                         int64_t* out_ids, float* out_scores, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,13 +17,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 # one translation unit per kernel family (what they share: csrc/lshrs_common.h); pipeline.hip: the native driver of the host-engine route
-UNITS = ("sig_setup", "sig_f32", "sig16", "sig16r", "sig_replay", "sig_small", "sig_split", "storage", "rerank", "pipeline")
+UNITS = ("sig_setup", "sig_f32", "sig16", "sig16r", "sig_replay", "sig_small", "sig_split", "storage", "rerank", "query", "pipeline")
 SOURCES = tuple(os.path.join(CSRC, u + ".hip") for u in UNITS)
 SOURCE = SOURCES[0]
 # (LSHRS_HIP_LIBRARY: load another build of the same ABI instead - A/B measurements of compiler flags, tools/ab_build.py)
 LIBRARY = os.environ.get("LSHRS_HIP_LIBRARY") or os.path.join(CSRC, "liblshrs_hip.so")
 INCLUDE = os.path.join(REPO_ROOT, "include")
-ABI_VERSION = 6
+ABI_VERSION = 7
+QUERY_MAX_PAIRS = 16384   # LSHRS_QUERY_MAX_PAIRS
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
 SIG_DEVICE_COUNTERS = SIG_COUNTERS + 6 * 4096      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
@@ -153,6 +154,25 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_topk_workspace_bytes.restype = i64
     lib.lshrs_topk_desc_f32.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     lib.lshrs_topk_desc_f32.restype = c.c_int
+    f64 = c.c_double
+    # (keys, q, bands, band_bytes, segments, nseg, slot_start, slot_len, slot_off, pair_count, stream)
+    lib.lshrs_query_lookup_u8.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]
+    lib.lshrs_query_lookup_u8.restype = c.c_int
+    # (counts, q, top_k, top_p, keep_out, offsets, totals, stream)
+    lib.lshrs_query_scan_i32.argtypes = [vp, i32, i32, f64, vp, vp, vp, vp]
+    lib.lshrs_query_scan_i32.restype = c.c_int
+    # (segments, nseg, bands, slot_start, slot_len, slot_off, pair_off, q, max_pairs, cand_ids, cand_hits, ucount, stream)
+    lib.lshrs_query_collide_index_i64.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.lshrs_query_collide_index_i64.restype = c.c_int
+    # (members, bands, pair_off, q, max_pairs, num_bands, cand_ids, cand_hits, ucount, stream)
+    lib.lshrs_query_collide_pairs_i64.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.lshrs_query_collide_pairs_i64.restype = c.c_int
+    # (corpus, m, ldc, dim, queries, q, cand_rows, row_off, row_cnt, total, scores, err, stream)
+    lib.lshrs_cosine_ragged_f32.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp]
+    lib.lshrs_cosine_ragged_f32.restype = c.c_int
+    # (cand_ids, scores, pair_off, ucount, keep, out_off, q, max_candidates, out_ids, out_scores, stream)
+    lib.lshrs_query_rank_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.lshrs_query_rank_f32.restype = c.c_int
     lib.lshrs_pipe_create.argtypes = [i32, i32, i32, i32, i32]
     lib.lshrs_pipe_create.restype = vp
     lib.lshrs_pipe_destroy.argtypes = [vp]
@@ -187,6 +207,12 @@ EXPORTS = (
     "lshrs_l2_normalize_f32",
     "lshrs_topk_workspace_bytes",
     "lshrs_topk_desc_f32",
+    "lshrs_query_lookup_u8",
+    "lshrs_query_scan_i32",
+    "lshrs_query_collide_index_i64",
+    "lshrs_query_collide_pairs_i64",
+    "lshrs_cosine_ragged_f32",
+    "lshrs_query_rank_f32",
     "lshrs_pipe_create",
     "lshrs_pipe_destroy",
     "lshrs_pipe_hash_f32",

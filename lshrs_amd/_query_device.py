@@ -1,0 +1,229 @@
+"""The candidate path of ``LSHRS.query_many`` on the device (round 6; SURVEY.md §8f row 2, the device variant).
+
+Per query the reference reads one bucket per band, counts in a dict how often every stored id turns up, sorts by
+``(-count, id)``, fetches the candidates' vectors, ranks them by cosine and cuts the list (lshrs/core/main.py:524-658,
+``_candidate_counts`` :1088-1111).  Here a whole batch of queries does that between ONE upload (the query vectors) and ONE
+download (ids, scores, bounds):
+
+  signature pass -> ``lshrs_query_lookup_u8`` (bisection in the device-resident bucket arrays) -> scan ->
+  ``lshrs_query_collide_*`` (sort / count / order inside a workgroup's LDS) -> [``lshrs_cosine_ragged_f32`` on the resident
+  corpus] -> ``lshrs_query_rank_f32`` (order by score, cut to top-p / top-k, compact)
+
+``DeviceBuckets`` mirrors the array segments of a store (``InMemoryStorage.array_segments``) in device memory: uploaded
+the first time a query meets them, kept until the store replaces them.  Stores that only answer ``get_bucket`` (the
+reference's ``RedisStorage``) hand their (query, member, band) pairs over flat (``collide_pairs``).  No CPU compute path:
+the host only moves arrays.
+"""
+
+from __future__ import annotations
+
+import threading
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+
+__all__ = ["DeviceBuckets", "TooLarge", "candidates_from_index", "candidates_from_pairs", "rank_and_cut"]
+
+
+class TooLarge(Exception):
+    """A query's lists do not fit the LDS-resident networks (``LSHRS_QUERY_MAX_PAIRS``) or an id does not fit the item
+    layout: the caller counts this batch on the host."""
+
+
+def upload(torch, a: np.ndarray, dev):
+    """Host array -> tensor on ``dev`` (the array is only read: a read-only view goes up without a defensive copy)."""
+    import warnings
+
+    a = np.ascontiguousarray(a)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return torch.from_numpy(a).to(dev)
+
+
+def _bbits(num_bands: int) -> int:
+    return max(0, int(num_bands - 1).bit_length())
+
+
+class DeviceBuckets:
+    """Device mirror of a store's array segments: per segment ``codes`` / ``offsets`` / ``members`` as int64 tensors and the
+    descriptor table ``lshrs_bucket_segment[nseg]`` the kernels read.  ``table(segments, dev)`` is cheap while the store's
+    segment list has not changed."""
+
+    def __init__(self) -> None:
+        self._lock = threading.Lock()
+        self._views: dict = {}           # id(segment) -> (segment, device index, codes, offsets, members)
+        self._table = None               # (key, descriptor tensor, views kept alive, largest id)
+        self.uploads = 0
+        self.upload_bytes = 0
+
+    def clear(self) -> None:
+        with self._lock:
+            self._views, self._table = {}, None
+
+    def table(self, segments: list, dev):
+        """(descriptor tensor or None for an empty index, nseg, largest member id) for this segment list on ``dev``."""
+        torch = _native.require_gpu()
+        segs = [s for s in segments if len(s)]
+        key = (dev.index, tuple(id(s) for s in segs))
+        with self._lock:
+            if self._table is not None and self._table[0] == key:
+                return self._table[1], len(segs), self._table[3]
+            views, max_id = {}, -1
+            rows = []
+            with torch.cuda.device(dev):
+                for s in segs:
+                    v = self._views.get(id(s))
+                    if v is None or v[0] is not s or v[1] != dev.index:
+                        codes = torch.from_numpy(np.ascontiguousarray(s.codes, dtype=np.int64)).to(dev)
+                        offsets = torch.from_numpy(np.ascontiguousarray(s.offsets, dtype=np.int64)).to(dev)
+                        members = torch.from_numpy(np.ascontiguousarray(s.members, dtype=np.int64)).to(dev)
+                        span = (int(s.members.min()), int(s.members.max())) if s.members.size else (0, -1)
+                        v = (s, dev.index, codes, offsets, members, span)
+                        self.uploads += 1
+                        self.upload_bytes += 8 * (codes.numel() + offsets.numel() + members.numel())
+                    views[id(s)] = v
+                    if v[5][0] < 0:
+                        raise TooLarge("negative member id")
+                    max_id = max(max_id, v[5][1])
+                    rows.append([v[2].data_ptr(), v[3].data_ptr(), v[4].data_ptr(), int(v[2].numel())])
+                desc = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
+            self._views = views          # (segments the store dropped go with their device copies)
+            self._table = (key, desc, views, max_id)
+            return desc, len(segs), max_id
+
+
+class _Lists:
+    """What the collide step leaves on the device: query i's candidates are ``cand_ids[pair_off[i] : pair_off[i] + ucount[i]]``,
+    ordered by (-collisions, id); ``hits`` their collision counts."""
+
+    __slots__ = ("nq", "total", "max_pairs", "pair_off", "cand_ids", "hits", "ucount", "dev", "segments")
+
+    def __init__(self, nq, total, max_pairs, pair_off, cand_ids, hits, ucount, dev, segments=0):
+        self.nq, self.total, self.max_pairs = nq, total, max_pairs
+        self.pair_off, self.cand_ids, self.hits, self.ucount, self.dev = pair_off, cand_ids, hits, ucount, dev
+        self.segments = segments
+
+
+def _scan(torch, lib, counts, nq, dev, stream, top_k=-1, top_p=-1.0, keep_out=None):
+    offsets = torch.empty(nq + 1, dtype=torch.int64, device=dev)
+    totals = torch.empty(2, dtype=torch.int64, device=dev)
+    _native.check(lib.lshrs_query_scan_i32(counts.data_ptr(), nq, int(top_k), float(top_p),
+                                           keep_out.data_ptr() if keep_out is not None else None, offsets.data_ptr(),
+                                           totals.data_ptr(), stream), "lshrs_query_scan_i32")
+    return offsets, totals
+
+
+def candidates_from_index(keys_dev, desc, nseg: int, max_id: int, *, want_hits: bool = False) -> _Lists:
+    """Lookup + collide for ``keys_dev`` (q, bands, B) uint8 on the device against the mirrored segments."""
+    torch = _native.require_gpu()
+    lib = _native.load()
+    dev = keys_dev.device
+    nq, nb, bb = (int(v) for v in keys_dev.shape)
+    if bb > 6:
+        raise TooLarge("band keys wider than 6 bytes have no codes")
+    if max_id >= (1 << (63 - _bbits(nb))):
+        raise TooLarge("member ids do not fit the item layout")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        nslots = nb * nseg
+        slot_start = torch.empty(max(1, nq * nslots), dtype=torch.int64, device=dev)
+        slot_len = torch.empty(max(1, nq * nslots), dtype=torch.int32, device=dev)
+        slot_off = torch.empty(max(1, nq * nslots), dtype=torch.int32, device=dev)
+        pair_count = torch.empty(nq, dtype=torch.int32, device=dev)
+        kd = keys_dev if keys_dev.is_contiguous() else keys_dev.contiguous()
+        _native.check(lib.lshrs_query_lookup_u8(kd.data_ptr(), nq, nb, bb, desc.data_ptr() if desc is not None else None,
+                                                nseg, slot_start.data_ptr(), slot_len.data_ptr(), slot_off.data_ptr(),
+                                                pair_count.data_ptr(), stream), "lshrs_query_lookup_u8")
+        pair_off, totals = _scan(torch, lib, pair_count, nq, dev, stream)
+        total, max_pairs = (int(v) for v in totals.cpu().tolist())         # (the one size the host must know: what to allocate)
+        if max_pairs > _native.QUERY_MAX_PAIRS:
+            raise TooLarge(f"a query's buckets hold {max_pairs} members")
+        cand_ids = torch.empty(max(1, total), dtype=torch.int64, device=dev)
+        hits = torch.empty(max(1, total), dtype=torch.int32, device=dev) if want_hits else None
+        ucount = torch.empty(nq, dtype=torch.int32, device=dev)
+        _native.check(lib.lshrs_query_collide_index_i64(desc.data_ptr() if desc is not None else None, nseg, nb,
+                                                        slot_start.data_ptr(), slot_len.data_ptr(), slot_off.data_ptr(),
+                                                        pair_off.data_ptr(), nq, max_pairs, cand_ids.data_ptr(),
+                                                        hits.data_ptr() if hits is not None else None, ucount.data_ptr(),
+                                                        stream), "lshrs_query_collide_index_i64")
+    return _Lists(nq, total, max_pairs, pair_off, cand_ids, hits, ucount, dev, nseg)
+
+
+def candidates_from_pairs(members: np.ndarray, bands: np.ndarray, pair_off: np.ndarray, num_bands: int, dev, *,
+                          want_hits: bool = False) -> _Lists:
+    """Collide for pairs gathered on the host (a store with ``get_bucket`` only): ``members`` / ``bands`` flat, query i's
+    at ``pair_off[i] : pair_off[i + 1]``."""
+    torch = _native.require_gpu()
+    lib = _native.load()
+    nq = int(pair_off.shape[0]) - 1
+    total = int(pair_off[-1])
+    lens = np.diff(pair_off)
+    max_pairs = int(lens.max()) if nq else 0
+    if max_pairs > _native.QUERY_MAX_PAIRS:
+        raise TooLarge(f"a query's buckets hold {max_pairs} members")
+    if total and (int(members.min()) < 0 or int(members.max()) >= (1 << (63 - _bbits(num_bands)))):
+        raise TooLarge("member ids do not fit the item layout")
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        m_d = torch.from_numpy(np.ascontiguousarray(members, dtype=np.int64)).to(dev)
+        b_d = torch.from_numpy(np.ascontiguousarray(bands, dtype=np.int32)).to(dev)
+        off_d = torch.from_numpy(np.ascontiguousarray(pair_off, dtype=np.int64)).to(dev)
+        cand_ids = torch.empty(max(1, total), dtype=torch.int64, device=dev)
+        hits = torch.empty(max(1, total), dtype=torch.int32, device=dev) if want_hits else None
+        ucount = torch.empty(nq, dtype=torch.int32, device=dev)
+        _native.check(lib.lshrs_query_collide_pairs_i64(m_d.data_ptr(), b_d.data_ptr(), off_d.data_ptr(), nq, max_pairs,
+                                                        int(num_bands), cand_ids.data_ptr(),
+                                                        hits.data_ptr() if hits is not None else None, ucount.data_ptr(),
+                                                        stream), "lshrs_query_collide_pairs_i64")
+        torch.cuda.current_stream(dev).synchronize()        # (the uploaded pairs die with this frame)
+    return _Lists(nq, total, max_pairs, off_d, cand_ids, hits, ucount, dev)
+
+
+def rank_and_cut(lists: _Lists, top_k: Optional[int], top_p: Optional[float], *, queries_dev=None, corpus=None,
+                 cand_rows=None) -> Tuple[np.ndarray, Optional[np.ndarray], np.ndarray]:
+    """The ranked, cut answer of every query as arrays ``(ids, scores or None, bounds)``: query i's ids are
+    ``ids[bounds[i]:bounds[i + 1]]``.  ``top_p`` None: the collision order, first ``top_k`` (lshrs/core/main.py:619-625).
+    Else the candidates scored against ``corpus`` (device (m, dim) float32; row = ``cand_rows`` entry, default the id
+    itself), ordered by score, cut to ``max(1, ceil(n * top_p))`` and ``top_k`` (:646-657)."""
+    torch = _native.require_gpu()
+    lib = _native.load()
+    dev, nq = lists.dev, lists.nq
+    k_arg = -1 if top_k is None else int(top_k)
+    with torch.cuda.device(dev):
+        cur = torch.cuda.current_stream(dev)
+        stream = cur.cuda_stream
+        keep = torch.empty(nq, dtype=torch.int32, device=dev)
+        out_off, _ = _scan(torch, lib, lists.ucount, nq, dev, stream, top_k=k_arg,
+                           top_p=-1.0 if top_p is None else float(top_p), keep_out=keep)
+        scores = err = None
+        if top_p is not None and lists.total:
+            rows = lists.cand_ids if cand_rows is None else cand_rows
+            scores = torch.empty(max(1, lists.total), dtype=torch.float32, device=dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            _native.check(lib.lshrs_cosine_ragged_f32(corpus.data_ptr(), int(corpus.shape[0]), int(corpus.stride(0)),
+                                                      int(corpus.shape[1]), queries_dev.data_ptr(), nq, rows.data_ptr(),
+                                                      lists.pair_off.data_ptr(), lists.ucount.data_ptr(), lists.total,
+                                                      scores.data_ptr(), err.data_ptr(), stream), "lshrs_cosine_ragged_f32")
+        bounds = out_off.cpu().numpy()                # (waits for the scan - and whatever is in front of it - only: the rerank runs on)
+        kept = int(bounds[-1])
+        # ids and scores side by side in ONE block: one copy back
+        packed = torch.empty(12 * max(1, kept), dtype=torch.uint8, device=dev)
+        out_ids = packed[:8 * kept].view(torch.int64)
+        out_scores = packed[8 * kept:12 * kept].view(torch.float32) if scores is not None else None
+        if kept:
+            _native.check(lib.lshrs_query_rank_f32(lists.cand_ids.data_ptr(), scores.data_ptr() if scores is not None else None,
+                                                   lists.pair_off.data_ptr(), lists.ucount.data_ptr(), keep.data_ptr(),
+                                                   out_off.data_ptr(), nq, lists.max_pairs, out_ids.data_ptr(),
+                                                   out_scores.data_ptr() if out_scores is not None else None, stream),
+                          "lshrs_query_rank_f32")
+        if scores is not None:
+            host = packed[:12 * kept].cpu().numpy()
+            code = int(err.item())
+            if code & 5:
+                raise ValueError("Cannot normalize zero vector")
+            if code & 2:
+                raise IndexError("candidate index out of range of the corpus")
+            return host[:8 * kept].view(np.int64), host[8 * kept:].view(np.float32), bounds
+        return out_ids.cpu().numpy(), None, bounds

@@ -206,6 +206,11 @@ class LSHRS:
             decode_responses=decode_responses, prefix=redis_prefix, max_connections=redis_max_connections)
         self._buffer: List[BucketOperation] = []
         self._buffer_lock = Lock()
+        self._corpus = None                  # device-resident vectors for the rerank (set_corpus)
+        self.last_query_stats: Dict[str, Any] = {}
+        from ._query_device import DeviceBuckets
+
+        self._dev_buckets = DeviceBuckets()  # device mirror of the store's bucket arrays (query_many)
         self._config: Dict[str, Any] = {
             "dim": dim, "num_perm": num_perm, "num_bands": num_bands, "rows_per_band": rows_per_band,
             "similarity_threshold": similarity_threshold, "buffer_size": buffer_size, "seed": seed,
@@ -401,16 +406,15 @@ class LSHRS:
 
         if not 0 < top_p <= 1:
             raise ValueError("top_p must be within the range (0, 1]")
-        fetched = self._require_vector_fetch_fn()(candidate_indices)
-        arr = np.asarray(fetched, dtype=np.float32)
-        if arr.ndim != 2 or arr.shape[1] != self._dim:
-            raise ValueError(f"Fetched vectors must have shape (n, {self._dim}); received {arr.shape}")
-        if arr.shape[0] != len(candidate_indices):
-            raise ValueError(
-                "vector_fetch_fn returned mismatched batch size "
-                f"(expected {len(candidate_indices)}, received {arr.shape[0]})")
+        if self._corpus is not None:
+            # the indexed vectors are resident on the device (set_corpus): gathered and scored there, nothing fetched
+            from .similarity import rerank_batch
 
-        ranked = top_k_cosine(query_vector, arr, k=len(candidate_indices))
+            ranked = rerank_batch(query_vector[None], self._corpus, np.asarray([candidate_indices], dtype=np.int64),
+                                  k=len(candidate_indices))[0]
+        else:
+            arr = self._fetch_checked(self._require_vector_fetch_fn(), candidate_indices)
+            ranked = top_k_cosine(query_vector, arr, k=len(candidate_indices))
         scored = [(candidate_indices[pos], score) for pos, score in ranked]
         limit = max(1, math.ceil(len(scored) * top_p))
         if top_k is not None:
@@ -425,15 +429,30 @@ class LSHRS:
     def get_above_p(self, vector, p: float = 0.95) -> List[Tuple[int, float]]:
         return list(self.query(vector, top_k=None, top_p=p))  # type: ignore[arg-type]
 
-    def query_many(self, vectors, *, top_k: Optional[int] = 10, top_p: Optional[float] = None, corpus=None
-                   ) -> List[Union[List[int], List[Tuple[int, float]]]]:
+    def set_corpus(self, corpus) -> None:
+        """Attach the indexed vectors as a device-resident ``(m, dim)`` float32 tensor whose row ``i`` is the vector of id
+        ``i``: ``query`` / ``get_above_p`` / ``query_many`` then gather their candidates from it on the device instead of
+        calling ``vector_fetch_fn`` (lshrs/core/main.py:629-646 fetches and stacks them on the host).  ``None`` detaches."""
+        if corpus is not None and (getattr(corpus, "ndim", 0) != 2 or int(corpus.shape[1]) != self._dim):
+            raise ValueError(f"corpus must have shape (m, {self._dim})")
+        self._corpus = corpus
+
+    def query_many(self, vectors, *, top_k: Optional[int] = 10, top_p: Optional[float] = None, corpus=None,
+                   return_arrays: bool = False, engine: str = "auto"):
         """Batched :meth:`query`: returns ``[query(v, top_k=top_k, top_p=top_p) for v in vectors]`` with ONE
-        signature launch for all queries and ONE rerank launch for all candidate lists (the step between the
-        two hot kernels; reference per query: main.py:524-658).
+        signature launch for all queries, the collision counting and candidate ordering of all of them on the device
+        (``lshrs_amd/_query_device.py``: bucket lookup in the device-resident bucket arrays, sort / count / order per query
+        inside a workgroup's LDS), ONE rerank over all candidate lists and ONE copy back (reference per
+        query: main.py:524-658, ``_candidate_counts`` :1088-1111).
 
         ``corpus``: optional device-resident ``(m, dim)`` float32 tensor whose row ``i`` is the vector of id
-        ``i``; with it the candidates are gathered on the device and ``vector_fetch_fn`` is not called.
-        """
+        ``i`` (default: what :meth:`set_corpus` attached); with it the candidates are gathered on the device and
+        ``vector_fetch_fn`` is not called.
+        ``return_arrays``: ``(ids, scores, bounds)`` instead of lists - query ``i``'s answer is ``ids[bounds[i]:bounds[i + 1]]``
+        (int64) with ``scores[...]`` (float32; ``None`` without ``top_p``): no Python object per result.
+        ``engine``: "auto" (the device path wherever the hasher is the HIP one; a batch with a candidate list beyond the
+        kernels' 16 384 entries is counted on the host), "device" (raise instead), "host" (NumPy counting between the two
+        launches: round 5's path)."""
         arr = np.asarray(vectors, dtype=np.float32)
         if arr.ndim != 2 or arr.shape[1] != self._dim:
             raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")
@@ -443,9 +462,127 @@ class LSHRS:
             raise ValueError("top_p must be within the range (0, 1]")
         if top_p is not None and top_k is not None and top_k <= 0:
             raise ValueError("top_k must be greater than zero when provided")
+        if engine not in ("auto", "device", "host"):
+            raise ValueError("engine must be 'auto', 'device' or 'host'")
+        if corpus is None:
+            corpus = self._corpus
         nq = arr.shape[0]
         if nq == 0:
-            return []
+            empty = (np.empty(0, np.int64), None if top_p is None else np.empty(0, np.float32), np.zeros(1, np.int64))
+            return empty if return_arrays else []
+        on_device = (engine != "host" and callable(getattr(self._hasher, "hash_device", None))
+                     and getattr(self._hasher, "tie_break", "host") == "host")
+        if engine == "device" and not on_device:
+            raise RuntimeError("engine='device' needs the HIP hasher")
+        got = None
+        if on_device:
+            from ._query_device import TooLarge
+
+            try:
+                got = self._query_many_device(arr, top_k, top_p, corpus)
+            except TooLarge:
+                if engine == "device":
+                    raise
+        if got is None:
+            got = self._query_many_host(arr, top_k, top_p, corpus)
+        ids, scores, bounds = got
+        if return_arrays:
+            return ids, scores, bounds
+        keep = np.diff(bounds)
+        with _gc_paused():
+            if scores is None:
+                return _split_rows(ids.tolist(), keep)
+            return _split_rows(list(zip(ids.tolist(), scores.astype(np.float64).tolist())), keep)
+
+    def _query_many_device(self, arr: np.ndarray, top_k, top_p, corpus):
+        """``query_many`` with everything between the upload of the queries and the download of the answers on the device."""
+        from . import _native
+        from . import _query_device as qd
+
+        torch = _native.require_gpu()
+        nq = arr.shape[0]
+        if corpus is not None and isinstance(corpus, torch.Tensor) and corpus.is_cuda:
+            dev = corpus.device
+        else:
+            dev = self._hasher._torch_device()
+        with torch.cuda.device(dev):
+            x = qd.upload(torch, arr, dev)
+            flags = torch.empty(nq, dtype=torch.uint8, device=dev)
+            keys_dev = self._hasher.hash_device(x, row_flags=flags)
+            if bool((flags & 1).any()):
+                raise ValueError(_ZERO_MSG)
+            lists = self._device_lists(qd, keys_dev, dev)
+            # (diagnostics of the last device-counted batch: bench.py's candidates/s; not part of the answer)
+            self.last_query_stats = {"queries": nq, "pairs": lists.total, "longest_list": lists.max_pairs, "engine": "device",
+                                     "segments": lists.segments}
+            if top_p is None:
+                return qd.rank_and_cut(lists, top_k, None)
+            if lists.total == 0:
+                return np.empty(0, np.int64), np.empty(0, np.float32), np.zeros(nq + 1, np.int64)
+            if corpus is not None:
+                table = corpus if isinstance(corpus, torch.Tensor) else qd.upload(torch, np.asarray(corpus, dtype=np.float32), dev)
+                if table.dtype != torch.float32 or table.dim() != 2 or int(table.shape[1]) != self._dim:
+                    raise ValueError(f"corpus must be a float32 tensor of shape (m, {self._dim})")
+                if not table.is_cuda:
+                    table = table.to(dev)
+                if table.stride(1) != 1:
+                    table = table.contiguous()
+                return qd.rank_and_cut(lists, top_k, top_p, queries_dev=x, corpus=table)
+            # no resident corpus: the candidates' vectors come from the caller's fetch function, list by list as the reference
+            # asks for them (main.py:629), and travel to the device as one table
+            fetch = self._require_vector_fetch_fn()
+            pair_off, ucount = lists.pair_off.cpu().numpy(), lists.ucount.cpu().numpy()
+            cand = lists.cand_ids.cpu().numpy()
+            rows_host = np.zeros(max(1, lists.total), dtype=np.int64)
+            blocks, pos = [], 0
+            for qi in np.flatnonzero(ucount):
+                lo, u = int(pair_off[qi]), int(ucount[qi])
+                blocks.append(self._fetch_checked(fetch, cand[lo:lo + u].tolist()))
+                rows_host[lo:lo + u] = np.arange(pos, pos + u, dtype=np.int64)
+                pos += u
+            table = qd.upload(torch, np.concatenate(blocks, axis=0), dev)
+            return qd.rank_and_cut(lists, top_k, top_p, queries_dev=x, corpus=table, cand_rows=qd.upload(torch, rows_host, dev))
+
+    def _device_lists(self, qd, keys_dev, dev):
+        """Every query's candidates, counted and ordered on the device: from the device mirror of the store's bucket arrays
+        where the store keeps arrays, else from one ``get_bucket`` per (query, band) (the reference's storage interface,
+        lshrs/storage/redis.py:282) with the pairs handed over flat."""
+        st = self._storage
+        if isinstance(st, _DeferredStorage):
+            st = st._resolve()
+        nq, nb, bb = (int(v) for v in keys_dev.shape)
+        segs = st.array_segments(bb) if callable(getattr(st, "array_segments", None)) else None
+        if segs is not None:
+            desc, nseg, max_id = self._dev_buckets.table(segs, dev)
+            return qd.candidates_from_index(keys_dev, desc, nseg, max_id)
+        keys = keys_dev.cpu().numpy()
+        ms, bs, off = [], [], np.zeros(nq + 1, dtype=np.int64)
+        for qi in range(nq):
+            n = 0
+            for b in range(nb):
+                mem = st.get_bucket(b, keys[qi, b].tobytes())
+                if mem:
+                    ms.append(np.fromiter((int(v) for v in mem), dtype=np.int64, count=len(mem)))
+                    bs.append(np.full(len(mem), b, dtype=np.int32))
+                    n += len(mem)
+            off[qi + 1] = off[qi] + n
+        members = np.concatenate(ms) if ms else np.empty(0, np.int64)
+        bands = np.concatenate(bs) if bs else np.empty(0, np.int32)
+        return qd.candidates_from_pairs(members, bands, off, nb, dev)
+
+    def _fetch_checked(self, fetch, ids: list) -> np.ndarray:
+        got = np.asarray(fetch(ids), dtype=np.float32)
+        if got.ndim != 2 or got.shape[1] != self._dim:
+            raise ValueError(f"Fetched vectors must have shape (n, {self._dim}); received {got.shape}")
+        if got.shape[0] != len(ids):
+            raise ValueError("vector_fetch_fn returned mismatched batch size "
+                             f"(expected {len(ids)}, received {got.shape[0]})")
+        return got
+
+    def _query_many_host(self, arr: np.ndarray, top_k, top_p, corpus):
+        """``query_many`` with the collision counting in NumPy between the signature launch and the rerank launch (round 5;
+        what hashers without ``hash_device`` and batches beyond the device path's limits take).  Same arrays out."""
+        nq = arr.shape[0]
         keys, flags = self._hasher.hash_batch_packed(arr, return_row_flags=True)
         if (flags & 1).any():
             raise ValueError(_ZERO_MSG)
@@ -453,30 +590,20 @@ class LSHRS:
         lens = np.diff(bounds)
         if top_p is None:
             keep = lens if top_k is None else np.minimum(lens, top_k)
-            with _gc_paused():
-                return _split_rows(um[_ragged_positions(bounds[:-1], keep)].tolist(), keep)
+            return um[_ragged_positions(bounds[:-1], keep)], None, np.r_[0, np.cumsum(keep)].astype(np.int64)
 
         # rerank every non-empty candidate list in one launch: a (q, c_max) index matrix padded with -1
         # (out-of-range entries score NaN, which the device sort places last)
         c_max = int(lens.max()) if nq else 0
         if c_max == 0:
-            return [[] for _ in range(nq)]
+            return np.empty(0, np.int64), np.empty(0, np.float32), np.zeros(nq + 1, np.int64)
         rows = np.repeat(np.arange(nq, dtype=np.int64), lens)
         cols = np.arange(um.shape[0], dtype=np.int64) - np.repeat(bounds[:-1], lens)
         cand_ids = np.full((nq, c_max), -1, dtype=np.int64)
         cand_ids[rows, cols] = um
         if corpus is None:
             fetch = self._require_vector_fetch_fn()
-            blocks = []
-            for qi in np.flatnonzero(lens):
-                ids = um[bounds[qi]:bounds[qi + 1]].tolist()
-                got = np.asarray(fetch(ids), dtype=np.float32)
-                if got.ndim != 2 or got.shape[1] != self._dim:
-                    raise ValueError(f"Fetched vectors must have shape (n, {self._dim}); received {got.shape}")
-                if got.shape[0] != len(ids):
-                    raise ValueError("vector_fetch_fn returned mismatched batch size "
-                                     f"(expected {len(ids)}, received {got.shape[0]})")
-                blocks.append(got)
+            blocks = [self._fetch_checked(fetch, um[bounds[qi]:bounds[qi + 1]].tolist()) for qi in np.flatnonzero(lens)]
             table = np.concatenate(blocks, axis=0)
             cand = np.full((nq, c_max), -1, dtype=np.int64)
             cand[rows, cols] = np.arange(um.shape[0], dtype=np.int64)     # row of `table` = position in the flat list
@@ -489,10 +616,8 @@ class LSHRS:
             keep = np.minimum(keep, top_k)
         krows = np.repeat(np.arange(nq, dtype=np.int64), keep)
         kcols = np.arange(int(keep.sum()), dtype=np.int64) - np.repeat(np.cumsum(keep) - keep, keep)
-        ids = cand_ids[krows, order[krows, kcols]]
-        with _gc_paused():
-            pairs = list(zip(ids.tolist(), scores[krows, kcols].astype(np.float64).tolist()))
-            return _split_rows(pairs, keep)
+        return (cand_ids[krows, order[krows, kcols]], np.ascontiguousarray(scores[krows, kcols], dtype=np.float32),
+                np.r_[0, np.cumsum(keep)].astype(np.int64))
 
     # ------------------------------------------------------------------ storage pass-throughs
     def delete(self, indices: Union[int, Sequence[int]]) -> None:

@@ -1,0 +1,413 @@
+// query.hip - part of liblshrs_hip.so, the gfx950 (MI355X / CDNA4) implementation of the lshrs hot path.
+// The candidate path of a batch of queries, between the signature pass and the cosine rerank: what the
+// reference does one dict entry at a time in LSHRS._candidate_counts (lshrs/core/main.py:1088-1111) and the sort of
+// LSHRS.query (:614), and its top-p / top-k cut (:650-657) - bucket lookup by bisection in the device-resident bucket
+// arrays, the members of a query's buckets sorted, counted and ordered inside ONE workgroup's LDS (a bitonic network over
+// 64-bit items; the lists are a few hundred to a few thousand entries: they never go through global memory), the
+// per-query order by score, and the compaction of what the caller asked for.  Integer / index work: bit-exact by
+// construction; HBM traffic is the bucket members once and the candidates once.
+// ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md §10.
+#include "lshrs_common.h"
+
+using namespace lshrs;
+
+namespace {
+constexpr int kQThreads = 256;
+constexpr int kQWaves = kQThreads / 64;
+constexpr uint64_t kTopBit = 1ull << 63;
+
+struct Segment {   // == lshrs_bucket_segment
+  const int64_t* codes;
+  const int64_t* offsets;
+  const int64_t* members;
+  int64_t n_codes;
+};
+static_assert(sizeof(Segment) == sizeof(lshrs_bucket_segment), "segment descriptor layout");
+
+__device__ __forceinline__ int pow2_ceil(int v) {
+  return v <= 2 ? 2 : 1 << (32 - __builtin_clz((unsigned)(v - 1)));
+}
+
+// Ascending bitonic network over P (a power of two) 64-bit items in LDS, all kQThreads threads of the workgroup; the items
+// are final - and visible to every thread - when it returns.
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* items, int P) {
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (P >> 1); t += kQThreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const uint64_t a = items[lo], b = items[hi];
+        if ((a > b) == up) {
+          items[lo] = b;
+          items[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Bucket lookup: one workgroup per query, one thread per (band, segment) slot.  code = band << 8 B | little-endian key
+// (what BucketCSR.codes holds, lshrs_amd/packed_ops.py); the bucket's members are segment.members[start .. start + len).
+// Also the running offset of every slot inside the query's pair list and the list's length.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kQThreads) void query_lookup_kernel(const uint8_t* __restrict__ keys, int nb, int bb,
+                                                                 const Segment* __restrict__ segs, int nseg,
+                                                                 int64_t* __restrict__ slot_start,
+                                                                 int32_t* __restrict__ slot_len,
+                                                                 int32_t* __restrict__ slot_off,
+                                                                 int32_t* __restrict__ pair_count) {
+  __shared__ long long scan[kQThreads];
+  const int tid = threadIdx.x;
+  const int qi = blockIdx.x;
+  const int nslots = nb * nseg;
+  const uint8_t* __restrict__ k = keys + (int64_t)qi * nb * bb;
+  long long carry = 0;
+  for (int tile = 0; tile < nslots; tile += kQThreads) {
+    const int s = tile + tid;
+    long long len = 0;
+    int64_t start = 0;
+    if (s < nslots) {
+      const int b = s / nseg, g = s - b * nseg;
+      int64_t code = (int64_t)b << (8 * bb);
+      for (int j = 0; j < bb; ++j) code |= (int64_t)k[b * bb + j] << (8 * j);
+      const Segment sg = segs[g];
+      int64_t lo = 0, hi = sg.n_codes;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sg.codes[mid] < code) lo = mid + 1; else hi = mid;
+      }
+      if (lo < sg.n_codes && sg.codes[lo] == code) {
+        start = sg.offsets[lo];
+        len = sg.offsets[lo + 1] - start;
+      }
+      const int64_t o = (int64_t)qi * nslots + s;
+      slot_start[o] = start;
+      slot_len[o] = (int32_t)(len > 0x7fffffffLL ? 0x7fffffffLL : len);
+    }
+    // inclusive scan of the tile's lengths, then exclusive + carry
+    scan[tid] = len;
+    __syncthreads();
+    for (int off = 1; off < kQThreads; off <<= 1) {
+      const long long v = tid >= off ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    if (s < nslots) {
+      const long long ex = carry + scan[tid] - len;
+      slot_off[(int64_t)qi * nslots + s] = (int32_t)(ex > 0x7fffffffLL ? 0x7fffffffLL : ex);
+    }
+    carry += scan[kQThreads - 1];
+    __syncthreads();
+  }
+  if (tid == 0) pair_count[qi] = (int32_t)(carry > 0x7fffffffLL ? 0x7fffffffLL : carry);
+}
+
+// ------------------------------------------------------------------------------------------
+// Exclusive scan of q small counts by ONE workgroup (q is a batch of queries: thousands, not billions), the sum and the
+// maximum beside it.  With `keep_out` the counts are first cut to what the caller asked for - the top-p / top-k limit of
+// LSHRS.query (lshrs/core/main.py:650-657): max(1, ceil(n * top_p)) in the double arithmetic `math.ceil(len(scored) * top_p)`
+// runs in, then min(., top_k).
+// ------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+
+__device__ __forceinline__ int keep_of(int u, int top_k, double top_p) {
+  if (u <= 0) return 0;
+  long long k = u;
+  if (top_p >= 0.0) {
+    const double lim = ceil((double)u * top_p);
+    k = lim < 1.0 ? 1 : (lim > (double)u ? u : (long long)lim);
+  }
+  if (top_k >= 0 && k > top_k) k = top_k;
+  return (int)k;
+}
+
+__global__ __launch_bounds__(kScanThreads) void query_scan_kernel(const int32_t* __restrict__ counts, int q, int top_k,
+                                                                  double top_p, int32_t* __restrict__ keep_out,
+                                                                  int64_t* __restrict__ offsets,
+                                                                  int64_t* __restrict__ totals) {
+  __shared__ long long part[kScanThreads];
+  __shared__ int pmax[kScanThreads];
+  const int tid = threadIdx.x;
+  const int per = (q + kScanThreads - 1) / kScanThreads;
+  const int lo = tid * per, hi = min(q, lo + per);
+  long long sum = 0;
+  int mx = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int v = keep_out != nullptr ? keep_of(counts[i], top_k, top_p) : counts[i];
+    sum += v;
+    mx = max(mx, v);
+  }
+  part[tid] = sum;
+  pmax[tid] = mx;
+  __syncthreads();
+  for (int off = 1; off < kScanThreads; off <<= 1) {
+    const long long v = tid >= off ? part[tid - off] : 0;
+    const int m = tid >= off ? pmax[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    pmax[tid] = max(pmax[tid], m);
+    __syncthreads();
+  }
+  long long run = part[tid] - sum;
+  for (int i = lo; i < hi; ++i) {
+    const int v = keep_out != nullptr ? keep_of(counts[i], top_k, top_p) : counts[i];
+    if (keep_out != nullptr) keep_out[i] = v;
+    offsets[i] = run;
+    run += v;
+  }
+  if (tid == kScanThreads - 1) {
+    offsets[q] = part[tid];
+    if (totals != nullptr) {
+      totals[0] = part[tid];
+      totals[1] = pmax[tid];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Collision counting + candidate order of one query inside one workgroup's LDS.
+//   items   (member << bbits) | band for every member of every bucket the query's keys select (bit 63 free: the caller
+//           has checked member < 2^(63 - bbits))
+//   sort    equal (member, band) pairs become neighbours - an id that reached one bucket through two sources (indexed by
+//           two calls: two array segments) counts ONCE per band, buckets are sets (lshrs/storage/redis.py:408-416 SADD) -
+//           and are struck out; the members' runs are then exactly their collision counts (lshrs/core/main.py:1101-1109)
+//   order   key = (bands - count) << (63 - bbits) | member, sorted ascending == sorted by (-count, id)  (main.py:614)
+// SRC 0: members fetched from the bucket segments through the lookup's slots; SRC 1: pairs handed in by the host (a storage
+// that only has get_bucket - Redis: main.py:1103).
+// ------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(kQThreads) void query_collide_kernel(const Segment* __restrict__ segs, int nseg, int nb,
+                                                                  int bbits, const int64_t* __restrict__ slot_start,
+                                                                  const int32_t* __restrict__ slot_len,
+                                                                  const int32_t* __restrict__ slot_off,
+                                                                  const int64_t* __restrict__ pair_members,
+                                                                  const int32_t* __restrict__ pair_bands,
+                                                                  const int64_t* __restrict__ pair_off,
+                                                                  int64_t* __restrict__ cand_ids,
+                                                                  int32_t* __restrict__ cand_hits,
+                                                                  int32_t* __restrict__ ucount) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t items[];
+  __shared__ int n_dup, n_head;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int qi = blockIdx.x;
+  const int64_t base = pair_off[qi];
+  int L = (int)(pair_off[qi + 1] - base);
+  if (L == 0) {
+    if (tid == 0) ucount[qi] = 0;
+    return;
+  }
+  const int P = pow2_ceil(L);
+  if (tid == 0) { n_dup = 0; n_head = 0; }
+  if (SRC == 0) {
+    const int nslots = nb * nseg;
+    const int64_t so = (int64_t)qi * nslots;
+    for (int s = wave; s < nslots; s += kQWaves) {       // one wave per bucket: its members are one contiguous read
+      const int len = slot_len[so + s];
+      if (len == 0) continue;
+      const int b = s / nseg, g = s - b * nseg;
+      const int64_t* __restrict__ src = segs[g].members + slot_start[so + s];
+      uint64_t* dst = items + slot_off[so + s];
+      for (int e = lane; e < len; e += 64) dst[e] = ((uint64_t)src[e] << bbits) | (uint64_t)b;
+    }
+  } else {
+    for (int t = tid; t < L; t += kQThreads)
+      items[t] = ((uint64_t)pair_members[base + t] << bbits) | (uint64_t)pair_bands[base + t];
+  }
+  for (int t = L + tid; t < P; t += kQThreads) items[t] = ~0ull;
+  bitonic_sort_lds(items, P);
+
+  // an id twice in one bucket (two sources): strike the repeats, close the gaps with one more sort (rare: skipped when none)
+  uint64_t dupmask = 0;        // (P / 256 <= 64 items per thread: one bit each)
+  for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
+    if (t > 0 && items[t] == items[t - 1]) dupmask |= 1ull << j;
+  if (dupmask) atomicAdd(&n_dup, __builtin_popcountll(dupmask));
+  __syncthreads();
+  const int dups = n_dup;
+  if (dups) {
+    for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
+      if ((dupmask >> j) & 1) items[t] = ~0ull;
+    bitonic_sort_lds(items, P);
+    L -= dups;
+  }
+  // heads of the members' runs: marked in bit 63, then each head walks to the next one (a run is at most `bands` long)
+  const uint64_t low = ((uint64_t)1 << bbits) - 1;
+  uint64_t headmask = 0;
+  for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
+    if (t == 0 || (items[t] >> bbits) != (items[t - 1] >> bbits)) headmask |= 1ull << j;
+  __syncthreads();
+  for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
+    if ((headmask >> j) & 1) items[t] |= kTopBit;
+  if (headmask) atomicAdd(&n_head, __builtin_popcountll(headmask));
+  __syncthreads();
+  // (the band field has done its work: a head keeps its run length - 1 there, read back below by the same thread)
+  for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
+    if ((headmask >> j) & 1) {
+      int e = t + 1;
+      while (e < L && !(items[e] & kTopBit)) ++e;
+      items[t] = (items[t] & ~low) | (uint64_t)(e - t - 1);
+    }
+  __syncthreads();
+  const int mshift = 63 - bbits;
+  for (int t = tid, j = 0; t < L; t += kQThreads, ++j) {
+    const uint64_t it = items[t];
+    uint64_t key = ~0ull;
+    if ((headmask >> j) & 1) {
+      const uint64_t cnt = (it & low) + 1;
+      key = ((uint64_t)(nb - cnt) << mshift) | ((it & ~kTopBit) >> bbits);
+    }
+    items[t] = key;
+  }
+  bitonic_sort_lds(items, P);
+  const int U = n_head;
+  const uint64_t mmask = ((uint64_t)1 << mshift) - 1;
+  for (int t = tid; t < U; t += kQThreads) {
+    const uint64_t key = items[t];
+    cand_ids[base + t] = (int64_t)(key & mmask);
+    if (cand_hits != nullptr) cand_hits[base + t] = nb - (int)(key >> mshift);
+  }
+  if (tid == 0) ucount[qi] = U;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per query: the candidates in descending score (ties by ascending candidate position, NaN last - as lshrs_topk_desc_f32),
+// the first keep[q] of them written to the caller's compact result arrays.  scores == NULL: the order the candidates
+// already have (collision order: the top_k-by-collisions answer of LSHRS.query, main.py:619-625).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t desc_key(float f) {
+  if (f != f) return 0xFFFFFFFFu;
+  uint32_t u = __float_as_uint(f);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ~u;
+}
+
+__global__ __launch_bounds__(kQThreads) void query_rank_kernel(const int64_t* __restrict__ cand_ids,
+                                                               const float* __restrict__ scores,
+                                                               const int64_t* __restrict__ pair_off,
+                                                               const int32_t* __restrict__ ucount,
+                                                               const int32_t* __restrict__ keep,
+                                                               const int64_t* __restrict__ out_off,
+                                                               int64_t* __restrict__ out_ids,
+                                                               float* __restrict__ out_scores) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t items[];
+  const int tid = threadIdx.x;
+  const int qi = blockIdx.x;
+  const int K = keep[qi];
+  if (K == 0) return;
+  const int64_t base = pair_off[qi], ob = out_off[qi];
+  if (scores == nullptr) {
+    for (int t = tid; t < K; t += kQThreads) out_ids[ob + t] = cand_ids[base + t];
+    return;
+  }
+  const int U = ucount[qi];
+  const int P = pow2_ceil(U);
+  for (int t = tid; t < P; t += kQThreads)
+    items[t] = t < U ? (((uint64_t)desc_key(scores[base + t]) << 32) | (uint32_t)t) : ~0ull;
+  bitonic_sort_lds(items, P);
+  for (int t = tid; t < K; t += kQThreads) {
+    const uint32_t pos = (uint32_t)items[t];
+    out_ids[ob + t] = cand_ids[base + pos];
+    out_scores[ob + t] = scores[base + pos];
+  }
+}
+
+int set_lds(const void* fn, size_t bytes) {
+  if (bytes <= 48 * 1024) return 0;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return e == hipSuccess ? 0 : -(int)e;
+}
+inline size_t items_bytes(int max_items) {
+  size_t p = 2;
+  while (p < (size_t)max_items) p <<= 1;
+  return p * sizeof(uint64_t);
+}
+}  // namespace
+
+extern "C" {
+
+int lshrs_query_lookup_u8(const uint8_t* keys, int32_t q, int32_t num_bands, int32_t band_bytes,
+                          const lshrs_bucket_segment* segments, int32_t nseg, int64_t* slot_start, int32_t* slot_len,
+                          int32_t* slot_off, int32_t* pair_count, void* stream) {
+  if (q == 0) return 0;
+  if (keys == nullptr || pair_count == nullptr || q < 0 || num_bands <= 0 || band_bytes <= 0 || nseg < 0) return LSHRS_E_BADARG;
+  if (nseg > 0 && (segments == nullptr || slot_start == nullptr || slot_len == nullptr || slot_off == nullptr))
+    return LSHRS_E_BADARG;
+  if (band_bytes > 6 || num_bands > 32768 || (int64_t)num_bands * nseg > (1 << 24)) return LSHRS_E_TOOLARGE;
+  hipLaunchKernelGGL(query_lookup_kernel, dim3((unsigned)q), dim3(kQThreads), 0, static_cast<hipStream_t>(stream), keys,
+                     num_bands, band_bytes, reinterpret_cast<const Segment*>(segments), nseg, slot_start, slot_len,
+                     slot_off, pair_count);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_query_scan_i32(const int32_t* counts, int32_t q, int32_t top_k, double top_p, int32_t* keep_out,
+                         int64_t* offsets, int64_t* totals, void* stream) {
+  if (counts == nullptr || offsets == nullptr || q < 0) return LSHRS_E_BADARG;
+  if (top_p > 1.0) return LSHRS_E_BADARG;
+  hipLaunchKernelGGL(query_scan_kernel, dim3(1), dim3(kScanThreads), 0, static_cast<hipStream_t>(stream), counts, q,
+                     top_k, top_p, keep_out, offsets, totals);
+  return -(int)hipGetLastError();
+}
+
+static int collide_bits(int32_t num_bands) {
+  int bbits = 0;
+  while ((1 << bbits) < num_bands) ++bbits;
+  return bbits;
+}
+
+int lshrs_query_collide_index_i64(const lshrs_bucket_segment* segments, int32_t nseg, int32_t num_bands,
+                                  const int64_t* slot_start, const int32_t* slot_len, const int32_t* slot_off,
+                                  const int64_t* pair_off, int32_t q, int32_t max_pairs, int64_t* cand_ids,
+                                  int32_t* cand_hits, int32_t* ucount, void* stream) {
+  if (q == 0) return 0;
+  if (pair_off == nullptr || ucount == nullptr || q < 0 || num_bands <= 0 || nseg < 0 || max_pairs < 0) return LSHRS_E_BADARG;
+  if (max_pairs > 0 && (segments == nullptr || slot_start == nullptr || slot_len == nullptr || slot_off == nullptr ||
+                        cand_ids == nullptr))
+    return LSHRS_E_BADARG;
+  if (max_pairs > LSHRS_QUERY_MAX_PAIRS || num_bands > 32768) return LSHRS_E_TOOLARGE;
+  const size_t shmem = items_bytes(max_pairs);
+  const int rc = set_lds(reinterpret_cast<const void*>(query_collide_kernel<0>), shmem);
+  if (rc) return rc;
+  hipLaunchKernelGGL(query_collide_kernel<0>, dim3((unsigned)q), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const Segment*>(segments), nseg, num_bands, collide_bits(num_bands), slot_start,
+                     slot_len, slot_off, nullptr, nullptr, pair_off, cand_ids, cand_hits, ucount);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_query_collide_pairs_i64(const int64_t* members, const int32_t* bands, const int64_t* pair_off, int32_t q,
+                                  int32_t max_pairs, int32_t num_bands, int64_t* cand_ids, int32_t* cand_hits,
+                                  int32_t* ucount, void* stream) {
+  if (q == 0) return 0;
+  if (pair_off == nullptr || ucount == nullptr || q < 0 || num_bands <= 0 || max_pairs < 0) return LSHRS_E_BADARG;
+  if (max_pairs > 0 && (members == nullptr || bands == nullptr || cand_ids == nullptr)) return LSHRS_E_BADARG;
+  if (max_pairs > LSHRS_QUERY_MAX_PAIRS || num_bands > 32768) return LSHRS_E_TOOLARGE;
+  const size_t shmem = items_bytes(max_pairs);
+  const int rc = set_lds(reinterpret_cast<const void*>(query_collide_kernel<1>), shmem);
+  if (rc) return rc;
+  hipLaunchKernelGGL(query_collide_kernel<1>, dim3((unsigned)q), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream),
+                     nullptr, 0, num_bands, collide_bits(num_bands), nullptr, nullptr, nullptr, members, bands, pair_off,
+                     cand_ids, cand_hits, ucount);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_query_rank_f32(const int64_t* cand_ids, const float* scores, const int64_t* pair_off, const int32_t* ucount,
+                         const int32_t* keep, const int64_t* out_off, int32_t q, int32_t max_candidates,
+                         int64_t* out_ids, float* out_scores, void* stream) {
+  if (q == 0) return 0;
+  if (cand_ids == nullptr || pair_off == nullptr || ucount == nullptr || keep == nullptr || out_off == nullptr ||
+      out_ids == nullptr || q < 0 || max_candidates < 0 || (scores != nullptr && out_scores == nullptr))
+    return LSHRS_E_BADARG;
+  if (max_candidates > LSHRS_QUERY_MAX_PAIRS) return LSHRS_E_TOOLARGE;
+  const size_t shmem = scores != nullptr ? items_bytes(max_candidates) : 0;
+  const int rc = set_lds(reinterpret_cast<const void*>(query_rank_kernel), shmem);
+  if (rc) return rc;
+  hipLaunchKernelGGL(query_rank_kernel, dim3((unsigned)q), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream),
+                     cand_ids, scores, pair_off, ucount, keep, out_off, out_ids, out_scores);
+  return -(int)hipGetLastError();
+}
+
+}  // extern "C"

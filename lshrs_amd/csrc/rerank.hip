@@ -25,18 +25,29 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <bool ALIGNED>
+// RAGGED (ABI 7, lshrs_cosine_ragged_f32): query qi has row_cnt[qi] candidates, listed - and scored - at row_off[qi] of the
+// flat cand_idx / scores arrays (the candidate lists of a batch of LSH queries, lshrs/core/main.py:629-646); what is wrong with
+// a candidate is OR-ed into err[0] (1 zero norm, 2 index outside the corpus) instead of a status byte per candidate.
+template <bool ALIGNED, bool RAGGED>
 __global__ __launch_bounds__(kCosThreads) void cosine_kernel(const float* __restrict__ corpus, int64_t m, int64_t ldc,
                                                              int dim, const float* __restrict__ queries,
                                                              const int64_t* __restrict__ cand_idx, int c, int slices,
                                                              float* __restrict__ scores, uint8_t* __restrict__ status,
-                                                             uint8_t* __restrict__ qstatus) {
+                                                             uint8_t* __restrict__ qstatus,
+                                                             const int64_t* __restrict__ row_off,
+                                                             const int32_t* __restrict__ row_cnt, int32_t* __restrict__ err) {
   extern __shared__ __attribute__((aligned(16))) float qlds[];  // dim floats (+ pad to 4) + kCosWaves partials
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int qi = blockIdx.x / slices;
   const int slice = blockIdx.x % slices;
+  int64_t obase = (int64_t)qi * c;
+  if (RAGGED) {
+    c = row_cnt[qi];
+    obase = row_off[qi];
+    if (slice * ((c + slices - 1) / slices) >= c) return;     // (nothing in this slice: the whole workgroup leaves together)
+  }
   const int dim4 = (dim + 3) & ~3;
   const float* __restrict__ qv = queries + (int64_t)qi * dim;
 
@@ -55,6 +66,7 @@ __global__ __launch_bounds__(kCosThreads) void cosine_kernel(const float* __rest
   for (int w = 0; w < kCosWaves; ++w) qnorm2 += part[w];
   const float qnorm = sqrtf(qnorm2);
   if (slice == 0 && tid == 0 && qstatus != nullptr) qstatus[qi] = (qnorm == 0.f) ? 1 : 0;
+  if (RAGGED && slice == 0 && tid == 0 && err != nullptr && qnorm == 0.f) atomicOr(err, 4);
 
   // candidates of this slice, dealt to waves in groups of kCosInflight
   const int per_slice = (c + slices - 1) / slices;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(kCosThreads) void cosine_kernel(const float* __rest
       int64_t idx = 0;
       st[u] = 3;  // 3 = not a candidate (past the end)
       if (ci < c_end) {
-        idx = cand_idx != nullptr ? cand_idx[(int64_t)qi * c + ci] : (int64_t)qi * c + ci;
+        idx = cand_idx != nullptr ? cand_idx[obase + ci] : obase + ci;
         st[u] = (idx < 0 || idx >= m) ? 2 : 0;
       }
       rowp[u] = corpus + (st[u] == 0 ? idx : 0) * ldc;
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(kCosThreads) void cosine_kernel(const float* __rest
       const float d = wave_sum(dot[u]);
       const float s2 = wave_sum(nn[u]);
       if (lane == 0 && st[u] != 3) {
-        const int64_t o = (int64_t)qi * c + base + u;
+        const int64_t o = obase + base + u;
         int code = st[u];
         float sc;
         if (code == 0) {
@@ -120,6 +132,7 @@ __global__ __launch_bounds__(kCosThreads) void cosine_kernel(const float* __rest
         if (code != 0) sc = __builtin_nanf("");
         scores[o] = sc;
         if (status != nullptr) status[o] = (uint8_t)code;
+        if (RAGGED && code != 0 && err != nullptr) atomicOr(err, code);
       }
     }
   }
@@ -284,11 +297,39 @@ int lshrs_cosine_batch_f32(const float* corpus, int64_t m, int64_t ldc, int32_t 
   const dim3 grid((unsigned)((int64_t)q * slices)), block(kCosThreads);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (aligned)
-    hipLaunchKernelGGL(cosine_kernel<true>, grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_idx, c, slices,
-                       scores, status, qstatus);
+    hipLaunchKernelGGL((cosine_kernel<true, false>), grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_idx, c, slices,
+                       scores, status, qstatus, nullptr, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(cosine_kernel<false>, grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_idx, c, slices,
-                       scores, status, qstatus);
+    hipLaunchKernelGGL((cosine_kernel<false, false>), grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_idx, c, slices,
+                       scores, status, qstatus, nullptr, nullptr, nullptr);
+  return -(int)hipGetLastError();
+}
+
+int lshrs_cosine_ragged_f32(const float* corpus, int64_t m, int64_t ldc, int32_t dim, const float* queries, int32_t q,
+                            const int64_t* cand_rows, const int64_t* row_off, const int32_t* row_cnt, int64_t total,
+                            float* scores, int32_t* err, void* stream) {
+  if (q == 0 || total == 0) return 0;
+  if (corpus == nullptr || queries == nullptr || cand_rows == nullptr || row_off == nullptr || row_cnt == nullptr ||
+      scores == nullptr || m <= 0 || dim <= 0 || q < 0 || total < 0 || ldc < dim)
+    return LSHRS_E_BADARG;
+  if (dim > 16384) return LSHRS_E_TOOLARGE;
+  // slices per query from the AVERAGE list (the lists of one batch are alike: a bucket per band each): enough workgroups to
+  // fill 256 CUs several times over even for a handful of queries
+  int slices = 1;
+  const int per_block = kCosWaves * kCosInflight;
+  const int64_t avg = (total + q - 1) / q;
+  while ((int64_t)q * slices < 4096 && (avg + slices - 1) / slices > 2 * per_block && slices < 1024) slices *= 2;
+  if ((int64_t)q * slices > 0x7fffffffLL) return LSHRS_E_TOOLARGE;
+  const bool aligned = (dim % 4 == 0) && (ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(corpus) & 15) == 0);
+  const size_t shmem = (size_t)(((dim + 3) & ~3) + kCosWaves) * sizeof(float);
+  const dim3 grid((unsigned)((int64_t)q * slices)), block(kCosThreads);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (aligned)
+    hipLaunchKernelGGL((cosine_kernel<true, true>), grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_rows, 0, slices,
+                       scores, nullptr, nullptr, row_off, row_cnt, err);
+  else
+    hipLaunchKernelGGL((cosine_kernel<false, true>), grid, block, shmem, s, corpus, m, ldc, dim, queries, cand_rows, 0, slices,
+                       scores, nullptr, nullptr, row_off, row_cnt, err);
   return -(int)hipGetLastError();
 }
 

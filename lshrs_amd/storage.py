@@ -84,6 +84,21 @@ class InMemoryStorage:
         through :meth:`get_buckets_many` rather than one :meth:`get_bucket` per band."""
         return bool(self._segments)
 
+    def array_segments(self, band_bytes: int):
+        """For a device mirror of the index (``lshrs_amd/_query_device.py``): the array segments holding keys of this width -
+        a snapshot of the list; the segments themselves are never modified in place, only replaced - provided EVERY bucket of
+        the store lives in such segments (no op-tuple buckets, no keys wider than 6 bytes); else None: the caller reads
+        buckets through :meth:`get_bucket`.  An empty store gives ``[]``."""
+        with self._lock:
+            if len(self._segments) > self.compact_above:
+                self._compact_locked()
+            if any(self._buckets.values()) or band_bytes > 6:
+                return None
+            segs = [s for s in self._segments if len(s)]
+            if any(s.codes is None for s in segs):
+                return None
+            return [s for s in segs if s.band_bytes == band_bytes]
+
     def get_buckets_many(self, keys) -> Tuple[np.ndarray, np.ndarray]:
         """Every member of every bucket a batch of queries touches, as two flat arrays ``(query index, member id)`` - one
         pair per (query, band, member), a member counted ONCE per band however many times and through whichever calls it

@@ -38,7 +38,7 @@ def test_header_and_library_agree(lib):
     assert sorted(_native.EXPORTS) == names, "python binding list and header drifted apart"
     for name in names:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
-    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 6
+    assert lib.lshrs_abi_version() == _native.ABI_VERSION == 7
     m = re.search(r"#define\s+LSHRS_ABI_VERSION\s+(\d+)", open(HEADER).read())
     assert int(m.group(1)) == lib.lshrs_abi_version()
 

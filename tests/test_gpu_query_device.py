@@ -1,0 +1,368 @@
+"""The candidate path of ``query_many`` on the device (round 6): bucket lookup, collision
+counting, candidate order, rerank, top-p / top-k cut - kernels of csrc/query.hip through the C ABI - against the
+reference's flow restated literally (oracle.query_literal: lshrs/core/main.py:524-658, :1088-1111) and against plain
+Python dict counting."""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _literal_lists(segments, keys, nb, bb):
+    """Per query: [(id, collisions)] ordered by (-collisions, id) - dict counting over the buckets the keys select, an id
+    once per band however many segments list it there."""
+    out = []
+    for qi in range(keys.shape[0]):
+        counts = {}
+        for b in range(nb):
+            code = (b << (8 * bb)) | int.from_bytes(keys[qi, b].tobytes(), "little")
+            members = set()
+            for seg in segments:
+                g = int(np.searchsorted(seg.codes, code))
+                if g < len(seg) and int(seg.codes[g]) == code:
+                    members.update(seg.members[seg.offsets[g]:seg.offsets[g + 1]].tolist())
+            for m in members:
+                counts[m] = counts.get(m, 0) + 1
+        out.append(sorted(counts.items(), key=lambda kv: (-kv[1], kv[0])))
+    return out
+
+
+def _random_segments(rng, nb, bb, nseg, n_rows, key_space, id_hi):
+    """`nseg` BucketCSR segments over a small key space (real collisions), ids overlapping between segments."""
+    from lshrs_amd.packed_ops import _csr_host
+
+    segs = []
+    for _ in range(nseg):
+        ids = rng.choice(id_hi, size=n_rows, replace=False).astype(np.int64)
+        keys = np.zeros((n_rows, nb, bb), dtype=np.uint8)
+        vals = rng.integers(0, key_space, size=(n_rows, nb))
+        for j in range(bb):
+            keys[:, :, j] = (vals >> (8 * j)) & 0xFF
+        csr = _csr_host(ids, keys)
+        csr.distinct = True
+        segs.append(csr)
+    return segs
+
+
+@pytest.mark.parametrize("nb,bb,nseg,key_space", [(16, 2, 3, 40), (1, 1, 1, 5), (3, 1, 2, 7), (20, 2, 4, 300), (16, 4, 2, 25),
+                                                   (33, 1, 2, 4), (128, 1, 5, 64), (8, 6, 2, 12)])
+def test_lookup_and_collide_equal_dict_counting(nb, bb, nseg, key_space):
+    import torch
+
+    from lshrs_amd import _query_device as qd
+
+    rng = np.random.default_rng(nb * 131 + bb)
+    segs = _random_segments(rng, nb, bb, nseg, 400, key_space, 600)        # ids overlap between segments: the same id twice in a bucket
+    nq = 257
+    vals = rng.integers(0, key_space + 3, size=(nq, nb))                    # (+3: some keys no bucket has)
+    keys = np.zeros((nq, nb, bb), dtype=np.uint8)
+    for j in range(bb):
+        keys[:, :, j] = (vals >> (8 * j)) & 0xFF
+    dev = torch.device("cuda", 0)
+    mirror = qd.DeviceBuckets()
+    desc, n, max_id = mirror.table(segs, dev)
+    assert n == nseg and max_id < 600
+    lists = qd.candidates_from_index(torch.from_numpy(keys).to(dev), desc, n, max_id, want_hits=True)
+    off, cnt = lists.pair_off.cpu().numpy(), lists.ucount.cpu().numpy()
+    ids, hits = lists.cand_ids.cpu().numpy(), lists.hits.cpu().numpy()
+    want = _literal_lists(segs, keys, nb, bb)
+    assert (vals >= key_space).any()                                         # keys that select no bucket
+    assert nb == 1 or any(h > 1 for w in want for _, h in w)                 # an id in several bands
+    for qi in range(nq):
+        got = list(zip(ids[off[qi]:off[qi] + cnt[qi]].tolist(), hits[off[qi]:off[qi] + cnt[qi]].tolist()))
+        assert got == want[qi], qi
+    # the same lists from pairs handed over flat (a store with get_bucket only); every (member, band) pair twice: sets
+    ms, bs, po = [], [], [0]
+    for qi in range(nq):
+        n_pairs = 0
+        for b in range(nb):
+            code = (b << (8 * bb)) | int.from_bytes(keys[qi, b].tobytes(), "little")
+            for seg in segs:
+                g = int(np.searchsorted(seg.codes, code))
+                if g < len(seg) and int(seg.codes[g]) == code:
+                    mem = seg.members[seg.offsets[g]:seg.offsets[g + 1]]
+                    ms.append(mem)
+                    bs.append(np.full(len(mem), b, np.int32))
+                    n_pairs += len(mem)
+        po.append(po[-1] + n_pairs)
+    flat = qd.candidates_from_pairs(np.concatenate(ms) if ms else np.empty(0, np.int64),
+                                    np.concatenate(bs) if bs else np.empty(0, np.int32), np.asarray(po, np.int64), nb, dev,
+                                    want_hits=True)
+    off2, cnt2 = flat.pair_off.cpu().numpy(), flat.ucount.cpu().numpy()
+    ids2, hits2 = flat.cand_ids.cpu().numpy(), flat.hits.cpu().numpy()
+    assert np.array_equal(cnt2, cnt)
+    for qi in range(nq):
+        assert list(zip(ids2[off2[qi]:off2[qi] + cnt2[qi]].tolist(), hits2[off2[qi]:off2[qi] + cnt2[qi]].tolist())) == want[qi]
+    # the mirror is reused while the store keeps its segments, rebuilt when one is replaced
+    assert mirror.uploads == nseg and mirror.table(segs, dev)[0] is desc and mirror.uploads == nseg
+    mirror.table(segs[1:], dev)
+    assert mirror.uploads == nseg
+
+
+def test_large_ids_and_the_limits_of_the_item_layout():
+    import torch
+
+    from lshrs_amd import _query_device as qd
+    from lshrs_amd.packed_ops import _csr_host
+
+    dev = torch.device("cuda", 0)
+    nb, bb = 16, 2
+    big = (1 << 59) - 5                                                     # 63 - 4 band bits
+    ids = np.array([big, 7, big - 1, 1 << 40], dtype=np.int64)
+    keys = np.zeros((4, nb, bb), dtype=np.uint8)
+    keys[:, :, 0] = np.arange(nb)[None, :]
+    keys[1, 3:, 1] = 1                                                      # id 7 shares three bands only
+    seg = _csr_host(ids, keys)
+    mirror = qd.DeviceBuckets()                                             # (owns the device arrays the descriptors point to)
+    desc, n, max_id = mirror.table([seg], dev)
+    lists = qd.candidates_from_index(torch.from_numpy(keys[:1].copy()).to(dev), desc, n, max_id, want_hits=True)
+    u = int(lists.ucount.cpu()[0])
+    assert lists.cand_ids.cpu().numpy()[:u].tolist() == [1 << 40, big - 1, big, 7]
+    assert lists.hits.cpu().numpy()[:u].tolist() == [16, 16, 16, 3]
+    seg2 = _csr_host(np.array([1 << 59], dtype=np.int64), keys[:1])
+    with pytest.raises(qd.TooLarge):
+        d2, n2, m2 = mirror.table([seg2], dev)
+        qd.candidates_from_index(torch.from_numpy(keys[:1].copy()).to(dev), d2, n2, m2)
+
+
+def test_the_cut_is_the_references_ceil():
+    """keep = min(max(1, ceil(n * top_p)), top_k) in the double arithmetic of `math.ceil(len(scored) * top_p)`
+    (lshrs/core/main.py:652-657), 0 for an empty list; offsets, sum and maximum of the scan."""
+    import torch
+
+    from lshrs_amd import _native
+    from lshrs_amd import _query_device as qd
+
+    lib = _native.load()
+    dev = torch.device("cuda", 0)
+    counts = np.r_[np.arange(0, 3000), [16384, 9999, 1, 0, 7]].astype(np.int32)
+    cd = torch.from_numpy(counts).to(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for top_k, top_p in [(None, 0.5), (None, 1.0), (10, 0.5), (3, 1.0), (None, 0.3), (None, 1e-9), (None, 0.9999999), (None, 0.1),
+                         (None, 1 / 3), (7, 0.7), (10, None), (None, None), (1, None), (None, 0.95), (None, 0.05)]:
+        keep = torch.empty(len(counts), dtype=torch.int32, device=dev)
+        off, totals = qd._scan(torch, lib, cd, len(counts), dev, stream, top_k=-1 if top_k is None else top_k,
+                               top_p=-1.0 if top_p is None else top_p, keep_out=keep)
+        want = []
+        for n in counts.tolist():
+            if n == 0:
+                want.append(0)
+            elif top_p is None:
+                want.append(n if top_k is None else min(n, top_k))
+            else:
+                lim = max(1, math.ceil(n * top_p))
+                want.append(min(min(lim, n), top_k) if top_k is not None else min(lim, n))
+        assert keep.cpu().numpy().tolist() == want, (top_k, top_p)
+        assert off.cpu().numpy().tolist() == np.r_[0, np.cumsum(want)].tolist()
+        assert totals.cpu().numpy().tolist() == [sum(want), max(want)]
+    off, totals = qd._scan(torch, lib, cd, len(counts), dev, stream)
+    assert off.cpu().numpy().tolist() == np.r_[0, np.cumsum(counts.astype(np.int64))].tolist()
+    assert totals.cpu().numpy().tolist() == [int(counts.sum()), 16384]
+
+
+def _clustered(rng, n, dim, clusters, spread):
+    centers = rng.standard_normal((clusters, dim)).astype(np.float32)
+    return (np.repeat(centers, n // clusters, axis=0) + spread * rng.standard_normal((n, dim))).astype(np.float32)
+
+
+def _same_ranking(got, want, tol=1e-5, gap=2e-5):
+    """Lists of (id, score): equal lengths; scores within `tol` wherever the ids agree; where they do not, the two are
+    near-ties of the reference - scores at most `gap` apart (the reference's own order among ties is unspecified, and a tie
+    may straddle the cut: the partner is then not in the list at all)."""
+    assert len(got) == len(want)
+    for j, ((gi, gs), (wi, ws)) in enumerate(zip(got, want)):
+        if gi == wi:
+            assert abs(gs - ws) <= tol, (j, gi, gs, ws)
+        else:
+            assert abs(gs - ws) <= tol + gap, (j, gi, wi, gs, ws)
+
+
+@pytest.mark.parametrize("dim,num_perm,nb,r,n,clusters,spread", [
+    (64, 64, 16, 4, 3000, 300, 0.35),          # one-byte keys, 16 crowded buckets per band: lists of thousands, many equal counts
+    (768, 256, 16, 16, 4000, 400, 0.3),        # config 2's shape
+    (96, 512, 16, 32, 3000, 300, 0.25),        # four-byte keys (config 5's layout): bisection on 32-bit codes
+    (50, 40, 8, 5, 2000, 100, 0.3),            # dim % 4 != 0, five-row bands
+])
+def test_query_many_on_the_device_equals_the_reference_flow(dim, num_perm, nb, r, n, clusters, spread):
+    """>= 1 000 queries per shape through LSHRS.query_many (engine="device") against oracle.query_literal on the same store:
+    top_k by collisions (equal counts -> id order, empty buckets, ids in several bands), top_p with its ceil, top_k AND top_p;
+    list form, array form, the host engine and - one query at a time - `query` itself."""
+    import torch
+
+    from lshrs_amd import LSHRS, InMemoryStorage
+    from oracle import lshrs_oracle as O
+
+    rng = np.random.default_rng(dim * 7 + nb)
+    data = _clustered(rng, n, dim, clusters, spread)
+    store = InMemoryStorage()
+    idx = LSHRS(dim=dim, num_perm=num_perm, num_bands=nb, rows_per_band=r, storage=store, packed_ingest=True, seed=42,
+                vector_fetch_fn=lambda ids: data[np.asarray(ids)])
+    third = n // 3
+    idx.index(np.arange(third), data[:third])                        # three calls: three array segments
+    idx.index(np.arange(third, 2 * third), data[third:2 * third])
+    idx.index(np.arange(2 * third, n), data[2 * third:])
+    idx.index(np.arange(100), data[:100])                            # ... and 100 ids indexed twice (the same buckets: sets)
+    assert len(store.array_segments((r + 7) // 8)) == 4 and not store.batches
+    nq = 1000
+    rows = rng.choice(n, nq, replace=False)
+    queries = (data[rows] + 0.05 * rng.standard_normal((nq, dim))).astype(np.float32)
+    queries[::50] = rng.standard_normal((len(queries[::50]), dim)).astype(np.float32)      # strangers: mostly empty buckets
+    P = idx._hasher.projections
+    fetch = lambda ids: data[np.asarray(ids)]  # noqa: E731
+    corpus = torch.from_numpy(data).cuda()
+
+    lit_all = [O.query_literal(store, P, dim, q, top_k=None) for q in queries]
+    assert (r <= 5 or any(len(w) == 0 for w in lit_all)) and any(len(w) > 5 for w in lit_all)
+    got_all = idx.query_many(queries, top_k=None, engine="device")
+    assert got_all == lit_all
+    assert idx.query_many(queries, top_k=10, engine="device") == [w[:10] for w in lit_all]
+    assert idx.query_many(queries, top_k=1, engine="device") == [w[:1] for w in lit_all]
+    assert idx.query_many(queries, top_k=None, engine="host") == lit_all
+    ids, scores, bounds = idx.query_many(queries, top_k=7, return_arrays=True)
+    assert scores is None and ids.dtype == np.int64 and bounds.shape == (nq + 1,)
+    assert [ids[bounds[i]:bounds[i + 1]].tolist() for i in range(nq)] == [w[:7] for w in lit_all]
+
+    # (the literal rerank normalises candidate by candidate in Python: 170 queries per setting, 40 where the lists are thousands long)
+    sample = np.r_[0:120, 950:1000] if r > 4 else np.r_[0:30, 990:1000]
+    for top_k, top_p in [(None, 0.5), (None, 1.0), (5, 0.3), (3, 1.0), (None, 0.01)]:
+        want = [O.query_literal(store, P, dim, queries[i], top_k=top_k, top_p=top_p, fetch=fetch) for i in sample]
+        on_corpus = idx.query_many(queries, top_k=top_k, top_p=top_p, corpus=corpus, engine="device")
+        fetched = idx.query_many(queries[sample], top_k=top_k, top_p=top_p, engine="device")
+        hosted = idx.query_many(queries[sample], top_k=top_k, top_p=top_p, corpus=corpus, engine="host")
+        for j, i in enumerate(sample):
+            _same_ranking(on_corpus[i], want[j])
+            _same_ranking(fetched[j], want[j])
+            _same_ranking(hosted[j], want[j])
+            n_cand = len(lit_all[i])
+            lim = 0 if n_cand == 0 else max(1, math.ceil(n_cand * top_p))
+            assert len(on_corpus[i]) == (min(lim, top_k) if top_k is not None else lim)
+        ids, scores, bounds = idx.query_many(queries, top_k=top_k, top_p=top_p, corpus=corpus, return_arrays=True)
+        assert scores.dtype == np.float32 and len(ids) == len(scores) == bounds[-1]
+        assert [list(zip(ids[bounds[i]:bounds[i + 1]].tolist(), scores[bounds[i]:bounds[i + 1]].astype(np.float64).tolist()))
+                for i in range(nq)] == on_corpus
+    # one query at a time: the reference's own entry points on the attached corpus
+    idx.set_corpus(corpus)
+    for i in sample[:40]:
+        _same_ranking(idx.get_above_p(queries[i], p=0.5),
+                      O.query_literal(store, P, dim, queries[i], top_k=None, top_p=0.5, fetch=fetch))
+        assert idx.get_top_k(queries[i], topk=4) == lit_all[i][:4]
+    # deleting ids replaces segments: the mirror follows
+    gone = [int(w[0]) for w in lit_all[:200] if w]
+    idx.delete(gone)
+    assert idx.query_many(queries[:200], top_k=5, engine="device") == [
+        O.query_literal(store, P, dim, q, top_k=5) for q in queries[:200]]
+    idx.clear()
+    assert idx.query_many(queries[:5], top_k=5, engine="device") == [[]] * 5
+    assert idx.query_many(queries[:5], top_k=None, top_p=0.5, engine="device") == [[]] * 5
+
+
+class _GetBucketOnly:
+    """The reference's storage interface and nothing else (lshrs/storage/redis.py: batch_add, get_bucket ...)."""
+
+    def __init__(self):
+        from lshrs_amd import InMemoryStorage
+
+        self._inner = InMemoryStorage()
+
+    def batch_add(self, ops):
+        self._inner.batch_add(ops)
+
+    def get_bucket(self, band_id, hash_val):
+        return self._inner.get_bucket(band_id, hash_val)
+
+    def remove_indices(self, indices):
+        self._inner.remove_indices(indices)
+
+    def clear(self):
+        self._inner.clear()
+
+    def close(self):
+        pass
+
+
+def test_stores_with_get_bucket_only_count_on_the_device_too():
+    """Redis-like stores: one get_bucket per (query, band) as the reference does (main.py:1103), the (member, band) pairs
+    uploaded flat, sort / count / order / rerank on the device.  Also a store holding BOTH op-tuple buckets and array segments."""
+    import torch
+
+    from lshrs_amd import LSHRS, InMemoryStorage
+    from oracle import lshrs_oracle as O
+
+    rng = np.random.default_rng(5)
+    dim, n = 128, 3000
+    data = _clustered(rng, n, dim, 150, 0.3)
+    queries = (data[rng.choice(n, 300, replace=False)] + 0.05 * rng.standard_normal((300, dim))).astype(np.float32)
+    corpus = torch.from_numpy(data).cuda()
+    fetch = lambda ids: data[np.asarray(ids)]  # noqa: E731
+    for store, packed in ((_GetBucketOnly(), "auto"), (InMemoryStorage(), False)):
+        idx = LSHRS(dim=dim, num_perm=64, storage=store, packed_ingest=packed, vector_fetch_fn=fetch)
+        idx.index(np.arange(n), data)
+        if isinstance(store, InMemoryStorage):
+            idx._packed_ingest = True
+            idx.index(np.arange(n, n + 500), data[:500])                      # tuples AND arrays in one store
+            assert store.array_segments(1) is None and store.prefers_batched_lookup
+        P = idx._hasher.projections
+        want = [O.query_literal(store, P, dim, q, top_k=None) for q in queries]
+        assert idx.query_many(queries, top_k=None, engine="device") == want
+        assert idx.query_many(queries, top_k=6, engine="device") == [w[:6] for w in want]
+        table = corpus if not isinstance(store, InMemoryStorage) else torch.cat([corpus, corpus[:500]])
+        full = np.concatenate([data, data[:500]])
+        got = idx.query_many(queries[:60], top_k=None, top_p=0.5, corpus=table, engine="device")
+        for g, q in zip(got, queries[:60]):
+            _same_ranking(g, O.query_literal(store, P, dim, q, top_k=None, top_p=0.5, fetch=lambda ids: full[np.asarray(ids)]))
+
+
+def test_lists_beyond_the_lds_network_fall_back_to_the_host_count():
+    """A query whose buckets hold more than LSHRS_QUERY_MAX_PAIRS members: engine="device" says so, "auto" answers through
+    the host count - the same answer."""
+    from lshrs_amd import LSHRS, InMemoryStorage, _native
+    from lshrs_amd import _query_device as qd
+    from oracle import lshrs_oracle as O
+
+    rng = np.random.default_rng(9)
+    dim = 32
+    base = rng.standard_normal(dim).astype(np.float32)
+    n = 1500                                                             # x 16 bands = 24 000 pairs for a query next to `base`
+    data = (base[None, :] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
+    store = InMemoryStorage()
+    idx = LSHRS(dim=dim, num_perm=64, storage=store, packed_ingest=True)
+    idx.index(np.arange(n), data)
+    q = np.stack([base, -base]).astype(np.float32)
+    with pytest.raises(qd.TooLarge):
+        idx.query_many(q, top_k=5, engine="device")
+    want = [O.query_literal(store, idx._hasher.projections, dim, v, top_k=5) for v in q]
+    assert len(want[0]) == 5 and idx.query_many(q, top_k=5) == want
+    assert _native.QUERY_MAX_PAIRS == 16384
+
+
+def test_errors_are_the_references():
+    import torch
+
+    from lshrs_amd import LSHRS, InMemoryStorage
+
+    rng = np.random.default_rng(2)
+    data = _clustered(rng, 600, 32, 30, 0.2)
+    idx = LSHRS(dim=32, num_perm=16, storage=InMemoryStorage(), packed_ingest=True)
+    idx.index(np.arange(600), data)
+    q = data[400:408] + 0.01
+    with pytest.raises(ValueError, match="Cannot index zero vector"):
+        idx.query_many(np.r_[q, np.zeros((1, 32), np.float32)], top_k=3)
+    with pytest.raises(RuntimeError, match="vector_fetch_fn must be supplied"):
+        idx.query_many(q, top_k=None, top_p=0.5)
+    corpus = torch.from_numpy(data).cuda()
+    short = corpus[:300]
+    with pytest.raises(IndexError, match="out of range"):
+        idx.query_many(q, top_k=None, top_p=1.0, corpus=short)
+    dead = corpus.clone()
+    dead[idx.query_many(q[:1], top_k=1)[0][0]] = 0
+    with pytest.raises(ValueError, match="Cannot normalize zero vector"):
+        idx.query_many(q[:1], top_k=None, top_p=1.0, corpus=dead)
+    with pytest.raises(ValueError, match="engine must be"):
+        idx.query_many(q, engine="gpu")
+    ids, scores, bounds = idx.query_many(np.empty((0, 32), np.float32), top_p=0.5, corpus=corpus, return_arrays=True)
+    assert len(ids) == 0 and len(scores) == 0 and bounds.tolist() == [0]
