@@ -66,26 +66,27 @@ typedef struct lshrs_sig_opts {
 /* Scratch that lets stage 2 of lshrs_sig_hash_batch_split_replay_f32 work through the flagged projections COLUMN BY COLUMN
  * (ABI 6; optional - the keys are the same with or without it, this is speed): every group of eight entries stage 2 takes
  * then shares one hyperplane, fetched once into LDS instead of eight times from L2 - the row gather of x is the only
- * stream left.  For hashers of at most 1024 padded key columns whose rows are longer than four k-tiles.  Two ways there:
- *   mode 1, BUCKETS (what lshrs_amd uses): stage 1 itself appends every flagged projection - and its audit sample, bit 62 of
- *     the entry - to the SEGMENT of its padded key column: list / y / thr are [columns][cap / columns], hist holds the
+ * stream left.  For hashers of at most 1024 padded key columns whose rows are longer than four k-tiles.
+ *   BUCKETS (mode 1 - the only mode since ABI 7): stage 1 itself appends every flagged projection - and its audit sample, bit 62
+ *     of the entry - to the SEGMENT of its padded key column: list / y / thr are [columns][cap / columns], hist holds the
  *     entries wanted per column, TWO sets of 1024 counters used alternately (`parity`: the set this call counts in - zero on
  *     entry; the call clears the other one for the next, so the caller can still read this call's).  A column that wanted
  *     more than its segment holds: counter [7] of the call's counters != 0 - repeat with room.  No launch between the stages.
  *     Padded columns are the key columns here (8 x key bytes per row): the zero-padded columns of a stage-1 column block
  *     have no segment - a NaN / Inf row's entries for them are dropped in stage 1 ([1] then counts fewer than without
- *     the scratch).  The chunked pass ignores `sort`: its chunks overlap and cannot share one scratch.
- *   mode 0, SORT: the stage-1 list is counting-sorted by padded column on the device (three small launches), runs padded to
- *     groups of eight; list DEVICE int64[cap], y DEVICE float[cap], cap >= flag_cap + 8 * padded columns; hist DEVICE
- *     int32[256 * padded columns + 1].  (Pays for config 5's 2.35 M entries of 1536 elements, not at 768-d.) */
+ *     the scratch).
+ *   (ABI 6 also had mode 0 - the plain stage-1 list counting-sorted by column in three launches; 2.46 ms against the buckets' 2.37 at config 5, slower
+ *   than the plain stage 2 at 768-d - and a chunked form of the pass whose stage 2 ran beside the
+ *   next chunk's stage 1; slower on every plan, profiles/r05_chunk_overlap.log.  Both are gone; a `mode` other than 1 is
+ *   ignored: the plain stage 2 runs.) */
 typedef struct lshrs_sig_sort {
   uint32_t struct_bytes;   /* sizeof(lshrs_sig_sort) */
   int32_t cap;             /* entries list / y (/ thr) hold */
   int64_t* list;
   float* y;
-  int32_t* hist;           /* mode 0: int32[256 * columns + 1]; mode 1: int32[2 * 1024] */
-  float* thr;              /* mode 1: DEVICE float[cap] - the window each audit entry was compared with */
-  int32_t mode;
+  int32_t* hist;           /* int32[2 * 1024] */
+  float* thr;              /* DEVICE float[cap] - the window each audit entry was compared with */
+  int32_t mode;            /* 1 */
   int32_t parity;
 } lshrs_sig_sort;
 
@@ -243,43 +244,6 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
                                           int64_t* flag_list, float* flag_y, int32_t flag_cap, float tau1,
                                           int32_t blas_model, int32_t* host_counts,
                                           const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream);
-
-/* lshrs_sig_hash_batch_split_replay_f32 as a short pipeline inside ONE call (ABI 6): the batch is cut into `nchunks` row
- * chunks; stage 1 of the chunks runs back to back on `stream`, stage 2 (and the export of the counters) of every chunk but
- * the last on a side stream of the caller's, BESIDE the next chunk's stage 1 - what is left serial is the last chunk's
- * stage 2.  Same keys as the one-launch form (chunks are row ranges; rows do not interact).  `stream` waits for every side
- * stream before the call's work counts as done: synchronising `stream` is enough, as for every other call.
- *   rows[c]        rows of chunk c, in order; their sum is n.  Whole rounds of workgroups (multiples of 65 536 rows) make a
- *                  chunk's stage 1 end evenly; the last chunk takes the ragged end.
- *   flag_cap[c]    list entries chunk c may use: the chunks' regions lie back to back in flag_list / flag_y (the caller
- *                  sizes both for the sum)
- *   side_stream[c] hipStream_t for stage 2 of chunk c < nchunks - 1 (distinct from `stream`; may repeat: stage 2 of two
- *                  chunks on one side stream run in order)
- *   ev_fork[c], ev_join[c]   hipEvent_t of the caller's (no timing needed), one pair per forked chunk
- *   ev_timing      optional hipEvent_t[4 * nchunks]: per chunk what lshrs_sig_opts' four events are per call (then `opts`
- *                  must be given; its own four are ignored)
- *   counters       DEVICE int32[nchunks * LSHRS_SIG_DEVICE_COUNTERS], zero on entry, left zeroed (one block per chunk)
- *   host_counts    PINNED HOST int32[nchunks * LSHRS_SIG_COUNTERS]: the counters of chunk c in block c - the caller adds /
- *                  maxes them; [1] of block c > flag_cap[c]: that chunk is incomplete, repeat the pass with room
- *   audit          its slots and target are shared out over the chunks by rows */
-#define LSHRS_SIG_MAX_CHUNKS 8
-typedef struct lshrs_sig_chunk_plan {
-  uint32_t struct_bytes;   /* sizeof(lshrs_sig_chunk_plan) */
-  int32_t nchunks;         /* 1 .. LSHRS_SIG_MAX_CHUNKS */
-  int64_t rows[LSHRS_SIG_MAX_CHUNKS];
-  int32_t flag_cap[LSHRS_SIG_MAX_CHUNKS];
-  void* side_stream[LSHRS_SIG_MAX_CHUNKS];
-  void* ev_fork[LSHRS_SIG_MAX_CHUNKS];
-  void* ev_join[LSHRS_SIG_MAX_CHUNKS];
-  void** ev_timing;
-} lshrs_sig_chunk_plan;
-int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int64_t ldx,
-                                                  const void* workspace, int32_t num_bands, int32_t rows_per_band,
-                                                  int32_t dim, uint8_t* keys, int32_t* counters, float tau,
-                                                  uint8_t* row_flags, int64_t* flag_list, float* flag_y, float tau1,
-                                                  int32_t blas_model, int32_t* host_counts,
-                                                  const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
-                                                  const lshrs_sig_chunk_plan* plan, void* stream);
 
 /* The tie-break on the device for the f32 kernel: behind lshrs_sig_hash_batch_f32 (same X, keys, tie_list, tie_count,
  * tau, same stream) it decides every reported tie by the host BLAS's value - the tie entries are unpacked into

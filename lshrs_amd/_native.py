@@ -28,7 +28,6 @@ QUERY_MAX_PAIRS = 16384   # LSHRS_QUERY_MAX_PAIRS
 SIG_COUNTERS = 8          # LSHRS_SIG_COUNTERS of include/lshrs_hip.h
 SIG_DEVICE_COUNTERS = SIG_COUNTERS + 6 * 4096      # LSHRS_SIG_DEVICE_COUNTERS: the device block (counters + stage-2 slots)
 SMALL_MAX_ROWS = 256      # LSHRS_SMALL_MAX_ROWS
-SIG_MAX_CHUNKS = 8        # LSHRS_SIG_MAX_CHUNKS
 SORT_MAX_COLS = 1024      # kSortMaxCols of csrc/lshrs_common.h: padded key columns the column-wise stage 2 takes
 
 BUILD_WRONG_KEYS = 0x1   # LSHRS_BUILD_WRONG_KEYS
@@ -115,11 +114,6 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_sig_hash_batch_split_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, i32, f32,
                                                           i32, vp, vp, vp, vp]
     lib.lshrs_sig_hash_batch_split_replay_f32.restype = c.c_int
-    # (X, n, ldx, workspace, bands, rows, dim, keys, counters, tau, row_flags, flag_list, flag_y, tau1, blas_model,
-    #  host_counts, audit, opts, plan, stream)
-    lib.lshrs_sig_hash_batch_split_replay_chunked_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, f32, vp, vp, vp,
-                                                                  f32, i32, vp, vp, vp, vp, vp]
-    lib.lshrs_sig_hash_batch_split_replay_chunked_f32.restype = c.c_int
     # (X, n, ldx, workspace, bands, rows, dim, keys, tie_list, tie_cap, counters, tau, flag_list, flag_cap, blas_model,
     #  host_counts, stream)
     lib.lshrs_sig_resolve_ties_replay_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, vp, i32, vp, f32, vp, i32, i32, vp,
@@ -191,7 +185,6 @@ EXPORTS = (
     "lshrs_sig_hash_batch_f32",
     "lshrs_sig_hash_batch_split_f32",
     "lshrs_sig_hash_batch_split_replay_f32",
-    "lshrs_sig_hash_batch_split_replay_chunked_f32",
     "lshrs_sig_resolve_ties_replay_f32",
     "lshrs_sig_hash_small_replay_f32",
     "lshrs_stream_synchronize",
@@ -288,7 +281,7 @@ class SigSort(ctypes.Structure):
     _fields_ = [("struct_bytes", ctypes.c_uint32), ("cap", ctypes.c_int32), ("list", ctypes.c_void_p), ("y", ctypes.c_void_p),
                 ("hist", ctypes.c_void_p), ("thr", ctypes.c_void_p), ("mode", ctypes.c_int32), ("parity", ctypes.c_int32)]
 
-    def __init__(self, list_ptr: int, y_ptr: int, hist_ptr: int, cap: int, thr_ptr=None, mode: int = 0):
+    def __init__(self, list_ptr: int, y_ptr: int, hist_ptr: int, cap: int, thr_ptr=None, mode: int = 1):
         super().__init__()
         self.struct_bytes = ctypes.sizeof(SigSort)
         self.list, self.y, self.hist, self.cap = list_ptr, y_ptr, hist_ptr, int(cap)
@@ -306,20 +299,6 @@ class SigAudit(ctypes.Structure):
         super().__init__()
         self.struct_bytes = ctypes.sizeof(SigAudit)
         self.list, self.vals, self.slots, self.target, self.seed = list_ptr, vals_ptr, int(slots), int(target), int(seed) & 0xFFFFFFFF
-
-
-class SigChunkPlan(ctypes.Structure):
-    """``lshrs_sig_chunk_plan`` of include/lshrs_hip.h: row chunks of one pass, the side streams their stage 2 runs on and the
-    events that fork / join them."""
-
-    _fields_ = [("struct_bytes", ctypes.c_uint32), ("nchunks", ctypes.c_int32),
-                ("rows", ctypes.c_int64 * SIG_MAX_CHUNKS), ("flag_cap", ctypes.c_int32 * SIG_MAX_CHUNKS),
-                ("side_stream", ctypes.c_void_p * SIG_MAX_CHUNKS), ("ev_fork", ctypes.c_void_p * SIG_MAX_CHUNKS),
-                ("ev_join", ctypes.c_void_p * SIG_MAX_CHUNKS), ("ev_timing", ctypes.POINTER(ctypes.c_void_p))]
-
-    def __init__(self):
-        super().__init__()
-        self.struct_bytes = ctypes.sizeof(SigChunkPlan)
 
 
 def check(code: int, what: str) -> None:

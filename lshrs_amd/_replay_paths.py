@@ -1,5 +1,5 @@
 """The device tie replay behind ``LSHHasher`` (mixin): launches of the split pass whose stage 2 replays the host BLAS's order
-(``lshrs_sig_hash_batch_split_replay_f32``; chunked: ``..._chunked_f32``; column-sorted stage 2: ``lshrs_sig_sort``), what comes
+(``lshrs_sig_hash_batch_split_replay_f32``; stage 2 by key column: ``lshrs_sig_sort``), what comes
 back from them (counters, the audit of un-flagged projections, the margin guard), the streaming handle, the live audit against
 ``P_band @ x`` and the f32 kernel + replay route.  Moved out of ``hasher.py`` in round 5 (no behaviour change): that file keeps the
 constructor, the hyperplanes, the windows and the one place that decides which route a batch takes."""
@@ -68,6 +68,13 @@ class _PendingKeys:
                 self._finish_locked()
         return self._out
 
+    @property
+    def stats(self) -> dict:
+        """THIS batch's statistics (route, flagged projections, ties, relaunches, the audit ...), once it is verified - the
+        per-call form of ``LSHHasher.last_stats``, which is the hasher's LAST batch and may be another thread's."""
+        self.result()
+        return dict(self._stats or {})
+
 
 
 class _ReplayPaths:
@@ -91,11 +98,6 @@ class _ReplayPaths:
             cap = max(int(self._flag_cap_hint), n // 4 + 4096)
             if self.tau1_ulps > 256.0:      # a wide (e.g. "bound") window flags ~1.3e-6 of the projections per unit
                 cap = max(cap, int(n * self.num_bands * self.rows_per_band * min(self.tau1_ulps, 4096.0) * 2.0e-6) + 4096)
-            chunk_rows = self._chunk_rows(n)
-            caps = None
-            if chunk_rows is not None:      # every chunk its share of the list (+ room for a chunk of unlucky rows)
-                caps = [int(cap * r // n) + 4096 for r in chunk_rows]
-                cap = sum(caps)
             skey = (dev.index, raw)
             scratch = self._replay_scratch.get(skey)
             if scratch is None or scratch[9][3] < cap:
@@ -115,7 +117,6 @@ class _ReplayPaths:
                     # a caller that keeps making new streams must not pile up lists: nothing is in flight, start over
                     self._replay_scratch.clear()
                     self._replay_events.clear()
-                    self._chunk_res.clear()
                     self._sort_res.clear()
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
@@ -143,31 +144,12 @@ class _ReplayPaths:
                         ring.append((quad, _native.SigOpts(events=tuple(e.cuda_event for e in quad))))
                     self._replay_events[skey] = ring
                 ev, opts = ring[slot]
-            cres = plan = None
-            if chunk_rows is not None:
-                cres = self._chunk_resources(torch, dev, skey)
-                plan = cres["plans"][slot]
-                plan.nchunks = len(chunk_rows)
-                for c, (r, fc) in enumerate(zip(chunk_rows, caps)):
-                    plan.rows[c], plan.flag_cap[c] = r, fc
-                plan.ev_timing = None
-                if timing:      # four events per chunk, riding on the chunks' dispatches (created at first use)
-                    if cres["timing"][slot] is None:
-                        cur = torch.cuda.current_stream(dev)
-                        tev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * _native.SIG_MAX_CHUNKS)]
-                        for e in tev:
-                            e.record(cur)
-                        arr = (ctypes.c_void_p * len(tev))(*[e.cuda_event for e in tev])
-                        cres["timing"][slot] = (tev, ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)), arr)
-                    ev, plan.ev_timing = cres["timing"][slot][:2]
-                    opts = cres["opts"]
-            smode = self._stage2_mode() if plan is None else None
+            smode = self._stage2_mode()
             sort = None
             if smode is not None:
-                sort = self._sort_scratch(torch, dev, skey, cap, smode)
-                if smode == 1:
-                    sort[0].parity = sort[4][0] & 1          # the set of column counters this launch counts in (the other: cleared by it)
-                    sort[4][0] += 1
+                sort = self._sort_scratch(torch, dev, skey, cap)
+                sort[0].parity = sort[4][0] & 1              # the set of column counters this launch counts in (the other: cleared by it)
+                sort[4][0] += 1
                 if opts is None:
                     opts = sort[1]
                 else:
@@ -184,31 +166,17 @@ class _ReplayPaths:
                 audit.target = self.audit_unflagged
                 audit.seed = (self._audit_seed * 2654435761) & 0xFFFFFFFF
             try:
-                if plan is not None:
-                    _native.check(
-                        lib.lshrs_sig_hash_batch_split_replay_chunked_f32(
-                            x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
-                            out.data_ptr(), cres["counts_ptr"], tau, row_flags.data_ptr() if row_flags is not None else None,
-                            ptrs[0], ptrs[2], self._tau1_arg(), model, cres["pinned_ptrs"][slot],
-                            ctypes.byref(audit) if audit is not None else None,
-                            ctypes.byref(opts) if opts is not None else None, ctypes.byref(plan), raw),
-                        "lshrs_sig_hash_batch_split_replay_chunked_f32")
-                else:
-                    _native.check(
-                        lib.lshrs_sig_hash_batch_split_replay_f32(
-                            x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
-                            out.data_ptr(), ptrs[1], tau, row_flags.data_ptr() if row_flags is not None else None,
-                            ptrs[0], ptrs[2], ptrs[3], self._tau1_arg(),
-                            model, ptrs[4][slot], ctypes.byref(audit) if audit is not None else None,
-                            ctypes.byref(opts) if opts is not None else None, raw),
-                        "lshrs_sig_hash_batch_split_replay_f32")
+                _native.check(
+                    lib.lshrs_sig_hash_batch_split_replay_f32(
+                        x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
+                        out.data_ptr(), ptrs[1], tau, row_flags.data_ptr() if row_flags is not None else None,
+                        ptrs[0], ptrs[2], ptrs[3], self._tau1_arg(),
+                        model, ptrs[4][slot], ctypes.byref(audit) if audit is not None else None,
+                        ctypes.byref(opts) if opts is not None else None, raw),
+                    "lshrs_sig_hash_batch_split_replay_f32")
             except BaseException:
                 torch.cuda.current_stream(dev).synchronize()
-                for side in (cres["streams"] if cres is not None else ()):
-                    side.synchronize()
                 counts.zero_()              # a failed launch may have left counts behind: the next call starts from zero
-                if cres is not None:
-                    cres["counts"].zero_()
                 if sort is not None:
                     sort[3][2].zero_()
                 turn[1].append(slot)
@@ -221,110 +189,42 @@ class _ReplayPaths:
                 done = _RawStreamWait(lib, raw)
         # (the ceiling the live check holds this launch to is the one of the coefficients it was launched with: `window_info`
         #  follows whichever BLAS-order model `_ensure_window` set last, and an async handle may be finished after a switch)
-        if plan is not None:      # (the counters of chunk c: block c of this launch's pinned blocks, judged against its own share)
-            host_counts, cap_of = cres["host"][slot][:len(caps)], caps
-        else:
-            host_counts, cap_of = host_counts[slot:slot + 1], (ptrs[3],)
-        return (done, host_counts, slot, cap_of, n, ev,
+        return (done, host_counts[slot:slot + 1], slot, (ptrs[3],), n, ev,
                 float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps),
                 float(self.window_info.get("window_units_worst_case_row", float("inf"))), turn[0], turn)
 
     def _stage2_mode(self):
-        """Which column-wise stage 2 a launch of the split pass asks for: 1 = buckets (stage 1 appends by key column), 0 = the list
-        sorted on the device, None = the plain stage 2 (what the resident-image kernel's short rows always take)."""
+        """Which stage 2 a launch of the split pass asks for: 1 = by key column, through the buckets stage 1 fills; None = the
+        plain stage 2 (what the resident-image kernel's short rows always take)."""
         want = self.stage2_sorted
+        if want not in ("auto", "buckets", False):
+            raise ValueError("stage2_sorted must be 'auto', 'buckets' or False")
         if want is False or self.dim <= 128:
             return None
         padcols = self.num_bands * self.band_bytes * 8
         if padcols > _native.SORT_MAX_COLS:
             return None
-        if want == "sort" or want is True:
-            return 0
         if self._resident_shape():    # (the resident-image kernel keeps one list: its stage 2 is the plain one)
             return None
         return 1                      # "auto", "buckets"
 
-    def _sort_scratch(self, torch, dev, skey, cap: int, mode: int):
-        """(SigSort, a SigOpts that carries it, capacity, tensors, launch counter) for launches on this (device, stream).  Buckets:
-        a segment per padded key column - 1.5 x its share of the list + 64 entries -, the entries' stage-1 values and the audit
-        entries' windows beside them, two sets of 1024 column counters.  Sort: the sorted list and its values - room for every
-        run padded to eight -, the per-workgroup histograms."""
+    def _sort_scratch(self, torch, dev, skey, cap: int):
+        """(SigSort, a SigOpts that carries it, capacity, tensors, launch counter) for launches on this (device, stream): a
+        segment per padded key column - 1.5 x its share of the list + 64 entries -, the entries' stage-1 values and the audit
+        entries' windows beside them, two sets of 1024 column counters."""
         padcols = self.num_bands * self.band_bytes * 8
-        if mode == 1:
-            per = max(int(1.5 * cap / padcols) + 64, int(self._bucket_cap_hint))
-            need = per * padcols
-        else:
-            need = int(cap) + 8 * padcols
+        per = max(int(1.5 * cap / padcols) + 64, int(self._bucket_cap_hint))
+        need = per * padcols
         got = self._sort_res.get(skey)
-        if got is None or got[2] < need or got[0].mode != mode:
+        if got is None or got[2] < need:
             lst = torch.empty(need, dtype=torch.int64, device=dev)
             y = torch.empty(need, dtype=torch.float32, device=dev)
-            if mode == 1:
-                hist = torch.zeros(2 * _native.SORT_MAX_COLS, dtype=torch.int32, device=dev)
-                thr = torch.empty(need, dtype=torch.float32, device=dev)
-                sort = _native.SigSort(lst.data_ptr(), y.data_ptr(), hist.data_ptr(), need, thr.data_ptr(), 1)
-            else:
-                hist = torch.zeros(256 * padcols + 1, dtype=torch.int32, device=dev)
-                thr = None
-                sort = _native.SigSort(lst.data_ptr(), y.data_ptr(), hist.data_ptr(), need)
+            hist = torch.zeros(2 * _native.SORT_MAX_COLS, dtype=torch.int32, device=dev)
+            thr = torch.empty(need, dtype=torch.float32, device=dev)
+            sort = _native.SigSort(lst.data_ptr(), y.data_ptr(), hist.data_ptr(), need, thr.data_ptr(), 1)
             got = (sort, _native.SigOpts(sort=sort), need, (lst, y, hist, thr), [0])
             self._sort_res[skey] = got
         return got
-
-    _ROUND_WORKGROUPS = 256            # one 256-row stage-1 workgroup per CU
-
-    def _chunk_rows(self, n: int):
-        """Row chunks of one synchronous pass (None: one launch of each stage).  Chunks end at whole rounds of stage-1
-        workgroups (256 workgroups of 256 rows over this hasher's column blocks), so a chunk's stage 1 ends evenly; the last
-        chunk takes the ragged end plus one round - short, because its stage 2 is the one nothing hides."""
-        mode = self.chunking
-        if mode == "off" or self._resident_shape():
-            return None
-        if mode not in ("on", "auto") and isinstance(mode, str):
-            raise ValueError("chunking must be 'off', 'on' or a sequence of row counts")
-        if not isinstance(mode, str):
-            rows = [int(r) for r in mode]
-            return rows if sum(rows) == n and all(r > 0 for r in rows) and 1 < len(rows) <= _native.SIG_MAX_CHUNKS else None
-        lib = _native.load()
-        blocks = max(1, -(-int(lib.lshrs_sig_padded_columns(self.num_bands, self.rows_per_band)) // 256))
-        rnd = max(256, self._ROUND_WORKGROUPS * 256 // blocks)
-        rounds = n // rnd
-        if rounds < self.chunk_min_rounds:
-            return None
-        last = n - (rounds - 1) * rnd          # the ragged end + one round
-        first = ((rounds - 1) * 4 // 7) * rnd   # a little more than half of what is in front of it
-        mid = n - last - first
-        return [first, mid, last] if mid > 0 else [first, last]
-
-    def _chunk_resources(self, torch, dev, skey) -> dict:
-        """What the chunked launch needs beside the scratch of `_replay_launch`, per (device, stream): a device counter block
-        and four pinned blocks with room for every chunk, two side streams (stage 2 of chunk c on stream c % 2), fork / join
-        events and a plan struct per pinned block (four launches may be unverified at a time)."""
-        res = self._chunk_res.get(skey)
-        if res is not None:
-            return res
-        mc, nc = _native.SIG_MAX_CHUNKS, _native.SIG_COUNTERS
-        cur = torch.cuda.current_stream(dev)
-        counts = torch.zeros(mc * _native.SIG_DEVICE_COUNTERS, dtype=torch.int32, device=dev)
-        pinned = torch.zeros((4, mc, nc), dtype=torch.int32).pin_memory()
-        streams = [torch.cuda.Stream(dev) for _ in range(2)]
-        events, plans, timing = [], [], []
-        for _ in range(4):
-            evs = [torch.cuda.Event() for _ in range(2 * mc)]
-            for e in evs:
-                e.record(cur)                # creates the handles
-            plan = _native.SigChunkPlan()
-            for c in range(mc):
-                plan.side_stream[c] = streams[c % 2].cuda_stream
-                plan.ev_fork[c], plan.ev_join[c] = evs[2 * c].cuda_event, evs[2 * c + 1].cuda_event
-            events.append(evs)
-            plans.append(plan)
-            timing.append(None)
-        res = {"counts": counts, "counts_ptr": counts.data_ptr(), "pinned": pinned, "host": pinned.numpy(),
-               "pinned_ptrs": tuple(pinned.data_ptr() + 4 * mc * nc * i for i in range(4)), "streams": streams,
-               "events": events, "plans": plans, "timing": timing, "opts": _native.SigOpts()}
-        self._chunk_res[skey] = res
-        return res
 
     def _replay_finish(self, state, stats) -> bool:
         """Wait for a launch of `_replay_launch`; False when it must be repeated: its stage-1 list was too small (more
@@ -335,28 +235,15 @@ class _ReplayPaths:
             done.synchronize()      # (the launch behind stage 2 has written the counters into the pinned block)
         finally:
             state[9][1].append(slot)        # (the pinned block is free for the next launch - also when the wait raised)
-        if len(caps) == 1:
-            ties, flagged, _, flips, audited, audit_bad, _, col_over = host_counts[0].tolist()
-            as_float = host_counts[0].view(np.float32)
-            max_dev, audit_ratio = float(as_float[2]), float(as_float[6])
-            over = flagged > caps[0]
-            if col_over:        # buckets: one key column wanted more than its segment holds (rows aligned with a hyperplane): double them
-                over = True
-                per = max(64, int(self._bucket_cap_hint), int(1.5 * caps[0] / max(1, self.num_bands * self.band_bytes * 8)) + 64)
-                self._bucket_cap_hint = 2 * per
-                flagged = max(flagged, caps[0])
-        else:       # one block per chunk: sums and maxima; a chunk that outgrew ITS share of the list makes the pass incomplete
-            rows = host_counts.tolist()
-            as_float = host_counts.view(np.float32)
-            ties, flagged = sum(r[0] for r in rows), sum(r[1] for r in rows)
-            flips, audited, audit_bad = sum(r[3] for r in rows), sum(r[4] for r in rows), sum(r[5] for r in rows)
-            max_dev, audit_ratio = float(as_float[:, 2].max()), float(as_float[:, 6].max())
-            over = any(r[1] > c for r, c in zip(rows, caps))
-            if over:      # (the hint is a capacity for the WHOLE batch: scale the worst chunk's need up to it)
-                flagged = int(max(r[1] / c for r, c in zip(rows, caps)) * sum(caps)) + 1
-            stats["chunks"] = len(caps)
-            stats["chunk_flagged"] = [r[1] for r in rows]
-            stats["flagged_first_chunk"] = rows[0][1]      # (the head of the list is chunk 0's: what `_audit_replay` samples)
+        ties, flagged, _, flips, audited, audit_bad, _, col_over = host_counts[0].tolist()
+        as_float = host_counts[0].view(np.float32)
+        max_dev, audit_ratio = float(as_float[2]), float(as_float[6])
+        over = flagged > caps[0]
+        if col_over:        # buckets: one key column wanted more than its segment holds (rows aligned with a hyperplane): double them
+            over = True
+            per = max(64, int(self._bucket_cap_hint), int(1.5 * caps[0] / max(1, self.num_bands * self.band_bytes * 8)) + 64)
+            self._bucket_cap_hint = 2 * per
+            flagged = max(flagged, caps[0])
         if over:
             self._flag_cap_hint = int(flagged * 1.25) + 4096      # (rows flagged wholesale: NaN / Inf / extreme scales)
             stats["relaunches"] += 1
@@ -409,14 +296,7 @@ class _ReplayPaths:
             stats["margin_escalations"] = self.margin_escalations
             return False
         if ev is not None and self.kernel_events is not None:
-            if len(caps) == 1:
-                self.kernel_events.append((ev[0].elapsed_time(ev[1]), None, n, ev[2].elapsed_time(ev[3])))
-            else:     # stage 1 of the chunks runs back to back on one stream: the launch's stage-1 time is their sum
-                k = len(caps)
-                s1 = [ev[4 * c].elapsed_time(ev[4 * c + 1]) for c in range(k)]
-                s2 = [ev[4 * c + 2].elapsed_time(ev[4 * c + 3]) for c in range(k)]
-                self.kernel_events.append((sum(s1), None, n, sum(s2), s1, s2,
-                                           ev[0].elapsed_time(ev[4 * (k - 1) + 3])))
+            self.kernel_events.append((ev[0].elapsed_time(ev[1]), None, n, ev[2].elapsed_time(ev[3])))
         stats["tie_entries"] = ties
         stats["tie_pairs"] = ties          # (tied PROJECTIONS here: each decided by the replayed host order)
         stats["flagged"] = flagged         # projections inside the stage-1 window: every one decided by stage 2
@@ -463,6 +343,7 @@ class _ReplayPaths:
                     out = self._hash_device_locked(x, out, row_flags, "host", host_rows=None)
                     self.last_stats["audit_failures"] = self.audit_failures
                     return out
+        self.last_stats = stats         # (the lock was yielded during the wait: another thread's batch may have put its own here)
         return out
 
     def _audit_replay(self, x, out, stats, sample: int = 16) -> bool:
@@ -476,7 +357,7 @@ class _ReplayPaths:
         scratch = self._replay_scratch.get((dev.index, torch.cuda.current_stream(dev).cuda_stream))
         if scratch is None:
             return True
-        k = min(sample, int(stats.get("flagged_first_chunk", stats["flagged"])), int(scratch[0].shape[0]))
+        k = min(sample, int(stats["flagged"]), int(scratch[0].shape[0]))
         if k <= 0:
             return True
         # list entries, their rows of x and of the keys: gathered on the device, ONE copy to the host

@@ -351,14 +351,12 @@ struct FixArgs {
   const float* audit_vals;     // replayed like the flagged ones behind them, nothing patched - only compared
   int audit_n;
   int tail_model;         // how the host compiles the dim % 4 elements behind the last group of four (1 / 2): sig_fixany_kernel, sig_fix8_kernel<., GENERAL>
-  // the list sorted by padded column (lshrs_sig_sort, SAMEP instantiations): every group of eight entries has ONE column, runs
-  // padded to whole groups with -1; sorted_y: the entries' stage-1 values in that order; sorted_count: entries incl. padding
+  // the list BY KEY COLUMN (lshrs_sig_sort, SAMEP instantiations; BUCKETS, SigArgs::col_cap): every group of eight entries has
+  // ONE column; sorted_list / sorted_y are the columns' segments (entries, their stage-1 values), col_count the entries stage 1
+  // wanted per column (more than col_cap: the column overflowed - reported through *overflow, the pass is repeated with room),
+  // flag_thr the window of the audit entries (bit 62 of an entry)
   const int64_t* sorted_list;
   const float* sorted_y;
-  const int* sorted_count;
-  // ... or in BUCKETS (SigArgs::col_cap): sorted_list / sorted_y are the segments, col_count the entries stage 1 wanted per
-  // column (more than col_cap: the column overflowed - reported through *overflow, the pass is repeated with room),
-  // flag_thr the window of the audit entries (bit 62 of an entry)
   const int* col_count;
   int col_cap;
   const float* flag_thr;
@@ -458,14 +456,6 @@ inline bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
   const int64_t padcols = (int64_t)num_bands * ((rows + 7) / 8) * 8;
   return padcols <= (1 << 21);
 }
-
-// A chunk of lshrs_sig_hash_batch_split_replay_chunked_f32 whose stage 2 runs BESIDE the next chunk's stage 1: stage 2 and the
-// export are enqueued on `side` behind `ev_fork` (recorded on the pass's own stream behind stage 1), `ev_join` is recorded
-// behind them; the caller makes its stream wait for ev_join before it returns.
-struct SplitFork {
-  hipStream_t side;
-  hipEvent_t ev_fork, ev_join;
-};
 
 }  // namespace lshrs
 

@@ -68,10 +68,12 @@ static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridG <= LSHRS_SIG_DEVICE_COU
 // are fetched from its start and read as zero, and a vector of 8 m + 4 elements gives its first four to the low lanes
 // before the tiles begin AT the fifth (the library's order: lshrs_tb_model_row_dot).  The common shapes (16 x 16 x 768 ...)
 // keep the plain loop.
-// SAMEP (REPLAY only; round 5): the list comes SORTED BY COLUMN (fix_sort_* below), every group of eight entries shares one
-// hyperplane - its row is fetched ONCE per slab (one LDS-DMA of SLAB x 128 bytes by 8 SLAB lanes) and read by all eight entries
-// from the same LDS words, instead of eight times from L2: the x rows are then the only stream (72.6 against 98.7 us per 115 k
-// entries at 768-d, profiles/r03_stage2_streams.log).  The audit sample is not sorted: it keeps the plain instantiation.
+// SAMEP (REPLAY only; round 5): the list comes BY KEY COLUMN - stage 1 appended every flagged (and sampled) projection to its
+// column's segment (BUCKETS: lshrs_sig_sort) -, every group of eight entries shares one hyperplane: its row is fetched ONCE per
+// slab (one LDS-DMA of SLAB x 128 bytes by 8 SLAB lanes) and read by all eight entries from the same LDS words, instead of eight
+// times from L2 - the x rows are then the only stream (72.6 against 98.7 us per 115 k entries at 768-d,
+// profiles/r03_stage2_streams.log).  (Round 5 also had a counting sort of the plain list in front of this instantiation - three
+// more launches, slower than the buckets at every shape: gone in round 6.)
 template <bool REPLAY, bool GENERAL = false, int SLAB = kFixSlabG, bool SAMEP = false>
 __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
   static_assert(!SAMEP || (REPLAY && SLAB * 8 <= 64), "the shared hyperplane slab is one LDS-DMA of the wave");
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     if (blockIdx.x == 0 && __any(over) && lane == 0) *a.overflow = 1;
     __syncthreads();
   }
-  const int cnt = !SAMEP ? min(*a.flag_count, a.flag_cap) : (buckets ? gstart[kSortMaxCols] * kFixG : *a.sorted_count);
+  const int cnt = !SAMEP ? min(*a.flag_count, a.flag_cap) : gstart[kSortMaxCols] * kFixG;
   const int fgroups = (cnt + kFixG - 1) / kFixG;
   const int groups = fgroups + (!SAMEP && REPLAY && a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);   // audit groups behind the list's
   const size_t ldp = (size_t)a.ktiles * kKTile;
@@ -149,10 +151,6 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
       it.e = grp * kFixG + g;
       inlist = it.e < cnt;
       item = list[inlist ? it.e : grp * kFixG];
-      if (SAMEP && item < 0) {                       // padding behind a column's run: the group's first entry, fetched, never used
-        inlist = false;
-        item = list[grp * kFixG];
-      }
     } else {
       it.e = (grp - fgroups) * kFixG + g;
       item = it.e < a.audit_n ? a.audit_list[it.e] : -1;
@@ -389,78 +387,6 @@ __global__ __launch_bounds__(64) void sig_fix8_kernel(const FixArgs a) {
     }
   }
 }
-
-// ---- The stage-1 list sorted by padded column (round 5), for sig_fix8_kernel<.., SAMEP>: a counting sort in three launches.
-// kSortWgs workgroups take one contiguous slice of the list each; (1) per-workgroup histogram of the columns in LDS, stored
-// workgroup-major (every access of the three kernels coalesced over the columns); (2) one workgroup: every column's total rounded up to whole groups of eight, scanned over the columns, then
-// over the workgroups inside a column - the slot where each workgroup's entries of each column start - and -1 into the
-// padding behind every column's run; (3) the slices once more: every entry to its column's next slot (LDS cursors).
-constexpr int kSortWgs = 256, kSortThreads = 256;      // (kSortMaxCols: lshrs_common.h)
-
-__global__ __launch_bounds__(kSortThreads) void fix_sort_hist_kernel(const int64_t* __restrict__ list, const int* __restrict__ count,
-                                                                     int cap, int padcols, int* __restrict__ wg_hist) {
-  __shared__ int hist[kSortMaxCols];
-  for (int c = threadIdx.x; c < padcols; c += kSortThreads) hist[c] = 0;
-  __syncthreads();
-  const int cnt = min(*count, cap);
-  const int per = (cnt + kSortWgs - 1) / kSortWgs;
-  const int lo = blockIdx.x * per, hi = min(cnt, lo + per);
-  for (int e = lo + threadIdx.x; e < hi; e += kSortThreads) {
-    const int col = (int)(list[e] & ((1 << 21) - 1));
-    if (col < padcols) atomicAdd(&hist[col], 1);      // (a column out of range - an entry stage 2 skips - is dropped here)
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < padcols; c += kSortThreads) wg_hist[(size_t)blockIdx.x * padcols + c] = hist[c];
-}
-
-__global__ __launch_bounds__(kSortMaxCols) void fix_sort_scan_kernel(int* __restrict__ wg_hist, int padcols, int64_t* __restrict__ sorted,
-                                                                      int* __restrict__ sorted_count) {
-  __shared__ int tot[kSortMaxCols];
-  const int c = threadIdx.x;
-  int mine = 0;
-  if (c < padcols)
-    for (int w = 0; w < kSortWgs; ++w) mine += wg_hist[(size_t)w * padcols + c];
-  const int padded = (mine + kFixG - 1) / kFixG * kFixG;
-  tot[c] = c < padcols ? padded : 0;
-  __syncthreads();
-  for (int off = 1; off < kSortMaxCols; off <<= 1) {      // inclusive scan over the columns
-    const int v = c >= off ? tot[c - off] : 0;
-    __syncthreads();
-    tot[c] += v;
-    __syncthreads();
-  }
-  if (c < padcols) {
-    int at = tot[c] - padded;                             // where this column's run starts
-    for (int w = 0; w < kSortWgs; ++w) {
-      const int n = wg_hist[(size_t)w * padcols + c];
-      wg_hist[(size_t)w * padcols + c] = at;
-      at += n;
-    }
-    for (int e = at; e < tot[c]; ++e) sorted[e] = -1;     // at most seven
-  }
-  if (c == kSortMaxCols - 1) *sorted_count = tot[c];
-}
-
-__global__ __launch_bounds__(kSortThreads) void fix_sort_scatter_kernel(const int64_t* __restrict__ list, const float* __restrict__ y,
-                                                                        const int* __restrict__ count, int cap, int padcols,
-                                                                        const int* __restrict__ wg_hist, int64_t* __restrict__ sorted,
-                                                                        float* __restrict__ sorted_y) {
-  __shared__ int cursor[kSortMaxCols];
-  for (int c = threadIdx.x; c < padcols; c += kSortThreads) cursor[c] = wg_hist[(size_t)blockIdx.x * padcols + c];
-  __syncthreads();
-  const int cnt = min(*count, cap);
-  const int per = (cnt + kSortWgs - 1) / kSortWgs;
-  const int lo = blockIdx.x * per, hi = min(cnt, lo + per);
-  for (int e = lo + threadIdx.x; e < hi; e += kSortThreads) {
-    const int64_t item = list[e];
-    const int col = (int)(item & ((1 << 21) - 1));
-    if (col >= padcols) continue;
-    const int at = atomicAdd(&cursor[col], 1);
-    sorted[at] = item;
-    if (y != nullptr) sorted_y[at] = y[e];
-  }
-}
-
 
 // Tie entries of the f32 kernel, (row * 65536 + word, mask of up to 32 columns), unpacked into the stage-2 list format
 // (row << 21 | padded column), one item per flagged column: what sig_fix8_kernel<true> takes.
@@ -772,7 +698,7 @@ uint32_t lshrs_flags_replay(void) {
 // Stage 2 of a split pass behind its stage 1 (sig_split.hip: split_pass), on stream s: the flagged projections of f.flag_list,
 // one by one.  blas_model 0: the canonical f32 chain, ties reported in f.tie_list.  > 0: the host BLAS's order replayed, keys
 // patched, the audit sample verified, the statistics folded into `counters` and handed to `host_counts`; where the caller
-// gave the scratch (lshrs_sig_sort) and the rows are long, through the list sorted by column.
+// gave the scratch (lshrs_sig_sort) and the rows are long, column by column through the buckets stage 1 filled.
 int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_counts, const Opts& o, hipStream_t s) {
   const int blas_model = f.blas_model, rows_per_band = f.rows_per_band, dim = f.dim, flag_cap = f.flag_cap;
   const int64_t* flag_list = f.flag_list;
@@ -784,8 +710,6 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
   const dim3 grid((unsigned)(groups < grid_cap ? groups : grid_cap)), block(64);
   if (blas_model != 0) {
     int nparts = (int)grid.x;
-    const bool sorted = o.sort != nullptr && o.sort->mode == 0 && !short_rows && f.padcols <= kSortMaxCols &&
-                        (int64_t)o.sort->cap >= (int64_t)flag_cap + (int64_t)kFixG * f.padcols;
     if (short_rows) {
       if (blas_general(rows_per_band, f.ktiles, dim))
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
@@ -816,49 +740,6 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
       hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)bgrid.x,
                          o.sort->hist + (size_t)(1 - (o.sort->parity & 1)) * kSortMaxCols, kSortMaxCols);
       return -(int)hipGetLastError();
-    } else if (sorted) {
-      // the list by column first (three launches), then stage 2 with ONE hyperplane per group of eight; the audit sample -
-      // unsorted, a few thousand entries - through the plain instantiation behind it, its statistics in the slots behind
-      int* hist = o.sort->hist;
-      int* sorted_count = hist + (size_t)kSortWgs * f.padcols;
-      hipExtLaunchKernelGGL(fix_sort_hist_kernel, dim3(kSortWgs), dim3(kSortThreads), 0, s, o.ev[2], nullptr, 0, flag_list, flag_count,
-                            flag_cap, f.padcols, hist);
-      hipLaunchKernelGGL(fix_sort_scan_kernel, dim3(1), dim3(kSortMaxCols), 0, s, hist, f.padcols, o.sort->list, sorted_count);
-      hipLaunchKernelGGL(fix_sort_scatter_kernel, dim3(kSortWgs), dim3(kSortThreads), 0, s, flag_list, flag_y, flag_count, flag_cap,
-                         f.padcols, hist, o.sort->list, o.sort->y);
-      FixArgs fs = f;
-      fs.sorted_list = o.sort->list;
-      fs.sorted_y = flag_y != nullptr ? o.sort->y : nullptr;
-      fs.sorted_count = sorted_count;
-      fs.audit_list = nullptr;
-      fs.audit_n = 0;
-      const bool has_audit = f.audit_list != nullptr && f.audit_n > 0;
-      const int64_t sgroups = ((int64_t)flag_cap + kFixG - 1) / kFixG + f.padcols;
-#ifndef LSHRS_SORTED_GRID
-#define LSHRS_SORTED_GRID 2048      // eight single-wave workgroups per CU (14 KB of LDS each); 1528: +4 %, 2304 / 2560: the same, 2816: +33 % (A/B builds, config 5)
-#endif
-      constexpr int kSlots = (LSHRS_SIG_DEVICE_COUNTERS - LSHRS_SIG_COUNTERS) / kFixParts - 512;
-      constexpr int kSortedGrid = LSHRS_SORTED_GRID < kSlots ? LSHRS_SORTED_GRID : kSlots / 8 * 8;
-      const dim3 sgrid((unsigned)(sgroups < kSortedGrid ? sgroups : kSortedGrid));     // (512 statistics slots stay for the audit launch)
-      hipEvent_t stop = has_audit ? nullptr : o.ev[3];
-      if (blas_general(rows_per_band, f.ktiles, dim))
-        hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabG, true>), sgrid, block, 0, s, nullptr, stop, 0, fs);
-      else
-        hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kFixSlabG, true>), sgrid, block, 0, s, nullptr, stop, 0, fs);
-      nparts = (int)sgrid.x;
-      if (has_audit) {
-        FixArgs fa = f;
-        fa.flag_cap = 0;                    // (no list entries: only the audit groups)
-        fa.count_ties = 0;
-        fa.partials = f.partials + (size_t)kFixParts * sgrid.x;
-        const int agroups = (f.audit_n + kFixG - 1) / kFixG;
-        const dim3 agrid((unsigned)(agroups < 512 ? agroups : 512));
-        if (blas_general(rows_per_band, f.ktiles, dim))
-          hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), agrid, block, 0, s, nullptr, o.ev[3], 0, fa);
-        else
-          hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), agrid, block, 0, s, nullptr, o.ev[3], 0, fa);
-        nparts += (int)agrid.x;
-      }
     } else if (blas_general(rows_per_band, f.ktiles, dim))
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     else

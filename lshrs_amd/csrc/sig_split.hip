@@ -1,6 +1,6 @@
 // sig_split.hip - part of liblshrs_hip.so, the gfx950 (MI355X / CDNA4) implementation of the lshrs hot path.
 // The split-precision signature pass as the C ABI offers it: stage 1 (sig16.hip / sig16r.hip) + stage 2 (sig_replay.hip) on
-// one stream, with the tie replay, as a chunked pipeline; the library's version and build flags.
+// one stream, with the tie replay; the library's version and build flags.
 // One translation unit per kernel family (round 5): what is shared lives in lshrs_common.h, measurement switches (-DLSHRS_AB_*,
 // tools/ab_build.py) are local to the unit whose kernel they alter and reported through lshrs_build_flags().
 // ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md.
@@ -25,8 +25,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
                       int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
                       int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, float* flag_y,
                       int32_t flag_cap, int32_t* flag_count, float tau1, int blas_model, int32_t* counters,
-                      int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream,
-                      const SplitFork* fork = nullptr) {
+                      int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts, void* stream) {
   if (n == 0) return 0;
   if (X == nullptr || workspace == nullptr || keys == nullptr || n < 0 || ldx < dim || flag_list == nullptr ||
       flag_count == nullptr || flag_cap <= 0 || !sig_shape_ok(num_bands, rows_per_band, dim))
@@ -186,13 +185,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     const int rc = lshrs_launch_sig16(a, (unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), cp.on, dim % kKTile != 0, s, o.ev[0], o.ev[1]);
     if (rc != 0) return rc;
   }
-  // stage 2: the flagged projections, one by one (a forked chunk: on the side stream, behind stage 1's event)
-  if (fork != nullptr) {
-    hipError_t e = hipEventRecord(fork->ev_fork, s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(fork->side, fork->ev_fork, 0);
-    if (e != hipSuccess) return -(int)e;
-    s = fork->side;
-  }
+  // stage 2: the flagged projections, one by one
   FixArgs f{};
   f.X = X;
   f.ldx = ldx;
@@ -234,10 +227,6 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   }
   const int rc2 = lshrs_replay_stage2(f, counters, host_counts, o, s);
   if (rc2 != 0) return rc2;
-  if (fork != nullptr) {
-    const hipError_t e = hipEventRecord(fork->ev_join, s);
-    if (e != hipSuccess) return -(int)e;
-  }
   return -(int)hipGetLastError();
 }
 
@@ -250,12 +239,12 @@ int lshrs_sig_hash_batch_split_f32(const float* X, int64_t n, int64_t ldx, const
                     row_flags, flag_list, nullptr, flag_cap, flag_count, tau1, 0, nullptr, nullptr, nullptr, opts, stream);
 }
 
-static int lshrs_sig_hash_batch_split_replay_f32_impl(const float* X, int64_t n, int64_t ldx, const void* workspace,
-                                                      int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
-                                                      int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
-                                                      float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
-                                                      int32_t* host_counts, const lshrs_sig_audit* audit,
-                                                      const lshrs_sig_opts* opts, void* stream, const SplitFork* fork) {
+int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
+                                          int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
+                                          int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
+                                          float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
+                                          int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
+                                          void* stream) {
   const bool resident = sig_resident(num_bands, rows_per_band, dim).on;
   // dim % 4 elements of scalar tail: modelled from 9 elements up, model 1 / 2 = how the build compiles them (sig_fixany_kernel);
   // whole groups of four: both builds sum alike, model 1
@@ -264,103 +253,7 @@ static int lshrs_sig_hash_batch_split_replay_f32_impl(const float* X, int64_t n,
   const int body = dim & ~3;
   if ((dim < 32 && !resident) || (body % 8 != 0 && body > 4096) || counters == nullptr) return LSHRS_E_BADARG;
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,
-                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, audit, opts, stream, fork);
-}
-
-int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
-                                          int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
-                                          int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
-                                          float* flag_y, int32_t flag_cap, float tau1, int32_t blas_model,
-                                          int32_t* host_counts, const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
-                                          void* stream) {
-  return lshrs_sig_hash_batch_split_replay_f32_impl(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, counters, tau,
-                                                    row_flags, flag_list, flag_y, flag_cap, tau1, blas_model, host_counts, audit,
-                                                    opts, stream, nullptr);
-}
-
-int lshrs_sig_hash_batch_split_replay_chunked_f32(const float* X, int64_t n, int64_t ldx, const void* workspace,
-                                                  int32_t num_bands, int32_t rows_per_band, int32_t dim, uint8_t* keys,
-                                                  int32_t* counters, float tau, uint8_t* row_flags, int64_t* flag_list,
-                                                  float* flag_y, float tau1, int32_t blas_model, int32_t* host_counts,
-                                                  const lshrs_sig_audit* audit, const lshrs_sig_opts* opts,
-                                                  const lshrs_sig_chunk_plan* plan, void* stream) {
-  if (plan == nullptr || plan->struct_bytes < sizeof(lshrs_sig_chunk_plan) || plan->nchunks < 1 ||
-      plan->nchunks > LSHRS_SIG_MAX_CHUNKS || counters == nullptr || host_counts == nullptr)
-    return LSHRS_E_BADARG;
-  const int nc = plan->nchunks;
-  int64_t total = 0;
-  for (int c = 0; c < nc; ++c) {
-    if (plan->rows[c] <= 0 || plan->flag_cap[c] <= 0) return LSHRS_E_BADARG;
-    if (c + 1 < nc && (plan->side_stream[c] == nullptr || plan->ev_fork[c] == nullptr || plan->ev_join[c] == nullptr ||
-                       plan->side_stream[c] == stream))
-      return LSHRS_E_BADARG;
-    total += plan->rows[c];
-  }
-  if (total != n) return LSHRS_E_BADARG;
-  const SigGeom g = sig_geom(num_bands, rows_per_band, dim);
-  const int64_t row_bytes = (int64_t)num_bands * g.bb;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  int64_t lo = 0, list_off = 0;
-  int32_t slot_off = 0;
-  const bool audit_on = audit != nullptr && audit->struct_bytes >= sizeof(lshrs_sig_audit) && audit->list != nullptr &&
-                        audit->vals != nullptr && audit->slots > 0 && audit->target > 0;
-  for (int c = 0; c < nc; ++c) {
-    const int64_t rows = plan->rows[c];
-    // the audit sample and its slots: every chunk its share by rows (the last one what is left)
-    lshrs_sig_audit au{};
-    if (audit_on) {
-      au = *audit;
-      const int32_t slots = c + 1 < nc ? (int32_t)((int64_t)audit->slots * rows / n) : audit->slots - slot_off;
-      int32_t target = (int32_t)((int64_t)audit->target * rows / n);
-      if (target < 1) target = 1;
-      au.list = audit->list + slot_off;
-      au.vals = audit->vals + 2 * (int64_t)slot_off;
-      au.slots = slots;
-      au.target = target < slots ? target : slots;
-      au.seed = audit->seed + 0x9E3779B9u * (uint32_t)c;
-      slot_off += slots;
-    }
-    // the measurement hooks: one quadruple of events per chunk, handed over back to back behind the struct's own
-    lshrs_sig_opts op{};
-    const lshrs_sig_opts* opp = nullptr;
-    if (opts != nullptr && opts->struct_bytes >= sizeof(lshrs_sig_opts)) {
-      op = *opts;
-      if (plan->ev_timing != nullptr) {
-        op.ev_stage1_start = plan->ev_timing[4 * c + 0];
-        op.ev_stage1_stop = plan->ev_timing[4 * c + 1];
-        op.ev_stage2_start = plan->ev_timing[4 * c + 2];
-        op.ev_stage2_stop = plan->ev_timing[4 * c + 3];
-      }
-      if (c != 0) op.clock_probe = nullptr;
-      if (nc > 1) op.sort = nullptr;       // (ONE column scratch: chunks of a pass overlap, they cannot share it)
-      opp = &op;
-    }
-    SplitFork fk{};
-    const bool forked = c + 1 < nc;
-    if (forked) {
-      fk.side = static_cast<hipStream_t>(plan->side_stream[c]);
-      fk.ev_fork = static_cast<hipEvent_t>(plan->ev_fork[c]);
-      fk.ev_join = static_cast<hipEvent_t>(plan->ev_join[c]);
-    }
-    int32_t* cnt = counters + (int64_t)c * LSHRS_SIG_DEVICE_COUNTERS;
-    const int rc = lshrs_sig_hash_batch_split_replay_f32_impl(
-        X + lo * ldx, rows, ldx, workspace, num_bands, rows_per_band, dim, keys + lo * row_bytes, cnt, tau,
-        row_flags != nullptr ? row_flags + lo : nullptr, flag_list + list_off, flag_y != nullptr ? flag_y + list_off : nullptr,
-        plan->flag_cap[c], tau1, blas_model, host_counts + (int64_t)c * LSHRS_SIG_COUNTERS, audit_on ? &au : nullptr, opp, stream,
-        forked ? &fk : nullptr);
-    if (rc != 0) {
-      // (chunks already enqueued run to their end: the caller's stream must still see them finish before buffers go away)
-      for (int d = 0; d < c && d + 1 < nc; ++d) (void)hipStreamWaitEvent(s, static_cast<hipEvent_t>(plan->ev_join[d]), 0);
-      return rc;
-    }
-    lo += rows;
-    list_off += plan->flag_cap[c];
-  }
-  for (int c = 0; c + 1 < nc; ++c) {
-    const hipError_t e = hipStreamWaitEvent(s, static_cast<hipEvent_t>(plan->ev_join[c]), 0);
-    if (e != hipSuccess) return -(int)e;
-  }
-  return 0;
+                    flag_list, flag_y, flag_cap, counters + 1, tau1, blas_model, counters, host_counts, audit, opts, stream);
 }
 
 }  // extern "C"

@@ -251,24 +251,14 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             raise ValueError("tie_replay must be 'auto' or 'off'")
         self.tie_replay = tie_replay
         self._replay_model_cache: Optional[tuple] = None
-        # One synchronous pass as a short pipeline (ABI 6, `lshrs_sig_hash_batch_split_replay_chunked_f32`): batches of at
-        # least `chunk_min_rounds` full-chip rounds of stage-1 workgroups are cut into row chunks at whole rounds; stage 2 of
-        # every chunk but the last runs on a side stream beside the next chunk's stage 1.  "off" (default): one launch of
-        # each stage; "on": the plan of `_chunk_rows`; a sequence of row counts: that plan.  Same keys in every mode.
-        # Off by default because it does not pay (profiles/r05_chunk_overlap.log): a stage-1 workgroup fills its CU
-        # (149.5 of 160 KB of LDS, 496 of 512 vector registers per SIMD), so stage 2 beside it only ever takes whole CUs
-        # away - the work is conserved, the stage-1 launches end one chunk boundary later each: 1 M x 768 -1 .. -4 %,
-        # 5 M x 1536 -1 .. -2 % on every plan tried.
-        self.chunking = "off"
         # Stage 2 column by column (ABI 6, lshrs_sig_sort): every eight entries stage 2 takes share one hyperplane, fetched once -
         # the row gather of x is the only stream left.  "auto" = "buckets" for every hasher the split pass's main kernel serves
         # (up to 1024 padded key columns, rows longer than four k-tiles): stage 1 itself appends flagged and sampled projections
         # to the segment of their key column, no launch between the stages (config 2: stage 2 0.107 -> 0.084 ms; config 5: 3.36 ->
-        # 2.37 ms).  "sort": the stage-1 list counting-sorted on the device instead (three launches: pays at dim >= 1024 only);
-        # False: the plain stage 2.  Same keys every way.
+        # 2.37 ms).  False: the plain stage 2.  Same keys every way.  (Round 5's two other experiments - a device counting sort of
+        # the plain list, and the pass cut into chunks whose stage 2 ran beside the next chunk's stage 1 - were slower than this
+        # on every shape and plan measured (profiles/r05_chunk_overlap.log) and were removed in round 6.)
         self.stage2_sorted = "auto"
-        self.chunk_min_rounds = 6
-        self._chunk_res: Dict[tuple, dict] = {}
         self._sort_res: Dict[tuple, tuple] = {}
         self._bucket_cap_hint = 0
         self._pipes: Dict[tuple, int] = {}
@@ -393,11 +383,13 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             self.tau_ulps = float(info["tie_units"])
 
     # ------------------------------------------------------------------ core: device -> device
-    def hash_device(self, x, *, out=None, row_flags=None, tie_break: Optional[str] = None):
+    def hash_device(self, x, *, out=None, row_flags=None, tie_break: Optional[str] = None, stats: Optional[dict] = None):
         """Hash a device-resident ``(n, dim)`` float32 ``torch.Tensor``.
 
         Returns a ``(n, num_bands, band_bytes)`` uint8 tensor on the same device.  ``row_flags``
-        (optional uint8 tensor of n) receives bit0 = zero vector, bit1 = NaN present.
+        (optional uint8 tensor of n) receives bit0 = zero vector, bit1 = NaN present.  ``stats`` (optional dict) receives THIS
+        call's statistics - ``last_stats`` is the hasher's last batch, which under concurrent callers may be another thread's
+        (``hash_device_async(...).stats`` for the streaming form).
         """
         torch = _native.require_gpu()
         if x.dim() != 2 or x.shape[1] != self.dim:
@@ -408,7 +400,10 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             x = x.contiguous()
         mode = self.tie_break if tie_break is None else tie_break
         with self._lock:
-            return self._hash_device_locked(x, out, row_flags, mode, host_rows=None, yield_lock=True)
+            keys = self._hash_device_locked(x, out, row_flags, mode, host_rows=None, yield_lock=True)
+            if stats is not None:
+                stats.update(self.last_stats)
+            return keys
 
     def _hash_device_locked(self, x, out, row_flags, mode, host_rows, allow_pipeline: bool = True, yield_lock: bool = False):
         torch = _native.require_gpu()
@@ -791,7 +786,6 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         state["_pipes"] = {}
         state["_plan_cache"] = {}
         state["_replay_scratch"] = {}
-        state["_chunk_res"] = {}
         state["_sort_res"] = {}
         state["_async_pending"] = []
         state["_replay_events"] = {}
@@ -808,12 +802,13 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self.__dict__.setdefault("_pipes", {})
         self.__dict__.setdefault("_plan_cache", {})
         self.__dict__.setdefault("_replay_scratch", {})
-        self.__dict__.setdefault("_chunk_res", {})
         self.__dict__.setdefault("_sort_res", {})
         self.__dict__.setdefault("stage2_sorted", "auto")
         self.__dict__.setdefault("_bucket_cap_hint", 0)
-        self.__dict__.setdefault("chunking", "off")
-        self.__dict__.setdefault("chunk_min_rounds", 6)
+        for gone in ("chunking", "chunk_min_rounds", "_chunk_res"):      # (options of round 5 a pickled hasher may still carry)
+            self.__dict__.pop(gone, None)
+        if self.__dict__.get("stage2_sorted") in ("sort", True):
+            self.stage2_sorted = "auto"
         self.__dict__.setdefault("_async_pending", [])
         self.__dict__.setdefault("_replay_events", {})
         self.__dict__.setdefault("_replay_model_cache", None)

@@ -54,55 +54,51 @@ def test_loader_refuses_a_build_whose_keys_are_wrong_by_design(tmp_path):
     assert out.startswith("LOADED") and int(out.split()[1]) == 2 | (1 << 16), out
 
 
-def test_chunk_plan_struct_is_the_headers():
+def test_struct_layouts_are_the_headers():
+    """The compiler's layout of the header's structs == what the binding builds: `lshrs_sig_sort` (ctypes), and
+    `lshrs_bucket_segment` (ABI 7) - uploaded as rows of four int64 by `lshrs_amd/_query_device.py`."""
     from lshrs_amd import _native
 
-    text = open(HEADER).read()
-    fields = re.search(r"typedef struct lshrs_sig_chunk_plan \{(.*?)\} lshrs_sig_chunk_plan;", text, flags=re.S).group(1)
-    names = re.findall(r"(\w+)(?:\[\w+\])?;", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
-    assert names == [f[0] for f in _native.SigChunkPlan._fields_]
-    assert int(re.search(r"#define\s+LSHRS_SIG_MAX_CHUNKS\s+(\d+)", text).group(1)) == _native.SIG_MAX_CHUNKS == 8
-    # the compiler's layout of the header's struct == ctypes' layout of the binding's
-    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "lshrs_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '
-           "sizeof(lshrs_sig_chunk_plan), offsetof(lshrs_sig_chunk_plan, rows), offsetof(lshrs_sig_chunk_plan, flag_cap), "
-           "offsetof(lshrs_sig_chunk_plan, side_stream), offsetof(lshrs_sig_chunk_plan, ev_join), "
-           "offsetof(lshrs_sig_chunk_plan, ev_timing)); return 0; }\n")
-    exe = os.path.join(ROOT, "oracle", "_build", "chunk_plan_layout")
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "lshrs_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+           "sizeof(lshrs_bucket_segment), offsetof(lshrs_bucket_segment, codes), offsetof(lshrs_bucket_segment, offsets), "
+           "offsetof(lshrs_bucket_segment, members), offsetof(lshrs_bucket_segment, n_codes), sizeof(lshrs_sig_sort), "
+           "offsetof(lshrs_sig_sort, hist), offsetof(lshrs_sig_sort, thr), offsetof(lshrs_sig_sort, parity)); return 0; }\n")
+    exe = os.path.join(ROOT, "oracle", "_build", "struct_layout")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-x", "c", "-", "-I" + os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, check=True)
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
-    P = _native.SigChunkPlan
-    assert got == [ctypes.sizeof(P), P.rows.offset, P.flag_cap.offset, P.side_stream.offset, P.ev_join.offset, P.ev_timing.offset]
+    S = _native.SigSort
+    assert got == [32, 0, 8, 16, 24, ctypes.sizeof(S), S.hist.offset, S.thr.offset, S.parity.offset]
+    text = open(HEADER).read()
+    assert int(re.search(r"#define\s+LSHRS_QUERY_MAX_PAIRS\s+(\d+)", text).group(1)) == _native.QUERY_MAX_PAIRS
+    assert "lshrs_sig_chunk_plan" not in text and "chunked_f32" not in text          # (round 6: the chunked pass is gone)
 
 
-def test_chunk_rows_plan():
-    """`LSHHasher._chunk_rows`: off by default; 'on' cuts at whole rounds of stage-1 workgroups, the last chunk = the ragged
-    end + one round; an explicit plan must add up."""
+def test_round5_experiments_are_gone_and_old_pickles_still_load():
+    """no `chunking`, no `stage2_sorted="sort"`; a hasher pickled by round 5 (which carried them) loads."""
+    import pickle
+
     from lshrs_amd import LSHHasher
 
     h = LSHHasher(16, 16, 768, seed=42)
-    assert h.chunking == "off" and h._chunk_rows(1_000_000) is None
-    h.chunking = "on"
-    assert h._chunk_rows(300_000) is None                      # fewer than chunk_min_rounds rounds: one launch
-    plan = h._chunk_rows(1_000_000)
-    assert plan == [524_288, 393_216, 82_496] and sum(plan) == 1_000_000
-    assert all(r % 65_536 == 0 for r in plan[:-1])
-    h5 = LSHHasher(16, 32, 1536, seed=7)                       # two column blocks: a round is 32 768 rows
-    h5.chunking = "on"
-    plan = h5._chunk_rows(5_000_000)
-    assert sum(plan) == 5_000_000 and all(r % 32_768 == 0 for r in plan[:-1]) and 32_768 <= plan[-1] < 2 * 32_768
-    hs = LSHHasher(16, 4, 128, seed=1)                         # short vectors (resident-image kernel): never chunked
-    hs.chunking = "on"
-    assert hs._chunk_rows(4_000_000) is None
-    h.chunking = [600_000, 400_000]
-    assert h._chunk_rows(1_000_000) == [600_000, 400_000]
-    assert h._chunk_rows(900_000) is None                      # a plan that does not add up is not used
-    h.chunking = "sometimes"
-    with pytest.raises(ValueError):
-        h._chunk_rows(1_000_000)
-    # argument validation of the entry point happens before anything touches a device
+    assert not hasattr(h, "chunking") and not hasattr(h, "_chunk_rows") and h.stage2_sorted == "auto" and h._stage2_mode() == 1
+    h.stage2_sorted = "sort"
+    with pytest.raises(ValueError, match="stage2_sorted"):
+        h._stage2_mode()
+    h.stage2_sorted = False
+    assert h._stage2_mode() is None
+    state = LSHHasher(4, 4, 32).__getstate__()
+    state.update(chunking="on", chunk_min_rounds=6, _chunk_res={}, stage2_sorted="sort")
+    old = LSHHasher.__new__(LSHHasher)
+    old.__setstate__(pickle.loads(pickle.dumps(state)))
+    assert not hasattr(old, "chunking") and old.stage2_sorted == "auto"
+    # argument validation of the query entry points happens before anything touches a device
     from lshrs_amd import _native
 
     lib = _native.load()
-    assert lib.lshrs_sig_hash_batch_split_replay_chunked_f32(None, 5, 32, None, 1, 1, 32, None, None, 0.0, None, None, None, 0.0,
-                                                             1, None, None, None, None, None) == -10001
+    assert lib.lshrs_query_lookup_u8(None, 5, 16, 2, None, 0, None, None, None, None, None) == -10001
+    assert lib.lshrs_query_lookup_u8(None, 0, 16, 2, None, 0, None, None, None, None, None) == 0
+    assert lib.lshrs_query_scan_i32(None, 5, -1, -1.0, None, None, None, None) == -10001
+    assert lib.lshrs_query_collide_pairs_i64(None, None, None, 3, 5, 16, None, None, None, None) == -10001
+    assert lib.lshrs_query_rank_f32(None, None, None, None, None, None, 3, 5, None, None, None) == -10001
+    assert lib.lshrs_cosine_ragged_f32(None, 10, 8, 8, None, 3, None, None, None, 7, None, None, None) == -10001

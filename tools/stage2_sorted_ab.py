@@ -22,7 +22,7 @@ for name, n, dim, nb, r, seed, steps in (("c5", 5_000_000, 1536, 16, 32, 7, 10),
     h.stage2_sorted = False
     ref = h.hash_device(x).clone()
     out = torch.empty_like(ref)
-    for mode in (False, "sort", "buckets", False, "sort", "buckets"):
+    for mode in (False, "buckets", False, "buckets"):
         h.stage2_sorted = mode
         for _ in range(steps // 3 + 2):
             h.hash_device(x, out=out)
