@@ -366,7 +366,9 @@ int lshrs_keys_to_hex_u8(const uint8_t* keys, int64_t nbytes, uint8_t* hex, void
  * instead of a copy engine (ABI 6).  For the small results of a streamed ingest - the bucket arrays of one chunk - which
  * travel back while the NEXT chunk's vectors are on their way in: on this platform a device->host memcpy issued then
  * waits, every third time, until that 400 MB host->device copy has finished (the engines are shared out round-robin:
- * profiles/r05_ingest_pipeline.log), a kernel's stores do not.  dst_host not page-locked: the runtime's error, negated. */
+ * profiles/r05_ingest_pipeline.log), a kernel's stores do not.  Any addresses and lengths: 16 bytes per lane wherever src and
+ * dst_host sit alike modulo 16 (the bytes in front of the first boundary and behind the last one by one), single bytes shared
+ * out over the whole grid where they do not.  dst_host not page-locked: the runtime's error, negated. */
 int lshrs_copy_to_host_u8(const void* src, void* dst_host, int64_t nbytes, void* stream);
 
 /* Storage-op path, grouping: what the reference does one `(band, key, id)` tuple and one SADD at a time

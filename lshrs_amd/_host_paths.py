@@ -43,7 +43,10 @@ class _HostPaths:
         every finished chunk's keys (and row flags, or None) ON THE DEVICE (rows ``lo:hi`` of the batch, final and verified;
         the current stream is one it may enqueue work on, and the tensors stay valid for work enqueued there) - ``LSHRS.index``
         groups them into buckets on the device under the next chunk's copy.  The return value is then ``(None, row_flags)``
-        / ``None``."""
+        / ``None``.  The sink runs WITHOUT the hasher's lock (round 6: it may wait for other work, write to a remote store, call
+        back into the hasher - queries go on meanwhile; what it holds is the streaming lock: one streamed batch per hasher at a
+        time, their staging buffers are shared); a sink that returns ``False`` ends the stream - the chunks in flight are
+        finished and discarded, nothing more is copied or hashed."""
         torch = _native.require_gpu()
         arr = np.asarray(vectors, dtype=np.float32)
         if arr.ndim != 2:
@@ -62,31 +65,38 @@ class _HostPaths:
         with self._lock:
             streamed = (n >= 2 * 16_384 and mode == "host" and self.tie_replay == "auto"
                         and self._split_applies(16_384, replay=True) and self._replay_model() in (1, 2))
-            if streamed:
+        if streamed:
+            # one streamed batch per hasher at a time (the staging buffers are shared); the hasher's own lock is only taken
+            # around each chunk's launch and verification - not around copies, waits or the sink
+            with self._stream_lock:
                 return self._hash_host_streamed(arr, return_row_flags, max(16_384, int(chunk_rows)), dev, pin, device_sink)
-            if 0 < n <= self._small_rows and mode == "host" and device_sink is None:
+        if 0 < n <= self._small_rows and mode == "host" and device_sink is None:
+            with self._lock:
                 got = self._hash_small_locked(arr, dev)
-                if got is not None:
-                    return got if return_row_flags else got[0]
-            keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8) if device_sink is None else None
-            flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
-            total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
-            for lo in range(0, n, 262_144):
-                hi = min(n, lo + 262_144)
-                chunk = arr[lo:hi]
-                x = torch.from_numpy(chunk).to(dev)
-                fl = torch.empty(hi - lo, dtype=torch.uint8, device=dev) if return_row_flags else None
+            if got is not None:
+                return got if return_row_flags else got[0]
+        keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8) if device_sink is None else None
+        flags = np.empty(n, dtype=np.uint8) if return_row_flags else None
+        total = {"n": n, "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
+        for lo in range(0, n, 262_144):
+            hi = min(n, lo + 262_144)
+            chunk = arr[lo:hi]
+            x = torch.from_numpy(chunk).to(dev)
+            fl = torch.empty(hi - lo, dtype=torch.uint8, device=dev) if return_row_flags else None
+            with self._lock:
                 out = self._hash_device_locked(x, None, fl, mode, host_rows=lambda r, c=chunk: c[r])
-                if device_sink is not None:
-                    with torch.cuda.device(dev):
-                        device_sink(lo, hi, out, fl)
-                else:
-                    keys[lo:hi] = out.cpu().numpy()
-                if fl is not None:
-                    flags[lo:hi] = fl.cpu().numpy()
                 for k in ("tie_entries", "tie_pairs", "relaunches"):
                     total[k] += self.last_stats.get(k, 0)
-        self.last_stats = total
+            if device_sink is not None:                  # (outside the lock: the keys are a tensor of this call's own)
+                with torch.cuda.device(dev):
+                    if device_sink(lo, hi, out, fl) is False:
+                        break
+            else:
+                keys[lo:hi] = out.cpu().numpy()
+            if fl is not None:
+                flags[lo:hi] = fl.cpu().numpy()
+        with self._lock:
+            self.last_stats = total
         return (keys, flags) if return_row_flags else keys
 
     def device_hashers(self) -> list:
@@ -294,9 +304,11 @@ class _HostPaths:
             if flags is not None:
                 flags[lo:hi] = buf["fh"][b][:hi - lo].numpy()
 
+        aborted = [False]          # the sink has said it wants no more (a bad row ends the unit: lshrs_amd/_ingest.py)
+
         def send_back(item):
             handle, (lo, hi), b = item
-            with torch.cuda.stream(comp_s):         # verify (repeats the chunk with room / with a wider window if it must)
+            with self._lock, torch.cuda.stream(comp_s):      # verify (repeats the chunk with room / with a wider window if it must)
                 st = handle._finish_locked() or {}
             while len(landed) > 1:                   # (the pinned key buffer b is about to be overwritten: empty it first)
                 land(landed.pop(0))
@@ -312,7 +324,8 @@ class _HostPaths:
             #  that finishes its work at once would wait a whole chunk's copy for keys that are there)
             with torch.cuda.stream(back_s):
                 if device_sink is not None:       # the keys (and flags) stay on the device: the caller's work on them rides on this stream
-                    device_sink(lo, hi, buf["k"][b][:hi - lo], buf["f"][b][:hi - lo] if want_flags else None)
+                    if not aborted[0] and device_sink(lo, hi, buf["k"][b][:hi - lo], buf["f"][b][:hi - lo] if want_flags else None) is False:
+                        aborted[0] = True
                 else:
                     buf["kh"][b][:hi - lo].copy_(buf["k"][b][:hi - lo], non_blocking=True)
                 if flags is not None:
@@ -334,12 +347,14 @@ class _HostPaths:
                 comp_s.wait_event(h2d)
                 if k_free[b] is not None:
                     comp_s.wait_event(k_free[b])       # (the keys this pass overwrites have left the device)
-                with torch.cuda.stream(comp_s):
+                with self._lock, torch.cuda.stream(comp_s):
                     handle = self._hash_device_async_locked(buf["x"][b][:hi - lo], buf["k"][b][:hi - lo],
                                                             buf["f"][b][:hi - lo] if want_flags else None)
                 hashed.append((handle, (lo, hi), b))
                 if len(hashed) > 1:
                     send_back(hashed.pop(0))
+                if aborted[0]:                 # (what is in flight is still verified below - its counter blocks go back - and dropped)
+                    break
             while hashed:
                 send_back(hashed.pop(0))
             while landed:
@@ -351,7 +366,10 @@ class _HostPaths:
                 torch.cuda.cudart().cudaHostUnregister(arr.ctypes.data)
         total["tie_break_engine"] = "device-replay"
         total["margin_escalations"] = self.margin_escalations
-        self.last_stats = total
+        if aborted[0]:
+            total["aborted_by_sink"] = True
+        with self._lock:
+            self.last_stats = total
         return (keys, flags) if want_flags else keys
 
     def hash_one_packed(self, vec: np.ndarray):

@@ -78,16 +78,28 @@ class CsrIngest:
         return self
 
     def __exit__(self, exc_type, exc, tb) -> None:
+        self.close()
+
+    def close(self, wait: bool = True) -> None:
+        """Wait for everything submitted and raise the first failure in row order.  (An exception of the CALLER's - its loader
+        raised - does not undo what it had already handed over: those units are stored, as the reference's sequential loop would
+        have stored them.)  ``wait=False`` - the caller is being interrupted: units not yet started are dropped, the ones in
+        flight are given ``interrupt_grace`` seconds, nothing is raised from here."""
         try:
-            # (an exception of the CALLER's - its loader raised - does not undo what it had already handed over: those units
-            #  are stored, as the reference's sequential loop would have stored them, then the exception goes on; a bad row
-            #  in one of them comes first in row order and is what is raised)
-            self._wait_all()
-            if self._failed is not None:
-                raise self._failed
+            if wait:
+                self._wait_all()
+                if self._failed is not None:
+                    raise self._failed
+            else:
+                self._fail(KeyboardInterrupt())            # (lanes stop at their next chunk; queued units return at once)
+                for f in self._futures:
+                    f.cancel()
+                self._last_done.wait(self.interrupt_grace)
         finally:
             for pool in self._hash_pools:
-                pool.shutdown(wait=True)
+                pool.shutdown(wait=wait, cancel_futures=not wait)
+
+    interrupt_grace = 5.0
 
     @property
     def failed(self) -> bool:
@@ -167,6 +179,10 @@ class CsrIngest:
             job = _ChunkJob(ids[lo:hi], keys_dev, flags_dev, ids_dev[lo:hi])
             self.chunks += 1
             commit(job, lo, hi)
+            # (the hasher calls this WITHOUT its lock - queries go on while a chunk is finished, waits for its turn and is
+            #  stored.)  A unit that is known to end inside or in front of this chunk - a zero vector, a storage failure, another
+            #  lane's failure - needs nothing behind it: False ends the stream instead of copying and hashing rows nobody stores
+            return not (state["stop"] < hi or self._failed is not None)
 
         try:
             if limit > 0 and self._failed is None:

@@ -36,6 +36,9 @@ class _PendingKeys:
     def __init__(self, hasher: "LSHHasher", x, out, row_flags, state) -> None:
         self._hasher, self._x, self._out, self._row_flags, self._state = hasher, x, out, row_flags, state
         self._stats = dict(hasher.last_stats) if state is None else None     # (a handle that was complete on creation)
+        # the stream the launch was enqueued on: whoever verifies this handle - it may be another thread that needs a counter
+        # block - repeats it THERE if it must be repeated (the buffers are ordered against that stream, not the verifier's)
+        self._stream = _native.require_gpu().cuda.current_stream(x.device) if state is not None else None
 
     def done(self) -> bool:
         return self._state is None or bool(self._state[0].query())
@@ -51,7 +54,8 @@ class _PendingKeys:
             return self._stats
         stats = {"n": int(self._x.shape[0]), "tie_entries": 0, "tie_pairs": 0, "relaunches": 0}
         if not h._replay_finish(state, stats):        # the stage-1 list was too small: once more, synchronously, with room
-            h._hash_device_locked(self._x, self._out, self._row_flags, "host", host_rows=None)
+            with _native.require_gpu().cuda.stream(self._stream):
+                h._hash_device_locked(self._x, self._out, self._row_flags, "host", host_rows=None)
             stats["relaunches"] += h.last_stats.get("relaunches", 0)
             for k in ("tie_entries", "tie_pairs", "tie_break_engine"):
                 if k in h.last_stats:

@@ -34,14 +34,19 @@ __global__ void gather_tied_rows_kernel(const float* __restrict__ X, int64_t ldx
 // Lower-case hex of every key byte (what `bytes.hex()` gives; the text of the reference's bucket keys,
 // lshrs/storage/redis.py:225), 16 input bytes -> 32 output characters per thread.
 // Device memory -> page-locked host memory by the CUs instead of a copy engine (lshrs_copy_to_host_u8): 16 bytes per lane,
-// grid-stride, the last nbytes % 16 bytes one by one.
-__global__ __launch_bounds__(256) void copy_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
-                                                            const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail) {
+// grid-stride.  `head` bytes in front of the first 16-byte boundary and the `tail` bytes behind the last whole 16 go one by
+// one (both < 16 when source and destination sit alike modulo 16; the caller passes everything as `tail` when they do not -
+// then every workgroup takes its share of the bytes).
+__global__ __launch_bounds__(256) void copy_to_host_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int head,
+                                                            int64_t n16, int64_t tail) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
-  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
-  if (blockIdx.x == 0 && tail > 256)
-    for (int i = 256 + threadIdx.x; i < tail; i += 256) dst_tail[i] = src_tail[i];
+  const int64_t me = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint4* __restrict__ s16 = reinterpret_cast<const uint4*>(src + head);
+  uint4* __restrict__ d16 = reinterpret_cast<uint4*>(dst + head);
+  for (int64_t i = me; i < n16; i += stride) d16[i] = s16[i];
+  if (me < head) dst[me] = src[me];
+  const int64_t t0 = head + 16 * n16;
+  for (int64_t i = me; i < tail; i += stride) dst[t0 + i] = src[t0 + i];
 }
 
 __global__ void keys_to_hex_kernel(const uint8_t* __restrict__ keys, int64_t nbytes, uint8_t* __restrict__ hex) {
@@ -130,15 +135,23 @@ int lshrs_copy_to_host_u8(const void* src, void* dst_host, int64_t nbytes, void*
   void* dst = nullptr;
   const hipError_t e = hipHostGetDevicePointer(&dst, dst_host, 0);        // (page-locked, device-visible: else an error, not a fault)
   if (e != hipSuccess || dst == nullptr) return e != hipSuccess ? -(int)e : LSHRS_E_BADARG;
-  const bool wide = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
-  const int64_t n16 = wide ? nbytes / 16 : 0;
-  const int tail = (int)(nbytes - 16 * n16 > 0x7fffffff ? 0 : nbytes - 16 * n16);
-  if (!wide && nbytes > 0x7fffffff) return LSHRS_E_TOOLARGE;
-  const int64_t want = (n16 + 255) / 256;
+  // 16 bytes per lane wherever source and destination sit alike modulo 16 (a row-offset slice of a flag buffer, an odd
+  // length: up to 15 bytes in front of the first boundary and behind the last go one by one); where they do not, bytes -
+  // shared out over the whole grid, not left to one workgroup
+  const uintptr_t sa = reinterpret_cast<uintptr_t>(src), da = reinterpret_cast<uintptr_t>(dst);
+  int head = 0;
+  int64_t n16 = 0, tail = nbytes;
+  if (((sa ^ da) & 15) == 0) {
+    head = (int)((16 - (sa & 15)) & 15);
+    if (head > nbytes) head = (int)nbytes;
+    n16 = (nbytes - head) / 16;
+    tail = nbytes - head - 16 * n16;
+  }
+  const int64_t work = n16 > tail ? n16 : tail;
+  const int64_t want = (work + 255) / 256;
   const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
   hipLaunchKernelGGL(copy_to_host_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16,
-                     static_cast<const uint8_t*>(src) + 16 * n16, static_cast<uint8_t*>(dst) + 16 * n16, tail);
+                     static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst), head, n16, tail);
   return -(int)hipGetLastError();
 }
 

@@ -229,6 +229,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self._split_shape_ok: Optional[Tuple[int, bool]] = None
         self._device = device
         self._lock = threading.Lock()
+        self._stream_lock = threading.Lock()     # one streamed host batch at a time (shared staging buffers); see hash_batch_packed
         self._one_lock = threading.Lock()
         self._one_queue: list = []
         self._one_leader = False
@@ -773,6 +774,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_lock"] = None
+        state["_stream_lock"] = None
         state["_one_lock"] = None
         state["_one_queue"] = []
         state["_one_leader"] = False
@@ -842,6 +844,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self._window_set = {}
         self._window_coef_cache = {}
         self._lock = threading.Lock()
+        self._stream_lock = threading.Lock()
         self._one_lock = threading.Lock()
         self._one_queue = []
         self._one_leader = False

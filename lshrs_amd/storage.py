@@ -25,13 +25,17 @@ __all__ = ["BucketOperation", "InMemoryStorage", "default_storage"]
 
 
 class InMemoryStorage:
-    """Thread-safe dict-of-sets bucket store: ``{prefix}:{band}:bucket:{hex}`` -> set of ids."""
+    """Thread-safe dict-of-sets bucket store: bucket ``{prefix}:{band}:bucket:{hex}`` -> set of ids (kept under the pair
+    ``(band, key bytes)``; the reference's key text is formatted where somebody asks for it: :meth:`bucket_key`,
+    :meth:`bucket_contents`).  ``record_batches=False``: do not keep every ``batch_add`` list alive in ``batches`` (the tests'
+    record of the flush boundaries; 100 bytes per operation)."""
 
-    def __init__(self, *, prefix: str = "lsh", fail_on_flush: bool = False) -> None:
+    def __init__(self, *, prefix: str = "lsh", fail_on_flush: bool = False, record_batches: bool = True) -> None:
         self.prefix = prefix
-        self._buckets: Dict[str, Set[int]] = {}
+        self._buckets: Dict[Tuple[int, bytes], Set[int]] = {}
         self._lock = threading.Lock()
         self._fail_on_flush = fail_on_flush
+        self.record_batches = bool(record_batches)
         self.batches: List[List[BucketOperation]] = []
         self.packed_batches: List[Tuple[int, int]] = []   # (vectors, distinct buckets) per batch_add_packed call
         self._segments: list = []                         # BucketCSR of every batch_add_csr call (array-backed buckets)
@@ -43,7 +47,7 @@ class InMemoryStorage:
 
     def add_to_bucket(self, band_id: int, hash_val: bytes, index: int) -> None:
         with self._lock:
-            self._buckets.setdefault(self.bucket_key(band_id, hash_val), set()).add(int(index))
+            self._buckets.setdefault((int(band_id), bytes(hash_val)), set()).add(int(index))
 
     compact_above = 32     # array segments a lookup tolerates before it folds them into one (many small index() calls)
 
@@ -61,7 +65,7 @@ class InMemoryStorage:
         with self._lock:
             if len(self._segments) > self.compact_above:
                 self._compact_locked()
-            out = set(self._buckets.get(self.bucket_key(band_id, hash_val), ()))
+            out = set(self._buckets.get((int(band_id), bytes(hash_val)), ()))
             segments = list(self._segments)
         key = bytes(hash_val)
         for seg in segments:
@@ -117,7 +121,7 @@ class InMemoryStorage:
             if self._buckets and array_path:            # buckets built from op tuples: dict lookups per (query, band),
                 for qi in range(nq):                    # under the lock (writers mutate these sets)
                     for b in range(nb):
-                        mem = self._buckets.get(self.bucket_key(b, keys[qi, b].tobytes()))
+                        mem = self._buckets.get((b, keys[qi, b].tobytes()))
                         if mem:
                             ms.append(np.fromiter(mem, dtype=np.int64, count=len(mem)))
                             qs.append(np.full(len(mem), qi, dtype=np.int64))
@@ -181,9 +185,21 @@ class InMemoryStorage:
         if self._fail_on_flush:
             raise ConnectionError("simulated storage failure")
         with self._lock:
-            self.batches.append(ops)
-            for band_id, hash_val, index in ops:
-                self._buckets.setdefault(self.bucket_key(band_id, hash_val), set()).add(int(index))
+            if self.record_batches:
+                self.batches.append(ops)
+            buckets = self._buckets
+            get = buckets.get
+            try:        # what LSHRS sends: (int, bytes, int) - the pair in front IS the bucket's name here
+                for op in ops:
+                    name = op[:2]
+                    members = get(name)
+                    if members is None:
+                        buckets[name] = {op[2]}
+                    else:
+                        members.add(op[2])
+            except TypeError:      # (a bytearray / memoryview key, a NumPy integer: normalised - adding twice is harmless, buckets are sets)
+                for band_id, hash_val, index in ops:
+                    buckets.setdefault((int(band_id), bytes(hash_val)), set()).add(int(index))
 
     def batch_add_packed(self, ids, keys) -> None:
         """Array form of :meth:`batch_add` (see lshrs_amd/packed_ops.py): ``keys`` is the ``(n, bands, B)``
@@ -196,7 +212,7 @@ class InMemoryStorage:
         with self._lock:
             self.packed_batches.append((len(ids), len(groups)))
             for band, key_bytes, members in groups:
-                self._buckets.setdefault(self.bucket_key(band, key_bytes), set()).update(members.tolist())
+                self._buckets.setdefault((int(band), bytes(key_bytes)), set()).update(members.tolist())
 
     def batch_add_csr(self, csr) -> None:
         """A whole batch's buckets as one :class:`lshrs_amd.packed_ops.BucketCSR`: kept as arrays (an O(1) append; no
@@ -247,7 +263,7 @@ class InMemoryStorage:
         """Every non-empty bucket, ``{prefix}:{band}:bucket:{hex}`` -> set of ids (op-tuple buckets and array segments
         merged)."""
         with self._lock:
-            out = {k: set(v) for k, v in self._buckets.items() if v}
+            out = {self.bucket_key(b, k): set(v) for (b, k), v in self._buckets.items() if v}
             segments = list(self._segments)
         for seg in segments:
             for g in range(len(seg)):

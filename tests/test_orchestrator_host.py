@@ -328,3 +328,57 @@ def test_array_collision_counting_equals_the_per_member_loop(monkeypatch, packed
         counts = idx._candidate_counts_from_keys(keys[i])
         assert many[i] == [k for k, _ in sorted(counts.items(), key=lambda it: (-it[1], it[0]))]
     assert max(len(m) for m in many) > 50
+
+
+@pytest.mark.parametrize("nb,r,buffer_size,prefill", [(4, 4, 1, 0), (4, 4, 7, 2), (16, 4, 100, 3), (3, 5, 16, 1), (8, 2, 10_000, 5),
+                                                       (16, 16, 33, 0), (5, 9, 4, 1)])
+def test_op_tuple_windows_are_the_per_vector_loops_batches(monkeypatch, nb, r, buffer_size, prefill):
+    """`index()` builds the operation tuples a flush WINDOW at a time (zipped, one lock acquisition) - the
+    batches the store receives are exactly those of the reference's per-vector loop (oracle.index_literal: one vector, `num_bands`
+    tuples, flush at the first vector boundary with >= buffer_size operations; lshrs/core/main.py:1113-1143), also with
+    operations of earlier `ingest()` calls already in the buffer, a bad row in the middle, and ids that are big Python ints."""
+    from oracle import lshrs_oracle as O
+
+    dim = 24
+    rng = np.random.default_rng(nb * 100 + buffer_size)
+    data = rng.standard_normal((257, dim)).astype(np.float32)
+    ids = [int(v) for v in rng.choice(10**6, 257, replace=False)]
+    ids[5] = 2**70 + 3                                                   # (no int64: the tuples carry the caller's ints)
+    got_store, want_store = InMemoryStorage(), InMemoryStorage()
+    idx = make_cpu_lshrs(monkeypatch, dim=dim, num_bands=nb, rows_per_band=r, num_perm=nb * r, buffer_size=buffer_size,
+                         storage=got_store, packed_ingest=False)
+    P = idx._hasher.projections
+    pre = rng.standard_normal((prefill, dim)).astype(np.float32)
+    for j in range(prefill):
+        idx.ingest(900_000 + j, pre[j])
+    idx.index(ids, data)
+    # the literal loop over the same sequence (the prefilled vectors first: one buffer)
+    O.index_literal(want_store, [900_000 + j for j in range(prefill)] + ids, np.concatenate([pre, data]), P, dim, buffer_size)
+    assert got_store.batches == want_store.batches
+    assert all(type(b) is int and type(k) is bytes and type(i) is int for batch in got_store.batches for b, k, i in batch)
+    assert got_store.bucket_contents() == want_store.bucket_contents()
+    # a zero vector at row 100: everything in front of it is enqueued (and flushed where the loop flushes), then the error;
+    # what is left in the buffer is what the reference leaves there
+    bad = data.copy()
+    bad[100] = 0
+    s2, w2 = InMemoryStorage(), InMemoryStorage()
+    idx2 = make_cpu_lshrs(monkeypatch, dim=dim, num_bands=nb, rows_per_band=r, num_perm=nb * r, buffer_size=buffer_size,
+                          storage=s2, packed_ingest=False)
+    with pytest.raises(ValueError, match="Cannot index zero vector"):
+        idx2.index(ids, bad)
+    O.index_literal(w2, ids[:100], bad[:100], P, dim, buffer_size)
+    flushed = [op for batch in s2.batches for op in batch] + list(idx2._buffer)
+    assert flushed == [op for batch in w2.batches for op in batch]
+    assert [len(b) for b in s2.batches] == [len(b) for b in w2.batches][:len(s2.batches)]
+
+
+def test_in_memory_store_takes_any_key_and_id_types():
+    """`batch_add` keeps buckets under (band, key bytes): what LSHRS sends goes in as it is; other byte-likes / NumPy integers
+    are normalised - same buckets, same key texts."""
+    a, b = InMemoryStorage(), InMemoryStorage(record_batches=False)
+    ops = [(0, b"\x01\x02", 5), (1, b"\x00\x00", 6), (0, b"\x01\x02", 7)]
+    a.batch_add(ops)
+    b.batch_add([(np.int64(0), bytearray(b"\x01\x02"), np.int64(5)), (1, memoryview(b"\x00\x00"), 6), (0, b"\x01\x02", np.int32(7))])
+    assert a.bucket_contents() == b.bucket_contents() == {"lsh:0:bucket:0102": {5, 7}, "lsh:1:bucket:0000": {6}}
+    assert a.batches == [ops] and b.batches == [] and b.get_bucket(0, b"\x01\x02") == {5, 7}
+    assert all(type(i) is int for i in b.get_bucket(0, bytearray(b"\x01\x02")))

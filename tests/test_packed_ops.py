@@ -40,7 +40,7 @@ def test_packed_ingest_builds_the_same_buckets(monkeypatch):
     idx.index(list(range(700)), data)
     assert packed.batches and packed.batches[0][0][2] == 9999
     assert [n for n, _ in packed.packed_batches] == [700]               # the whole batch as one bucket CSR
-    expect = {k: set(v) for k, v in plain._buckets.items()}
+    expect = plain.bucket_contents()
     for b, kb, i in packed.batches[0]:
         expect.setdefault(packed.bucket_key(b, kb), set()).add(i)
     assert packed.bucket_contents() == expect
