@@ -457,6 +457,8 @@ def main() -> None:
         if split:
             roofline = stage1_roofline(kernel_ms_mean, rows_per_launch_mean, DIM, NUM_PERM,
                                        "sig16_kernel (stage 1 of the split-precision pass: bf16x3 on v_mfma_f32_16x16x32_bf16)")
+            # (what the step costs beyond its dominant kernel - `value` as a fraction of rows / stage-1 time)
+            roofline["step_over_stage1"] = (total_rows * args.steps / elapsed) / (rows_per_launch_mean / (kernel_ms_mean * 1e-3)) / world
             roofline.update({"fix_kernel_ms_mean": sum(fix_ms) / max(1, len(fix_ms)), "launches_timed": len(kernel_ms),
                              "launches_per_step": len(kernel_ms) / max(1, args.steps),
                              "kernel_ms_per_step": sum(kernel_ms) / max(1, args.steps)})
@@ -614,6 +616,8 @@ def main() -> None:
         except Exception as exc:  # noqa: BLE001
             result["c5"] = {"error": f"{type(exc).__name__}: {exc}"}
 
+    if rank == 0 and world == 1:
+        result["floors"] = floors(result)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -879,10 +883,64 @@ def bench_host_fed(torch, np, hasher, x, rows, barrier=None):
             "note": "hash_batch_packed(NumPy array) -> NumPy keys; best of 3"}
 
 
+class _CountingStore:
+    """The least a third-party store with only `batch_add` can do with the operation lists: count them (what is left of
+    `index_op_tuples` with it is the LSHRS side: signature pass + building the reference's tuples)."""
+
+    def __init__(self):
+        self.ops = 0
+        self.calls = 0
+
+    def batch_add(self, operations):
+        self.ops += len(operations)
+        self.calls += 1
+
+    def get_bucket(self, band_id, hash_val):
+        return set()
+
+
+def floors(result) -> dict:
+    """The wall-clock floors of `pytest -m perf` (kept out of `-m gpu` so that a slow box cannot turn parity red - and then run by
+    nobody) evaluated on THIS run's own figures, non-fatal: {name: {value, floor, ok}}.  A floor is the rate below which something
+    is broken (or, for the round's targets, not met), not the rate to expect."""
+    def dig(*path):
+        cur = result
+        for k in path:
+            if not isinstance(cur, dict) or k not in cur:
+                return None
+            cur = cur[k]
+        return cur if isinstance(cur, (int, float)) else None
+
+    table = (
+        ("config2_vectors_per_s", ("value",), 700e6),
+        ("config2_value_over_rows_per_stage1_time", ("roofline", "step_over_stage1"), 0.87),
+        ("config5_vectors_per_s", ("c5", "value"), 200e6),
+        ("rerank_candidates_per_s", ("rerank", "value"), 1.5e9),
+        ("shape_16x4x128_vectors_per_s", ("other_shapes", "16x4x128", "value"), 3.0e9),
+        ("shape_20x6x128_vectors_per_s", ("other_shapes", "20x6x128", "value"), 3.0e9),
+        ("host_fed_vectors_per_s", ("host_fed", "value"), 12e6),
+        ("index_packed_vectors_per_s", ("e2e_ingest", "index_packed"), 10e6),
+        ("index_op_tuples_lshrs_side_vectors_per_s", ("e2e_ingest", "index_op_tuples_breakdown", "lshrs_side_vectors_per_s"), 300e3),
+        ("index_op_tuples_vectors_per_s", ("e2e_ingest", "index_op_tuples"), 300e3),
+        ("hash_batch_list_vectors_per_s", ("e2e_ingest", "hash_batch_list_of_HashSignatures", "value"), 300e3),
+        ("query_many_top_k_10_queries_per_s", ("e2e_ingest", "query_many", "top_k_10"), 400e3),
+        ("query_many_top_p_half_arrays_queries_per_s", ("e2e_ingest", "query_many", "top_p_0.5_arrays"), 300e3),
+        ("small_n_one_vector_us", ("small_n", "gpu_us_per_vector_p50"), None),
+    )
+    out = {}
+    for name, path, floor in table:
+        v = dig(*path)
+        if v is None or floor is None:
+            continue
+        out[name] = {"value": v, "floor": floor, "ok": bool(v >= floor)}
+    return out
+
+
 def bench_e2e(torch, np, x, local_dev):
     """LSHRS.index() end to end from host memory into the in-memory store, beside the reference's own
-    per-vector loop restated literally (oracle)."""
-    from lshrs_amd import LSHRS, InMemoryStorage
+    per-vector loop restated literally (oracle); the reference-shaped object forms - operation tuples for stores with only
+    `batch_add`, `hash_batch` -> list[HashSignatures] - with where their host time goes."""
+    from lshrs_amd import LSHRS, InMemoryStorage, LSHHasher
     from oracle.lshrs_oracle import index_literal
 
     rows = min(500_000, int(x.shape[0]))
@@ -890,17 +948,59 @@ def bench_e2e(torch, np, x, local_dev):
     ids = np.arange(rows, dtype=np.int64)
     out = {"rows": rows, "unit": "vectors/s"}
     for label, packed in (("index_packed", True), ("index_op_tuples", False)):
-        m = rows if packed else min(rows, 100_000)
-        idx = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(), device=local_dev, packed_ingest=packed)
+        m = rows if packed else min(rows, 200_000)
+        idx = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(record_batches=False), device=local_dev, packed_ingest=packed)
         idx.index(ids[:100_000] if packed else ids[:5_000], host[:100_000] if packed else host[:5_000])   # (buffers, workspace)
         best = None
-        for rep in range(2 if packed else 1):
+        cpu0 = time.process_time()
+        for rep in range(2):
             t0 = time.perf_counter()
             idx.index(ids[:m] + 10_000_000 * (rep + 1), host[:m])
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         out[label] = m / best
+        if packed:      # (the host half of the ingest, in CPU seconds of this process - all its threads - per million rows)
+            out["host_cpu_seconds_per_M_rows"] = (time.process_time() - cpu0) / (2 * m / 1e6)
         del idx
+    # the op-tuple path taken apart: the same call into a store that only counts (= the LSHRS side:
+    # host -> device copy, signature pass, keys back, the tuples), the signature pass alone, and the store's own share
+    m = min(rows, 200_000)
+    counting = _CountingStore()
+    idx = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=counting, device=local_dev, packed_ingest=False)
+    idx.index(ids[:5_000], host[:5_000])
+    best = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        idx.index(ids[:m], host[:m])
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    t0 = time.perf_counter()
+    idx._hasher.hash_batch_packed(host[:m], return_row_flags=True)
+    t_hash = time.perf_counter() - t0
+    out["index_op_tuples_breakdown"] = {
+        "rows": m, "operations_per_vector": BANDS,
+        "lshrs_side_vectors_per_s": m / best, "lshrs_side_seconds": best,
+        "of_which_signature_pass_host_to_host_seconds": t_hash, "of_which_building_tuples_and_flushing_seconds": max(0.0, best - t_hash),
+        "in_memory_store_batch_add_seconds": max(0.0, m / out["index_op_tuples"] - best),
+        "ns_per_operation_lshrs_side": 1e9 * best / (m * BANDS),
+        "note": "lshrs_side = index() into a store whose batch_add only counts; index_op_tuples (above) = into InMemoryStorage, a "
+                "Python dict of sets (its batch_add is the rest).  The tuples are built a flush window at a time: key bytes -> "
+                "bytes objects, ids and band numbers repeated, zipped (lshrs_amd/core.py; reference: main.py:1113-1143)"}
+    del idx
+    # hash_batch -> list[HashSignatures] (lshrs/hash/lsh.py:136-169): the reference-shaped object form of the signature pass
+    hb = LSHHasher(BANDS, ROWS, DIM, seed=42, device=local_dev)
+    hb.hash_batch(host[:50_000])
+    t0 = time.perf_counter()
+    sigs = hb.hash_batch(host)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hb.hash_batch_packed(host)
+    dt_packed = time.perf_counter() - t0
+    out["hash_batch_list_of_HashSignatures"] = {
+        "value": rows / dt, "unit": "vectors/s", "rows": rows, "seconds": dt, "of_which_keys_as_array_seconds": dt_packed,
+        "objects_per_vector": 2 + BANDS, "first": [b.hex() for b in sigs[0]][:3],
+        "note": "hash_batch(NumPy array) -> list of HashSignatures (a dataclass, a tuple, num_bands bytes objects per vector)"}
+    del sigs, hb
     out["query_many"] = bench_query_many(torch, np, x, host, local_dev)
     m = 20_000
     t0 = time.perf_counter()

@@ -54,13 +54,16 @@ uint32_t lshrs_build_flags(void);
 struct lshrs_sig_sort;
 typedef struct lshrs_sig_opts {
   uint32_t struct_bytes;   /* sizeof(lshrs_sig_opts): lets the struct grow without breaking old callers */
-  uint32_t reserved;       /* 0 */
+  int32_t done_epoch;      /* ABI 7: the value the replay pass stores to *done_host when its counters are out (below) */
   void* ev_stage1_start;
   void* ev_stage1_stop;
   void* ev_stage2_start;
   void* ev_stage2_stop;
   void* clock_probe;
   const struct lshrs_sig_sort* sort;   /* ABI 6: scratch for the column-sorted stage 2 (below), or NULL */
+  int32_t* done_host;      /* ABI 7: PINNED HOST int32[1] or NULL.  The launch that exports the counters of
+                            * lshrs_sig_hash_batch_split_replay_f32 stores done_epoch there last, behind a system-scope fence: a
+                            * caller that waits with lshrs_wait_done sees the pass end a wake-up earlier than through the stream */
 } lshrs_sig_opts;
 
 /* Scratch that lets stage 2 of lshrs_sig_hash_batch_split_replay_f32 work through the flagged projections COLUMN BY COLUMN
@@ -292,6 +295,11 @@ int lshrs_sig_hash_small_replay_f32(const float* X, int64_t n, int64_t ldx,
  * caller - LSHHasher.hash_batch returning its keys, lshrs/hash/lsh.py:136-169 - does behind the replay entry points before
  * it reads the counters they left in pinned memory.  A convenience for bindings that hold a raw stream handle only. */
 int lshrs_stream_synchronize(void* stream);
+
+/* Wait for *done_host == epoch (lshrs_sig_opts::done_host): the calling thread polls the pinned word for at most spin_ns
+ * nanoseconds - what a synchronous caller of a 0.1 .. 1 ms pass wants: the runtime's stream wait sleeps on an interrupt and
+ * wakes 10 - 20 us late - and then falls back to hipStreamSynchronize(stream).  0, or the runtime's error, negated. */
+int lshrs_wait_done(const int32_t* done_host, int32_t epoch, int64_t spin_ns, void* stream);
 
 /* Diagnostic twin of lshrs_sig_hash_batch_f32: writes the raw projections instead of their sign bits.
  *   Y (n, ldy) f32 with ldy >= padded columns rounded up to the kernel's column tile

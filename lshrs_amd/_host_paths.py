@@ -425,6 +425,4 @@ class _HostPaths:
 
     def hash_batch(self, vectors) -> List[HashSignatures]:
         """``(n, dim)`` -> list of ``HashSignatures`` (reference: lsh.py:136-169)."""
-        packed = self.hash_batch_packed(vectors)
-        nb = self.num_bands
-        return [HashSignatures(tuple(row[b].tobytes() for b in range(nb))) for row in packed]
+        return HashSignatures._from_packed(self.hash_batch_packed(vectors))

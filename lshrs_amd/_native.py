@@ -124,6 +124,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_sig_hash_small_replay_f32.restype = c.c_int
     lib.lshrs_stream_synchronize.argtypes = [vp]
     lib.lshrs_stream_synchronize.restype = c.c_int
+    lib.lshrs_wait_done.argtypes = [vp, i32, i64, vp]
+    lib.lshrs_wait_done.restype = c.c_int
     lib.lshrs_sig_project_f32.argtypes = [vp, i64, i64, vp, i32, i32, i32, vp, i64, vp]
     lib.lshrs_sig_project_f32.restype = c.c_int
     lib.lshrs_gather_rows_f32.argtypes = [vp, i64, i32, vp, i64, vp, vp]
@@ -188,6 +190,7 @@ EXPORTS = (
     "lshrs_sig_resolve_ties_replay_f32",
     "lshrs_sig_hash_small_replay_f32",
     "lshrs_stream_synchronize",
+    "lshrs_wait_done",
     "lshrs_sig_project_f32",
     "lshrs_gather_rows_f32",
     "lshrs_gather_tied_rows_f32",
@@ -255,13 +258,14 @@ def load() -> ctypes.CDLL:
 class SigOpts(ctypes.Structure):
     """``lshrs_sig_opts`` of include/lshrs_hip.h: optional per-call measurement hooks (events, clock probe)."""
 
-    _fields_ = [("struct_bytes", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+    _fields_ = [("struct_bytes", ctypes.c_uint32), ("done_epoch", ctypes.c_int32),
                 ("ev_stage1_start", ctypes.c_void_p), ("ev_stage1_stop", ctypes.c_void_p),
                 ("ev_stage2_start", ctypes.c_void_p), ("ev_stage2_stop", ctypes.c_void_p),
-                ("clock_probe", ctypes.c_void_p), ("sort", ctypes.c_void_p)]
+                ("clock_probe", ctypes.c_void_p), ("sort", ctypes.c_void_p), ("done_host", ctypes.c_void_p)]
 
     def __init__(self, events=None, clock_probe=None, sort=None):
         super().__init__()
+        self._sort_ref = None
         self.struct_bytes = ctypes.sizeof(SigOpts)
         if events is not None:
             (self.ev_stage1_start, self.ev_stage1_stop, self.ev_stage2_start, self.ev_stage2_stop) = events

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import time
 
 import numpy as np
 
@@ -25,6 +26,24 @@ class _RawStreamWait:
 
     def synchronize(self) -> None:
         _native.check(self._lib.lshrs_stream_synchronize(self._raw), "lshrs_stream_synchronize")
+
+    def query(self) -> bool:
+        return False
+
+
+class _EpochWait:
+    """What a synchronous launch of the split pass waits on: the `done` word of its counter block (`lshrs_wait_done`: a bounded
+    poll of pinned memory - the runtime's stream wait wakes 10 - 20 us late - then the stream)."""
+
+    __slots__ = ("_lib", "_word", "_epoch", "_spin_ns", "_raw")
+
+    def __init__(self, lib, word, epoch, spin_ns, raw) -> None:
+        self._lib, self._word, self._epoch, self._spin_ns, self._raw = lib, word, epoch, spin_ns, raw
+
+    def synchronize(self) -> None:
+        rc = self._lib.lshrs_wait_done(self._word, self._epoch, self._spin_ns, self._raw)
+        if rc != 0:
+            _native.check(rc, "lshrs_wait_done")
 
     def query(self) -> bool:
         return False
@@ -87,18 +106,24 @@ class _ReplayPaths:
         The counters of the launch come back through one of four pinned blocks, taken from a free list and returned by
         `_replay_finish` (streamed launches keep at most three; a synchronous caller that takes the last one keeps the lock
         until it is back).  Scratch is per (device, stream): launches enqueued on different streams never share a list or a
-        counter block; launches on one stream are ordered by the stream."""
+        counter block; launches on one stream are ordered by the stream.
+        Round 6 (the lean step): everything a launch passes that does not change from call to call - the option structs of
+        the four counter blocks with their `done` words, the audit struct, their ctypes references - is made once per
+        scratch; a synchronous caller waits on the `done` word of its block (`lshrs_wait_done`: a bounded poll, then the
+        stream) instead of sleeping on the stream."""
         torch = _native.require_gpu()
         lib = _native.load()
         dev = x.device
         n = int(x.shape[0])
         timing = self.kernel_events is not None
-        ctx = contextlib.nullcontext() if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
-        with ctx:
+        switch = torch._C._cuda_getDevice() != dev.index
+        if switch:
+            guard = torch.cuda.device(dev)
+            guard.__enter__()
+        try:
             # (the raw handle of the device's current stream: building a torch Stream object per launch costs more than the
             #  arithmetic around it; the object is made where something needs it - events, the error path)
             raw = torch._C._cuda_getCurrentRawStream(dev.index)
-            cur = None
             cap = max(int(self._flag_cap_hint), n // 4 + 4096)
             if self.tau1_ulps > 256.0:      # a wide (e.g. "bound") window flags ~1.3e-6 of the projections per unit
                 cap = max(cap, int(n * self.num_bands * self.rows_per_band * min(self.tau1_ulps, 4096.0) * 2.0e-6) + 4096)
@@ -106,17 +131,25 @@ class _ReplayPaths:
             scratch = self._replay_scratch.get(skey)
             if scratch is None or scratch[9][3] < cap:
                 nc = _native.SIG_COUNTERS
-                pinned = torch.zeros((4, nc), dtype=torch.int32).pin_memory()
+                pinned = torch.zeros((4, nc + 8), dtype=torch.int32).pin_memory()       # per block: the counters, then its `done` word
+                audit = _native.SigAudit(0, 0, 0, 0, 0)
                 scratch = (torch.empty((cap,), dtype=torch.int64, device=dev),
                            torch.zeros(_native.SIG_DEVICE_COUNTERS, dtype=torch.int32, device=dev),   # counters + stage-2 slots
                            pinned, pinned.numpy(), [0, [3, 2, 1, 0]],             # launches so far, free pinned blocks
                            torch.empty((cap,), dtype=torch.float32, device=dev),   # stage-1 value of every list entry
                            # the audit sample of a launch: entry, (stage-1 value, window) per slot
                            torch.empty((2 * max(1, self.audit_unflagged),), dtype=torch.int64, device=dev),
-                           torch.empty((4 * max(1, self.audit_unflagged),), dtype=torch.float32, device=dev), [None])
-                # ... and what every launch passes of it: list / counter / value pointers, the list's capacity, the four pinned blocks
+                           torch.empty((4 * max(1, self.audit_unflagged),), dtype=torch.float32, device=dev), [audit])
+                audit.list, audit.vals, audit.slots = scratch[6].data_ptr(), scratch[7].data_ptr(), int(scratch[6].shape[0])
+                opts4 = [_native.SigOpts() for _ in range(4)]
+                for i, o in enumerate(opts4):
+                    o.done_host = pinned.data_ptr() + 4 * ((nc + 8) * i + nc)
+                # ... and what every launch passes of it: list / counter / value pointers, the list's capacity, the four pinned
+                # blocks, the option struct of each block with its reference, the audit struct's reference, the epoch counter
                 scratch += ((scratch[0].data_ptr(), scratch[1].data_ptr(), scratch[5].data_ptr(), int(scratch[0].shape[0]),
-                             tuple(pinned.data_ptr() + 4 * nc * i for i in range(4))),)
+                             tuple(pinned.data_ptr() + 4 * (nc + 8) * i for i in range(4)), opts4,
+                             tuple(ctypes.byref(o) for o in opts4), ctypes.byref(audit), [0],
+                             tuple(o.done_host for o in opts4)),)
                 if len(self._replay_scratch) >= 16 and not self._async_pending:
                     # a caller that keeps making new streams must not pile up lists: nothing is in flight, start over
                     self._replay_scratch.clear()
@@ -124,15 +157,17 @@ class _ReplayPaths:
                     self._sort_res.clear()
                 self._replay_scratch[skey] = scratch
             # (the device counters are zero: at creation, and the launch that exports them leaves them so)
-            flag_list, counts, pinned, host_counts, turn, flag_y, audit_list, audit_vals, audit_box, ptrs = scratch
+            counts, host_counts, turn, audit_box, ptrs = scratch[1], scratch[3], scratch[4], scratch[8], scratch[9]
             while not turn[1]:        # every pinned block belongs to an unverified launch: verify the oldest streamed one
                 if not self._async_pending:      # (cannot happen: a synchronous caller that takes the last block keeps the lock)
                     raise _native.NativeLibraryError("no free counter block for a replay launch")
                 self._async_pending[0]._finish_locked()
             slot = turn[1].pop()
             turn[0] += 1
+            opts = ptrs[5][slot]
+            epoch = ptrs[8][0] = (ptrs[8][0] % 0x7FFFFFF0) + 1
+            opts.done_epoch = epoch
             ev = None
-            opts = None
             if timing:
                 # four timing events per launch, from a ring as deep as the pinned blocks (creating and recording them
                 # afresh costs ~20 us of host time per launch - on a 1.2 ms step that is the measurement disturbing
@@ -145,55 +180,50 @@ class _ReplayPaths:
                         quad = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
                         for e in quad:
                             e.record(cur)            # creates the handles; the library re-arms them on its dispatches
-                        ring.append((quad, _native.SigOpts(events=tuple(e.cuda_event for e in quad))))
+                        ring.append(quad)
                     self._replay_events[skey] = ring
-                ev, opts = ring[slot]
-            smode = self._stage2_mode()
+                ev = ring[slot]
+                (opts.ev_stage1_start, opts.ev_stage1_stop, opts.ev_stage2_start, opts.ev_stage2_stop) = [e.cuda_event for e in ev]
+            elif opts.ev_stage1_start:
+                opts.ev_stage1_start = opts.ev_stage1_stop = opts.ev_stage2_start = opts.ev_stage2_stop = None
             sort = None
-            if smode is not None:
+            if self._stage2_mode() is not None:
                 sort = self._sort_scratch(torch, dev, skey, cap)
                 sort[0].parity = sort[4][0] & 1              # the set of column counters this launch counts in (the other: cleared by it)
                 sort[4][0] += 1
-                if opts is None:
-                    opts = sort[1]
-                else:
+                if opts._sort_ref is not sort[0]:
                     opts.set_sort(sort[0])
-            elif opts is not None and opts.sort:
+            elif opts.sort:
                 opts.set_sort(None)
-            audit = None
+            audit_ref = None
             if self.audit_unflagged > 0:
                 self._audit_seed = (self._audit_seed + 1) & 0x7FFFFFFF
                 audit = audit_box[0]                 # (the struct of this scratch: the library reads it during the call only)
-                if audit is None:
-                    audit = audit_box[0] = _native.SigAudit(audit_list.data_ptr(), audit_vals.data_ptr(),
-                                                            int(audit_list.shape[0]), self.audit_unflagged, 0)
                 audit.target = self.audit_unflagged
                 audit.seed = (self._audit_seed * 2654435761) & 0xFFFFFFFF
-            try:
-                _native.check(
-                    lib.lshrs_sig_hash_batch_split_replay_f32(
-                        x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
-                        out.data_ptr(), ptrs[1], tau, row_flags.data_ptr() if row_flags is not None else None,
-                        ptrs[0], ptrs[2], ptrs[3], self._tau1_arg(),
-                        model, ptrs[4][slot], ctypes.byref(audit) if audit is not None else None,
-                        ctypes.byref(opts) if opts is not None else None, raw),
-                    "lshrs_sig_hash_batch_split_replay_f32")
-            except BaseException:
+                audit_ref = ptrs[7]
+            rc = lib.lshrs_sig_hash_batch_split_replay_f32(
+                x.data_ptr(), n, x.stride(0), ws.data_ptr(), self.num_bands, self.rows_per_band, self.dim,
+                out.data_ptr(), ptrs[1], tau, row_flags.data_ptr() if row_flags is not None else None,
+                ptrs[0], ptrs[2], ptrs[3], self._tau1_arg(), model, ptrs[4][slot], audit_ref, ptrs[6][slot], raw)
+            if rc != 0:
                 torch.cuda.current_stream(dev).synchronize()
                 counts.zero_()              # a failed launch may have left counts behind: the next call starts from zero
                 if sort is not None:
                     sort[3][2].zero_()
                 turn[1].append(slot)
-                raise
-            done = None
-            if want_event:          # (the synchronous path waits for the stream instead)
+                _native.check(rc, "lshrs_sig_hash_batch_split_replay_f32")
+            if want_event:          # (the streaming handle asks the event whether the launch is done)
                 done = torch.cuda.Event()
                 done.record(torch.cuda.current_stream(dev))
             else:
-                done = _RawStreamWait(lib, raw)
+                done = _EpochWait(lib, ptrs[9][slot], epoch, int(self.spin_wait_us) * 1000, raw)
+        finally:
+            if switch:
+                guard.__exit__(None, None, None)
         # (the ceiling the live check holds this launch to is the one of the coefficients it was launched with: `window_info`
         #  follows whichever BLAS-order model `_ensure_window` set last, and an async handle may be finished after a switch)
-        return (done, host_counts[slot:slot + 1], slot, (ptrs[3],), n, ev,
+        return (done, host_counts[slot:slot + 1, :_native.SIG_COUNTERS], slot, (ptrs[3],), n, ev,
                 float("inf") if self.window_mode["tau1"] == "bound" else float(self.tau1_ulps),
                 float(self.window_info.get("window_units_worst_case_row", float("inf"))), turn[0], turn)
 
@@ -337,8 +367,10 @@ class _ReplayPaths:
             stats["reference_blas"] = self.reference_blas
         if self.audit_every > 0 and stats.get("flagged", 0) > 0 and undisturbed and self._host_blas_agrees():
             self._audit_countdown -= 1
-            if self._audit_countdown <= 0:
+            if self._audit_countdown <= 0 and (time.monotonic() - self._audit_last >= self.audit_min_interval_s
+                                               or self._audit_last == 0.0):
                 self._audit_countdown = self.audit_every
+                self._audit_last = time.monotonic()
                 if not self._audit_replay(x, out, stats):
                     # what the device decided is not what this process's NumPy computes: the replay's licence is void
                     # for this hasher - the host engine (the library's own call) takes over, starting with this batch

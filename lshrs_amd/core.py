@@ -21,8 +21,6 @@ tests/golden/g5_orchestration.json holds the reference's own batches for these c
 
 from __future__ import annotations
 
-import contextlib
-import gc
 import itertools
 import json
 import logging
@@ -35,6 +33,7 @@ from typing import Any, Callable, Dict, Iterable, Iterator, List, Optional, Sequ
 import numpy as np
 
 from . import _hostblas
+from ._gcpause import gc_paused as _gc_paused
 from .bandrows import get_optimal_config
 from .hasher import LSHHasher
 from .packed_ops import bucket_csr as _bucket_csr
@@ -100,25 +99,6 @@ class _DeferredStorage:
         if item in ("batch_add_csr", "batch_add_packed", "get_buckets_many") and self._real is None:
             raise AttributeError(item)          # (capability probes must not open a connection)
         return getattr(self._resolve(), item)
-
-
-@contextlib.contextmanager
-def _gc_paused():
-    """Building millions of small result objects: the cyclic collector's passes over them are 40 % of the time and can
-    free nothing (ints, floats and tuples of them).  Paused while they are built - and on the way out the young generation
-    (these results: they cannot be part of a cycle) is moved to the oldest one in O(1) (``gc.freeze`` + ``gc.unfreeze``)
-    instead of being walked by the collection the next allocation would trigger - as long as building them took (0.18 s
-    per 1.3 M (id, score) pairs).  Not done when the process keeps frozen objects of its own (a pre-fork server)."""
-    was = gc.isenabled()
-    gc.disable()
-    try:
-        yield
-    finally:
-        if was:
-            if gc.get_freeze_count() == 0:
-                gc.freeze()
-                gc.unfreeze()
-            gc.enable()
 
 
 def _ragged_positions(starts: np.ndarray, lens: np.ndarray) -> np.ndarray:

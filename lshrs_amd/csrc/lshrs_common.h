@@ -436,6 +436,8 @@ struct Opts {            // the caller's lshrs_sig_opts, or all-null
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned long long* clock_probe = nullptr;
   const lshrs_sig_sort* sort = nullptr;
+  int* done = nullptr;      // pinned host word (device-visible address) that receives `epoch` behind the counters
+  int epoch = 0;
 };
 inline Opts read_opts(const lshrs_sig_opts* o) {
   Opts r;
@@ -445,9 +447,16 @@ inline Opts read_opts(const lshrs_sig_opts* o) {
     r.ev[2] = static_cast<hipEvent_t>(o->ev_stage2_start);
     r.ev[3] = static_cast<hipEvent_t>(o->ev_stage2_stop);
     r.clock_probe = static_cast<unsigned long long*>(o->clock_probe);
-    if (o->struct_bytes >= sizeof(lshrs_sig_opts) && o->sort != nullptr && o->sort->struct_bytes >= sizeof(lshrs_sig_sort) &&
+    if (o->struct_bytes >= offsetof(lshrs_sig_opts, done_host) && o->sort != nullptr && o->sort->struct_bytes >= sizeof(lshrs_sig_sort) &&
         o->sort->list != nullptr && o->sort->y != nullptr && o->sort->hist != nullptr)
       r.sort = o->sort;
+    if (o->struct_bytes >= sizeof(lshrs_sig_opts) && o->done_host != nullptr) {
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, o->done_host, 0) == hipSuccess && dp != nullptr) {
+        r.done = static_cast<int*>(dp);
+        r.epoch = o->done_epoch;
+      }
+    }
   }
   return r;
 }

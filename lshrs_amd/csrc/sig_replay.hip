@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
 // Without host_counts the folded counters stay in the device block (the caller copies it).
 constexpr int kExportThreads = 1024;      // one part or two per thread: the fold is one memory round trip deep, not nparts / 64
 __global__ __launch_bounds__(kExportThreads) void export_counts_kernel(int* counters, int* host_counts, int nparts, int* zero = nullptr,
-                                                                      int nzero = 0) {
+                                                                      int nzero = 0, int* done = nullptr, int epoch = 0) {
   __shared__ int fold[kExportThreads / 64][kFixParts];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < nzero; i += kExportThreads) zero[i] = 0;      // (buckets: the column counters of the NEXT launch)
@@ -670,6 +670,13 @@ __global__ __launch_bounds__(kExportThreads) void export_counts_kernel(int* coun
       counters[tid] = 0;
     } else {
       counters[tid] = v;
+    }
+  }
+  if (done != nullptr) {        // (lshrs_wait_done: the counters first - and everything the pass did before them -, then the word the host polls)
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -738,13 +745,14 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
       else
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, false, kBucketSlab, true>), bgrid, block, 0, s, o.ev[2], o.ev[3], 0, fb);
       hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, (int)bgrid.x,
-                         o.sort->hist + (size_t)(1 - (o.sort->parity & 1)) * kSortMaxCols, kSortMaxCols);
+                         o.sort->hist + (size_t)(1 - (o.sort->parity & 1)) * kSortMaxCols, kSortMaxCols, o.done, o.epoch);
       return -(int)hipGetLastError();
     } else if (blas_general(rows_per_band, f.ktiles, dim))
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, true>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
     else
       hipExtLaunchKernelGGL((sig_fix8_kernel<true, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
-    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, nparts);
+    hipLaunchKernelGGL(export_counts_kernel, dim3(1), dim3(kExportThreads), 0, s, counters, host_counts, nparts, nullptr, 0, o.done,
+                       o.epoch);
   } else {
     hipExtLaunchKernelGGL((sig_fix8_kernel<false, false>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
   }

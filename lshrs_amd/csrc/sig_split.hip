@@ -6,6 +6,8 @@
 // ABI and reference citations: include/lshrs_hip.h.  Design notes: DESIGN.md.
 #include "lshrs_common.h"
 
+#include <chrono>
+
 using namespace lshrs;
 
 extern "C" {
@@ -17,6 +19,23 @@ int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
 uint32_t lshrs_build_flags(void) { return lshrs_flags_sig16() | lshrs_flags_sig16r() | lshrs_flags_replay(); }
 
 int lshrs_stream_synchronize(void* stream) { return -(int)hipStreamSynchronize(static_cast<hipStream_t>(stream)); }
+
+int lshrs_wait_done(const int32_t* done_host, int32_t epoch, int64_t spin_ns, void* stream) {
+  if (done_host != nullptr && spin_ns > 0) {
+    const volatile int32_t* word = done_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t spins = 0;; ++spins) {
+      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == epoch) return 0;
+#if !defined(__HIP_DEVICE_COMPILE__)
+      __builtin_ia32_pause();
+#endif
+      if ((spins & 255) == 255 &&
+          std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > spin_ns)
+        break;
+    }
+  }
+  return -(int)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+}
 
 // blas_model 0: ties are reported in tie_list (the caller resolves them on the host); > 0: stage 2 resolves them itself
 // by replaying that summation order of the host BLAS (sig_fix8_kernel<true>), tie_list is not used.

@@ -219,6 +219,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self.split_min_rows = 4_096
         self.split_min_elems = 16 << 20
         self.replay_min_rows = 256      # with the ties broken on the device the split pass pays from here (see _split_applies)
+        # a synchronous `hash_device` polls the pinned `done` word of its launch for at most this long before it sleeps on the stream
+        # (lshrs_wait_done): the runtime's wake-up is 10 - 20 us late - 10 % of a short-vector step; 0 = always the stream
+        self.spin_wait_us = 2_000
         # host tie-break workers (lshrs_amd/_hostblas.py): None = this process's share of the cores (at most 8),
         # 1 = NumPy's batched matmul on the calling thread.  Same BLAS call either way.
         if tie_threads is not None and int(tie_threads) < 1:
@@ -252,6 +255,11 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             raise ValueError("tie_replay must be 'auto' or 'off'")
         self.tie_replay = tie_replay
         self._replay_model_cache: Optional[tuple] = None
+        self._route_memo: Optional[tuple] = None
+        # the live audit against `P_band @ x` (audit_every): not more often than this, however short the batches are (it costs
+        # ~0.3 ms - a small device gather, one copy, sixteen host sgemv calls: 3 % of a stream of 0.15 ms steps at every 64th)
+        self.audit_min_interval_s = 0.05
+        self._audit_last = 0.0
         # Stage 2 column by column (ABI 6, lshrs_sig_sort): every eight entries stage 2 takes share one hyperplane, fetched once -
         # the row gather of x is the only stream left.  "auto" = "buckets" for every hasher the split pass's main kernel serves
         # (up to 1024 padded key columns, rows longer than four k-tiles): stage 1 itself appends flagged and sampled projections
@@ -421,9 +429,20 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         if n == 0:
             return out
         ws = self._workspace(dev)
-        route, model = self._route(n, mode, aligned=x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0,
-                                   short_stride=x.stride(0) < (1 << 20), host_rows=host_rows is not None,
-                                   allow_pipeline=allow_pipeline)
+        # (the route of a batch depends on a handful of facts that rarely change from call to call: remembered per set of them -
+        #  the table of `_route` is consulted again when the hyperplanes, the BLAS's configuration or an option changes)
+        ldx = x.stride(0)
+        facts = (n if n < 131_072 else -1, mode, x.data_ptr() % 16 == 0 and ldx % 4 == 0, ldx < (1 << 20), host_rows is not None,
+                 allow_pipeline, self._projection_version, self.tie_replay, self.precision, self.replay_min_rows, self.reference_blas,
+                 _hostblas.blas_signature() if self.reference_blas == "host" else None)
+        memo = self._route_memo
+        if memo is not None and memo[0] == facts:
+            route, model = memo[1]
+        else:
+            route, model = self._route(n, mode, aligned=facts[2], short_stride=facts[3], host_rows=host_rows is not None,
+                                       allow_pipeline=allow_pipeline)
+            if model:        # (the replay routes depend on nothing else; the host-engine routes also look at windows and engines)
+                self._route_memo = (facts, (route, model))
         if route != "raw":                     # (the raw bits consult no window)
             self._ensure_window(dev, ws, model)
         tau = self._tau_arg()
@@ -792,6 +811,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         state["_async_pending"] = []
         state["_replay_events"] = {}
         state["_replay_model_cache"] = None
+        state["_route_memo"] = None
         state["_host_agrees"] = None
         state["_host_planes_cache"] = None
         state["kernel_events"] = None
@@ -814,11 +834,15 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self.__dict__.setdefault("_async_pending", [])
         self.__dict__.setdefault("_replay_events", {})
         self.__dict__.setdefault("_replay_model_cache", None)
+        self.__dict__.setdefault("_route_memo", None)
+        self.__dict__.setdefault("audit_min_interval_s", 0.05)
+        self.__dict__.setdefault("_audit_last", 0.0)
         self.__dict__.setdefault("tie_replay", "auto")
         self.__dict__.setdefault("reference_blas", "host")
         self.reference_blas = _hostblas.LEGACY_BUILD_NAMES.get(self.reference_blas, self.reference_blas)
         self.__dict__.setdefault("_host_agrees", None)
         self.__dict__.setdefault("replay_min_rows", 256)
+        self.__dict__.setdefault("spin_wait_us", 2_000)
         self.__dict__.setdefault("pipeline_pair_head", True)
         self.__dict__.setdefault("_host_planes_cache", None)
         self.__dict__.setdefault("_split_range_ok", None)

@@ -122,7 +122,7 @@ def test_pure_host_entry_points(lib):
     names = re.findall(r"(\w+);", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
     from lshrs_amd import _native
     assert names == [f[0] for f in _native.SigOpts._fields_]
-    assert ctypes.sizeof(_native.SigOpts) == 8 + 6 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_native.SigOpts) == 8 + 7 * ctypes.sizeof(ctypes.c_void_p)      # (ABI 7: + done_host)
     fields = re.search(r"typedef struct lshrs_sig_sort \{(.*?)\} lshrs_sig_sort;", text, flags=re.S).group(1)
     names = re.findall(r"(\w+);", re.sub(r"/\*.*?\*/", "", fields, flags=re.S))
     assert names == [f[0] for f in _native.SigSort._fields_]
