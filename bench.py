@@ -108,6 +108,7 @@ def parse():
     ap.add_argument("--only", choices=("c5", "rerank", "e2e", "query"), default=None,
                     help="run just that block (BASELINE config 5 / config 3) and print it as the JSON line: the command the "
                          "per-kernel rocprofv3 --stats summaries under profiles/ are taken with (tools/profile_round.sh)")
+    ap.add_argument("--no-numa", action="store_true", help="N > 1: do not bind the ranks to their GPUs' NUMA nodes")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous, one barrier and the JSON line only - no GPU work (exercises the launcher on a CPU box)")
     ap.add_argument("--backend", default=os.environ.get("LSHRS_BENCH_BACKEND", "nccl"),
@@ -278,8 +279,14 @@ def main() -> None:
             dist.barrier()
             dist.destroy_process_group()
         if int(os.environ.get("RANK", "0")) == 0:
+            # the lane <-> GPU <-> NUMA node <-> CPUs plan the ranks (and the lanes of an in-process multi-device ingest) bind to
+            # (lshrs_amd/numa.py; from sysfs - no GPU is touched here: a box without the topology says "unbound")
+            from lshrs_amd import numa
+
             os.write(real_stdout, (json.dumps({"dry_run": True, "n_gpus": world, "self_launched":
-                                               bool(os.environ.get("LSHRS_BENCH_SELF_LAUNCHED"))}) + "\n").encode())
+                                               bool(os.environ.get("LSHRS_BENCH_SELF_LAUNCHED")),
+                                               "numa_plan": numa.describe_plan(numa.lane_plan(range(world), use_torch=False))})
+                                   + "\n").encode())
         return
     import numpy as np
     import torch
@@ -305,6 +312,13 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local_dev = local_rank % max(1, torch.cuda.device_count())   # (== local_rank on a real N-GPU node)
     torch.cuda.set_device(local_dev)
+    rank_node = None
+    if world > 1 and not args.no_numa:
+        # one process per GPU: this rank's threads (the ones it starts inherit the binding) and the pinned memory it allocates
+        # onto the NUMA node its GPU hangs off - eight ranks feeding eight GPUs over two sockets' PCIe roots
+        from lshrs_amd import numa
+
+        rank_node = numa.bind_current_thread(local_dev)
     dev = torch.device("cuda", local_dev)
     if distributed:
         import torch.distributed as dist
@@ -556,17 +570,66 @@ def main() -> None:
                 result[name] = {"error": f"{type(exc).__name__}: {exc}"}
     elif world > 1 and not args.no_extras:
         # host-fed ingest on every rank at once: what the node's PCIe + host memory give N ranks together
+        def max_over_ranks(seconds):
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
         try:
             hf = bench_host_fed(torch, np, hasher, x, 250_000, barrier=barrier)
-            t = torch.tensor([hf["seconds"]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_max = max_over_ranks(hf["seconds"])
             if rank == 0:
-                hf["value"] = hf["rows"] * world / float(t.item())
+                hf["value"] = hf["rows"] * world / t_max
                 hf["note"] = f"{world} ranks at once, each {hf['rows']} rows from its own host array; whole-node rate, max time over ranks"
                 result["host_fed"] = hf
         except Exception as exc:  # noqa: BLE001
             if rank == 0:
                 result["host_fed"] = {"error": f"{type(exc).__name__}: {exc}"}
+        # ... and what north_star calls ingestion: host vectors -> buckets in a store, (a) every rank into a
+        # store of its own at once, (b) ONE process - rank 0 - driving all N GPUs as lanes of `LSHRS(devices=range(N))` while
+        # the other ranks wait on the CPU (a gloo barrier: an RCCL barrier would spin on their GPUs)
+        try:
+            from lshrs_amd import LSHRS, InMemoryStorage
+
+            rows_e = min(250_000, n)
+            host_e = x[:rows_e].cpu().numpy()
+            ids_e = np.arange(rows_e, dtype=np.int64)
+            idx_e = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(record_batches=False), device=local_dev, packed_ingest=True)
+            idx_e.index(ids_e[:100_000], host_e[:100_000])
+            barrier()
+            cpu0 = time.process_time()
+            t0 = time.perf_counter()
+            idx_e.index(ids_e + 10_000_000, host_e)
+            dt = time.perf_counter() - t0
+            cpu_s = time.process_time() - cpu0
+            t_max = max_over_ranks(dt)
+            if rank == 0:
+                result["e2e_ingest"] = {"per_rank": {
+                    "value": rows_e * world / t_max, "unit": "vectors/s", "rows_per_rank": rows_e, "seconds_max_over_ranks": t_max,
+                    "host_cpu_seconds_per_M_rows": cpu_s / (rows_e / 1e6), "numa_node_of_rank_0": rank_node,
+                    "note": f"{world} ranks at once: LSHRS.index(host rows) -> bucket arrays in a store of the rank's own"}}
+            del idx_e
+            cpu_group = dist.new_group(backend="gloo") if args.backend == "nccl" else None
+            if rank == 0:
+                from lshrs_amd import numa
+
+                lanes = list(range(min(world, torch.cuda.device_count())))
+                multi = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(record_batches=False), devices=lanes, packed_ingest=True)
+                batches = [(ids_e + 100_000_000 * (k + 1), host_e) for k in range(2 * len(lanes))]
+                multi.create_signatures(format="batches", batches=batches[:len(lanes)])          # (lanes' buffers, workspaces)
+                t0 = time.perf_counter()
+                multi.create_signatures(format="batches", batches=batches)
+                dt = time.perf_counter() - t0
+                result["e2e_ingest"]["in_process"] = {
+                    "value": rows_e * len(batches) / dt, "unit": "vectors/s", "lanes": len(lanes), "batches": len(batches), "rows_per_batch": rows_e,
+                    "seconds": dt, "numa_plan": numa.describe_plan(numa.lane_plan(lanes)),
+                    "note": "one process, LSHRS(devices=range(N)).create_signatures: loader batches dealt round-robin to one lane per "
+                            "GPU (thread + pinned blocks on the GPU's NUMA node), stored in batch order; the other ranks idle"}
+                del multi
+            dist.barrier(group=cpu_group)
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                result.setdefault("e2e_ingest", {})["error"] = f"{type(exc).__name__}: {exc}"
 
     # ---------------- CPU baseline (rank 0, N=1 only) ----------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

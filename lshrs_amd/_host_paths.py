@@ -11,7 +11,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from . import _native
+from . import _native, numa
 from ._config import HashSignatures
 from .windows import _U
 
@@ -141,6 +141,7 @@ class _HostPaths:
             def work(i):
                 lo, hi = spans[i]
                 child = self._children[i]
+                numa.bind_current_thread(devs[i])        # (a worker thread of the pool: onto its device's NUMA node)
                 with torch.cuda.device(devs[i]):
                     got = child.hash_batch_packed(arr[lo:hi], return_row_flags=want_flags, chunk_rows=chunk_rows, pin=pin)
                 if want_flags:

@@ -30,7 +30,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from . import _native
+from . import _native, numa
 from .packed_ops import DeviceCSRJob, bucket_csr
 
 _ZERO_BIT = 1
@@ -72,6 +72,7 @@ class CsrIngest:
         self._fail_lock = threading.Lock()
         self.units = 0
         self.chunks = 0
+        self.lane_nodes: dict = {}            # lane -> NUMA node its worker thread was bound to (None: unbound)
 
     # ------------------------------------------------------------------ public
     def __enter__(self) -> "CsrIngest":
@@ -147,6 +148,9 @@ class CsrIngest:
         callback, which first finishes and commits the chunk BEFORE it (whose device work ended a chunk's copy ago)."""
         torch = _native.require_gpu()
         hasher = self._hashers[lane]
+        if not self._inline:        # a lane's own worker thread: onto the CPUs of its GPU's NUMA node, with the pinned blocks it
+            dev = hasher._torch_device()       # allocates from here on (lshrs_amd/numa.py; never the caller's thread)
+            self.lane_nodes[lane] = numa.bind_current_thread(dev.index if dev.index is not None else 0)
         ids, arr = unit.ids, unit.arr
         n = int(ids.shape[0])
         negs = np.flatnonzero(ids < 0)

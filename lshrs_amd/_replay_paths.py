@@ -233,7 +233,7 @@ class _ReplayPaths:
         want = self.stage2_sorted
         if want not in ("auto", "buckets", False):
             raise ValueError("stage2_sorted must be 'auto', 'buckets' or False")
-        if want is False or self.dim <= 128:
+        if want is False or self.dim <= 128 or self.rows_per_band == 1:      # (one-row bands: stage 2 is the sdot replay, one list)
             return None
         padcols = self.num_bands * self.band_bytes * 8
         if padcols > _native.SORT_MAX_COLS:

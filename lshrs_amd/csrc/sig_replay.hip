@@ -476,19 +476,34 @@ __device__ __forceinline__ float small_skx_dot(const float* __restrict__ a, cons
   }
 }
 
+// (Round 6: also stage 2 of the SPLIT pass for bands of one row - stage 1 on the matrix cores, the sdot replay here: the stage-1
+// value of every list entry is measured against the host's (a.flag_y -> slot [2]) and the audit sample of un-flagged projections
+// is verified behind the list (a.audit_list / a.audit_vals -> slots [3] [4] [5]), as sig_fix8_kernel does.)
 __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
   const int lane = threadIdx.x, g = lane & (kFixG - 1), sub = lane >> 3;
   const int cnt = min(*a.flag_count, a.flag_cap);
-  const int groups = (cnt + kFixG - 1) / kFixG;
+  const int fgroups = (cnt + kFixG - 1) / kFixG;
+  const int groups = fgroups + (a.audit_list != nullptr ? (a.audit_n + kFixG - 1) / kFixG : 0);     // audit groups behind the list's
   const size_t ldp = (size_t)a.ktiles * kKTile;
   const int body = a.dim & ~3, m3 = a.dim & 3;
-  int n_ties = 0, n_flips = 0;
+  int n_ties = 0, n_flips = 0, n_aud = 0, n_abad = 0;
+  float max_dev = 0.f, max_ratio = 0.f;
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {     // (uniform per wave)
-    const int e = grp * kFixG + g;
-    const int64_t item = a.flag_list[e < cnt ? e : grp * kFixG];
+    const bool audit = grp >= fgroups;                              // (uniform per wave: a group is the list's or the audit's)
+    const int e = (audit ? grp - fgroups : grp) * kFixG + g;
+    int64_t item;
+    bool inlist;
+    if (!audit) {
+      inlist = e < cnt;
+      item = a.flag_list[inlist ? e : grp * kFixG];
+    } else {
+      item = e < a.audit_n ? a.audit_list[e] : -1;
+      inlist = item >= 0;
+      if (!inlist) item = 0;                                        // (an empty slot: row 0, column 0 - fetched, never used)
+    }
     const int64_t row = item >> 21;
     const int col_raw = (int)(item & ((1 << 21) - 1));
-    const bool live = e < cnt && col_raw < a.padcols;
+    const bool live = inlist && col_raw < a.padcols;
     const int col = col_raw < a.padcols ? col_raw : 0;
     const float* __restrict__ xr = a.X + row * a.ldx;
     const float* __restrict__ pr = a.prow + (size_t)col * ldp;
@@ -584,7 +599,18 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
     float s2 = ss + __shfl(ss, (lane + 32) & 63);
     s2 += __shfl(s2, (lane + 8) & 63);
     s2 += __shfl(s2, (lane + 16) & 63);
-    if (sub == 0 && live) {
+    if (sub == 0 && live && audit) {
+      // a projection stage 1 decided on its own: its key bit must be the sign of the host's value, its stage-1 value within the
+      // window it was compared with; nothing is patched (sig_fix8_kernel's audit)
+      const uint8_t kbyte = a.keys[row * (int64_t)a.row_bytes + (col >> 3)];
+      ++n_aud;
+      if ((y > 0.f) != (((kbyte >> (col & 7)) & 1) != 0)) ++n_abad;
+      const float thr = a.audit_vals[2 * e + 1];
+      if (thr > 0.f) {
+        const float ratio = __builtin_fabsf(a.audit_vals[2 * e] - y) / thr;
+        if (ratio < __builtin_inff()) max_ratio = __builtin_fmaxf(max_ratio, ratio);
+      }
+    } else if (sub == 0 && live) {
       uint8_t* kb = a.keys + row * (int64_t)a.row_bytes + (col >> 3);
       const uintptr_t addr = reinterpret_cast<uintptr_t>(kb);
       unsigned int* w32 = reinterpret_cast<unsigned int*>(addr & ~(uintptr_t)3);
@@ -592,6 +618,13 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
       const bool want = y > 0.f;                                   // (0, -0 and NaN give 0: lsh.py:204)
       const bool have = (*kb >> (col & 7)) & 1;
       if (__builtin_fabsf(y) < a.tau * sqrtf(s2) * a.tie_coef[col]) ++n_ties;
+      if (a.flag_y != nullptr) {                                   // the live margin of stage 1, in the units its window is given in
+        const float scale = sqrtf(s2) * a.norms[col];
+        if (scale > 0.f) {
+          const float dev = __builtin_fabsf(a.flag_y[e] - y) / (scale * 0x1p-24f);
+          if (dev < __builtin_inff()) max_dev = __builtin_fmaxf(max_dev, dev);   // (NaN - a row flagged wholesale - drops out)
+        }
+      }
       if (want != have) {
         ++n_flips;
         if (want) atomicOr(w32, bitmask);
@@ -603,12 +636,19 @@ __global__ __launch_bounds__(64) void sig_fixany_kernel(const FixArgs a) {
   for (int off = 1; off < 8; off <<= 1) {
     n_ties += __shfl_xor(n_ties, off);
     n_flips += __shfl_xor(n_flips, off);
+    max_dev = __builtin_fmaxf(max_dev, __shfl_xor(max_dev, off));
+    n_aud += __shfl_xor(n_aud, off);
+    n_abad += __shfl_xor(n_abad, off);
+    max_ratio = __builtin_fmaxf(max_ratio, __shfl_xor(max_ratio, off));
   }
   if (lane == 0) {
     int* p = a.partials + kFixParts * blockIdx.x;
     p[0] = a.count_ties ? n_ties : 0;
     p[1] = n_flips;
-    p[2] = p[3] = p[4] = p[5] = 0;
+    p[2] = __float_as_int(max_dev);
+    p[3] = n_aud;
+    p[4] = n_abad;
+    p[5] = __float_as_int(max_ratio);
   }
 }
 
@@ -717,7 +757,15 @@ int lshrs_replay_stage2(const FixArgs& f, int32_t* counters, int32_t* host_count
   const dim3 grid((unsigned)(groups < grid_cap ? groups : grid_cap)), block(64);
   if (blas_model != 0) {
     int nparts = (int)grid.x;
-    if (short_rows) {
+    if (rows_per_band == 1) {
+      // a band of ONE row: the host calls sdot - replayed by the plain-load form, at every length (round 6: behind the matrix
+      // cores' stage 1; round 5 had these shapes on the exact-f32 kernel: 0.05 of the HBM roof at 64 x 1 x 100)
+      const int64_t agroups = f.audit_list != nullptr ? ((int64_t)f.audit_n + kFixG - 1) / kFixG : 0;
+      const int64_t want = groups + agroups;
+      const dim3 ogrid((unsigned)(want < kFixGridG ? want : kFixGridG));
+      hipExtLaunchKernelGGL(sig_fixany_kernel, ogrid, block, 0, s, o.ev[2], o.ev[3], 0, f);
+      nparts = (int)ogrid.x;
+    } else if (short_rows) {
       if (blas_general(rows_per_band, f.ktiles, dim))
         hipExtLaunchKernelGGL((sig_fix8_kernel<true, true, kFixSlabShort>), grid, block, 0, s, o.ev[2], o.ev[3], 0, f);
       else

@@ -160,7 +160,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   // BUCKETS (lshrs_sig_sort mode 1): sig16_kernel appends flagged and sampled projections by key column (sig_replay.hip takes
   // them from there): long rows, at most 1024 padded key columns, the replaying stage 2, the caller's scratch given
   const int padcols_all = row_bytes * 8;
-  const bool buckets = !rs.on && blas_model != 0 && o.sort != nullptr && o.sort->mode == 1 && o.sort->thr != nullptr &&
+  const bool buckets = !rs.on && blas_model != 0 && rows_per_band != 1 && o.sort != nullptr && o.sort->mode == 1 && o.sort->thr != nullptr &&
                        padcols_all <= kSortMaxCols && g.ktiles > kFixSlabShort && o.sort->cap / padcols_all >= 64;
   if (buckets) {
     a.tie_list = o.sort->list;
@@ -268,7 +268,9 @@ int lshrs_sig_hash_batch_split_replay_f32(const float* X, int64_t n, int64_t ldx
   // dim % 4 elements of scalar tail: modelled from 9 elements up, model 1 / 2 = how the build compiles them (sig_fixany_kernel);
   // whole groups of four: both builds sum alike, model 1
   const bool tail_ok = dim % 4 != 0 && dim >= 9 && rows_per_band >= 2 && (blas_model == 1 || blas_model == 2);
-  if (!tail_ok && (blas_model != 1 || dim % 4 != 0)) return LSHRS_E_BADARG;
+  // bands of ONE row: the host calls sdot - modelled for both builds at every length (stage 2: sig_fixany_kernel)
+  const bool one_row_ok = rows_per_band == 1 && (blas_model == 1 || blas_model == 2);
+  if (!tail_ok && !one_row_ok && (blas_model != 1 || dim % 4 != 0)) return LSHRS_E_BADARG;
   const int body = dim & ~3;
   if ((dim < 32 && !resident) || (body % 8 != 0 && body > 4096) || counters == nullptr) return LSHRS_E_BADARG;
   return split_pass(X, n, ldx, workspace, num_bands, rows_per_band, dim, keys, nullptr, 0, counters + 0, tau, row_flags,

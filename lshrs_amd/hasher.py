@@ -591,7 +591,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         ("split+replay",           "host BLAS order recognised, >= replay_min_rows rows, shape takes the split pass (>= 256 key columns "
                                    "or 128 .. 224 with dim >= 384 - or at most 256 key columns at dim <= 128 .. 256: the resident-image "
                                    "kernel -, hyperplane norms in range); rows of any length >= 9 (8 m + 4 elements: up to 4096) at any "
-                                   "4-byte address"),
+                                   "4-byte address; bands of one row included (round 6: stage 2 replays the host's sdot)"),
         ("f32+replay",             "host BLAS order recognised: small batches and shapes the split pass does not take - any dim "
                                    "(dim % 4 elements through the library's scalar tail), rows at any 4-byte address"),
         ("host-engine pipelined",  "no recognised BLAS order (or tie_replay='off'), >= 131 072 rows, the host engine exists, a tie window "
@@ -676,8 +676,8 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             return False
         if self.dim % 4 != 0 and not (replay and self.dim >= 9):
             return False              # (a scalar tail: stage 1 shifts it into place, the plain-load replay follows it - from 9 elements)
-        if self.rows_per_band == 1:       # (the host sums a one-row band with sdot: only the plain-load replay follows that)
-            return False
+        if self.rows_per_band == 1 and not replay:      # (the host sums a one-row band with sdot: stage 2 of the REPLAYING pass follows that -
+            return False                                #  round 6; the host-engine routes keep the f32 kernel for such bands)
         body = self.dim & ~3
         if body % 8 != 0 and body > 4096:  # (8 m + 4 elements beyond 4096: the library's short last block - the plain-load replay)
             return False

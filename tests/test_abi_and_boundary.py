@@ -257,8 +257,9 @@ def test_route_table():
         assert LSHHasher(16, 4, 128, seed=1)._route(5_000, "host", aligned=False, short_stride=True, host_rows=False) == ("split+replay", 1)
         assert h._route(1_000_000, "host", aligned=False, short_stride=True, host_rows=False) == ("split+replay", 1)  # a 4-byte offset view (round 5)
         one = LSHHasher(64, 1, 64, seed=1)._route(5_000, "host", **ok)                              # one row per band: NumPy calls sdot -
-        assert one in (("f32+replay", 1), ("f32+replay", 2))                                        # modelled for whole 64 / 32-element steps
-        assert LSHHasher(64, 1, 64, seed=1)._route(1_000_000, "host", **ok) == one                  # (never the split pass)
+        assert one in (("split+replay", 1), ("split+replay", 2))                                    # round 6: stage 1 on the matrix cores, the sdot
+        assert LSHHasher(64, 1, 64, seed=1)._route(1_000_000, "host", **ok) == one                  # replay as its stage 2 (round 5: the f32 kernel)
+        assert LSHHasher(64, 1, 64, seed=1)._route(100, "host", **ok) == ("f32+replay", one[1])     # ... a handful of rows: the f32 kernel
         assert LSHHasher(8, 1, 100, seed=1)._route(5_000, "host", **ok) == one                      # ... at every length (round 5:
         assert LSHHasher(8, 1, 5, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"             #  the elements behind the last whole 32
         assert LSHHasher(8, 1, 1, seed=1)._route(5_000, "host", **ok)[0] == "f32+replay"             #  are summed in a double)

@@ -26,7 +26,18 @@ def test_self_launch_two_ranks_one_json_line():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout                      # ONE line on stdout, whatever gloo prints (it goes to stderr)
-    assert json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "self_launched": True}
+    line = json.loads(lines[0])
+    # (round 6: + the lane <-> GPU <-> NUMA node plan the ranks bind to; this container has no GPUs in sysfs: every lane "unbound")
+    plan = line.pop("numa_plan")
+    assert line == {"dry_run": True, "n_gpus": 2, "self_launched": True}
+    assert [e["lane"] for e in plan] == [0, 1] and all(set(e) == {"lane", "device", "numa_node", "cpus", "bound"} for e in plan)
+
+
+def _line(text: str) -> dict:
+    """The one JSON line without its NUMA plan (checked where it matters)."""
+    d = json.loads([ln for ln in text.splitlines() if ln.strip().startswith("{")][0])
+    d.pop("numa_plan", None)
+    return d
 
 
 def _free_port() -> int:
@@ -43,7 +54,7 @@ def test_world_size_one_in_the_environment_still_launches_n_ranks():
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300,
                          env=dict(_env(), WORLD_SIZE="1"))
     assert out.returncode == 0, out.stderr[-2000:]
-    assert json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0]) == {"dry_run": True, "n_gpus": 2, "self_launched": True}
+    assert _line(out.stdout) == {"dry_run": True, "n_gpus": 2, "self_launched": True}
     out = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120,
                          env=dict(_env(), WORLD_SIZE="2", RANK="0"))
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and out.stdout.strip() == ""
@@ -56,7 +67,7 @@ def test_launcher_form_still_works():
                          capture_output=True, text=True, timeout=300, env=_env())
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 2, "self_launched": False}
+    assert len(lines) == 1 and _line(lines[0]) == {"dry_run": True, "n_gpus": 2, "self_launched": False}
 
 
 def test_a_failing_rank_fails_the_launch_quickly():
@@ -84,11 +95,12 @@ def test_eight_ranks_dry_run_under_every_world_size_the_driver_may_export():
                              env=dict(_env(), **extra))
         assert out.returncode == 0, (label, out.stderr[-2000:])
         lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-        assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "self_launched": True}, (label, out.stdout)
+        assert len(lines) == 1 and _line(lines[0]) == {"dry_run": True, "n_gpus": 8, "self_launched": True}, (label, out.stdout)
+        assert len(json.loads(lines[0])["numa_plan"]) == 8
     # under the driver's own launcher the eight ranks are the launcher's
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "8", "--dry-run"],
                          capture_output=True, text=True, timeout=600, env=_env())
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0]) == {"dry_run": True, "n_gpus": 8, "self_launched": False}
+    assert len(lines) == 1 and _line(lines[0]) == {"dry_run": True, "n_gpus": 8, "self_launched": False}

@@ -310,7 +310,8 @@ def test_bands_of_one_row_replay_the_hosts_sdot(torch_mod, nb, dim, n):
         x[i] = (v - (v @ np.linalg.pinv(pl)) @ pl).astype(np.float32)
     got = h.hash_device(torch.from_numpy(x).cuda())
     st = dict(h.last_stats)
-    assert st["route"] == "f32+replay" and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] > special.size, st
+    # (round 6: where the split pass takes the shape its stage 1 goes first and the sdot replay is its stage 2)
+    assert st["route"] in ("f32+replay", "split+replay") and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] > special.size, st
     want = hash_batch_literal_packed(h.projections, x)
     assert np.array_equal(got.cpu().numpy(), want), int((got.cpu().numpy() != want).any(axis=(1, 2)).sum())
     assert torch.equal(_hasher(17, nb, 1, dim, tie_replay="off").hash_device(torch.from_numpy(x).cuda()), got)

@@ -29,7 +29,8 @@ def _hasher(seed, nb, r, dim, **kw):
 def test_bands_of_one_row_at_lengths_with_a_tail(torch_mod, nb, dim, n):
     """`rows_per_band = 1`: the host calls sdot - the build's SIMD kernel over the whole 32-element steps, the f32 products of the
     elements behind them summed in a DOUBLE, one rounding (round 5, `tb_model_sdot`).  The plain-load replay follows that at
-    every length: route `f32+replay`, true ties included, the reference-literal loop's bytes."""
+    every length, true ties included, the reference-literal loop's bytes - behind the exact-f32 kernel (`f32+replay`: round 5) and,
+    since round 6, as stage 2 of the split pass wherever its stage 1 takes the shape (`split+replay`: the matrix cores first)."""
     torch = torch_mod
     from oracle.lshrs_oracle import hash_batch_literal_packed
 
@@ -46,9 +47,15 @@ def test_bands_of_one_row_at_lengths_with_a_tail(torch_mod, nb, dim, n):
         x[i] = (v - (v @ np.linalg.pinv(pl)) @ pl).astype(np.float32)
     got = h.hash_device(torch.from_numpy(x).cuda())
     st = dict(h.last_stats)
-    assert st["route"] == "f32+replay" and st["tie_break_engine"] == "device-replay" and st["tie_pairs"] >= special.size // 2, st
+    assert st["route"] in ("f32+replay", "split+replay") and st["tie_break_engine"] == "device-replay", st
+    assert st["tie_pairs"] >= special.size // 2, st
+    if st["route"] == "split+replay":           # stage 2 measured stage 1 against the host's sdot on every flagged projection, and audited the rest
+        assert st["flagged"] >= special.size and st["audit_sign_disagreements"] == 0 and st["audited_unflagged"] > 0, st
+        assert 0.0 < st["max_dev_units"] <= h.window_info["window_units_worst_case_row"], st
     want = hash_batch_literal_packed(h.projections, x)
     assert np.array_equal(got.cpu().numpy(), want), int((got.cpu().numpy() != want).any(axis=(1, 2)).sum())
+    f32 = _hasher(19, nb, 1, dim, precision="f32")       # the other route: the same bytes
+    assert torch.equal(f32.hash_device(torch.from_numpy(x).cuda()), got) and f32.last_stats["route"] == "f32+replay"
     assert np.array_equal(h.hash_batch_packed(x[:60]), want[:60])
     assert h.hash_vector(x[special[2]]).as_tuple() == tuple(bytes(kk) for kk in want[special[2]])
 

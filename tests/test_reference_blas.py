@@ -122,7 +122,8 @@ def test_a_named_build_keeps_the_device_route_on_a_host_whose_blas_is_not_recogn
         assert not h._host_blas_agrees()                      # ... and the live audit against NumPy is off: NumPy is another BLAS
         assert LSHHasher(16, 16, 102, seed=42, reference_blas=build)._route(50_000, "host", **ok)[0] == "split+replay"   # (round 5: a scalar tail)
         assert LSHHasher(4, 13, 1001, seed=42, reference_blas=build)._route(50_000, "host", **ok)[0] == "f32+replay"
-        assert LSHHasher(64, 1, 100, seed=42, reference_blas=build)._route(50_000, "host", **ok)[0] == "f32+replay"
+        assert LSHHasher(64, 1, 100, seed=42, reference_blas=build)._route(50_000, "host", **ok)[0] == "split+replay"    # (round 6: one-row bands too)
+        assert LSHHasher(64, 1, 5, seed=42, reference_blas=build)._route(50_000, "host", **ok)[0] == "f32+replay"
 
 
 def test_the_choice_travels_with_the_index(tmp_path):

@@ -102,3 +102,56 @@ def test_round5_experiments_are_gone_and_old_pickles_still_load():
     assert lib.lshrs_query_collide_pairs_i64(None, None, None, 3, 5, 16, None, None, None, None) == -10001
     assert lib.lshrs_query_rank_f32(None, None, None, None, None, None, 3, 5, None, None, None) == -10001
     assert lib.lshrs_cosine_ragged_f32(None, 10, 8, 8, None, 3, None, None, None, 7, None, None, None) == -10001
+
+
+def test_ingest_lanes_are_planned_onto_their_gpus_numa_nodes(tmp_path, monkeypatch):
+    """lane <-> GPU <-> NUMA node <-> CPUs from sysfs (`lshrs_amd/numa.py`), on a fabricated 8-GPU / 2-socket
+    tree; a worker thread binds itself to its node's CPUs (the ones this process may use) and back to another node's when the
+    pool hands it another device; unknown topology = unbound, never an error."""
+    import threading
+
+    from lshrs_amd import numa
+
+    root = tmp_path / "sys"
+    cpus_here = sorted(os.sched_getaffinity(0))
+    half = max(1, len(cpus_here) // 2)
+    node_sets = [cpus_here[:half], cpus_here[half:] or cpus_here[:half]]
+    for node, cpus in enumerate(node_sets):
+        d = root / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    for card in range(8):
+        bdf = f"0000:{0x10 + card:02x}:00.0"
+        pci = root / "bus" / "pci" / "devices" / bdf
+        pci.mkdir(parents=True)
+        (pci / "vendor").write_text("0x1002\n")
+        (pci / "numa_node").write_text(f"{card // 4}\n")
+        drm = root / "class" / "drm" / f"card{card}"
+        drm.mkdir(parents=True)
+        os.symlink(pci, drm / "device")
+        (root / "class" / "drm" / f"card{card}-DP-1").mkdir()
+    monkeypatch.setattr(numa, "SYS_ROOT", str(root))
+    plan = numa.lane_plan(range(8), use_torch=False)
+    assert [e["numa_node"] for e in plan] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert plan[0]["cpus"] == node_sets[0] and plan[7]["cpus"] == sorted(node_sets[1])
+    folded = numa.describe_plan(plan)
+    assert all(e["bound"] for e in folded) and isinstance(folded[0]["cpus"], str)
+    assert numa.gpu_numa_node(8, use_torch=False) is None and numa.lane_plan([9], use_torch=False)[0]["cpus"] == []
+    seen = {}
+
+    def worker():
+        seen["n0"] = numa.bind_current_thread(1, use_torch=False)
+        seen["a0"] = sorted(os.sched_getaffinity(0))
+        seen["n1"] = numa.bind_current_thread(6, use_torch=False)          # the same pool thread, another device
+        seen["a1"] = sorted(os.sched_getaffinity(0))
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen["n0"] == 0 and seen["a0"] == node_sets[0] and seen["n1"] == 1 and seen["a1"] == sorted(node_sets[1])
+    assert sorted(os.sched_getaffinity(0)) == cpus_here                     # the caller's own thread is never touched
+    monkeypatch.setenv("LSHRS_NUMA", "0")
+    assert numa.bind_current_thread(2, use_torch=False) is None
+    monkeypatch.setattr(numa, "SYS_ROOT", str(tmp_path / "nothing"))
+    assert numa.lane_plan([0, 1], use_torch=False) == [{"lane": 0, "device": 0, "numa_node": None, "cpus": []},
+                                                        {"lane": 1, "device": 1, "numa_node": None, "cpus": []}]
