@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-KEEP = ("sig_kernel", "sig16_kernel", "sig16r_kernel", "sig_fixany", "sig_fix8_kernel", "sig_small", "export_", "cosine_kernel", "topk_kernel", "copy", "bucket_")
+KEEP = ("sig_kernel", "sig16_kernel", "sig16r_kernel", "sig_fixany", "sig_fix8_kernel", "sig_small", "export_", "cosine_kernel", "topk_kernel", "copy", "bucket_", "query_")
 args = sys.argv[1:]
 out_json = None
 if args and args[0] == "--json":

@@ -15,6 +15,7 @@ stats bench python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --
 python3 tools/trace_steps.py "$OUT/bench" > "$OUT/bench_kernel_trace_timed_steps.json" 2>> "$OUT/bench_under_rocprof.err"
 stats c5 python3 bench.py --only c5 --no-check
 stats rerank python3 bench.py --only rerank --no-cpu-baseline
+stats query python3 bench.py --only query
 stats short python3 tools/short_shapes.py 1000000 10
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"
 B="SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"
