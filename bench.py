@@ -996,7 +996,7 @@ def floors(result) -> dict:
         ("hash_batch_list_vectors_per_s", ("e2e_ingest", "hash_batch_list_of_HashSignatures", "value"), 300e3),
         ("query_many_top_k_10_queries_per_s", ("e2e_ingest", "query_many", "top_k_10"), 400e3),
         ("query_many_top_p_half_arrays_queries_per_s", ("e2e_ingest", "query_many", "top_p_0.5_arrays"), 300e3),
-        ("small_n_one_vector_us", ("small_n", "gpu_us_per_vector_p50"), None),
+        ("get_top_k_calls_per_s", ("e2e_ingest", "query_many", "one_query_per_call", "get_top_k_10", "calls_per_s"), 8e3),
     )
     out = {}
     for name, path, floor in table:
@@ -1176,6 +1176,21 @@ def bench_query_many(torch, np, x, host_rows, local_dev):
             worst = max(worst, abs(gs - wsc))
             same_ids = same_ids and (gi == wi or abs(gs - wsc) <= 2e-5)
     out["top_p_0.5_vs_reference_literal"] = {"queries": lit, "max_abs_score_diff": worst, "tolerance": 1e-5, "ids_equal_up_to_near_ties": bool(same_ids)}
+    # ONE query per call - the reference's own calling pattern (get_top_k / get_above_p, main.py:524-658): signature kernel + ONE
+    # launch for lookup / count / order / cut (+ rerank and rank launches), one wait, the answer in pinned memory
+    one = {}
+    for label, fn in (("get_top_k_10", lambda v: idx.get_top_k(v, topk=10)), ("get_above_p_0.5", lambda v: idx.get_above_p(v, p=0.5))):
+        for v in q[:100]:
+            fn(v)
+        t0 = time.perf_counter()
+        res = [fn(v) for v in q[:1000]]
+        dt = (time.perf_counter() - t0) / 1000
+        one[label] = {"us_per_call": dt * 1e6, "calls_per_s": 1.0 / dt}
+        if label == "get_top_k_10":
+            one[label]["equal_to_query_many"] = bool(res == got[:1000])
+    one["get_top_k_10"]["cpu_reference_literal_us_per_call"] = 1e6 / out["top_k_10_cpu_reference_literal"]
+    one["get_above_p_0.5"]["cpu_reference_literal_us_per_call"] = 1e6 / out["top_p_0.5_cpu_reference_literal"]
+    out["one_query_per_call"] = one
     return out
 
 

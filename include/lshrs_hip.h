@@ -471,7 +471,8 @@ int lshrs_query_scan_i32(const int32_t* counts, int32_t q, int32_t top_k, double
 
 /* Collision counts and candidate order, one workgroup per query, in LDS.  pair_off int64[q + 1]: the scan of pair_count;
  * max_pairs >= every list (<= LSHRS_QUERY_MAX_PAIRS).  Query qi's candidates - distinct ids over its buckets - are written
- * to cand_ids[pair_off[qi] .. + ucount[qi]) ordered by (-collisions, id), cand_hits (optional) the collisions of each: an id
+ * to cand_ids[pair_off[qi] .. + ucount[qi]) ordered by (-collisions, id) (ucount[qi] = -1: the list is longer than max_pairs -
+ * nothing written), cand_hits (optional) the collisions of each: an id
  * found twice in ONE band's bucket (two segments) counts once there (buckets are sets).  Needs every id < 2^(63 - bits(num_bands)).
  * _index: members read from the segments through lshrs_query_lookup_u8's slots; _pairs: (member, band) pairs handed in flat
  * (query qi's at pair_off[qi]) - for stores that only answer get_bucket (lshrs/storage/redis.py:282). */
@@ -483,6 +484,19 @@ int lshrs_query_collide_pairs_i64(const int64_t* members, const int32_t* bands, 
                                   int32_t max_pairs, int32_t num_bands, int64_t* cand_ids, int32_t* cand_hits,
                                   int32_t* ucount, void* stream);
 
+/* ONE query in ONE launch (behind lshrs_sig_hash_small_replay_f32, whose keys may sit in pinned host memory): lookup, pair
+ * list, collision count and order, and the cut of lshrs_query_scan_i32 (top_k < 0 / top_p < 0: none) by a single workgroup -
+ * LSHRS.get_top_k / get_above_p, the reference's calling pattern (lshrs/core/main.py:524-658), without a size read back in
+ * between.  slot_*: scratch for num_bands * nseg slots; max_pairs: what cand_ids holds (<= LSHRS_QUERY_MAX_PAIRS; a longer list
+ * leaves ucount[0] = -1 and keeps nothing).  Leaves pair_off int64[2] = {0, pairs}, the ordered candidates in cand_ids,
+ * ucount[0], keep[0], out_off int64[2] = {0, keep} (each DEVICE or PINNED HOST memory).  rerank_follows == 0: the first keep ids
+ * go to out_ids and `epoch` to *done_host (optional) behind them; != 0: lshrs_cosine_ragged_f32 and lshrs_query_rank_f32 (q = 1,
+ * with done_host) follow on the same stream - unless nothing is kept: then this launch publishes. */
+int lshrs_query_one_u8(const uint8_t* keys, int32_t num_bands, int32_t band_bytes, const lshrs_bucket_segment* segments,
+                       int32_t nseg, int64_t* slot_start, int32_t* slot_len, int32_t* slot_off, int32_t max_pairs, int32_t top_k,
+                       double top_p, int32_t rerank_follows, int64_t* pair_off, int64_t* cand_ids, int32_t* ucount, int32_t* keep,
+                       int64_t* out_off, int64_t* out_ids, int32_t* done_host, int32_t epoch, void* stream);
+
 /* lshrs_cosine_batch_f32 over ragged candidate lists: query qi's candidates are corpus rows cand_rows[row_off[qi] .. +
  * row_cnt[qi]), their scores land at the same flat positions.  total = entries the lists span (sizes the launch only).
  * err int32[1] (optional, zeroed by the caller): OR of 1 = a candidate of zero norm, 2 = a row outside [0, m), 4 = a query of
@@ -493,10 +507,14 @@ int lshrs_cosine_ragged_f32(const float* corpus, int64_t m, int64_t ldc, int32_t
 
 /* Per query the first keep[qi] candidates in descending score (ties: ascending position in the list; NaN last - the order of
  * lshrs_topk_desc_f32) into the compact arrays out_ids / out_scores at out_off[qi]; lists and scores at pair_off[qi], ucount[qi]
- * long (<= max_candidates <= LSHRS_QUERY_MAX_PAIRS).  scores == NULL: the order the lists already have (out_scores unused). */
+ * long (<= max_candidates <= LSHRS_QUERY_MAX_PAIRS).  scores == NULL: the order the lists already have (out_scores unused).
+ * done_host (optional, q == 1 only; PINNED HOST int32[1]): ONE query - LSHRS.get_top_k / get_above_p, the reference's own calling
+ * pattern - whose sizes the host never reads back in between (fixed capacities: max_pairs / max_candidates = what the buffers
+ * hold; a list beyond them leaves ucount = -1) and whose out_ids / out_scores / offsets may be pinned host memory themselves:
+ * `epoch` is stored to *done_host last, behind a system-scope fence - the host waits with lshrs_wait_done. */
 int lshrs_query_rank_f32(const int64_t* cand_ids, const float* scores, const int64_t* pair_off, const int32_t* ucount,
                          const int32_t* keep, const int64_t* out_off, int32_t q, int32_t max_candidates,
-                         int64_t* out_ids, float* out_scores, void* stream);
+                         int64_t* out_ids, float* out_scores, int32_t* done_host, int32_t epoch, void* stream);
 
 #ifdef __cplusplus
 }

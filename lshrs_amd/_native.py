@@ -163,11 +163,15 @@ def _declare(lib: ctypes.CDLL) -> None:
     # (members, bands, pair_off, q, max_pairs, num_bands, cand_ids, cand_hits, ucount, stream)
     lib.lshrs_query_collide_pairs_i64.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.lshrs_query_collide_pairs_i64.restype = c.c_int
+    # (keys, bands, band_bytes, segments, nseg, slot_start, slot_len, slot_off, max_pairs, top_k, top_p, rerank_follows, pair_off,
+    #  cand_ids, ucount, keep, out_off, out_ids, done_host, epoch, stream)
+    lib.lshrs_query_one_u8.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.lshrs_query_one_u8.restype = c.c_int
     # (corpus, m, ldc, dim, queries, q, cand_rows, row_off, row_cnt, total, scores, err, stream)
     lib.lshrs_cosine_ragged_f32.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp]
     lib.lshrs_cosine_ragged_f32.restype = c.c_int
-    # (cand_ids, scores, pair_off, ucount, keep, out_off, q, max_candidates, out_ids, out_scores, stream)
-    lib.lshrs_query_rank_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    # (cand_ids, scores, pair_off, ucount, keep, out_off, q, max_candidates, out_ids, out_scores, done_host, epoch, stream)
+    lib.lshrs_query_rank_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp]
     lib.lshrs_query_rank_f32.restype = c.c_int
     lib.lshrs_pipe_create.argtypes = [i32, i32, i32, i32, i32]
     lib.lshrs_pipe_create.restype = vp
@@ -207,6 +211,7 @@ EXPORTS = (
     "lshrs_query_scan_i32",
     "lshrs_query_collide_index_i64",
     "lshrs_query_collide_pairs_i64",
+    "lshrs_query_one_u8",
     "lshrs_cosine_ragged_f32",
     "lshrs_query_rank_f32",
     "lshrs_pipe_create",

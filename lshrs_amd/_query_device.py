@@ -23,6 +23,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 from . import _native
+from .windows import _U
 
 __all__ = ["DeviceBuckets", "TooLarge", "candidates_from_index", "candidates_from_pairs", "rank_and_cut"]
 
@@ -216,7 +217,7 @@ def rank_and_cut(lists: _Lists, top_k: Optional[int], top_p: Optional[float], *,
             _native.check(lib.lshrs_query_rank_f32(lists.cand_ids.data_ptr(), scores.data_ptr() if scores is not None else None,
                                                    lists.pair_off.data_ptr(), lists.ucount.data_ptr(), keep.data_ptr(),
                                                    out_off.data_ptr(), nq, lists.max_pairs, out_ids.data_ptr(),
-                                                   out_scores.data_ptr() if out_scores is not None else None, stream),
+                                                   out_scores.data_ptr() if out_scores is not None else None, None, 0, stream),
                           "lshrs_query_rank_f32")
         if scores is not None:
             host = packed[:12 * kept].cpu().numpy()
@@ -227,3 +228,111 @@ def rank_and_cut(lists: _Lists, top_k: Optional[int], top_p: Optional[float], *,
                 raise IndexError("candidate index out of range of the corpus")
             return host[:8 * kept].view(np.int64), host[8 * kept:].view(np.float32), bounds
         return out_ids.cpu().numpy(), None, bounds
+
+
+class OneQuery:
+    """ONE query - ``LSHRS.get_top_k`` / ``get_above_p`` / ``query``, the reference's own calling pattern
+    (lshrs/core/main.py:524-658) - as one chain of launches with NO size read back in between and ONE wait at its end: the
+    vector goes into pinned memory, the one-launch signature kernel leaves its keys there, ``lshrs_query_one_u8`` (lookup, pair
+    list, count, order and cut in one workgroup) [and the rerank + rank launches] follow on the same stream with fixed capacities (``CAP`` pairs: a longer list leaves ``ucount = -1`` and the
+    caller counts on the host), the answer lands in pinned memory and the last kernel publishes an epoch the host polls
+    (``lshrs_wait_done``).  ~60 us against ~250 for the host-counted path.  One query at a time per instance (a lock)."""
+
+    CAP = _native.QUERY_MAX_PAIRS
+
+    def __init__(self, hasher, dev) -> None:
+        torch = _native.require_gpu()
+        self.dev = dev
+        self.lock = threading.Lock()
+        nb, bb, dim = hasher.num_bands, hasher.band_bytes, hasher.dim
+        self.shape = (nb, bb, dim)
+        self.ldx = (dim + 31) // 32 * 32
+        pin = lambda n, dt: torch.zeros(n, dtype=dt).pin_memory()      # noqa: E731
+        self.pin_x = pin(self.ldx, torch.float32)
+        self.pin_keys = pin(max(16, nb * bb), torch.uint8)
+        self.pin_flags = pin(16, torch.uint8)
+        self.pin_i64 = pin(4, torch.int64)                 # [0:2] out_off
+        self.pin_i32 = pin(8, torch.int32)                 # [0] ucount, [1] err, [2] done
+        self.pin_ids = pin(self.CAP, torch.int64)
+        self.pin_scores = pin(self.CAP, torch.float32)
+        self.h_x, self.h_keys, self.h_flags = self.pin_x.numpy(), self.pin_keys.numpy(), self.pin_flags.numpy()
+        self.h_i64, self.h_i32 = self.pin_i64.numpy(), self.pin_i32.numpy()
+        self.h_ids, self.h_scores = self.pin_ids.numpy(), self.pin_scores.numpy()
+        with torch.cuda.device(dev):
+            self.hash_counters = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.pair_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.pair_off = torch.zeros(2, dtype=torch.int64, device=dev)
+            self.keep = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.cand_ids = torch.empty(self.CAP, dtype=torch.int64, device=dev)
+            self.scores = torch.empty(self.CAP, dtype=torch.float32, device=dev)
+            self.slots = None
+        self.epoch = 0
+        p32 = self.pin_i32.data_ptr()
+        self.ptr = dict(x=self.pin_x.data_ptr(), keys=self.pin_keys.data_ptr(), flags=self.pin_flags.data_ptr(),
+                        out_off=self.pin_i64.data_ptr(), ucount=p32, err=p32 + 4, done=p32 + 8, ids=self.pin_ids.data_ptr(),
+                        scores_out=self.pin_scores.data_ptr(), hash_counters=self.hash_counters.data_ptr(),
+                        pair_count=self.pair_count.data_ptr(), pair_off=self.pair_off.data_ptr(), keep=self.keep.data_ptr(),
+                        cand=self.cand_ids.data_ptr(), scores=self.scores.data_ptr())
+
+    @staticmethod
+    def applies(hasher) -> bool:
+        """Where the one-launch signature kernel serves (``LSHHasher._hash_small_locked``'s conditions)."""
+        return (getattr(hasher, "tie_replay", None) == "auto" and getattr(hasher, "tie_break", None) == "host"
+                and hasher.dim % 4 == 0 and 8 <= hasher.dim <= 4096 and hasher.rows_per_band != 1
+                and hasher._replay_model() in (1, 2))
+
+    def run(self, hasher, vec: np.ndarray, desc, nseg: int, max_id: int, top_k: int, top_p: float, corpus):
+        """(number of candidates or -1, ids int64[keep], scores float32[keep] or None, row flag).  ``top_k`` -1 = all,
+        ``top_p`` -1.0 = no rerank."""
+        torch = _native.require_gpu()
+        lib = _native.load()
+        nb, bb, dim = self.shape
+        if max_id >= (1 << (63 - _bbits(nb))):
+            raise TooLarge("member ids do not fit the item layout")
+        dev = self.dev
+        p = self.ptr
+        with self.lock, torch.cuda.device(dev):
+            raw = torch._C._cuda_getCurrentRawStream(dev.index)
+            nslots = nb * nseg
+            if self.slots is None or self.slots[0] < nslots:
+                self.slots = (nslots, torch.empty(max(1, nslots), dtype=torch.int64, device=dev),
+                              torch.empty(max(1, nslots), dtype=torch.int32, device=dev),
+                              torch.empty(max(1, nslots), dtype=torch.int32, device=dev))
+            _, s_start, s_len, s_off = self.slots
+            with hasher._lock:                       # (the hasher's caches: the device image of the hyperplanes, the order model)
+                ws = hasher._workspace(dev)
+                model = hasher._replay_model()
+            self.h_x[:dim] = vec
+            self.h_i32[0] = 0
+            self.h_i32[1] = 0
+            self.epoch = epoch = self.epoch % 0x7FFFFFF0 + 1
+            rc = lib.lshrs_sig_hash_small_replay_f32(p["x"], 1, self.ldx, ws.data_ptr(), nb, hasher.rows_per_band, dim, p["keys"],
+                                                     p["flags"], p["hash_counters"], float(8.0 * _U), model, None, 0, raw)
+            rerank = top_p >= 0.0
+            rc = rc or lib.lshrs_query_one_u8(p["keys"], nb, bb, desc.data_ptr() if desc is not None else None, nseg,
+                                              s_start.data_ptr(), s_len.data_ptr(), s_off.data_ptr(), self.CAP, int(top_k),
+                                              float(top_p), 1 if rerank else 0, p["pair_off"], p["cand"], p["ucount"], p["keep"],
+                                              p["out_off"], p["ids"], p["done"], epoch, raw)
+            if rerank and not rc:
+                rc = lib.lshrs_cosine_ragged_f32(corpus.data_ptr(), int(corpus.shape[0]), int(corpus.stride(0)), dim, p["x"], 1,
+                                                 p["cand"], p["pair_off"], p["ucount"], 4096, p["scores"], p["err"], raw)
+                rc = rc or lib.lshrs_query_rank_f32(p["cand"], p["scores"], p["pair_off"], p["ucount"], p["keep"], p["out_off"], 1,
+                                                    self.CAP, p["ids"], p["scores_out"], p["done"], epoch, raw)
+            if rc:
+                torch.cuda.current_stream(dev).synchronize()
+                _native.check(rc, "the one-query chain")
+            rc = lib.lshrs_wait_done(p["done"], epoch, 2_000_000, raw)
+            if rc:
+                _native.check(rc, "lshrs_wait_done")
+            flag = int(self.h_flags[0])
+            ucount = int(self.h_i32[0])
+            kept = int(self.h_i64[1])
+            err = int(self.h_i32[1])
+            ids = self.h_ids[:kept].copy()
+            scores = self.h_scores[:kept].copy() if rerank else None
+        if rerank and ucount > 0 and not (flag & 1):
+            if err & 5:
+                raise ValueError("Cannot normalize zero vector")
+            if err & 2:
+                raise IndexError("candidate index out of range of the corpus")
+        return ucount, ids, scores, flag

@@ -198,6 +198,7 @@ class LSHRS:
         from ._query_device import DeviceBuckets
 
         self._dev_buckets = DeviceBuckets()  # device mirror of the store's bucket arrays (query_many)
+        self._one_query: Dict[int, Any] = {}    # per device: the pinned / device buffers of the single-query chain
         self._config: Dict[str, Any] = {
             "dim": dim, "num_perm": num_perm, "num_bands": num_bands, "rows_per_band": rows_per_band,
             "similarity_threshold": similarity_threshold, "buffer_size": buffer_size, "seed": seed,
@@ -391,6 +392,9 @@ class LSHRS:
               ) -> Union[List[int], List[Tuple[int, float]]]:
         """Band-collision candidates, optionally reranked by cosine (reference: main.py:524-658)."""
         query_vector = self._check_dim(vector)
+        answered = self._query_one_device(query_vector, top_k, top_p)
+        if answered is not None:
+            return answered
         keys, flag = self._hash_one(query_vector)
         if flag & 1:
             raise ValueError(_ZERO_MSG)
@@ -428,6 +432,58 @@ class LSHRS:
                 raise ValueError("top_k must be greater than zero when provided")
             limit = min(limit, top_k)
         return scored[:limit]
+
+    def _query_one_device(self, query_vector: np.ndarray, top_k, top_p):
+        """:meth:`query` as ONE chain of launches with one wait at its end (``_query_device.OneQuery``: signature kernel, bucket
+        lookup, collision count and order, [rerank on the attached corpus], cut - the answer straight into pinned memory), where
+        the store keeps its buckets as arrays and the hasher's one-launch kernel serves the shape; None: the caller takes the
+        host-counted path (any other store or hasher, a rerank through ``vector_fetch_fn``, a list beyond the kernels' capacity).
+        Errors in the reference's order: zero vector, then - only if there are candidates - the arguments."""
+        from . import _query_device as qd
+
+        h = self._hasher
+        try:
+            if not qd.OneQuery.applies(h):
+                return None
+        except Exception:      # noqa: BLE001 - a hasher of another kind
+            return None
+        bad_p = top_p is not None and not 0 < top_p <= 1
+        rerank = top_p is not None and not bad_p
+        corpus = self._corpus
+        if rerank:
+            torch = __import__("torch")
+            if not (isinstance(corpus, torch.Tensor) and corpus.is_cuda and corpus.dtype == torch.float32 and corpus.dim() == 2
+                    and int(corpus.shape[1]) == self._dim and corpus.stride(1) == 1):
+                return None
+        st = self._storage
+        if isinstance(st, _DeferredStorage):
+            st = st._resolve()
+        segs = st.array_segments(h.band_bytes) if callable(getattr(st, "array_segments", None)) else None
+        if segs is None:
+            return None
+        dev = corpus.device if rerank else h._torch_device()
+        one = self._one_query.get(dev.index)
+        if one is None or one.shape != (h.num_bands, h.band_bytes, h.dim):
+            one = self._one_query[dev.index] = qd.OneQuery(h, dev)
+        try:
+            desc, nseg, max_id = self._dev_buckets.table(segs, dev)
+            k_arg = top_k if (top_k is not None and top_k > 0) else -1
+            ucount, ids, scores, flag = one.run(h, query_vector, desc, nseg, max_id, k_arg, float(top_p) if rerank else -1.0, corpus)
+        except qd.TooLarge:
+            return None
+        if flag & 1:
+            raise ValueError(_ZERO_MSG)
+        if ucount < 0:
+            return None                      # (more pairs than the chain's fixed capacity: counted on the host)
+        if ucount == 0:
+            return []
+        if bad_p:
+            raise ValueError("top_p must be within the range (0, 1]")
+        if top_k is not None and top_k <= 0:
+            raise ValueError("top_k must be greater than zero when provided")
+        if scores is None:
+            return ids.tolist()
+        return list(zip(ids.tolist(), scores.astype(np.float64).tolist()))
 
     def get_top_k(self, vector, topk: int = 10) -> List[int]:
         return list(self.query(vector, top_k=topk, top_p=None))  # type: ignore[arg-type]

@@ -54,17 +54,12 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* items, int P) {
 // (what BucketCSR.codes holds, lshrs_amd/packed_ops.py); the bucket's members are segment.members[start .. start + len).
 // Also the running offset of every slot inside the query's pair list and the list's length.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kQThreads) void query_lookup_kernel(const uint8_t* __restrict__ keys, int nb, int bb,
-                                                                 const Segment* __restrict__ segs, int nseg,
-                                                                 int64_t* __restrict__ slot_start,
-                                                                 int32_t* __restrict__ slot_len,
-                                                                 int32_t* __restrict__ slot_off,
-                                                                 int32_t* __restrict__ pair_count) {
-  __shared__ long long scan[kQThreads];
+// (the body: also the first phase of query_one_kernel.)  Returns the list's length in every thread.
+__device__ __forceinline__ long long lookup_body(const uint8_t* __restrict__ k, int nb, int bb, const Segment* __restrict__ segs,
+                                                 int nseg, int64_t* __restrict__ slot_start, int32_t* __restrict__ slot_len,
+                                                 int32_t* __restrict__ slot_off, long long* scan) {
   const int tid = threadIdx.x;
-  const int qi = blockIdx.x;
   const int nslots = nb * nseg;
-  const uint8_t* __restrict__ k = keys + (int64_t)qi * nb * bb;
   long long carry = 0;
   for (int tile = 0; tile < nslots; tile += kQThreads) {
     const int s = tile + tid;
@@ -84,9 +79,8 @@ __global__ __launch_bounds__(kQThreads) void query_lookup_kernel(const uint8_t* 
         start = sg.offsets[lo];
         len = sg.offsets[lo + 1] - start;
       }
-      const int64_t o = (int64_t)qi * nslots + s;
-      slot_start[o] = start;
-      slot_len[o] = (int32_t)(len > 0x7fffffffLL ? 0x7fffffffLL : len);
+      slot_start[s] = start;
+      slot_len[s] = (int32_t)(len > 0x7fffffffLL ? 0x7fffffffLL : len);
     }
     // inclusive scan of the tile's lengths, then exclusive + carry
     scan[tid] = len;
@@ -99,12 +93,26 @@ __global__ __launch_bounds__(kQThreads) void query_lookup_kernel(const uint8_t* 
     }
     if (s < nslots) {
       const long long ex = carry + scan[tid] - len;
-      slot_off[(int64_t)qi * nslots + s] = (int32_t)(ex > 0x7fffffffLL ? 0x7fffffffLL : ex);
+      slot_off[s] = (int32_t)(ex > 0x7fffffffLL ? 0x7fffffffLL : ex);
     }
     carry += scan[kQThreads - 1];
     __syncthreads();
   }
-  if (tid == 0) pair_count[qi] = (int32_t)(carry > 0x7fffffffLL ? 0x7fffffffLL : carry);
+  return carry;
+}
+
+__global__ __launch_bounds__(kQThreads) void query_lookup_kernel(const uint8_t* __restrict__ keys, int nb, int bb,
+                                                                 const Segment* __restrict__ segs, int nseg,
+                                                                 int64_t* __restrict__ slot_start,
+                                                                 int32_t* __restrict__ slot_len,
+                                                                 int32_t* __restrict__ slot_off,
+                                                                 int32_t* __restrict__ pair_count) {
+  __shared__ long long scan[kQThreads];
+  const int qi = blockIdx.x;
+  const int64_t so = (int64_t)qi * nb * nseg;
+  const long long total = lookup_body(keys + (int64_t)qi * nb * bb, nb, bb, segs, nseg, slot_start + so, slot_len + so,
+                                      slot_off + so, scan);
+  if (threadIdx.x == 0) pair_count[qi] = (int32_t)(total > 0x7fffffffLL ? 0x7fffffffLL : total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,44 +188,36 @@ __global__ __launch_bounds__(kScanThreads) void query_scan_kernel(const int32_t*
 // SRC 0: members fetched from the bucket segments through the lookup's slots; SRC 1: pairs handed in by the host (a storage
 // that only has get_bucket - Redis: main.py:1103).
 // ------------------------------------------------------------------------------------------
+// (the body: items loaded -> the candidates, ordered, at cand_ids[0 .. U) (+ their collisions); also the second phase of
+//  query_one_kernel.)  `so`: this query's slots.  Returns U in every thread.
 template <int SRC>
-__global__ __launch_bounds__(kQThreads) void query_collide_kernel(const Segment* __restrict__ segs, int nseg, int nb,
-                                                                  int bbits, const int64_t* __restrict__ slot_start,
-                                                                  const int32_t* __restrict__ slot_len,
-                                                                  const int32_t* __restrict__ slot_off,
-                                                                  const int64_t* __restrict__ pair_members,
-                                                                  const int32_t* __restrict__ pair_bands,
-                                                                  const int64_t* __restrict__ pair_off,
-                                                                  int64_t* __restrict__ cand_ids,
-                                                                  int32_t* __restrict__ cand_hits,
-                                                                  int32_t* __restrict__ ucount) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t items[];
-  __shared__ int n_dup, n_head;
+__device__ __forceinline__ int collide_body(uint64_t* items, int L, const Segment* __restrict__ segs, int nseg, int nb, int bbits,
+                                            const int64_t* __restrict__ slot_start, const int32_t* __restrict__ slot_len,
+                                            const int32_t* __restrict__ slot_off, const int64_t* __restrict__ pair_members,
+                                            const int32_t* __restrict__ pair_bands, int64_t* __restrict__ cand_ids,
+                                            int32_t* __restrict__ cand_hits, int* n_dup, int* n_head) {
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int qi = blockIdx.x;
-  const int64_t base = pair_off[qi];
-  int L = (int)(pair_off[qi + 1] - base);
-  if (L == 0) {
-    if (tid == 0) ucount[qi] = 0;
-    return;
-  }
   const int P = pow2_ceil(L);
-  if (tid == 0) { n_dup = 0; n_head = 0; }
+  if (tid == 0) { *n_dup = 0; *n_head = 0; }
   if (SRC == 0) {
+    // one THREAD per pair: its slot is the last one whose offset is <= t (a bisection in the slots' running offsets - empty
+    // slots share their offset with the slot behind them, so the last one at or below t is the one that holds t), then one
+    // load of the member.  (A wave per bucket walked the slots one after the other: 32 dependent round trips per wave at
+    // 16 bands x 8 segments - half of this kernel's time, and most of a single query's.)
     const int nslots = nb * nseg;
-    const int64_t so = (int64_t)qi * nslots;
-    for (int s = wave; s < nslots; s += kQWaves) {       // one wave per bucket: its members are one contiguous read
-      const int len = slot_len[so + s];
-      if (len == 0) continue;
-      const int b = s / nseg, g = s - b * nseg;
-      const int64_t* __restrict__ src = segs[g].members + slot_start[so + s];
-      uint64_t* dst = items + slot_off[so + s];
-      for (int e = lane; e < len; e += 64) dst[e] = ((uint64_t)src[e] << bbits) | (uint64_t)b;
+    for (int t = tid; t < L; t += kQThreads) {
+      int lo = 0, hi = nslots;                              // first slot with offset > t
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (slot_off[mid] <= t) lo = mid + 1; else hi = mid;
+      }
+      const int sl = lo - 1;
+      const int b = sl / nseg, g = sl - b * nseg;
+      const int64_t m = segs[g].members[slot_start[sl] + (t - slot_off[sl])];
+      items[t] = ((uint64_t)m << bbits) | (uint64_t)b;
     }
   } else {
-    for (int t = tid; t < L; t += kQThreads)
-      items[t] = ((uint64_t)pair_members[base + t] << bbits) | (uint64_t)pair_bands[base + t];
+    for (int t = tid; t < L; t += kQThreads) items[t] = ((uint64_t)pair_members[t] << bbits) | (uint64_t)pair_bands[t];
   }
   for (int t = L + tid; t < P; t += kQThreads) items[t] = ~0ull;
   bitonic_sort_lds(items, P);
@@ -226,9 +226,9 @@ __global__ __launch_bounds__(kQThreads) void query_collide_kernel(const Segment*
   uint64_t dupmask = 0;        // (P / 256 <= 64 items per thread: one bit each)
   for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
     if (t > 0 && items[t] == items[t - 1]) dupmask |= 1ull << j;
-  if (dupmask) atomicAdd(&n_dup, __builtin_popcountll(dupmask));
+  if (dupmask) atomicAdd(n_dup, __builtin_popcountll(dupmask));
   __syncthreads();
-  const int dups = n_dup;
+  const int dups = *n_dup;
   if (dups) {
     for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
       if ((dupmask >> j) & 1) items[t] = ~0ull;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kQThreads) void query_collide_kernel(const Segment*
   __syncthreads();
   for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
     if ((headmask >> j) & 1) items[t] |= kTopBit;
-  if (headmask) atomicAdd(&n_head, __builtin_popcountll(headmask));
+  if (headmask) atomicAdd(n_head, __builtin_popcountll(headmask));
   __syncthreads();
   // (the band field has done its work: a head keeps its run length - 1 there, read back below by the same thread)
   for (int t = tid, j = 0; t < L; t += kQThreads, ++j)
@@ -264,14 +264,90 @@ __global__ __launch_bounds__(kQThreads) void query_collide_kernel(const Segment*
     items[t] = key;
   }
   bitonic_sort_lds(items, P);
-  const int U = n_head;
+  const int U = *n_head;
   const uint64_t mmask = ((uint64_t)1 << mshift) - 1;
   for (int t = tid; t < U; t += kQThreads) {
     const uint64_t key = items[t];
-    cand_ids[base + t] = (int64_t)(key & mmask);
-    if (cand_hits != nullptr) cand_hits[base + t] = nb - (int)(key >> mshift);
+    cand_ids[t] = (int64_t)(key & mmask);
+    if (cand_hits != nullptr) cand_hits[t] = nb - (int)(key >> mshift);
   }
-  if (tid == 0) ucount[qi] = U;
+  return U;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(kQThreads) void query_collide_kernel(const Segment* __restrict__ segs, int nseg, int nb,
+                                                                  int bbits, const int64_t* __restrict__ slot_start,
+                                                                  const int32_t* __restrict__ slot_len,
+                                                                  const int32_t* __restrict__ slot_off,
+                                                                  const int64_t* __restrict__ pair_members,
+                                                                  const int32_t* __restrict__ pair_bands,
+                                                                  const int64_t* __restrict__ pair_off,
+                                                                  int64_t* __restrict__ cand_ids,
+                                                                  int32_t* __restrict__ cand_hits,
+                                                                  int32_t* __restrict__ ucount, int max_items) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t items[];
+  __shared__ int n_dup, n_head;
+  const int qi = blockIdx.x;
+  const int64_t base = pair_off[qi];
+  const int64_t L64 = pair_off[qi + 1] - base;
+  if (L64 <= 0 || L64 > max_items) {      // nothing to count - or more than the LDS network was sized for (the caller told us its
+    if (threadIdx.x == 0) ucount[qi] = L64 <= 0 ? 0 : -1;    // maximum, or a fixed capacity): -1 says so
+    return;
+  }
+  const int64_t so = (int64_t)qi * nb * nseg;
+  const int U = collide_body<SRC>(items, (int)L64, segs, nseg, nb, bbits, SRC == 0 ? slot_start + so : nullptr,
+                                  SRC == 0 ? slot_len + so : nullptr, SRC == 0 ? slot_off + so : nullptr,
+                                  SRC == 1 ? pair_members + base : nullptr, SRC == 1 ? pair_bands + base : nullptr, cand_ids + base,
+                                  cand_hits != nullptr ? cand_hits + base : nullptr, &n_dup, &n_head);
+  if (threadIdx.x == 0) ucount[qi] = U;
+}
+
+// ------------------------------------------------------------------------------------------
+// ONE query - LSHRS.get_top_k / get_above_p, the reference's own calling pattern (lshrs/core/main.py:524-658) - in ONE
+// workgroup and ONE launch behind the one-launch signature kernel: lookup, pair list, collision count and order, the cut; the
+// ids of a top-k-by-collisions answer go straight into the caller's (pinned) result array and `epoch` into *done behind them;
+// a rerank follows in two more launches (cosine_kernel over the candidates left here, query_rank_kernel, which publishes).
+// A list beyond max_items: ucount = -1, nothing kept - the host counts.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kQThreads) void query_one_kernel(const uint8_t* __restrict__ keys, int nb, int bb, int bbits,
+                                                              const Segment* __restrict__ segs, int nseg,
+                                                              int64_t* __restrict__ slot_start, int32_t* __restrict__ slot_len,
+                                                              int32_t* __restrict__ slot_off, int max_items, int top_k,
+                                                              double top_p, int emit, int64_t* __restrict__ pair_off,
+                                                              int64_t* __restrict__ cand_ids, int32_t* __restrict__ ucount,
+                                                              int32_t* __restrict__ keep, int64_t* __restrict__ out_off,
+                                                              int64_t* __restrict__ out_ids, int* __restrict__ done, int epoch) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t items[];
+  __shared__ long long scan[kQThreads];
+  __shared__ int n_dup, n_head;
+  const int tid = threadIdx.x;
+  const long long total = lookup_body(keys, nb, bb, segs, nseg, slot_start, slot_len, slot_off, scan);
+  int U = 0;
+  if (total > max_items) U = -1;
+  else if (total > 0) {
+    __threadfence_block();          // (the slots were written by other threads of this workgroup: through global memory)
+    __syncthreads();
+    U = collide_body<0>(items, (int)total, segs, nseg, nb, bbits, slot_start, slot_len, slot_off, nullptr, nullptr, cand_ids,
+                        nullptr, &n_dup, &n_head);
+  }
+  const int K = keep_of(U, top_k, top_p);
+  if (tid == 0) {
+    pair_off[0] = 0;
+    pair_off[1] = total > max_items ? 0 : total;
+    ucount[0] = U;
+    keep[0] = K;
+    out_off[0] = 0;
+    out_off[1] = K;
+  }
+  if (emit || K == 0) {            // the answer by collisions (or nothing to rerank): out, and the word the host polls
+    __syncthreads();               // (cand_ids[0 .. U) written by other threads above)
+    for (int t = tid; t < K; t += kQThreads) out_ids[t] = cand_ids[t];
+    if (done != nullptr) {
+      __threadfence_system();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -293,26 +369,33 @@ __global__ __launch_bounds__(kQThreads) void query_rank_kernel(const int64_t* __
                                                                const int32_t* __restrict__ keep,
                                                                const int64_t* __restrict__ out_off,
                                                                int64_t* __restrict__ out_ids,
-                                                               float* __restrict__ out_scores) {
+                                                               float* __restrict__ out_scores, int* __restrict__ done,
+                                                               int epoch) {
   extern __shared__ __attribute__((aligned(16))) uint64_t items[];
   const int tid = threadIdx.x;
   const int qi = blockIdx.x;
   const int K = keep[qi];
-  if (K == 0) return;
-  const int64_t base = pair_off[qi], ob = out_off[qi];
-  if (scores == nullptr) {
-    for (int t = tid; t < K; t += kQThreads) out_ids[ob + t] = cand_ids[base + t];
-    return;
+  if (K > 0) {                                        // (workgroup-uniform)
+    const int64_t base = pair_off[qi], ob = out_off[qi];
+    if (scores == nullptr) {
+      for (int t = tid; t < K; t += kQThreads) out_ids[ob + t] = cand_ids[base + t];
+    } else {
+      const int U = ucount[qi];
+      const int P = pow2_ceil(U);
+      for (int t = tid; t < P; t += kQThreads)
+        items[t] = t < U ? (((uint64_t)desc_key(scores[base + t]) << 32) | (uint32_t)t) : ~0ull;
+      bitonic_sort_lds(items, P);
+      for (int t = tid; t < K; t += kQThreads) {
+        const uint32_t pos = (uint32_t)items[t];
+        out_ids[ob + t] = cand_ids[base + pos];
+        out_scores[ob + t] = scores[base + pos];
+      }
+    }
   }
-  const int U = ucount[qi];
-  const int P = pow2_ceil(U);
-  for (int t = tid; t < P; t += kQThreads)
-    items[t] = t < U ? (((uint64_t)desc_key(scores[base + t]) << 32) | (uint32_t)t) : ~0ull;
-  bitonic_sort_lds(items, P);
-  for (int t = tid; t < K; t += kQThreads) {
-    const uint32_t pos = (uint32_t)items[t];
-    out_ids[ob + t] = cand_ids[base + pos];
-    out_scores[ob + t] = scores[base + pos];
+  if (done != nullptr) {     // ONE query answered straight into pinned host memory: its results first, then the word the host polls
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -365,8 +448,8 @@ int lshrs_query_collide_index_i64(const lshrs_bucket_segment* segments, int32_t 
                                   int32_t* cand_hits, int32_t* ucount, void* stream) {
   if (q == 0) return 0;
   if (pair_off == nullptr || ucount == nullptr || q < 0 || num_bands <= 0 || nseg < 0 || max_pairs < 0) return LSHRS_E_BADARG;
-  if (max_pairs > 0 && (segments == nullptr || slot_start == nullptr || slot_len == nullptr || slot_off == nullptr ||
-                        cand_ids == nullptr))
+  if (max_pairs > 0 && nseg > 0 && (segments == nullptr || slot_start == nullptr || slot_len == nullptr || slot_off == nullptr ||
+                                    cand_ids == nullptr))
     return LSHRS_E_BADARG;
   if (max_pairs > LSHRS_QUERY_MAX_PAIRS || num_bands > 32768) return LSHRS_E_TOOLARGE;
   const size_t shmem = items_bytes(max_pairs);
@@ -374,7 +457,7 @@ int lshrs_query_collide_index_i64(const lshrs_bucket_segment* segments, int32_t 
   if (rc) return rc;
   hipLaunchKernelGGL(query_collide_kernel<0>, dim3((unsigned)q), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const Segment*>(segments), nseg, num_bands, collide_bits(num_bands), slot_start,
-                     slot_len, slot_off, nullptr, nullptr, pair_off, cand_ids, cand_hits, ucount);
+                     slot_len, slot_off, nullptr, nullptr, pair_off, cand_ids, cand_hits, ucount, (int)(shmem / sizeof(uint64_t)));
   return -(int)hipGetLastError();
 }
 
@@ -390,23 +473,58 @@ int lshrs_query_collide_pairs_i64(const int64_t* members, const int32_t* bands, 
   if (rc) return rc;
   hipLaunchKernelGGL(query_collide_kernel<1>, dim3((unsigned)q), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream),
                      nullptr, 0, num_bands, collide_bits(num_bands), nullptr, nullptr, nullptr, members, bands, pair_off,
-                     cand_ids, cand_hits, ucount);
+                     cand_ids, cand_hits, ucount, (int)(shmem / sizeof(uint64_t)));
+  return -(int)hipGetLastError();
+}
+
+int lshrs_query_one_u8(const uint8_t* keys, int32_t num_bands, int32_t band_bytes, const lshrs_bucket_segment* segments,
+                       int32_t nseg, int64_t* slot_start, int32_t* slot_len, int32_t* slot_off, int32_t max_pairs, int32_t top_k,
+                       double top_p, int32_t rerank_follows, int64_t* pair_off, int64_t* cand_ids, int32_t* ucount, int32_t* keep,
+                       int64_t* out_off, int64_t* out_ids, int32_t* done_host, int32_t epoch, void* stream) {
+  if (keys == nullptr || pair_off == nullptr || cand_ids == nullptr || ucount == nullptr || keep == nullptr || out_off == nullptr ||
+      out_ids == nullptr || num_bands <= 0 || band_bytes <= 0 || nseg < 0 || max_pairs <= 0 || top_p > 1.0)
+    return LSHRS_E_BADARG;
+  if (nseg > 0 && (segments == nullptr || slot_start == nullptr || slot_len == nullptr || slot_off == nullptr)) return LSHRS_E_BADARG;
+  if (band_bytes > 6 || num_bands > 32768 || max_pairs > LSHRS_QUERY_MAX_PAIRS || (int64_t)num_bands * nseg > (1 << 24))
+    return LSHRS_E_TOOLARGE;
+  int* done = nullptr;
+  if (done_host != nullptr) {
+    void* dp = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dp, done_host, 0);
+    if (e != hipSuccess || dp == nullptr) return e != hipSuccess ? -(int)e : LSHRS_E_BADARG;
+    done = static_cast<int*>(dp);
+  }
+  const size_t shmem = items_bytes(max_pairs);
+  const int rc = set_lds(reinterpret_cast<const void*>(query_one_kernel), shmem);
+  if (rc) return rc;
+  hipLaunchKernelGGL(query_one_kernel, dim3(1), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream), keys, num_bands,
+                     band_bytes, collide_bits(num_bands), reinterpret_cast<const Segment*>(segments), nseg, slot_start, slot_len,
+                     slot_off, (int)(shmem / sizeof(uint64_t)), top_k, top_p, rerank_follows ? 0 : 1, pair_off, cand_ids, ucount,
+                     keep, out_off, out_ids, done, (int)epoch);
   return -(int)hipGetLastError();
 }
 
 int lshrs_query_rank_f32(const int64_t* cand_ids, const float* scores, const int64_t* pair_off, const int32_t* ucount,
                          const int32_t* keep, const int64_t* out_off, int32_t q, int32_t max_candidates,
-                         int64_t* out_ids, float* out_scores, void* stream) {
+                         int64_t* out_ids, float* out_scores, int32_t* done_host, int32_t epoch, void* stream) {
   if (q == 0) return 0;
   if (cand_ids == nullptr || pair_off == nullptr || ucount == nullptr || keep == nullptr || out_off == nullptr ||
-      out_ids == nullptr || q < 0 || max_candidates < 0 || (scores != nullptr && out_scores == nullptr))
+      out_ids == nullptr || q < 0 || max_candidates < 0 || (scores != nullptr && out_scores == nullptr) ||
+      (done_host != nullptr && q != 1))
     return LSHRS_E_BADARG;
   if (max_candidates > LSHRS_QUERY_MAX_PAIRS) return LSHRS_E_TOOLARGE;
+  int* done = nullptr;
+  if (done_host != nullptr) {
+    void* dp = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dp, done_host, 0);
+    if (e != hipSuccess || dp == nullptr) return e != hipSuccess ? -(int)e : LSHRS_E_BADARG;
+    done = static_cast<int*>(dp);
+  }
   const size_t shmem = scores != nullptr ? items_bytes(max_candidates) : 0;
   const int rc = set_lds(reinterpret_cast<const void*>(query_rank_kernel), shmem);
   if (rc) return rc;
   hipLaunchKernelGGL(query_rank_kernel, dim3((unsigned)q), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream),
-                     cand_ids, scores, pair_off, ucount, keep, out_off, out_ids, out_scores);
+                     cand_ids, scores, pair_off, ucount, keep, out_off, out_ids, out_scores, done, (int)epoch);
   return -(int)hipGetLastError();
 }
 

@@ -366,3 +366,89 @@ def test_errors_are_the_references():
         idx.query_many(q, engine="gpu")
     ids, scores, bounds = idx.query_many(np.empty((0, 32), np.float32), top_p=0.5, corpus=corpus, return_arrays=True)
     assert len(ids) == 0 and len(scores) == 0 and bounds.tolist() == [0]
+
+
+def test_one_query_is_one_chain_of_launches_and_equals_the_reference_flow():
+    """`get_top_k` / `get_above_p` / `query` - the reference's own calling pattern (main.py:524-658) - through
+    `_query_device.OneQuery`: signature kernel, lookup, collide, cut (and the rerank on the attached corpus) enqueued back to
+    back with fixed capacities, ONE wait, the answer in pinned memory.  Against oracle.query_literal: 400 queries (strangers with
+    empty buckets among them), every argument form, the reference's error order, concurrent callers."""
+    import threading
+
+    import torch
+
+    from lshrs_amd import LSHRS, InMemoryStorage
+    from oracle import lshrs_oracle as O
+
+    rng = np.random.default_rng(21)
+    dim, n = 768, 5000
+    data = _clustered(rng, n, dim, 250, 0.3)
+    store = InMemoryStorage()
+    idx = LSHRS(dim=dim, num_perm=256, storage=store, packed_ingest=True)
+    idx.index(np.arange(2500), data[:2500])
+    idx.index(np.arange(2500, n), data[2500:])
+    P = idx._hasher.projections
+    fetch = lambda ids: data[np.asarray(ids)]  # noqa: E731
+    queries = (data[rng.choice(n, 400, replace=False)] + 0.05 * rng.standard_normal((400, dim))).astype(np.float32)
+    queries[::40] = rng.standard_normal((10, dim)).astype(np.float32)
+    calls = []
+    run = idx._query_one_device
+    idx._query_one_device = lambda *a: (calls.append(1), run(*a))[1]
+    got = [idx.get_top_k(q, topk=5) for q in queries]
+    assert calls and idx._one_query, "the single-query chain was not taken"
+    want = [O.query_literal(store, P, dim, q, top_k=5) for q in queries]
+    assert got == want and any(len(w) == 0 for w in want)
+    assert [idx.query(q, top_k=None) for q in queries[:100]] == [O.query_literal(store, P, dim, q, top_k=None) for q in queries[:100]]
+    assert all(type(i) is int for r in got for i in r)
+    # rerank on the attached corpus
+    idx.set_corpus(torch.from_numpy(data).cuda())
+    for q in queries[:120]:
+        for kw in ({"top_k": None, "top_p": 0.5}, {"top_k": 3, "top_p": 1.0}, {"top_k": None, "top_p": 0.01}):
+            _same_ranking(idx.query(q, **kw), O.query_literal(store, P, dim, q, fetch=fetch, **kw))
+    res = idx.get_above_p(queries[1], p=0.5)
+    assert all(type(i) is int and type(s) is float for i, s in res)
+    # errors, in the reference's order: a zero vector first; the arguments only when there are candidates
+    with pytest.raises(ValueError, match="Cannot index zero vector"):
+        idx.get_top_k(np.zeros(dim, np.float32), topk=0)
+    with pytest.raises(ValueError, match="top_k must be greater than zero"):
+        idx.get_top_k(queries[1], topk=0)
+    with pytest.raises(ValueError, match=r"top_p must be within the range \(0, 1\]"):
+        idx.get_above_p(queries[1], p=1.5)
+    with pytest.raises(ValueError, match="top_k must be greater than zero"):
+        idx.query(queries[1], top_k=-2, top_p=0.5)
+    stranger = next(q for q, w in zip(queries, want) if not w)
+    assert idx.get_top_k(stranger, topk=0) == [] and idx.get_above_p(stranger, p=7.0) == []     # (no candidates: nothing is checked)
+    # concurrent callers (the reference's test_concurrency pattern): one chain at a time, every answer right
+    out = [None] * 64
+    def work(j):
+        out[j] = idx.get_top_k(queries[j], topk=5)
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(64)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert out == want[:64]
+    # a store that keeps tuples, a rerank through vector_fetch_fn: the host-counted path answers (same lists)
+    n_calls = len(calls)
+    plain = LSHRS(dim=dim, num_perm=256, storage=InMemoryStorage(), packed_ingest=False, vector_fetch_fn=fetch)
+    plain.index(np.arange(600), data[:600])
+    assert plain.get_top_k(data[5] + 0.01, topk=3) == O.query_literal(plain._storage, P, dim, data[5] + 0.01, top_k=3)
+    _same_ranking(plain.get_above_p(data[5] + 0.01, p=0.5), O.query_literal(plain._storage, P, dim, data[5] + 0.01, top_k=None, top_p=0.5, fetch=fetch))
+    assert not plain._one_query and len(calls) == n_calls
+
+
+def test_one_query_beyond_the_chains_capacity_is_counted_on_the_host():
+    from lshrs_amd import LSHRS, InMemoryStorage
+    from oracle import lshrs_oracle as O
+
+    rng = np.random.default_rng(9)
+    dim = 32
+    base = rng.standard_normal(dim).astype(np.float32)
+    n = 1500                                                             # x 16 bands = 24 000 pairs > 16 384
+    data = (base[None, :] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
+    store = InMemoryStorage()
+    idx = LSHRS(dim=dim, num_perm=64, storage=store, packed_ingest=True)
+    idx.index(np.arange(n), data)
+    assert idx.get_top_k(base, topk=7) == O.query_literal(store, idx._hasher.projections, dim, base, top_k=7)
+    assert idx._one_query                                                 # (the chain ran, said -1, the host counted)
+    assert idx.get_top_k(-base, topk=7) == []
