@@ -58,6 +58,7 @@ class DeviceBuckets:
         self._table = None               # (key, descriptor tensor, views kept alive, largest id)
         self.uploads = 0
         self.upload_bytes = 0
+        self.kept_from_ingest = 0        # segments whose device arrays the ingest left behind (no upload)
 
     def clear(self) -> None:
         with self._lock:
@@ -77,13 +78,18 @@ class DeviceBuckets:
                 for s in segs:
                     v = self._views.get(id(s))
                     if v is None or v[0] is not s or v[1] != dev.index:
-                        codes = torch.from_numpy(np.ascontiguousarray(s.codes, dtype=np.int64)).to(dev)
-                        offsets = torch.from_numpy(np.ascontiguousarray(s.offsets, dtype=np.int64)).to(dev)
-                        members = torch.from_numpy(np.ascontiguousarray(s.members, dtype=np.int64)).to(dev)
                         span = (int(s.members.min()), int(s.members.max())) if s.members.size else (0, -1)
-                        v = (s, dev.index, codes, offsets, members, span)
-                        self.uploads += 1
-                        self.upload_bytes += 8 * (codes.numel() + offsets.numel() + members.numel())
+                        kept = getattr(s, "_dev", None)        # the ingest's own device arrays of this segment (DeviceCSRJob)
+                        if kept is not None and kept[0] == dev and int(kept[1].numel()) == len(s):
+                            v = (s, dev.index, kept[1], kept[2], kept[3], span)
+                            self.kept_from_ingest += 1
+                        else:
+                            codes = torch.from_numpy(np.ascontiguousarray(s.codes, dtype=np.int64)).to(dev)
+                            offsets = torch.from_numpy(np.ascontiguousarray(s.offsets, dtype=np.int64)).to(dev)
+                            members = torch.from_numpy(np.ascontiguousarray(s.members, dtype=np.int64)).to(dev)
+                            v = (s, dev.index, codes, offsets, members, span)
+                            self.uploads += 1
+                            self.upload_bytes += 8 * (codes.numel() + offsets.numel() + members.numel())
                     views[id(s)] = v
                     if v[5][0] < 0:
                         raise TooLarge("negative member id")

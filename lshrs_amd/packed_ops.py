@@ -304,9 +304,15 @@ class DeviceCSRJob:
             _native.check(lib.lshrs_copy_to_host_u8(d.data_ptr(), h.data_ptr(), d.numel() * d.element_size(), stream),
                           "lshrs_copy_to_host_u8")
             d.record_stream(cur)
+        # what a query's bucket lookup needs of this grouping stays ON THE DEVICE (round 6, `_query_device.DeviceBuckets`): the live
+        # codes, the offsets with a leading zero (static shape: entry g + 1 = the end of live bucket g; what lies behind the
+        # live ones is never read) and the members - the store's segment carries them, so the first query after an ingest does
+        # not upload what was here a moment ago (240 MB per 1 M x 16 bands)
+        off_full = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), off_end])
+        self._dev = (dev, safe, off_full, members)
         self.event = torch.cuda.Event()
         self.event.record(cur)
-        for t in (kd, idd, counts, ends, offsets, cursors, members, mask, pos, slot, safe, off_end, kb, n_live, live_out, off_out):
+        for t in (kd, idd, counts, ends, offsets, cursors, members, mask, pos, slot, safe, off_end, kb, n_live, live_out, off_out, off_full):
             t.record_stream(cur)                          # (used on `cur`, perhaps allocated under another stream)
 
     def finish(self) -> BucketCSR:
@@ -340,7 +346,11 @@ class DeviceCSRJob:
                 t()
         csr = BucketCSR(self.bb, bands, kb, codes, offsets, members, self.n, ids_are_distinct(self.ids))
         self._host = None
-        return csr if csr.distinct else dedupe_csr(csr)
+        if csr.distinct:
+            dev, codes_d, off_d, members_d = self._dev
+            csr._dev = (dev, codes_d[:m], off_d[:m + 1], members_d)     # (views: the device copies of exactly these arrays)
+            return csr
+        return dedupe_csr(csr)        # (an id twice in the batch: the segment is rebuilt on the host - and uploaded when a query needs it)
 
 
 def hex_keys_device(keys):

@@ -220,6 +220,10 @@ def test_query_many_on_the_device_equals_the_reference_flow(dim, num_perm, nb, r
     assert (r <= 5 or any(len(w) == 0 for w in lit_all)) and any(len(w) > 5 for w in lit_all)
     got_all = idx.query_many(queries, top_k=None, engine="device")
     assert got_all == lit_all
+    # the device arrays the ingest grouped these buckets into are the ones the lookup reads (keys of 1 or 2 bytes: DeviceCSRJob):
+    # nothing is uploaded for them; wider keys are grouped by a device sort whose result lives on the host: uploaded once
+    mirror = idx._dev_buckets
+    assert (mirror.kept_from_ingest, mirror.uploads) == ((4, 0) if (r + 7) // 8 <= 2 else (0, 4)), (mirror.kept_from_ingest, mirror.uploads)
     assert idx.query_many(queries, top_k=10, engine="device") == [w[:10] for w in lit_all]
     assert idx.query_many(queries, top_k=1, engine="device") == [w[:1] for w in lit_all]
     assert idx.query_many(queries, top_k=None, engine="host") == lit_all
