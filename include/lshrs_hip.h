@@ -484,6 +484,16 @@ int lshrs_query_collide_pairs_i64(const int64_t* members, const int32_t* bands, 
                                   int32_t max_pairs, int32_t num_bands, int64_t* cand_ids, int32_t* cand_hits,
                                   int32_t* ucount, void* stream);
 
+/* The same for ONE query whose pair list is longer than LSHRS_QUERY_MAX_PAIRS (16-bit keys over tens of millions of stored ids:
+ * rare), through global memory: gather, K3's global bitonic network, counts of DISTINCT (member, band) pairs per member, the
+ * network again, the candidates.  slot_start / slot_off: THIS query's slots (lshrs_query_lookup_u8's arrays at qi * num_bands *
+ * nseg); pairs: its pair_count; workspace: lshrs_query_big_workspace_bytes(pairs) bytes, 8-byte aligned; cand_ids (/ cand_hits):
+ * room for `pairs` entries (the query's place in the flat arrays: cand_ids + pair_off[qi]); ucount: int32[1] (ucount + qi). */
+int64_t lshrs_query_big_workspace_bytes(int64_t pairs);
+int lshrs_query_collide_big_i64(const lshrs_bucket_segment* segments, int32_t nseg, int32_t num_bands, const int64_t* slot_start,
+                                const int32_t* slot_off, int64_t pairs, void* workspace, int64_t* cand_ids, int32_t* cand_hits,
+                                int32_t* ucount, void* stream);
+
 /* ONE query in ONE launch (behind lshrs_sig_hash_small_replay_f32, whose keys may sit in pinned host memory): lookup, pair
  * list, collision count and order, and the cut of lshrs_query_scan_i32 (top_k < 0 / top_p < 0: none) by a single workgroup -
  * LSHRS.get_top_k / get_above_p, the reference's calling pattern (lshrs/core/main.py:524-658), without a size read back in
@@ -507,7 +517,8 @@ int lshrs_cosine_ragged_f32(const float* corpus, int64_t m, int64_t ldc, int32_t
 
 /* Per query the first keep[qi] candidates in descending score (ties: ascending position in the list; NaN last - the order of
  * lshrs_topk_desc_f32) into the compact arrays out_ids / out_scores at out_off[qi]; lists and scores at pair_off[qi], ucount[qi]
- * long (<= max_candidates <= LSHRS_QUERY_MAX_PAIRS).  scores == NULL: the order the lists already have (out_scores unused).
+ * long; a list longer than max_candidates (<= LSHRS_QUERY_MAX_PAIRS: the LDS network) is left to the caller (lshrs_topk_desc_f32
+ * ranks it through global memory).  scores == NULL: the order the lists already have (out_scores unused; any length).
  * done_host (optional, q == 1 only; PINNED HOST int32[1]): ONE query - LSHRS.get_top_k / get_above_p, the reference's own calling
  * pattern - whose sizes the host never reads back in between (fixed capacities: max_pairs / max_candidates = what the buffers
  * hold; a list beyond them leaves ucount = -1) and whose out_ids / out_scores / offsets may be pinned host memory themselves:

@@ -163,6 +163,11 @@ def _declare(lib: ctypes.CDLL) -> None:
     # (members, bands, pair_off, q, max_pairs, num_bands, cand_ids, cand_hits, ucount, stream)
     lib.lshrs_query_collide_pairs_i64.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     lib.lshrs_query_collide_pairs_i64.restype = c.c_int
+    lib.lshrs_query_big_workspace_bytes.argtypes = [i64]
+    lib.lshrs_query_big_workspace_bytes.restype = i64
+    # (segments, nseg, bands, slot_start, slot_off, pairs, workspace, cand_ids, cand_hits, ucount, stream)
+    lib.lshrs_query_collide_big_i64.argtypes = [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp]
+    lib.lshrs_query_collide_big_i64.restype = c.c_int
     # (keys, bands, band_bytes, segments, nseg, slot_start, slot_len, slot_off, max_pairs, top_k, top_p, rerank_follows, pair_off,
     #  cand_ids, ucount, keep, out_off, out_ids, done_host, epoch, stream)
     lib.lshrs_query_one_u8.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
@@ -211,6 +216,8 @@ EXPORTS = (
     "lshrs_query_scan_i32",
     "lshrs_query_collide_index_i64",
     "lshrs_query_collide_pairs_i64",
+    "lshrs_query_big_workspace_bytes",
+    "lshrs_query_collide_big_i64",
     "lshrs_query_one_u8",
     "lshrs_cosine_ragged_f32",
     "lshrs_query_rank_f32",

@@ -105,12 +105,13 @@ class _Lists:
     """What the collide step leaves on the device: query i's candidates are ``cand_ids[pair_off[i] : pair_off[i] + ucount[i]]``,
     ordered by (-collisions, id); ``hits`` their collision counts."""
 
-    __slots__ = ("nq", "total", "max_pairs", "pair_off", "cand_ids", "hits", "ucount", "dev", "segments")
+    __slots__ = ("nq", "total", "max_pairs", "pair_off", "cand_ids", "hits", "ucount", "dev", "segments", "big")
 
-    def __init__(self, nq, total, max_pairs, pair_off, cand_ids, hits, ucount, dev, segments=0):
+    def __init__(self, nq, total, max_pairs, pair_off, cand_ids, hits, ucount, dev, segments=0, big=()):
         self.nq, self.total, self.max_pairs = nq, total, max_pairs
         self.pair_off, self.cand_ids, self.hits, self.ucount, self.dev = pair_off, cand_ids, hits, ucount, dev
         self.segments = segments
+        self.big = list(big)             # queries whose pair lists went through global memory (longer than the LDS network)
 
 
 def _scan(torch, lib, counts, nq, dev, stream, top_k=-1, top_p=-1.0, keep_out=None):
@@ -145,17 +146,38 @@ def candidates_from_index(keys_dev, desc, nseg: int, max_id: int, *, want_hits: 
                                                 pair_count.data_ptr(), stream), "lshrs_query_lookup_u8")
         pair_off, totals = _scan(torch, lib, pair_count, nq, dev, stream)
         total, max_pairs = (int(v) for v in totals.cpu().tolist())         # (the one size the host must know: what to allocate)
-        if max_pairs > _native.QUERY_MAX_PAIRS:
-            raise TooLarge(f"a query's buckets hold {max_pairs} members")
+        cap = _native.QUERY_MAX_PAIRS
+        if max_pairs >= (1 << 31) - 1:
+            raise TooLarge(f"a query's buckets hold {max_pairs} members or more")
         cand_ids = torch.empty(max(1, total), dtype=torch.int64, device=dev)
         hits = torch.empty(max(1, total), dtype=torch.int32, device=dev) if want_hits else None
         ucount = torch.empty(nq, dtype=torch.int32, device=dev)
         _native.check(lib.lshrs_query_collide_index_i64(desc.data_ptr() if desc is not None else None, nseg, nb,
                                                         slot_start.data_ptr(), slot_len.data_ptr(), slot_off.data_ptr(),
-                                                        pair_off.data_ptr(), nq, max_pairs, cand_ids.data_ptr(),
+                                                        pair_off.data_ptr(), nq, min(max_pairs, cap), cand_ids.data_ptr(),
                                                         hits.data_ptr() if hits is not None else None, ucount.data_ptr(),
                                                         stream), "lshrs_query_collide_index_i64")
-    return _Lists(nq, total, max_pairs, pair_off, cand_ids, hits, ucount, dev, nseg)
+        big = []
+        if max_pairs > cap:
+            # queries whose buckets hold more members than a workgroup's LDS network takes (the launch above left them ucount =
+            # -1): one at a time through global memory - the same sorts, K3's long-list network (rare: 16-bit keys over tens of
+            # millions of stored ids)
+            counts = pair_count.cpu().numpy()
+            offs = pair_off.cpu().numpy()
+            big = np.flatnonzero(counts > cap).tolist()
+            nbytes = int(lib.lshrs_query_big_workspace_bytes(int(counts.max())))
+            if nbytes < 0:
+                _native.check(nbytes, "lshrs_query_big_workspace_bytes")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            for qi in big:
+                o = int(offs[qi])
+                _native.check(lib.lshrs_query_collide_big_i64(desc.data_ptr(), nseg, nb, slot_start.data_ptr() + 8 * qi * nslots,
+                                                              slot_off.data_ptr() + 4 * qi * nslots, int(counts[qi]), ws.data_ptr(),
+                                                              cand_ids.data_ptr() + 8 * o,
+                                                              hits.data_ptr() + 4 * o if hits is not None else None,
+                                                              ucount.data_ptr() + 4 * qi, stream), "lshrs_query_collide_big_i64")
+            torch.cuda.current_stream(dev).synchronize()            # (the workspace dies with this frame)
+    return _Lists(nq, total, min(max_pairs, cap), pair_off, cand_ids, hits, ucount, dev, nseg, big)
 
 
 def candidates_from_pairs(members: np.ndarray, bands: np.ndarray, pair_off: np.ndarray, num_bands: int, dev, *,
@@ -225,6 +247,21 @@ def rank_and_cut(lists: _Lists, top_k: Optional[int], top_p: Optional[float], *,
                                                    out_off.data_ptr(), nq, lists.max_pairs, out_ids.data_ptr(),
                                                    out_scores.data_ptr() if out_scores is not None else None, None, 0, stream),
                           "lshrs_query_rank_f32")
+        if scores is not None and lists.big and kept:
+            # a candidate list longer than the rank kernel's LDS network (it skipped those queries): K3's global network, per query
+            from .similarity import topk_desc_device
+
+            ucounts = lists.ucount.cpu().numpy()
+            offs = lists.pair_off.cpu().numpy()
+            keeps = np.diff(bounds)
+            for qi in lists.big:
+                u, k_q = int(ucounts[qi]), int(keeps[qi])
+                if u <= _native.QUERY_MAX_PAIRS or k_q == 0:
+                    continue
+                o, ob = int(offs[qi]), int(bounds[qi])
+                order, srt = topk_desc_device(scores[o:o + u].view(1, u), k_q)
+                out_ids[ob:ob + k_q] = lists.cand_ids[o:o + u][order.view(-1).to(torch.int64)]
+                out_scores[ob:ob + k_q] = srt.view(-1)
         if scores is not None:
             host = packed[:12 * kept].cpu().numpy()
             code = int(err.item())

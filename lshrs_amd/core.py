@@ -473,8 +473,14 @@ class LSHRS:
             return None
         if flag & 1:
             raise ValueError(_ZERO_MSG)
-        if ucount < 0:
-            return None                      # (more pairs than the chain's fixed capacity: counted on the host)
+        if ucount < 0:                       # more pairs than the chain's fixed capacity: the batch form, which sizes its arrays
+            try:                             # by what it finds (and takes lists beyond the LDS network through global memory)
+                got = self._query_many_device(query_vector[None], top_k if (top_k is None or top_k > 0) else None,
+                                              top_p if rerank else None, corpus if rerank else None)
+            except qd.TooLarge:
+                return None
+            ids, scores = got[0], got[1]
+            ucount = 1 if len(ids) else 0
         if ucount == 0:
             return []
         if bad_p:
@@ -563,6 +569,8 @@ class LSHRS:
 
         torch = _native.require_gpu()
         nq = arr.shape[0]
+        if arr.strides[0] < arr.shape[1] * 4:            # (`v[None]`: NumPy gives the new axis stride 0 - the kernels take a row stride)
+            arr = arr.reshape(-1).copy().reshape(nq, arr.shape[1])
         if corpus is not None and isinstance(corpus, torch.Tensor) and corpus.is_cuda:
             dev = corpus.device
         else:

@@ -474,6 +474,7 @@ LSHRS_HIDDEN int lshrs_launch_sig16(const lshrs::SigArgs& a, unsigned grid, bool
 LSHRS_HIDDEN int lshrs_launch_sig16r(const lshrs::SigArgs& a, int nct, int kt, unsigned grid, unsigned block, hipStream_t s,
                                      hipEvent_t start, hipEvent_t stop);
 LSHRS_HIDDEN int lshrs_replay_stage2(const lshrs::FixArgs& f, int32_t* counters, int32_t* host_counts, const lshrs::Opts& o, hipStream_t s);
+LSHRS_HIDDEN int lshrs_sort_u64_rows(uint64_t* items, int q, int64_t cpad, hipStream_t s);     // rerank.hip: K3's global network
 LSHRS_HIDDEN uint32_t lshrs_flags_sig16(void);
 LSHRS_HIDDEN uint32_t lshrs_flags_sig16r(void);
 LSHRS_HIDDEN uint32_t lshrs_flags_replay(void);

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kQThreads) void query_rank_kernel(const int64_t* __
                                                                const int64_t* __restrict__ out_off,
                                                                int64_t* __restrict__ out_ids,
                                                                float* __restrict__ out_scores, int* __restrict__ done,
-                                                               int epoch) {
+                                                               int epoch, int max_items) {
   extern __shared__ __attribute__((aligned(16))) uint64_t items[];
   const int tid = threadIdx.x;
   const int qi = blockIdx.x;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kQThreads) void query_rank_kernel(const int64_t* __
     const int64_t base = pair_off[qi], ob = out_off[qi];
     if (scores == nullptr) {
       for (int t = tid; t < K; t += kQThreads) out_ids[ob + t] = cand_ids[base + t];
-    } else {
+    } else if (ucount[qi] <= max_items) {        // (a longer list: ranked through global memory by the caller, lshrs_topk_desc_f32)
       const int U = ucount[qi];
       const int P = pow2_ceil(U);
       for (int t = tid; t < P; t += kQThreads)
@@ -397,6 +397,68 @@ __global__ __launch_bounds__(kQThreads) void query_rank_kernel(const int64_t* __
     __syncthreads();
     if (tid == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// A query whose buckets hold more members than the LDS network takes (LSHRS_QUERY_MAX_PAIRS): the same three steps through
+// global memory, one query at a time (rare: 16-bit keys over tens of millions of stored ids).  gather: items[t] as in
+// collide_body, padded to `cpad` with ~0; sort (K3's global network); mark: every head of a member's run counts the DISTINCT
+// (member, band) pairs of its run (an id twice in one bucket counts once) and becomes (bands - count) << (63 - bbits) | member,
+// everything else ~0; sort; emit.
+// ------------------------------------------------------------------------------------------
+__global__ void query_big_gather_kernel(const Segment* __restrict__ segs, int nseg, int nb, int bbits,
+                                        const int64_t* __restrict__ slot_start, const int32_t* __restrict__ slot_off,
+                                        int64_t L, int64_t cpad, uint64_t* __restrict__ items) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cpad) return;
+  if (t >= L) { items[t] = ~0ull; return; }
+  const int nslots = nb * nseg;
+  int lo = 0, hi = nslots;                                  // first slot with offset > t
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (slot_off[mid] <= t) lo = mid + 1; else hi = mid;
+  }
+  const int sl = lo - 1;
+  const int b = sl / nseg, g = sl - b * nseg;
+  const int64_t m = segs[g].members[slot_start[sl] + (t - slot_off[sl])];
+  items[t] = ((uint64_t)m << bbits) | (uint64_t)b;
+}
+
+__global__ void query_big_mark_kernel(const uint64_t* __restrict__ items, int64_t L, int64_t cpad, int nb, int bbits,
+                                      uint64_t* __restrict__ keyed, int* __restrict__ n_head) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cpad) return;
+  uint64_t key = ~0ull;
+  if (t < L) {
+    const uint64_t it = items[t];
+    const uint64_t member = it >> bbits;
+    if (t == 0 || (items[t - 1] >> bbits) != member) {      // head of the member's run
+      int cnt = 1;
+      uint64_t prev = it;
+      for (int64_t e = t + 1; e < L; ++e) {                 // (a run is at most bands x sources long)
+        const uint64_t nx = items[e];
+        if ((nx >> bbits) != member) break;
+        cnt += nx != prev;
+        prev = nx;
+      }
+      key = ((uint64_t)(nb - cnt) << (63 - bbits)) | member;
+      atomicAdd(n_head, 1);
+    }
+  }
+  keyed[t] = key;
+}
+
+__global__ void query_big_emit_kernel(const uint64_t* __restrict__ keyed, const int* __restrict__ n_head, int nb, int bbits,
+                                      int64_t* __restrict__ cand_ids, int32_t* __restrict__ cand_hits,
+                                      int32_t* __restrict__ ucount) {
+  const int U = *n_head;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *ucount = U;
+  if (t >= U) return;
+  const int mshift = 63 - bbits;
+  const uint64_t key = keyed[t];
+  cand_ids[t] = (int64_t)(key & (((uint64_t)1 << mshift) - 1));
+  if (cand_hits != nullptr) cand_hits[t] = nb - (int)(key >> mshift);
 }
 
 int set_lds(const void* fn, size_t bytes) {
@@ -477,6 +539,44 @@ int lshrs_query_collide_pairs_i64(const int64_t* members, const int32_t* bands, 
   return -(int)hipGetLastError();
 }
 
+static int64_t big_pad(int64_t pairs) {
+  int64_t cpad = 4096;
+  while (cpad < pairs) cpad <<= 1;
+  return cpad;
+}
+
+int64_t lshrs_query_big_workspace_bytes(int64_t pairs) {
+  if (pairs < 0 || pairs > ((int64_t)1 << 31)) return LSHRS_E_TOOLARGE;
+  return 2 * big_pad(pairs) * (int64_t)sizeof(uint64_t) + 16;
+}
+
+int lshrs_query_collide_big_i64(const lshrs_bucket_segment* segments, int32_t nseg, int32_t num_bands, const int64_t* slot_start,
+                                const int32_t* slot_off, int64_t pairs, void* workspace, int64_t* cand_ids, int32_t* cand_hits,
+                                int32_t* ucount, void* stream) {
+  if (segments == nullptr || slot_start == nullptr || slot_off == nullptr || workspace == nullptr || cand_ids == nullptr ||
+      ucount == nullptr || num_bands <= 0 || nseg <= 0 || pairs <= 0 || (reinterpret_cast<uintptr_t>(workspace) & 7))
+    return LSHRS_E_BADARG;
+  if (pairs > ((int64_t)1 << 31) - 1 || num_bands > 32768) return LSHRS_E_TOOLARGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t cpad = big_pad(pairs);
+  uint64_t* items = static_cast<uint64_t*>(workspace);
+  uint64_t* keyed = items + cpad;
+  int* n_head = reinterpret_cast<int*>(keyed + cpad);
+  const int bbits = collide_bits(num_bands);
+  const dim3 grid((unsigned)((cpad + 255) / 256)), block(256);
+  hipError_t e = hipMemsetAsync(n_head, 0, sizeof(int), s);
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(query_big_gather_kernel, grid, block, 0, s, reinterpret_cast<const Segment*>(segments), nseg, num_bands, bbits,
+                     slot_start, slot_off, pairs, cpad, items);
+  int rc = lshrs_sort_u64_rows(items, 1, cpad, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(query_big_mark_kernel, grid, block, 0, s, items, pairs, cpad, num_bands, bbits, keyed, n_head);
+  rc = lshrs_sort_u64_rows(keyed, 1, cpad, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(query_big_emit_kernel, grid, block, 0, s, keyed, n_head, num_bands, bbits, cand_ids, cand_hits, ucount);
+  return -(int)hipGetLastError();
+}
+
 int lshrs_query_one_u8(const uint8_t* keys, int32_t num_bands, int32_t band_bytes, const lshrs_bucket_segment* segments,
                        int32_t nseg, int64_t* slot_start, int32_t* slot_len, int32_t* slot_off, int32_t max_pairs, int32_t top_k,
                        double top_p, int32_t rerank_follows, int64_t* pair_off, int64_t* cand_ids, int32_t* ucount, int32_t* keep,
@@ -524,7 +624,8 @@ int lshrs_query_rank_f32(const int64_t* cand_ids, const float* scores, const int
   const int rc = set_lds(reinterpret_cast<const void*>(query_rank_kernel), shmem);
   if (rc) return rc;
   hipLaunchKernelGGL(query_rank_kernel, dim3((unsigned)q), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream),
-                     cand_ids, scores, pair_off, ucount, keep, out_off, out_ids, out_scores, done, (int)epoch);
+                     cand_ids, scores, pair_off, ucount, keep, out_off, out_ids, out_scores, done, (int)epoch,
+                     (int)(shmem / sizeof(uint64_t)));
   return -(int)hipGetLastError();
 }
 

@@ -277,6 +277,21 @@ inline int64_t topk_pad(int64_t c) {
 }
 }  // namespace
 
+// Ascending sort of every row of a (q, cpad) array of 64-bit items in global memory (cpad a power of two >= kTopkChunk): the
+// network K3 runs for long lists, for the candidate path's lists that do not fit LDS (query.hip).
+int lshrs_sort_u64_rows(uint64_t* items, int q, int64_t cpad, hipStream_t s) {
+  if (q <= 0 || q > 65535 || cpad < kTopkChunk || (cpad & (cpad - 1)) != 0) return LSHRS_E_BADARG;
+  const dim3 half((unsigned)(((cpad >> 1) + 255) / 256), (unsigned)q);
+  const dim3 chunks((unsigned)(cpad / kTopkChunk), (unsigned)q);
+  hipLaunchKernelGGL(topk_local_kernel, chunks, dim3(kTopkThreads), 0, s, items, cpad, (int64_t)kTopkChunk, true);
+  for (int64_t size = 2 * (int64_t)kTopkChunk; size <= cpad; size <<= 1) {
+    for (int64_t stride = size >> 1; stride >= kTopkChunk; stride >>= 1)
+      hipLaunchKernelGGL(topk_global_step_kernel, half, dim3(256), 0, s, items, cpad, size, stride);
+    hipLaunchKernelGGL(topk_local_kernel, chunks, dim3(kTopkThreads), 0, s, items, cpad, size, false);
+  }
+  return -(int)hipGetLastError();
+}
+
 extern "C" {
 
 int lshrs_cosine_batch_f32(const float* corpus, int64_t m, int64_t ldc, int32_t dim, const float* queries, int32_t q,

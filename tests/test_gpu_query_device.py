@@ -321,27 +321,51 @@ def test_stores_with_get_bucket_only_count_on_the_device_too():
             _same_ranking(g, O.query_literal(store, P, dim, q, top_k=None, top_p=0.5, fetch=lambda ids: full[np.asarray(ids)]))
 
 
-def test_lists_beyond_the_lds_network_fall_back_to_the_host_count():
-    """A query whose buckets hold more than LSHRS_QUERY_MAX_PAIRS members: engine="device" says so, "auto" answers through
-    the host count - the same answer."""
+def test_lists_beyond_the_lds_network_go_through_global_memory():
+    """A query whose buckets hold more than LSHRS_QUERY_MAX_PAIRS members (here 24 000 and 320 000 pairs; 1 500 and 20 000 distinct
+    candidates - the second also beyond the rank kernel's network): gathered, sorted, counted and ordered through global memory
+    (`lshrs_query_collide_big_i64`: K3's long-list network), ranked by `lshrs_topk_desc_f32` - the literal flow's answers, in one
+    batch with ordinary queries, through `query_many` and through `get_top_k` / `get_above_p`."""
+    import torch
+
     from lshrs_amd import LSHRS, InMemoryStorage, _native
     from lshrs_amd import _query_device as qd
     from oracle import lshrs_oracle as O
 
+    assert _native.QUERY_MAX_PAIRS == 16384
     rng = np.random.default_rng(9)
     dim = 32
     base = rng.standard_normal(dim).astype(np.float32)
-    n = 1500                                                             # x 16 bands = 24 000 pairs for a query next to `base`
-    data = (base[None, :] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
-    store = InMemoryStorage()
-    idx = LSHRS(dim=dim, num_perm=64, storage=store, packed_ingest=True)
-    idx.index(np.arange(n), data)
-    q = np.stack([base, -base]).astype(np.float32)
+    other = rng.standard_normal((300, dim)).astype(np.float32)
+    for n in (1500, 20_000):
+        near = (base[None, :] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
+        data = np.concatenate([near, other])
+        store = InMemoryStorage()
+        idx = LSHRS(dim=dim, num_perm=64, storage=store, packed_ingest=True)
+        idx.index(np.arange(n), near)
+        idx.index(np.arange(n, n + 300), other)
+        idx.index(np.arange(50), near[:50])                               # ids indexed twice: once per bucket
+        P = idx._hasher.projections
+        q = np.stack([base, -base, other[3] + 0.01, base * 2.0, other[7]]).astype(np.float32)
+        want = [O.query_literal(store, P, dim, v, top_k=7) for v in q]
+        assert len(want[0]) == 7 and idx.query_many(q, top_k=7, engine="device") == want
+        assert idx.last_query_stats["longest_list"] == 16384 and idx.last_query_stats["pairs"] >= 2 * 16 * n
+        assert idx.query_many(q, top_k=None, engine="device") == [O.query_literal(store, P, dim, v, top_k=None) for v in q]
+        assert idx.query_many(q, top_k=7, engine="host") == want
+        corpus = torch.from_numpy(data).cuda()
+        fetch = lambda ids: data[np.asarray(ids)]  # noqa: E731
+        for top_k, top_p in ((None, 0.002), (5, 1.0), (None, 1.0)):
+            got = idx.query_many(q, top_k=top_k, top_p=top_p, corpus=corpus, engine="device")
+            for g, v in zip(got, q):
+                _same_ranking(g, O.query_literal(store, P, dim, v, top_k=top_k, top_p=top_p, fetch=fetch), gap=1e-4)
+        # one query per call: the chain says "beyond my capacity", the batch form answers
+        assert idx.get_top_k(base, topk=7) == want[0] and idx.get_top_k(-base, topk=7) == want[1]
+        idx.set_corpus(corpus)
+        _same_ranking(idx.get_above_p(base, p=0.002), O.query_literal(store, P, dim, base, top_k=None, top_p=0.002, fetch=fetch), gap=1e-4)
+    # pairs handed over by the host (a store with get_bucket only) are not taken beyond the LDS network: the host counts
     with pytest.raises(qd.TooLarge):
-        idx.query_many(q, top_k=5, engine="device")
-    want = [O.query_literal(store, idx._hasher.projections, dim, v, top_k=5) for v in q]
-    assert len(want[0]) == 5 and idx.query_many(q, top_k=5) == want
-    assert _native.QUERY_MAX_PAIRS == 16384
+        qd.candidates_from_pairs(np.zeros(20_000, np.int64), np.zeros(20_000, np.int32), np.array([0, 20_000], np.int64), 16,
+                                 torch.device("cuda", 0))
 
 
 def test_errors_are_the_references():
@@ -439,20 +463,3 @@ def test_one_query_is_one_chain_of_launches_and_equals_the_reference_flow():
     assert plain.get_top_k(data[5] + 0.01, topk=3) == O.query_literal(plain._storage, P, dim, data[5] + 0.01, top_k=3)
     _same_ranking(plain.get_above_p(data[5] + 0.01, p=0.5), O.query_literal(plain._storage, P, dim, data[5] + 0.01, top_k=None, top_p=0.5, fetch=fetch))
     assert not plain._one_query and len(calls) == n_calls
-
-
-def test_one_query_beyond_the_chains_capacity_is_counted_on_the_host():
-    from lshrs_amd import LSHRS, InMemoryStorage
-    from oracle import lshrs_oracle as O
-
-    rng = np.random.default_rng(9)
-    dim = 32
-    base = rng.standard_normal(dim).astype(np.float32)
-    n = 1500                                                             # x 16 bands = 24 000 pairs > 16 384
-    data = (base[None, :] + 1e-4 * rng.standard_normal((n, dim))).astype(np.float32)
-    store = InMemoryStorage()
-    idx = LSHRS(dim=dim, num_perm=64, storage=store, packed_ingest=True)
-    idx.index(np.arange(n), data)
-    assert idx.get_top_k(base, topk=7) == O.query_literal(store, idx._hasher.projections, dim, base, top_k=7)
-    assert idx._one_query                                                 # (the chain ran, said -1, the host counted)
-    assert idx.get_top_k(-base, topk=7) == []
