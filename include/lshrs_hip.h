@@ -445,6 +445,10 @@ typedef struct lshrs_bucket_segment {
   const int64_t* offsets;   /* int64[n_codes + 1] */
   const int64_t* members;   /* int64[offsets[n_codes]]: vector ids, >= 0 */
   int64_t n_codes;
+  const int32_t* directory; /* optional (NULL: bisection): int32[dir_codes + 1], directory[c] = the first bucket whose code is >= c -
+                             * for code spaces small enough to list (num_bands << 8 B codes: keys of 1 or 2 bytes), the lookup is then
+                             * two memory round trips instead of log2(n_codes) */
+  int64_t dir_codes;
 } lshrs_bucket_segment;
 
 /* Longest pair list (members of all its buckets, with multiplicity) - and longest candidate list - ONE query may have for the

@@ -59,6 +59,7 @@ class DeviceBuckets:
         self.uploads = 0
         self.upload_bytes = 0
         self.kept_from_ingest = 0        # segments whose device arrays the ingest left behind (no upload)
+        self.directory_max_codes = 1 << 22      # code spaces up to this size get a dense directory (16 MB of int32 per segment)
 
     def clear(self) -> None:
         with self._lock:
@@ -90,12 +91,25 @@ class DeviceBuckets:
                             v = (s, dev.index, codes, offsets, members, span)
                             self.uploads += 1
                             self.upload_bytes += 8 * (codes.numel() + offsets.numel() + members.numel())
+                    if len(v) == 6:
+                        # keys of 1 or 2 bytes: every possible code listed - directory[c] = the first bucket with code >= c -, built
+                        # once per segment on the device (one searchsorted); the lookup reads it instead of bisecting
+                        directory, dir_codes = None, 0
+                        space = int(s.bands.max() + 1) << (8 * s.band_bytes) if len(s) else 0
+                        if s.band_bytes <= 2 and 0 < space <= self.directory_max_codes:
+                            every = torch.arange(space + 1, dtype=torch.int64, device=dev)
+                            directory = torch.searchsorted(v[2], every).to(torch.int32)
+                            dir_codes = space
+                        v = v + (directory, dir_codes)
                     views[id(s)] = v
                     if v[5][0] < 0:
                         raise TooLarge("negative member id")
                     max_id = max(max_id, v[5][1])
-                    rows.append([v[2].data_ptr(), v[3].data_ptr(), v[4].data_ptr(), int(v[2].numel())])
+                    rows.append([v[2].data_ptr(), v[3].data_ptr(), v[4].data_ptr(), int(v[2].numel()),
+                                 v[6].data_ptr() if v[6] is not None else 0, v[7]])
                 desc = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
+                if rows:
+                    torch.cuda.current_stream(dev).synchronize()
             self._views = views          # (segments the store dropped go with their device copies)
             self._table = (key, desc, views, max_id)
             return desc, len(segs), max_id

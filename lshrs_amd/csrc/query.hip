@@ -21,6 +21,8 @@ struct Segment {   // == lshrs_bucket_segment
   const int64_t* offsets;
   const int64_t* members;
   int64_t n_codes;
+  const int32_t* directory;   // optional: directory[c] = first bucket whose code is >= c, c = 0 .. dir_codes (dense small code spaces)
+  int64_t dir_codes;
 };
 static_assert(sizeof(Segment) == sizeof(lshrs_bucket_segment), "segment descriptor layout");
 
@@ -70,14 +72,24 @@ __device__ __forceinline__ long long lookup_body(const uint8_t* __restrict__ k, 
       int64_t code = (int64_t)b << (8 * bb);
       for (int j = 0; j < bb; ++j) code |= (int64_t)k[b * bb + j] << (8 * j);
       const Segment sg = segs[g];
-      int64_t lo = 0, hi = sg.n_codes;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (sg.codes[mid] < code) lo = mid + 1; else hi = mid;
-      }
-      if (lo < sg.n_codes && sg.codes[lo] == code) {
-        start = sg.offsets[lo];
-        len = sg.offsets[lo + 1] - start;
+      if (sg.directory != nullptr && code < sg.dir_codes) {
+        // a code space small enough to list (keys of 1 or 2 bytes): the bucket's position from a table - two round trips
+        // instead of the twenty of a bisection in a million codes (latency is all this kernel has)
+        const int lo = sg.directory[code];
+        if (lo < sg.directory[code + 1]) {
+          start = sg.offsets[lo];
+          len = sg.offsets[lo + 1] - start;
+        }
+      } else {
+        int64_t lo = 0, hi = sg.n_codes;
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) >> 1;
+          if (sg.codes[mid] < code) lo = mid + 1; else hi = mid;
+        }
+        if (lo < sg.n_codes && sg.codes[lo] == code) {
+          start = sg.offsets[lo];
+          len = sg.offsets[lo + 1] - start;
+        }
       }
       slot_start[s] = start;
       slot_len[s] = (int32_t)(len > 0x7fffffffLL ? 0x7fffffffLL : len);

@@ -56,19 +56,19 @@ def test_loader_refuses_a_build_whose_keys_are_wrong_by_design(tmp_path):
 
 def test_struct_layouts_are_the_headers():
     """The compiler's layout of the header's structs == what the binding builds: `lshrs_sig_sort` (ctypes), and
-    `lshrs_bucket_segment` (ABI 7) - uploaded as rows of four int64 by `lshrs_amd/_query_device.py`."""
+    `lshrs_bucket_segment` (ABI 7) - uploaded as rows of six int64 by `lshrs_amd/_query_device.py`."""
     from lshrs_amd import _native
 
     src = ('#include <stdio.h>\n#include <stddef.h>\n#include "lshrs_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
            "sizeof(lshrs_bucket_segment), offsetof(lshrs_bucket_segment, codes), offsetof(lshrs_bucket_segment, offsets), "
-           "offsetof(lshrs_bucket_segment, members), offsetof(lshrs_bucket_segment, n_codes), sizeof(lshrs_sig_sort), "
+           "offsetof(lshrs_bucket_segment, members), offsetof(lshrs_bucket_segment, n_codes) + 100 * offsetof(lshrs_bucket_segment, directory) + 10000 * offsetof(lshrs_bucket_segment, dir_codes), sizeof(lshrs_sig_sort), "
            "offsetof(lshrs_sig_sort, hist), offsetof(lshrs_sig_sort, thr), offsetof(lshrs_sig_sort, parity)); return 0; }\n")
     exe = os.path.join(ROOT, "oracle", "_build", "struct_layout")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-x", "c", "-", "-I" + os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, check=True)
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     S = _native.SigSort
-    assert got == [32, 0, 8, 16, 24, ctypes.sizeof(S), S.hist.offset, S.thr.offset, S.parity.offset]
+    assert got == [48, 0, 8, 16, 24 + 100 * 32 + 10000 * 40, ctypes.sizeof(S), S.hist.offset, S.thr.offset, S.parity.offset]
     text = open(HEADER).read()
     assert int(re.search(r"#define\s+LSHRS_QUERY_MAX_PAIRS\s+(\d+)", text).group(1)) == _native.QUERY_MAX_PAIRS
     assert "lshrs_sig_chunk_plan" not in text and "chunked_f32" not in text          # (round 6: the chunked pass is gone)
