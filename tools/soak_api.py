@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised differential soak of the public API: LSHRS (HIP hasher + rerank, packed or tuple ingest) against the
+"""(round 6: the queries go through the device candidate path - one-query chain and batch form, store mirrored or read
+bucket by bucket -, half of the rounds with the stored vectors attached as a device corpus.)
+Randomised differential soak of the public API: LSHRS (HIP hasher + rerank, packed or tuple ingest) against the
 reference's flow restated literally (oracle.index_literal / query_literal over a second InMemoryStorage) - sequences of
 index / ingest / delete / get_top_k / get_above_p / query_many with clustered data (real collisions), several shapes.
 Scores are compared to 1e-5, ids exactly wherever adjacent scores are more than 2e-5 apart."""
@@ -66,6 +68,11 @@ def run(rounds: int, seed: int = 2025, steps: int = 30, verbose: bool = True):
                 idx.delete(gone); b_store.remove_indices(gone)
             elif next_id:
                 q = draw(int(rng.integers(1, 40)))
+                if rnd % 4 >= 2:      # (round 6) every other pair of rounds: the stored vectors attached as a device-resident corpus -
+                    import torch      # get_above_p / query_many(top_p=) gather and score on the device, nothing is fetched
+                    if getattr(idx, "_corpus_rows", -1) != next_id:
+                        idx.set_corpus(torch.from_numpy(np.stack([table[i] for i in range(next_id)])).cuda())
+                        idx._corpus_rows = next_id
                 if op == "top_k":
                     k = int(rng.integers(1, 30))
                     got = [idx.get_top_k(v, topk=k) for v in q[:5]]
