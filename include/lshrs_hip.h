@@ -503,13 +503,17 @@ int lshrs_query_collide_big_i64(const lshrs_bucket_segment* segments, int32_t ns
  * LSHRS.get_top_k / get_above_p, the reference's calling pattern (lshrs/core/main.py:524-658), without a size read back in
  * between.  slot_*: scratch for num_bands * nseg slots; max_pairs: what cand_ids holds (<= LSHRS_QUERY_MAX_PAIRS; a longer list
  * leaves ucount[0] = -1 and keeps nothing).  Leaves pair_off int64[2] = {0, pairs}, the ordered candidates in cand_ids,
- * ucount[0], keep[0], out_off int64[2] = {0, keep} (each DEVICE or PINNED HOST memory).  rerank_follows == 0: the first keep ids
+ * ucount[0], keep[0], out_off int64[3] = {0, keep, ucount} (each DEVICE or PINNED HOST memory; out_off is what a host that
+ * polls done_host reads: the launches behind this one take the other three from device memory).  rerank_follows == 0: the first keep ids
  * go to out_ids and `epoch` to *done_host (optional) behind them; != 0: lshrs_cosine_ragged_f32 and lshrs_query_rank_f32 (q = 1,
- * with done_host) follow on the same stream - unless nothing is kept: then this launch publishes. */
+ * with done_host) follow on the same stream - unless nothing is kept: then this launch publishes.  copy_src / copy_dst / copy_n
+ * (optional, copy_n = 0: none): copy_n floats copied by this launch - the query vector from the pinned block it was handed over
+ * in to device memory, for the rerank launch (a workgroup per candidate slice reading it over the link is 25 us of that launch). */
 int lshrs_query_one_u8(const uint8_t* keys, int32_t num_bands, int32_t band_bytes, const lshrs_bucket_segment* segments,
                        int32_t nseg, int64_t* slot_start, int32_t* slot_len, int32_t* slot_off, int32_t max_pairs, int32_t top_k,
                        double top_p, int32_t rerank_follows, int64_t* pair_off, int64_t* cand_ids, int32_t* ucount, int32_t* keep,
-                       int64_t* out_off, int64_t* out_ids, int32_t* done_host, int32_t epoch, void* stream);
+                       int64_t* out_off, int64_t* out_ids, int32_t* done_host, int32_t epoch, const float* copy_src,
+                       float* copy_dst, int32_t copy_n, void* stream);
 
 /* lshrs_cosine_batch_f32 over ragged candidate lists: query qi's candidates are corpus rows cand_rows[row_off[qi] .. +
  * row_cnt[qi]), their scores land at the same flat positions.  total = entries the lists span (sizes the launch only).

@@ -169,8 +169,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.lshrs_query_collide_big_i64.argtypes = [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp]
     lib.lshrs_query_collide_big_i64.restype = c.c_int
     # (keys, bands, band_bytes, segments, nseg, slot_start, slot_len, slot_off, max_pairs, top_k, top_p, rerank_follows, pair_off,
-    #  cand_ids, ucount, keep, out_off, out_ids, done_host, epoch, stream)
-    lib.lshrs_query_one_u8.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    #  cand_ids, ucount, keep, out_off, out_ids, done_host, epoch, copy_src, copy_dst, copy_n, stream)
+    lib.lshrs_query_one_u8.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp]
     lib.lshrs_query_one_u8.restype = c.c_int
     # (corpus, m, ldc, dim, queries, q, cand_rows, row_off, row_cnt, total, scores, err, stream)
     lib.lshrs_cosine_ragged_f32.argtypes = [vp, i64, i64, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp]

@@ -308,8 +308,8 @@ class OneQuery:
         self.pin_x = pin(self.ldx, torch.float32)
         self.pin_keys = pin(max(16, nb * bb), torch.uint8)
         self.pin_flags = pin(16, torch.uint8)
-        self.pin_i64 = pin(4, torch.int64)                 # [0:2] out_off
-        self.pin_i32 = pin(8, torch.int32)                 # [0] ucount, [1] err, [2] done
+        self.pin_i64 = pin(4, torch.int64)                 # out_off: [0] 0, [1] kept, [2] candidates found (-1: beyond the capacity)
+        self.pin_i32 = pin(8, torch.int32)                 # [1] err, [2] done
         self.pin_ids = pin(self.CAP, torch.int64)
         self.pin_scores = pin(self.CAP, torch.float32)
         self.h_x, self.h_keys, self.h_flags = self.pin_x.numpy(), self.pin_keys.numpy(), self.pin_flags.numpy()
@@ -320,16 +320,20 @@ class OneQuery:
             self.pair_count = torch.zeros(1, dtype=torch.int32, device=dev)
             self.pair_off = torch.zeros(2, dtype=torch.int64, device=dev)
             self.keep = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.ucount = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.zero_off = torch.zeros(2, dtype=torch.int64, device=dev)      # (one query: its results start at 0)
+            self.x_dev = torch.zeros(self.ldx, dtype=torch.float32, device=dev)      # the query vector, for the rerank launch
             self.cand_ids = torch.empty(self.CAP, dtype=torch.int64, device=dev)
             self.scores = torch.empty(self.CAP, dtype=torch.float32, device=dev)
             self.slots = None
         self.epoch = 0
         p32 = self.pin_i32.data_ptr()
         self.ptr = dict(x=self.pin_x.data_ptr(), keys=self.pin_keys.data_ptr(), flags=self.pin_flags.data_ptr(),
-                        out_off=self.pin_i64.data_ptr(), ucount=p32, err=p32 + 4, done=p32 + 8, ids=self.pin_ids.data_ptr(),
+                        out_off=self.pin_i64.data_ptr(), ucount=self.ucount.data_ptr(), zero_off=self.zero_off.data_ptr(), err=p32 + 4,
+                        done=p32 + 8, ids=self.pin_ids.data_ptr(),
                         scores_out=self.pin_scores.data_ptr(), hash_counters=self.hash_counters.data_ptr(),
                         pair_count=self.pair_count.data_ptr(), pair_off=self.pair_off.data_ptr(), keep=self.keep.data_ptr(),
-                        cand=self.cand_ids.data_ptr(), scores=self.scores.data_ptr())
+                        cand=self.cand_ids.data_ptr(), scores=self.scores.data_ptr(), x_dev=self.x_dev.data_ptr())
 
     @staticmethod
     def applies(hasher) -> bool:
@@ -360,7 +364,6 @@ class OneQuery:
                 ws = hasher._workspace(dev)
                 model = hasher._replay_model()
             self.h_x[:dim] = vec
-            self.h_i32[0] = 0
             self.h_i32[1] = 0
             self.epoch = epoch = self.epoch % 0x7FFFFFF0 + 1
             rc = lib.lshrs_sig_hash_small_replay_f32(p["x"], 1, self.ldx, ws.data_ptr(), nb, hasher.rows_per_band, dim, p["keys"],
@@ -369,11 +372,12 @@ class OneQuery:
             rc = rc or lib.lshrs_query_one_u8(p["keys"], nb, bb, desc.data_ptr() if desc is not None else None, nseg,
                                               s_start.data_ptr(), s_len.data_ptr(), s_off.data_ptr(), self.CAP, int(top_k),
                                               float(top_p), 1 if rerank else 0, p["pair_off"], p["cand"], p["ucount"], p["keep"],
-                                              p["out_off"], p["ids"], p["done"], epoch, raw)
+                                              p["out_off"], p["ids"], p["done"], epoch, p["x"] if rerank else None,
+                                              p["x_dev"] if rerank else None, dim if rerank else 0, raw)
             if rerank and not rc:
-                rc = lib.lshrs_cosine_ragged_f32(corpus.data_ptr(), int(corpus.shape[0]), int(corpus.stride(0)), dim, p["x"], 1,
+                rc = lib.lshrs_cosine_ragged_f32(corpus.data_ptr(), int(corpus.shape[0]), int(corpus.stride(0)), dim, p["x_dev"], 1,
                                                  p["cand"], p["pair_off"], p["ucount"], 4096, p["scores"], p["err"], raw)
-                rc = rc or lib.lshrs_query_rank_f32(p["cand"], p["scores"], p["pair_off"], p["ucount"], p["keep"], p["out_off"], 1,
+                rc = rc or lib.lshrs_query_rank_f32(p["cand"], p["scores"], p["pair_off"], p["ucount"], p["keep"], p["zero_off"], 1,
                                                     self.CAP, p["ids"], p["scores_out"], p["done"], epoch, raw)
             if rc:
                 torch.cuda.current_stream(dev).synchronize()
@@ -382,7 +386,7 @@ class OneQuery:
             if rc:
                 _native.check(rc, "lshrs_wait_done")
             flag = int(self.h_flags[0])
-            ucount = int(self.h_i32[0])
+            ucount = int(self.h_i64[2])
             kept = int(self.h_i64[1])
             err = int(self.h_i32[1])
             ids = self.h_ids[:kept].copy()

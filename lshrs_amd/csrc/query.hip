@@ -328,11 +328,16 @@ __global__ __launch_bounds__(kQThreads) void query_one_kernel(const uint8_t* __r
                                                               double top_p, int emit, int64_t* __restrict__ pair_off,
                                                               int64_t* __restrict__ cand_ids, int32_t* __restrict__ ucount,
                                                               int32_t* __restrict__ keep, int64_t* __restrict__ out_off,
-                                                              int64_t* __restrict__ out_ids, int* __restrict__ done, int epoch) {
+                                                              int64_t* __restrict__ out_ids, int* __restrict__ done, int epoch,
+                                                              const float* __restrict__ copy_src, float* __restrict__ copy_dst,
+                                                              int copy_n) {
   extern __shared__ __attribute__((aligned(16))) uint64_t items[];
   __shared__ long long scan[kQThreads];
   __shared__ int n_dup, n_head;
   const int tid = threadIdx.x;
+  // the query vector from pinned host memory into device memory, once, for the rerank launch behind this one (128 workgroups
+  // reading it over the link each cost that launch 25 us)
+  for (int k = tid; k < copy_n; k += kQThreads) copy_dst[k] = copy_src[k];
   const long long total = lookup_body(keys, nb, bb, segs, nseg, slot_start, slot_len, slot_off, scan);
   int U = 0;
   if (total > max_items) U = -1;
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(kQThreads) void query_one_kernel(const uint8_t* __r
     keep[0] = K;
     out_off[0] = 0;
     out_off[1] = K;
+    out_off[2] = U;             // (for the host: candidates found, -1 = beyond the capacity - out_off is where it looks)
   }
   if (emit || K == 0) {            // the answer by collisions (or nothing to rerank): out, and the word the host polls
     __syncthreads();               // (cand_ids[0 .. U) written by other threads above)
@@ -592,7 +598,9 @@ int lshrs_query_collide_big_i64(const lshrs_bucket_segment* segments, int32_t ns
 int lshrs_query_one_u8(const uint8_t* keys, int32_t num_bands, int32_t band_bytes, const lshrs_bucket_segment* segments,
                        int32_t nseg, int64_t* slot_start, int32_t* slot_len, int32_t* slot_off, int32_t max_pairs, int32_t top_k,
                        double top_p, int32_t rerank_follows, int64_t* pair_off, int64_t* cand_ids, int32_t* ucount, int32_t* keep,
-                       int64_t* out_off, int64_t* out_ids, int32_t* done_host, int32_t epoch, void* stream) {
+                       int64_t* out_off, int64_t* out_ids, int32_t* done_host, int32_t epoch, const float* copy_src,
+                       float* copy_dst, int32_t copy_n, void* stream) {
+  if (copy_n < 0 || (copy_n > 0 && (copy_src == nullptr || copy_dst == nullptr))) return LSHRS_E_BADARG;
   if (keys == nullptr || pair_off == nullptr || cand_ids == nullptr || ucount == nullptr || keep == nullptr || out_off == nullptr ||
       out_ids == nullptr || num_bands <= 0 || band_bytes <= 0 || nseg < 0 || max_pairs <= 0 || top_p > 1.0)
     return LSHRS_E_BADARG;
@@ -612,7 +620,7 @@ int lshrs_query_one_u8(const uint8_t* keys, int32_t num_bands, int32_t band_byte
   hipLaunchKernelGGL(query_one_kernel, dim3(1), dim3(kQThreads), shmem, static_cast<hipStream_t>(stream), keys, num_bands,
                      band_bytes, collide_bits(num_bands), reinterpret_cast<const Segment*>(segments), nseg, slot_start, slot_len,
                      slot_off, (int)(shmem / sizeof(uint64_t)), top_k, top_p, rerank_follows ? 0 : 1, pair_off, cand_ids, ucount,
-                     keep, out_off, out_ids, done, (int)epoch);
+                     keep, out_off, out_ids, done, (int)epoch, copy_src, copy_dst, (int)copy_n);
   return -(int)hipGetLastError();
 }
 

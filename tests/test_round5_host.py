@@ -98,7 +98,7 @@ def test_round5_experiments_are_gone_and_old_pickles_still_load():
     lib = _native.load()
     assert lib.lshrs_query_lookup_u8(None, 5, 16, 2, None, 0, None, None, None, None, None) == -10001
     assert lib.lshrs_query_lookup_u8(None, 0, 16, 2, None, 0, None, None, None, None, None) == 0
-    assert lib.lshrs_query_one_u8(None, 16, 2, None, 0, None, None, None, 16384, -1, -1.0, 0, None, None, None, None, None, None, None, 0, None) == -10001
+    assert lib.lshrs_query_one_u8(None, 16, 2, None, 0, None, None, None, 16384, -1, -1.0, 0, None, None, None, None, None, None, None, 0, None, None, 0, None) == -10001
     assert lib.lshrs_query_scan_i32(None, 5, -1, -1.0, None, None, None, None) == -10001
     assert lib.lshrs_query_collide_big_i64(None, 1, 16, None, None, 20000, None, None, None, None, None) == -10001
     assert lib.lshrs_query_big_workspace_bytes(20000) == 2 * 32768 * 8 + 16 and lib.lshrs_query_big_workspace_bytes(-1) < 0
