@@ -125,6 +125,9 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
                   Haswell .., AMD Zen 1 - 3); `LSHHasher.host_blas_name()` says which one THIS process's NumPy runs.
                   The choice travels with `LSHRS.save_to_disk` / pickle.  Every shape is modelled on both builds (bands of
                   two rows or more over fewer than 9 elements: the SkylakeX build's small-matrix kernels, model 3).
+      (attributes, settable after construction)  ``spin_wait_us`` (2 000): how long a synchronous ``hash_device`` polls the pinned
+                  `done` word of its launch before it sleeps on the stream (0: always the stream); ``audit_min_interval_s`` (0.05):
+                  the live audit of ``audit_every`` runs at most this often, however short the batches are
       devices     in-process multi-device ingestion: host batches of >= 32 768 rows per device are cut into one row slice
                   per entry, hashed concurrently (one thread + hasher per entry), keys returned in row order
     """

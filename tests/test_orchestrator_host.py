@@ -294,6 +294,27 @@ def test_query_many_equals_looping_query(monkeypatch):
                 assert [i for i, _ in a] == [i for i, _ in b]
                 assert np.allclose([s for _, s in a], [s for _, s in b], atol=1e-6)
     assert idx.query_many(np.empty((0, 32), dtype=np.float32)) == []
+    # the array form (round 6): ids / scores / bounds carry exactly the lists; engines other than the host's need the HIP hasher
+    for kw in ({"top_k": 5, "top_p": None}, {"top_k": None, "top_p": 0.5}, {"top_k": 2, "top_p": 1.0}):
+        lists = idx.query_many(queries, **kw)
+        ids, scores, bounds = idx.query_many(queries, return_arrays=True, **kw)
+        assert ids.dtype == np.int64 and bounds.dtype == np.int64 and bounds.shape == (26,) and bounds[0] == 0 and bounds[-1] == len(ids)
+        if kw["top_p"] is None:
+            assert scores is None and [ids[bounds[i]:bounds[i + 1]].tolist() for i in range(25)] == lists
+        else:
+            assert scores.dtype == np.float32 and len(scores) == len(ids)
+            assert [list(zip(ids[bounds[i]:bounds[i + 1]].tolist(), scores[bounds[i]:bounds[i + 1]].astype(np.float64).tolist()))
+                    for i in range(25)] == lists
+    e_ids, e_scores, e_bounds = idx.query_many(np.empty((0, 32), dtype=np.float32), top_p=0.5, return_arrays=True)
+    assert len(e_ids) == 0 and len(e_scores) == 0 and e_bounds.tolist() == [0]
+    with pytest.raises(RuntimeError, match="HIP hasher"):
+        idx.query_many(queries, engine="device")
+    with pytest.raises(ValueError, match="engine must be"):
+        idx.query_many(queries, engine="gpu")
+    idx.set_corpus(data)                                     # (a host array: the host engine's rerank takes it like a tensor)
+    with pytest.raises(ValueError, match="corpus must have shape"):
+        idx.set_corpus(np.zeros((5, 31), np.float32))
+    idx.set_corpus(None)
     with pytest.raises(ValueError, match="zero vector"):
         idx.query_many(np.zeros((2, 32), dtype=np.float32))
     with pytest.raises(ValueError, match="shape"):
