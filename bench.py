@@ -610,7 +610,8 @@ def main() -> None:
                     "note": f"{world} ranks at once: LSHRS.index(host rows) -> bucket arrays in a store of the rank's own"}}
             del idx_e
             cpu_group = dist.new_group(backend="gloo") if args.backend == "nccl" else None
-            if rank == 0:
+            try:
+              if rank == 0:
                 from lshrs_amd import numa
 
                 lanes = list(range(min(world, torch.cuda.device_count())))
@@ -626,7 +627,10 @@ def main() -> None:
                     "note": "one process, LSHRS(devices=range(N)).create_signatures: loader batches dealt round-robin to one lane per "
                             "GPU (thread + pinned blocks on the GPU's NUMA node), stored in batch order; the other ranks idle"}
                 del multi
-            dist.barrier(group=cpu_group)
+            except Exception as exc:  # noqa: BLE001 - rank 0's own leg: the others are waiting at the barrier below either way
+                result["e2e_ingest"]["in_process"] = {"error": f"{type(exc).__name__}: {exc}"}
+            finally:
+                dist.barrier(group=cpu_group)
         except Exception as exc:  # noqa: BLE001
             if rank == 0:
                 result.setdefault("e2e_ingest", {})["error"] = f"{type(exc).__name__}: {exc}"
