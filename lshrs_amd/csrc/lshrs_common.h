@@ -413,6 +413,8 @@ constexpr int kFixGridG = LSHRS_FIX_GRID;    // 256 CUs x 6 resident single-wave
 // workgroups per CU) and a grid of up to 2 048 let every group of a short list be in flight at once - the list of a 1 M x 128
 // batch (15 k flagged + 4 k audited) takes one round trip instead of two and a half (17 -> ~9 us)
 constexpr int kFixSlabShort = 4;
+constexpr int kHalfMaxTiles = 11;   // sig16_kernel: vectors of up to this many k-tiles take 128-row workgroups, two per CU (sig_split.hip: sig16_half_rows)
+constexpr int kHalfMaxGroups = 128; // ... and so do batches of up to this many 256-row workgroups (half of the CUs would have none)
 constexpr int kFixGridShort = 2048;
 static_assert(LSHRS_SIG_COUNTERS + kFixParts * kFixGridShort <= LSHRS_SIG_DEVICE_COUNTERS, "stage 2's per-workgroup slots must fit the counter block");
 constexpr int kSortMaxCols = 1024;       // the column-sorted stage 2 (lshrs_sig_sort) takes hashers of up to this many padded key columns
@@ -469,7 +471,7 @@ inline bool sig_shape_ok(int32_t num_bands, int32_t rows, int32_t dim) {
 }  // namespace lshrs
 
 // ---- entry points one translation unit offers another (hidden: not part of the C ABI)
-LSHRS_HIDDEN int lshrs_launch_sig16(const lshrs::SigArgs& a, unsigned grid, bool compact, bool partial, hipStream_t s, hipEvent_t start,
+LSHRS_HIDDEN int lshrs_launch_sig16(const lshrs::SigArgs& a, unsigned grid, bool compact, bool partial, bool half, hipStream_t s, hipEvent_t start,
                                     hipEvent_t stop);
 LSHRS_HIDDEN int lshrs_launch_sig16r(const lshrs::SigArgs& a, int nct, int kt, unsigned grid, unsigned block, hipStream_t s,
                                      hipEvent_t start, hipEvent_t stop);

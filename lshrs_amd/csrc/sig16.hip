@@ -15,27 +15,44 @@ namespace {
 #ifndef LSHRS_X_AUX
 #define LSHRS_X_AUX 0              // cache policy of stage 1's x loads (A/B builds: 2 = nt)
 #endif
-constexpr int kS1ListCap = 8192;   // flagged projections a workgroup stages in LDS before its ONE global append
+// flagged projections a workgroup stages in LDS before its ONE global append: 8192 for the 256-row workgroup, 4096 for the 128-row one
 // COMPACT: the column blocks hold the bands' key columns side by side (sig_compact) - list entries and keys leave through
 // the tables; a template parameter so that the padded layout's kernel is instruction for instruction what it was.
 // PARTIAL: vectors that are not whole 32-element k-tiles (300-d, 100-d; round 5: any length, 301-d, 767-d) - in the last k-tile
 // the 16-byte chunks that reach past a row's end are fetched from the row's last four elements instead (never a byte past the
 // row): the chunk that holds the row's last dim % 4 elements is shifted into place when it is read back, the ones behind it
 // read as zero.  Rows may start at any 4-byte address (the LDS-DMA takes it: tools/probes/lds_dma_align_probe.hip).
-template <bool COMPACT, bool PARTIAL = false>
-__global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
-  constexpr int RT = 2, W = 8;
+// W: waves of a workgroup = 32 W rows.  W = 8: one workgroup per CU (the ring is 144 KiB).  W = 4 (round 6, vectors of up to
+// ~512 elements): TWO workgroups of 128 rows per CU, each with its own fragment ring and a two-deep x ring (80 KiB: the x
+// tile a k-tile's second stage reads into registers is free again two stages before the tile after next lands in its place) -
+// independent barriers, so one workgroup's prologue, epilogue and dispatch run under the other one's k-tiles, which at ten
+// to sixteen k-tiles is 20-28 % of a 256-row workgroup's time.  Twice the fragment traffic from L2, the same x traffic, the
+// same instruction schedule per wave, the same accumulation.
+template <bool COMPACT, bool PARTIAL = false, int W = 8>
+__global__ __launch_bounds__(64 * W, 8 / W) void sig16_kernel(const SigArgs args) {
+  constexpr int RT = 2;
+  constexpr int kRows = 32 * W;                   // rows of a workgroup
+  constexpr int kXDepth = W == 8 ? 3 : 2;         // x tiles in the ring
+  constexpr int kS1ListCap = W == 8 ? 8192 : 4096;
   constexpr int kWaveRows = 16 * RT;
   constexpr int kPP = 16 / W;                     // fragment pieces a wave stages per stage
   constexpr int kXPS = RT;                        // x pieces a wave stages per stage (2 RT per k-tile)
   constexpr int kE = 6 * RT;                      // MFMAs per eighth: 2 column tiles x 3 terms x RT row tiles
   constexpr int kSlices = 12 * RT;                // split slices per k-tile: 4 RT pairs x 3 steps
   constexpr int kPHalf = 16 * kFragFloats;        // floats of one fragment stage (16 blocks of 1 KiB)
-  constexpr int kXTile = 256 * kKTile;            // floats of one x tile of the workgroup
+  constexpr int kXTile = kRows * kKTile;          // floats of one x tile of the workgroup
   constexpr int kXWave = kWaveRows * kKTile;
-  constexpr int kRingFloats = 3 * kPHalf + 3 * kXTile;
+  constexpr int kRingFloats = 3 * kPHalf + kXDepth * kXTile;
+  constexpr int kIssues = (kPP + kXPS) / 2;       // DMA instructions a wave issues under each of a stage's last two eighths
+  constexpr int kIssueStep = kE / kIssues;
+  static_assert((kPP + kXPS) % 2 == 0 && kE % kIssues == 0, "DMA issue slots");
   static_assert(3 * kS1ListCap <= kRingFloats, "the epilogue's list stage reuses the ring");
-  __shared__ __attribute__((aligned(16))) float lds[kRingFloats + 512 + 4];     // + two windows per row + list counters
+  // the epilogue's tables: behind the list stage in the ring; the rows' two windows and the list counters behind the ring where
+  // one workgroup owns the CU, inside it (behind the sign words) where two share it: 80 KiB each, to the byte
+  constexpr int kTabOff = 3 * kS1ListCap;
+  constexpr int kWndOff = W == 8 ? kRingFloats : kTabOff + 768 + kRows * 8;
+  static_assert(kWndOff + 2 * kRows + 4 <= (W == 8 ? kRingFloats + 512 + 4 : kRingFloats), "windows and counters");
+  __shared__ __attribute__((aligned(16))) float lds[W == 8 ? kRingFloats + 512 + 4 : kRingFloats];
   struct Bf16Pairs { bf16x2 p[4]; };
 
   const int tid = threadIdx.x;
@@ -51,7 +68,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   // lane au_lane, slot au_q of that word's eight values
   int au_slot = -1, au_rw = -1, au_lane = 0, au_q = 0;
   if (args.audit_list != nullptr) {
-    const unsigned u = (unsigned)bid * 8u + (unsigned)wave;
+    const unsigned u = (unsigned)bid * (unsigned)W + (unsigned)wave;
     if ((int)(u % (unsigned)args.audit_div) == args.audit_phase) {
       const unsigned h = audit_hash(u, args.audit_seed);
       au_slot = (int)(u / (unsigned)args.audit_div);
@@ -60,14 +77,14 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
       au_lane = (int)((h >> 7) & 63u);
     }
   }
-  if ((int64_t)row_tile * 256 >= args.n) {           // (whole workgroup: the grid is padded to a multiple of 8 row tiles)
+  if ((int64_t)row_tile * kRows >= args.n) {           // (whole workgroup: the grid is padded to a multiple of 8 row tiles)
     if (au_slot >= 0 && lane == 0) args.audit_list[au_slot] = -1;
     return;
   }
   const int ktiles = args.ktiles;
   const int stages = 2 * ktiles, lasts = stages - 1;
   const char* img = reinterpret_cast<const char*>(args.image) + (size_t)cb * ktiles * 32768;
-  const int64_t blk_row0 = (int64_t)row_tile * 256;
+  const int64_t blk_row0 = (int64_t)row_tile * kRows;
   const int64_t row0 = blk_row0 + wave * kWaveRows;
   const char* xblk = reinterpret_cast<const char*>(args.X + blk_row0 * args.ldx);
 
@@ -77,7 +94,8 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   // conflict-free for ds_read_b128's 16-lane groups.
   unsigned poff[kPP], xfo[2 * RT], xrd[RT][2];
 #pragma unroll
-  for (int q = 0; q < kPP; ++q) poff[q] = (unsigned)(((W * q + wave) * 64 + lane) * 16);
+  for (int q = 0; q < kPP; ++q) poff[q] = (unsigned)(((W * (W == 8 ? q : 0) + wave) * 64 + lane) * 16);
+  // (W = 4: one offset in a register, piece d is W d KiB behind it on both sides - four would not fit beside the accumulators)
   {
     const int r8 = lane >> 3, q8 = lane & 7;
 #pragma unroll
@@ -127,20 +145,20 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     f.xg = xblk + (size_t)t * (kKTile * 4);
     f.pdst = lds + (ns % 3) * kPHalf + wave * kFragFloats;
     f.j0 = kXPS * (s & 1);
-    f.xdst = lds + 3 * kPHalf + (nt % 3) * kXTile + wave * kXWave + f.j0 * kFragFloats;
+    f.xdst = lds + 3 * kPHalf + (nt % kXDepth) * kXTile + wave * kXWave + f.j0 * kFragFloats;
     return f;
   };
   auto issue = [&](const Dma& f, int d) {
     if constexpr (!PARTIAL) {
       if (d < kPP)
-        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + W * d * kFragFloats),
-                                         16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + (W == 8 ? poff[d] : poff[0] + (unsigned)(W * d * 1024))),
+                                         (LDS_AS void*)(f.pdst + W * d * kFragFloats), 16, 0, 0);
       else
         __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.xg + (f.j0 ? xfo[kXPS + d - kPP] : xfo[d - kPP])),
                                          (LDS_AS void*)(f.xdst + (d - kPP) * kFragFloats), 16, 0, LSHRS_X_AUX);
     } else if (d < kPP) {
-      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + poff[d]), (LDS_AS void*)(f.pdst + W * d * kFragFloats),
-                                       16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(f.pg + (W == 8 ? poff[d] : poff[0] + (unsigned)(W * d * 1024))),
+                                       (LDS_AS void*)(f.pdst + W * d * kFragFloats), 16, 0, 0);
     } else {
       // branch-free (a branch here changes where hipcc joins the accumulator tiles around the inline-asm MFMAs): in the last
       // k-tile a chunk that is not wholly inside the row is fetched from the row's last four elements instead; this lane's
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   };
   f32x4 xr[RT][2];                           // raw f32 x of one k-tile: [row tile][chunk]
   auto read_x = [&](int t) {
-    const char* xt = reinterpret_cast<const char*>(lds + 3 * kPHalf + (t % 3) * kXTile + wave * kXWave);
+    const char* xt = reinterpret_cast<const char*>(lds + 3 * kPHalf + (t % kXDepth) * kXTile + wave * kXWave);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -212,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   // four accumulator tiles of the eighth take turns, so two MFMAs on the same tile are four instructions (64 cycles)
   // apart.  (Two apart - tile order (j, term, rt) - the result of a 4-pass MFMA is not back in time and hipcc pads every
   // other MFMA with an s_nop: 33 per k-tile and wave.)  Every tile still sees its terms in the order 0, 1, 2.
-  auto mfma_one = [&](int ct0, int k, const f32x4 (&f)[2][2], const Bf16Pairs (&hi)[RT], const Bf16Pairs (&mid)[RT]) {
+  auto mfma_one = [&](int ct0, int k, const f32x4 (&f)[2][2], const Bf16Pairs (&hi)[RT], const Bf16Pairs (&mid)[RT], const bool drain = false) {
     const int term = k / (2 * RT), j = (k / RT) % 2, rt = k % RT;
     const bf16x8 a = __builtin_bit_cast(bf16x8, term == 2 ? mid[rt] : hi[rt]);
     const bf16x8 b = __builtin_bit_cast(bf16x8, f[j][term == 1 ? 1 : 0]);
@@ -222,7 +240,11 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
 #ifdef LSHRS_T16_BUILTIN
     acc[rt][ct0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[rt][ct0 + j], 0, 0, 0);
 #else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[rt][ct0 + j]) : "v"(a), "v"(b));
+    // drain (behind the last barrier, where the two ends of the tile loop join): the wait states are PART of the statement -
+    // hipcc may move accumulator tiles between registers at the join, and as two statements it put those moves between
+    // the MFMA and its wait states (round 6, odd k-tile counts: the live audit fired; tools/check_mfma_hazards.py looks for it)
+    if (drain) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 4" : "+a"(acc[rt][ct0 + j]) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[rt][ct0 + j]) : "v"(a), "v"(b));
 #endif
   };
 
@@ -269,7 +291,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     for (int k = 0; k < kE; ++k) {
       mfma_one(8 * ch + 2, k, fb, hc, mc);
       if (ch == 1 && k % 3 != 2) split_step((k / 3) * 2 + k % 3, hn, mn);          // first third of the next tile's split
-      if (k % 6 == 0) issue(f, k / 6);
+      if (k % kIssueStep == 0) issue(f, k / kIssueStep);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     for (int k = 0; k < kE; ++k) {
       mfma_one(8 * ch + 4, k, fa, hc, mc);
       if (ch == 1 && k % 3 != 2) split_step(kSlices / 3 + (k / 3) * 2 + k % 3, hn, mn);   // second third
-      if (k % 6 == 0) issue(f, kE / 6 + k / 6);
+      if (k % kIssueStep == 0) issue(f, kIssues + k / kIssueStep);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -309,7 +331,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   // VALU arbitration (priority, then age) on every stage; one s_setprio for that half, no flips (MI355X_MICROARCH.md, "Two
   // waves per SIMD", item 4).  Same box, interleaved, four pairs: +0.2 .. +0.9 % (profiles/r03_static_prio_ab.log).
 #ifndef LSHRS_AB_NO_STATIC_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if (W == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
   issue_prologue();
   zero_tile_state();
@@ -327,10 +349,10 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   if (t < ktiles) {                                                      // even number of k-tiles: one more, then drain with its set
     tile(t, false, hs1, ms1, hs0, ms0);
 #pragma unroll
-    for (int k = 0; k < kE; ++k) { mfma_one(14, k, fb, hs1, ms1); asm volatile("s_nop 7\n\ts_nop 4"); }
+    for (int k = 0; k < kE; ++k) mfma_one(14, k, fb, hs1, ms1, true);
   } else {
 #pragma unroll
-    for (int k = 0; k < kE; ++k) { mfma_one(14, k, fb, hs0, ms0); asm volatile("s_nop 7\n\ts_nop 4"); }
+    for (int k = 0; k < kE; ++k) mfma_one(14, k, fb, hs0, ms0, true);
   }
   // (the wait states after every MFMA of the drain: where the two branches join hipcc may copy accumulator tiles, and
   //  it does not know that the asm in front of such a copy is an MFMA whose result takes passes to arrive)
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   asm volatile("" : "+v"(r16e), "+v"(ge), "+v"(lanee));
   int64_t* l_list = reinterpret_cast<int64_t*>(lds);
   float* l_y = lds + 2 * kS1ListCap;
-  int* l_count = reinterpret_cast<int*>(lds + kRingFloats + 512);   // [0] staged + overflowed entries, [1] global base
+  int* l_count = reinterpret_cast<int*>(lds + kWndOff + 2 * kRows);   // [0] staged + overflowed entries, [1] global base
   if (tid == 0) l_count[0] = 0;
 
   // ---- row statistics -> the two factors of the stage-1 window per row ------------------------------------------------
@@ -370,18 +392,19 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
   // which also covers what separates ||x_hi|| + ||x_mid|| from ||x||).  A row whose largest |x| is outside
   // [2^-32, 2^32] leaves the range in which the squares and the split neither underflow nor overflow: all of its
   // projections are re-evaluated (NOT(|y| > +inf) holds for every y).  A true zero row gives y = 0 in both passes.
-  float* wnd_lds = lds + kRingFloats + wave * kWaveRows;
-  float* wnb_lds = lds + kRingFloats + 256 + wave * kWaveRows;
+  float* wnd_lds = lds + kWndOff + wave * kWaveRows;
+  float* wnb_lds = lds + kWndOff + kRows + wave * kWaveRows;
   // the window coefficients of this column block, staged once (behind the list stage, which owns the first 3 x kS1ListCap
   // floats of the ring): with the proven window the exact test below runs on a third of the 32-column words, and a
   // global load in front of each of its compares is latency two waves per SIMD cannot hide
-  float* coef_lds = lds + 3 * kS1ListCap;
-  static_assert(3 * kS1ListCap + 512 <= kRingFloats, "coefficients behind the list stage");
-  coef_lds[tid] = tid < 256 ? args.wa[cb * 256 + tid] : args.wb[cb * 256 + tid - 256];
+  float* coef_lds = lds + kTabOff;
+  static_assert(kTabOff + 512 <= kRingFloats, "coefficients behind the list stage");
+#pragma unroll
+  for (int i = tid; i < 512; i += 64 * W) coef_lds[i] = i < 256 ? args.wa[cb * 256 + i] : args.wb[cb * 256 + i - 256];
   // compact column blocks (sig_compact): the padded id of every column of this block, and room for the block's sign words
-  int* padcol_lds = reinterpret_cast<int*>(lds + 3 * kS1ListCap + 512);
-  uint32_t* cw_lds = reinterpret_cast<uint32_t*>(lds + 3 * kS1ListCap + 768);
-  static_assert(3 * kS1ListCap + 768 + 256 * 8 <= kRingFloats, "compact tables behind the coefficients");
+  int* padcol_lds = reinterpret_cast<int*>(lds + kTabOff + 512);
+  uint32_t* cw_lds = reinterpret_cast<uint32_t*>(lds + kTabOff + 768);
+  static_assert(kTabOff + 768 + kRows * 8 <= kRingFloats, "compact tables behind the coefficients");
   if (COMPACT && tid < 256) padcol_lds[tid] = args.padcol[cb * 256 + tid];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
@@ -565,7 +588,7 @@ __global__ __launch_bounds__(512, 1) void sig16_kernel(const SigArgs args) {
     const int nby = bands_here * args.band_bytes;
     const int byte_base = cb * args.bpb * args.band_bytes;
     const int* tab = args.bytetab + cb * 512;
-    for (int idx = tid; idx < 256 * nby; idx += 64 * W) {
+    for (int idx = tid; idx < kRows * nby; idx += 64 * W) {
       const int rl = idx / nby, o = idx - rl * nby;
       const int64_t grow = blk_row0 + rl;
       if (grow < args.n) {
@@ -626,9 +649,18 @@ uint32_t lshrs_flags_sig16(void) {
   return f;
 }
 
-int lshrs_launch_sig16(const SigArgs& a, unsigned grid, bool compact, bool partial, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
-  const dim3 g(grid, 1, 1), b(512, 1, 1);
-  if (compact) {
+int lshrs_launch_sig16(const SigArgs& a, unsigned grid, bool compact, bool partial, bool half, hipStream_t s, hipEvent_t start,
+                       hipEvent_t stop) {
+  const dim3 g(grid, 1, 1), b(half ? 256 : 512, 1, 1);
+  if (half) {          // 128-row workgroups, two per CU (`grid` counts those)
+    if (compact) {
+      if (partial) hipExtLaunchKernelGGL((sig16_kernel<true, true, 4>), g, b, 0, s, start, stop, 0, a);
+      else hipExtLaunchKernelGGL((sig16_kernel<true, false, 4>), g, b, 0, s, start, stop, 0, a);
+    } else {
+      if (partial) hipExtLaunchKernelGGL((sig16_kernel<false, true, 4>), g, b, 0, s, start, stop, 0, a);
+      else hipExtLaunchKernelGGL((sig16_kernel<false, false, 4>), g, b, 0, s, start, stop, 0, a);
+    }
+  } else if (compact) {
     if (partial) hipExtLaunchKernelGGL((sig16_kernel<true, true>), g, b, 0, s, start, stop, 0, a);
     else hipExtLaunchKernelGGL((sig16_kernel<true, false>), g, b, 0, s, start, stop, 0, a);
   } else {

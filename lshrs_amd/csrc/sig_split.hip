@@ -7,6 +7,7 @@
 #include "lshrs_common.h"
 
 #include <chrono>
+#include <cstdlib>
 
 using namespace lshrs;
 
@@ -40,6 +41,20 @@ int lshrs_wait_done(const int32_t* done_host, int32_t epoch, int64_t spin_ns, vo
 // blas_model 0: ties are reported in tie_list (the caller resolves them on the host); > 0: stage 2 resolves them itself
 // by replaying that summation order of the host BLAS (sig_fix8_kernel<true>), tie_list is not used.
 // counters (replay only): the LSHRS_SIG_DEVICE_COUNTERS block; flag_y: the stage-1 value of every list entry (may be NULL).
+// Which workgroup of sig16_kernel a launch takes: 128 rows, two per CU (sig16.hip), for vectors of up to kHalfMaxTiles k-tiles
+// (measured, 1 M rows of 16 x 16: stage 1 +2 .. +5 % from 5 to 11 k-tiles, -1 .. -3 % from 12 on) and for batches whose
+// 256-row workgroups would leave half of the CUs without one (up to 32 768 rows per column block: stage 1 59 -> 47 us at 768-d).
+// LSHRS_SIG16_HALF_MAX_TILES (environment, read once; a measurement switch: tools/half_rows_ab.py) replaces both rules by a
+// k-tile limit: 0 = never, 64 = always.
+static bool sig16_half_rows(int ktiles, int64_t groups_of_256) {
+  static const int forced = [] {
+    const char* e = std::getenv("LSHRS_SIG16_HALF_MAX_TILES");
+    return e != nullptr ? std::atoi(e) : -1;
+  }();
+  if (forced >= 0) return ktiles <= forced;
+  return ktiles <= kHalfMaxTiles || groups_of_256 <= kHalfMaxGroups;
+}
+
 static int split_pass(const float* X, int64_t n, int64_t ldx, const void* workspace, int32_t num_bands,
                       int32_t rows_per_band, int32_t dim, uint8_t* keys, int64_t* tie_list, int32_t tie_cap,
                       int32_t* tie_count, float tau, uint8_t* row_flags, int64_t* flag_list, float* flag_y,
@@ -60,8 +75,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   SigResident rs = sig_resident(num_bands, rows_per_band, dim);
   if (rs.on && dim % kKTile != 0 && blas_model == 0) rs.on = false;   // (only the replaying stage 2 masks a row's end)
   if (!sig_has_split(g) && !narrow && !rs.on) return LSHRS_E_TOOLARGE;
-  const int64_t row_tiles = (n + 255) / 256;
-  const int64_t wgs = (row_tiles + 7) / 8 * 8 * g.cb;
+  const int64_t wgs = ((n + 127) / 128 + 7) / 8 * 8 * g.cb;          // (the most any launch below makes)
   if (n >= ((int64_t)1 << 42) || wgs > 0x7fffffffLL || g.cb > 65535) return LSHRS_E_TOOLARGE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const Opts o = read_opts(opts);
@@ -139,12 +153,16 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
   }
   a.row_flags = row_flags;
   a.clock_probe = o.clock_probe;
+  // sig16_kernel's workgroup: 256 rows, or 128 (two per CU) - sig16_half_rows
+  const bool half = !rs.on && sig16_half_rows(g.ktiles, (n + 255) / 256 * a.ncb);
+  const int wg_rows = half ? 128 : 256, wg_waves = half ? 4 : 8;
+  const int64_t row_tiles = (n + wg_rows - 1) / wg_rows;
   // the audit sample (lshrs_sig_audit): one unit in `div` - a wave of sig16_kernel, a 32-row tile of sig16r_kernel
   int audit_n = 0;
   if (audit != nullptr && audit->struct_bytes >= sizeof(lshrs_sig_audit) && audit->list != nullptr && audit->vals != nullptr &&
       audit->slots > 0 && audit->target > 0 && blas_model != 0) {
     const int res_rows = 16 * res_rt(rs.nct, rs.kt);
-    const int64_t units = rs.on ? (n + res_rows - 1) / res_rows : (row_tiles + 7) / 8 * 8 * a.ncb * 8;
+    const int64_t units = rs.on ? (n + res_rows - 1) / res_rows : (row_tiles + 7) / 8 * 8 * a.ncb * wg_waves;
     int64_t div = units / audit->target;
     if (div < 1) div = 1;
     if ((units + div - 1) / div > audit->slots) div = (units + audit->slots - 1) / audit->slots;
@@ -201,7 +219,7 @@ static int split_pass(const float* X, int64_t n, int64_t ldx, const void* worksp
     const int rc = lshrs_launch_sig16r(a, rs.nct, rs.kt, grid, 64u * (unsigned)rwaves, s, o.ev[0], o.ev[1]);
     if (rc != 0) return rc;
   } else {
-    const int rc = lshrs_launch_sig16(a, (unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), cp.on, dim % kKTile != 0, s, o.ev[0], o.ev[1]);
+    const int rc = lshrs_launch_sig16(a, (unsigned)((row_tiles + 7) / 8 * 8 * a.ncb), cp.on, dim % kKTile != 0, half, s, o.ev[0], o.ev[1]);
     if (rc != 0) return rc;
   }
   // stage 2: the flagged projections, one by one

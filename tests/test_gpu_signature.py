@@ -401,6 +401,15 @@ def test_device_tie_replay_equals_host_engine_and_reference(torch_mod):
     (8, 7, 200, 20_000, "split+replay"),        # not whole k-tiles (resident image, eight k-tiles, the seventh partial)
     (8, 7, 260, 20_000, "f32+replay"),
     (16, 16, 1000, 20_000, "split+replay"),
+    # sig16_kernel's two workgroups (round 6) at odd and even k-tile counts: 128 rows for vectors of up to eleven k-tiles and for
+    # batches of up to 128 row groups, 256 rows beyond both
+    (16, 16, 160, 20_000, "split+replay"),      # five k-tiles
+    (16, 16, 288, 40_000, "split+replay"),      # nine
+    (16, 16, 348, 40_000, "split+replay"),      # eleven, the last one 28 elements long
+    (32, 16, 224, 40_000, "split+replay"),      # seven, two column blocks
+    (16, 16, 416, 40_000, "split+replay"),      # thirteen: 256-row workgroups
+    (16, 16, 768, 40_000, "split+replay"),
+    (32, 16, 428, 40_000, "split+replay"),      # fourteen, partial, two column blocks
     (16, 16, 36, 20_000, "split+replay"),
     (16, 16, 5000, 9_000, "split+replay"),      # a partial last k-tile behind a whole block of the library
     (4, 6, 1004, 9_000, "f32+replay"),
@@ -1094,7 +1103,21 @@ def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
     """Stage 1 of the split pass, projection by projection, against oracle/mfma_model.c's accumulator: the bf16 split of
     x and p (round to nearest even, exact residual), per 32-deep k-tile the three instructions xh*ph, xh*pm, xm*ph in
     that order on one accumulator, each instruction the four-step model.  Bit for bit - which pins the kernel's
-    accumulation order, its split and the instruction model together, on Gaussian, wide-range and adversarial rows."""
+    accumulation order, its split and the instruction model together, on Gaussian, wide-range and adversarial rows.
+    (A batch of 512 rows: sig16_kernel's 128-row workgroups, round 6.)"""
+    _stage1_model_case(torch_mod, seed, nb, r, dim, copies=1)
+
+
+@pytest.mark.parametrize("seed,nb,r,dim", [(42, 16, 16, 768), (25, 16, 16, 416), (23, 16, 16, 767), (26, 16, 16, 429),      # even / odd k-tile counts,
+                                           (11, 20, 10, 768), (27, 20, 10, 429)])                                        # whole and partial; compact blocks
+def test_stage1_values_of_the_256_row_workgroups(torch_mod, seed, nb, r, dim):
+    """The same, for sig16_kernel<., ., 8> (round 6: batches of more than 128 row groups of vectors of twelve k-tiles and
+    more): the 512 rows 66 times over - every copy, in every workgroup, is the model's.  13 and 14 k-tiles: both ends of
+    the kernel's tile loop (an ODD count is the one whose drain hipcc once broke: tools/check_mfma_hazards.py)."""
+    _stage1_model_case(torch_mod, seed, nb, r, dim, copies=66)
+
+
+def _stage1_model_case(torch_mod, seed, nb, r, dim, copies):
     torch = torch_mod
     from oracle.build import split_stage1_model
     from tests._adversary import adversarial_row, tent_row
@@ -1111,14 +1134,15 @@ def test_stage1_values_are_the_accumulator_model(torch_mod, seed, nb, r, dim):
         x[i] = adversarial_row(h.projections[i % nb][i % r], 20.0, seed=i)
     for i in range(332, 364):                                    # partial sums as large as a near-zero projection allows
         x[i] = tent_row(h.projections[i % nb][(3 * i) % r], 5.0, seed=i)
-    y = _stage1_values(torch, h, torch.from_numpy(x).cuda())
+    y = _stage1_values(torch, h, torch.from_numpy(np.tile(x, (copies, 1))).cuda())
     want = split_stage1_model(h.projections, x)                                           # (n, nb * r)
     bb8 = 8 * h.band_bytes
     cols = (np.arange(nb).repeat(r) * bb8 + np.tile(np.arange(r), nb))
-    got = y[:, cols]
-    assert not np.isnan(got).any()
-    bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
-    assert bad.size == 0, (bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+    for c in range(copies):
+        got = y[c * n:(c + 1) * n, cols]
+        assert not np.isnan(got).any()
+        bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        assert bad.size == 0, (c, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
 
 
 def test_adversarial_rows_and_the_proven_window(torch_mod):

@@ -158,3 +158,33 @@ def test_ingest_lanes_are_planned_onto_their_gpus_numa_nodes(tmp_path, monkeypat
     monkeypatch.setattr(numa, "SYS_ROOT", str(tmp_path / "nothing"))
     assert numa.lane_plan([0, 1], use_torch=False) == [{"lane": 0, "device": 0, "numa_node": None, "cpus": []},
                                                         {"lane": 1, "device": 1, "numa_node": None, "cpus": []}]
+
+
+def test_stage1_assembly_has_no_unpadded_accumulator_moves():
+    """Round 6: sig16_kernel's matrix instructions are inline asm, hipcc pads nothing behind them.  A change of the kernel's
+    template arguments once made it put accumulator moves between the drain's MFMAs and their wait states (keys of vectors with
+    an odd number of k-tiles were off until the live audit refused them).  `tools/check_mfma_hazards.py` reads the unit's
+    assembly (no GPU) for any v_accvgpr_* that touches an MFMA's tile too early; its scanner is checked on a made-up listing."""
+    import importlib.util
+    import shutil
+
+    spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(ROOT, "tools", "check_mfma_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    listing = """
+_Zkernel:
+	v_mfma_f32_16x16x32_bf16 a[16:19], v[14:17], v[54:57], a[16:19]
+	v_accvgpr_read_b32 v61, a7
+	v_accvgpr_read_b32 v69, a19
+	s_nop 7
+	s_nop 4
+	v_accvgpr_read_b32 v70, a18
+	v_mfma_f32_16x16x32_bf16 a[0:3], v[14:17], v[54:57], a[0:3]
+	s_nop 7
+	v_accvgpr_mov_b32 a4, a1
+"""
+    found = mod.scan(listing)
+    assert [(f[1], f[4]) for f in found] == [(5, 1), (11, 8)], found      # (line, wait states elapsed behind the MFMA)
+    if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
+        pytest.skip("no hipcc here")
+    assert mod.main() == 0
