@@ -14,7 +14,7 @@ from ._config import HashSignatures
 from ._native import NativeLibraryError
 from .bandrows import get_optimal_config
 from .core import LSHRS, lshrs
-from .hasher import LSHHasher
+from .hasher import HostBlasNotRecognised, LSHHasher
 from .packed_ops import RedisPackedWriter, group_by_bucket, hex_keys
 from .similarity import cosine_similarity, l2_norm, rerank_batch, top_k_cosine
 from .storage import BucketOperation, InMemoryStorage
@@ -22,6 +22,6 @@ from .storage import BucketOperation, InMemoryStorage
 __all__ = [
     "LSHRS", "lshrs", "LSHHasher", "HashSignatures", "top_k_cosine", "cosine_similarity", "l2_norm",
     "rerank_batch", "get_optimal_config", "InMemoryStorage", "BucketOperation", "NativeLibraryError",
-    "RedisPackedWriter", "group_by_bucket", "hex_keys",
+    "RedisPackedWriter", "group_by_bucket", "hex_keys", "HostBlasNotRecognised",
 ]
 __version__ = "0.1.0"

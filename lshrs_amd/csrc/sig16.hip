@@ -460,8 +460,13 @@ __global__ __launch_bounds__(64 * W, 8 / W) void sig16_kernel(const SigArgs args
         for (int reg = 0; reg < 4; ++reg) {
           const float y0 = acc[rt][2 * w][reg], y1 = acc[rt][2 * w + 1][reg];
           const int p0 = 8 * rt + reg * 2;              // pair (rt, reg, g'pair = 0); g'pair = 1 is p0 + 1
+#ifdef LSHRS_AB_CHEAP_SIGNS      // (A/B builds only: what the transposition through SGPRs costs - one v_alignbit per value instead; wrong keys by design)
+          A[w & 1] = __builtin_amdgcn_alignbit(A[w & 1], __float_as_uint(y0), 31u);
+          B[w & 1] = __builtin_amdgcn_alignbit(B[w & 1], __float_as_uint(y1), 31u);
+#else
           deposit_positive(A[w & 1], y0, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
           deposit_positive(B[w & 1], y1, 4 * p0 + (w >> 1), 4 * (p0 + 1) + (w >> 1));
+#endif
           asm("v_min3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(y0), "v"(y1));
         }
         const bool aud = au_rw == 8 * rt + w;                   // (wave-uniform: this word holds the wave's audit sample)
@@ -639,6 +644,9 @@ uint32_t lshrs_flags_sig16(void) {
 #endif
 #ifdef LSHRS_AB_NO_STATIC_PRIO
   f |= LSHRS_BUILD_TUNED | (1u << 16);
+#endif
+#ifdef LSHRS_AB_CHEAP_SIGNS
+  f |= LSHRS_BUILD_WRONG_KEYS | (1u << 22);
 #endif
 #ifdef LSHRS_T16_BUILTIN
   f |= LSHRS_BUILD_TUNED | (1u << 20);

@@ -25,7 +25,14 @@ import numpy as np
 from . import _hostblas, _native
 from ._config import HashSignatures  # noqa: F401  (re-exported)
 
-__all__ = ["LSHHasher"]
+__all__ = ["LSHHasher", "HostBlasNotRecognised"]
+
+
+class HostBlasNotRecognised(UserWarning):
+    """This process's BLAS sums `P_band @ x` in an order the device replay does not know (an OpenBLAS / NumPy this library
+    was not verified against): keys stay the host's own - every near-tie is decided by the host engine calling that BLAS -
+    at the host engine's rate (~20 M vectors/s instead of ~800 M).  Naming the build (`reference_blas="openblas-skylakex"` /
+    `"openblas-haswell"`) keeps the device route and pins the keys to that build instead."""
 
 from ._host_engine_route import _HostEngineRoute
 from ._host_paths import _HostPaths, _OneRequest  # noqa: F401
@@ -645,6 +652,15 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
             planes = self._stacked().reshape(self.num_bands, self.rows_per_band, self.dim)
             cached = (self._projection_version, int(_hostblas.blas_order_model(planes)), sig)
             self._replay_model_cache = cached
+            if cached[1] == 0 and self.tie_replay != "off" and not getattr(self, "_warned_unrecognised", False):
+                self._warned_unrecognised = True        # (once per hasher: the drop from the device route to the host engine is 40 x)
+                import warnings
+
+                warnings.warn("lshrs_amd: the summation order of this process's BLAS ("
+                              f"{sig[0] or 'not found'}) is not one the "
+                              "device replay knows: near-ties are decided by the host engine (same keys as the reference on this "
+                              "host, ~40 x slower than the device route); reference_blas=\"openblas-skylakex\" / \"openblas-haswell\" "
+                              "pins the keys to a named build and keeps the device route", HostBlasNotRecognised, stacklevel=3)
         return cached[1]
 
     @staticmethod

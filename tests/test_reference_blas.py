@@ -251,3 +251,24 @@ def test_host_blas_name_and_the_warning_when_a_host_index_moves_to_the_other_bui
     assert other["pinned"] == ["openblas-skylakex", 0]                         # (naming the recorded build: hashed as built, nothing to warn about)
     assert _hostblas.builds_differ(16, 102) and _hostblas.builds_differ(1, 768) and _hostblas.builds_differ(4, 6)
     assert not _hostblas.builds_differ(16, 768) and not _hostblas.builds_differ(32, 1536) and not _hostblas.builds_differ(4, 128)
+
+
+def test_an_unrecognised_host_blas_says_so_once(monkeypatch):
+    """a NumPy / OpenBLAS whose summation order the replay does not know drops the hasher from the device
+    route to the host engine (same keys, ~40 x slower) - it says so, once per hasher (`HostBlasNotRecognised`); a named build,
+    and `tie_replay="off"`, have nothing to say."""
+    import warnings
+
+    from lshrs_amd import HostBlasNotRecognised, LSHHasher, _hostblas
+
+    monkeypatch.setattr(_hostblas, "blas_order_model", lambda planes: 0)
+    h = LSHHasher(8, 8, 64, seed=1)
+    with pytest.warns(HostBlasNotRecognised, match="not one the device replay knows"):
+        assert h._replay_model() == 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert h._replay_model() == 0                      # (cached; and once per hasher anyway)
+        h._replay_model_cache = None
+        assert h._replay_model() == 0
+        assert LSHHasher(8, 8, 64, seed=1, reference_blas="openblas-haswell")._replay_model() != 0
+        assert LSHHasher(8, 8, 64, seed=1, tie_replay="off")._replay_model() == 0
