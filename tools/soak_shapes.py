@@ -4,7 +4,7 @@ to three column blocks, padded bands, 128 key columns; per shape Gaussian rows, 
 (tests/_adversary.py: residual-aligned and tent rows, for hyperplanes drawn at random), rows at extreme and mixed scales,
 rows dominated by one element, rows with empty k-tiles.  Every batch: split pass + proven window against the exact-f32
 kernel + proven tie window (same replay) on the whole batch, and against the reference-literal NumPy loop on a slice.
-    python tools/soak_shapes.py [rounds]"""
+    python tools/soak_shapes.py [rounds] [new | r6]"""
 import os
 import sys
 import time
@@ -45,23 +45,33 @@ SHAPES = ((16, 16, 32), (16, 16, 64), (16, 16, 96), (32, 8, 128), (32, 8, 256), 
           # round 5: 8 m + 4 elements beyond 4096 (the library's short last block)
           (8, 6, 4100), (4, 16, 8196), (16, 16, 4109),
           # round 5: fewer than 9 elements with bands of two rows and more (model 2 on the Haswell / Zen build, 3 on the SkylakeX build)
-          (8, 4, 2), (5, 3, 7), (6, 2, 8), (4, 13, 8), (16, 16, 4), (3, 9, 5), (7, 6, 3), (2, 33, 6))
+          (8, 4, 2), (5, 3, 7), (6, 2, 8), (4, 13, 8), (16, 16, 4), (3, 9, 5), (7, 6, 3), (2, 33, 6),
+          # round 6: sig16_kernel's two workgroup shapes at odd and even k-tile counts (5 .. 48), one and two column blocks, compact
+          # blocks (`r6`: each of them at a batch of ~24 000 rows - 128-row workgroups at every length - and at the usual size)
+          (16, 16, 160), (16, 16, 224), (16, 16, 288), (16, 16, 348), (32, 16, 224), (16, 16, 416), (32, 16, 428), (20, 10, 429),
+          (16, 16, 520), (16, 16, 768), (32, 16, 1536), (128, 4, 768), (16, 16, 353), (40, 5, 300))
 
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     only_new = len(sys.argv) > 2 and sys.argv[2] == "new"          # (the shapes round 5 added)
+    r6 = len(sys.argv) > 2 and sys.argv[2] == "r6"                 # (the shapes round 6 added, at two batch sizes)
     shapes = SHAPES[SHAPES.index((64, 1, 100)):] if only_new else SHAPES
+    if r6:
+        shapes = tuple(sh + (small,) for sh in SHAPES[SHAPES.index((16, 16, 160)):] for small in (True, False))
     t0 = time.time()
     rows = bad = batches = audit_bad = audited = 0
     routes = {}
     worst = 0.0
     for rnd in range(rounds):
-        for nb, r, dim in shapes:
+        for shape in shapes:
+            nb, r, dim = shape[:3]
             rng = np.random.default_rng(7919 * rnd + 31 * dim + nb)
             a = LSHHasher(nb, r, dim, seed=3 + rnd)
             b = LSHHasher(nb, r, dim, seed=3 + rnd, precision="f32")
             n = int(np.clip((24 << 20) // dim, 20_000, 200_000)) + int(rng.integers(0, 300))
+            if len(shape) > 3:
+                n = 24_000 + int(rng.integers(0, 300)) if shape[3] else max(n, 70_000)
             g = torch.Generator("cuda").manual_seed(17 * rnd + dim + nb)
             x0 = torch.randn(n, dim, device="cuda", generator=g)
             planes = np.concatenate([np.asarray(p, dtype=np.float32) for p in a.projections])
