@@ -70,8 +70,10 @@ CONFIG4_TOTAL_ROWS = 10_000_000
 
 def pmc_traffic(kernel: str, field: str, units: float):
     """HBM bytes per launch measured by the PMC passes committed under profiles/ (None if absent)."""
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        try:
+    import glob
+
+    for name in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json"))), reverse=True):
+        try:            # (the latest round's first)
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)[kernel][field] * units, name
         except (OSError, KeyError, ValueError):
@@ -822,11 +824,17 @@ def bench_pinned(torch, x, keys, local_dev, steps, barrier):
     real = _hostblas.blas_order_model
     host_model = int(real(np_planes(x.device.index)))
     _hostblas.blas_order_model = lambda planes: 0
+    import warnings
+
+    from lshrs_amd import HostBlasNotRecognised
+
     try:
-        out = bench_variant(torch, x, keys, local_dev, steps, barrier,
-                            "reference_blas='openblas-skylakex' on a host whose own BLAS the licence check does not recognise "
-                            "(forced: blas_order_model -> 0): the named build's order is replayed on the device, no host engine",
-                            reference_blas="openblas-skylakex")
+        with warnings.catch_warnings():      # (a default hasher met while the check is forced says what it would say on such a host)
+            warnings.simplefilter("ignore", HostBlasNotRecognised)
+            out = bench_variant(torch, x, keys, local_dev, steps, barrier,
+                                "reference_blas='openblas-skylakex' on a host whose own BLAS the licence check does not recognise "
+                                "(forced: blas_order_model -> 0): the named build's order is replayed on the device, no host engine",
+                                reference_blas="openblas-skylakex")
     finally:
         _hostblas.blas_order_model = real
     out["host_blas_model_really"] = host_model      # (1: this host IS that build for this shape - then the keys are the default hasher's)
@@ -1186,10 +1194,19 @@ def bench_query_many(torch, np, x, host_rows, local_dev):
     for label, fn in (("get_top_k_10", lambda v: idx.get_top_k(v, topk=10)), ("get_above_p_0.5", lambda v: idx.get_above_p(v, p=0.5))):
         for v in q[:100]:
             fn(v)
+        import gc
+
+        gc.collect()        # (what the legs in front left behind: a full collection over this process's heap costs ~0.1 s - not inside the loop)
+        res, per = [], []
         t0 = time.perf_counter()
-        res = [fn(v) for v in q[:1000]]
+        for v in q[:1000]:
+            t1 = time.perf_counter()
+            res.append(fn(v))
+            per.append(time.perf_counter() - t1)
         dt = (time.perf_counter() - t0) / 1000
-        one[label] = {"us_per_call": dt * 1e6, "calls_per_s": 1.0 / dt}
+        per.sort()
+        one[label] = {"us_per_call": dt * 1e6, "calls_per_s": 1.0 / dt, "us_per_call_median": per[500] * 1e6, "us_per_call_p99": per[989] * 1e6,
+                      "us_per_call_max": per[-1] * 1e6}
         if label == "get_top_k_10":
             one[label]["equal_to_query_many"] = bool(res == got[:1000])
     one["get_top_k_10"]["cpu_reference_literal_us_per_call"] = 1e6 / out["top_k_10_cpu_reference_literal"]
