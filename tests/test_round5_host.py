@@ -182,9 +182,16 @@ _Zkernel:
 	v_mfma_f32_16x16x32_bf16 a[0:3], v[14:17], v[54:57], a[0:3]
 	s_nop 7
 	v_accvgpr_mov_b32 a4, a1
+	s_nop 7
+	v_accvgpr_write_b32 a9, 0
+	s_nop 0
+	v_mfma_f32_16x16x32_bf16 a[8:11], v[14:17], v[54:57], a[8:11]
+	v_accvgpr_write_b32 a20, 0
+	s_nop 2
+	v_mfma_f32_16x16x32_bf16 a[20:23], v[14:17], v[54:57], a[20:23]
 """
     found = mod.scan(listing)
-    assert [(f[1], f[4]) for f in found] == [(5, 1), (11, 8)], found      # (line, wait states elapsed behind the MFMA)
+    assert [(f[1], f[4]) for f in found] == [(5, 1), (11, 8), (15, 1)], found      # (line, wait states elapsed behind the write)
     if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
         pytest.skip("no hipcc here")
     assert mod.main() == 0
