@@ -224,7 +224,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         self._audit_countdown = 1
         self.audit_failures = 0
         self.margin_escalations = 0        # batches whose measured stage-1 deviation tripped the guard (then: bound window)
-        # the split pass (two launches, 256-row workgroups) overtakes the f32 kernel at about 16 M input elements:
+        # the split pass (two launches; 256-row workgroups, 128-row ones for short vectors and small batches) overtakes the f32 kernel at about 16 M input elements:
         # 20 k rows at 768-d, 8 k at 1536-d, 120 k at 128-d (tools/split_crossover.py)
         self.split_min_rows = 4_096
         self.split_min_elems = 16 << 20
@@ -253,7 +253,7 @@ class LSHHasher(_HostPaths, _HostEngineRoute, _ReplayPaths):
         # (bench.py uses it to time the kernel on the stream it runs on)
         self.kernel_events: Optional[list] = None
         # device batches of >= 2 chunks take the pipelined path; 262144 rows = four full-chip rounds of the f32
-        # kernel (128-row workgroups, two per CU) and of the split pass (256-row workgroups, one per CU): each
+        # kernel (128-row workgroups, two per CU) and of the split pass (256-row workgroups, one per CU, at these sizes): each
         # chunk boundary costs a kernel ramp-down/ramp-up, each chunk a fixed ~60 us of host work
         self.pipeline_chunk_rows = 262_144
         self.pipeline_pair_head = True     # long batches: full-size chunks at the head are launched two at a time
