@@ -30,9 +30,69 @@ __device__ __forceinline__ int pow2_ceil(int v) {
   return v <= 2 ? 2 : 1 << (32 - __builtin_clz((unsigned)(v - 1)));
 }
 
+// The same network for up to E x kQThreads items held in REGISTERS (item e * kQThreads + tid is thread tid's e-th): exchanges over
+// fewer than 64 positions are lane shuffles, over 64 and 128 positions trips through `items`, over 256 and more the thread's own
+// registers.  The list of ONE query is a few hundred items (sixteen buckets of fifteen members at 1 M stored ids): through LDS
+// with a workgroup barrier per step its two sorts were 15 of the one-query kernel's 29 us (tools/_ab/one_probe.py).
+template <int E>
+__device__ __forceinline__ void bitonic_sort_regs(uint64_t* items, int P) {
+  const int tid = threadIdx.x;
+  uint64_t v[E];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = e * kQThreads + tid < P ? items[e * kQThreads + tid] : ~0ull;
+  __syncthreads();
+#pragma unroll
+  for (int size = 2; size <= E * kQThreads; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= kQThreads) {                       // both items are this thread's
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int f = e ^ (stride / kQThreads);
+          if (f > e) {
+            const bool up = (((e * kQThreads + tid) & size) == 0);
+            const uint64_t lo = v[e] < v[f] ? v[e] : v[f], hi = v[e] < v[f] ? v[f] : v[e];
+            v[e] = up ? lo : hi;
+            v[f] = up ? hi : lo;
+          }
+        }
+      } else {
+        uint64_t o[E];
+        if (stride >= 64) {                            // another wave's: through LDS
+#pragma unroll
+          for (int e = 0; e < E; ++e) items[e * kQThreads + tid] = v[e];
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] = items[e * kQThreads + (tid ^ stride)];
+          __syncthreads();
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) o[e] = __shfl_xor((unsigned long long)v[e], stride);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = e * kQThreads + tid;
+          const bool keep_min = ((i & size) == 0) == ((i & stride) == 0);
+          const uint64_t lo = v[e] < o[e] ? v[e] : o[e], hi = v[e] < o[e] ? o[e] : v[e];
+          v[e] = keep_min ? lo : hi;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    if (e * kQThreads + tid < P) items[e * kQThreads + tid] = v[e];
+  __syncthreads();
+}
+
 // Ascending bitonic network over P (a power of two) 64-bit items in LDS, all kQThreads threads of the workgroup; the items
 // are final - and visible to every thread - when it returns.
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* items, int P) {
+#ifndef LSHRS_AB_QUERY_LDS_SORT
+  if (P <= kQThreads) return bitonic_sort_regs<1>(items, P);
+  if (P <= 2 * kQThreads) return bitonic_sort_regs<2>(items, P);
+#endif
   __syncthreads();
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -485,7 +545,7 @@ int set_lds(const void* fn, size_t bytes) {
   return e == hipSuccess ? 0 : -(int)e;
 }
 inline size_t items_bytes(int max_items) {
-  size_t p = 2;
+  size_t p = 2 * kQThreads;          // (bitonic_sort_regs exchanges through the first 2 x kQThreads items whatever the list's length)
   while (p < (size_t)max_items) p <<= 1;
   return p * sizeof(uint64_t);
 }
