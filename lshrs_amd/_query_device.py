@@ -290,10 +290,10 @@ def rank_and_cut(lists: _Lists, top_k: Optional[int], top_p: Optional[float], *,
 class OneQuery:
     """ONE query - ``LSHRS.get_top_k`` / ``get_above_p`` / ``query``, the reference's own calling pattern
     (lshrs/core/main.py:524-658) - as one chain of launches with NO size read back in between and ONE wait at its end: the
-    vector goes into pinned memory, the one-launch signature kernel leaves its keys there, ``lshrs_query_one_u8`` (lookup, pair
+    vector goes into pinned memory, the one-launch signature kernel leaves its keys on the device, ``lshrs_query_one_u8`` (lookup, pair
     list, count, order and cut in one workgroup) [and the rerank + rank launches] follow on the same stream with fixed capacities (``CAP`` pairs: a longer list leaves ``ucount = -1`` and the
     caller counts on the host), the answer lands in pinned memory and the last kernel publishes an epoch the host polls
-    (``lshrs_wait_done``).  ~60 us against ~250 for the host-counted path.  One query at a time per instance (a lock)."""
+    (``lshrs_wait_done``).  ~50 us against ~250 for the host-counted path.  One query at a time per instance (a lock)."""
 
     CAP = _native.QUERY_MAX_PAIRS
 
@@ -306,17 +306,19 @@ class OneQuery:
         self.ldx = (dim + 31) // 32 * 32
         pin = lambda n, dt: torch.zeros(n, dtype=dt).pin_memory()      # noqa: E731
         self.pin_x = pin(self.ldx, torch.float32)
-        self.pin_keys = pin(max(16, nb * bb), torch.uint8)
         self.pin_flags = pin(16, torch.uint8)
         self.pin_i64 = pin(4, torch.int64)                 # out_off: [0] 0, [1] kept, [2] candidates found (-1: beyond the capacity)
         self.pin_i32 = pin(8, torch.int32)                 # [1] err, [2] done
         self.pin_ids = pin(self.CAP, torch.int64)
         self.pin_scores = pin(self.CAP, torch.float32)
-        self.h_x, self.h_keys, self.h_flags = self.pin_x.numpy(), self.pin_keys.numpy(), self.pin_flags.numpy()
+        self.h_x, self.h_flags = self.pin_x.numpy(), self.pin_flags.numpy()
         self.h_i64, self.h_i32 = self.pin_i64.numpy(), self.pin_i32.numpy()
         self.h_ids, self.h_scores = self.pin_ids.numpy(), self.pin_scores.numpy()
         with torch.cuda.device(dev):
             self.hash_counters = torch.zeros(1, dtype=torch.int32, device=dev)
+            # the query's keys: from the signature launch to the lookup launch behind it, on the device (nobody on the host reads
+            # them: in pinned memory they cost the lookup a round trip over the link before its first bucket)
+            self.keys_dev = torch.zeros(max(16, nb * bb), dtype=torch.uint8, device=dev)
             self.pair_count = torch.zeros(1, dtype=torch.int32, device=dev)
             self.pair_off = torch.zeros(2, dtype=torch.int64, device=dev)
             self.keep = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -328,7 +330,7 @@ class OneQuery:
             self.slots = None
         self.epoch = 0
         p32 = self.pin_i32.data_ptr()
-        self.ptr = dict(x=self.pin_x.data_ptr(), keys=self.pin_keys.data_ptr(), flags=self.pin_flags.data_ptr(),
+        self.ptr = dict(x=self.pin_x.data_ptr(), keys=self.keys_dev.data_ptr(), flags=self.pin_flags.data_ptr(),
                         out_off=self.pin_i64.data_ptr(), ucount=self.ucount.data_ptr(), zero_off=self.zero_off.data_ptr(), err=p32 + 4,
                         done=p32 + 8, ids=self.pin_ids.data_ptr(),
                         scores_out=self.pin_scores.data_ptr(), hash_counters=self.hash_counters.data_ptr(),
