@@ -463,3 +463,51 @@ def test_one_query_is_one_chain_of_launches_and_equals_the_reference_flow():
     assert plain.get_top_k(data[5] + 0.01, topk=3) == O.query_literal(plain._storage, P, dim, data[5] + 0.01, top_k=3)
     _same_ranking(plain.get_above_p(data[5] + 0.01, p=0.5), O.query_literal(plain._storage, P, dim, data[5] + 0.01, top_k=None, top_p=0.5, fetch=fetch))
     assert not plain._one_query and len(calls) == n_calls
+
+
+def test_lists_of_every_length_through_the_register_and_the_lds_sorts():
+    """Round 6: lists of up to 256 / 512 items are sorted in registers (lane shuffles + two trips through LDS), longer ones
+    through LDS - every length around the seams, with repeated (member, band) pairs and members in many bands: the candidates
+    and their collision counts against a dict, and the ranked answer (scores descending, a permutation of the candidates,
+    every score the cosine) for the same lists."""
+    import torch
+
+    from lshrs_amd import _query_device as qd
+
+    rng = np.random.default_rng(99)
+    nb, dim, m = 16, 32, 6000
+    lengths = [1, 2, 3, 5, 31, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 300, 400, 511, 512, 513, 700, 1023, 1024, 1025, 3000, 9000]
+    ms, bs, po, want = [], [], [0], []
+    for L in lengths:
+        pool = rng.choice(m, size=max(1, L // 3), replace=False)             # few distinct members: real collisions
+        mem = rng.choice(pool, size=L).astype(np.int64)
+        band = rng.integers(0, nb, size=L).astype(np.int32)
+        ms.append(mem)
+        bs.append(band)
+        po.append(po[-1] + L)
+        counts = {}
+        for mm, bb in set(zip(mem.tolist(), band.tolist())):                 # buckets are sets: a pair counts once
+            counts[mm] = counts.get(mm, 0) + 1
+        want.append(sorted(counts.items(), key=lambda kv: (-kv[1], kv[0])))
+    ms.append(np.full(300, 7, np.int64))                                     # one member, one band, 300 times: one candidate, one hit
+    bs.append(np.full(300, 3, np.int32))
+    po.append(po[-1] + 300)
+    want.append([(7, 1)])
+    dev = torch.device("cuda", 0)
+    lists = qd.candidates_from_pairs(np.concatenate(ms), np.concatenate(bs), np.asarray(po, np.int64), nb, dev, want_hits=True)
+    off, cnt = lists.pair_off.cpu().numpy(), lists.ucount.cpu().numpy()
+    ids, hits = lists.cand_ids.cpu().numpy(), lists.hits.cpu().numpy()
+    for qi, w in enumerate(want):
+        got = list(zip(ids[off[qi]:off[qi] + cnt[qi]].tolist(), hits[off[qi]:off[qi] + cnt[qi]].tolist()))
+        assert got == w, (qi, len(w))
+    corpus = rng.standard_normal((m, dim)).astype(np.float32)
+    queries = rng.standard_normal((len(want), dim)).astype(np.float32)
+    r_ids, r_scores, bounds = qd.rank_and_cut(lists, None, 1.0, queries_dev=torch.from_numpy(queries).to(dev),
+                                              corpus=torch.from_numpy(corpus).to(dev))
+    cn = corpus / np.linalg.norm(corpus, axis=1, keepdims=True)
+    for qi, w in enumerate(want):
+        g_ids, g_sc = r_ids[bounds[qi]:bounds[qi + 1]], r_scores[bounds[qi]:bounds[qi + 1]]
+        assert sorted(g_ids.tolist()) == sorted(i for i, _ in w), qi
+        assert np.all(g_sc[:-1] >= g_sc[1:]), qi
+        ref = cn[g_ids] @ (queries[qi] / np.linalg.norm(queries[qi]))
+        assert np.abs(ref - g_sc).max() <= 1e-5, qi
