@@ -199,6 +199,7 @@ class LSHRS:
 
         self._dev_buckets = DeviceBuckets()  # device mirror of the store's bucket arrays (query_many)
         self._one_query: Dict[int, Any] = {}    # per device: the pinned / device buffers of the single-query chain
+        self._one_table = None          # (store token, band bytes, device) -> the segments' descriptor on the device (_query_one_device)
         self._config: Dict[str, Any] = {
             "dim": dim, "num_perm": num_perm, "num_bands": num_bands, "rows_per_band": rows_per_band,
             "similarity_threshold": similarity_threshold, "buffer_size": buffer_size, "seed": seed,
@@ -458,15 +459,30 @@ class LSHRS:
         st = self._storage
         if isinstance(st, _DeferredStorage):
             st = st._resolve()
-        segs = st.array_segments(h.band_bytes) if callable(getattr(st, "array_segments", None)) else None
-        if segs is None:
-            return None
         dev = corpus.device if rerank else h._torch_device()
+        # what the store's segments look like on the device: kept beside the store's change token (one comparison per call
+        # instead of a walk over the segments under the store's lock)
+        token_fn = getattr(st, "array_segments_token", None)
+        token = token_fn() if callable(token_fn) else None
+        kept = self._one_table
+        if token is not None and kept is not None and kept[0] == (id(st), token, h.band_bytes, dev.index):
+            desc, nseg, max_id = kept[1]
+        else:
+            segs = st.array_segments(h.band_bytes) if callable(getattr(st, "array_segments", None)) else None
+            if segs is None:
+                return None
+            try:
+                desc, nseg, max_id = self._dev_buckets.table(segs, dev)
+            except qd.TooLarge:
+                return None
+            token = token_fn() if callable(token_fn) else None        # (array_segments may have folded the segments)
+            # (with it: the segments and the mirror's device arrays the descriptor points into - alive as long as the entry is)
+            self._one_table = None if token is None else ((id(st), token, h.band_bytes, dev.index), (desc, nseg, max_id), segs,
+                                                          self._dev_buckets._table, st)      # (and the store: its id is the key)
         one = self._one_query.get(dev.index)
         if one is None or one.shape != (h.num_bands, h.band_bytes, h.dim):
             one = self._one_query[dev.index] = qd.OneQuery(h, dev)
         try:
-            desc, nseg, max_id = self._dev_buckets.table(segs, dev)
             k_arg = top_k if (top_k is not None and top_k > 0) else -1
             ucount, ids, scores, flag = one.run(h, query_vector, desc, nseg, max_id, k_arg, float(top_p) if rerank else -1.0, corpus)
         except qd.TooLarge:

@@ -39,6 +39,7 @@ class InMemoryStorage:
         self.batches: List[List[BucketOperation]] = []
         self.packed_batches: List[Tuple[int, int]] = []   # (vectors, distinct buckets) per batch_add_packed call
         self._segments: list = []                         # BucketCSR of every batch_add_csr call (array-backed buckets)
+        self._version = 0                                 # bumped by everything that changes a bucket (array_segments_token)
         self.closed = False
 
     # key format of the reference (redis.py:187-225)
@@ -47,6 +48,7 @@ class InMemoryStorage:
 
     def add_to_bucket(self, band_id: int, hash_val: bytes, index: int) -> None:
         with self._lock:
+            self._version += 1
             self._buckets.setdefault((int(band_id), bytes(hash_val)), set()).add(int(index))
 
     compact_above = 32     # array segments a lookup tolerates before it folds them into one (many small index() calls)
@@ -60,6 +62,7 @@ class InMemoryStorage:
         for seg in self._segments:
             (by_width.setdefault(seg.band_bytes, []) if seg.codes is not None else rest).append(seg)
         self._segments = [merge_csr(group) if len(group) > 1 else group[0] for group in by_width.values()] + rest
+        self._version += 1
 
     def get_bucket(self, band_id: int, hash_val: bytes) -> Set[int]:
         with self._lock:
@@ -102,6 +105,14 @@ class InMemoryStorage:
             if any(s.codes is None for s in segs):
                 return None
             return [s for s in segs if s.band_bytes == band_bytes]
+
+    def array_segments_token(self):
+        """Something that changes whenever :meth:`array_segments` could answer differently - or None where every call must ask
+        (buckets kept as dict entries).  A query per call (``LSHRS.get_top_k``) keeps the answer beside the token instead of
+        walking the segments again (no lock: two integers and a length)."""
+        if self._buckets:
+            return None
+        return (self._version, id(self._segments), len(self._segments))
 
     def get_buckets_many(self, keys) -> Tuple[np.ndarray, np.ndarray]:
         """Every member of every bucket a batch of queries touches, as two flat arrays ``(query index, member id)`` - one
@@ -185,6 +196,7 @@ class InMemoryStorage:
         if self._fail_on_flush:
             raise ConnectionError("simulated storage failure")
         with self._lock:
+            self._version += 1
             if self.record_batches:
                 self.batches.append(ops)
             buckets = self._buckets
@@ -210,6 +222,7 @@ class InMemoryStorage:
             raise ConnectionError("simulated storage failure")
         groups = list(group_by_bucket(ids, keys))
         with self._lock:
+            self._version += 1
             self.packed_batches.append((len(ids), len(groups)))
             for band, key_bytes, members in groups:
                 self._buckets.setdefault((int(band), bytes(key_bytes)), set()).update(members.tolist())
@@ -223,12 +236,14 @@ class InMemoryStorage:
 
         csr = dedupe_csr(csr)                            # (no-op for the builders' output: they mark it distinct)
         with self._lock:
+            self._version += 1
             self.packed_batches.append((int(csr.vectors), len(csr)))
             self._segments.append(csr)
 
     def remove_indices(self, indices: Iterable[int]) -> None:
         gone = {int(i) for i in indices}
         with self._lock:
+            self._version += 1
             for members in self._buckets.values():
                 members -= gone
             if self._segments:
@@ -252,6 +267,7 @@ class InMemoryStorage:
 
     def clear(self) -> None:
         with self._lock:
+            self._version += 1
             self._buckets.clear()
             self._segments = []
 

@@ -156,3 +156,38 @@ def test_loader_errors_keep_their_cause_and_bad_rows_come_first():
     assert sum(v for v, _ in store2.packed_batches) == 77
     cause = info.value.__cause__ or info.value.__context__
     assert cause is None or isinstance(cause, Boom)       # (the bad row may surface through `ingest.failed` before the loader is asked again)
+
+
+def test_one_query_per_call_follows_the_store_through_its_changes():
+    """Round 6: `get_top_k` keeps the device descriptor of the store's segments beside the store's change token - every way the
+    store can change (another `index`, `delete`, `clear`, op-tuple buckets appearing, another store) is seen by the next call."""
+    from lshrs_amd import LSHRS, InMemoryStorage
+
+    rng = np.random.default_rng(12)
+    dim = 64
+    data = rng.standard_normal((6000, dim)).astype(np.float32)
+    store = InMemoryStorage()
+    idx = LSHRS(dim=dim, num_perm=64, storage=store, packed_ingest=True)
+    idx.index(np.arange(2000), data[:2000])
+    assert idx.get_top_k(data[10], topk=1) == [10] and idx.get_top_k(data[10], topk=1) == [10]
+    assert idx._one_table is not None
+    kept = idx._one_table[0]
+    assert idx.get_top_k(data[3000], topk=1) != [3000]
+    assert idx._one_table[0] == kept                                 # (the same entry served the calls in between)
+    idx.index(np.arange(2000, 4000), data[2000:4000])                # another segment
+    assert idx.get_top_k(data[3000], topk=1) == [3000] and idx._one_table[0] != kept
+    idx.delete(3000)
+    assert 3000 not in idx.get_top_k(data[3000], topk=5)
+    idx.ingest(5000, data[5000])                                     # an op-tuple bucket: the store answers through get_bucket again
+    idx.flush()
+    assert idx.get_top_k(data[5000], topk=1) == [5000]
+    assert idx.get_top_k(data[10], topk=1) == [10]
+    store.clear()
+    assert idx.get_top_k(data[10], topk=1) == []
+    idx.index(np.arange(100), data[:100])
+    assert idx.get_top_k(data[10], topk=1) == [10]
+    other = InMemoryStorage()
+    idx2 = LSHRS(dim=dim, num_perm=64, storage=other, packed_ingest=True)
+    idx2._hasher.projections = idx._hasher.projections
+    idx2.index(np.arange(4000, 4100), data[4000:4100])
+    assert idx2.get_top_k(data[4050], topk=1) == [4050] and idx.get_top_k(data[4050], topk=1) != [4050]
