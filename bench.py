@@ -570,6 +570,14 @@ def main() -> None:
                 result[name] = fn()
             except Exception as exc:  # noqa: BLE001 - an extra must not take the headline down with it
                 result[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        two = result.get("sustained", {}).get("two_streams") if isinstance(result.get("sustained"), dict) else None
+        if isinstance(two, dict) and "value" in two:
+            # beside `value` (one synchronous hash_device per step): the same batches through the streaming entry point, what a
+            # loader that keeps two batches in flight sees - stage 2, the export and the host's share of batch i under stage 1 of i + 1
+            result["pipelined"] = {"value": two["value"], "unit": "vectors/s", "ms_per_step": two.get("ms_per_step_mean"),
+                                   "value_over_synchronous": two["value"] / result["value"],
+                                   "entry_point": two.get("entry_point"), "keys_equal": two.get("keys_equal"),
+                                   "note": "sustained.two_streams, repeated at the top level; `value` stays the synchronous step"}
     elif world > 1 and not args.no_extras:
         # host-fed ingest on every rank at once: what the node's PCIe + host memory give N ranks together
         def max_over_ranks(seconds):
