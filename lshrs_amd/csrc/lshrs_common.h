@@ -480,5 +480,6 @@ LSHRS_HIDDEN int lshrs_sort_u64_rows(uint64_t* items, int q, int64_t cpad, hipSt
 LSHRS_HIDDEN uint32_t lshrs_flags_sig16(void);
 LSHRS_HIDDEN uint32_t lshrs_flags_sig16r(void);
 LSHRS_HIDDEN uint32_t lshrs_flags_replay(void);
+LSHRS_HIDDEN uint32_t lshrs_flags_query(void);
 
 #endif

@@ -33,7 +33,7 @@ __device__ __forceinline__ int pow2_ceil(int v) {
 // The same network for up to E x kQThreads items held in REGISTERS (item e * kQThreads + tid is thread tid's e-th): exchanges over
 // fewer than 64 positions are lane shuffles, over 64 and 128 positions trips through `items`, over 256 and more the thread's own
 // registers.  The list of ONE query is a few hundred items (sixteen buckets of fifteen members at 1 M stored ids): through LDS
-// with a workgroup barrier per step its two sorts were 15 of the one-query kernel's 29 us (tools/_ab/one_probe.py).
+// with a workgroup barrier per step its two sorts were 15 of the one-query kernel's 29 us (tools/one_query_stages.py).
 template <int E>
 __device__ __forceinline__ void bitonic_sort_regs(uint64_t* items, int P) {
   const int tid = threadIdx.x;
@@ -262,6 +262,13 @@ __global__ __launch_bounds__(kScanThreads) void query_scan_kernel(const int32_t*
 // ------------------------------------------------------------------------------------------
 // (the body: items loaded -> the candidates, ordered, at cand_ids[0 .. U) (+ their collisions); also the second phase of
 //  query_one_kernel.)  `so`: this query's slots.  Returns U in every thread.
+#ifdef LSHRS_AB_ONE_PROBE      // (A/B builds only, tools/one_query_stages.py: where ONE query's kernel spends its time - s_memrealtime, 10 ns ticks)
+__device__ unsigned long long g_probe[16];
+#define LSHRS_PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LSHRS_PROBE(i) do { } while (0)
+#endif
+
 template <int SRC>
 __device__ __forceinline__ int collide_body(uint64_t* items, int L, const Segment* __restrict__ segs, int nseg, int nb, int bbits,
                                             const int64_t* __restrict__ slot_start, const int32_t* __restrict__ slot_len,
@@ -292,7 +299,9 @@ __device__ __forceinline__ int collide_body(uint64_t* items, int L, const Segmen
     for (int t = tid; t < L; t += kQThreads) items[t] = ((uint64_t)pair_members[t] << bbits) | (uint64_t)pair_bands[t];
   }
   for (int t = L + tid; t < P; t += kQThreads) items[t] = ~0ull;
+  LSHRS_PROBE(3);
   bitonic_sort_lds(items, P);
+  LSHRS_PROBE(4);
 
   // an id twice in one bucket (two sources): strike the repeats, close the gaps with one more sort (rare: skipped when none)
   uint64_t dupmask = 0;        // (P / 256 <= 64 items per thread: one bit each)
@@ -335,7 +344,9 @@ __device__ __forceinline__ int collide_body(uint64_t* items, int L, const Segmen
     }
     items[t] = key;
   }
+  LSHRS_PROBE(5);
   bitonic_sort_lds(items, P);
+  LSHRS_PROBE(6);
   const int U = *n_head;
   const uint64_t mmask = ((uint64_t)1 << mshift) - 1;
   for (int t = tid; t < U; t += kQThreads) {
@@ -397,8 +408,14 @@ __global__ __launch_bounds__(kQThreads) void query_one_kernel(const uint8_t* __r
   const int tid = threadIdx.x;
   // the query vector from pinned host memory into device memory, once, for the rerank launch behind this one (128 workgroups
   // reading it over the link each cost that launch 25 us)
+  LSHRS_PROBE(0);
   for (int k = tid; k < copy_n; k += kQThreads) copy_dst[k] = copy_src[k];
+#ifdef LSHRS_AB_ONE_PROBE
+  __syncthreads();
+#endif
+  LSHRS_PROBE(1);
   const long long total = lookup_body(keys, nb, bb, segs, nseg, slot_start, slot_len, slot_off, scan);
+  LSHRS_PROBE(2);
   int U = 0;
   if (total > max_items) U = -1;
   else if (total > 0) {
@@ -417,6 +434,7 @@ __global__ __launch_bounds__(kQThreads) void query_one_kernel(const uint8_t* __r
     out_off[1] = K;
     out_off[2] = U;             // (for the host: candidates found, -1 = beyond the capacity - out_off is where it looks)
   }
+  LSHRS_PROBE(7);
   if (emit || K == 0) {            // the answer by collisions (or nothing to rerank): out, and the word the host polls
     __syncthreads();               // (cand_ids[0 .. U) written by other threads above)
     for (int t = tid; t < K; t += kQThreads) out_ids[t] = cand_ids[t];
@@ -426,6 +444,7 @@ __global__ __launch_bounds__(kQThreads) void query_one_kernel(const uint8_t* __r
       if (tid == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  LSHRS_PROBE(8);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -550,6 +569,17 @@ inline size_t items_bytes(int max_items) {
   return p * sizeof(uint64_t);
 }
 }  // namespace
+
+uint32_t lshrs_flags_query(void) {
+  uint32_t f = 0;
+#ifdef LSHRS_AB_ONE_PROBE
+  f |= LSHRS_BUILD_TUNED | (1u << 23);
+#endif
+#ifdef LSHRS_AB_QUERY_LDS_SORT
+  f |= LSHRS_BUILD_TUNED | (1u << 24);
+#endif
+  return f;
+}
 
 extern "C" {
 
@@ -710,3 +740,7 @@ int lshrs_query_rank_f32(const int64_t* cand_ids, const float* scores, const int
 }
 
 }  // extern "C"
+
+#ifdef LSHRS_AB_ONE_PROBE
+extern "C" int lshrs_ab_one_probe(unsigned long long* host16) { return -(int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), 16 * sizeof(unsigned long long)); }
+#endif

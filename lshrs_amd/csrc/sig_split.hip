@@ -17,7 +17,7 @@ int lshrs_abi_version(void) { return LSHRS_ABI_VERSION; }
 
 // Which measurement switches this build was compiled with (include/lshrs_hip.h, LSHRS_BUILD_*): every translation unit
 // reports its own; the product build returns 0.
-uint32_t lshrs_build_flags(void) { return lshrs_flags_sig16() | lshrs_flags_sig16r() | lshrs_flags_replay(); }
+uint32_t lshrs_build_flags(void) { return lshrs_flags_sig16() | lshrs_flags_sig16r() | lshrs_flags_replay() | lshrs_flags_query(); }
 
 int lshrs_stream_synchronize(void* stream) { return -(int)hipStreamSynchronize(static_cast<hipStream_t>(stream)); }
 
