@@ -1148,6 +1148,15 @@ def bench_query_many(torch, np, x, host_rows, local_dev):
     t, arrs = best_of(lambda: idx.query_many(q, top_k=None, top_p=0.5, return_arrays=True))
     out["top_p_0.5_arrays"] = nq / t
     stats = dict(idx.last_query_stats)
+    # the same with the queries already on the GPU (round 6: a torch tensor is taken as it is - 30 MB that do not cross the link)
+    q_dev = torch.from_numpy(q).to(torch.device("cuda", local_dev))
+    t, arrs_dev = best_of(lambda: idx.query_many(q_dev, top_k=None, top_p=0.5, return_arrays=True))
+    out["top_p_0.5_arrays_queries_on_device"] = nq / t
+    t, arr10_dev = best_of(lambda: idx.query_many(q_dev, top_k=10, return_arrays=True))
+    out["top_k_10_arrays_queries_on_device"] = nq / t
+    out["queries_on_device_equal_host_queries"] = bool(np.array_equal(arrs_dev[0], arrs[0]) and np.array_equal(arrs_dev[2], arrs[2])
+                                                       and np.array_equal(arrs_dev[1], arrs[1]) and np.array_equal(arr10_dev[0], arr10[0]))
+    del q_dev
     t_all, full = best_of(lambda: idx.query_many(q, top_k=None, top_p=1.0, return_arrays=True))
     cands = int(full[2][-1])
     out["top_p_1.0_arrays"] = nq / t_all

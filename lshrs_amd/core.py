@@ -52,6 +52,16 @@ _FORMAT_VERSION = "0.1.1a4"  # on-disk format version string the reference write
 _ZERO_MSG = "Cannot index zero vector - norm undefined. Check embeddings for corruption."
 
 
+def _device_tensor(obj):
+    """`obj` if it is a torch tensor on a GPU (torch is only looked at when it is already imported), else None."""
+    import sys
+
+    torch = sys.modules.get("torch")
+    if torch is not None and isinstance(obj, torch.Tensor) and obj.is_cuda:
+        return obj
+    return None
+
+
 class ReferenceBlasMismatch(UserWarning):
     """An index hashed with ``reference_blas="host"`` is being loaded on a host whose BLAS sums differently at its shape."""
 
@@ -529,6 +539,8 @@ class LSHRS:
         inside a workgroup's LDS), ONE rerank over all candidate lists and ONE copy back (reference per
         query: main.py:524-658, ``_candidate_counts`` :1088-1111).
 
+        ``vectors``: ``(n, dim)`` array-like as in the reference - or a torch tensor that already lives on a GPU (round 6: the
+        queries then never cross the link; 10 000 x 768 are 30 MB = 0.7 of the 2.7 ms a reranked batch takes).
         ``corpus``: optional device-resident ``(m, dim)`` float32 tensor whose row ``i`` is the vector of id
         ``i`` (default: what :meth:`set_corpus` attached); with it the candidates are gathered on the device and
         ``vector_fetch_fn`` is not called.
@@ -537,9 +549,19 @@ class LSHRS:
         ``engine``: "auto" (the device path wherever the hasher is the HIP one; a batch with a candidate list beyond the
         kernels' 16 384 entries is counted on the host), "device" (raise instead), "host" (NumPy counting between the two
         launches: round 5's path)."""
-        arr = np.asarray(vectors, dtype=np.float32)
-        if arr.ndim != 2 or arr.shape[1] != self._dim:
-            raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")
+        resident = _device_tensor(vectors)         # queries that already live on a GPU stay there (no copy over the link, no host array)
+        if resident is not None:
+            if resident.dim() != 2 or int(resident.shape[1]) != self._dim:
+                raise ValueError(f"Vectors must have shape (n, {self._dim}); received {tuple(resident.shape)}")
+            if resident.dtype != __import__("torch").float32:
+                resident = resident.float()
+            arr = None
+            shape0 = int(resident.shape[0])
+        else:
+            arr = np.asarray(vectors, dtype=np.float32)
+            if arr.ndim != 2 or arr.shape[1] != self._dim:
+                raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")
+            shape0 = arr.shape[0]
         if top_p is None and top_k is not None and top_k <= 0:
             raise ValueError("top_k must be greater than zero when provided")
         if top_p is not None and not 0 < top_p <= 1:
@@ -550,7 +572,7 @@ class LSHRS:
             raise ValueError("engine must be 'auto', 'device' or 'host'")
         if corpus is None:
             corpus = self._corpus
-        nq = arr.shape[0]
+        nq = shape0
         if nq == 0:
             empty = (np.empty(0, np.int64), None if top_p is None else np.empty(0, np.float32), np.zeros(1, np.int64))
             return empty if return_arrays else []
@@ -563,12 +585,12 @@ class LSHRS:
             from ._query_device import TooLarge
 
             try:
-                got = self._query_many_device(arr, top_k, top_p, corpus)
+                got = self._query_many_device(arr if resident is None else resident, top_k, top_p, corpus)
             except TooLarge:
                 if engine == "device":
                     raise
         if got is None:
-            got = self._query_many_host(arr, top_k, top_p, corpus)
+            got = self._query_many_host(arr if resident is None else resident.cpu().numpy(), top_k, top_p, corpus)
         ids, scores, bounds = got
         if return_arrays:
             return ids, scores, bounds
@@ -584,15 +606,23 @@ class LSHRS:
         from . import _query_device as qd
 
         torch = _native.require_gpu()
-        nq = arr.shape[0]
-        if arr.strides[0] < arr.shape[1] * 4:            # (`v[None]`: NumPy gives the new axis stride 0 - the kernels take a row stride)
+        nq = int(arr.shape[0])
+        resident = isinstance(arr, torch.Tensor)
+        if not resident and arr.strides[0] < arr.shape[1] * 4:            # (`v[None]`: NumPy gives the new axis stride 0 - the kernels take a row stride)
             arr = arr.reshape(-1).copy().reshape(nq, arr.shape[1])
         if corpus is not None and isinstance(corpus, torch.Tensor) and corpus.is_cuda:
             dev = corpus.device
+        elif resident:
+            dev = arr.device
         else:
             dev = self._hasher._torch_device()
         with torch.cuda.device(dev):
-            x = qd.upload(torch, arr, dev)
+            if resident:                                # queries handed over on a GPU: rows of `dim` floats, on the device that ranks them
+                x = arr.to(dev) if arr.device != dev else arr
+                if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+                    x = x.contiguous()
+            else:
+                x = qd.upload(torch, arr, dev)
             flags = torch.empty(nq, dtype=torch.uint8, device=dev)
             keys_dev = self._hasher.hash_device(x, row_flags=flags)
             if bool((flags & 1).any()):

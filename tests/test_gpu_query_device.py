@@ -511,3 +511,36 @@ def test_lists_of_every_length_through_the_register_and_the_lds_sorts():
         assert np.all(g_sc[:-1] >= g_sc[1:]), qi
         ref = cn[g_ids] @ (queries[qi] / np.linalg.norm(queries[qi]))
         assert np.abs(ref - g_sc).max() <= 1e-5, qi
+
+
+def test_queries_that_live_on_the_gpu_are_taken_as_they_are():
+    """Round 6: `query_many` with a torch tensor on the GPU - contiguous, a strided view, float64 - gives what the same rows
+    give as a NumPy array, in both result forms and with the rerank; a wrong shape is the reference's error."""
+    import torch
+
+    from lshrs_amd import LSHRS, InMemoryStorage
+
+    rng = np.random.default_rng(21)
+    n, dim = 20_000, 64
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    idx = LSHRS(dim=dim, num_perm=64, storage=InMemoryStorage(), packed_ingest=True)
+    idx.index(np.arange(n), data)
+    dev = torch.device("cuda", 0)
+    idx.set_corpus(torch.from_numpy(data).to(dev))
+    q = data[rng.choice(n, 500, replace=False)] + 0.05 * rng.standard_normal((500, dim)).astype(np.float32)
+    want_k = idx.query_many(q, top_k=7)
+    want_p = idx.query_many(q, top_k=None, top_p=0.5, return_arrays=True)
+    qd_ = torch.from_numpy(q).to(dev)
+    assert idx.query_many(qd_, top_k=7) == want_k
+    got_p = idx.query_many(qd_, top_k=None, top_p=0.5, return_arrays=True)
+    assert all(np.array_equal(a, b) for a, b in zip(got_p, want_p))
+    wide = torch.zeros(500, 2 * dim, device=dev)
+    wide[:, :dim] = qd_
+    assert idx.query_many(wide[:, :dim], top_k=7) == want_k                          # rows of a wider matrix
+    every_other = torch.zeros(1000, dim, device=dev)
+    every_other[::2] = qd_
+    assert idx.query_many(every_other[::2], top_k=7) == want_k                       # every other row
+    assert idx.query_many(qd_.double(), top_k=7) == want_k
+    assert idx.query_many(qd_[:0], top_k=7) == []
+    with pytest.raises(ValueError, match="Vectors must have shape"):
+        idx.query_many(qd_[:, :10], top_k=7)
