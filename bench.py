@@ -1053,6 +1053,25 @@ def bench_e2e(torch, np, x, local_dev):
         if packed:      # (the host half of the ingest, in CPU seconds of this process - all its threads - per million rows)
             out["host_cpu_seconds_per_M_rows"] = (time.process_time() - cpu0) / (2 * m / 1e6)
         del idx
+    # vectors that already live on the GPU (round 6: `index(ids, x)` takes a torch tensor as it is - hashed where it is, the buckets
+    # grouped on the device, only the bucket arrays cross the link)
+    try:
+        m = int(x.shape[0])
+        ids_all = np.arange(m, dtype=np.int64)
+        idx = LSHRS(dim=DIM, num_perm=NUM_PERM, storage=InMemoryStorage(record_batches=False), device=local_dev, packed_ingest=True)
+        idx.index(ids_all[:200_000], x[:200_000])
+        best = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            idx.index(ids_all + 10_000_000 * (rep + 1), x)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["index_packed_vectors_on_device"] = {"value": m / best, "rows": m,
+                                                 "note": "LSHRS.index(ids, x) with x a torch tensor on the GPU, into InMemoryStorage "
+                                                         "(bucket arrays): no vector crosses the link"}
+        del idx
+    except Exception as exc:  # noqa: BLE001
+        out["index_packed_vectors_on_device"] = {"error": f"{type(exc).__name__}: {exc}"}
     # the op-tuple path taken apart: the same call into a store that only counts (= the LSHRS side:
     # host -> device copy, signature pass, keys back, the tuples), the signature pass alone, and the store's own share
     m = min(rows, 200_000)

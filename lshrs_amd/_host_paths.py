@@ -48,6 +48,8 @@ class _HostPaths:
         time, their staging buffers are shared); a sink that returns ``False`` ends the stream - the chunks in flight are
         finished and discarded, nothing more is copied or hashed."""
         torch = _native.require_gpu()
+        if isinstance(vectors, torch.Tensor) and vectors.is_cuda:      # vectors that already live on a GPU: nothing crosses the link
+            return self._hash_resident(vectors, return_row_flags, chunk_rows, device_sink)
         arr = np.asarray(vectors, dtype=np.float32)
         if arr.ndim != 2:
             raise ValueError("Batch input must be a 2D array")
@@ -97,6 +99,37 @@ class _HostPaths:
                 flags[lo:hi] = fl.cpu().numpy()
         with self._lock:
             self.last_stats = total
+        return (keys, flags) if return_row_flags else keys
+
+    def _hash_resident(self, x, return_row_flags: bool, chunk_rows: int, device_sink):
+        """:meth:`hash_batch_packed` for a torch tensor on a GPU (round 6): `hash_device` chunk by chunk on the tensor's own
+        device - the keys to the sink as they are (``LSHRS.index`` of device-resident vectors: the buckets are grouped on the
+        device, only the bucket arrays travel), or back to the host as the array the other form returns."""
+        torch = _native.require_gpu()
+        if x.dim() != 2:
+            raise ValueError("Batch input must be a 2D array")
+        if int(x.shape[1]) != self.dim:
+            raise ValueError(f"Expected vectors of dimension {self.dim}, received {int(x.shape[1])}")
+        if x.dtype != torch.float32:
+            x = x.float()
+        if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+            x = x.contiguous()
+        n, dev = int(x.shape[0]), x.device
+        keys = np.empty((n, self.num_bands, self.band_bytes), dtype=np.uint8) if device_sink is None else None
+        flags = np.empty(n, dtype=np.uint8) if return_row_flags and device_sink is None else None
+        step = 4 * max(16_384, int(chunk_rows))        # (no copy to pace: larger chunks than the host-fed stream's - fewer waits)
+        with torch.cuda.device(dev):
+            for lo in range(0, n, step):
+                hi = min(n, lo + step)
+                fl = torch.empty(hi - lo, dtype=torch.uint8, device=dev) if (return_row_flags or device_sink is not None) else None
+                out = self.hash_device(x[lo:hi], row_flags=fl)           # (final and verified; takes the hasher's lock itself)
+                if device_sink is not None:
+                    if device_sink(lo, hi, out, fl) is False:
+                        break
+                else:
+                    keys[lo:hi] = out.cpu().numpy()
+                    if flags is not None:
+                        flags[lo:hi] = fl.cpu().numpy()
         return (keys, flags) if return_row_flags else keys
 
     def device_hashers(self) -> list:

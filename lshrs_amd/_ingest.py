@@ -157,6 +157,7 @@ class CsrIngest:
         limit = int(negs[0]) if negs.size else n          # rows from the first negative id on are never stored
         state = {"stop": limit, "error": self._neg_error() if limit < n else None, "committed_to": 0}
         pending: list = []
+        resident = isinstance(arr, torch.Tensor) and arr.is_cuda      # (vectors that live on a GPU: hashed where they are)
 
         def commit(job, lo, hi):
             """Chunk order: bucket arrays of rows lo:hi -> storage, unless a bad row lies at or before them."""
@@ -182,7 +183,14 @@ class CsrIngest:
             # longer than all of this, so the link never waits - and behind the last chunk only ITS finish is left.
             job = _ChunkJob(ids[lo:hi], keys_dev, flags_dev, ids_dev[lo:hi])
             self.chunks += 1
-            commit(job, lo, hi)
+            if resident:
+                # vectors that live on the GPU: there is no copy for this chunk's grouping to hide under - the chunk BEFORE it is
+                # finished and stored (host work) while the device groups this one
+                pending.append((job, lo, hi))
+                if len(pending) > 1:
+                    commit(*pending.pop(0))
+            else:
+                commit(job, lo, hi)
             # (the hasher calls this WITHOUT its lock - queries go on while a chunk is finished, waits for its turn and is
             #  stored.)  A unit that is known to end inside or in front of this chunk - a zero vector, a storage failure, another
             #  lane's failure - needs nothing behind it: False ends the stream instead of copying and hashing rows nobody stores
@@ -190,7 +198,7 @@ class CsrIngest:
 
         try:
             if limit > 0 and self._failed is None:
-                dev = hasher._torch_device()
+                dev = arr.device if resident else hasher._torch_device()
                 with torch.cuda.device(dev):
                     ids_dev = torch.from_numpy(np.ascontiguousarray(ids[:limit])).to(dev)   # once, in front of the stream
                     hasher.hash_batch_packed(arr[:limit], return_row_flags=True, device_sink=sink, chunk_rows=self.chunk_rows)
@@ -204,9 +212,10 @@ class CsrIngest:
             if stop > done_to:
                 unit.prev_done.wait()
                 if self._failed is None:
-                    with torch.cuda.device(hasher._torch_device()):
+                    tail_dev = arr.device if resident else hasher._torch_device()
+                    with torch.cuda.device(tail_dev):
                         keys = hasher.hash_batch_packed(arr[done_to:stop])
-                        self._sink.batch_add_csr(bucket_csr(ids[done_to:stop], keys, device=hasher._torch_device()))
+                        self._sink.batch_add_csr(bucket_csr(ids[done_to:stop], keys, device=tail_dev))
             if state["error"] is not None:
                 unit.prev_done.wait()
                 self._fail(state["error"])

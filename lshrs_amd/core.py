@@ -289,6 +289,24 @@ class LSHRS:
             return
         if vectors is None:
             vectors = self._require_vector_fetch_fn()(indices)
+        resident = _device_tensor(vectors)
+        if resident is not None:
+            # vectors that already live on a GPU (round 6): hashed where they are, their buckets grouped on the device - only the
+            # bucket arrays cross the link (a store that takes arrays; any other store gets the host form of the same rows)
+            if resident.dim() != 2 or int(resident.shape[1]) != self._dim:
+                raise ValueError(f"Vectors must have shape (n, {self._dim}); received {tuple(resident.shape)}")
+            if int(resident.shape[0]) != len(indices):
+                raise ValueError(
+                    "Number of vectors does not match number of indices "
+                    f"(received {int(resident.shape[0])} vectors for {len(indices)} indices)")
+            if self._streams_buckets(int(resident.shape[0]) * self._config["num_bands"]):
+                self.flush()
+                id_arr = np.asarray(indices)
+                id_arr = id_arr.astype(np.int64) if id_arr.dtype.kind in "iuf" else np.array([int(i) for i in indices], dtype=np.int64)
+                with self._open_ingest(inline=True) as ingest:
+                    ingest.submit(id_arr, resident)
+                return
+            vectors = resident.detach().cpu().numpy()
         arr = np.asarray(vectors, dtype=np.float32)
         if arr.ndim != 2 or arr.shape[1] != self._dim:
             raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")

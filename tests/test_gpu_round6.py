@@ -191,3 +191,68 @@ def test_one_query_per_call_follows_the_store_through_its_changes():
     idx2._hasher.projections = idx._hasher.projections
     idx2.index(np.arange(4000, 4100), data[4000:4100])
     assert idx2.get_top_k(data[4050], topk=1) == [4050] and idx.get_top_k(data[4050], topk=1) != [4050]
+
+
+def test_vectors_that_live_on_the_gpu_are_indexed_where_they_are():
+    """Round 6: `index(ids, x)` with a torch tensor on the GPU - the same buckets as the same rows from host memory (whole and
+    ragged chunks, a strided view, float64), the reference's errors at the reference's rows (a zero vector: the rows in front of
+    it stored; a negative id; wrong shapes), and a store without arrays gets the host form."""
+    import torch
+
+    from lshrs_amd import LSHRS, InMemoryStorage
+
+    rng = np.random.default_rng(31)
+    n, dim = 300_001, 64
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(data).to(dev)
+    ids = rng.permutation(10 * n)[:n].astype(np.int64)
+
+    def built(vectors, idv=ids, **kw):
+        st = InMemoryStorage()
+        idx = LSHRS(dim=dim, num_perm=64, storage=st, packed_ingest=True, **kw)
+        idx.index(idv, vectors)
+        return idx, st
+
+    _, want = built(data)
+    idx, got = built(x)
+    assert got.bucket_contents() == want.bucket_contents()
+    assert sum(v for v, _ in got.packed_batches) == n
+    assert idx.get_top_k(data[777], topk=1) == [int(ids[777])]
+    wide = torch.zeros(n, dim + 8, device=dev)
+    wide[:, :dim] = x
+    assert built(wide[:, :dim])[1].bucket_contents() == want.bucket_contents()          # rows of a wider matrix
+    assert built(x[:5000].double(), ids[:5000])[1].bucket_contents() == built(data[:5000], ids[:5000])[1].bucket_contents()
+    # the reference's errors, at its rows
+    bad = x.clone()
+    bad[200_123] = 0
+    st = InMemoryStorage()
+    idx = LSHRS(dim=dim, num_perm=64, storage=st, packed_ingest=True)
+    with pytest.raises(ValueError, match="Cannot index zero vector"):
+        idx.index(ids, bad)
+    assert sum(v for v, _ in st.packed_batches) == 200_123
+    neg = ids.copy()
+    neg[150_000] = -5
+    st2 = InMemoryStorage()
+    with pytest.raises(ValueError, match="index must be non-negative"):
+        LSHRS(dim=dim, num_perm=64, storage=st2, packed_ingest=True).index(neg, x)
+    assert sum(v for v, _ in st2.packed_batches) == 150_000
+    with pytest.raises(ValueError, match="Vectors must have shape"):
+        idx.index(ids, x[:, :10])
+    with pytest.raises(ValueError, match="Number of vectors does not match"):
+        idx.index(ids[:10], x)
+    # a store that only takes operation tuples: the same rows, from the host
+    class Plain:
+        def __init__(self):
+            self.ops = []
+
+        def batch_add(self, ops):
+            self.ops.extend(ops)
+
+        def get_bucket(self, b, k):
+            return set()
+
+    p1, p2 = Plain(), Plain()
+    LSHRS(dim=dim, num_perm=64, storage=p1).index(ids[:3000], x[:3000])
+    LSHRS(dim=dim, num_perm=64, storage=p2).index(ids[:3000], data[:3000])
+    assert p1.ops == p2.ops and len(p1.ops) == 3000 * 16
