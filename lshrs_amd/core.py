@@ -293,16 +293,9 @@ class LSHRS:
         if resident is not None:
             # vectors that already live on a GPU (round 6): hashed where they are, their buckets grouped on the device - only the
             # bucket arrays cross the link (a store that takes arrays; any other store gets the host form of the same rows)
-            if resident.dim() != 2 or int(resident.shape[1]) != self._dim:
-                raise ValueError(f"Vectors must have shape (n, {self._dim}); received {tuple(resident.shape)}")
-            if int(resident.shape[0]) != len(indices):
-                raise ValueError(
-                    "Number of vectors does not match number of indices "
-                    f"(received {int(resident.shape[0])} vectors for {len(indices)} indices)")
+            id_arr, resident = self._check_batch(indices, resident)
             if self._streams_buckets(int(resident.shape[0]) * self._config["num_bands"]):
                 self.flush()
-                id_arr = np.asarray(indices)
-                id_arr = id_arr.astype(np.int64) if id_arr.dtype.kind in "iuf" else np.array([int(i) for i in indices], dtype=np.int64)
                 with self._open_ingest(inline=True) as ingest:
                     ingest.submit(id_arr, resident)
                 return
@@ -978,17 +971,20 @@ class LSHRS:
                          lambda: ValueError("index must be non-negative"), inline=inline)
 
     def _check_batch(self, indices, vectors):
-        """(ids int64, rows float32 C-contiguous) of one batch, with the reference's shape errors (main.py:504-511)."""
-        arr = np.asarray(vectors, dtype=np.float32)
-        if arr.ndim != 2 or arr.shape[1] != self._dim:
-            raise ValueError(f"Vectors must have shape (n, {self._dim}); received {arr.shape}")
-        if arr.shape[0] != len(indices):
+        """(ids int64, rows float32 C-contiguous) of one batch, with the reference's shape errors (main.py:504-511); rows that
+        live on a GPU (a torch tensor) stay where they are."""
+        resident = _device_tensor(vectors)
+        arr = resident if resident is not None else np.asarray(vectors, dtype=np.float32)
+        shape = tuple(int(v) for v in arr.shape)
+        if len(shape) != 2 or shape[1] != self._dim:
+            raise ValueError(f"Vectors must have shape (n, {self._dim}); received {shape}")
+        if shape[0] != len(indices):
             raise ValueError(
                 "Number of vectors does not match number of indices "
-                f"(received {arr.shape[0]} vectors for {len(indices)} indices)")
+                f"(received {shape[0]} vectors for {len(indices)} indices)")
         id_arr = np.asarray(indices)
         id_arr = id_arr.astype(np.int64) if id_arr.dtype.kind in "iuf" else np.array([int(i) for i in indices], dtype=np.int64)
-        return id_arr, np.ascontiguousarray(arr)
+        return id_arr, (arr if resident is not None else np.ascontiguousarray(arr))
 
     def _packed_sink(self, n_ops: int):
         """The object ``index()`` hands a batch's buckets to as arrays, or None for the reference's operation tuples

@@ -241,6 +241,11 @@ def test_vectors_that_live_on_the_gpu_are_indexed_where_they_are():
         idx.index(ids, x[:, :10])
     with pytest.raises(ValueError, match="Number of vectors does not match"):
         idx.index(ids[:10], x)
+    # a loader that yields device tensors (`create_signatures(format="batches")`): the pipelined ingest takes them too
+    st3 = InMemoryStorage()
+    idx3 = LSHRS(dim=dim, num_perm=64, storage=st3, packed_ingest=True)
+    idx3.create_signatures(format="batches", batches=((ids[lo:lo + 100_000], x[lo:lo + 100_000]) for lo in range(0, n, 100_000)))
+    assert st3.bucket_contents() == want.bucket_contents()
     # a store that only takes operation tuples: the same rows, from the host
     class Plain:
         def __init__(self):
