@@ -880,6 +880,9 @@ class LSHRS:
     def _check_dim(self, vector) -> np.ndarray:
         """float32, flattened, right length (reference: main.py:1075-1080; the near-zero test of
         :1083 is evaluated by the kernel's row flag, see ``_ZERO_MSG`` call sites)."""
+        resident = _device_tensor(vector)
+        if resident is not None:       # ONE vector that lives on a GPU: the single-vector calls read theirs from (pinned) host memory
+            vector = resident.detach().reshape(-1).cpu().numpy()
         arr = np.asarray(vector, dtype=np.float32).reshape(-1)
         if arr.shape[0] != self._dim:
             raise ValueError(f"Vector must have dimension {self._dim}; received {arr.shape[0]}")

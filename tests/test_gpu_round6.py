@@ -219,6 +219,8 @@ def test_vectors_that_live_on_the_gpu_are_indexed_where_they_are():
     assert got.bucket_contents() == want.bucket_contents()
     assert sum(v for v, _ in got.packed_batches) == n
     assert idx.get_top_k(data[777], topk=1) == [int(ids[777])]
+    assert idx.get_top_k(x[777], topk=1) == [int(ids[777])]                         # one vector on the GPU: the single-vector calls too
+    idx.ingest(10 ** 12, x[5])
     wide = torch.zeros(n, dim + 8, device=dev)
     wide[:, :dim] = x
     assert built(wide[:, :dim])[1].bucket_contents() == want.bucket_contents()          # rows of a wider matrix
